@@ -1,0 +1,237 @@
+"""Deterministic synthetic corpus for the five BASELINE.json configs.
+
+Payload classes mirror the reference's fixture recipes (Tests/Constants.swift:10-20):
+  P-text  Zipf-distributed pseudo-words (ratio ~3x under deflate level 6)
+  P-rep   short phrase repeated
+  P-zero  zeros
+  P-rand  uniform random bytes (forces stored / incompressible paths)
+  P-mix   50 % text / 25 % rep / 25 % rand spliced at 4 KiB granularity
+
+The reference's own compressors cannot produce dynamic-Huffman / LZMA2 / XZ inputs,
+so zlib / bz2 / lzma / liblz4 act as ENCODERS here.  Everything is seeded: numpy PCG64, base 0x5C0DE.
+"""
+import bz2
+import ctypes
+import ctypes.util
+import lzma
+import struct
+import zlib
+
+import numpy as np
+
+SEED_BASE = 0x5C0DE
+
+_VOCAB = None
+
+
+def _vocab():
+    global _VOCAB
+    if _VOCAB is None:
+        rng = np.random.Generator(np.random.PCG64(SEED_BASE))
+        v = 3000
+        lens = rng.integers(2, 11, size=v)
+        table = np.zeros((v, 12), dtype=np.uint8)
+        letters = np.frombuffer(b"etaoinshrdlcumwfgypbvkjxqz", dtype=np.uint8)
+        lp = 1.0 / np.arange(1, 27) ** 0.8
+        lp /= lp.sum()
+        for i in range(v):
+            w = rng.choice(letters, size=lens[i], p=lp)
+            table[i, : lens[i]] = w
+            table[i, lens[i]] = 0x20
+        # a few "punctuation" words
+        for i, tok in enumerate([b". ", b", ", b";\n", b"\n", b"(", b") ", b"= ", b"0x", b"1", b"42 "]):
+            table[i * 37 + 5, :] = 0
+            table[i * 37 + 5, : len(tok)] = np.frombuffer(tok, dtype=np.uint8)
+            lens[i * 37 + 5] = len(tok) - 1
+        p = 1.0 / np.arange(1, v + 1) ** 1.05
+        p /= p.sum()
+        _VOCAB = (table, lens + 1, p)
+    return _VOCAB
+
+
+def p_text(n, seed):
+    table, wl, p = _vocab()
+    rng = np.random.Generator(np.random.PCG64(SEED_BASE + seed))
+    nwords = n // 4 + 16
+    idx = rng.choice(len(wl), size=nwords, p=p)
+    lens = wl[idx]
+    starts = np.cumsum(lens) - lens
+    total = int(starts[-1] + lens[-1])
+    ci = np.arange(total) - np.repeat(starts, lens)
+    out = table[np.repeat(idx, lens), ci]
+    while out.size < n:  # pragma: no cover (nwords is generous)
+        out = np.concatenate([out, out])
+    return out[:n].tobytes()
+
+
+def p_rep(n, seed):
+    rng = np.random.Generator(np.random.PCG64(SEED_BASE + seed))
+    phrase = bytes(rng.integers(32, 127, size=int(rng.integers(8, 48)), dtype=np.uint8))
+    return (phrase * (n // len(phrase) + 1))[:n]
+
+
+def p_zero(n, seed=0):
+    return bytes(n)
+
+
+def p_rand(n, seed):
+    rng = np.random.Generator(np.random.PCG64(SEED_BASE + seed))
+    return rng.integers(0, 256, size=n, dtype=np.uint8).tobytes()
+
+
+def p_mix(n, seed):
+    rng = np.random.Generator(np.random.PCG64(SEED_BASE + seed))
+    text, rep, rand = p_text(n, seed), p_rep(n, seed + 1), p_rand(n, seed + 2)
+    parts = []
+    for off in range(0, n, 4096):
+        k = rng.integers(0, 4)
+        src = text if k < 2 else rep if k == 2 else rand
+        parts.append(src[off:off + 4096])
+    return b"".join(parts)[:n]
+
+
+PAYLOADS = {"text": p_text, "rep": p_rep, "zero": p_zero, "rand": p_rand, "mix": p_mix}
+
+
+# ------------------------------------------------------------------------------- Deflate / gzip / zlib
+def deflate_raw(payload, level=6):
+    """Raw RFC-1951 stream.  memLevel 9 keeps 64 KiB of text in ONE dynamic-Huffman block (config 1)."""
+    c = zlib.compressobj(level, zlib.DEFLATED, -15, 9)
+    return c.compress(payload) + c.flush()
+
+
+def gzip_member(payload, level=6, bgzf=False):
+    raw = deflate_raw(payload, level)
+    trailer = struct.pack("<II", zlib.crc32(payload) & 0xFFFFFFFF, len(payload) & 0xFFFFFFFF)
+    if bgzf:
+        # BGZF: FEXTRA with subfield 'B','C', len 2, BSIZE = total member size - 1
+        total = 18 + len(raw) + 8
+        if total > 65536:
+            raise ValueError("BGZF members are limited to 64 KiB (BSIZE is a u16)")
+        hdr = b"\x1f\x8b\x08\x04" + b"\0\0\0\0" + b"\x00\xff" + struct.pack("<H", 6) + b"BC" + struct.pack("<HH", 2, total - 1)
+    else:
+        hdr = b"\x1f\x8b\x08\x00" + b"\0\0\0\0" + b"\x00\xff"
+    return hdr + raw + trailer
+
+
+def zlib_stream(payload, level=6):
+    return zlib.compress(payload, level)
+
+
+# ------------------------------------------------------------------------------- LZ4
+_lz4 = None
+
+
+def _liblz4():
+    global _lz4
+    if _lz4 is None:
+        name = ctypes.util.find_library("lz4")
+        if name is None:
+            raise RuntimeError("liblz4 not found (needed only as an ENCODER for the synthetic corpus)")
+        _lz4 = ctypes.CDLL(name)
+        _lz4.LZ4_compressBound.restype = ctypes.c_int
+        _lz4.LZ4_compressBound.argtypes = [ctypes.c_int]
+        _lz4.LZ4_compress_default.restype = ctypes.c_int
+        _lz4.LZ4_compress_default.argtypes = [ctypes.c_char_p, ctypes.c_char_p, ctypes.c_int, ctypes.c_int]
+        _lz4.LZ4_compress_fast_continue.restype = ctypes.c_int
+    return _lz4
+
+
+def lz4_block(payload):
+    lib = _liblz4()
+    bound = lib.LZ4_compressBound(len(payload))
+    dst = ctypes.create_string_buffer(bound)
+    n = lib.LZ4_compress_default(payload, dst, len(payload), bound)
+    if n <= 0:
+        raise RuntimeError("LZ4_compress_default failed")
+    return dst.raw[:n]
+
+
+def _xxh32(data, seed=0):
+    # small pure-python XXH32 for frame headers only (a few bytes)
+    P1, P2, P3, P4, P5 = 0x9E3779B1, 0x85EBCA77, 0xC2B2AE3D, 0x27D4EB2F, 0x165667B1
+    M = 0xFFFFFFFF
+    rotl = lambda x, r: ((x << r) | (x >> (32 - r))) & M
+    n = len(data)
+    i = 0
+    if n >= 16:
+        v = [(seed + P1 + P2) & M, (seed + P2) & M, seed & M, (seed - P1) & M]
+        while n - i >= 16:
+            for j in range(4):
+                lane = int.from_bytes(data[i + 4 * j:i + 4 * j + 4], "little")
+                v[j] = (rotl((v[j] + lane * P2) & M, 13) * P1) & M
+            i += 16
+        h = (rotl(v[0], 1) + rotl(v[1], 7) + rotl(v[2], 12) + rotl(v[3], 18)) & M
+    else:
+        h = (seed + P5) & M
+    h = (h + n) & M
+    while n - i >= 4:
+        h = (rotl((h + int.from_bytes(data[i:i + 4], "little") * P3) & M, 17) * P4) & M
+        i += 4
+    while i < n:
+        h = (rotl((h + data[i] * P5) & M, 11) * P1) & M
+        i += 1
+    h ^= h >> 15
+    h = (h * P2) & M
+    h ^= h >> 13
+    h = (h * P3) & M
+    h ^= h >> 16
+    return h
+
+
+def lz4_frame(payload, block_size_code=7, independent=True, content_checksum=False, block_checksum=False,
+              content_size=False, xxh32=None):
+    """LZ4 frame v1.x written by hand (FLG/BD per LZ4.swift:196-228), blocks from LZ4_compress_default.
+
+    Only independent blocks are produced here (dependent blocks need the streaming encoder)."""
+    assert independent
+    xxh = xxh32 or _xxh32
+    max_block = {4: 64 << 10, 5: 256 << 10, 6: 1 << 20, 7: 4 << 20}[block_size_code]
+    flg = 0x40 | (0x20 if independent else 0) | (0x10 if block_checksum else 0) | (0x08 if content_size else 0) | (0x04 if content_checksum else 0)
+    desc = bytes([flg, block_size_code << 4])
+    if content_size:
+        desc += struct.pack("<Q", len(payload))
+    out = [struct.pack("<I", 0x184D2204), desc, bytes([(xxh(desc) >> 8) & 0xFF])]
+    for off in range(0, len(payload), max_block):
+        chunk = payload[off:off + max_block]
+        comp = lz4_block(chunk)
+        if len(comp) >= len(chunk):
+            out.append(struct.pack("<I", len(chunk) | 0x80000000))
+            body = chunk
+        else:
+            out.append(struct.pack("<I", len(comp)))
+            body = comp
+        out.append(body)
+        if block_checksum:
+            out.append(struct.pack("<I", xxh(body)))
+    out.append(struct.pack("<I", 0))
+    if content_checksum:
+        out.append(struct.pack("<I", xxh(payload)))
+    return b"".join(out)
+
+
+# ------------------------------------------------------------------------------- BZip2 / LZMA / XZ
+def bzip2_stream(payload, level=9):
+    return bz2.compress(payload, level)
+
+
+def lzma2_raw(payload, preset=6, dict_size=1 << 20):
+    """Raw LZMA2 stream (XZ block body) -- config 5 unit."""
+    return lzma.compress(payload, format=lzma.FORMAT_RAW, filters=[{"id": lzma.FILTER_LZMA2, "preset": preset, "dict_size": dict_size}])
+
+
+def lzma2_dict_byte(dict_size):
+    for bits in range(40):
+        if ((2 | (bits & 1)) << (bits // 2 + 11)) >= dict_size:
+            return bits
+    return 39
+
+
+def lzma_alone(payload, preset=6):
+    return lzma.compress(payload, format=lzma.FORMAT_ALONE, preset=preset)
+
+
+def xz_stream(payload, preset=6, check=lzma.CHECK_CRC64, filters=None):
+    if filters is not None:
+        return lzma.compress(payload, format=lzma.FORMAT_XZ, check=check, filters=filters)
+    return lzma.compress(payload, format=lzma.FORMAT_XZ, check=check, preset=preset)
