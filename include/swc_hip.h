@@ -1,0 +1,142 @@
+/*
+ * swc_hip.h -- C ABI of libswc_hip.so, the MI355X (gfx950) many-stream decode engine that sits behind
+ * SWCompression's `decompress(data:)` entry points.
+ *
+ * The reference (tsolomko/SWCompression 4.9.0) is pure Swift and has no FFI layer; its boundary for
+ * this path is the protocol `DecompressionAlgorithm { static func decompress(data: Data) throws -> Data }`
+ * (Sources/Common/DecompressionAlgorithm.swift:9-14) plus the internal reader-taking overloads that
+ * the archive/container layers call.  Each entry point below names the Swift function whose BODY it
+ * replaces (file:line under /root/reference); INTEGRATION.md shows the Swift-side binding.
+ *
+ * Rules common to all entry points
+ *  - return value / swc_job.status is an swc_status (swc_status.h): 0 = OK, otherwise 1:1 with the Swift
+ *    error enum case the reference would throw, SWC_E_REF_TRAP where the reference would trap.
+ *  - single-shot calls take HOST buffers, run the HIP kernels (there is no CPU fallback: without a
+ *    usable gfx950 device they return SWC_E_DEVICE), and hand back a malloc()ed buffer the caller
+ *    releases with swc_free().  *out is valid also for the error codes that carry data in the reference
+ *    (wrongCRC / wrongAdler32 / wrongCheck / checksumMismatch).
+ *  - *in_consumed reports how far the reference's shared reader would have advanced, so callers can
+ *    keep parsing trailers exactly like GzipArchive.swift:88-94 / ZlibArchive.swift:31-37 /
+ *    ZipContainer.swift:73-86 / XZBlock.swift:78-82 do.
+ *  - thread-safe; never aborts the process.
+ */
+#ifndef SWC_HIP_H
+#define SWC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+#include "swc_status.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched many-buffer launch (the engine proper).  All pointers inside swc_job are DEVICE pointers
+ * (HBM-resident input and output); the job array itself is in device memory too.
+ * ---------------------------------------------------------------------------------------------- */
+typedef enum swc_codec {
+    SWC_CODEC_DEFLATE = 1, /* raw RFC 1951 stream      -- Deflate.decompress(_:)   Deflate.swift:30-249     */
+    SWC_CODEC_LZ4_BLOCK = 2, /* one LZ4 block           -- LZ4.process(block:_:)    LZ4.swift:332-413        */
+    SWC_CODEC_LZMA2 = 3,   /* raw LZMA2 chunk stream   -- LZMA2Decoder.decode()    LZMA2Decoder.swift:34-99 */
+    SWC_CODEC_LZMA = 4,    /* raw LZMA1 stream         -- LZMADecoder.decode()     LZMADecoder.swift:107-284*/
+    SWC_CODEC_BZIP2_BLOCK = 5 /* one bzip2 block body  -- BZip2.decode(_:_:)       BZip2.swift:97-270       */
+} swc_codec;
+
+typedef struct swc_job {
+    const uint8_t* in;    /* device pointer to the unit's compressed bytes                           */
+    uint64_t in_len;
+    uint8_t* out;         /* device pointer, caller allocated                                        */
+    uint64_t out_cap;
+    uint64_t out_len;     /* OUT: bytes produced; for SWC_E_CAPACITY on Deflate/LZ4: bytes required   */
+    uint64_t in_consumed; /* OUT                                                                     */
+    int32_t status;       /* OUT: swc_status                                                         */
+    int32_t aux;          /* IN : LZMA2 dictionary-size byte | LZMA props (lc | lp<<8 | pb<<16) | BZIP2: start bit (0..7) */
+    const uint8_t* dict;  /* IN : LZ4 prefix dictionary (device) or NULL                             */
+    uint64_t dict_len;    /* IN : LZ4 dictionary length | LZMA: uncompressed size (UINT64_MAX = unknown) | LZMA dict size in the high half, see swc_hip.h notes */
+} swc_job;
+
+typedef struct swc_batch_opts {
+    int32_t device;        /* HIP device ordinal, -1 = current                                       */
+    void* stream;          /* hipStream_t, NULL = default stream                                     */
+    int32_t synchronize;   /* non-zero: wait for completion before returning                         */
+    int32_t reserved;
+} swc_batch_opts;
+
+/* Launches one lane per job.  `jobs` is a device pointer to n swc_job records. */
+int swc_batch_decompress(int codec, swc_job* jobs, size_t n, const swc_batch_opts* opts);
+
+/* Scratch bytes the codec needs per job in HBM (LZMA probability model spill, BZip2 tt[]); 0 for
+ * Deflate/LZ4.  Allocated internally by the single-shot calls; batch callers pass it via
+ * swc_batch_decompress_ws. */
+size_t swc_batch_workspace_bytes(int codec, size_t n_jobs, uint64_t max_out_cap);
+int swc_batch_decompress_ws(int codec, swc_job* jobs, size_t n, void* workspace, size_t workspace_bytes,
+                            const swc_batch_opts* opts);
+
+/* ------------------------------------------------------------------------------------------------
+ * Single-shot calls (host buffers in, malloc()ed host buffer out).
+ * ---------------------------------------------------------------------------------------------- */
+/* Deflate.decompress(data:) Deflate.swift:24-28 and decompress(_ bitReader:) :30-249
+ * (callers GzipArchive.swift:88, ZlibArchive.swift:31, ZipContainer.swift:74) */
+int swc_deflate_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t* in_consumed);
+
+/* BZip2.decompress(data:) BZip2.swift:22-26 and decompress(_ bitReader:) :50-95 (caller ZipContainer.swift:82);
+ * one stream; *out valid on SWC_E_BZIP2_WRONG_CRC */
+int swc_bzip2_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t* in_consumed);
+/* BZip2.multiDecompress(data:) BZip2.swift:40-48; sizes[] (swc_free) splits *out per stream */
+int swc_bzip2_multi_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_streams);
+
+/* LZMA.decompress(data:properties:uncompressedSize:) LZMA.swift:56-73 (caller ZipContainer.swift:89);
+ * uncompressed_size < 0 = unknown (end marker required) */
+int swc_lzma_decompress(const uint8_t* in, size_t in_len, int lc, int lp, int pb, int64_t dict_size,
+                        int64_t uncompressed_size, uint8_t** out, size_t* out_len, size_t* in_consumed);
+/* LZMA.decompress(data:) LZMA.swift:25-34 (13-byte .lzma header) */
+int swc_lzma_alone_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len);
+/* LZMA2.decompress(_:_:) LZMA2.swift:32-36 (callers XZBlock.swift:51, 7zFolder.swift:159) */
+int swc_lzma2_decompress(const uint8_t* in, size_t in_len, uint8_t dict_byte, uint8_t** out, size_t* out_len, size_t* in_consumed);
+/* LZMA2.decompress(data:) LZMA2.swift:25-30 (first byte = dictionary size) */
+int swc_lzma2_decompress_data(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len);
+
+/* LZ4.decompress(data:dictionary:dictionaryID:) LZ4.swift:73-91; dict NULL = no dictionary,
+ * dict_id < 0 = no id passed; *out valid on SWC_E_DATA_CHECKSUM_MISMATCH */
+int swc_lz4_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len, int64_t dict_id,
+                       uint8_t** out, size_t* out_len, size_t* in_consumed);
+/* LZ4.multiDecompress(data:dictionary:dictionaryID:) LZ4.swift:116-146 */
+int swc_lz4_multi_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len, int64_t dict_id,
+                             uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_frames);
+
+/* Host-side framing around the batch API (reference L3 "archives") */
+/* GzipArchive.unarchive(archive:) GzipArchive.swift:38-48 */
+int swc_gzip_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len);
+/* GzipArchive.multiUnarchive(archive:) GzipArchive.swift:62-77; sizes[] splits *out per member */
+int swc_gzip_multi_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_members);
+/* ZlibArchive.unarchive(archive:) ZlibArchive.swift:25-42 */
+int swc_zlib_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len);
+/* XZArchive.unarchive(archive:) XZArchive.swift:27-51 / splitUnarchive :69-88 */
+int swc_xz_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len);
+int swc_xz_split_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_streams);
+
+/* Many independent archives in one call: host-side block discovery + ONE batched launch.
+ * archives[i]/lens[i] are host buffers; outs[i]/out_lens[i]/statuses[i] are filled per archive
+ * (outs[i] released with swc_free).  kind: 1 = gzip member (incl. BGZF), 2 = zlib stream,
+ * 3 = raw deflate, 4 = LZ4 frame, 5 = bzip2 stream, 6 = xz stream, 7 = raw LZMA2 (first byte = dict byte). */
+int swc_unarchive_many(int kind, const uint8_t* const* archives, const size_t* lens, size_t n,
+                       uint8_t** outs, size_t* out_lens, int32_t* statuses);
+
+/* checksums used by the framing layer (CheckSums.swift:12-57, XxHash32.swift:24-83, Sha256.swift:28-142) */
+uint32_t swc_crc32(const uint8_t* p, size_t n, uint32_t prev);
+uint32_t swc_adler32(const uint8_t* p, size_t n);
+uint64_t swc_crc64(const uint8_t* p, size_t n);
+uint32_t swc_bzip2_crc32(const uint8_t* p, size_t n);
+uint32_t swc_xxh32(const uint8_t* p, size_t n, uint32_t seed);
+void swc_sha256(const uint8_t* p, size_t n, uint8_t digest[32]);
+
+void swc_free(void* p);
+/* 1 if a gfx950 device is usable, 0 otherwise (then every decode entry point returns SWC_E_DEVICE) */
+int swc_device_available(void);
+const char* swc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWC_HIP_H */

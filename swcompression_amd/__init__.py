@@ -1,0 +1,253 @@
+"""swcompression_amd -- Python binding of the MI355X-native decode engine (libswc_hip.so).
+
+The names mirror the decode side of tsolomko/SWCompression's public API so that parity tests read like
+the reference's own tests:
+
+    Deflate.decompress(data)            Sources/Deflate/Deflate.swift:24
+    GzipArchive.unarchive(archive)      Sources/GZip/GzipArchive.swift:38      (.multi_unarchive :62)
+    ZlibArchive.unarchive(archive)      Sources/Zlib/ZlibArchive.swift:25
+    BZip2.decompress(data)              Sources/BZip2/BZip2.swift:22           (.multi_decompress :40)
+    LZMA.decompress(data[, properties]) Sources/LZMA/LZMA.swift:25,56
+    LZMA2.decompress(data)              Sources/LZMA2/LZMA2.swift:25
+    XZArchive.unarchive(archive)        Sources/XZ/XZArchive.swift:27          (.split_unarchive :69)
+    LZ4.decompress(data[, dictionary])  Sources/LZ4/LZ4.swift:49,73            (.multi_decompress :116)
+
+Everything decodes on the GPU through the C ABI in include/swc_hip.h.  There is no CPU fallback: on a
+machine without a gfx950 device every call raises DeviceError.  Swift error enums map to exception
+classes whose `.case` is the Swift case name; errors that carry decoded bytes in the reference
+(`wrongCRC`, `wrongAdler32`, `wrongCheck`, `checksumMismatch`) expose them as `.data`.
+"""
+import ctypes as C
+
+from . import _lib
+from ._lib import SwcJob, SwcBatchOpts
+
+__all__ = ["Deflate", "GzipArchive", "ZlibArchive", "BZip2", "LZMA", "LZMA2", "LZMAProperties", "XZArchive", "LZ4",
+           "SWCError", "DeflateError", "GzipError", "ZlibError", "BZip2Error", "LZMAError", "LZMA2Error", "XZError",
+           "DataError", "ReferenceTrap", "DeviceError", "device_available", "STATUS"]
+
+# status code -> (exception family, Swift case name); numeric values from include/swc_status.h
+STATUS = {
+    101: ("DeflateError", "wrongUncompressedBlockLengths"), 102: ("DeflateError", "wrongBlockType"),
+    103: ("DeflateError", "wrongSymbol"), 104: ("DeflateError", "symbolNotFound"),
+    201: ("BZip2Error", "wrongMagic"), 202: ("BZip2Error", "wrongVersion"), 203: ("BZip2Error", "wrongBlockSize"),
+    204: ("BZip2Error", "wrongBlockType"), 205: ("BZip2Error", "randomizedBlock"), 206: ("BZip2Error", "wrongHuffmanGroups"),
+    207: ("BZip2Error", "wrongSelector"), 208: ("BZip2Error", "wrongHuffmanCodeLength"), 209: ("BZip2Error", "symbolNotFound"),
+    210: ("BZip2Error", "wrongCRC"),
+    301: ("LZMAError", "wrongProperties"), 302: ("LZMAError", "rangeDecoderInitError"),
+    303: ("LZMAError", "exceededUncompressedSize"), 304: ("LZMAError", "windowIsEmpty"),
+    305: ("LZMAError", "rangeDecoderFinishError"), 306: ("LZMAError", "repeatWillExceed"), 307: ("LZMAError", "notEnoughToRepeat"),
+    401: ("LZMA2Error", "wrongDictionarySize"), 402: ("LZMA2Error", "wrongControlByte"), 403: ("LZMA2Error", "wrongReset"),
+    404: ("LZMA2Error", "wrongSizes"),
+    501: ("DataError", "truncated"), 502: ("DataError", "corrupted"), 503: ("DataError", "checksumMismatch"),
+    504: ("DataError", "unsupportedFeature"),
+    601: ("GzipError", "wrongMagic"), 602: ("GzipError", "wrongCompressionMethod"), 603: ("GzipError", "wrongFlags"),
+    604: ("GzipError", "wrongHeaderCRC"), 605: ("GzipError", "wrongCRC"), 606: ("GzipError", "wrongISize"),
+    701: ("ZlibError", "wrongCompressionMethod"), 702: ("ZlibError", "wrongCompressionInfo"), 703: ("ZlibError", "wrongFcheck"),
+    704: ("ZlibError", "wrongCompressionLevel"), 705: ("ZlibError", "wrongAdler32"),
+    801: ("XZError", "wrongMagic"), 802: ("XZError", "wrongField"), 803: ("XZError", "wrongInfoCRC"), 804: ("XZError", "wrongFilterID"),
+    805: ("XZError", "checkTypeSHA256"), 806: ("XZError", "wrongDataSize"), 807: ("XZError", "wrongCheck"),
+    808: ("XZError", "wrongPadding"), 809: ("XZError", "multiByteIntegerError"),
+    900: ("ReferenceTrap", "trap"), 901: ("SWCError", "capacity"), 902: ("DeviceError", "device"),
+    903: ("SWCError", "invalidArgument"),
+}
+
+
+class SWCError(Exception):
+    def __init__(self, status, data=None):
+        family, case = STATUS.get(status, ("SWCError", "unknown"))
+        super().__init__("%s.%s (status %d)" % (family, case, status))
+        self.status = status
+        self.case = case
+        self.data = data  # bytes / list[bytes] carried by the Swift error, else None
+
+
+class DeflateError(SWCError): pass
+class GzipError(SWCError): pass
+class ZlibError(SWCError): pass
+class BZip2Error(SWCError): pass
+class LZMAError(SWCError): pass
+class LZMA2Error(SWCError): pass
+class XZError(SWCError): pass
+class DataError(SWCError): pass
+class ReferenceTrap(SWCError):
+    """Input on which the Swift reference would hit a runtime trap (abort)."""
+class DeviceError(SWCError):
+    """No usable gfx950 device / HIP failure.  There is no CPU fallback."""
+
+
+_FAMILIES = {c.__name__: c for c in (SWCError, DeflateError, GzipError, ZlibError, BZip2Error, LZMAError, LZMA2Error,
+                                     XZError, DataError, ReferenceTrap, DeviceError)}
+_CARRIES_DATA = {210, 503, 605, 705, 807}
+
+
+def _raise(status, data=None):
+    family = STATUS.get(status, ("SWCError", ""))[0]
+    raise _FAMILIES[family](status, data if status in _CARRIES_DATA else None)
+
+
+def device_available():
+    return bool(_lib.load().swc_device_available())
+
+
+def _take(ptr, n):
+    lib = _lib.load()
+    data = C.string_at(ptr, n) if n else b""
+    lib.swc_free(ptr)
+    return data
+
+
+def _take_sizes(ptr, n):
+    lib = _lib.load()
+    v = [ptr[i] for i in range(n)]
+    lib.swc_free(ptr)
+    return v
+
+
+def _split(blob, sizes):
+    out, o = [], 0
+    for s in sizes:
+        out.append(blob[o:o + s])
+        o += s
+    return out
+
+
+def _call_simple(name, data, *mid, consumed=False):
+    lib = _lib.load()
+    data = bytes(data)
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    cons = C.c_size_t()
+    args = [data, len(data)] + list(mid) + [C.byref(out), C.byref(n)]
+    if consumed:
+        args.append(C.byref(cons))
+    st = getattr(lib, name)(*args)
+    blob = _take(out, n.value)
+    if st:
+        _raise(st, blob)
+    return (blob, cons.value) if consumed else blob
+
+
+def _call_multi(name, data, *mid):
+    lib = _lib.load()
+    data = bytes(data)
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    sizes = C.POINTER(C.c_size_t)()
+    cnt = C.c_size_t()
+    st = getattr(lib, name)(data, len(data), *mid, C.byref(out), C.byref(n), C.byref(sizes), C.byref(cnt))
+    parts = _split(_take(out, n.value), _take_sizes(sizes, cnt.value))
+    if st:
+        _raise(st, parts)
+    return parts
+
+
+class Deflate:
+    @staticmethod
+    def decompress(data):
+        return _call_simple("swc_deflate_decompress", data, consumed=True)[0]
+
+    @staticmethod
+    def decompress_consumed(data):
+        """(output, bytes consumed) -- the reader-taking overload Deflate.swift:30."""
+        return _call_simple("swc_deflate_decompress", data, consumed=True)
+
+
+class GzipArchive:
+    @staticmethod
+    def unarchive(archive):
+        return _call_simple("swc_gzip_unarchive", archive)
+
+    @staticmethod
+    def multi_unarchive(archive):
+        return _call_multi("swc_gzip_multi_unarchive", archive)
+
+
+class ZlibArchive:
+    @staticmethod
+    def unarchive(archive):
+        return _call_simple("swc_zlib_unarchive", archive)
+
+
+class BZip2:
+    @staticmethod
+    def decompress(data):
+        return _call_simple("swc_bzip2_decompress", data, consumed=True)[0]
+
+    @staticmethod
+    def multi_decompress(data):
+        return _call_multi("swc_bzip2_multi_decompress", data)
+
+
+class LZMAProperties:
+    """LZMAProperties.swift:9-48 (no validation, as in the reference)."""
+    def __init__(self, lc=3, lp=0, pb=2, dictionary_size=1 << 24):
+        self.lc, self.lp, self.pb, self.dictionary_size = lc, lp, pb, dictionary_size
+
+
+class LZMA:
+    @staticmethod
+    def decompress(data, properties=None, uncompressed_size=None):
+        if properties is None:
+            return _call_simple("swc_lzma_alone_decompress", data)
+        us = -1 if uncompressed_size is None else int(uncompressed_size)
+        return _call_simple("swc_lzma_decompress", data, properties.lc, properties.lp, properties.pb,
+                            properties.dictionary_size, us, consumed=True)[0]
+
+
+class LZMA2:
+    @staticmethod
+    def decompress(data):
+        return _call_simple("swc_lzma2_decompress_data", data)
+
+    @staticmethod
+    def decompress_raw(data, dict_byte):
+        """(output, consumed) -- LZMA2.decompress(_:_:) LZMA2.swift:32."""
+        return _call_simple("swc_lzma2_decompress", data, dict_byte, consumed=True)
+
+
+class XZArchive:
+    @staticmethod
+    def unarchive(archive):
+        return _call_simple("swc_xz_unarchive", archive)
+
+    @staticmethod
+    def split_unarchive(archive):
+        return _call_multi("swc_xz_split_unarchive", archive)
+
+
+class LZ4:
+    @staticmethod
+    def decompress(data, dictionary=None, dictionary_id=None):
+        d = None if dictionary is None else bytes(dictionary)
+        if d is not None and len(d) == 0:
+            d = C.create_string_buffer(1).raw  # non-NULL pointer + length 0 = empty dictionary
+            dl = 0
+        else:
+            dl = 0 if d is None else len(d)
+        did = -1 if dictionary_id is None else int(dictionary_id)
+        return _call_simple("swc_lz4_decompress", data, d, dl, did, consumed=True)[0]
+
+    @staticmethod
+    def multi_decompress(data, dictionary=None, dictionary_id=None):
+        d = None if dictionary is None else bytes(dictionary)
+        did = -1 if dictionary_id is None else int(dictionary_id)
+        return _call_multi("swc_lz4_multi_decompress", data, d, 0 if d is None else len(d), did)
+
+
+def unarchive_many(kind, archives):
+    """Host-side discovery + ONE batched launch for many independent archives.
+    kind: 'gzip' | 'zlib' | 'deflate' | 'lz4' | 'bzip2' | 'xz' | 'lzma2'.  Returns list of (status, bytes)."""
+    kinds = {"gzip": 1, "zlib": 2, "deflate": 3, "lz4": 4, "bzip2": 5, "xz": 6, "lzma2": 7}
+    lib = _lib.load()
+    n = len(archives)
+    bufs = [bytes(a) for a in archives]
+    arr = (C.c_char_p * n)(*bufs)
+    lens = (C.c_size_t * n)(*[len(b) for b in bufs])
+    outs = (C.POINTER(C.c_uint8) * n)()
+    out_lens = (C.c_size_t * n)()
+    sts = (C.c_int32 * n)()
+    rc = lib.swc_unarchive_many(kinds[kind], arr, lens, n, outs, out_lens, sts)
+    if rc:
+        _raise(rc)
+    return [(sts[i], _take(outs[i], out_lens[i])) for i in range(n)]

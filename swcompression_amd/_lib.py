@@ -1,0 +1,68 @@
+"""Loader for libswc_hip.so.  Fails loudly: there is no fallback implementation in this package."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libswc_hip.so")
+
+
+class SwcJob(C.Structure):
+    """Mirror of `swc_job` (include/swc_hip.h)."""
+    _fields_ = [("in_", C.c_void_p), ("in_len", C.c_uint64), ("out", C.c_void_p), ("out_cap", C.c_uint64),
+                ("out_len", C.c_uint64), ("in_consumed", C.c_uint64), ("status", C.c_int32), ("aux", C.c_int32),
+                ("dict", C.c_void_p), ("dict_len", C.c_uint64)]
+
+
+class SwcBatchOpts(C.Structure):
+    _fields_ = [("device", C.c_int32), ("stream", C.c_void_p), ("synchronize", C.c_int32), ("reserved", C.c_int32)]
+
+
+_lib = None
+
+
+def load():
+    """Return the ctypes handle of libswc_hip.so, building it first if the sources are newer."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        from . import build as _build
+        _build.build()
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libswc_hip.so is missing and could not be built: the MI355X engine is required")
+    lib = C.CDLL(LIB_PATH)
+    u8pp = C.POINTER(C.POINTER(C.c_uint8))
+    szp = C.POINTER(C.c_size_t)
+    szpp = C.POINTER(szp)
+    I = C.c_int
+
+    def sig(name, res, *args):
+        f = getattr(lib, name)
+        f.restype = res
+        f.argtypes = list(args)
+
+    sig("swc_free", None, C.c_void_p)
+    sig("swc_device_available", I)
+    sig("swc_version", C.c_char_p)
+    sig("swc_batch_decompress", I, I, C.c_void_p, C.c_size_t, C.POINTER(SwcBatchOpts))
+    sig("swc_batch_workspace_bytes", C.c_size_t, I, C.c_size_t, C.c_uint64)
+    sig("swc_batch_decompress_ws", I, I, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(SwcBatchOpts))
+    for n in ("swc_deflate_decompress", "swc_bzip2_decompress"):
+        sig(n, I, C.c_char_p, C.c_size_t, u8pp, szp, szp)
+    for n in ("swc_gzip_unarchive", "swc_zlib_unarchive", "swc_xz_unarchive", "swc_lzma_alone_decompress", "swc_lzma2_decompress_data"):
+        sig(n, I, C.c_char_p, C.c_size_t, u8pp, szp)
+    for n in ("swc_gzip_multi_unarchive", "swc_xz_split_unarchive", "swc_bzip2_multi_decompress"):
+        sig(n, I, C.c_char_p, C.c_size_t, u8pp, szp, szpp, szp)
+    sig("swc_lzma_decompress", I, C.c_char_p, C.c_size_t, I, I, I, C.c_int64, C.c_int64, u8pp, szp, szp)
+    sig("swc_lzma2_decompress", I, C.c_char_p, C.c_size_t, C.c_uint8, u8pp, szp, szp)
+    sig("swc_lz4_decompress", I, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int64, u8pp, szp, szp)
+    sig("swc_lz4_multi_decompress", I, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int64, u8pp, szp, szpp, szp)
+    sig("swc_unarchive_many", I, I, C.POINTER(C.c_char_p), szp, C.c_size_t, u8pp, szp, C.POINTER(C.c_int32))
+    sig("swc_crc32", C.c_uint32, C.c_char_p, C.c_size_t, C.c_uint32)
+    sig("swc_adler32", C.c_uint32, C.c_char_p, C.c_size_t)
+    sig("swc_crc64", C.c_uint64, C.c_char_p, C.c_size_t)
+    sig("swc_bzip2_crc32", C.c_uint32, C.c_char_p, C.c_size_t)
+    sig("swc_xxh32", C.c_uint32, C.c_char_p, C.c_size_t, C.c_uint32)
+    sig("swc_sha256", None, C.c_char_p, C.c_size_t, C.c_char_p)
+    _lib = lib
+    return lib

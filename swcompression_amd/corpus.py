@@ -235,3 +235,40 @@ def xz_stream(payload, preset=6, check=lzma.CHECK_CRC64, filters=None):
     if filters is not None:
         return lzma.compress(payload, format=lzma.FORMAT_XZ, check=check, filters=filters)
     return lzma.compress(payload, format=lzma.FORMAT_XZ, check=check, preset=preset)
+
+
+# ------------------------------------------------------------------------------- bench / test corpora
+def _cache_path(tag):
+    import os
+    import tempfile
+    d = os.path.join(tempfile.gettempdir(), "swc_corpus_cache")
+    os.makedirs(d, exist_ok=True)
+    return os.path.join(d, tag + ".npz")
+
+
+def build_units(kind, n_distinct, unit_size, payload="text", seed=2, cache=True):
+    """`n_distinct` independent compressed units of `unit_size` uncompressed bytes each.
+
+    kind: 'deflate' (raw RFC 1951, one dynamic block at 64 KiB), 'gzip', 'lz4_block', 'bzip2', 'lzma2'.
+    Returns (units: list[bytes], plains: list[bytes]).  Cached under $TMPDIR because zlib/bz2/lzma
+    as encoders dominate the set-up time of tests and bench."""
+    import os
+    tag = "%s_%s_%d_%d_%d" % (kind, payload, n_distinct, unit_size, seed)
+    path = _cache_path(tag)
+    if cache and os.path.exists(path):
+        z = np.load(path)
+        ub, uo, pb, po = z["ub"], z["uo"], z["pb"], z["po"]
+        units = [ub[uo[i]:uo[i + 1]].tobytes() for i in range(n_distinct)]
+        plains = [pb[po[i]:po[i + 1]].tobytes() for i in range(n_distinct)]
+        return units, plains
+    gen = PAYLOADS[payload]
+    enc = {"deflate": deflate_raw, "gzip": gzip_member, "lz4_block": lz4_block, "bzip2": bzip2_stream,
+           "lzma2": lzma2_raw}[kind]
+    plains = [gen(unit_size, seed + i) for i in range(n_distinct)]
+    units = [enc(p) for p in plains]
+    if cache:
+        uo = np.cumsum([0] + [len(u) for u in units])
+        po = np.cumsum([0] + [len(p) for p in plains])
+        np.savez(path, ub=np.frombuffer(b"".join(units), dtype=np.uint8), uo=uo,
+                 pb=np.frombuffer(b"".join(plains), dtype=np.uint8), po=po)
+    return units, plains

@@ -1,0 +1,156 @@
+// api.cpp -- C ABI of libswc_hip.so: device management, the batched launch, and the host-side batch
+// runner used by every single-shot entry point.  Compiled with hipcc.  There is deliberately no CPU
+// decode path in this library: without a usable gfx950 device every decode entry point returns
+// SWC_E_DEVICE.
+#include <algorithm>
+#include <mutex>
+#include <string.h>
+#include "host_util.h"
+#include "launch.h"
+
+static_assert(sizeof(swc_job) == sizeof(swc::Job), "swc_job and swc::Job must have the same layout");
+static_assert(offsetof(swc_job, status) == offsetof(swc::Job, status), "layout");
+static_assert(offsetof(swc_job, dict_len) == offsetof(swc::Job, dict_len), "layout");
+
+namespace swc {
+
+static std::once_flag g_dev_once;
+static bool g_dev_ok = false;
+
+bool device_ready() {
+    std::call_once(g_dev_once, [] {
+        int n = 0;
+        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return; }
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return; }
+        // The code object in this library is gfx950 only.
+        g_dev_ok = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+    });
+    return g_dev_ok;
+}
+
+static hipError_t launch_codec(int codec, Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {
+    switch (codec) {
+        case SWC_CODEC_DEFLATE: return launch_inflate(jobs, n, stream);
+        default: return hipErrorInvalidValue;
+    }
+}
+
+static size_t default_cap(int codec, const HostUnit& u) {
+    if (u.cap_hint) return u.cap_hint;
+    switch (codec) {
+        case SWC_CODEC_DEFLATE: return std::max<size_t>(65536, u.in_len * 4 + 1024);
+        case SWC_CODEC_LZ4_BLOCK: return std::max<size_t>(65536, u.in_len * 4 + 1024);
+        default: return std::max<size_t>(1 << 20, u.in_len * 8);
+    }
+}
+
+int run_units(int codec, std::vector<HostUnit>& units) {
+    if (!device_ready()) return SWC_E_DEVICE;
+    const size_t n = units.size();
+    if (n == 0) return SWC_OK;
+    std::vector<size_t> pending(n);
+    for (size_t i = 0; i < n; i++) pending[i] = i;
+    std::vector<size_t> cap(n);
+    for (size_t i = 0; i < n; i++) cap[i] = default_cap(codec, units[i]);
+
+    for (int round = 0; round < 12 && !pending.empty(); round++) {
+        const size_t m = pending.size();
+        std::vector<size_t> in_off(m), out_off(m), dict_off(m);
+        size_t in_total = 0, out_total = 0;
+        for (size_t k = 0; k < m; k++) {
+            const HostUnit& u = units[pending[k]];
+            in_off[k] = in_total;
+            in_total += (u.in_len + 15) & ~(size_t)15;
+            dict_off[k] = in_total;
+            if (u.dict) in_total += (u.dict_len + 15) & ~(size_t)15;
+            out_off[k] = out_total;
+            out_total += (cap[pending[k]] + 15) & ~(size_t)15;
+        }
+        size_t ws_bytes = swc_batch_workspace_bytes(codec, m, *std::max_element(cap.begin(), cap.end()));
+        DevBuf d_in(in_total + 16), d_out(out_total + 16), d_jobs(m * sizeof(Job)), d_ws(ws_bytes);
+        if (!d_in.ok() || !d_out.ok() || !d_jobs.ok() || !d_ws.ok()) return SWC_E_DEVICE;
+
+        std::vector<uint8_t> stage(in_total + 16);
+        std::vector<Job> jobs(m);
+        for (size_t k = 0; k < m; k++) {
+            const HostUnit& u = units[pending[k]];
+            if (u.in_len) memcpy(stage.data() + in_off[k], u.in, u.in_len);
+            if (u.dict && u.dict_len) memcpy(stage.data() + dict_off[k], u.dict, u.dict_len);
+            Job& j = jobs[k];
+            j.in = d_in.u8() + in_off[k];
+            j.in_len = u.in_len;
+            j.out = d_out.u8() + out_off[k];
+            j.out_cap = cap[pending[k]];
+            j.out_len = 0;
+            j.in_consumed = 0;
+            j.status = SWC_E_DEVICE;
+            j.aux = u.aux;
+            j.dict = u.dict ? d_in.u8() + dict_off[k] : nullptr;
+            j.dict_len = u.dict ? u.dict_len : u.extra;
+        }
+        if (hipMemcpy(d_in.ptr(), stage.data(), in_total, hipMemcpyHostToDevice) != hipSuccess) return SWC_E_DEVICE;
+        if (hipMemcpy(d_jobs.ptr(), jobs.data(), m * sizeof(Job), hipMemcpyHostToDevice) != hipSuccess) return SWC_E_DEVICE;
+        if (launch_codec(codec, static_cast<Job*>(d_jobs.ptr()), m, d_ws.ptr(), ws_bytes, nullptr) != hipSuccess) return SWC_E_DEVICE;
+        if (hipDeviceSynchronize() != hipSuccess) return SWC_E_DEVICE;
+        if (hipMemcpy(jobs.data(), d_jobs.ptr(), m * sizeof(Job), hipMemcpyDeviceToHost) != hipSuccess) return SWC_E_DEVICE;
+        std::vector<uint8_t> out_stage(out_total + 16);
+        if (hipMemcpy(out_stage.data(), d_out.ptr(), out_total, hipMemcpyDeviceToHost) != hipSuccess) return SWC_E_DEVICE;
+
+        std::vector<size_t> next;
+        for (size_t k = 0; k < m; k++) {
+            HostUnit& u = units[pending[k]];
+            const Job& j = jobs[k];
+            if (j.status == SWC_E_CAPACITY && !u.cap_exact && cap[pending[k]] < ((size_t)1 << 34)) {
+                size_t want = j.out_len > cap[pending[k]] ? (size_t)j.out_len : cap[pending[k]] * 4;
+                cap[pending[k]] = want;
+                next.push_back(pending[k]);
+                continue;
+            }
+            u.status = j.status;
+            u.in_consumed = (size_t)j.in_consumed;
+            size_t produced = (size_t)std::min<uint64_t>(j.out_len, j.out_cap);
+            u.out.assign(out_stage.data() + out_off[k], out_stage.data() + out_off[k] + produced);
+        }
+        pending.swap(next);
+    }
+    for (size_t i : pending) units[i].status = SWC_E_CAPACITY;
+    return SWC_OK;
+}
+
+}  // namespace swc
+
+using namespace swc;
+
+extern "C" {
+
+int swc_device_available(void) { return device_ready() ? 1 : 0; }
+const char* swc_version(void) { return "swc-hip 0.1 (gfx950)"; }
+void swc_free(void* p) { free(p); }
+
+size_t swc_batch_workspace_bytes(int codec, size_t n_jobs, uint64_t max_out_cap) {
+    (void)codec; (void)n_jobs; (void)max_out_cap;
+    return 0;
+}
+
+int swc_batch_decompress_ws(int codec, swc_job* jobs, size_t n, void* workspace, size_t workspace_bytes,
+                            const swc_batch_opts* opts) {
+    if (!device_ready()) return SWC_E_DEVICE;
+    if (n && !jobs) return SWC_E_INVALID_ARGUMENT;
+    if (opts && opts->device >= 0 && hipSetDevice(opts->device) != hipSuccess) return SWC_E_DEVICE;
+    hipStream_t stream = opts ? static_cast<hipStream_t>(opts->stream) : nullptr;
+    hipError_t e = launch_codec(codec, reinterpret_cast<Job*>(jobs), n, workspace, workspace_bytes, stream);
+    if (e == hipErrorInvalidValue) return SWC_E_INVALID_ARGUMENT;
+    if (e != hipSuccess) return SWC_E_DEVICE;
+    if (opts && opts->synchronize && hipStreamSynchronize(stream) != hipSuccess) return SWC_E_DEVICE;
+    return SWC_OK;
+}
+
+int swc_batch_decompress(int codec, swc_job* jobs, size_t n, const swc_batch_opts* opts) {
+    if (swc_batch_workspace_bytes(codec, n, 0) != 0) return SWC_E_INVALID_ARGUMENT;  // needs _ws
+    return swc_batch_decompress_ws(codec, jobs, n, nullptr, 0, opts);
+}
+
+}  // extern "C"

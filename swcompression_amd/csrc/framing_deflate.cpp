@@ -1,0 +1,221 @@
+// framing_deflate.cpp -- host side of the Deflate family: single-shot Deflate, and the GZip / Zlib
+// archive framing that stays on the host and feeds the batched HIP launch.
+//   Deflate.decompress(data:)            reference Sources/Deflate/Deflate.swift:24-28
+//   GzipArchive.unarchive/multiUnarchive reference Sources/GZip/GzipArchive.swift:38-100
+//   GzipHeader.init(_:)                  reference Sources/GZip/GzipHeader.swift:68-199
+//   ZlibArchive.unarchive                reference Sources/Zlib/ZlibArchive.swift:25-42
+//   ZlibHeader.init(_:)                  reference Sources/Zlib/ZlibHeader.swift:47-92
+#include <vector>
+#include "host_util.h"
+#include "framing.h"
+
+namespace swc {
+
+int run_one(int codec, HostUnit& u) {
+    std::vector<HostUnit> v(1);
+    v[0] = std::move(u);
+    int st = run_units(codec, v);
+    u = std::move(v[0]);
+    return st;
+}
+
+void give(const std::vector<uint8_t>& src, uint8_t** out, size_t* out_len) {
+    uint8_t* p = host_result(src.size());
+    if (!src.empty()) memcpy(p, src.data(), src.size());
+    *out = p;
+    *out_len = src.size();
+}
+void give_empty(uint8_t** out, size_t* out_len) {
+    *out = host_result(0);
+    *out_len = 0;
+}
+size_t* give_sizes(const std::vector<size_t>& v) {
+    size_t* s = static_cast<size_t*>(malloc((v.size() ? v.size() : 1) * sizeof(size_t)));
+    for (size_t i = 0; i < v.size(); i++) s[i] = v[i];
+    return s;
+}
+
+// ---- GZip header (host) ------------------------------------------------------------------------
+// Walks one member header starting at `pos`; on success `pos` is the first byte of the Deflate
+// stream.  Error taxonomy follows GzipHeader.swift line by line; `trap` marks inputs on which the
+// reference would read past the end of its reader (a Swift precondition failure).
+int gzip_parse_header(const uint8_t* d, size_t n, size_t& pos, GzipHeaderInfo* info) {
+    struct Cursor {
+        const uint8_t* d; size_t n; size_t p; bool trap;
+        size_t left() const { return n - p; }
+        uint8_t u8() { if (p >= n) { trap = true; return 0; } return d[p++]; }
+        uint32_t le16() { uint32_t a = u8(); uint32_t b = u8(); return a | (b << 8); }
+    } c{d, n, pos, false};
+    const size_t start = pos;
+    if (c.left() < 10) return SWC_E_GZIP_WRONG_MAGIC;                  // GzipHeader.swift:70
+    if (c.le16() != 0x8b1f) return SWC_E_GZIP_WRONG_MAGIC;             // :75
+    if (c.u8() != 8) return SWC_E_GZIP_WRONG_COMPRESSION_METHOD;       // :81
+    const uint32_t flags = c.u8();
+    if (flags & 0xE0) return SWC_E_GZIP_WRONG_FLAGS;                   // :87
+    c.p += 6;                                                          // MTIME, XFL, OS
+    if (info) { info->bgzf_bsize = 0; }
+    if (flags & 0x04) {                                                // FEXTRA :110-156
+        if (c.left() < 2) return SWC_E_GZIP_WRONG_MAGIC;
+        int64_t xlen = c.le16();
+        if (!((int64_t)c.left() >= xlen && xlen >= 4)) return SWC_E_GZIP_WRONG_MAGIC;  // :123
+        while (xlen > 0) {
+            uint8_t si1 = c.u8();
+            uint8_t si2 = c.u8();
+            if (c.trap) return SWC_E_REF_TRAP;
+            if (si2 == 0) return SWC_E_GZIP_WRONG_FLAGS;               // :131
+            int64_t len = c.le16();
+            if (c.trap) return SWC_E_REF_TRAP;
+            xlen -= 4;
+            if (xlen < len) return SWC_E_GZIP_WRONG_MAGIC;             // :145
+            if ((int64_t)c.left() < len) return SWC_E_REF_TRAP;
+            if (info && si1 == 'B' && si2 == 'C' && len == 2)           // BGZF: BSIZE = member size - 1
+                info->bgzf_bsize = (uint32_t)c.d[c.p] | ((uint32_t)c.d[c.p + 1] << 8);
+            c.p += (size_t)len;
+            xlen -= len;
+        }
+    }
+    for (uint32_t bit : {0x08u, 0x10u}) {                              // FNAME :158-172, FCOMMENT :174-188
+        if (flags & bit) {
+            for (;;) {
+                if (c.p >= c.n) return SWC_E_GZIP_WRONG_MAGIC;
+                if (c.d[c.p++] == 0) break;
+            }
+        }
+    }
+    if (flags & 0x02) {                                                // FHCRC :190-198
+        if (c.left() < 2) return SWC_E_GZIP_WRONG_MAGIC;
+        const size_t hend = c.p;
+        uint32_t crc16 = c.le16();
+        if ((swc_crc32(d + start, hend - start, 0) & 0xFFFF) != crc16) return SWC_E_GZIP_WRONG_HEADER_CRC;
+    }
+    if (c.trap) return SWC_E_REF_TRAP;
+    pos = c.p;
+    return SWC_OK;
+}
+
+// processMember (GzipArchive.swift:79-100) split in two around the device call.
+int gzip_member_prepare(const uint8_t* d, size_t n, size_t pos, HostUnit& u) {
+    if (n - pos < 20) return SWC_E_GZIP_WRONG_MAGIC;                   // :83 (members are byte aligned by construction)
+    size_t p = pos;
+    int st = gzip_parse_header(d, n, p, nullptr);
+    if (st) return st;
+    u = HostUnit();
+    u.in = d + p;
+    u.in_len = n - p;
+    // ISIZE of a single-member archive is its last four bytes: a good capacity guess, never trusted.
+    uint32_t isize = (uint32_t)d[n - 4] | (uint32_t)d[n - 3] << 8 | (uint32_t)d[n - 2] << 16 | (uint32_t)d[n - 1] << 24;
+    if ((uint64_t)isize <= (uint64_t)u.in_len * 1100 + 4096) u.cap_hint = std::max<size_t>(isize, 64);
+    return SWC_OK;
+}
+// `u` holds the decoded Deflate stream; `data_pos` = offset of the Deflate stream in `d`.
+int gzip_member_finish(const uint8_t* d, size_t n, size_t data_pos, const HostUnit& u, size_t& next_pos, bool& crc_error) {
+    crc_error = false;
+    if (u.status) return u.status;                                     // DeflateError propagates
+    size_t p = data_pos + u.in_consumed;                               // align() already applied by the engine
+    if (n - p < 8) return SWC_E_GZIP_WRONG_MAGIC;                      // :91
+    uint32_t crc = (uint32_t)d[p] | (uint32_t)d[p + 1] << 8 | (uint32_t)d[p + 2] << 16 | (uint32_t)d[p + 3] << 24;
+    uint32_t isize = (uint32_t)d[p + 4] | (uint32_t)d[p + 5] << 8 | (uint32_t)d[p + 6] << 16 | (uint32_t)d[p + 7] << 24;
+    if ((uint32_t)(u.out.size() & 0xFFFFFFFFu) != isize) return SWC_E_GZIP_WRONG_ISIZE;  // :95
+    crc_error = swc_crc32(u.out.data(), u.out.size(), 0) != crc;       // :99
+    next_pos = p + 8;
+    return SWC_OK;
+}
+
+// ZlibHeader.init (ZlibHeader.swift:47-92): returns offset of the Deflate stream in `pos`.
+int zlib_parse_header(const uint8_t* d, size_t n, size_t& pos) {
+    if (n < 2) return SWC_E_ZLIB_WRONG_COMPRESSION_METHOD;             // :49
+    const uint32_t cmf = d[0], flg = d[1];
+    if ((cmf & 0x0F) != 8) return SWC_E_ZLIB_WRONG_COMPRESSION_METHOD; // :57
+    if ((cmf >> 4) > 7) return SWC_E_ZLIB_WRONG_COMPRESSION_INFO;      // :63
+    if (((cmf << 8) + flg) % 31 != 0) return SWC_E_ZLIB_WRONG_FCHECK;  // :83
+    size_t p = 2;
+    if (flg & 0x20) {                                                  // FDICT: skip DICTID :87-90
+        if (n - p < 4) return SWC_E_ZLIB_WRONG_FCHECK;
+        p += 4;
+    }
+    pos = p;
+    return SWC_OK;
+}
+
+}  // namespace swc
+
+using namespace swc;
+
+extern "C" {
+
+int swc_deflate_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t* in_consumed) {
+    if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
+    HostUnit u;
+    u.in = in; u.in_len = in_len;
+    int st = run_one(SWC_CODEC_DEFLATE, u);
+    if (st) { give_empty(out, out_len); return st; }
+    if (in_consumed) *in_consumed = u.in_consumed;
+    if (u.status) { give_empty(out, out_len); return u.status; }       // DeflateError cases carry no data
+    give(u.out, out, out_len);
+    return SWC_OK;
+}
+
+int swc_gzip_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) {
+    if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
+    HostUnit u;
+    int st = gzip_member_prepare(in, in_len, 0, u);
+    if (st) { give_empty(out, out_len); return st; }
+    const size_t data_pos = (size_t)(u.in - in);
+    st = run_one(SWC_CODEC_DEFLATE, u);
+    if (st) { give_empty(out, out_len); return st; }
+    size_t next; bool crc_error;
+    st = gzip_member_finish(in, in_len, data_pos, u, next, crc_error);
+    if (st) { give_empty(out, out_len); return st; }
+    give(u.out, out, out_len);                                         // wrongCRC carries the member (:44)
+    return crc_error ? SWC_E_GZIP_WRONG_CRC : SWC_OK;
+}
+
+int swc_gzip_multi_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_members) {
+    if (!out || !out_len || !sizes || !n_members || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
+    // Plain multi-member gzip has no compressed-size field: member k+1 can only be located after
+    // member k has been inflated, so members are discovered sequentially here.
+    // (BGZF and many-archive batches go through swc_unarchive_many, which launches them together.)
+    std::vector<uint8_t> all;
+    std::vector<size_t> sz;
+    size_t pos = 0;
+    int st = SWC_OK;
+    while (pos < in_len) {                                             // :66
+        HostUnit u;
+        st = gzip_member_prepare(in, in_len, pos, u);
+        if (st) break;
+        u.cap_hint = 0;                                                // ISIZE guess only valid for the last member
+        const size_t data_pos = (size_t)(u.in - in);
+        st = run_one(SWC_CODEC_DEFLATE, u);
+        if (st) break;
+        bool crc_error;
+        st = gzip_member_finish(in, in_len, data_pos, u, pos, crc_error);
+        if (st) break;
+        all.insert(all.end(), u.out.begin(), u.out.end());
+        sz.push_back(u.out.size());
+        if (crc_error) { st = SWC_E_GZIP_WRONG_CRC; break; }           // :71-72 carries the members so far
+    }
+    if (st != SWC_OK && st != SWC_E_GZIP_WRONG_CRC) { all.clear(); sz.clear(); }
+    give(all, out, out_len);
+    *sizes = give_sizes(sz);
+    *n_members = sz.size();
+    return st;
+}
+
+int swc_zlib_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) {
+    if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
+    size_t p = 0;
+    int st = zlib_parse_header(in, in_len, p);
+    if (st) { give_empty(out, out_len); return st; }
+    HostUnit u;
+    u.in = in + p; u.in_len = in_len - p;
+    st = run_one(SWC_CODEC_DEFLATE, u);
+    if (st) { give_empty(out, out_len); return st; }
+    if (u.status) { give_empty(out, out_len); return u.status; }
+    size_t q = p + u.in_consumed;
+    give(u.out, out, out_len);                                         // wrongAdler32 carries the data (:34,39)
+    if (in_len - q < 4) return SWC_E_ZLIB_WRONG_ADLER32;
+    uint32_t stored = (uint32_t)in[q] << 24 | (uint32_t)in[q + 1] << 16 | (uint32_t)in[q + 2] << 8 | in[q + 3];
+    return swc_adler32(u.out.data(), u.out.size()) == stored ? SWC_OK : SWC_E_ZLIB_WRONG_ADLER32;
+}
+
+}  // extern "C"

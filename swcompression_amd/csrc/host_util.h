@@ -1,0 +1,69 @@
+// host_util.h -- small host-side helpers shared by the C-ABI translation units.
+#ifndef SWC_HOST_UTIL_H
+#define SWC_HOST_UTIL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+#include "swc_common.h"
+#include "../../include/swc_hip.h"
+
+namespace swc {
+
+// RAII device allocation.  ok() is false when hipMalloc failed (=> SWC_E_DEVICE, never a CPU fallback).
+class DevBuf {
+public:
+    DevBuf() : p_(nullptr), n_(0) {}
+    explicit DevBuf(size_t n) : p_(nullptr), n_(0) { alloc(n); }
+    ~DevBuf() { release(); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    bool alloc(size_t n) {
+        release();
+        if (n == 0) n = 1;
+        if (hipMalloc(&p_, n) != hipSuccess) { p_ = nullptr; (void)hipGetLastError(); return false; }
+        n_ = n;
+        return true;
+    }
+    void release() {
+        if (p_) (void)hipFree(p_);
+        p_ = nullptr; n_ = 0;
+    }
+    bool ok() const { return p_ != nullptr; }
+    uint8_t* u8() const { return static_cast<uint8_t*>(p_); }
+    void* ptr() const { return p_; }
+    size_t size() const { return n_; }
+private:
+    void* p_;
+    size_t n_;
+};
+
+// malloc()ed host result handed to the caller (released with swc_free); never NULL.
+inline uint8_t* host_result(size_t n) { return static_cast<uint8_t*>(malloc(n ? n : 1)); }
+
+bool device_ready();  // api.cpp: true when a gfx950 device is present and selected
+
+// One unit of work for the host-side batch runner (host pointers; the runner stages to HBM).
+struct HostUnit {
+    const uint8_t* in = nullptr;
+    size_t in_len = 0;
+    size_t cap_hint = 0;         // 0 = use the codec's default policy
+    bool cap_exact = false;      // cap_hint is authoritative (declared size): do not grow
+    int32_t aux = 0;
+    const uint8_t* dict = nullptr;
+    size_t dict_len = 0;
+    uint64_t extra = 0;          // codec specific (goes to Job::dict_len when dict == nullptr)
+    // results
+    std::vector<uint8_t> out;
+    size_t in_consumed = 0;
+    int32_t status = SWC_OK;
+};
+
+// Stage units to HBM, run ONE batched launch of `codec` (re-launching only the units that reported
+// SWC_E_CAPACITY with a larger buffer), fetch the results.  Returns SWC_OK or SWC_E_DEVICE.
+int run_units(int codec, std::vector<HostUnit>& units);
+
+}  // namespace swc
+#endif

@@ -1,0 +1,9 @@
+// launch.h -- host-side launch wrappers implemented in kernels.hip.
+#ifndef SWC_LAUNCH_H
+#define SWC_LAUNCH_H
+#include <hip/hip_runtime.h>
+#include "swc_common.h"
+namespace swc {
+hipError_t launch_inflate(Job* jobs, size_t n, hipStream_t stream);
+}
+#endif

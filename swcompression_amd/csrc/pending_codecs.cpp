@@ -1,0 +1,19 @@
+// pending_codecs.cpp -- entry points whose kernels are not built yet in this revision report
+// SWC_E_DEVICE ("no device path") instead of silently decoding on the CPU.  Each one moves to its own
+// framing_<codec>.cpp when its kernel lands; this file must be empty by the end of the round.
+#include "framing.h"
+using namespace swc;
+extern "C" {
+#define PENDING_OUT(out, out_len) do { give_empty(out, out_len); return SWC_E_DEVICE; } while (0)
+int swc_bzip2_decompress(const uint8_t*, size_t, uint8_t** out, size_t* out_len, size_t*) { PENDING_OUT(out, out_len); }
+int swc_bzip2_multi_decompress(const uint8_t*, size_t, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n) { *sizes = give_sizes({}); *n = 0; PENDING_OUT(out, out_len); }
+int swc_lzma_decompress(const uint8_t*, size_t, int, int, int, int64_t, int64_t, uint8_t** out, size_t* out_len, size_t*) { PENDING_OUT(out, out_len); }
+int swc_lzma_alone_decompress(const uint8_t*, size_t, uint8_t** out, size_t* out_len) { PENDING_OUT(out, out_len); }
+int swc_lzma2_decompress(const uint8_t*, size_t, uint8_t, uint8_t** out, size_t* out_len, size_t*) { PENDING_OUT(out, out_len); }
+int swc_lzma2_decompress_data(const uint8_t*, size_t, uint8_t** out, size_t* out_len) { PENDING_OUT(out, out_len); }
+int swc_lz4_decompress(const uint8_t*, size_t, const uint8_t*, size_t, int64_t, uint8_t** out, size_t* out_len, size_t*) { PENDING_OUT(out, out_len); }
+int swc_lz4_multi_decompress(const uint8_t*, size_t, const uint8_t*, size_t, int64_t, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n) { *sizes = give_sizes({}); *n = 0; PENDING_OUT(out, out_len); }
+int swc_xz_unarchive(const uint8_t*, size_t, uint8_t** out, size_t* out_len) { PENDING_OUT(out, out_len); }
+int swc_xz_split_unarchive(const uint8_t*, size_t, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n) { *sizes = give_sizes({}); *n = 0; PENDING_OUT(out, out_len); }
+int swc_unarchive_many(int, const uint8_t* const*, const size_t*, size_t, uint8_t**, size_t*, int32_t*) { return SWC_E_DEVICE; }
+}

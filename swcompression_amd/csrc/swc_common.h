@@ -1,0 +1,77 @@
+// swc_common.h -- shared declarations for the MI355X decode engine (device code + host launcher).
+//
+// The per-lane decoders in this directory are written as plain sequential C++ ("one lane = one
+// compressed stream") so that the same source compiles for gfx950 (hipcc) and, with
+// -DSWC_HOST_EMULATION, for the host (g++) where tests/ run every lane of a wave sequentially and
+// compare against the oracle without a GPU.  The host build is test infrastructure only; the
+// shipped library contains the device build and nothing else.
+#ifndef SWC_COMMON_H
+#define SWC_COMMON_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include "../../include/swc_status.h"
+
+#if defined(__HIPCC__) && !defined(SWC_HOST_EMULATION)
+#include <hip/hip_runtime.h>
+#define SWC_HD __host__ __device__ __forceinline__
+#define SWC_D __device__ __forceinline__
+#else
+#define SWC_HD inline
+#define SWC_D inline
+#endif
+
+namespace swc {
+
+constexpr int kWave = 64;  // CDNA wavefront width; LDS tables are interleaved at this stride
+
+// One decode job.  Layout == `swc_job` of include/swc_hip.h (checked by static_assert in api.cpp).
+struct Job {
+    const uint8_t* in;
+    uint64_t in_len;
+    uint8_t* out;
+    uint64_t out_cap;
+    uint64_t out_len;      // result: bytes produced (or required, for SWC_E_CAPACITY on size-countable codecs)
+    uint64_t in_consumed;  // result: bytes of `in` consumed (after the caller-side align())
+    int32_t status;        // result: swc_status
+    int32_t aux;           // codec specific input (LZMA2: dictionary-size byte; LZMA: packed lc/lp/pb; LZ4: unused)
+    const uint8_t* dict;   // optional prefix dictionary (LZ4) / reserved
+    uint64_t dict_len;     // LZ4: dictionary length; LZMA: declared uncompressed size (or ~0 = unknown)
+};
+
+SWC_HD uint32_t brev32(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __brev(x);
+#else
+    x = ((x >> 1) & 0x55555555u) | ((x & 0x55555555u) << 1);
+    x = ((x >> 2) & 0x33333333u) | ((x & 0x33333333u) << 2);
+    x = ((x >> 4) & 0x0F0F0F0Fu) | ((x & 0x0F0F0F0Fu) << 4);
+    x = ((x >> 8) & 0x00FF00FFu) | ((x & 0x00FF00FFu) << 8);
+    return (x >> 16) | (x << 16);
+#endif
+}
+
+SWC_HD uint32_t load_u32(const uint8_t* p) {  // gfx950 global loads are unaligned-capable
+    uint32_t v;
+    __builtin_memcpy(&v, p, 4);
+    return v;
+}
+SWC_HD uint64_t load_u64(const uint8_t* p) {
+    uint64_t v;
+    __builtin_memcpy(&v, p, 8);
+    return v;
+}
+SWC_HD void store_u32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
+SWC_HD void store_u64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+
+// Per-lane view of an LDS region interleaved at wave stride: word j of this lane lives at
+// base[j * 64 + lane], so any per-lane index pattern is bank-conflict free for 32-bit accesses
+// (bank = lane % 32, the two 32-lane halves are serviced separately).
+struct LaneLds {
+    uint32_t* p;  // base + lane
+    SWC_HD uint32_t get(int j) const { return p[j * kWave]; }
+    SWC_HD void set(int j, uint32_t v) const { p[j * kWave] = v; }
+};
+
+}  // namespace swc
+#endif

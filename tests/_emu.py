@@ -1,0 +1,65 @@
+"""ctypes binding of tests/host_emu/libswc_emu.so -- the device decoders compiled for the host.
+TEST INFRASTRUCTURE ONLY (see tests/host_emu/emu.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DIR = os.path.join(_HERE, "host_emu")
+_LIB = os.path.join(_DIR, "libswc_emu.so")
+_CSRC = os.path.join(os.path.dirname(_HERE), "swcompression_amd", "csrc")
+
+
+class Job(C.Structure):
+    _fields_ = [("in_", C.c_void_p), ("in_len", C.c_uint64), ("out", C.c_void_p), ("out_cap", C.c_uint64),
+                ("out_len", C.c_uint64), ("in_consumed", C.c_uint64), ("status", C.c_int32), ("aux", C.c_int32),
+                ("dict", C.c_void_p), ("dict_len", C.c_uint64)]
+
+
+def build(force=False):
+    srcs = [os.path.join(_DIR, "emu.cpp")] + [os.path.join(_CSRC, f) for f in os.listdir(_CSRC) if f.endswith(".h")]
+    if not force and os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs):
+        return
+    subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-DSWC_HOST_EMULATION", "-fPIC", "-shared",
+                    "-Wno-unknown-pragmas", "-o", _LIB, os.path.join(_DIR, "emu.cpp")], check=True)
+
+
+build()
+lib = C.CDLL(_LIB)
+
+
+def run_batch(fn_name, inputs, caps, aux=None, dicts=None, extra=None):
+    """inputs: list[bytes]; caps: list[int].  Returns list of (status, out_bytes, in_consumed, out_len)."""
+    n = len(inputs)
+    jobs = (Job * n)()
+    keep = []
+    for i, (data, cap) in enumerate(zip(inputs, caps)):
+        ib = C.create_string_buffer(bytes(data), max(len(data), 1))
+        ob = C.create_string_buffer(max(cap, 1) + 16)  # 16 guard bytes
+        C.memset(C.addressof(ob) + cap, 0xA5, 16)
+        keep.append((ib, ob))
+        jobs[i].in_ = C.addressof(ib)
+        jobs[i].in_len = len(data)
+        jobs[i].out = C.addressof(ob)
+        jobs[i].out_cap = cap
+        jobs[i].aux = 0 if aux is None else aux[i]
+        if dicts is not None and dicts[i] is not None:
+            db = C.create_string_buffer(bytes(dicts[i]), max(len(dicts[i]), 1))
+            keep.append(db)
+            jobs[i].dict = C.addressof(db)
+            jobs[i].dict_len = len(dicts[i])
+        if extra is not None:
+            jobs[i].dict_len = extra[i]
+    getattr(lib, fn_name)(jobs, C.c_size_t(n))
+    res = []
+    for i in range(n):
+        ib, ob = keep[i] if dicts is None else [k for k in keep if isinstance(k, tuple)][i]
+        cap = caps[i]
+        assert ob.raw[cap:cap + 16] == b"\xA5" * 16, "guard bytes overwritten (job %d)" % i
+        nout = min(jobs[i].out_len, cap)
+        res.append((jobs[i].status, ob.raw[:nout], jobs[i].in_consumed, jobs[i].out_len))
+    return res
+
+
+def inflate(inputs, caps):
+    return run_batch("emu_inflate", inputs, caps)

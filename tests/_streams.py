@@ -1,0 +1,189 @@
+"""Deterministic inputs shared by the CPU-tier and GPU-tier parity tests (TEST INFRASTRUCTURE)."""
+import random
+import zlib
+
+from swcompression_amd import corpus
+
+
+class LsbBitWriter:
+    def __init__(self):
+        self.bits = []
+
+    def write(self, number, n):
+        self.bits.extend((number >> i) & 1 for i in range(n))
+
+    def code(self, code, n):
+        """Huffman codes go MSB-first into the LSB-first stream (RFC 1951 3.1.1)."""
+        self.bits.extend((code >> (n - 1 - i)) & 1 for i in range(n))
+
+    def data(self):
+        b = self.bits + [0] * (-len(self.bits) % 8)
+        return bytes(sum(x << i for i, x in enumerate(b[k:k + 8])) for k in range(0, len(b), 8))
+
+
+CL_ORDER = [16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15]
+
+
+def _ref_codes(lengths):
+    """Code.huffmanCodes (Code.swift:15-39): counter values per symbol, NOT validated."""
+    order = sorted((l, s) for s, l in enumerate(lengths) if l > 0)
+    codes, sym, loop = {}, -1, -1
+    for l, s in order:
+        sym += 1
+        if l != loop:
+            sym <<= (l - loop)
+            loop = l
+        codes[s] = (sym & ((1 << l) - 1), l)
+    return codes
+
+
+def dynamic_block(lit_lengths, dist_lengths, symbols, final=True):
+    """Hand-assemble one dynamic-Huffman block with ARBITRARY (possibly incomplete or over-subscribed)
+    code-length vectors.  `symbols` = list of ('lit', v) | ('len', sym, extra_bits, extra_val) |
+    ('dist', sym, extra_bits, extra_val) | ('eob',).  Code lengths are sent raw (code-length alphabet:
+    every symbol 0..15 gets a 4-bit code... i.e. lengths 4 for 16 symbols = complete)."""
+    w = LsbBitWriter()
+    w.write(1 if final else 0, 1)
+    w.write(2, 2)
+    hlit, hdist = len(lit_lengths), len(dist_lengths)
+    w.write(hlit - 257, 5)
+    w.write(hdist - 1, 5)
+    w.write(19 - 4, 4)
+    cl = [0] * 19
+    for s in range(16):
+        cl[s] = 4
+    for s in CL_ORDER:
+        w.write(cl[s], 3)
+    clc = _ref_codes(cl)
+    for l in list(lit_lengths) + list(dist_lengths):
+        c, n = clc[l]
+        w.code(c, n)
+    lc, dc = _ref_codes(lit_lengths), _ref_codes(dist_lengths)
+    for s in symbols:
+        if s[0] == "lit":
+            c, n = lc[s[1]]
+            w.code(c, n)
+        elif s[0] == "eob":
+            c, n = lc[256]
+            w.code(c, n)
+        elif s[0] == "len":
+            c, n = lc[s[1]]
+            w.code(c, n)
+            w.write(s[3], s[2])
+        elif s[0] == "dist":
+            c, n = dc[s[1]]
+            w.code(c, n)
+            w.write(s[3], s[2])
+        elif s[0] == "rawbits":
+            w.write(s[1], s[2])
+    return w.data()
+
+
+def crafted_deflate():
+    """Streams that exercise App. A of SURVEY.md: incomplete / over-subscribed sets, shadowing,
+    bad distances, reserved symbols."""
+    out = []
+    lit = [0] * 286
+    # incomplete literal set: 'A' len 1, EOB len 2 (code 11 unused)
+    lit[65], lit[256] = 1, 2
+    out.append(("incomplete-ok", dynamic_block(lit, [0], [("lit", 65)] * 5 + [("eob",)])))
+    out.append(("incomplete-hit-unassigned", dynamic_block(lit, [0], [("lit", 65), ("rawbits", 3, 2), ("eob",)])))
+    # over-subscribed: three 1-bit codes + EOB 2 bits: later codes overwrite earlier leaves, short shadows long
+    lit2 = [0] * 286
+    lit2[65], lit2[66], lit2[67], lit2[256] = 1, 1, 1, 2
+    out.append(("oversub-1", dynamic_block(lit2, [0], [("lit", 65), ("lit", 66), ("lit", 67), ("eob",)])))
+    lit3 = [0] * 286
+    for s in range(48, 58):
+        lit3[s] = 3  # ten 3-bit codes: over-subscribed
+    lit3[256] = 4
+    lit3[257] = 4
+    out.append(("oversub-2", dynamic_block(lit3, [1, 1, 1], [("lit", 48 + i) for i in range(10)] + [("len", 257, 0, 0), ("dist", 0, 0, 0), ("eob",)])))
+    out.append(("oversub-3", dynamic_block(lit3, [2, 2, 2, 2, 2, 2], [("lit", 50), ("lit", 57), ("len", 257, 0, 0), ("dist", 5, 1, 1), ("eob",)])))
+    # over-subscribed AND decodable to the end: A, B and EOB all claim 1 bit; EOB (last writer) takes '0'
+    lit5 = [0] * 286
+    lit5[65], lit5[66], lit5[256] = 1, 1, 1
+    out.append(("oversub-ok", dynamic_block(lit5, [0], [("lit", 66), ("lit", 66), ("eob",)])))
+    out.append(("oversub-ok-shadowed-A", dynamic_block(lit5, [0], [("lit", 66), ("lit", 65), ("lit", 66), ("eob",)])))
+    # valid set, distance too far back (trap class), reserved distance symbols 30/31, lit 286 cannot be sent (HLIT<=286)
+    lit4 = [0] * 286
+    lit4[97], lit4[256], lit4[257], lit4[285] = 2, 2, 2, 2
+    out.append(("dist-too-far", dynamic_block(lit4, [1, 1], [("lit", 97), ("len", 257, 0, 0), ("dist", 1, 0, 0), ("eob",)])))
+    out.append(("dist-ok-258", dynamic_block(lit4, [1, 1], [("lit", 97), ("len", 285, 0, 0), ("dist", 0, 0, 0), ("eob",)])))
+    d32 = [5] * 32
+    out.append(("dist-sym-30", dynamic_block(lit4, d32, [("lit", 97)] * 4 + [("len", 257, 0, 0), ("dist", 30, 0, 0), ("eob",)])))
+    out.append(("dist-sym-29", dynamic_block(lit4, d32, [("lit", 97)] * 4 + [("len", 257, 0, 0), ("dist", 29, 13, 0), ("eob",)])))
+    # multi-block: non-final crafted block followed by nothing (header past the end -> trap class)
+    out.append(("second-header-missing", dynamic_block(lit, [0], [("lit", 65), ("eob",)], final=False)))
+    # stored-block edge cases
+    out.append(("stored-weak-check", bytes([0x01, 0x03, 0x00, 0x00, 0x00, 1, 2, 3])))  # LEN=3 NLEN=0: (len & nlen)==0 accepted
+    out.append(("stored-bad-nlen", bytes([0x01, 0x03, 0x00, 0x03, 0x00, 1, 2, 3])))
+    out.append(("stored-truncated", bytes([0x01, 0x05, 0x00, 0xfa, 0xff, 1, 2])))
+    out.append(("blocktype-3", bytes([0x07, 0x00])))
+    out.append(("too-short", bytes([0x03])))
+    # static block using reserved literal 286 (code 11000110, 8 bits) -> wrongSymbol
+    w = LsbBitWriter()
+    w.write(1, 1); w.write(1, 2); w.code(0b11000110, 8)
+    out.append(("static-286", w.data()))
+    w = LsbBitWriter()
+    w.write(1, 1); w.write(1, 2); w.code(0x30 + 65, 8); w.code(0, 7)
+    out.append(("static-A", w.data()))
+    return out
+
+
+def valid_deflate_corpus(seed=0, sizes=(0, 1, 2, 7, 8, 9, 100, 5000, 65536, 70000)):
+    """(compressed, plain) pairs: every payload class x zlib level, fixed Huffman, stored, multi-block."""
+    pairs = []
+    for kind in ("text", "rep", "zero", "rand", "mix"):
+        for n in sizes:
+            x = corpus.PAYLOADS[kind](n, seed + 11)
+            for lvl in (1, 6, 9):
+                pairs.append((corpus.deflate_raw(x, lvl), x))
+    for n in (10, 1000, 70000):
+        x = corpus.p_text(n, seed + 5)
+        c = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_FIXED)
+        pairs.append((c.compress(x) + c.flush(), x))
+        c = zlib.compressobj(0, zlib.DEFLATED, -15)
+        pairs.append((c.compress(x) + c.flush(), x))
+        c = zlib.compressobj(6, zlib.DEFLATED, -15)
+        z = b""
+        for off in range(0, n, 3000):
+            z += c.compress(x[off:off + 3000]) + c.flush(zlib.Z_FULL_FLUSH)
+        pairs.append((z + c.flush(), x))
+    return pairs
+
+
+def fuzz_deflate(seed=1234, per_base=24, n_random=1200):
+    """Truncations, bit flips and random garbage (the reference's testTruncation idea, DeflateTests.swift:14-33)."""
+    rnd = random.Random(seed)
+    base = []
+    for kind in ("text", "rep", "mix", "rand"):
+        for n in (50, 600, 5000, 40000):
+            x = corpus.PAYLOADS[kind](n, 21)
+            base.append(corpus.deflate_raw(x, 6))
+            c = zlib.compressobj(6, zlib.DEFLATED, -15, 9, zlib.Z_FIXED)
+            base.append(c.compress(x) + c.flush())
+    ins = []
+    for z in base:
+        for _ in range(per_base):
+            b = bytearray(z)
+            mode = rnd.randrange(4)
+            if mode == 0:
+                b = b[:rnd.randrange(0, len(b))]
+            elif mode == 1:
+                for _ in range(rnd.randrange(1, 4)):
+                    b[rnd.randrange(min(len(b), 80))] ^= 1 << rnd.randrange(8)
+            elif mode == 2:
+                for _ in range(rnd.randrange(1, 4)):
+                    b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+            else:
+                i = rnd.randrange(len(b))
+                b[i:] = bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 50)))
+            ins.append(bytes(b))
+    for _ in range(n_random):
+        ins.append(bytes(rnd.randrange(256) for _ in range(rnd.randrange(0, 64))))
+    for _ in range(n_random):
+        b = bytearray(rnd.randrange(256) for _ in range(rnd.randrange(4, 120)))
+        if rnd.random() < 0.7:
+            b[0] = (b[0] & ~7) | 0b101
+        ins.append(bytes(b))
+    return ins

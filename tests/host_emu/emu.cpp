@@ -1,0 +1,18 @@
+// emu.cpp -- TEST INFRASTRUCTURE.  Builds the per-lane device decoders of swcompression_amd/csrc for
+// the HOST (g++ -DSWC_HOST_EMULATION) and runs the lanes of each wave one after another, with the
+// same wave-interleaved table layout the kernels use in LDS.  Lets the CPU-only test tier exercise
+// the exact source the gfx950 kernels are compiled from against the oracle.  Never shipped, never
+// linked into libswc_hip.so.
+#include <vector>
+#include <cstring>
+#include "../../swcompression_amd/csrc/inflate_lane.h"
+
+extern "C" void emu_inflate(swc::Job* jobs, size_t n) {
+    std::vector<uint32_t> lds(swc::inflate::kWordsPerLane * swc::kWave);
+    for (size_t g = 0; g < n; g++) {
+        int lane = (int)(g % swc::kWave);
+        if (lane == 0) std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);  // LDS is uninitialised on device
+        swc::LaneLds l{lds.data() + lane};
+        swc::inflate::inflate_job(jobs[g], l);
+    }
+}

@@ -1,0 +1,79 @@
+"""CPU tier: the C-ABI library builds for gfx950, loads, exports every symbol include/swc_hip.h declares,
+its host-only helpers (checksums) work, and -- with no GPU in this container -- every decode entry point
+fails loudly with SWC_E_DEVICE instead of falling back to a CPU decoder."""
+import ctypes as C
+import hashlib
+import os
+import re
+import zlib
+
+import pytest
+
+import swcompression_amd as swc
+from swcompression_amd import _lib, corpus
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    hdr = open(os.path.join(ROOT, "include", "swc_hip.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    return sorted(set(re.findall(r"\b(swc_[a-z0-9_]+)\s*\(", hdr)))
+
+
+def test_exports_every_declared_symbol():
+    lib = _lib.load()
+    names = _declared()
+    assert len(names) >= 25
+    for n in names:
+        assert hasattr(lib, n), "libswc_hip.so does not export %s" % n
+
+
+def test_status_table_matches_header():
+    hdr = open(os.path.join(ROOT, "include", "swc_status.h")).read()
+    codes = {int(v) for v in re.findall(r"=\s*(\d+)", hdr)} - {0}
+    assert codes == set(swc.STATUS)
+
+
+def test_job_layout():
+    assert C.sizeof(_lib.SwcJob) == 72 and _lib.SwcJob.status.offset == 48 and _lib.SwcJob.dict_len.offset == 64
+
+
+def test_host_checksums():
+    lib = _lib.load()
+    for n in (0, 1, 7, 8, 9, 63, 64, 65, 5551, 5552, 5553, 100000):
+        x = corpus.p_mix(n, 5)
+        assert lib.swc_crc32(x, n, 0) == zlib.crc32(x) & 0xFFFFFFFF
+        assert lib.swc_adler32(x, n) == zlib.adler32(x) & 0xFFFFFFFF
+        d = C.create_string_buffer(32)
+        lib.swc_sha256(x, n, d)
+        assert d.raw == hashlib.sha256(x).digest()
+    assert lib.swc_crc32(b"world", 5, zlib.crc32(b"hello ")) == zlib.crc32(b"hello world")
+    assert lib.swc_crc64(b"123456789", 9) == 0x995DC9BBDF1939FA
+    assert lib.swc_bzip2_crc32(b"123456789", 9) == 0xFC891918
+    assert lib.swc_xxh32(b"abc", 3, 0) == 0x32D153FF
+    assert lib.swc_xxh32(b"1234567890" * 8, 80, 0) == 0x9C05F475
+
+
+def test_code_object_is_gfx950_only():
+    blob = open(_lib.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+    for other in (b"gfx942", b"gfx90a", b"sm_90", b"gfx1100"):
+        assert other not in blob
+
+
+@pytest.mark.skipif(swc.device_available(), reason="GPU present: covered by the gpu tier")
+def test_no_cpu_fallback_without_gpu():
+    x = corpus.p_text(1000, 1)
+    calls = [
+        lambda: swc.Deflate.decompress(corpus.deflate_raw(x)),
+        lambda: swc.GzipArchive.unarchive(corpus.gzip_member(x)),
+        lambda: swc.ZlibArchive.unarchive(zlib.compress(x)),
+        lambda: swc.BZip2.decompress(corpus.bzip2_stream(x)),
+        lambda: swc.LZMA.decompress(corpus.lzma_alone(x)),
+        lambda: swc.XZArchive.unarchive(corpus.xz_stream(x)),
+        lambda: swc.LZ4.decompress(corpus.lz4_frame(x)),
+    ]
+    for c in calls:
+        with pytest.raises(swc.DeviceError):
+            c()

@@ -1,0 +1,179 @@
+"""GPU tier (MI355X): the HIP Deflate path, reached through the C ABI, against the CPU oracle.
+
+ - single-shot calls (host buffers) on the reference's payload classes, inline golden vectors, crafted
+   App.-A streams and framing error cases -- the same cases the CPU tier runs on the host emulation;
+ - the batched many-buffer launch on >= 4096 DISTINCT 64 KiB dynamic-Huffman blocks, bit-exact;
+ - BASELINE.json config 2 at full size (100,000 x 64 KiB members) through size-independent
+   properties: every job OK with the declared length, every replica tile identical on device,
+   CRC-32 of sampled outputs equal to the gzip trailers.
+"""
+import json
+import os
+import random
+import zlib
+
+import numpy as np
+import pytest
+
+import _oracle as O
+import _streams as S
+import swcompression_amd as swc
+from swcompression_amd import corpus
+from swcompression_amd.batch import DeviceBatch
+
+pytestmark = pytest.mark.gpu
+
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_inline_vectors.json")))
+
+
+def test_device_present_and_native_library_loaded():
+    assert swc.device_available(), "the HIP engine must run on the GPU box (no CPU fallback exists)"
+
+
+def _batch_vs_oracle(inputs, caps=None, check_partial=False):
+    exp = [O.deflate(z) for z in inputs]
+    if caps is None:
+        caps = [max(len(e[1]), 1) for e in exp]
+    b = DeviceBatch("deflate", inputs, caps)
+    b.launch(sync=True)
+    r = b.results()
+    for i, e in enumerate(exp):
+        assert int(r["status"][i]) == e[0], "status mismatch on input %d (%s...)" % (i, inputs[i][:12].hex())
+        if e[0] == 0:
+            assert int(r["out_len"][i]) == len(e[1]) and int(r["in_consumed"][i]) == e[2]
+            assert b.output(i, len(e[1])) == e[1], "bytes differ on input %d" % i
+        elif check_partial:
+            n = min(len(e[1]), int(caps[i]))
+            assert b.output(i, n) == e[1][:n]
+    return r
+
+
+@pytest.mark.parametrize("vec", GOLD["deflate"], ids=lambda v: v["name"])
+def test_inline_golden_vectors_single_shot(vec):
+    data = bytes.fromhex(vec["input"])
+    if vec["expect"] == "throws":
+        with pytest.raises(swc.DeflateError):
+            swc.Deflate.decompress(data)
+    else:
+        assert swc.Deflate.decompress(data) == bytes.fromhex(vec["expect"])
+
+
+def test_single_shot_payload_classes():
+    for z, x in S.valid_deflate_corpus(sizes=(0, 1, 9, 5000, 65536, 300000)):
+        out, consumed = swc.Deflate.decompress_consumed(z)
+        assert out == x and consumed == len(z)
+
+
+def test_single_shot_error_taxonomy():
+    for name, z in S.crafted_deflate():
+        st, out, cons = O.deflate(z)
+        if st == 0:
+            assert swc.Deflate.decompress_consumed(z) == (out, cons), name
+        else:
+            with pytest.raises(swc.SWCError) as ei:
+                swc.Deflate.decompress(z)
+            assert ei.value.status == st, name
+
+
+def test_batch_valid_corpus_and_crafted():
+    pairs = S.valid_deflate_corpus()
+    _batch_vs_oracle([z for z, _ in pairs])
+    cr = S.crafted_deflate()
+    _batch_vs_oracle([z for _, z in cr], caps=[600] * len(cr), check_partial=True)
+
+
+def test_batch_fuzz_status_parity():
+    O.lib.refcpu_set_max_output(1 << 24)
+    ins = S.fuzz_deflate()
+    exp = [O.deflate(z) for z in ins]
+    keep = [i for i, e in enumerate(exp) if e[0] != 901]
+    rnd = random.Random(7)
+    _batch_vs_oracle([ins[i] for i in keep], [max(len(exp[i][1]), 1) + rnd.choice([0, 0, 5]) for i in keep])
+    O.lib.refcpu_set_max_output(1 << 30)
+
+
+def test_batch_capacity_reports_required_size():
+    pairs = S.valid_deflate_corpus(sizes=(5000, 70000))
+    b = DeviceBatch("deflate", [z for z, _ in pairs], [len(x) // 2 for _, x in pairs])
+    b.launch(sync=True)
+    r = b.results()
+    for i, (z, x) in enumerate(pairs):
+        assert int(r["status"][i]) == 901 and int(r["out_len"][i]) == len(x)
+        assert b.output(i, len(x) // 2) == x[:len(x) // 2]
+
+
+def test_batch_4096_distinct_64k_blocks_bit_exact():
+    units, plains = corpus.build_units("deflate", 4096, 65536)
+    assert all(((u[0] >> 1) & 3) == 2 and (u[0] & 1) == 1 for u in units[:64])  # single dynamic-Huffman block
+    b = DeviceBatch("deflate", units, [65536] * len(units))
+    b.launch(sync=True)
+    r = b.results()
+    assert (r["status"] == 0).all() and (r["out_len"] == 65536).all()
+    assert (r["in_consumed"] == np.array([len(u) for u in units])).all()
+    blob = b.d_out.cpu().numpy()
+    for i in range(len(units)):
+        o = int(b._out_off[i])
+        got = blob[o:o + 65536].tobytes()
+        assert got == plains[i], "block %d differs" % i
+    # oracle == zlib == engine on a sample (three-way)
+    for i in range(0, len(units), 97):
+        assert O.deflate(units[i])[:2] == (0, plains[i])
+
+
+def test_gzip_zlib_framing():
+    x = corpus.p_text(70000, 2)
+    g = corpus.gzip_member(x)
+    assert swc.GzipArchive.unarchive(g) == x
+    assert swc.GzipArchive.unarchive(corpus.gzip_member(x[:30000], bgzf=True)) == x[:30000]
+    assert swc.GzipArchive.multi_unarchive(corpus.gzip_member(x[:100]) + corpus.gzip_member(x[100:])) == [x[:100], x[100:]]
+    assert swc.ZlibArchive.unarchive(zlib.compress(x)) == x
+    bad = bytearray(g); bad[-8] ^= 1
+    with pytest.raises(swc.GzipError) as ei:
+        swc.GzipArchive.unarchive(bytes(bad))
+    assert ei.value.case == "wrongCRC" and ei.value.data == x          # GzipTests.swift:190-206
+    bad = bytearray(g); bad[-1] ^= 1
+    with pytest.raises(swc.GzipError) as ei:
+        swc.GzipArchive.unarchive(bytes(bad))
+    assert ei.value.case == "wrongISize"
+    zl = bytearray(zlib.compress(x)); zl[-1] ^= 1
+    with pytest.raises(swc.ZlibError) as ei:
+        swc.ZlibArchive.unarchive(bytes(zl))
+    assert ei.value.case == "wrongAdler32" and ei.value.data == x      # ZlibTests.swift:59-75
+    for name, data in (("empty", b""), ("zero", b"\x00"), ("zeros", bytes(1 << 16))):
+        assert O.gzip_unarchive(data)[0] != 0
+        with pytest.raises(swc.SWCError) as ei:
+            swc.GzipArchive.unarchive(data)
+        assert ei.value.status == O.gzip_unarchive(data)[0], name
+        with pytest.raises(swc.SWCError) as ei:
+            swc.ZlibArchive.unarchive(data)
+        assert ei.value.status == O.zlib_unarchive(data)[0], name
+    # truncation fuzz (GzipTests.swift:249-291): must raise the same error the reference raises
+    rnd = random.Random(3)
+    for _ in range(12):
+        cut = g[:rnd.randrange(1, len(g))]
+        st = O.gzip_unarchive(cut)[0]
+        assert st != 0
+        with pytest.raises(swc.SWCError) as ei:
+            swc.GzipArchive.unarchive(cut)
+        assert ei.value.status == st
+
+
+def test_config2_full_size_properties():
+    """BASELINE.json config 2: 100,000 independent 64 KiB members on one GPU."""
+    n_distinct, tile = 4000, 25
+    units, plains = corpus.build_units("gzip", n_distinct, 65536)
+    raw = [u[10:-8] for u in units]                                    # host-side framing: 10-byte header, 8-byte trailer
+    b = DeviceBatch("deflate", raw, [65536] * n_distinct, tile=tile)
+    assert b.n == 100000
+    b.launch(sync=True)
+    r = b.results()
+    assert (r["status"] == 0).all() and (r["out_len"] == 65536).all()
+    assert (r["in_consumed"] == np.tile(np.array([len(x) for x in raw]), tile)).all()
+    span = n_distinct * 65536
+    first = b.d_out[:span]
+    for t in range(1, tile):                                           # every replica identical, compared in HBM
+        assert bool((b.d_out[t * span:(t + 1) * span] == first).all()), "tile %d differs" % t
+    host = first.cpu().numpy()
+    for i in range(0, n_distinct, 7):                                  # gzip trailers: CRC-32 + ISIZE
+        crc, isize = np.frombuffer(units[i][-8:], dtype="<u4")
+        assert isize == 65536 and zlib.crc32(host[i * 65536:(i + 1) * 65536].tobytes()) & 0xFFFFFFFF == crc

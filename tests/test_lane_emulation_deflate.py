@@ -1,0 +1,74 @@
+"""CPU tier: the per-lane Deflate decoder the gfx950 kernel is compiled from
+(swcompression_amd/csrc/inflate_lane.h), built for the host and run lane by lane with the kernel's
+wave-interleaved table layout, must agree with the oracle on status, output bytes and bytes consumed.
+The GPU tier (test_gpu_deflate.py) repeats the same cases through the C ABI on the device."""
+import random
+
+import pytest
+
+import _emu as E
+import _oracle as O
+import _streams as S
+
+
+def _check(inputs, caps=None):
+    exp = [O.deflate(z) for z in inputs]
+    if caps is None:
+        caps = [max(len(e[1]), 1) for e in exp]
+    res = E.inflate(inputs, caps)
+    for i, (r, e) in enumerate(zip(res, exp)):
+        st, out, cons, _ = r
+        assert st == e[0], "status mismatch on input %d (%s...)" % (i, inputs[i][:12].hex())
+        if e[0] == 0:
+            assert out == e[1] and cons == e[2], "output/consumed mismatch on input %d" % i
+
+
+def test_valid_corpus():
+    pairs = S.valid_deflate_corpus()
+    _check([z for z, _ in pairs])
+    for (z, x), r in zip(pairs, E.inflate([z for z, _ in pairs], [len(x) for _, x in pairs])):
+        assert r[:2] == (0, x)
+
+
+def test_crafted_reference_semantics():
+    cr = S.crafted_deflate()
+    ins = [z for _, z in cr]
+    exp = [O.deflate(z) for z in ins]
+    res = E.inflate(ins, [600] * len(ins))
+    for (name, _), r, e in zip(cr, res, exp):
+        assert r[0] == e[0], name
+        # partial output up to the error is not part of the contract, but for these vectors it pins
+        # the heap-overwrite / shadowing semantics of over-subscribed sets:
+        assert r[1] == e[1][:600], name
+    by_name = {n: e for (n, _), e in zip(cr, exp)}
+    assert by_name["oversub-ok"][:2] == (0, b"BB")
+    assert by_name["oversub-ok-shadowed-A"][:2] == (0, b"B")      # 'A' was overwritten by EOB
+    assert by_name["dist-too-far"][0] == 900 and by_name["dist-sym-30"][0] == 103
+
+
+def test_fuzz_status_parity():
+    O.lib.refcpu_set_max_output(1 << 24)
+    ins = S.fuzz_deflate()
+    exp = [O.deflate(z) for z in ins]
+    keep = [i for i, e in enumerate(exp) if e[0] != 901]
+    rnd = random.Random(7)
+    _check([ins[i] for i in keep], [max(len(exp[i][1]), 1) + rnd.choice([0, 0, 5]) for i in keep])
+    O.lib.refcpu_set_max_output(1 << 30)
+
+
+def test_capacity_reports_required_size():
+    pairs = S.valid_deflate_corpus(sizes=(5000, 70000))
+    ins = [z for z, _ in pairs]
+    res = E.inflate(ins, [len(x) // 2 for _, x in pairs])
+    for (z, x), r in zip(pairs, res):
+        assert r[0] == 901 and r[3] == len(x)                      # SWC_E_CAPACITY, out_len = bytes required
+        assert r[1] == x[:len(x) // 2]
+
+
+@pytest.mark.parametrize("lanes", [1, 63, 64, 65, 130])
+def test_wave_tail_and_table_reuse(lanes):
+    """More jobs than one wave: tables of a previous job in the same LDS lane must not leak."""
+    pairs = S.valid_deflate_corpus(sizes=(100, 5000))
+    pairs = (pairs * (lanes // len(pairs) + 1))[:lanes]
+    res = E.inflate([z for z, _ in pairs], [len(x) for _, x in pairs])
+    assert [r[:2] for r in res] == [(0, x) for _, x in pairs]
