@@ -135,6 +135,8 @@ void swc_free(void* p);
 /* 1 if a gfx950 device is usable, 0 otherwise (then every decode entry point returns SWC_E_DEVICE) */
 int swc_device_available(void);
 const char* swc_version(void);
+/* Performance knobs (never change results).  "inflate_lanes_per_stream" = 1 | 2 | 4. */
+int swc_set_tuning(const char* key, int value);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,13 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm ships its own libamdhip64; it must be the first HIP runtime mapped into the process,
+    # otherwise torch later reports "No HIP GPUs are available".  torch is only plumbing (HBM tensors,
+    # streams, torch.distributed) -- a C/Swift host links libswc_hip.so against /opt/rocm directly.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         from . import build as _build
         _build.build()
@@ -44,6 +51,7 @@ def load():
     sig("swc_free", None, C.c_void_p)
     sig("swc_device_available", I)
     sig("swc_version", C.c_char_p)
+    sig("swc_set_tuning", I, C.c_char_p, I)
     sig("swc_batch_decompress", I, I, C.c_void_p, C.c_size_t, C.POINTER(SwcBatchOpts))
     sig("swc_batch_workspace_bytes", C.c_size_t, I, C.c_size_t, C.c_uint64)
     sig("swc_batch_decompress_ws", I, I, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(SwcBatchOpts))

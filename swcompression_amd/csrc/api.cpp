@@ -126,6 +126,12 @@ using namespace swc;
 
 extern "C" {
 
+int swc_set_tuning(const char* key, int value) {
+    if (!key) return SWC_E_INVALID_ARGUMENT;
+    if (!strcmp(key, "inflate_lanes_per_stream") && (value == 1 || value == 2 || value == 4)) { set_inflate_group(value); return SWC_OK; }
+    return SWC_E_INVALID_ARGUMENT;
+}
+
 int swc_device_available(void) { return device_ready() ? 1 : 0; }
 const char* swc_version(void) { return "swc-hip 0.1 (gfx950)"; }
 void swc_free(void* p) { free(p); }

@@ -16,21 +16,36 @@ namespace swc {
 
 // ---- Deflate --------------------------------------------------------------------------------
 // LDS: 152 words/lane -> 38,912 B per wave -> 4 resident waves per CU (160 KiB LDS).
+// G lanes execute each stream redundantly (identical registers, shared LDS tables): G x fewer streams per
+// wave, G x less LDS per wave, so G x more resident waves per SIMD to hide latency.
+template <int G>
 __global__ __launch_bounds__(64, 1) void swc_inflate_kernel(Job* __restrict__ jobs, uint32_t n) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t g = blockIdx.x * kWave + threadIdx.x;
+    constexpr int kStreams = kWave / G;
+    uint32_t sl = threadIdx.x / G;
+    uint32_t g = blockIdx.x * kStreams + sl;
     if (g >= n) return;
     Job job = jobs[g];
-    inflate::inflate_job(job, LaneLds{lds + threadIdx.x});
-    jobs[g].out_len = job.out_len;
-    jobs[g].in_consumed = job.in_consumed;
-    jobs[g].status = job.status;
+    inflate::inflate_job(job, LaneLds{lds + sl, kStreams});
+    if (threadIdx.x % G == 0) {
+        jobs[g].out_len = job.out_len;
+        jobs[g].in_consumed = job.in_consumed;
+        jobs[g].status = job.status;
+    }
 }
+
+static int g_inflate_g = 1;
+void set_inflate_group(int g) { g_inflate_g = g; }
 
 hipError_t launch_inflate(Job* jobs, size_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    dim3 grid((unsigned)((n + kWave - 1) / kWave)), block(kWave);
-    hipLaunchKernelGGL(swc_inflate_kernel, grid, block, inflate::kLdsBytesPerWave, stream, jobs, (uint32_t)n);
+    const int G = g_inflate_g;
+    const unsigned streams = kWave / G;
+    dim3 grid((unsigned)((n + streams - 1) / streams)), block(kWave);
+    size_t lds = inflate::kLdsBytesPerWave;
+    if (G == 1) hipLaunchKernelGGL(swc_inflate_kernel<1>, grid, block, lds, stream, jobs, (uint32_t)n);
+    else if (G == 2) hipLaunchKernelGGL(swc_inflate_kernel<2>, grid, block, lds / 2, stream, jobs, (uint32_t)n);
+    else hipLaunchKernelGGL(swc_inflate_kernel<4>, grid, block, lds / 4, stream, jobs, (uint32_t)n);
     return hipGetLastError();
 }
 

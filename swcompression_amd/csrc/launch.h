@@ -5,5 +5,6 @@
 #include "swc_common.h"
 namespace swc {
 hipError_t launch_inflate(Job* jobs, size_t n, hipStream_t stream);
+void set_inflate_group(int g);
 }
 #endif

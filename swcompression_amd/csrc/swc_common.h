@@ -68,9 +68,10 @@ SWC_HD void store_u64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
 // base[j * 64 + lane], so any per-lane index pattern is bank-conflict free for 32-bit accesses
 // (bank = lane % 32, the two 32-lane halves are serviced separately).
 struct LaneLds {
-    uint32_t* p;  // base + lane
-    SWC_HD uint32_t get(int j) const { return p[j * kWave]; }
-    SWC_HD void set(int j, uint32_t v) const { p[j * kWave] = v; }
+    uint32_t* p;  // base + stream column
+    int stride;   // streams per wave (64 when every lane owns a stream)
+    SWC_HD uint32_t get(int j) const { return p[j * stride]; }
+    SWC_HD void set(int j, uint32_t v) const { p[j * stride] = v; }
 };
 
 }  // namespace swc

@@ -12,7 +12,7 @@ extern "C" void emu_inflate(swc::Job* jobs, size_t n) {
     for (size_t g = 0; g < n; g++) {
         int lane = (int)(g % swc::kWave);
         if (lane == 0) std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);  // LDS is uninitialised on device
-        swc::LaneLds l{lds.data() + lane};
+        swc::LaneLds l{lds.data() + lane, swc::kWave};
         swc::inflate::inflate_job(jobs[g], l);
     }
 }
