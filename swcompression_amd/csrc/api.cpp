@@ -129,6 +129,7 @@ extern "C" {
 int swc_set_tuning(const char* key, int value) {
     if (!key) return SWC_E_INVALID_ARGUMENT;
     if (!strcmp(key, "inflate_lanes_per_stream") && (value == 1 || value == 2 || value == 4)) { set_inflate_group(value); return SWC_OK; }
+    if (!strcmp(key, "inflate_debug_mode") && value >= 0 && value <= 2) { set_inflate_debug(value); return SWC_OK; }
     return SWC_E_INVALID_ARGUMENT;
 }
 

@@ -44,7 +44,7 @@ constexpr int kLdsBytesPerWave = kWordsPerLane * 4 * kWave;  // 38,912 B
 // LSB-first bit reader (BitByteData.LsbBitReader contract) with a 64-bit window
 // and one dword of read-ahead so the HBM/L2 latency of the next refill is hidden behind decode work.
 struct BitReader {
-    const uint8_t* in;
+    gcptr in;
     uint32_t len;    // stream length in bytes
     uint32_t ppos;   // byte offset of the next dword to prefetch
     uint32_t nextw;  // prefetched dword (nextn valid bytes)
@@ -65,7 +65,7 @@ struct BitReader {
         }
         ppos += nextn;
     }
-    SWC_HD void init(const uint8_t* p, uint32_t n, uint32_t byte_off) {
+    SWC_HD void init(gcptr p, uint32_t n, uint32_t byte_off) {
         in = p; len = n; ppos = byte_off; bb = 0; bc = 0;
         prefetch();
         refill();
@@ -76,6 +76,15 @@ struct BitReader {
             bb |= (uint64_t)nextw << bc;
             bc += nextn * 8;
             prefetch();
+        }
+    }
+    // refill() for the interior of the stream: the caller guarantees ppos + 4 <= len, so nextn == 4
+    SWC_HD void refill_fast() {
+        if (bc <= 32) {
+            bb |= (uint64_t)nextw << bc;
+            bc += 32;
+            nextw = load_u32(in + ppos);
+            ppos += 4;
         }
     }
     SWC_HD uint32_t peek32() const { return (uint32_t)bb; }
@@ -159,24 +168,27 @@ SWC_HD void clear_slots(const LaneLds& l, int wlen) {
     for (int d = 0; d <= MAXD + 1; d++) l.set(wlen + d, 0);
 }
 
+// DBG != 0 builds timing-only variants for on-GPU experiments (results are wrong by design):
+//   1 = history loads replaced by constants, 2 = additionally no output stores.
+template <int DBG = 0>
 struct Lane {
     LaneLds l;
     BitReader br;
     Limits lit, dist;
-    uint8_t* out;
+    gptr out;
     uint64_t cap;
     uint64_t pos;  // bytes produced (keeps counting past cap: size pass for SWC_E_CAPACITY)
 
     // Decode one symbol of the lit/len (LIT=true) or distance alphabet.  Returns the symbol or
     // -1 (DeflateError.symbolNotFound: unassigned path, or the code runs past the end of input).
-    template <bool LIT>
+    template <bool LIT, bool CHECKED = true>
     SWC_HD int decode_sym() {
         const Limits& lm = LIT ? lit : dist;
         const int wlen = LIT ? W_LIT_LEN : W_DIST_LEN;
         uint32_t c15 = brev32(br.peek32()) >> 17;
         uint32_t len;
         int idx;
-        if (!lm.oversub) {
+        if (!CHECKED || !lm.oversub) {
             len = 1;
 #pragma unroll
             for (int d = 1; d <= 15; d++) len += (c15 >= lm.lim[d]) ? 1u : 0u;
@@ -187,7 +199,7 @@ struct Lane {
             idx = lookup_exact<15>(l, wlen, c15, len);
             if (idx < 0) return -1;
         }
-        if (len > br.bc) return -1;  // DecodingTree.swift:39 -- ran out of bits before reaching a leaf
+        if (CHECKED && len > br.bc) return -1;  // DecodingTree.swift:39 -- ran out of bits before reaching a leaf
         br.consume(len);
         return LIT ? (int)lit_sym(l, (uint32_t)idx) : (int)byte_sym(l, W_DIST_SYM, (uint32_t)idx);
     }
@@ -328,6 +340,68 @@ struct Lane {
     // so that, within a wave, lanes that are mid-copy do not stall lanes that are decoding.
     SWC_HD int run_block() {
         uint32_t crem = 0, cdist = 0;
+        // ---- interior fast loop: >= 8 input bytes beyond the read-ahead and >= 272 output bytes of
+        // room, code sets not over-subscribed => no truncation / capacity / exact-lookup checks.
+        if (!lit.oversub && !dist.oversub) {
+            while ((uint64_t)br.ppos + 8 <= br.len && pos + 272 <= cap) {
+                if (crem != 0) {
+                    if (DBG == 0) {
+                        if (cdist >= 16) {  // both source words precede the destination: issue both loads, one wait
+                            uint64_t a = load_u64(out + pos - cdist), b = load_u64(out + pos + 8 - cdist);
+                            store_u64(out + pos, a);
+                            store_u64(out + pos + 8, b);
+                        } else {
+                            store_u64(out + pos, load_u64(out + pos - cdist));
+                            if (crem > 8) store_u64(out + pos + 8, load_u64(out + pos + 8 - cdist));
+                        }
+                    } else if (DBG == 1) {
+                        store_u64(out + pos, cdist);
+                        if (crem > 8) store_u64(out + pos + 8, cdist);
+                    }
+                    uint32_t n = crem < 16 ? crem : 16;
+                    pos += n;
+                    crem -= n;
+                    if (crem != 0) continue;
+                }
+                br.refill_fast();
+                int sym = decode_sym<true, false>();
+                if (sym < 0) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;
+                if (sym < 256) {
+                    if (DBG < 2) out[pos] = (uint8_t)sym;
+                    pos++;
+                    continue;
+                }
+                if (sym == 256) return SWC_OK;
+                if (sym > 285) return SWC_E_DEFLATE_WRONG_SYMBOL;
+                uint32_t s = (uint32_t)sym - 257u;
+                uint32_t e = s < 8 || s == 28 ? 0u : (s >> 2) - 1u;
+                uint32_t length = (s < 8 ? 3u + s : s == 28 ? 258u : 3u + ((4u + (s & 3u)) << e)) + br.bits(e);
+                br.refill_fast();
+                int dc = decode_sym<false, false>();
+                if (dc < 0) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;
+                if (dc > 29) return SWC_E_DEFLATE_WRONG_SYMBOL;
+                uint32_t de = dc < 4 ? 0u : ((uint32_t)dc >> 1) - 1u;
+                uint32_t distance = (dc < 4 ? 1u + (uint32_t)dc : 1u + ((2u + ((uint32_t)dc & 1u)) << de)) + br.bits(de);
+                if ((uint64_t)distance > pos) return SWC_E_REF_TRAP;
+                if (distance >= 8) {
+                    crem = length;
+                    cdist = distance;
+                } else {
+                    uint32_t sh = 8 * distance;
+                    uint64_t w = (DBG == 0 ? load_u64(out + pos - distance) : (uint64_t)distance) & ((1ull << sh) - 1ull);
+                    w |= w << sh;
+                    sh *= 2;
+                    if (sh < 64) { w |= w << sh; sh *= 2; }
+                    if (sh < 64) w |= w << sh;
+                    if (DBG < 2) store_u64(out + pos, w);
+                    uint32_t n = length < 8 ? length : 8;
+                    pos += n;
+                    crem = length - n;
+                    cdist = ((7u + distance) / distance) * distance;
+                }
+            }
+        }
+        // ---- careful loop: stream tail, output tail, over-subscribed sets, size-counting mode
         for (;;) {
             if (crem != 0) {
                 uint32_t n = crem < 8 ? crem : 8;
@@ -406,7 +480,7 @@ struct Lane {
         br.consume(br.bc & 7);  // align()
         uint32_t p = (uint32_t)(br.consumed_bits() >> 3);
         if (br.len - p < 4) return SWC_E_DEFLATE_WRONG_UNCOMPRESSED_BLOCK_LENGTHS;  // :48
-        const uint8_t* q = br.in + p;
+        gcptr q = br.in + p;
         uint32_t length = (uint32_t)q[0] | ((uint32_t)q[1] << 8);
         uint32_t nlength = (uint32_t)q[2] | ((uint32_t)q[3] << 8);
         if ((length & nlength) != 0) return SWC_E_DEFLATE_WRONG_UNCOMPRESSED_BLOCK_LENGTHS;  // :56
@@ -450,18 +524,19 @@ struct Lane {
 };
 
 // One lane = one job.  `lds` is this lane's view of the wave's table region.
+template <int DBG = 0>
 SWC_HD void inflate_job(Job& job, LaneLds lds) {
-    Lane ln;
+    Lane<DBG> ln;
     ln.l = lds;
-    ln.out = job.out;
+    ln.out = (gptr)job.out;
     ln.cap = job.out_cap;
     ln.pos = 0;
     int st;
     if (job.in_len > 0xFFFFFFF0ull) {
         st = SWC_E_INVALID_ARGUMENT;  // streams are addressed with 32-bit byte offsets on device
-        ln.br.init(job.in, 0, 0);
+        ln.br.init((gcptr)job.in, 0, 0);
     } else {
-        ln.br.init(job.in, (uint32_t)job.in_len, 0);
+        ln.br.init((gcptr)job.in, (uint32_t)job.in_len, 0);
         st = ln.run();
     }
     if (st == SWC_OK && ln.pos > ln.cap) st = SWC_E_CAPACITY;

@@ -18,7 +18,7 @@ namespace swc {
 // LDS: 152 words/lane -> 38,912 B per wave -> 4 resident waves per CU (160 KiB LDS).
 // G lanes execute each stream redundantly (identical registers, shared LDS tables): G x fewer streams per
 // wave, G x less LDS per wave, so G x more resident waves per SIMD to hide latency.
-template <int G>
+template <int G, int DBG>
 __global__ __launch_bounds__(64, 1) void swc_inflate_kernel(Job* __restrict__ jobs, uint32_t n) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     constexpr int kStreams = kWave / G;
@@ -26,7 +26,7 @@ __global__ __launch_bounds__(64, 1) void swc_inflate_kernel(Job* __restrict__ jo
     uint32_t g = blockIdx.x * kStreams + sl;
     if (g >= n) return;
     Job job = jobs[g];
-    inflate::inflate_job(job, LaneLds{lds + sl, kStreams});
+    inflate::inflate_job<DBG>(job, LaneLds{lds + sl, kStreams});
     if (threadIdx.x % G == 0) {
         jobs[g].out_len = job.out_len;
         jobs[g].in_consumed = job.in_consumed;
@@ -34,8 +34,9 @@ __global__ __launch_bounds__(64, 1) void swc_inflate_kernel(Job* __restrict__ jo
     }
 }
 
-static int g_inflate_g = 1;
+static int g_inflate_g = 1, g_inflate_dbg = 0;
 void set_inflate_group(int g) { g_inflate_g = g; }
+void set_inflate_debug(int m) { g_inflate_dbg = m; }
 
 hipError_t launch_inflate(Job* jobs, size_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;
@@ -43,9 +44,11 @@ hipError_t launch_inflate(Job* jobs, size_t n, hipStream_t stream) {
     const unsigned streams = kWave / G;
     dim3 grid((unsigned)((n + streams - 1) / streams)), block(kWave);
     size_t lds = inflate::kLdsBytesPerWave;
-    if (G == 1) hipLaunchKernelGGL(swc_inflate_kernel<1>, grid, block, lds, stream, jobs, (uint32_t)n);
-    else if (G == 2) hipLaunchKernelGGL(swc_inflate_kernel<2>, grid, block, lds / 2, stream, jobs, (uint32_t)n);
-    else hipLaunchKernelGGL(swc_inflate_kernel<4>, grid, block, lds / 4, stream, jobs, (uint32_t)n);
+    if (g_inflate_dbg == 1) hipLaunchKernelGGL((swc_inflate_kernel<1, 1>), grid, block, lds, stream, jobs, (uint32_t)n);
+    else if (g_inflate_dbg == 2) hipLaunchKernelGGL((swc_inflate_kernel<1, 2>), grid, block, lds, stream, jobs, (uint32_t)n);
+    else if (G == 1) hipLaunchKernelGGL((swc_inflate_kernel<1, 0>), grid, block, lds, stream, jobs, (uint32_t)n);
+    else if (G == 2) hipLaunchKernelGGL((swc_inflate_kernel<2, 0>), grid, block, lds / 2, stream, jobs, (uint32_t)n);
+    else hipLaunchKernelGGL((swc_inflate_kernel<4, 0>), grid, block, lds / 4, stream, jobs, (uint32_t)n);
     return hipGetLastError();
 }
 

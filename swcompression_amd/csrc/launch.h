@@ -6,5 +6,6 @@
 namespace swc {
 hipError_t launch_inflate(Job* jobs, size_t n, hipStream_t stream);
 void set_inflate_group(int g);
+void set_inflate_debug(int m);
 }
 #endif

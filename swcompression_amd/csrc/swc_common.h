@@ -51,18 +51,24 @@ SWC_HD uint32_t brev32(uint32_t x) {
 #endif
 }
 
-SWC_HD uint32_t load_u32(const uint8_t* p) {  // gfx950 global loads are unaligned-capable
-    uint32_t v;
-    __builtin_memcpy(&v, p, 4);
-    return v;
-}
-SWC_HD uint64_t load_u64(const uint8_t* p) {
-    uint64_t v;
-    __builtin_memcpy(&v, p, 8);
-    return v;
-}
-SWC_HD void store_u32(uint8_t* p, uint32_t v) { __builtin_memcpy(p, &v, 4); }
-SWC_HD void store_u64(uint8_t* p, uint64_t v) { __builtin_memcpy(p, &v, 8); }
+// Pointers into HBM.  On the device they carry the global address space so that the compiler emits
+// global_load/global_store instead of FLAT instructions (pointers loaded from a job record are generic
+// otherwise; FLAT ops tie up both vmcnt and lgkmcnt and serialise against the LDS table reads).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SWC_AS_GLOBAL __attribute__((address_space(1)))
+#else
+#define SWC_AS_GLOBAL
+#endif
+typedef const SWC_AS_GLOBAL uint8_t* gcptr;
+typedef SWC_AS_GLOBAL uint8_t* gptr;
+typedef uint32_t __attribute__((aligned(1), may_alias)) u32_unaligned;
+typedef uint64_t __attribute__((aligned(1), may_alias)) u64_unaligned;
+
+// gfx950 global loads/stores are unaligned-capable (hipcc emits plain global_load_dword for these)
+SWC_HD uint32_t load_u32(gcptr p) { return *(const SWC_AS_GLOBAL u32_unaligned*)p; }
+SWC_HD uint64_t load_u64(gcptr p) { return *(const SWC_AS_GLOBAL u64_unaligned*)p; }
+SWC_HD void store_u32(gptr p, uint32_t v) { *(SWC_AS_GLOBAL u32_unaligned*)p = v; }
+SWC_HD void store_u64(gptr p, uint64_t v) { *(SWC_AS_GLOBAL u64_unaligned*)p = v; }
 
 // Per-lane view of an LDS region interleaved at wave stride: word j of this lane lives at
 // base[j * 64 + lane], so any per-lane index pattern is bank-conflict free for 32-bit accesses
