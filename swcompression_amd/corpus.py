@@ -272,3 +272,38 @@ def build_units(kind, n_distinct, unit_size, payload="text", seed=2, cache=True)
         np.savez(path, ub=np.frombuffer(b"".join(units), dtype=np.uint8), uo=uo,
                  pb=np.frombuffer(b"".join(plains), dtype=np.uint8), po=po)
     return units, plains
+
+
+class _LZ4F_frameInfo(ctypes.Structure):
+    _fields_ = [("blockSizeID", ctypes.c_int), ("blockMode", ctypes.c_int), ("contentChecksumFlag", ctypes.c_int),
+                ("frameType", ctypes.c_int), ("contentSize", ctypes.c_ulonglong), ("dictID", ctypes.c_uint),
+                ("blockChecksumFlag", ctypes.c_int)]
+
+
+class _LZ4F_preferences(ctypes.Structure):
+    _fields_ = [("frameInfo", _LZ4F_frameInfo), ("compressionLevel", ctypes.c_int), ("autoFlush", ctypes.c_uint),
+                ("favorDecSpeed", ctypes.c_uint), ("reserved", ctypes.c_uint * 3)]
+
+
+def lz4f_frame(payload, block_size_code=4, linked=True, content_checksum=False, block_checksum=False, content_size=False):
+    """A frame produced by liblz4's own frame API (LZ4F_compressFrame) -- the only way to get
+    DEPENDENT (linked) blocks, which the reference decodes with a 64 KiB sliding prefix (LZ4.swift:306-313)."""
+    lib = _liblz4()
+    lib.LZ4F_compressFrameBound.restype = ctypes.c_size_t
+    lib.LZ4F_compressFrameBound.argtypes = [ctypes.c_size_t, ctypes.c_void_p]
+    lib.LZ4F_compressFrame.restype = ctypes.c_size_t
+    lib.LZ4F_compressFrame.argtypes = [ctypes.c_char_p, ctypes.c_size_t, ctypes.c_char_p, ctypes.c_size_t, ctypes.c_void_p]
+    lib.LZ4F_isError.restype = ctypes.c_uint
+    lib.LZ4F_isError.argtypes = [ctypes.c_size_t]
+    prefs = _LZ4F_preferences()
+    prefs.frameInfo.blockSizeID = block_size_code
+    prefs.frameInfo.blockMode = 0 if linked else 1
+    prefs.frameInfo.contentChecksumFlag = 1 if content_checksum else 0
+    prefs.frameInfo.blockChecksumFlag = 1 if block_checksum else 0
+    prefs.frameInfo.contentSize = len(payload) if content_size else 0
+    bound = lib.LZ4F_compressFrameBound(len(payload), ctypes.byref(prefs))
+    dst = ctypes.create_string_buffer(bound)
+    n = lib.LZ4F_compressFrame(dst, bound, payload, len(payload), ctypes.byref(prefs))
+    if lib.LZ4F_isError(n):
+        raise RuntimeError("LZ4F_compressFrame failed")
+    return dst.raw[:n]

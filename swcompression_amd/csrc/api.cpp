@@ -34,6 +34,7 @@ bool device_ready() {
 static hipError_t launch_codec(int codec, Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {
     switch (codec) {
         case SWC_CODEC_DEFLATE: return launch_inflate(jobs, n, stream);
+        case SWC_CODEC_LZ4_BLOCK: return launch_lz4(jobs, n, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -1,0 +1,259 @@
+// framing_lz4.cpp -- host side of LZ4: frame / legacy-frame / skippable-frame parsing and block
+// discovery feeding ONE batched launch per frame (independent blocks) -- the reference decodes the
+// blocks one after another on the CPU.
+//   LZ4.decompress(data:dictionary:dictionaryID:)   reference Sources/LZ4/LZ4.swift:73-91
+//   LZ4.multiDecompress                              :116-146
+//   process(skippableFrame:) :148-155   process(legacyFrame:) :160-186   process(frame:_:_:) :188-330
+// Errors are reported in STREAM ORDER exactly as the sequential reference would meet them: framing
+// checks of block k only count once every block before k has decoded cleanly.
+#include <vector>
+#include "framing.h"
+
+namespace swc {
+
+namespace {
+
+inline uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+
+struct BlockRef {
+    size_t off, len;
+    bool compressed;
+};
+
+// Decode `blocks` (all independent of each other) on the device and append to `out` in order.
+// Returns the first decode error in stream order, or SWC_OK / SWC_E_DEVICE.
+int decode_independent(const uint8_t* base, const std::vector<BlockRef>& blocks, const uint8_t* dict, size_t dict_len,
+                       bool have_dict, size_t max_block, std::vector<uint8_t>& out) {
+    std::vector<HostUnit> units;
+    units.reserve(blocks.size());
+    for (const BlockRef& b : blocks) {
+        if (!b.compressed) continue;
+        HostUnit u;
+        u.in = base + b.off;
+        u.in_len = b.len;
+        u.cap_hint = max_block;  // a block normally decodes to <= the frame's maximum block size (not enforced by the reference)
+        if (have_dict) { u.dict = dict ? dict : reinterpret_cast<const uint8_t*>(""); u.dict_len = dict_len; }
+        units.push_back(std::move(u));
+    }
+    if (!units.empty()) {
+        int st = run_units(SWC_CODEC_LZ4_BLOCK, units);
+        if (st) return st;
+    }
+    size_t k = 0;
+    for (const BlockRef& b : blocks) {
+        if (b.compressed) {
+            HostUnit& u = units[k++];
+            if (u.status) return u.status;
+            out.insert(out.end(), u.out.begin(), u.out.end());
+        } else {
+            out.insert(out.end(), base + b.off, base + b.off + b.len);
+        }
+    }
+    return SWC_OK;
+}
+
+// process(legacyFrame:) :160-186; p points just after the magic.
+int legacy_frame(const uint8_t* p, size_t n, std::vector<uint8_t>& out, size_t& adv) {
+    std::vector<BlockRef> blocks;
+    size_t off = 0;
+    int framing = SWC_OK;
+    while (off < n) {
+        if (n - off < 4) { framing = SWC_E_DATA_TRUNCATED; break; }               // :165
+        uint32_t raw = le32(p + off);
+        off += 4;
+        if (raw == 0x184D2204u || raw == 0x184C2102u || (raw >= 0x184D2A50u && raw <= 0x184D2A5Fu)) { off -= 4; break; }  // :168-171
+        if (n - off < raw) { framing = SWC_E_DATA_TRUNCATED; break; }             // :177
+        blocks.push_back({off, raw, true});
+        off += raw;
+    }
+    int st = decode_independent(p, blocks, nullptr, 0, false, 8u << 20, out);
+    if (st) return st;
+    if (framing) return framing;
+    adv = off;
+    return SWC_OK;
+}
+
+// process(frame:_:_:) :188-330; p points just after the magic.
+int frame(const uint8_t* p, size_t n, const uint8_t* dict, size_t dict_len, bool have_dict, int64_t ext_dict_id,
+          std::vector<uint8_t>& out, size_t& adv) {
+    if (n < 7) return SWC_E_DATA_TRUNCATED;                                       // :191
+    size_t off = 0;
+    const uint32_t flg = p[off++];
+    if (!(((flg & 0xC0) >> 6) == 1 && (flg & 0x02) == 0)) return SWC_E_DATA_CORRUPTED;  // :198
+    const bool independent = flg & 0x20, block_checksum = flg & 0x10, content_size_present = flg & 0x08,
+               content_checksum = flg & 0x04, dict_id_present = flg & 0x01;
+    size_t max_block;
+    switch (p[off++]) {                                                           // :216-228
+        case 0x40: max_block = 64u << 10; break;
+        case 0x50: max_block = 256u << 10; break;
+        case 0x60: max_block = 1u << 20; break;
+        case 0x70: max_block = 4u << 20; break;
+        default: return SWC_E_DATA_CORRUPTED;
+    }
+    uint64_t content_size = 0;
+    if (content_size_present) {
+        if (n - off < 13) return SWC_E_DATA_TRUNCATED;                            // :234
+        for (int i = 0; i < 8; i++) content_size |= (uint64_t)p[off + i] << (8 * i);
+        off += 8;
+        if (content_size > (uint64_t)INT64_MAX) return SWC_E_DATA_UNSUPPORTED_FEATURE;  // :240
+    }
+    int64_t dict_id = -1;
+    if (dict_id_present) {
+        if (!have_dict) return SWC_E_DATA_CORRUPTED;                              // :250
+        if (n - off < 9) return SWC_E_DATA_TRUNCATED;                             // :254
+        dict_id = le32(p + off);
+        off += 4;
+    }
+    if (ext_dict_id >= 0 && dict_id >= 0 && ext_dict_id != dict_id) return SWC_E_DATA_CORRUPTED;  // :266-270
+    if ((uint8_t)((swc_xxh32(p, off, 0) >> 8) & 0xFF) != p[off]) return SWC_E_DATA_CORRUPTED;     // :272-275
+    off++;
+
+    // block discovery
+    std::vector<BlockRef> blocks;
+    int framing = SWC_OK;
+    for (;;) {
+        if (n - off < 4) { framing = SWC_E_DATA_TRUNCATED; break; }               // :279
+        const uint32_t mark = le32(p + off);
+        off += 4;
+        if (mark == 0) break;                                                     // EndMark :284
+        const size_t bs = mark & 0x7FFFFFFFu;
+        if (bs > max_block) { framing = SWC_E_DATA_CORRUPTED; break; }            // :292
+        if (n - off < bs + (block_checksum ? 4 : 0) + 4) { framing = SWC_E_DATA_TRUNCATED; break; }  // :295
+        const size_t boff = off;
+        off += bs;
+        if (block_checksum) {
+            const uint32_t c = le32(p + off);
+            off += 4;
+            if (swc_xxh32(p + boff, bs, 0) != c) { framing = SWC_E_DATA_CORRUPTED; break; }  // :300
+        }
+        blocks.push_back({boff, bs, (mark & 0x80000000u) == 0});
+    }
+
+    const size_t start = out.size();
+    if (independent) {
+        int st = decode_independent(p, blocks, dict, dict_len, have_dict, max_block, out);  // :305
+        if (st) return st;
+    } else {
+        // Dependent blocks: block k references the last 64 KiB produced so far (:306-313) -- a serial chain.
+        for (const BlockRef& b : blocks) {
+            if (!b.compressed) { out.insert(out.end(), p + b.off, p + b.off + b.len); continue; }
+            HostUnit u;
+            u.in = p + b.off;
+            u.in_len = b.len;
+            u.cap_hint = max_block;
+            const size_t produced = out.size() - start;
+            std::vector<uint8_t> window;
+            if (produced == 0 && have_dict) {
+                const size_t dl = dict_len > 65536 ? 65536 : dict_len;
+                u.dict = dict_len ? dict + (dict_len - dl) : reinterpret_cast<const uint8_t*>("");
+                u.dict_len = dl;
+            } else {
+                const size_t dl = produced > 65536 ? 65536 : produced;
+                window.assign(out.end() - dl, out.end());
+                u.dict = dl ? window.data() : reinterpret_cast<const uint8_t*>("");
+                u.dict_len = dl;
+            }
+            int st = run_one(SWC_CODEC_LZ4_BLOCK, u);
+            if (st) return st;
+            if (u.status) return u.status;
+            out.insert(out.end(), u.out.begin(), u.out.end());
+        }
+    }
+    if (framing) return framing;
+    if (content_size_present && (uint64_t)(out.size() - start) != content_size) return SWC_E_DATA_CORRUPTED;  // :320
+    if (content_checksum) {
+        if (n - off < 4) return SWC_E_DATA_TRUNCATED;                             // :324
+        const uint32_t c = le32(p + off);
+        off += 4;
+        adv = off;
+        if (swc_xxh32(out.data() + start, out.size() - start, 0) != c) return SWC_E_DATA_CHECKSUM_MISMATCH;  // :326
+    }
+    adv = off;
+    return SWC_OK;
+}
+
+int skippable(const uint8_t* p, size_t n, size_t& adv) {                          // :148-155
+    if (n < 4) return SWC_E_DATA_TRUNCATED;
+    const size_t size = le32(p);
+    if (n < size + 4) return SWC_E_DATA_TRUNCATED;
+    adv = size + 4;
+    return SWC_OK;
+}
+
+}  // namespace
+}  // namespace swc
+
+using namespace swc;
+
+extern "C" {
+
+int swc_lz4_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len, int64_t dict_id,
+                       uint8_t** out, size_t* out_len, size_t* in_consumed) {
+    if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
+    std::vector<uint8_t> res;
+    bool have_dict = dict != nullptr;
+    size_t pos = 0, adv = 0;
+    int st;
+    for (;;) {
+        if (in_len - pos < 4) { st = SWC_E_DATA_TRUNCATED; break; }               // :75
+        const uint32_t magic = le32(in + pos);
+        pos += 4;
+        if (magic == 0x184D2204u) {
+            st = frame(in + pos, in_len - pos, dict, dict_len, have_dict, dict_id, res, adv);
+            if (st == SWC_OK || st == SWC_E_DATA_CHECKSUM_MISMATCH) pos += adv;
+            break;
+        } else if (magic >= 0x184D2A50u && magic <= 0x184D2A5Fu) {
+            st = skippable(in + pos, in_len - pos, adv);
+            if (st) break;
+            pos += adv;
+            have_dict = false; dict = nullptr; dict_len = 0; dict_id = -1;        // :85 recursion drops the dictionary
+        } else if (magic == 0x184C2102u) {
+            st = legacy_frame(in + pos, in_len - pos, res, adv);
+            if (st == SWC_OK) pos += adv;
+            break;
+        } else {
+            st = SWC_E_DATA_CORRUPTED;
+            break;
+        }
+    }
+    if (st != SWC_OK && st != SWC_E_DATA_CHECKSUM_MISMATCH) res.clear();          // only checksumMismatch carries data
+    if (in_consumed) *in_consumed = pos;
+    give(res, out, out_len);
+    return st;
+}
+
+int swc_lz4_multi_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len, int64_t dict_id,
+                             uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_frames) {
+    if (!out || !out_len || !sizes || !n_frames || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
+    std::vector<uint8_t> all;
+    std::vector<size_t> sz;
+    const bool have_dict = dict != nullptr;
+    size_t pos = 0;
+    int st = SWC_OK;
+    do {
+        if (pos + 4 > in_len) { st = SWC_E_DATA_TRUNCATED; break; }               // :123
+        const uint32_t magic = le32(in + pos);
+        pos += 4;
+        size_t adv = 0;
+        std::vector<uint8_t> one;
+        bool produced = false;
+        if (magic == 0x184D2204u) { st = frame(in + pos, in_len - pos, dict, dict_len, have_dict, dict_id, one, adv); produced = true; }
+        else if (magic >= 0x184D2A50u && magic <= 0x184D2A5Fu) st = skippable(in + pos, in_len - pos, adv);
+        else if (magic == 0x184C2102u) { st = legacy_frame(in + pos, in_len - pos, one, adv); produced = true; }
+        else st = SWC_E_DATA_CORRUPTED;
+        if (st == SWC_E_DATA_CHECKSUM_MISMATCH) {                                 // :326 carries [out] of the failing frame only
+            all = std::move(one);
+            sz.assign(1, all.size());
+            break;
+        }
+        if (st) { all.clear(); sz.clear(); break; }
+        pos += adv;
+        if (produced) { sz.push_back(one.size()); all.insert(all.end(), one.begin(), one.end()); }
+    } while (pos < in_len);
+    give(all, out, out_len);
+    *sizes = give_sizes(sz);
+    *n_frames = sz.size();
+    return st;
+}
+
+}  // extern "C"

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include "swc_common.h"
 #include "inflate_lane.h"
+#include "lz4_lane.h"
 #include "launch.h"
 
 namespace swc {
@@ -49,6 +50,24 @@ hipError_t launch_inflate(Job* jobs, size_t n, hipStream_t stream) {
     else if (G == 1) hipLaunchKernelGGL((swc_inflate_kernel<1, 0>), grid, block, lds, stream, jobs, (uint32_t)n);
     else if (G == 2) hipLaunchKernelGGL((swc_inflate_kernel<2, 0>), grid, block, lds / 2, stream, jobs, (uint32_t)n);
     else hipLaunchKernelGGL((swc_inflate_kernel<4, 0>), grid, block, lds / 4, stream, jobs, (uint32_t)n);
+    return hipGetLastError();
+}
+
+// ---- LZ4, one block per lane (many small blocks) -------------------------------------------------
+__global__ __launch_bounds__(64) void swc_lz4_lane_kernel(Job* __restrict__ jobs, uint32_t n) {
+    uint32_t g = blockIdx.x * kWave + threadIdx.x;
+    if (g >= n) return;
+    Job job = jobs[g];
+    lz4::lz4_block_job(job);
+    jobs[g].out_len = job.out_len;
+    jobs[g].in_consumed = job.in_consumed;
+    jobs[g].status = job.status;
+}
+
+hipError_t launch_lz4(Job* jobs, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    dim3 grid((unsigned)((n + kWave - 1) / kWave)), block(kWave);
+    hipLaunchKernelGGL(swc_lz4_lane_kernel, grid, block, 0, stream, jobs, (uint32_t)n);
     return hipGetLastError();
 }
 

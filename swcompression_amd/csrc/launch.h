@@ -5,6 +5,7 @@
 #include "swc_common.h"
 namespace swc {
 hipError_t launch_inflate(Job* jobs, size_t n, hipStream_t stream);
+hipError_t launch_lz4(Job* jobs, size_t n, hipStream_t stream);
 void set_inflate_group(int g);
 void set_inflate_debug(int m);
 }

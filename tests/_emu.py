@@ -63,3 +63,7 @@ def run_batch(fn_name, inputs, caps, aux=None, dicts=None, extra=None):
 
 def inflate(inputs, caps):
     return run_batch("emu_inflate", inputs, caps)
+
+
+def lz4_block(inputs, caps, dicts=None):
+    return run_batch("emu_lz4_block", inputs, caps, dicts=dicts)

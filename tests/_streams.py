@@ -187,3 +187,56 @@ def fuzz_deflate(seed=1234, per_base=24, n_random=1200):
             b[0] = (b[0] & ~7) | 0b101
         ins.append(bytes(b))
     return ins
+
+
+# ------------------------------------------------------------------------------------------- LZ4
+def lz4_blocks_valid(seed=3):
+    """(block, dictionary-or-None) pairs decoding successfully."""
+    out = []
+    for kind in ("text", "rep", "zero", "rand", "mix"):
+        for n in (1, 4, 12, 13, 100, 5000, 70000):
+            out.append((corpus.lz4_block(corpus.PAYLOADS[kind](n, seed)), None))
+    out.append((bytes([0x00, 0x03, 0x00, 0x80]) + b"stuvwxyz", b"abc"))                 # match entirely inside the dictionary
+    out.append((bytes([0x0F, 0x03, 0x00, 0x02, 0x80]) + b"stuvwxyz", b"abc"))           # match starts in the dictionary, runs into the output
+    out.append((bytes([0x10, 0x41, 0x01, 0x00, 0xC0]) + b"0123456789AB", None))         # RLE-style offset 1
+    return out
+
+
+def lz4_blocks_fuzz(seed=5, n_random=1500):
+    rnd = random.Random(seed)
+    ins = []
+    for z, d in lz4_blocks_valid()[:30]:
+        for _ in range(24):
+            b = bytearray(z)
+            m = rnd.randrange(3)
+            if m == 0 and len(b) > 1:
+                b = b[:rnd.randrange(1, len(b))]
+            elif m == 1 and b:
+                b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+            else:
+                b += bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 9)))
+            ins.append((bytes(b), d))
+    for _ in range(n_random):
+        ins.append((bytes(rnd.randrange(256) for _ in range(rnd.randrange(0, 40))), rnd.choice([None, b"0123456789" * 3])))
+    return ins
+
+
+def lz4_frames():
+    """(name, frame bytes, dictionary, dictionary id) covering the frame features the reference tests
+    (LZ4Tests.swift:77-184): block sizes B4-B7, independent / dependent blocks, checksums, content size,
+    legacy and skippable frames, multi-frame input."""
+    import struct
+    x = corpus.p_text(300000, 5)
+    y = corpus.p_mix(150000, 6)
+    out = []
+    for code in (4, 5, 6, 7):
+        for linked in (False, True):
+            out.append(("B%d-%s" % (code, "BD" if linked else "BI"), corpus.lz4f_frame(x, code, linked, True, code == 5, code == 6), None, None))
+    out.append(("stored-blocks", corpus.lz4f_frame(corpus.p_rand(100000, 1), 4, False, True), None, None))
+    out.append(("empty-payload", corpus.lz4f_frame(b"", 4, False, True), None, None))
+    out.append(("mix-dependent", corpus.lz4f_frame(y, 4, True, True, True, True), None, None))
+    b = corpus.lz4_block(x[:50000])
+    out.append(("legacy", struct.pack("<II", 0x184C2102, len(b)) + b, None, None))
+    skip = struct.pack("<II", 0x184D2A53, 5) + b"hello"
+    out.append(("skippable-then-frame", skip + corpus.lz4f_frame(x[:3000], 4, False), None, None))
+    return out

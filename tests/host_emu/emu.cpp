@@ -6,6 +6,7 @@
 #include <vector>
 #include <cstring>
 #include "../../swcompression_amd/csrc/inflate_lane.h"
+#include "../../swcompression_amd/csrc/lz4_lane.h"
 
 extern "C" void emu_inflate(swc::Job* jobs, size_t n) {
     std::vector<uint32_t> lds(swc::inflate::kWordsPerLane * swc::kWave);
@@ -15,4 +16,8 @@ extern "C" void emu_inflate(swc::Job* jobs, size_t n) {
         swc::LaneLds l{lds.data() + lane, swc::kWave};
         swc::inflate::inflate_job(jobs[g], l);
     }
+}
+
+extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {
+    for (size_t g = 0; g < n; g++) swc::lz4::lz4_block_job(jobs[g]);
 }

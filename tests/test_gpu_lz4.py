@@ -1,0 +1,99 @@
+"""GPU tier: LZ4 through the C ABI on the MI355X vs the oracle (reference Sources/LZ4/LZ4.swift)."""
+import random
+import struct
+
+import numpy as np
+import pytest
+
+import _oracle as O
+import _streams as S
+import swcompression_amd as swc
+from swcompression_amd import corpus
+from swcompression_amd.batch import DeviceBatch
+
+pytestmark = pytest.mark.gpu
+
+
+def test_batch_blocks_vs_oracle():
+    O.lib.refcpu_set_max_output(1 << 22)
+    cases = [c for c in S.lz4_blocks_valid() + S.lz4_blocks_fuzz() if c[1] is None]
+    exp = [O.lz4_block(z) for z, _ in cases]
+    keep = [i for i, e in enumerate(exp) if e[0] != 901]
+    rnd = random.Random(1)
+    caps = [max(len(exp[i][1]), 1) + rnd.choice([0, 0, 3, 64]) for i in keep]
+    b = DeviceBatch("lz4_block", [cases[i][0] for i in keep], caps)
+    b.launch(sync=True)
+    r = b.results()
+    for k, i in enumerate(keep):
+        assert int(r["status"][k]) == exp[i][0], cases[i][0].hex()
+        if exp[i][0] == 0:
+            assert int(r["out_len"][k]) == len(exp[i][1]) and b.output(k, len(exp[i][1])) == exp[i][1]
+    O.lib.refcpu_set_max_output(1 << 30)
+
+
+@pytest.mark.parametrize("case", S.lz4_frames(), ids=lambda c: c[0])
+def test_frames(case):
+    name, frame, d, did = case
+    st, out, cons = O.lz4(frame, d, -1 if did is None else did)
+    assert st == 0
+    assert swc.LZ4.decompress(frame, d, did) == out
+
+
+def test_multi_frame_and_error_taxonomy():
+    x = corpus.p_text(5000, 4)
+    f1, f2 = corpus.lz4f_frame(x[:700], 4, False, True), corpus.lz4f_frame(x[700:], 4, True, True)
+    skip = struct.pack("<II", 0x184D2A53, 5) + b"hello"
+    assert swc.LZ4.multi_decompress(f1 + skip + f2) == [x[:700], x[700:]]
+    assert swc.LZ4.decompress(f1 + f2) == x[:700]                       # only the first frame (LZ4.swift:41)
+    bad = bytearray(f1); bad[-1] ^= 1
+    with pytest.raises(swc.DataError) as ei:
+        swc.LZ4.decompress(bytes(bad))
+    assert ei.value.case == "checksumMismatch" and ei.value.data == x[:700]   # LZ4Tests.swift:186-203
+    for data, case in ((b"", "truncated"), (b"\x00", "truncated"), (bytes(1 << 16), "corrupted")):
+        with pytest.raises(swc.DataError) as ei:
+            swc.LZ4.decompress(data)
+        assert ei.value.case == case                                     # LZ4Tests.swift:87-108
+    rnd = random.Random(9)
+    for _ in range(16):                                                  # truncation fuzz, LZ4Tests.swift:205-214
+        cut = f2[:rnd.randrange(1, len(f2))]
+        st = O.lz4(cut)[0]
+        assert st != 0
+        with pytest.raises(swc.SWCError) as ei:
+            swc.LZ4.decompress(cut)
+        assert ei.value.status == st
+    for _ in range(16):                                                  # bit-flip fuzz: same status, same bytes
+        b2 = bytearray(f2); b2[rnd.randrange(7, len(b2))] ^= 1 << rnd.randrange(8)
+        st, out, _ = O.lz4(bytes(b2))
+        if st == 0:
+            assert swc.LZ4.decompress(bytes(b2)) == out
+        else:
+            with pytest.raises(swc.SWCError) as ei:
+                swc.LZ4.decompress(bytes(b2))
+            assert ei.value.status == st
+
+
+def test_dictionary_frames():
+    d = corpus.p_text(70000, 8)
+    blk = bytes([0x0F, 0x03, 0x00, 0x02, 0x80]) + b"stuvwxyz"
+    desc = bytes([0x60, 0x40])
+    frame = struct.pack("<I", 0x184D2204) + desc + bytes([(O.xxh32(desc) >> 8) & 0xFF]) + struct.pack("<I", len(blk)) + blk + struct.pack("<I", 0)
+    for dictionary in (b"abc", d, None):
+        st, out, _ = O.lz4(frame, dictionary)
+        if st == 0:
+            assert swc.LZ4.decompress(frame, dictionary) == out
+        else:
+            with pytest.raises(swc.SWCError) as ei:
+                swc.LZ4.decompress(frame, dictionary)
+            assert ei.value.status == st
+
+
+def test_many_64k_blocks_bit_exact():
+    units, plains = corpus.build_units("lz4_block", 2048, 65536, payload="mix")
+    b = DeviceBatch("lz4_block", units, [65536] * len(units))
+    b.launch(sync=True)
+    r = b.results()
+    assert (r["status"] == 0).all() and (r["out_len"] == 65536).all()
+    blob = b.d_out.cpu().numpy()
+    for i in range(len(units)):
+        o = int(b._out_off[i])
+        assert blob[o:o + 65536].tobytes() == plains[i]
