@@ -88,7 +88,8 @@ typedef enum swc_status {
     SWC_E_REF_TRAP = 900,
     SWC_E_CAPACITY = 901,
     SWC_E_DEVICE = 902,
-    SWC_E_INVALID_ARGUMENT = 903
+    SWC_E_INVALID_ARGUMENT = 903,
+    SWC_E_NEED_WORKSPACE = 904 /* batch API: the unit needs the HBM workspace of swc_batch_workspace_bytes(); single-shot calls retry internally */
 } swc_status;
 
 #ifdef __cplusplus

@@ -49,7 +49,7 @@ STATUS = {
     805: ("XZError", "checkTypeSHA256"), 806: ("XZError", "wrongDataSize"), 807: ("XZError", "wrongCheck"),
     808: ("XZError", "wrongPadding"), 809: ("XZError", "multiByteIntegerError"),
     900: ("ReferenceTrap", "trap"), 901: ("SWCError", "capacity"), 902: ("DeviceError", "device"),
-    903: ("SWCError", "invalidArgument"),
+    903: ("SWCError", "invalidArgument"), 904: ("SWCError", "needWorkspace"),
 }
 
 

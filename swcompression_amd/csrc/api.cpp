@@ -35,6 +35,8 @@ static hipError_t launch_codec(int codec, Job* jobs, size_t n, void* ws, size_t 
     switch (codec) {
         case SWC_CODEC_DEFLATE: return launch_inflate(jobs, n, stream);
         case SWC_CODEC_LZ4_BLOCK: return launch_lz4(jobs, n, stream);
+        case SWC_CODEC_LZMA2: return launch_lzma(true, jobs, n, ws_bytes >= n * lzma_spill_bytes_per_job() ? ws : nullptr, stream);
+        case SWC_CODEC_LZMA: return launch_lzma(false, jobs, n, ws_bytes >= n * lzma_spill_bytes_per_job() ? ws : nullptr, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -57,6 +59,7 @@ int run_units(int codec, std::vector<HostUnit>& units) {
     std::vector<size_t> cap(n);
     for (size_t i = 0; i < n; i++) cap[i] = default_cap(codec, units[i]);
 
+    bool want_ws = codec == SWC_CODEC_BZIP2_BLOCK;  // LZMA: only after a unit reported SWC_E_NEED_WORKSPACE
     for (int round = 0; round < 12 && !pending.empty(); round++) {
         const size_t m = pending.size();
         std::vector<size_t> in_off(m), out_off(m), dict_off(m);
@@ -70,7 +73,7 @@ int run_units(int codec, std::vector<HostUnit>& units) {
             out_off[k] = out_total;
             out_total += (cap[pending[k]] + 15) & ~(size_t)15;
         }
-        size_t ws_bytes = swc_batch_workspace_bytes(codec, m, *std::max_element(cap.begin(), cap.end()));
+        size_t ws_bytes = want_ws ? swc_batch_workspace_bytes(codec, m, *std::max_element(cap.begin(), cap.end())) : 0;
         DevBuf d_in(in_total + 16), d_out(out_total + 16), d_jobs(m * sizeof(Job)), d_ws(ws_bytes);
         if (!d_in.ok() || !d_out.ok() || !d_jobs.ok() || !d_ws.ok()) return SWC_E_DEVICE;
 
@@ -89,7 +92,7 @@ int run_units(int codec, std::vector<HostUnit>& units) {
             j.in_consumed = 0;
             j.status = SWC_E_DEVICE;
             j.aux = u.aux;
-            j.dict = u.dict ? d_in.u8() + dict_off[k] : nullptr;
+            j.dict = u.dict ? d_in.u8() + dict_off[k] : reinterpret_cast<const uint8_t*>((uintptr_t)u.dict_value);
             j.dict_len = u.dict ? u.dict_len : u.extra;
         }
         if (hipMemcpy(d_in.ptr(), stage.data(), in_total, hipMemcpyHostToDevice) != hipSuccess) return SWC_E_DEVICE;
@@ -104,6 +107,10 @@ int run_units(int codec, std::vector<HostUnit>& units) {
         for (size_t k = 0; k < m; k++) {
             HostUnit& u = units[pending[k]];
             const Job& j = jobs[k];
+            if (j.status == SWC_E_NEED_WORKSPACE && !want_ws) {
+                next.push_back(pending[k]);
+                continue;
+            }
             if (j.status == SWC_E_CAPACITY && !u.cap_exact && cap[pending[k]] < ((size_t)1 << 34)) {
                 size_t want = j.out_len > cap[pending[k]] ? (size_t)j.out_len : cap[pending[k]] * 4;
                 cap[pending[k]] = want;
@@ -115,6 +122,9 @@ int run_units(int codec, std::vector<HostUnit>& units) {
             size_t produced = (size_t)std::min<uint64_t>(j.out_len, j.out_cap);
             u.out.assign(out_stage.data() + out_off[k], out_stage.data() + out_off[k] + produced);
         }
+        if (!next.empty() && !want_ws)
+            for (size_t k = 0; k < m; k++)
+                if (jobs[k].status == SWC_E_NEED_WORKSPACE) { want_ws = true; break; }
         pending.swap(next);
     }
     for (size_t i : pending) units[i].status = SWC_E_CAPACITY;
@@ -139,8 +149,12 @@ const char* swc_version(void) { return "swc-hip 0.1 (gfx950)"; }
 void swc_free(void* p) { free(p); }
 
 size_t swc_batch_workspace_bytes(int codec, size_t n_jobs, uint64_t max_out_cap) {
-    (void)codec; (void)n_jobs; (void)max_out_cap;
-    return 0;
+    (void)max_out_cap;
+    switch (codec) {
+        case SWC_CODEC_LZMA:
+        case SWC_CODEC_LZMA2: return n_jobs * lzma_spill_bytes_per_job();  // optional: only streams with lc+lp > 4 use it
+        default: return 0;
+    }
 }
 
 int swc_batch_decompress_ws(int codec, swc_job* jobs, size_t n, void* workspace, size_t workspace_bytes,
@@ -157,7 +171,7 @@ int swc_batch_decompress_ws(int codec, swc_job* jobs, size_t n, void* workspace,
 }
 
 int swc_batch_decompress(int codec, swc_job* jobs, size_t n, const swc_batch_opts* opts) {
-    if (swc_batch_workspace_bytes(codec, n, 0) != 0) return SWC_E_INVALID_ARGUMENT;  // needs _ws
+    if (codec == SWC_CODEC_BZIP2_BLOCK) return SWC_E_INVALID_ARGUMENT;  // needs the workspace: use swc_batch_decompress_ws
     return swc_batch_decompress_ws(codec, jobs, n, nullptr, 0, opts);
 }
 

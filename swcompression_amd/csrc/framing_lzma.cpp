@@ -1,0 +1,394 @@
+// framing_lzma.cpp -- host side of LZMA / LZMA2 / XZ.
+//   LZMA.decompress(data:)  reference Sources/LZMA/LZMA.swift:25-34 (.lzma header) and :56-73 (raw + properties)
+//   LZMA2.decompress        reference Sources/LZMA2/LZMA2.swift:25-36
+//   XZArchive.unarchive / splitUnarchive / processStream / processIndex / processFooter / processPadding
+//                           reference Sources/XZ/XZArchive.swift:27-218
+//   XZBlock.init            reference Sources/XZ/XZBlock.swift:18-97
+//   XZStreamHeader.init     reference Sources/XZ/XZStreamHeader.swift:33-57
+//   multiByteDecode         reference Sources/XZ/LittleEndianByteReader+XZ.swift:10-30
+//   DeltaFilter.decode      reference Sources/Common/DeltaFilter.swift:11-33
+// Headers, index, footer, padding and checks are verified on the host; every LZMA2 block body is a
+// unit of the batched device launch.
+#include <vector>
+#include "framing.h"
+
+namespace swc {
+namespace {
+
+// A cursor with LittleEndianByteReader's contract: reads past the end latch `trap`.
+struct Reader {
+    const uint8_t* d;
+    size_t n;
+    int64_t off;
+    bool trap;
+    int64_t left() const { return (int64_t)n - off; }
+    bool finished() const { return off >= (int64_t)n; }
+    uint8_t u8() {
+        if (off < 0 || off >= (int64_t)n) { trap = true; return 0; }
+        return d[off++];
+    }
+    uint64_t le(int k) {
+        if (off < 0 || left() < k) { trap = true; off = (int64_t)n; return 0; }
+        uint64_t v = 0;
+        for (int i = 0; i < k; i++) v |= (uint64_t)d[off + i] << (8 * i);
+        off += k;
+        return v;
+    }
+};
+
+int multibyte(Reader& r, int64_t& v) {  // LittleEndianByteReader+XZ.swift:10-30
+    int i = 1;
+    int64_t result = r.u8();
+    if (r.trap) return SWC_E_REF_TRAP;
+    if (result <= 127) { v = result; return SWC_OK; }
+    result &= 0x7F;
+    for (;;) {
+        const uint32_t b = r.u8();
+        if (r.trap) return SWC_E_REF_TRAP;
+        if (i >= 9 || b == 0) return SWC_E_XZ_MULTI_BYTE_INTEGER_ERROR;
+        result += (int64_t)(b & 0x7F) << (7 * i);
+        i++;
+        if (!(b & 0x80)) break;
+    }
+    v = result;
+    return SWC_OK;
+}
+
+// Sum of the unpacked sizes announced by the chunk headers (LZMA2Decoder.swift:56-61,84-86) -- an exact
+// output capacity for well-formed streams, a hint otherwise.
+size_t lzma2_announced_size(const uint8_t* p, size_t n) {
+    size_t off = 0, total = 0;
+    while (off < n) {
+        const uint32_t c = p[off];
+        if (c == 0) break;
+        if (c == 1 || c == 2) {
+            if (n - off < 3) break;
+            const size_t sz = ((size_t)p[off + 1] << 8) + p[off + 2] + 1;
+            total += sz;
+            off += 3 + sz;
+        } else if (c >= 0x80) {
+            if (n - off < 5) break;
+            total += ((size_t)(c & 0x1F) << 16) + ((size_t)p[off + 1] << 8) + p[off + 2] + 1;
+            const size_t comp = ((size_t)p[off + 3] << 8) + p[off + 4] + 1;
+            off += 5 + (((c >> 5) & 3) >= 2 ? 1 : 0) + comp;
+        } else {
+            break;
+        }
+        if (total > ((size_t)1 << 34)) break;
+    }
+    return total;
+}
+
+int run_lzma_unit(int codec, HostUnit& u) {
+    int st = run_one(codec, u);
+    if (st) return st;
+    return SWC_OK;
+}
+
+void delta_decode(const std::vector<uint8_t>& in, int distance, std::vector<uint8_t>& out) {  // DeltaFilter.swift:11-33
+    uint8_t delta[256] = {0};
+    int pos = 0;
+    out.resize(in.size());
+    for (size_t i = 0; i < in.size(); i++) {
+        uint8_t tmp = delta[(distance + pos) % 256];
+        tmp = (uint8_t)(in[i] + tmp);
+        delta[pos] = tmp;
+        out[i] = tmp;
+        pos = pos == 0 ? 255 : pos - 1;
+    }
+}
+
+struct Filter { int id; int prop; };
+
+// XZBlock.init (XZBlock.swift:18-97).  Appends the block's data to `out`.
+int xz_block(uint32_t header_size_byte, Reader& r, int check_size, std::vector<uint8_t>& out, int64_t& unpadded_size,
+             int64_t& uncomp_size) {
+    int st;
+    const int64_t header_start = r.off - 1;
+    const int64_t real_header_size = ((int64_t)header_size_byte + 1) * 4;
+    const uint32_t flags = r.u8();
+    if (r.trap) return SWC_E_REF_TRAP;
+    const int filters_count = (int)(flags & 0x03) + 1;
+    if (flags & 0x3C) return SWC_E_XZ_WRONG_FIELD;                                // :27
+    int64_t compressed_size = -1, uncompressed_size = -1;
+    if (flags & 0x40) { if ((st = multibyte(r, compressed_size))) return st; }
+    if (flags & 0x80) { if ((st = multibyte(r, uncompressed_size))) return st; }
+    Filter filters[4];
+    for (int i = 0; i < filters_count; i++) {
+        int64_t id, ps;
+        if ((st = multibyte(r, id))) return st;
+        if ((uint64_t)id >= 0x4000000000000000ull) return SWC_E_XZ_WRONG_FILTER_ID;
+        if (id == 0x21) {
+            if ((st = multibyte(r, ps))) return st;
+            if (ps != 1) return SWC_E_LZMA2_WRONG_DICTIONARY_SIZE;                // :47
+            filters[i] = {0x21, r.u8()};
+        } else if (id == 0x03) {
+            if ((st = multibyte(r, ps))) return st;
+            if (ps != 1) return SWC_E_XZ_WRONG_FIELD;                             // :55
+            filters[i] = {0x03, (int)(uint8_t)(r.u8() + 1)};
+        } else {
+            return SWC_E_XZ_WRONG_FILTER_ID;
+        }
+        if (r.trap) return SWC_E_REF_TRAP;
+    }
+    while (r.off - header_start < real_header_size - 4) {                         // :64-68
+        const uint8_t b = r.u8();
+        if (r.trap) return SWC_E_REF_TRAP;
+        if (b != 0) return SWC_E_XZ_WRONG_PADDING;
+    }
+    const uint32_t hcrc = (uint32_t)r.le(4);
+    if (r.trap) return SWC_E_REF_TRAP;
+    if (header_start < 0 || header_start + real_header_size - 4 > (int64_t)r.n) return SWC_E_REF_TRAP;
+    if (swc_crc32(r.d + header_start, (size_t)(real_header_size - 4), 0) != hcrc) return SWC_E_XZ_WRONG_INFO_CRC;
+    r.off = header_start + real_header_size;
+
+    const int64_t data_start = r.off;
+    // :78 filters.reversed().reduce(byteReader): the last filter reads the archive, earlier ones its output
+    std::vector<uint8_t> cur;
+    bool have_cur = false;
+    for (int i = filters_count - 1; i >= 0; i--) {
+        std::vector<uint8_t> next;
+        if (filters[i].id == 0x21) {
+            HostUnit u;
+            u.in = have_cur ? cur.data() : r.d + r.off;
+            u.in_len = have_cur ? cur.size() : (size_t)(r.n - r.off);
+            u.aux = filters[i].prop;
+            u.cap_hint = lzma2_announced_size(u.in, u.in_len);
+            if (u.cap_hint == 0) u.cap_hint = 16;
+            if ((st = run_lzma_unit(SWC_CODEC_LZMA2, u))) return st;
+            if (!have_cur) r.off += (int64_t)u.in_consumed;
+            if (u.status) return u.status;
+            next = std::move(u.out);
+        } else {
+            std::vector<uint8_t> src;
+            if (have_cur) src = std::move(cur);
+            else { src.assign(r.d + r.off, r.d + r.n); r.off = (int64_t)r.n; }   // Delta reads until its reader is finished
+            delta_decode(src, filters[i].prop, next);
+        }
+        cur = std::move(next);
+        have_cur = true;
+    }
+    if (!((compressed_size < 0 || compressed_size == r.off - data_start) &&
+          (uncompressed_size < 0 || uncompressed_size == (int64_t)cur.size()))) return SWC_E_XZ_WRONG_DATA_SIZE;  // :80-82
+    const int64_t unpadded = r.off - header_start;
+    if (unpadded % 4 != 0) {
+        for (int k = (int)(4 - unpadded % 4); k > 0; k--) {
+            const uint8_t b = r.u8();
+            if (r.trap) return SWC_E_REF_TRAP;
+            if (b != 0) return SWC_E_XZ_WRONG_PADDING;
+        }
+    }
+    out.insert(out.end(), cur.begin(), cur.end());
+    unpadded_size = unpadded + check_size;
+    uncomp_size = (int64_t)cur.size();
+    return SWC_OK;
+}
+
+// processStream (XZArchive.swift:90-130)
+int xz_stream(Reader& r, std::vector<uint8_t>& out, bool& check_error) {
+    static const uint8_t magic[6] = {0xFD, 0x37, 0x7A, 0x58, 0x5A, 0x00};
+    check_error = false;
+    if (r.left() < 12) return SWC_E_REF_TRAP;
+    if (memcmp(r.d + r.off, magic, 6) != 0) return SWC_E_XZ_WRONG_MAGIC;         // XZStreamHeader.swift:35
+    r.off += 6;
+    const uint8_t f0 = r.u8(), f1 = r.u8();
+    const uint32_t fcrc = (uint32_t)r.le(4);
+    const uint8_t fb[2] = {f0, f1};
+    if (swc_crc32(fb, 2, 0) != fcrc) return SWC_E_XZ_WRONG_INFO_CRC;
+    if (!(f0 == 0 && (f1 & 0xF0) == 0)) return SWC_E_XZ_WRONG_FIELD;
+    const int check_type = f1 & 0x0F;
+    int check_size;
+    switch (check_type) {
+        case 0x00: check_size = 0; break;
+        case 0x01: check_size = 4; break;
+        case 0x04: check_size = 8; break;
+        case 0x0A: check_size = 32; break;
+        default: return SWC_E_XZ_WRONG_FIELD;
+    }
+    std::vector<std::pair<int64_t, int64_t>> infos;
+    int64_t index_size = -1;
+    int st;
+    for (;;) {
+        const uint32_t hs = r.u8();
+        if (r.trap) return SWC_E_REF_TRAP;
+        if (hs == 0) {                                                            // processIndex :132-167
+            const int64_t index_start = r.off - 1;
+            int64_t records;
+            if ((st = multibyte(r, records))) return st;
+            if (records != (int64_t)infos.size()) return SWC_E_XZ_WRONG_FIELD;
+            for (auto& bi : infos) {
+                int64_t a, b;
+                if ((st = multibyte(r, a))) return st;
+                if (a != bi.first) return SWC_E_XZ_WRONG_FIELD;
+                if ((st = multibyte(r, b))) return st;
+                if (b != bi.second) return SWC_E_XZ_WRONG_DATA_SIZE;
+            }
+            index_size = r.off - index_start;
+            if (index_size % 4 != 0) {
+                for (int k = (int)(4 - index_size % 4); k > 0; k--) {
+                    const uint8_t b = r.u8();
+                    if (r.trap) return SWC_E_REF_TRAP;
+                    if (b != 0) return SWC_E_XZ_WRONG_PADDING;
+                    index_size++;
+                }
+            }
+            const uint32_t icrc = (uint32_t)r.le(4);
+            if (r.trap) return SWC_E_REF_TRAP;
+            if (swc_crc32(r.d + index_start, (size_t)index_size, 0) != icrc) return SWC_E_XZ_WRONG_INFO_CRC;
+            index_size += 4;
+            break;
+        }
+        int64_t unpadded, uncomp;
+        const size_t bstart = out.size();
+        if ((st = xz_block(hs, r, check_size, out, unpadded, uncomp))) return st;
+        const uint8_t* bd = out.data() + bstart;
+        const size_t bl = out.size() - bstart;
+        if (check_type == 0x01) {
+            const uint32_t c = (uint32_t)r.le(4);
+            if (r.trap) return SWC_E_REF_TRAP;
+            if (swc_crc32(bd, bl, 0) != c) { check_error = true; return SWC_OK; }
+        } else if (check_type == 0x04) {
+            const uint64_t c = r.le(8);
+            if (r.trap) return SWC_E_REF_TRAP;
+            if (swc_crc64(bd, bl) != c) { check_error = true; return SWC_OK; }
+        } else if (check_type == 0x0A) {
+            if (r.left() < 32) return SWC_E_REF_TRAP;
+            uint8_t dg[32];
+            swc_sha256(bd, bl, dg);
+            const bool ok = memcmp(dg, r.d + r.off, 32) == 0;
+            r.off += 32;
+            if (!ok) { check_error = true; return SWC_OK; }
+        }
+        infos.emplace_back(unpadded, uncomp);
+    }
+    // processFooter :169-192
+    const uint32_t footer_crc = (uint32_t)r.le(4);
+    const int64_t backward = ((int64_t)r.le(4) + 1) * 4;
+    const uint32_t fflags = (uint32_t)r.le(2);
+    if (r.trap) return SWC_E_REF_TRAP;
+    if (swc_crc32(r.d + r.off - 6, 6, 0) != footer_crc) return SWC_E_XZ_WRONG_INFO_CRC;
+    if (backward != index_size) return SWC_E_XZ_WRONG_FIELD;
+    if (!((fflags & 0xFF) == 0 && ((fflags & 0xF00) >> 8) == (uint32_t)check_type && (fflags & 0xF000) == 0)) return SWC_E_XZ_WRONG_FIELD;
+    if (r.left() < 2) return SWC_E_REF_TRAP;
+    if (!(r.d[r.off] == 0x59 && r.d[r.off + 1] == 0x5A)) return SWC_E_XZ_WRONG_MAGIC;
+    r.off += 2;
+    return SWC_OK;
+}
+
+int xz_padding(Reader& r) {                                                       // processPadding :194-218
+    if (r.finished()) return SWC_OK;
+    int64_t padding = 0;
+    for (;;) {
+        const uint8_t b = r.u8();
+        if (r.trap) return SWC_E_REF_TRAP;
+        if (b != 0) {
+            if (padding % 4 != 0) return SWC_E_XZ_WRONG_PADDING;
+            break;
+        }
+        if (r.finished()) {
+            if (b != 0 || padding % 4 != 3) return SWC_E_XZ_WRONG_PADDING;
+            return SWC_OK;
+        }
+        padding++;
+    }
+    r.off -= 1;
+    return SWC_OK;
+}
+
+int xz_run(const uint8_t* in, size_t in_len, std::vector<uint8_t>& all, std::vector<size_t>& sizes) {
+    Reader r{in, in_len, 0, false};
+    while (!r.finished()) {
+        if (r.left() < 32) { all.clear(); sizes.clear(); return SWC_E_XZ_WRONG_MAGIC; }  // :37
+        bool check_error;
+        const size_t start = all.size();
+        int st = xz_stream(r, all, check_error);
+        if (st) { all.clear(); sizes.clear(); return st; }
+        sizes.push_back(all.size() - start);
+        if (check_error) return SWC_E_XZ_WRONG_CHECK;                             // :44 carries the result so far
+        st = xz_padding(r);
+        if (st) { all.clear(); sizes.clear(); return st; }
+    }
+    return SWC_OK;
+}
+
+}  // namespace
+}  // namespace swc
+
+using namespace swc;
+
+extern "C" {
+
+int swc_lzma_decompress(const uint8_t* in, size_t in_len, int lc, int lp, int pb, int64_t dict_size,
+                        int64_t uncompressed_size, uint8_t** out, size_t* out_len, size_t* in_consumed) {
+    if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
+    HostUnit u;
+    u.in = in; u.in_len = in_len;
+    if (lc < 0 || lc > 255 || lp < 0 || lp > 255 || pb < 0 || pb > 255 || dict_size < 0) { give_empty(out, out_len); return SWC_E_REF_TRAP; }
+    u.aux = lc | (lp << 8) | (pb << 16);
+    u.extra = uncompressed_size < 0 ? ~0ull : (uint64_t)uncompressed_size;
+    u.dict_value = (uint64_t)dict_size;
+    if (uncompressed_size >= 0) u.cap_hint = (size_t)uncompressed_size + 16;      // +16: a stream may overrun its declared size before the error is detected
+    int st = run_one(SWC_CODEC_LZMA, u);
+    if (st) { give_empty(out, out_len); return st; }
+    if (in_consumed) *in_consumed = u.in_consumed;
+    if (u.status) { give_empty(out, out_len); return u.status; }                  // LZMAError cases carry no data
+    give(u.out, out, out_len);
+    return SWC_OK;
+}
+
+int swc_lzma_alone_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) {
+    if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
+    if (in_len < 13) { give_empty(out, out_len); return SWC_E_LZMA_WRONG_PROPERTIES; }   // LZMA.swift:27
+    const uint32_t b = in[0];
+    if (b >= 225) { give_empty(out, out_len); return SWC_E_LZMA_WRONG_PROPERTIES; }      // LZMAProperties.swift:51
+    const int lc = b % 9, pb = (b / 9) / 5, lp = (b / 9) % 5;
+    const int64_t dict = (int64_t)((uint32_t)in[1] | (uint32_t)in[2] << 8 | (uint32_t)in[3] << 16 | (uint32_t)in[4] << 24);
+    uint64_t us = 0;
+    for (int i = 0; i < 8; i++) us |= (uint64_t)in[5 + i] << (8 * i);
+    size_t consumed;
+    return swc_lzma_decompress(in + 13, in_len - 13, lc, lp, pb, dict, (int64_t)us, out, out_len, &consumed);
+}
+
+int swc_lzma2_decompress(const uint8_t* in, size_t in_len, uint8_t dict_byte, uint8_t** out, size_t* out_len, size_t* in_consumed) {
+    if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
+    HostUnit u;
+    u.in = in; u.in_len = in_len;
+    u.aux = dict_byte;
+    u.cap_hint = lzma2_announced_size(in, in_len);
+    if (u.cap_hint == 0) u.cap_hint = 16;
+    int st = run_one(SWC_CODEC_LZMA2, u);
+    if (st) { give_empty(out, out_len); return st; }
+    if (in_consumed) *in_consumed = u.in_consumed;
+    if (u.status) { give_empty(out, out_len); return u.status; }
+    give(u.out, out, out_len);
+    return SWC_OK;
+}
+
+int swc_lzma2_decompress_data(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) {
+    if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
+    if (in_len < 1) { give_empty(out, out_len); return SWC_E_LZMA_RANGE_DECODER_INIT_ERROR; }  // LZMA2.swift:27
+    size_t consumed;
+    return swc_lzma2_decompress(in + 1, in_len - 1, in[0], out, out_len, &consumed);
+}
+
+int swc_xz_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) {
+    if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
+    std::vector<uint8_t> all;
+    std::vector<size_t> sizes;
+    int st = xz_run(in, in_len, all, sizes);
+    give(all, out, out_len);
+    return st;
+}
+
+int swc_xz_split_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_streams) {
+    if (!out || !out_len || !sizes || !n_streams || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
+    std::vector<uint8_t> all;
+    std::vector<size_t> sz;
+    int st = xz_run(in, in_len, all, sz);
+    give(all, out, out_len);
+    *sizes = give_sizes(sz);
+    *n_streams = sz.size();
+    return st;
+}
+
+}  // extern "C"

@@ -55,6 +55,7 @@ struct HostUnit {
     const uint8_t* dict = nullptr;
     size_t dict_len = 0;
     uint64_t extra = 0;          // codec specific (goes to Job::dict_len when dict == nullptr)
+    uint64_t dict_value = 0;     // codec specific integer carried in Job::dict when dict == nullptr (LZMA: dictionary size)
     // results
     std::vector<uint8_t> out;
     size_t in_consumed = 0;

@@ -11,6 +11,7 @@
 #include "swc_common.h"
 #include "inflate_lane.h"
 #include "lz4_lane.h"
+#include "lzma_wave.h"
 #include "launch.h"
 
 namespace swc {
@@ -68,6 +69,36 @@ hipError_t launch_lz4(Job* jobs, size_t n, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     dim3 grid((unsigned)((n + kWave - 1) / kWave)), block(kWave);
     hipLaunchKernelGGL(swc_lz4_lane_kernel, grid, block, 0, stream, jobs, (uint32_t)n);
+    return hipGetLastError();
+}
+
+// ---- LZMA / LZMA2, one stream per wavefront ---------------------------------------------------------
+// LDS: 28,272 B of u16 probability cells per wave -> 5 streams per CU.  `spill` (may be null) holds
+// kLzmaSpillBytes per job for streams with lc+lp > 4.
+constexpr size_t kLzmaSpillBytes = (size_t)(0x300u << 12) * 2;
+
+template <bool LZMA2>
+__global__ __launch_bounds__(64) void swc_lzma_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* spill) {
+    extern __shared__ __attribute__((aligned(16))) uint16_t lzma_lds[];
+    uint32_t g = blockIdx.x;
+    if (g >= n) return;
+    Job job = jobs[g];
+    SWC_AS_GLOBAL uint16_t* sp = spill ? (SWC_AS_GLOBAL uint16_t*)(spill + (size_t)g * kLzmaSpillBytes) : nullptr;
+    lzma::lzma_job<kWave>(job, LZMA2, lzma_lds, sp, (int)threadIdx.x);
+    if (threadIdx.x == 0) {
+        jobs[g].out_len = job.out_len;
+        jobs[g].in_consumed = job.in_consumed;
+        jobs[g].status = job.status;
+    }
+}
+
+size_t lzma_spill_bytes_per_job() { return kLzmaSpillBytes; }
+
+hipError_t launch_lzma(bool lzma2, Job* jobs, size_t n, void* spill, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    dim3 grid((unsigned)n), block(kWave);
+    if (lzma2) hipLaunchKernelGGL(swc_lzma_kernel<true>, grid, block, lzma::kLdsBytesPerWave, stream, jobs, (uint32_t)n, (uint8_t*)spill);
+    else hipLaunchKernelGGL(swc_lzma_kernel<false>, grid, block, lzma::kLdsBytesPerWave, stream, jobs, (uint32_t)n, (uint8_t*)spill);
     return hipGetLastError();
 }
 

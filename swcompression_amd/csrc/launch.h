@@ -6,6 +6,8 @@
 namespace swc {
 hipError_t launch_inflate(Job* jobs, size_t n, hipStream_t stream);
 hipError_t launch_lz4(Job* jobs, size_t n, hipStream_t stream);
+hipError_t launch_lzma(bool lzma2, Job* jobs, size_t n, void* spill, hipStream_t stream);
+size_t lzma_spill_bytes_per_job();
 void set_inflate_group(int g);
 void set_inflate_debug(int m);
 }

@@ -1,0 +1,425 @@
+// lzma_wave.h -- LZMA / LZMA2 decode, one stream per WAVEFRONT.
+//
+// Replaces LZMADecoder.decode() (reference Sources/LZMA/LZMADecoder.swift:107-284) with its range
+// decoder (LZMARangeDecoder.swift:20-80), bit-tree / length decoders (LZMABitTreeDecoder.swift:18-43,
+// LZMALenDecoder.swift:30-38) and the LZMA2 chunk framing (Sources/LZMA2/LZMA2Decoder.swift:34-99).
+//
+// The range coder is a strictly serial chain, so a stream cannot be split; the adaptive probability
+// model (up to 14,135 11-bit cells for lc+lp <= 4) is far too large to keep per LANE, so one wavefront
+// owns one stream: the model lives in the wave's LDS slice as u16 cells (28.3 KiB => 5 streams per CU),
+// all 64 lanes execute the decode chain redundantly (wave-uniform control flow, LDS broadcasts), and
+// the LZ copy of every match is spread over the lanes.  Streams with lc+lp > 4 (legal for .lzma, never
+// produced by xz) spill the literal coder to an HBM workspace.
+//
+// The same source is compiled for the host with WAVE = 1 (tests/host_emu) to check the serial logic
+// against the oracle without a GPU; the wave-parallel copy is the only part that differs.
+#ifndef SWC_LZMA_WAVE_H
+#define SWC_LZMA_WAVE_H
+
+#include "swc_common.h"
+
+namespace swc {
+namespace lzma {
+
+// probability model layout (u16 cells).  The reference keeps `probabilities[432]` with its own index
+// arithmetic (LZMADecoder.swift:50-62); only cell independence matters, except that index 432 does
+// not exist there (state 11, posState 15 => Swift trap) -- reproduced below.
+constexpr int P_IS_MATCH = 0;        // [12 << 4]
+constexpr int P_IS_REP = 192;        // [12]
+constexpr int P_IS_REP_G0 = 204;     // [12]
+constexpr int P_IS_REP_G1 = 216;     // [12]
+constexpr int P_IS_REP_G2 = 228;     // [12]
+constexpr int P_IS_REP0_LONG = 240;  // [12 << 4]
+constexpr int P_POS_SLOT = 432;      // [4][64]
+constexpr int P_ALIGN = 688;         // [16]
+constexpr int P_POS_DEC = 704;       // [115]  (reference: 1 + 128 - 14 cells, LZMADecoder.swift:96-97)
+constexpr int P_LEN = 819;           // choice, choice2, low[16][8], mid[16][8], high[256] = 514
+constexpr int P_REP_LEN = 1333;
+constexpr int P_LITERAL = 1847;      // [0x300 << (lc+lp)]
+constexpr int kMaxLdsLitBits = 4;
+constexpr int kProbCells = P_LITERAL + (0x300 << kMaxLdsLitBits);  // 14,135
+constexpr int kLdsBytesPerWave = ((kProbCells * 2 + 15) / 16) * 16;  // 28,272 B
+constexpr int LEN_CHOICE = 0, LEN_CHOICE2 = 1, LEN_LOW = 2, LEN_MID = 2 + 128, LEN_HIGH = 2 + 256;
+
+template <int WAVE>
+struct Decoder {
+    // ---- I/O -----------------------------------------------------------------------------------
+    gcptr in;
+    uint64_t n;        // input bytes
+    uint64_t ip;       // next input byte
+    gptr out;
+    uint64_t cap;
+    uint64_t pos;      // bytes produced == dictEnd == out.count of the reference
+    int lane;
+    // ---- model -----------------------------------------------------------------------------------
+    uint16_t* probs;            // LDS (host: heap) -- kProbCells cells
+    SWC_AS_GLOBAL uint16_t* lit_spill;  // HBM literal coder when lc+lp > 4, else unused
+    bool have_model;
+    int lc, lp, pb;
+    uint64_t dict_size;
+    int64_t uncompressed_size;  // < 0: unknown
+    uint64_t dict_start;
+    uint32_t range, code;
+    uint64_t rep0, rep1, rep2, rep3;
+    int state;
+    bool trap;                  // the reference would trap (reader past the end, index out of range)
+    bool overflow;              // out_cap exhausted: LZMA needs the bytes it wrote, so decoding stops
+    bool need_ws;               // lc+lp > 4 but no HBM workspace was supplied
+
+    SWC_HD uint8_t next_byte() {  // LittleEndianByteReader.byte(): past the end is a trap (App. A L4)
+        if (ip >= n) { trap = true; return 0; }
+        return in[ip++];
+    }
+    SWC_HD void normalize() {     // LZMARangeDecoder.swift:38-43
+        if (range < (1u << 24)) {
+            range <<= 8;
+            code = (code << 8) | next_byte();
+        }
+    }
+    SWC_HD int bit(uint16_t* p) {  // LZMARangeDecoder.swift:65-80
+        uint32_t pr = *p;
+        uint32_t bound = (range >> 11) * pr;
+        int sym;
+        if (code < bound) {
+            *p = (uint16_t)(pr + ((2048u - pr) >> 5));
+            range = bound;
+            sym = 0;
+        } else {
+            *p = (uint16_t)(pr - (pr >> 5));
+            code -= bound;
+            range -= bound;
+            sym = 1;
+        }
+        normalize();
+        return sym;
+    }
+    SWC_HD int bit_spill(SWC_AS_GLOBAL uint16_t* p) {
+        uint32_t pr = *p;
+        uint32_t bound = (range >> 11) * pr;
+        int sym;
+        if (code < bound) {
+            if (lane == 0) *p = (uint16_t)(pr + ((2048u - pr) >> 5));
+            range = bound;
+            sym = 0;
+        } else {
+            if (lane == 0) *p = (uint16_t)(pr - (pr >> 5));
+            code -= bound;
+            range -= bound;
+            sym = 1;
+        }
+        normalize();
+        return sym;
+    }
+    SWC_HD uint32_t direct_bits(int count) {  // LZMARangeDecoder.swift:46-62
+        uint32_t res = 0;
+        do {
+            range >>= 1;
+            code -= range;
+            uint32_t t = 0u - (code >> 31);
+            code += range & t;
+            normalize();
+            res = (res << 1) + (t + 1);
+            count--;
+        } while (count > 0);
+        return res;
+    }
+    SWC_HD int tree(uint16_t* p, int nbits) {  // LZMABitTreeDecoder.swift:18-24
+        int m = 1;
+        for (int i = 0; i < nbits; i++) m = (m << 1) + bit(&p[m]);
+        return m - (1 << nbits);
+    }
+    SWC_HD int tree_reverse(uint16_t* p, int limit, int start, int bits) {  // :26-43
+        int m = 1, sym = 0;
+        for (int i = 0; i < bits; i++) {
+            int idx = start + m;
+            if (idx < 0 || idx >= limit) { trap = true; return 0; }
+            int b = bit(&p[idx]);
+            m = (m << 1) + b;
+            sym |= b << i;
+        }
+        return sym;
+    }
+    SWC_HD int len_decode(uint16_t* p, int pos_state) {  // LZMALenDecoder.swift:30-38
+        if (bit(&p[LEN_CHOICE]) == 0) return tree(&p[LEN_LOW + pos_state * 8], 3);
+        if (bit(&p[LEN_CHOICE2]) == 0) return 8 + tree(&p[LEN_MID + pos_state * 8], 3);
+        return 16 + tree(&p[LEN_HIGH], 8);
+    }
+
+    // LZMADecoder.swift:79-100.  All lanes initialise a slice of the model.
+    SWC_HD void reset_state_and_decoders() {
+        state = 0;
+        rep0 = rep1 = rep2 = rep3 = 0;
+        need_ws = false;
+        const int lit_bits = lc + lp;
+        const int lds_cells = P_LITERAL + (lit_bits <= kMaxLdsLitBits ? (0x300 << lit_bits) : 0);
+        for (int i = lane; i < lds_cells; i += WAVE) probs[i] = 1024;
+        if (lit_bits > kMaxLdsLitBits) {
+            const uint32_t cells = 0x300u << lit_bits;
+            if (lit_spill) for (uint32_t i = (uint32_t)lane; i < cells; i += WAVE) lit_spill[i] = 1024;
+            else need_ws = true;
+        }
+        have_model = true;
+    }
+    SWC_HD void reset_dictionary() { dict_start = pos; }  // LZMADecoder.swift:102-104
+
+    // put(): LZMADecoder.swift:288-294.  One byte, written by lane 0.
+    SWC_HD void put(uint8_t b) {
+        if (pos < cap) { if (lane == 0) out[pos] = b; }
+        else overflow = true;
+        pos++;
+        if (pos - dict_start == dict_size) dict_start++;
+    }
+    // byte(at:): LZMADecoder.swift:296-298 -- out[distance <= dictEnd ? dictEnd - distance : dictSize - distance + dictEnd]
+    SWC_HD uint8_t byte_at(uint64_t distance) {
+        uint64_t idx;
+        if (distance <= pos) idx = pos - distance;
+        else { trap = true; return 0; }  // the wrap branch indexes at or past out.count (dictSize >= distance): Swift trap
+        if (idx >= cap) { overflow = true; return 0; }
+        return out[idx];
+    }
+    // `len` bytes from `distance` back, spread over the wave (LZMADecoder.swift:278-282).
+    SWC_HD void copy_match(uint64_t distance, uint32_t len) {
+        if (pos + len <= cap) {
+            gptr dst = out + pos;
+            if (distance >= len) {
+                for (uint32_t i = (uint32_t)lane; i < len; i += WAVE) dst[i] = dst[(int64_t)i - (int64_t)distance];
+            } else {
+                // overlapping: every byte is a copy of one of the `distance` bytes before `pos`
+                for (uint32_t i = (uint32_t)lane; i < len; i += WAVE) dst[i] = dst[(int64_t)(i % (uint32_t)distance) - (int64_t)distance];
+            }
+        } else {
+            overflow = true;
+        }
+        pos += len;
+        uint64_t span = pos - dict_start;
+        if (span >= dict_size && dict_size > 0) dict_start = pos - dict_size + 1;  // `len` put()s worth of window sliding
+    }
+
+    // LZMADecoder.swift:107-284.  Returns an swc_status.
+    SWC_HD int decode() {
+        if (n - ip < 5) return SWC_E_LZMA_RANGE_DECODER_INIT_ERROR;  // LZMARangeDecoder.swift:21
+        const uint8_t first = next_byte();
+        code = 0;
+        for (int i = 0; i < 4; i++) code = (code << 8) | next_byte();  // uint32().byteSwapped
+        range = 0xFFFFFFFFu;
+        if (first != 0) return SWC_E_LZMA_RANGE_DECODER_INIT_ERROR;
+        if (!have_model) return SWC_E_REF_TRAP;  // `probabilities` is still empty: index trap at :119
+        if (need_ws) return SWC_E_NEED_WORKSPACE;
+        const int lit_bits = lc + lp;
+        const bool spill = lit_bits > kMaxLdsLitBits;
+
+        for (;;) {
+            if (trap) return SWC_E_REF_TRAP;
+            if (overflow) return SWC_E_CAPACITY;
+            if (uncompressed_size == 0 && code == 0) break;  // :114
+            const int pos_state = (int)(pos & ((1u << pb) - 1));
+            if (bit(&probs[P_IS_MATCH + (state << 4) + pos_state]) == 0) {
+                if (trap) return SWC_E_REF_TRAP;
+                if (uncompressed_size == 0) return SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :121
+                const uint32_t prev = pos == dict_start ? 0u : byte_at(1);
+                const uint32_t lit_state = (uint32_t)(((pos & ((1u << lp) - 1)) << lc) + (prev >> (8 - lc)));
+                int symbol = 1;
+                if (!spill) {
+                    uint16_t* lpb = &probs[P_LITERAL + lit_state * 0x300];
+                    if (state >= 7) {
+                        uint32_t match_byte = byte_at(rep0 + 1);
+                        if (trap) return SWC_E_REF_TRAP;
+                        do {
+                            const int match_bit = (match_byte >> 7) & 1;
+                            match_byte = (match_byte << 1) & 0xFF;
+                            const int b = bit(&lpb[((1 + match_bit) << 8) + symbol]);
+                            symbol = (symbol << 1) | b;
+                            if (match_bit != b) break;
+                        } while (symbol < 0x100);
+                    }
+                    while (symbol < 0x100) symbol = (symbol << 1) | bit(&lpb[symbol]);
+                } else {
+                    SWC_AS_GLOBAL uint16_t* lpb = lit_spill + (size_t)lit_state * 0x300;
+                    if (state >= 7) {
+                        uint32_t match_byte = byte_at(rep0 + 1);
+                        if (trap) return SWC_E_REF_TRAP;
+                        do {
+                            const int match_bit = (match_byte >> 7) & 1;
+                            match_byte = (match_byte << 1) & 0xFF;
+                            const int b = bit_spill(&lpb[((1 + match_bit) << 8) + symbol]);
+                            symbol = (symbol << 1) | b;
+                            if (match_bit != b) break;
+                        } while (symbol < 0x100);
+                    }
+                    while (symbol < 0x100) symbol = (symbol << 1) | bit_spill(&lpb[symbol]);
+                }
+                if (trap) return SWC_E_REF_TRAP;
+                uncompressed_size -= 1;
+                put((uint8_t)(symbol - 0x100));
+                state = state < 4 ? 0 : state < 10 ? state - 3 : state - 6;
+                continue;
+            }
+            if (trap) return SWC_E_REF_TRAP;
+
+            uint32_t len;
+            if (bit(&probs[P_IS_REP + state]) != 0) {
+                if (trap) return SWC_E_REF_TRAP;
+                if (uncompressed_size == 0) return SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :178
+                if (pos == dict_start) return SWC_E_LZMA_WINDOW_IS_EMPTY;                  // :181
+                if (bit(&probs[P_IS_REP_G0 + state]) == 0) {
+                    if ((state << 4) + pos_state >= 191) return SWC_E_REF_TRAP;            // reference index 241+... == 432
+                    if (bit(&probs[P_IS_REP0_LONG + (state << 4) + pos_state]) == 0) {
+                        if (trap) return SWC_E_REF_TRAP;
+                        state = state < 7 ? 9 : 11;
+                        const uint8_t b = byte_at(rep0 + 1);
+                        if (trap) return SWC_E_REF_TRAP;
+                        put(b);
+                        uncompressed_size -= 1;
+                        continue;
+                    }
+                } else {
+                    uint64_t dist;
+                    if (bit(&probs[P_IS_REP_G1 + state]) == 0) {
+                        dist = rep1;
+                    } else {
+                        if (bit(&probs[P_IS_REP_G2 + state]) == 0) {
+                            dist = rep2;
+                        } else {
+                            dist = rep3;
+                            rep3 = rep2;
+                        }
+                        rep2 = rep1;
+                    }
+                    rep1 = rep0;
+                    rep0 = dist;
+                }
+                len = (uint32_t)len_decode(&probs[P_REP_LEN], pos_state);
+                state = state < 7 ? 8 : 11;
+            } else {
+                rep3 = rep2; rep2 = rep1; rep1 = rep0;
+                len = (uint32_t)len_decode(&probs[P_LEN], pos_state);
+                state = state < 7 ? 7 : 10;
+                const int len_state = len > 3 ? 3 : (int)len;
+                const int pos_slot = tree(&probs[P_POS_SLOT + len_state * 64], 6);
+                if (pos_slot < 4) {
+                    rep0 = (uint64_t)pos_slot;
+                } else {
+                    const int ndb = (pos_slot >> 1) - 1;
+                    uint64_t dist = (uint64_t)(2 | (pos_slot & 1)) << ndb;
+                    if (pos_slot < 14) {
+                        dist += (uint64_t)tree_reverse(&probs[P_POS_DEC], 115, (int)(dist - (uint64_t)pos_slot), ndb);
+                    } else {
+                        dist += (uint64_t)direct_bits(ndb - 4) << 4;
+                        dist += (uint64_t)tree_reverse(&probs[P_ALIGN], 16, 0, 4);
+                    }
+                    rep0 = dist;
+                }
+                if (trap) return SWC_E_REF_TRAP;
+                if (rep0 == 0xFFFFFFFFull) {                                               // :260 end marker
+                    if (code != 0) return SWC_E_LZMA_RANGE_DECODER_FINISH_ERROR;           // :261
+                    break;
+                }
+                if (uncompressed_size == 0) return SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :266
+                if (rep0 >= dict_size || (rep0 > pos && pos < dict_size)) return SWC_E_LZMA_NOT_ENOUGH_TO_REPEAT;  // :269
+            }
+            if (trap) return SWC_E_REF_TRAP;
+            len += 2;
+            if (uncompressed_size > -1 && uncompressed_size < (int64_t)len) return SWC_E_LZMA_REPEAT_WILL_EXCEED;  // :275
+            if (rep0 + 1 > pos) return SWC_E_REF_TRAP;  // byte(at:) would index past out.count (App. A L2)
+            copy_match(rep0 + 1, len);
+            uncompressed_size -= len;
+        }
+        if (trap) return SWC_E_REF_TRAP;
+        if (overflow) return SWC_E_CAPACITY;
+        return SWC_OK;
+    }
+
+    // LZMA2Decoder.init + decode(): Sources/LZMA2/LZMA2Decoder.swift:17-99
+    SWC_HD int decode_lzma2(uint8_t dict_byte) {
+        if (dict_byte & 0xC0) return SWC_E_LZMA2_WRONG_DICTIONARY_SIZE;  // :21
+        const int bits = dict_byte & 0x3F;
+        if (bits >= 40) return SWC_E_LZMA2_WRONG_DICTIONARY_SIZE;        // :24
+        uint32_t ds = (uint32_t)(2 | (bits & 1)) << (bits / 2 + 11);
+        dict_size = ds < 4096 ? 4096 : ds;                               // didSet clamp, LZMAProperties.swift:26-32
+        for (;;) {
+            const uint32_t control = next_byte();                        // :36
+            if (trap) return SWC_E_REF_TRAP;
+            if (control == 0) return SWC_OK;
+            if (control == 1 || control == 2) {
+                if (control == 1) reset_dictionary();
+                const uint32_t b1 = next_byte(), b2 = next_byte();       // decodeUncompressed :84-89
+                if (trap) return SWC_E_REF_TRAP;
+                const uint64_t size = ((uint64_t)b1 << 8) + b2 + 1;
+                if (n - ip < size) return SWC_E_REF_TRAP;                // byte() past the end inside the copy loop
+                if (pos + size <= cap) {
+                    for (uint64_t i = (uint64_t)lane; i < size; i += WAVE) out[pos + i] = in[ip + i];
+                } else {
+                    overflow = true;
+                }
+                ip += size;
+                pos += size;
+                if (pos - dict_start >= dict_size) dict_start = pos - dict_size + 1;
+                if (overflow) return SWC_E_CAPACITY;
+                continue;
+            }
+            if (control <= 0x7F) return SWC_E_LZMA2_WRONG_CONTROL_BYTE;  // :45
+            const int reset = (control & 0x60) >> 5;                     // dispatch :56-82
+            const uint32_t u1 = next_byte(), u2 = next_byte();
+            const int64_t unpack = ((int64_t)(control & 0x1F) << 16) + ((int64_t)u1 << 8) + u2 + 1;
+            const uint32_t c1 = next_byte(), c2 = next_byte();
+            const int64_t comp = ((int64_t)c1 << 8) + c2 + 1;
+            if (trap) return SWC_E_REF_TRAP;
+            if (reset == 1) {
+                reset_state_and_decoders();
+            } else if (reset >= 2) {                                     // updateProperties :95-99
+                const uint32_t pbyte = next_byte();
+                if (trap) return SWC_E_REF_TRAP;
+                if (pbyte >= 225) return SWC_E_LZMA_WRONG_PROPERTIES;
+                lc = pbyte % 9; pb = (pbyte / 9) / 5; lp = (pbyte / 9) % 5;
+                reset_state_and_decoders();
+                if (reset == 3) reset_dictionary();
+            }
+            uncompressed_size = unpack;
+            const uint64_t out_start = pos, in_start = ip;
+            const int st = decode();
+            if (st) return st;
+            if (!(unpack == (int64_t)(pos - out_start) && (int64_t)(ip - in_start) == comp)) return SWC_E_LZMA2_WRONG_SIZES;  // :79-81
+        }
+    }
+};
+
+// job.aux: LZMA2 = dictionary-size byte; LZMA = lc | lp << 8 | pb << 16.
+// job.dict_len: LZMA = declared uncompressed size (UINT64_MAX = unknown); job.dict (reinterpreted) = dictionary size.
+template <int WAVE>
+SWC_HD void lzma_job(Job& job, bool is_lzma2, uint16_t* probs, SWC_AS_GLOBAL uint16_t* lit_spill, int lane) {
+    Decoder<WAVE> d;
+    d.in = (gcptr)job.in; d.n = job.in_len; d.ip = 0;
+    d.out = (gptr)job.out; d.cap = job.out_cap; d.pos = 0;
+    d.lane = lane;
+    d.probs = probs; d.lit_spill = lit_spill;
+    d.have_model = false;
+    d.lc = 3; d.lp = 0; d.pb = 2;             // LZMAProperties defaults, LZMAProperties.swift:12-18
+    d.dict_size = 1u << 24;
+    d.uncompressed_size = -1;
+    d.dict_start = 0;
+    d.range = 0; d.code = 0;
+    d.rep0 = d.rep1 = d.rep2 = d.rep3 = 0;
+    d.state = 0;
+    d.trap = false; d.overflow = false; d.need_ws = false;
+    int st;
+    if (is_lzma2) {
+        st = d.decode_lzma2((uint8_t)job.aux);
+    } else {
+        d.lc = job.aux & 0xFF; d.lp = (job.aux >> 8) & 0xFF; d.pb = (job.aux >> 16) & 0xFF;
+        d.dict_size = (uint64_t)(uintptr_t)job.dict;
+        d.uncompressed_size = (int64_t)job.dict_len;
+        if (d.lc > 8 || d.lp > 4 || d.pb > 4) {
+            st = SWC_E_REF_TRAP;  // LZMAProperties(lc:lp:pb:) is not validated; such values trap downstream
+        } else {
+            d.reset_state_and_decoders();
+            st = d.decode();
+        }
+    }
+    job.out_len = d.pos;
+    job.in_consumed = d.ip;
+    job.status = st;
+}
+
+}  // namespace lzma
+}  // namespace swc
+#endif

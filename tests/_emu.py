@@ -28,7 +28,7 @@ build()
 lib = C.CDLL(_LIB)
 
 
-def run_batch(fn_name, inputs, caps, aux=None, dicts=None, extra=None):
+def run_batch(fn_name, inputs, caps, aux=None, dicts=None, extra=None, fn_args=(), dict_ptr_values=None):
     """inputs: list[bytes]; caps: list[int].  Returns list of (status, out_bytes, in_consumed, out_len)."""
     n = len(inputs)
     jobs = (Job * n)()
@@ -50,7 +50,9 @@ def run_batch(fn_name, inputs, caps, aux=None, dicts=None, extra=None):
             jobs[i].dict_len = len(dicts[i])
         if extra is not None:
             jobs[i].dict_len = extra[i]
-    getattr(lib, fn_name)(jobs, C.c_size_t(n))
+        if dict_ptr_values is not None:
+            jobs[i].dict = dict_ptr_values[i]
+    getattr(lib, fn_name)(jobs, C.c_size_t(n), *fn_args)
     res = []
     for i in range(n):
         ib, ob = keep[i] if dicts is None else [k for k in keep if isinstance(k, tuple)][i]
@@ -67,3 +69,14 @@ def inflate(inputs, caps):
 
 def lz4_block(inputs, caps, dicts=None):
     return run_batch("emu_lz4_block", inputs, caps, dicts=dicts)
+
+
+def lzma2(inputs, caps, dict_bytes):
+    return run_batch("emu_lzma", inputs, caps, aux=dict_bytes, fn_args=(C.c_int(1),))
+
+
+def lzma(inputs, caps, props, dict_sizes, sizes):
+    """props: list of (lc, lp, pb); sizes: declared uncompressed size or -1."""
+    aux = [lc | (lp << 8) | (pb << 16) for lc, lp, pb in props]
+    extra = [s & 0xFFFFFFFFFFFFFFFF for s in sizes]
+    return run_batch("emu_lzma", inputs, caps, aux=aux, extra=extra, fn_args=(C.c_int(0),), dict_ptr_values=dict_sizes)

@@ -240,3 +240,87 @@ def lz4_frames():
     skip = struct.pack("<II", 0x184D2A53, 5) + b"hello"
     out.append(("skippable-then-frame", skip + corpus.lz4f_frame(x[:3000], 4, False), None, None))
     return out
+
+
+# ------------------------------------------------------------------------------------------- LZMA
+def lzma2_valid(seed=7, sizes=(0, 1, 100, 5000, 70000, 300000)):
+    """(raw LZMA2 stream, dict byte, plain)"""
+    out = []
+    for kind in ("text", "rep", "zero", "rand", "mix"):
+        for n in sizes:
+            x = corpus.PAYLOADS[kind](n, seed)
+            for ds in (1 << 12, 1 << 16, 1 << 20):
+                out.append((corpus.lzma2_raw(x, dict_size=ds), corpus.lzma2_dict_byte(ds), x))
+    return out
+
+
+def lzma_alone_valid(seed=9):
+    """(.lzma file, plain) with several lc/lp/pb combinations (all of which liblzma can produce)."""
+    import lzma
+    out = []
+    for kind in ("text", "mix", "rand"):
+        for n in (0, 1, 5000, 100000):
+            x = corpus.PAYLOADS[kind](n, seed)
+            for flt in (dict(lc=3, lp=0, pb=2), dict(lc=0, lp=2, pb=0), dict(lc=4, lp=0, pb=4), dict(lc=1, lp=3, pb=1)):
+                out.append((lzma.compress(x, format=lzma.FORMAT_ALONE, filters=[dict(id=lzma.FILTER_LZMA1, dict_size=1 << 16, **flt)]), x))
+    return out
+
+
+def lzma2_fuzz(seed=11, per_base=16, n_random=400):
+    """(stream, dict byte): truncations / bit flips of valid LZMA2 streams, crafted control bytes, random bytes."""
+    rnd = random.Random(seed)
+    ins = []
+    base = [(z, db) for z, db, _ in lzma2_valid(sizes=(100, 5000, 70000))[::3]]
+    for z, db in base:
+        for _ in range(per_base):
+            b = bytearray(z)
+            m = rnd.randrange(4)
+            if m == 0:
+                b = b[:rnd.randrange(0, len(b))]
+            elif m == 1:
+                b[rnd.randrange(min(len(b), 12))] ^= 1 << rnd.randrange(8)
+            elif m == 2:
+                for _ in range(rnd.randrange(1, 3)):
+                    b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+            else:
+                b += bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 20)))
+            ins.append((bytes(b), db))
+    for _ in range(n_random):
+        b = bytearray(rnd.randrange(256) for _ in range(rnd.randrange(0, 80)))
+        if b and rnd.random() < 0.6:
+            b[0] = rnd.choice([0x01, 0x02, 0x80, 0xA0, 0xC0, 0xE0, 0xFF])
+            if len(b) > 5 and b[0] >= 0xC0 and rnd.random() < 0.7:
+                b[5] = rnd.choice([0x5D, 0x00, 0x2C, 0x6C, 0xE0, 0x08, 0x51])   # props byte incl. lc+lp > 4 and >= 225
+        ins.append((bytes(b), rnd.choice([0, 12, 24, 39, 40, 0x40])))
+    # a first chunk without a state reset (model never initialised => trap class), stored chunks, dictionary reset
+    ins.append((b"\x80\x00\x00\x00\x04\x00\x00\x00\x00\x00", 0x18))
+    ins.append((b"\x01\x00\x04hello\x00", 0x18))
+    ins.append((b"\x02\x00\x04hello\x00", 0x18))
+    ins.append((b"\x01\x00\x04hel", 0x18))
+    return ins
+
+
+def lzma_raw_fuzz(seed=13, n_random=300):
+    """(raw LZMA1 payload, (lc, lp, pb), dict size, declared size)"""
+    rnd = random.Random(seed)
+    ins = []
+    for z, x in lzma_alone_valid()[::2]:
+        b = z[0]
+        props = (b % 9, (b // 9) % 5, (b // 9) // 5)
+        ds = int.from_bytes(z[1:5], "little")
+        body = z[13:]
+        for _ in range(6):
+            m = rnd.randrange(4)
+            bb = bytearray(body)
+            if m == 0 and len(bb) > 1:
+                bb = bb[:rnd.randrange(0, len(bb))]
+            elif m == 1 and bb:
+                bb[rnd.randrange(len(bb))] ^= 1 << rnd.randrange(8)
+            size = rnd.choice([-1, len(x), len(x) + 3, max(len(x) - 3, 0), 0])
+            dsz = rnd.choice([ds, 0, 1, 100, 4096])
+            ins.append((bytes(bb), props, dsz, size))
+    for _ in range(n_random):
+        body = b"\x00" + bytes(rnd.randrange(256) for _ in range(rnd.randrange(4, 120)))
+        props = rnd.choice([(3, 0, 2), (8, 4, 4), (0, 0, 0), (4, 4, 0), (8, 0, 4), (2, 3, 1)])
+        ins.append((body, props, rnd.choice([1 << 16, 4096, 50]), rnd.choice([-1, 20, 200, 0])))
+    return ins

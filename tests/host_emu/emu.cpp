@@ -7,6 +7,7 @@
 #include <cstring>
 #include "../../swcompression_amd/csrc/inflate_lane.h"
 #include "../../swcompression_amd/csrc/lz4_lane.h"
+#include "../../swcompression_amd/csrc/lzma_wave.h"
 
 extern "C" void emu_inflate(swc::Job* jobs, size_t n) {
     std::vector<uint32_t> lds(swc::inflate::kWordsPerLane * swc::kWave);
@@ -20,4 +21,15 @@ extern "C" void emu_inflate(swc::Job* jobs, size_t n) {
 
 extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {
     for (size_t g = 0; g < n; g++) swc::lz4::lz4_block_job(jobs[g]);
+}
+
+// LZMA: the wave-uniform decode chain is run as a single logical lane (WAVE = 1); the literal-coder
+// spill (lc+lp > 4) is always available, as the single-shot C ABI guarantees on the device.
+extern "C" void emu_lzma(swc::Job* jobs, size_t n, int is_lzma2) {
+    std::vector<uint16_t> probs(swc::lzma::kProbCells + 8);
+    std::vector<uint16_t> spill((size_t)0x300 << 12);
+    for (size_t g = 0; g < n; g++) {
+        std::fill(probs.begin(), probs.end(), (uint16_t)0xBEEF);
+        swc::lzma::lzma_job<1>(jobs[g], is_lzma2 != 0, probs.data(), spill.data(), 0);
+    }
 }
