@@ -26,7 +26,7 @@ class DeviceBatch:
     addresses (inputs are replicated, every job owns its own output range), as SURVEY.md section 8d asks for:
     nothing is served from the 256 MiB Infinity Cache by accident."""
 
-    def __init__(self, codec, units, caps, aux=None, extra=None, tile=1, device="cuda:0", replicate_inputs=True):
+    def __init__(self, codec, units, caps, aux=None, extra=None, dict_values=None, tile=1, device="cuda:0", replicate_inputs=True):
         import torch
         self.torch = torch
         self.lib = _lib.load()
@@ -67,6 +67,8 @@ class DeviceBatch:
             jobs["aux"] = np.array(aux, dtype=np.int32)[k_idx]
         if extra is not None:
             jobs["dict_len"] = np.array(extra, dtype=np.uint64)[k_idx]
+        if dict_values is not None:  # integer carried in the `dict` field (LZMA: dictionary size, BZip2: stored block CRC)
+            jobs["dict"] = np.array(dict_values, dtype=np.uint64)[k_idx]
         self._out_off = (t_idx * np.uint64(out_round) + out_off[k_idx]).astype(np.int64)
         self.caps = caps[k_idx]
         self.in_lens = lens[k_idx]

@@ -3,6 +3,7 @@
 // decode path in this library: without a usable gfx950 device every decode entry point returns
 // SWC_E_DEVICE.
 #include <algorithm>
+#include <map>
 #include <mutex>
 #include <string.h>
 #include "host_util.h"
@@ -37,6 +38,7 @@ static hipError_t launch_codec(int codec, Job* jobs, size_t n, void* ws, size_t 
         case SWC_CODEC_LZ4_BLOCK: return launch_lz4(jobs, n, stream);
         case SWC_CODEC_LZMA2: return launch_lzma(true, jobs, n, ws_bytes >= n * lzma_spill_bytes_per_job() ? ws : nullptr, stream);
         case SWC_CODEC_LZMA: return launch_lzma(false, jobs, n, ws_bytes >= n * lzma_spill_bytes_per_job() ? ws : nullptr, stream);
+        case SWC_CODEC_BZIP2_BLOCK: return launch_bzip2(jobs, n, ws, ws_bytes, stream);
         default: return hipErrorInvalidValue;
     }
 }
@@ -63,11 +65,15 @@ int run_units(int codec, std::vector<HostUnit>& units) {
     for (int round = 0; round < 12 && !pending.empty(); round++) {
         const size_t m = pending.size();
         std::vector<size_t> in_off(m), out_off(m), dict_off(m);
+        std::vector<char> in_shared(m, 0);
+        std::map<std::pair<const uint8_t*, size_t>, size_t> seen;  // units that share one input buffer (bzip2 blocks of a stream) are staged once
         size_t in_total = 0, out_total = 0;
         for (size_t k = 0; k < m; k++) {
             const HostUnit& u = units[pending[k]];
-            in_off[k] = in_total;
-            in_total += (u.in_len + 15) & ~(size_t)15;
+            auto key = std::make_pair(u.in, u.in_len);
+            auto it = seen.find(key);
+            if (it != seen.end()) { in_off[k] = it->second; in_shared[k] = 1; }
+            else { in_off[k] = in_total; seen[key] = in_total; in_total += (u.in_len + 15) & ~(size_t)15; }
             dict_off[k] = in_total;
             if (u.dict) in_total += (u.dict_len + 15) & ~(size_t)15;
             out_off[k] = out_total;
@@ -81,7 +87,7 @@ int run_units(int codec, std::vector<HostUnit>& units) {
         std::vector<Job> jobs(m);
         for (size_t k = 0; k < m; k++) {
             const HostUnit& u = units[pending[k]];
-            if (u.in_len) memcpy(stage.data() + in_off[k], u.in, u.in_len);
+            if (u.in_len && !in_shared[k]) memcpy(stage.data() + in_off[k], u.in, u.in_len);
             if (u.dict && u.dict_len) memcpy(stage.data() + dict_off[k], u.dict, u.dict_len);
             Job& j = jobs[k];
             j.in = d_in.u8() + in_off[k];
@@ -111,6 +117,11 @@ int run_units(int codec, std::vector<HostUnit>& units) {
                 next.push_back(pending[k]);
                 continue;
             }
+            if (j.status == SWC_E_NEED_WORKSPACE && codec == SWC_CODEC_BZIP2_BLOCK && cap[pending[k]] < ((size_t)15 << 20)) {
+                cap[pending[k]] = std::min<size_t>(cap[pending[k]] * 4, (size_t)15 << 20);  // L outgrew the workspace sized from cap
+                next.push_back(pending[k]);
+                continue;
+            }
             if (j.status == SWC_E_CAPACITY && !u.cap_exact && cap[pending[k]] < ((size_t)1 << 34)) {
                 size_t want = j.out_len > cap[pending[k]] ? (size_t)j.out_len : cap[pending[k]] * 4;
                 cap[pending[k]] = want;
@@ -118,6 +129,7 @@ int run_units(int codec, std::vector<HostUnit>& units) {
                 continue;
             }
             u.status = j.status;
+            u.aux_out = j.aux;
             u.in_consumed = (size_t)j.in_consumed;
             size_t produced = (size_t)std::min<uint64_t>(j.out_len, j.out_cap);
             u.out.assign(out_stage.data() + out_off[k], out_stage.data() + out_off[k] + produced);
@@ -153,6 +165,7 @@ size_t swc_batch_workspace_bytes(int codec, size_t n_jobs, uint64_t max_out_cap)
     switch (codec) {
         case SWC_CODEC_LZMA:
         case SWC_CODEC_LZMA2: return n_jobs * lzma_spill_bytes_per_job();  // optional: only streams with lc+lp > 4 use it
+        case SWC_CODEC_BZIP2_BLOCK: return n_jobs * bzip2_ws_bytes_per_job((size_t)max_out_cap + 64);  // L is never longer than the output
         default: return 0;
     }
 }

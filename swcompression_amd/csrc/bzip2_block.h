@@ -1,0 +1,469 @@
+// bzip2_block.h -- BZip2 block decode as three device stages.
+//
+// Replaces BZip2.decode(_:_:) (reference Sources/BZip2/BZip2.swift:97-270), BurrowsWheeler.reverse
+// (Sources/BZip2/BurrowsWheeler.swift:29-64) and CheckSums.bzip2crc32 (Sources/Common/CheckSums.swift:30-37):
+//
+//   stage 1  one block per WAVEFRONT  symbol map, selectors (MTF), 2-6 Huffman tables, symbol loop with
+//            RUNA/RUNB runs and inverse MTF  ->  the BWT last column L[0..n) in the HBM workspace plus the
+//            per-byte histogram.  The decode chain is serial, so it runs wave-uniform; the 20 code-length
+//            limit compares, the MTF list shift, run fills and L stores are spread over the lanes.
+//   stage 2  one block per WAVEFRONT  stable counting-sort scatter  P[base[c]++] = i << 8 | c  (c = L[i]),
+//            each lane owning a contiguous slice of i (per-lane counters in LDS).
+//   stage 3  one block per LANE       the n dependent gathers  v = P[end]; end = v >> 8; byte = v & 255,
+//            fused with the RLE1 undo (4 equal bytes + count, BZip2.swift:251-267), the MSB-first CRC-32
+//            and the output stores.  n random 4-byte loads per block cannot be parallelised within a block
+//            (single permutation cycle); throughput comes from thousands of blocks in flight.
+//
+// Reference semantics kept: lengths 0..20 accepted and never validated (App. A B2), surplus selectors
+// ignored / too few => wrongSelector (B3), origPtr unchecked => trap (B4), block size not enforced (B5),
+// positional RLE1 rule (B6).  Deviation: a FINAL code length > 20, which only the unchecked
+// last delta can produce, is classified as trap-class instead of building a 2^22+ entry tree.
+#ifndef SWC_BZIP2_BLOCK_H
+#define SWC_BZIP2_BLOCK_H
+
+#include "swc_common.h"
+
+namespace swc {
+namespace bzip2 {
+
+constexpr int kMaxSyms = 258;
+constexpr int kMaxTables = 6;
+constexpr int kMaxLen = 20;
+
+// ---- LDS layout of stage 1 (bytes) ---------------------------------------------------------------
+struct Stage1Lds {
+    uint32_t slot[kMaxTables][kMaxLen + 2];  // slot[d] = v0 << 9 | start, slot[21] = total
+    uint32_t lim[kMaxTables][kMaxLen + 1];   // left-justified (20-bit) limits, non-decreasing
+    uint32_t oversub[kMaxTables];
+    uint32_t counts[256];                    // histogram of L
+    uint16_t sym[kMaxTables][kMaxSyms + 2];  // (length, symbol)-sorted symbols
+    int8_t lengths[kMaxSyms + 6];            // scratch while building one table
+    uint8_t mtf[256];                        // usedSymbols: the MTF list itself (BZip2.swift:243-245)
+    uint8_t tmtf[8];                         // selector MTF
+    uint8_t stage[64];                       // L staging for coalesced stores
+    uint32_t tcnt[kMaxLen + 2];              // scratch while building one table
+    uint32_t tstart[kMaxLen + 2];
+};
+constexpr int kStage1LdsBytes = (sizeof(Stage1Lds) + 15) / 16 * 16;
+
+// workspace per job (HBM): L[lcap] | selectors[32768] | P[lcap] (u32) | header
+struct BlockHeader {   // stage 1 -> stage 2/3
+    uint32_t n;        // length of L
+    uint32_t orig_ptr;
+    uint32_t status;
+    uint32_t pad;
+    uint64_t end_bit;  // absolute bit position just past the block's EOB symbol
+    uint32_t counts[256];
+};
+SWC_HD size_t ws_bytes_per_job(size_t lcap) { return ((lcap + 15) & ~(size_t)15) + 32768 + lcap * 4 + sizeof(BlockHeader) + 64; }
+struct Workspace {
+    gptr L;
+    gptr selectors;
+    SWC_AS_GLOBAL uint32_t* P;
+    SWC_AS_GLOBAL BlockHeader* hdr;
+    size_t lcap;
+};
+SWC_HD Workspace carve(uint8_t* base, size_t job, size_t lcap) {
+    uint8_t* p = base + job * ws_bytes_per_job(lcap);
+    Workspace w;
+    size_t lpad = (lcap + 15) & ~(size_t)15;
+    w.L = (gptr)p;
+    w.selectors = (gptr)(p + lpad);
+    w.P = (SWC_AS_GLOBAL uint32_t*)(p + lpad + 32768);
+    w.hdr = (SWC_AS_GLOBAL BlockHeader*)(p + lpad + 32768 + lcap * 4);
+    w.lcap = lcap;
+    return w;
+}
+
+// MSB-first bit reader (BitByteData.MsbBitReader contract), wave-uniform.
+struct MsbReader {
+    gcptr in;
+    uint64_t n;        // bytes
+    uint64_t next;     // next byte to load
+    uint64_t bb;       // next bit at bit 63
+    uint32_t bc;
+    SWC_HD void init(gcptr p, uint64_t nbytes, uint64_t start_bit) {
+        in = p; n = nbytes; next = start_bit >> 3; bb = 0; bc = 0;
+        refill();
+        uint32_t skip = (uint32_t)(start_bit & 7);
+        if (skip > bc) skip = bc;
+        bb <<= skip; bc -= skip;
+        refill();
+    }
+    SWC_HD void refill() {
+        if (bc <= 32) {
+            if (next + 4 <= n) {
+                uint32_t w = load_u32(in + next);
+                w = (w >> 24) | ((w >> 8) & 0xFF00u) | ((w << 8) & 0xFF0000u) | (w << 24);
+                bb |= (uint64_t)w << (32 - bc);
+                bc += 32;
+                next += 4;
+            } else {
+                while (bc <= 56 && next < n) {
+                    bb |= (uint64_t)in[next++] << (56 - bc);
+                    bc += 8;
+                }
+            }
+        }
+    }
+    SWC_HD int64_t bits_left() const { return (int64_t)(n - next) * 8 + bc; }
+    SWC_HD uint64_t position() const { return next * 8 - bc; }
+    SWC_HD uint32_t peek(uint32_t k) const { return k ? (uint32_t)(bb >> (64 - k)) : 0u; }
+    SWC_HD void consume(uint32_t k) { bb <<= k; bc -= k; }
+    SWC_HD uint32_t bits(uint32_t k) {  // k <= 24, caller checked bits_left() >= k
+        refill();
+        uint32_t v = peek(k);
+        consume(k);
+        return v;
+    }
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+SWC_D uint32_t wave_count(bool pred) { return (uint32_t)__popcll(__ballot(pred)); }
+#endif
+
+template <int WAVE>
+struct Stage1 {
+    Stage1Lds* s;
+    MsbReader br;
+    Workspace ws;
+    int lane;
+    uint32_t n_out;     // bytes in L so far
+    uint32_t staged;
+    bool l_overflow;
+
+    SWC_HD void flush_stage() {
+        if (WAVE == 1) {
+            for (uint32_t i = 0; i < staged; i++) ws.L[n_out - staged + i] = s->stage[i];
+        } else {
+            if ((uint32_t)lane < staged) ws.L[n_out - staged + lane] = s->stage[lane];
+        }
+        staged = 0;
+    }
+    SWC_HD void emit(uint8_t b) {
+        if (n_out >= ws.lcap) { l_overflow = true; return; }
+        s->stage[staged++] = b;
+        s->counts[b] += 1;
+        n_out++;
+        if (staged == 64) flush_stage();
+    }
+    SWC_HD void emit_run(uint8_t b, uint64_t run) {
+        if (n_out + run > ws.lcap || run > 0xFFFFFFFFull) { l_overflow = true; return; }
+        flush_stage();
+        for (uint64_t i = (uint64_t)lane; i < run; i += WAVE) ws.L[n_out + i] = b;
+        s->counts[b] += (uint32_t)run;
+        n_out += (uint32_t)run;
+    }
+
+    // Selectors were stored to HBM by lane 0; lane 0 reads them back (same-lane store -> load order is
+    // architectural) and the value is broadcast, so no cross-lane memory visibility is assumed.
+    SWC_HD int selector_at(int i) {
+        int v = lane == 0 ? (int)ws.selectors[i] : 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        if (WAVE > 1) v = __builtin_amdgcn_readfirstlane(v);
+#endif
+        return v;
+    }
+
+    // Code.huffmanCodes + DecodingTree.init for table t from s->lengths[0..count)  (Code.swift:15-39)
+    SWC_HD int build_table(int t, int count) {
+        uint32_t* cnt = s->tcnt;
+        uint32_t* start = s->tstart;
+        for (int d = 0; d <= kMaxLen + 1; d++) cnt[d] = 0;
+        for (int i = 0; i < count; i++) {
+            int l = s->lengths[i];
+            if (l > kMaxLen) return SWC_E_REF_TRAP;  // see header: only the unchecked final length can get here
+            if (l > 0) cnt[l]++;
+        }
+        uint32_t v = 0, off = 0;
+        bool over = false;
+        for (int d = 1; d <= kMaxLen; d++) {
+            s->lim[t][d] = (v + cnt[d]) << (kMaxLen - d);
+            if (cnt[d] != 0 && v + cnt[d] > (1u << d)) over = true;
+            s->slot[t][d] = ((v & 0xFFFFFu) << 9) | off;
+            start[d] = off;
+            off += cnt[d];
+            v = (v + cnt[d]) << 1;
+        }
+        s->slot[t][kMaxLen + 1] = off;
+        s->oversub[t] = over ? 1u : 0u;
+        for (int i = 0; i < count; i++) {
+            int l = s->lengths[i];
+            if (l > 0) s->sym[t][start[l]++] = (uint16_t)i;
+        }
+        return SWC_OK;
+    }
+
+    // DecodingTree.findNextSymbol for table t: returns the symbol or -1.
+    SWC_HD int decode_symbol(int t, uint32_t my_lim) {
+        br.refill();
+        const uint32_t c = br.peek(kMaxLen);
+        uint32_t len;
+        int idx = -1;
+        if (!s->oversub[t]) {
+#if defined(__HIP_DEVICE_COMPILE__)
+            if (WAVE > 1) {
+                len = 1 + wave_count(lane >= 1 && lane <= kMaxLen && c >= my_lim);
+            } else
+#endif
+            {
+                len = 1;
+                for (int d = 1; d <= kMaxLen; d++) len += c >= s->lim[t][d] ? 1u : 0u;
+            }
+            (void)my_lim;
+            if (len > kMaxLen) return -1;
+            const uint32_t w = s->slot[t][len];
+            idx = (int)((w & 511u) + (c >> (kMaxLen - len)) - (w >> 9));
+        } else {
+            uint32_t w = s->slot[t][1];
+            len = 0;
+            for (int d = 1; d <= kMaxLen; d++) {
+                const uint32_t wn = s->slot[t][d + 1];
+                const uint32_t cnt = (wn & 511u) - (w & 511u);
+                const uint32_t k0 = ((c >> (kMaxLen - d)) - (w >> 9)) & ((1u << d) - 1u);
+                if (k0 < cnt) {
+                    len = (uint32_t)d;
+                    idx = (int)((w & 511u) + k0 + (((cnt - 1u - k0) >> d) << d));
+                    break;
+                }
+                w = wn;
+            }
+            if (idx < 0) return -1;
+        }
+        if ((int64_t)len > br.bits_left()) return -1;  // DecodingTree.swift:39
+        br.consume(len);
+        return (int)s->sym[t][idx];
+    }
+
+    // usedSymbols.remove(at: idx) + insert(at: 0)  (BZip2.swift:243-244), spread over the lanes
+    SWC_HD uint8_t mtf_to_front(uint32_t idx) {
+        const uint8_t el = s->mtf[idx];
+        if (WAVE == 1) {
+            for (uint32_t j = idx; j > 0; j--) s->mtf[j] = s->mtf[j - 1];
+        } else {
+            for (int base = (int)((idx == 0 ? 0 : idx - 1) / WAVE) * WAVE; base >= 0 && idx > 0; base -= WAVE) {
+                const uint32_t j = (uint32_t)base + (uint32_t)lane;
+                uint8_t t = 0;
+                if (j < idx) t = s->mtf[j];
+                if (j < idx) s->mtf[j + 1] = t;
+            }
+        }
+        s->mtf[0] = el;
+        return el;
+    }
+
+    // BZip2.swift:97-246.  Returns an swc_status; on success L/counts/n/origPtr are complete.
+    SWC_HD int run(uint32_t& orig_ptr) {
+        if (br.bits_left() < 41) return SWC_E_BZIP2_WRONG_MAGIC;  // :103
+        if (br.bits(1) != 0) return SWC_E_BZIP2_RANDOMIZED_BLOCK;  // :106
+        orig_ptr = br.bits(24);
+        const uint32_t used_map = br.bits(16);
+        uint32_t pop = 0;
+        for (int i = 0; i < 16; i++) pop += (used_map >> i) & 1u;
+        if (br.bits_left() < (int64_t)(16 * pop + 3 + 15)) return SWC_E_BZIP2_WRONG_MAGIC;  // :118
+        int n_used = 0;
+        for (int blk = 0; blk < 16; blk++) {
+            if (used_map & (0x8000u >> blk)) {
+                const uint32_t m = br.bits(16);
+                for (int k = 0; k < 16; k++)
+                    if (m & (0x8000u >> k)) s->mtf[n_used++] = (uint8_t)(blk * 16 + k);
+            }
+        }
+        const int used_count = 2 + n_used;  // :139
+        const int n_tables = (int)br.bits(3);
+        if (n_tables < 2 || n_tables > 6) return SWC_E_BZIP2_WRONG_HUFFMAN_GROUPS;  // :142
+        const int n_selectors = (int)br.bits(15);
+        for (int i = 0; i < n_tables; i++) s->tmtf[i] = (uint8_t)i;
+        for (int i = 0; i < n_selectors; i++) {  // :155-173
+            int c = 0;
+            for (;;) {
+                br.refill();
+                if (br.bits_left() <= 0) break;
+                const uint32_t b = br.peek(1);
+                br.consume(1);
+                if (b == 0) break;
+                c++;
+            }
+            if (c >= n_tables) return SWC_E_BZIP2_WRONG_SELECTOR;
+            const uint8_t el = s->tmtf[c];
+            for (int k = c; k > 0; k--) s->tmtf[k] = s->tmtf[k - 1];
+            s->tmtf[0] = el;
+            if (lane == 0) ws.selectors[i] = el;
+        }
+        for (int t = 0; t < n_tables; t++) {  // :177-203
+            if (br.bits_left() < 5) return SWC_E_BZIP2_WRONG_HUFFMAN_CODE_LENGTH;
+            int length = (int)br.bits(5);
+            for (int i = 0; i < used_count; i++) {
+                if (!(length >= 0 && length <= 20)) return SWC_E_BZIP2_WRONG_HUFFMAN_CODE_LENGTH;  // :185
+                for (;;) {
+                    br.refill();
+                    if (br.bits_left() <= 0) break;
+                    const uint32_t b = br.peek(1);
+                    br.consume(1);
+                    if (b == 0) break;
+                    if (br.bits_left() <= 0) return SWC_E_BZIP2_WRONG_HUFFMAN_CODE_LENGTH;  // :193
+                    br.refill();
+                    const uint32_t d = br.peek(1);
+                    br.consume(1);
+                    length -= (int)d * 2 - 1;
+                }
+                // a non-final symbol outside 0...20 is rejected at the top of the next iteration (:185); the
+                // FINAL one is never checked: <= 0 is skipped by Code.huffmanCodes, > 20 is trap-class
+                s->lengths[i] = (int8_t)(length < -128 ? -128 : length > 127 ? 127 : length);
+            }
+            const int st = build_table(t, used_count);
+            if (st) return st;
+        }
+        // ---- symbol loop :205-246
+        if (n_selectors == 0) return SWC_E_REF_TRAP;  // selectors[0] on an empty array (App. A B3)
+        int decoded = 0;
+        int selector_index = 1;
+        int table = selector_at(0);
+        uint32_t my_lim = (lane >= 1 && lane <= kMaxLen) ? s->lim[table][lane] : 0xFFFFFFFFu;
+        uint64_t run_length = 0, repeat_power = 1;
+        for (;;) {
+            if (decoded >= 50) {
+                if (!(selector_index < n_selectors)) return SWC_E_BZIP2_WRONG_SELECTOR;  // :214
+                table = selector_at(selector_index);
+                my_lim = (lane >= 1 && lane <= kMaxLen) ? s->lim[table][lane] : 0xFFFFFFFFu;
+                selector_index++;
+                decoded = 0;
+            }
+            const int symbol = decode_symbol(table, my_lim);
+            if (symbol == -1) return SWC_E_BZIP2_SYMBOL_NOT_FOUND;  // :222
+            decoded++;
+            if (symbol == 0 || symbol == 1) {  // RUNA / RUNB :226-230 (wrapping, like &+ and smart shifts)
+                run_length += repeat_power << symbol;
+                repeat_power <<= 1;
+                continue;
+            }
+            if ((int64_t)run_length > 0) {
+                if (n_used == 0) return SWC_E_REF_TRAP;  // usedSymbols[0] on an empty array
+                emit_run(s->mtf[0], run_length);
+                if (l_overflow) return SWC_E_NEED_WORKSPACE;
+                run_length = 0;
+                repeat_power = 1;
+            }
+            if (symbol == used_count - 1) break;  // :239 end of block
+            emit(mtf_to_front((uint32_t)symbol - 1));
+            if (l_overflow) return SWC_E_NEED_WORKSPACE;
+        }
+        flush_stage();
+        return SWC_OK;
+    }
+};
+
+// Stage 1 entry.  job.dict_len = bit offset of the block body (just past the 48-bit magic and the CRC).
+template <int WAVE>
+SWC_HD void stage1_job(const Job& job, Stage1Lds* lds, Workspace ws, int lane) {
+    Stage1<WAVE> d;
+    d.s = lds;
+    d.ws = ws;
+    d.lane = lane;
+    d.n_out = 0;
+    d.staged = 0;
+    d.l_overflow = false;
+    for (int i = lane; i < 256; i += WAVE) lds->counts[i] = 0;
+    uint32_t orig_ptr = 0;
+    int st;
+    if (job.dict_len > job.in_len * 8) {
+        st = SWC_E_INVALID_ARGUMENT;
+        d.br.init((gcptr)job.in, 0, 0);
+    } else {
+        d.br.init((gcptr)job.in, job.in_len, job.dict_len);
+        st = d.run(orig_ptr);
+    }
+    if (lane == 0) {
+        ws.hdr->n = d.n_out;
+        ws.hdr->orig_ptr = orig_ptr;
+        ws.hdr->status = (uint32_t)st;
+        ws.hdr->end_bit = d.br.position();
+    }
+    for (int i = lane; i < 256; i += WAVE) ws.hdr->counts[i] = lds->counts[i];
+}
+
+// Stage 2: P[base[c]++] = i << 8 | c in increasing i (BurrowsWheeler.swift:38-53), lane-sliced.
+// `cnt` is LDS: uint32_t[256 * WAVE].
+template <int WAVE>
+SWC_HD void stage2_job(Workspace ws, uint32_t* cnt, int lane) {
+    if (ws.hdr->status != SWC_OK) return;
+    const uint32_t n = ws.hdr->n;
+    if (n == 0) return;
+    const uint32_t chunk = (n + WAVE - 1) / WAVE;
+    const uint32_t lo = (uint32_t)lane * chunk < n ? (uint32_t)lane * chunk : n;
+    const uint32_t hi = lo + chunk < n ? lo + chunk : n;
+    for (int c = 0; c < 256; c++) cnt[c * WAVE + lane] = 0;
+    for (uint32_t i = lo; i < hi; i++) cnt[(uint32_t)ws.L[i] * WAVE + lane] += 1;
+    // exclusive scan over (symbol, lane) in symbol-major order; lane l owns symbols l, l+WAVE, ...
+    // first the per-symbol bases from the histogram of stage 1
+    for (int c = lane; c < 256; c += WAVE) {
+        uint32_t base = 0;
+        for (int k = 0; k < c; k++) base += ws.hdr->counts[k];
+        for (int l = 0; l < WAVE; l++) {
+            const uint32_t t = cnt[c * WAVE + l];
+            cnt[c * WAVE + l] = base;
+            base += t;
+        }
+    }
+    for (uint32_t i = lo; i < hi; i++) {
+        const uint32_t c = ws.L[i];
+        const uint32_t j = cnt[c * WAVE + lane]++;
+        ws.P[j] = (i << 8) | c;
+    }
+}
+
+// MSB-first CRC-32 table (CheckSums.swift:95-127 holds the same 256 constants)
+SWC_HD uint32_t crc_table_entry(uint32_t i) {
+    uint32_t b = i << 24;
+    for (int k = 0; k < 8; k++) b = (b & 0x80000000u) ? (b << 1) ^ 0x04C11DB7u : b << 1;
+    return b;
+}
+
+// Stage 3: one block per lane.  `crc_tab` = 256-entry table (LDS on device).
+// job.dict (as integer) = stored block CRC.
+SWC_HD void stage3_job(Job& job, Workspace ws, const uint32_t* crc_tab) {
+    const uint32_t st1 = ws.hdr->status;
+    job.in_consumed = ws.hdr->end_bit;  // bit position just past the block (BITS for this codec)
+    if (st1 != SWC_OK) { job.status = (int32_t)st1; job.out_len = 0; return; }
+    const uint32_t n = ws.hdr->n;
+    gptr out = (gptr)job.out;
+    const uint64_t cap = job.out_cap;
+    uint64_t pos = 0;
+    uint32_t crc = 0xFFFFFFFFu;
+    int st = SWC_OK;
+    if (n > 0) {  // BurrowsWheeler.swift:30-31: empty input => []
+        uint32_t end = ws.hdr->orig_ptr;
+        uint32_t run = 0, prev = 0;
+        for (uint32_t i = 0; i < n; i++) {
+            if (end >= n) { st = SWC_E_REF_TRAP; break; }  // pointers[end] out of range (App. A B4)
+            const uint32_t v = ws.P[end];
+            end = v >> 8;
+            const uint32_t b = v & 0xFFu;
+            if (run == 4) {
+                // the byte after four equal ones is a repeat count (it exists: this is position i <= n-1)
+                for (uint32_t k = 0; k < b; k++) {
+                    if (pos < cap) out[pos] = (uint8_t)prev;
+                    pos++;
+                    crc = (crc << 8) ^ crc_tab[(crc >> 24) ^ prev];
+                }
+                run = 0;
+                continue;
+            }
+            run = (run > 0 && b == prev) ? run + 1 : 1;
+            prev = b;
+            if (pos < cap) out[pos] = (uint8_t)b;
+            pos++;
+            crc = (crc << 8) ^ crc_tab[(crc >> 24) ^ b];
+        }
+    }
+    crc = ~crc;
+    if (st == SWC_OK && pos > cap) st = SWC_E_CAPACITY;
+    if (st == SWC_OK && crc != (uint32_t)(uintptr_t)job.dict) st = SWC_E_BZIP2_WRONG_CRC;  // BZip2.swift:81
+    job.out_len = pos;
+    job.status = st;
+    job.aux = (int32_t)crc;
+}
+
+}  // namespace bzip2
+}  // namespace swc
+#endif

@@ -1,0 +1,166 @@
+// framing_bzip2.cpp -- host side of BZip2: stream header, block discovery, CRC chaining.
+//   BZip2.decompress(data:) / decompress(_ bitReader:)   reference Sources/BZip2/BZip2.swift:22-26, 50-95
+//   BZip2.multiDecompress(data:)                          :40-48
+//   BlockSize.init?                                       Sources/BZip2/BZip2+BlockSize.swift:29-52
+// bzip2 blocks start at arbitrary BIT offsets and carry no length, so the sequential reference only
+// learns where block k+1 starts after decoding block k.  Here the host scans the input for every
+// occurrence of the 48-bit block magic, hands ALL candidates to one batched device launch, and then
+// replays the reference's sequential walk over the results: a candidate is used only if the walk
+// arrives exactly at its bit offset, so false positives inside block data are simply never visited
+// and the outcome (bytes, error, error order) is identical to the sequential decoder.
+#include <map>
+#include <vector>
+#include "framing.h"
+
+namespace swc {
+namespace {
+
+constexpr uint64_t kBlockMagic = 0x314159265359ull;
+constexpr uint64_t kEosMagic = 0x177245385090ull;
+
+inline uint64_t read_bits(const uint8_t* d, uint64_t bit, int count) {  // MSB-first, count <= 56, caller checked bounds
+    uint64_t v = 0;
+    for (int i = 0; i < count; i++) {
+        const uint64_t p = bit + i;
+        v = (v << 1) | ((d[p >> 3] >> (7 - (p & 7))) & 1u);
+    }
+    return v;
+}
+
+// every bit offset (>= from_bit) at which the 48-bit block magic occurs
+void scan_block_magics(const uint8_t* d, size_t n, uint64_t from_bit, std::vector<uint64_t>& out) {
+    const uint64_t total = (uint64_t)n * 8;
+    if (total < 48) return;
+    uint64_t w = 0;
+    uint64_t bit = 0;
+    for (size_t i = 0; i < n; i++) {
+        const uint32_t b = d[i];
+        for (int k = 7; k >= 0; k--, bit++) {
+            w = ((w << 1) | ((b >> k) & 1u)) & 0xFFFFFFFFFFFFull;
+            if (w == kBlockMagic && bit + 1 >= 48) {
+                const uint64_t start = bit + 1 - 48;
+                if (start >= from_bit) out.push_back(start);
+            }
+        }
+    }
+}
+
+struct Decoded {
+    int status;
+    std::vector<uint8_t> out;
+    uint64_t end_bit;
+};
+
+// decompress(_:) BZip2.swift:50-95 replayed over pre-decoded blocks.  `byte_pos` is the aligned start of
+// the stream; on return it is the aligned position just past the stream (callers align(), :45).
+int walk_stream(const uint8_t* d, size_t n, size_t& byte_pos, const std::map<uint64_t, Decoded>& blocks,
+                std::vector<uint8_t>& out) {
+    const uint64_t total = (uint64_t)n * 8;
+    uint64_t cur = (uint64_t)byte_pos * 8;
+    if (total - cur < 32) return SWC_E_BZIP2_WRONG_MAGIC;                         // :53
+    if (!(d[byte_pos] == 0x42 && d[byte_pos + 1] == 0x5A)) return SWC_E_BZIP2_WRONG_MAGIC;   // "BZ" :59-60
+    if (d[byte_pos + 2] != 104) return SWC_E_BZIP2_WRONG_VERSION;                  // 'h' :62-63
+    if (d[byte_pos + 3] < 0x31 || d[byte_pos + 3] > 0x39) return SWC_E_BZIP2_WRONG_BLOCK_SIZE;  // :65-66
+    cur += 32;
+    uint32_t total_crc = 0;
+    for (;;) {
+        if (total - cur < 80) return SWC_E_BZIP2_WRONG_MAGIC;                     // :71
+        const uint64_t type = read_bits(d, cur, 48);
+        const uint32_t crc = (uint32_t)read_bits(d, cur + 48, 32);
+        if (type == kBlockMagic) {
+            auto it = blocks.find(cur);
+            if (it == blocks.end()) return SWC_E_DEVICE;                           // cannot happen: every magic was scanned
+            const Decoded& b = it->second;
+            if (b.status != SWC_OK && b.status != SWC_E_BZIP2_WRONG_CRC) return b.status;
+            out.insert(out.end(), b.out.begin(), b.out.end());
+            if (b.status == SWC_E_BZIP2_WRONG_CRC) return SWC_E_BZIP2_WRONG_CRC;   // :81 carries everything so far
+            total_crc = (total_crc << 1) | (total_crc >> 31);                      // :83-84
+            total_crc ^= crc;
+            cur = b.end_bit;
+        } else if (type == kEosMagic) {
+            if (total_crc != crc) return SWC_E_BZIP2_WRONG_CRC;                    // :86
+            cur += 80;
+            break;
+        } else {
+            return SWC_E_BZIP2_WRONG_BLOCK_TYPE;                                   // :89
+        }
+    }
+    byte_pos = (size_t)((cur + 7) >> 3);
+    return SWC_OK;
+}
+
+// Decode every candidate block of `d` on the device in one batch.
+int decode_candidates(const uint8_t* d, size_t n, std::map<uint64_t, Decoded>& blocks) {
+    std::vector<uint64_t> cand;
+    scan_block_magics(d, n, 32, cand);
+    std::vector<HostUnit> units;
+    std::vector<uint64_t> used;
+    for (uint64_t c : cand) {
+        if ((uint64_t)n * 8 - c < 80) continue;                                    // the walk reports wrongMagic there
+        HostUnit u;
+        u.in = d;
+        u.in_len = n;
+        u.extra = c + 80;                                                         // bit offset of the block body
+        u.dict_value = read_bits(d, c + 48, 32);                                  // stored block CRC
+        u.cap_hint = std::min<size_t>(1000000, std::max<size_t>(65536, n * 16));
+        units.push_back(std::move(u));
+        used.push_back(c);
+    }
+    if (!units.empty()) {
+        int st = run_units(SWC_CODEC_BZIP2_BLOCK, units);
+        if (st) return st;
+    }
+    for (size_t i = 0; i < units.size(); i++) {
+        Decoded dec;
+        dec.status = units[i].status;
+        dec.out = std::move(units[i].out);
+        dec.end_bit = units[i].in_consumed;                                       // bits for this codec
+        blocks.emplace(used[i], std::move(dec));
+    }
+    return SWC_OK;
+}
+
+}  // namespace
+}  // namespace swc
+
+using namespace swc;
+
+extern "C" {
+
+int swc_bzip2_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t* in_consumed) {
+    if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
+    std::map<uint64_t, Decoded> blocks;
+    std::vector<uint8_t> res;
+    int st = decode_candidates(in, in_len, blocks);
+    if (st) { give_empty(out, out_len); return st; }
+    size_t pos = 0;
+    st = walk_stream(in, in_len, pos, blocks, res);
+    if (st != SWC_OK && st != SWC_E_BZIP2_WRONG_CRC) res.clear();                  // only wrongCRC carries data
+    if (in_consumed) *in_consumed = pos;
+    give(res, out, out_len);
+    return st;
+}
+
+int swc_bzip2_multi_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_streams) {
+    if (!out || !out_len || !sizes || !n_streams || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
+    std::map<uint64_t, Decoded> blocks;
+    std::vector<uint8_t> all;
+    std::vector<size_t> sz;
+    int st = decode_candidates(in, in_len, blocks);
+    if (st) { give_empty(out, out_len); *sizes = give_sizes(sz); *n_streams = 0; return st; }
+    size_t pos = 0;
+    while (pos < in_len) {                                                         // :43 !reader.isFinished
+        std::vector<uint8_t> one;
+        st = walk_stream(in, in_len, pos, blocks, one);
+        if (st == SWC_E_BZIP2_WRONG_CRC) { all = std::move(one); sz.assign(1, all.size()); break; }  // carries the failing archive only
+        if (st) { all.clear(); sz.clear(); break; }
+        sz.push_back(one.size());
+        all.insert(all.end(), one.begin(), one.end());
+    }
+    give(all, out, out_len);
+    *sizes = give_sizes(sz);
+    *n_streams = sz.size();
+    return st;
+}
+
+}  // extern "C"

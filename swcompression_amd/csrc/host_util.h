@@ -60,6 +60,7 @@ struct HostUnit {
     std::vector<uint8_t> out;
     size_t in_consumed = 0;
     int32_t status = SWC_OK;
+    int32_t aux_out = 0;         // codec specific result (bzip2: computed block CRC)
 };
 
 // Stage units to HBM, run ONE batched launch of `codec` (re-launching only the units that reported

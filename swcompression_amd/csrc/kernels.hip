@@ -12,6 +12,7 @@
 #include "inflate_lane.h"
 #include "lz4_lane.h"
 #include "lzma_wave.h"
+#include "bzip2_block.h"
 #include "launch.h"
 
 namespace swc {
@@ -99,6 +100,53 @@ hipError_t launch_lzma(bool lzma2, Job* jobs, size_t n, void* spill, hipStream_t
     dim3 grid((unsigned)n), block(kWave);
     if (lzma2) hipLaunchKernelGGL(swc_lzma_kernel<true>, grid, block, lzma::kLdsBytesPerWave, stream, jobs, (uint32_t)n, (uint8_t*)spill);
     else hipLaunchKernelGGL(swc_lzma_kernel<false>, grid, block, lzma::kLdsBytesPerWave, stream, jobs, (uint32_t)n, (uint8_t*)spill);
+    return hipGetLastError();
+}
+
+// ---- BZip2: three stages per block (see bzip2_block.h) ---------------------------------------------
+__global__ __launch_bounds__(64) void swc_bzip2_stage1_kernel(const Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t lcap) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t bz_lds[];
+    uint32_t g = blockIdx.x;
+    if (g >= n) return;
+    Job job = jobs[g];
+    bzip2::stage1_job<kWave>(job, reinterpret_cast<bzip2::Stage1Lds*>(bz_lds), bzip2::carve(ws, g, lcap), (int)threadIdx.x);
+}
+
+__global__ __launch_bounds__(64) void swc_bzip2_stage2_kernel(uint32_t n, uint8_t* ws, size_t lcap) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t bz_lds[];
+    uint32_t g = blockIdx.x;
+    if (g >= n) return;
+    bzip2::stage2_job<kWave>(bzip2::carve(ws, g, lcap), reinterpret_cast<uint32_t*>(bz_lds), (int)threadIdx.x);
+}
+
+__global__ __launch_bounds__(64) void swc_bzip2_stage3_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t lcap) {
+    __shared__ uint32_t crc_tab[256];
+    for (uint32_t i = threadIdx.x; i < 256; i += kWave) crc_tab[i] = bzip2::crc_table_entry(i);
+    __syncthreads();
+    uint32_t g = blockIdx.x * kWave + threadIdx.x;
+    if (g >= n) return;
+    Job job = jobs[g];
+    bzip2::stage3_job(job, bzip2::carve(ws, g, lcap), crc_tab);
+    jobs[g].out_len = job.out_len;
+    jobs[g].in_consumed = job.in_consumed;
+    jobs[g].status = job.status;
+    jobs[g].aux = job.aux;
+}
+
+size_t bzip2_ws_bytes_per_job(size_t lcap) { return bzip2::ws_bytes_per_job(lcap); }
+
+hipError_t launch_bzip2(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    if (!ws) return hipErrorInvalidValue;
+    const size_t per_job = ws_bytes / n;
+    const size_t fixed = 32768 + sizeof(bzip2::BlockHeader) + 64 + 16;
+    if (per_job <= fixed + 5 * 16) return hipErrorInvalidValue;
+    size_t lcap = (per_job - fixed) / 5;
+    if (lcap > 16000000) lcap = 16000000;  // i << 8 | c packing of stage 2
+    dim3 block(kWave);
+    hipLaunchKernelGGL(swc_bzip2_stage1_kernel, dim3((unsigned)n), block, bzip2::kStage1LdsBytes, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
+    hipLaunchKernelGGL(swc_bzip2_stage2_kernel, dim3((unsigned)n), block, 256 * kWave * 4, stream, (uint32_t)n, (uint8_t*)ws, lcap);
+    hipLaunchKernelGGL(swc_bzip2_stage3_kernel, dim3((unsigned)((n + kWave - 1) / kWave)), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
     return hipGetLastError();
 }
 

@@ -5,7 +5,5 @@
 using namespace swc;
 extern "C" {
 #define PENDING_OUT(out, out_len) do { give_empty(out, out_len); return SWC_E_DEVICE; } while (0)
-int swc_bzip2_decompress(const uint8_t*, size_t, uint8_t** out, size_t* out_len, size_t*) { PENDING_OUT(out, out_len); }
-int swc_bzip2_multi_decompress(const uint8_t*, size_t, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n) { *sizes = give_sizes({}); *n = 0; PENDING_OUT(out, out_len); }
 int swc_unarchive_many(int, const uint8_t* const*, const size_t*, size_t, uint8_t**, size_t*, int32_t*) { return SWC_E_DEVICE; }
 }

@@ -80,3 +80,8 @@ def lzma(inputs, caps, props, dict_sizes, sizes):
     aux = [lc | (lp << 8) | (pb << 16) for lc, lp, pb in props]
     extra = [s & 0xFFFFFFFFFFFFFFFF for s in sizes]
     return run_batch("emu_lzma", inputs, caps, aux=aux, extra=extra, fn_args=(C.c_int(0),), dict_ptr_values=dict_sizes)
+
+
+def bzip2_block(streams, body_bits, crcs, caps, lcap=1000000):
+    """One bzip2 block per job: `streams[i]` is the whole stream, body_bits[i] the bit offset of the block body."""
+    return run_batch("emu_bzip2_block", streams, caps, extra=body_bits, dict_ptr_values=crcs, fn_args=(C.c_size_t(lcap),))

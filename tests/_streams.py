@@ -324,3 +324,45 @@ def lzma_raw_fuzz(seed=13, n_random=300):
         props = rnd.choice([(3, 0, 2), (8, 4, 4), (0, 0, 0), (4, 4, 0), (8, 0, 4), (2, 3, 1)])
         ins.append((body, props, rnd.choice([1 << 16, 4096, 50]), rnd.choice([-1, 20, 200, 0])))
     return ins
+
+
+# ------------------------------------------------------------------------------------------- BZip2
+def bzip2_valid(seed=7):
+    """(stream, plain): single- and multi-block streams of every payload class."""
+    import bz2
+    out = []
+    for kind in ("text", "rep", "zero", "rand", "mix"):
+        for n, level in ((1, 9), (100, 1), (5000, 5), (70000, 1), (300000, 1), (300000, 9)):
+            x = corpus.PAYLOADS[kind](n, seed)
+            out.append((bz2.compress(x, level), x))
+    out.append((bz2.compress(b"", 9), b""))
+    out.append((bz2.compress(bytes(range(256)) * 40, 9), bytes(range(256)) * 40))
+    out.append((bz2.compress(b"\x00\x01\x00\x01\x00\x00\x01\x00\x01", 9), b"\x00\x01\x00\x01\x00\x00\x01\x00\x01"))  # BZip2CompressionTests.swift:87-95
+    return out
+
+
+def bzip2_fuzz(seed=17, per_base=20, n_random=300):
+    import bz2
+    rnd = random.Random(seed)
+    ins = []
+    base = [bz2.compress(corpus.PAYLOADS[k](n, 3), 1) for k in ("text", "rep", "mix", "rand") for n in (40, 700, 6000)]
+    for z in base:
+        for _ in range(per_base):
+            b = bytearray(z)
+            m = rnd.randrange(5)
+            if m == 0:
+                b = b[:rnd.randrange(0, len(b))]
+            elif m == 1:
+                b[rnd.randrange(min(len(b), 40))] ^= 1 << rnd.randrange(8)
+            elif m == 2:
+                for _ in range(rnd.randrange(1, 3)):
+                    b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+            elif m == 3:
+                b[rnd.randrange(14, max(15, len(b) - 10))] ^= 1 << rnd.randrange(8)
+            else:
+                b += bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 20)))
+            ins.append(bytes(b))
+    for _ in range(n_random):
+        body = bytes(rnd.randrange(256) for _ in range(rnd.randrange(0, 90)))
+        ins.append(b"BZh9" + bytes.fromhex("314159265359") + body if rnd.random() < 0.8 else body)
+    return ins

@@ -8,6 +8,7 @@
 #include "../../swcompression_amd/csrc/inflate_lane.h"
 #include "../../swcompression_amd/csrc/lz4_lane.h"
 #include "../../swcompression_amd/csrc/lzma_wave.h"
+#include "../../swcompression_amd/csrc/bzip2_block.h"
 
 extern "C" void emu_inflate(swc::Job* jobs, size_t n) {
     std::vector<uint32_t> lds(swc::inflate::kWordsPerLane * swc::kWave);
@@ -31,5 +32,22 @@ extern "C" void emu_lzma(swc::Job* jobs, size_t n, int is_lzma2) {
     for (size_t g = 0; g < n; g++) {
         std::fill(probs.begin(), probs.end(), (uint16_t)0xBEEF);
         swc::lzma::lzma_job<1>(jobs[g], is_lzma2 != 0, probs.data(), spill.data(), 0);
+    }
+}
+
+// BZip2: the three stages run back to back for each job, single logical lane (WAVE = 1).
+extern "C" void emu_bzip2_block(swc::Job* jobs, size_t n, size_t lcap) {
+    using namespace swc::bzip2;
+    std::vector<uint8_t> ws(ws_bytes_per_job(lcap) + 64);
+    std::vector<uint32_t> cnt(256), crc(256);
+    for (uint32_t i = 0; i < 256; i++) crc[i] = crc_table_entry(i);
+    Stage1Lds lds;
+    for (size_t g = 0; g < n; g++) {
+        std::memset(&lds, 0xEE, sizeof lds);
+        std::fill(ws.begin(), ws.end(), (uint8_t)0xCD);
+        Workspace w = carve(ws.data(), 0, lcap);
+        stage1_job<1>(jobs[g], &lds, w, 0);
+        stage2_job<1>(w, cnt.data(), 0);
+        stage3_job(jobs[g], w, crc.data());
     }
 }

@@ -1,0 +1,74 @@
+"""GPU tier: BZip2 through the C ABI on the MI355X vs the oracle (reference Sources/BZip2)."""
+import bz2
+import random
+
+import numpy as np
+import pytest
+
+import _oracle as O
+import _streams as S
+import swcompression_amd as swc
+from swcompression_amd import corpus
+from swcompression_amd.batch import DeviceBatch
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(data):
+    st, out, cons = O.bzip2(data)
+    if st == 0:
+        assert swc.BZip2.decompress(data) == out
+    else:
+        with pytest.raises(swc.SWCError) as ei:
+            swc.BZip2.decompress(data)
+        assert ei.value.status == st, data[:24].hex()
+        if st == 210:
+            assert ei.value.data == out                                   # wrongCRC carries the output so far
+
+
+def test_valid_streams_single_and_multi_block():
+    for z, x in S.bzip2_valid():
+        assert swc.BZip2.decompress(z) == x
+
+
+def test_fuzz_same_status_as_reference():
+    O.lib.refcpu_set_max_output(1 << 24)
+    for z in S.bzip2_fuzz():
+        if O.bzip2(z)[0] != 901:
+            _same(z)
+    O.lib.refcpu_set_max_output(1 << 30)
+
+
+def test_trivial_inputs_and_crc_errors():
+    for data in (b"", b"\x00", bytes(1 << 16)):
+        _same(data)                                                       # BZip2Tests.swift:61-79
+    x = corpus.p_text(250000, 2)
+    z = bytearray(bz2.compress(x, 1))                                     # 3 blocks
+    z[10] ^= 1                                                            # first block's stored CRC
+    with pytest.raises(swc.BZip2Error) as ei:
+        swc.BZip2.decompress(bytes(z))
+    assert ei.value.case == "wrongCRC" and ei.value.data == O.bzip2(bytes(z))[1] and len(ei.value.data) > 0
+    z = bytearray(bz2.compress(x, 1)); z[-1] ^= 0x10                      # combined CRC at the end
+    _same(bytes(z))
+
+
+def test_multi_stream():
+    x = corpus.p_text(5000, 4)
+    two = bz2.compress(x[:10]) + bz2.compress(x[10:])
+    assert swc.BZip2.multi_decompress(two) == [x[:10], x[10:]] == O.bzip2_multi(two)[1]
+    assert swc.BZip2.decompress(two) == x[:10]                            # decompress(data:) stops after the first stream (App. A B8)
+
+
+def test_config4_shape_900k_blocks():
+    """BASELINE.json config 4 shape at reduced count: level-9 streams of one ~900 kB block each, decoded as ONE batch."""
+    n = 48
+    plains = [corpus.p_text(899000, 500 + i) for i in range(n)]
+    streams = [bz2.compress(p, 9) for p in plains]
+    assert all(s.count(bytes.fromhex("314159265359")) >= 1 for s in streams)
+    b = DeviceBatch("bzip2_block", streams, [899000 + 64] * n, extra=[112] * n,
+                    dict_values=[int.from_bytes(s[10:14], "big") for s in streams])
+    b.launch(sync=True)
+    r = b.results()
+    assert (r["status"] == 0).all() and (r["out_len"] == 899000).all()
+    for i in range(n):
+        assert b.output(i, 899000) == plains[i]

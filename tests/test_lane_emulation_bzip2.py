@@ -1,0 +1,65 @@
+"""CPU tier: the three BZip2 device stages (swcompression_amd/csrc/bzip2_block.h) built for the host vs the
+oracle (reference Sources/BZip2/BZip2.swift, BurrowsWheeler.swift).  The stages decode ONE block; stream
+walking lives in the C++ host framing and is covered by the GPU tier through the C ABI, so here single-block
+streams are used and only block-level outcomes are compared."""
+import random
+
+import _emu as E
+import _oracle as O
+import _streams as S
+
+BLOCK_LEVEL = {205, 206, 207, 208, 209, 900}
+
+
+def _single_block(stream):
+    return stream[4:10] == bytes.fromhex("314159265359")
+
+
+def test_valid_single_block_streams():
+    cases = [(z, x) for z, x in S.bzip2_valid() if _single_block(z) and z.count(bytes.fromhex("314159265359")) == 1 and len(x) <= 100000 or len(x) == 300000 and z[3:4] == b"9"]
+    assert len(cases) >= 15
+    res = E.bzip2_block([z for z, _ in cases], [112] * len(cases), [int.from_bytes(z[10:14], "big") for z, _ in cases],
+                        [max(len(x), 1) for _, x in cases])
+    for r, (z, x) in zip(res, cases):
+        assert r[:2] == (0, x)
+        assert O.bzip2(z)[:2] == (0, x)
+
+
+def test_body_fuzz_block_level_outcomes():
+    O.lib.refcpu_set_max_output(1 << 24)
+    rnd = random.Random(23)
+    import bz2
+    from swcompression_amd import corpus
+    base = [bz2.compress(corpus.PAYLOADS[k](n, 3), 9) for k in ("text", "rep", "mix", "rand", "zero") for n in (40, 700, 6000, 40000)]
+    ins = []
+    for z in base:
+        for _ in range(30):
+            b = bytearray(z)
+            for _ in range(rnd.randrange(1, 3)):
+                b[rnd.randrange(14, len(b) - 10)] ^= 1 << rnd.randrange(8)
+            ins.append(bytes(b))
+        for _ in range(10):
+            ins.append(z[:rnd.randrange(15, len(z))])
+    exp = [O.bzip2(z) for z in ins]
+    res = E.bzip2_block(ins, [112] * len(ins), [int.from_bytes(z[10:14], "big") for z in ins], [1 << 20] * len(ins), lcap=1 << 20)
+    checked = 0
+    for r, e, z in zip(res, exp, ins):
+        if e[0] in BLOCK_LEVEL:
+            assert r[0] == e[0], z[:24].hex()
+            checked += 1
+        elif e[0] == 0:
+            assert r[:2] == (0, e[1])
+            checked += 1
+        elif e[0] == 210 and r[0] == 210:
+            assert r[1] == e[1]
+            checked += 1
+    assert checked > len(ins) // 2
+    O.lib.refcpu_set_max_output(1 << 30)
+
+
+def test_capacity_reports_required_size():
+    cases = [(z, x) for z, x in S.bzip2_valid() if _single_block(z) and 5000 <= len(x) <= 100000][:6]
+    res = E.bzip2_block([z for z, _ in cases], [112] * len(cases), [int.from_bytes(z[10:14], "big") for z, _ in cases],
+                        [len(x) // 2 for _, x in cases])
+    for r, (z, x) in zip(res, cases):
+        assert r[0] == 901 and r[3] == len(x) and r[1] == x[:len(x) // 2]
