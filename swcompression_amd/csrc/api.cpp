@@ -5,6 +5,7 @@
 #include <algorithm>
 #include <map>
 #include <mutex>
+#include <vector>
 #include <string.h>
 #include "host_util.h"
 #include "launch.h"
@@ -34,7 +35,7 @@ bool device_ready() {
 
 static hipError_t launch_codec(int codec, Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {
     switch (codec) {
-        case SWC_CODEC_DEFLATE: return launch_inflate(jobs, n, stream);
+        case SWC_CODEC_DEFLATE: return launch_inflate(jobs, n, ws, ws_bytes, stream);
         case SWC_CODEC_LZ4_BLOCK: return launch_lz4(jobs, n, stream);
         case SWC_CODEC_LZMA2: return launch_lzma(true, jobs, n, ws_bytes >= n * lzma_spill_bytes_per_job() ? ws : nullptr, stream);
         case SWC_CODEC_LZMA: return launch_lzma(false, jobs, n, ws_bytes >= n * lzma_spill_bytes_per_job() ? ws : nullptr, stream);
@@ -61,7 +62,7 @@ int run_units(int codec, std::vector<HostUnit>& units) {
     std::vector<size_t> cap(n);
     for (size_t i = 0; i < n; i++) cap[i] = default_cap(codec, units[i]);
 
-    bool want_ws = codec == SWC_CODEC_BZIP2_BLOCK;  // LZMA: only after a unit reported SWC_E_NEED_WORKSPACE
+    bool want_ws = codec == SWC_CODEC_BZIP2_BLOCK || codec == SWC_CODEC_DEFLATE;  // LZMA: only after a unit reported SWC_E_NEED_WORKSPACE
     for (int round = 0; round < 12 && !pending.empty(); round++) {
         const size_t m = pending.size();
         std::vector<size_t> in_off(m), out_off(m), dict_off(m);
@@ -151,8 +152,8 @@ extern "C" {
 
 int swc_set_tuning(const char* key, int value) {
     if (!key) return SWC_E_INVALID_ARGUMENT;
-    if (!strcmp(key, "inflate_lanes_per_stream") && (value == 1 || value == 2 || value == 4)) { set_inflate_group(value); return SWC_OK; }
-    if (!strcmp(key, "inflate_debug_mode") && value >= 0 && value <= 2) { set_inflate_debug(value); return SWC_OK; }
+    if (!strcmp(key, "resolve_threads") && (value == 64 || value == 128 || value == 256 || value == 512 || value == 1024)) { set_resolve_threads(value); return SWC_OK; }
+    if (!strcmp(key, "resolve_debug") && value >= 0 && value < 32) { set_resolve_debug(value); return SWC_OK; }  // timing experiments only
     return SWC_E_INVALID_ARGUMENT;
 }
 
@@ -166,6 +167,7 @@ size_t swc_batch_workspace_bytes(int codec, size_t n_jobs, uint64_t max_out_cap)
         case SWC_CODEC_LZMA:
         case SWC_CODEC_LZMA2: return n_jobs * lzma_spill_bytes_per_job();  // optional: only streams with lc+lp > 4 use it
         case SWC_CODEC_BZIP2_BLOCK: return n_jobs * bzip2_ws_bytes_per_job((size_t)max_out_cap + 64);  // L is never longer than the output
+        case SWC_CODEC_DEFLATE: return n_jobs * inflate_ws_bytes_per_job(max_out_cap);  // match records of phase 1 (lz_resolve.h)
         default: return 0;
     }
 }
@@ -185,6 +187,25 @@ int swc_batch_decompress_ws(int codec, swc_job* jobs, size_t n, void* workspace,
 
 int swc_batch_decompress(int codec, swc_job* jobs, size_t n, const swc_batch_opts* opts) {
     if (codec == SWC_CODEC_BZIP2_BLOCK) return SWC_E_INVALID_ARGUMENT;  // needs the workspace: use swc_batch_decompress_ws
+    if (codec == SWC_CODEC_DEFLATE && n) {
+        // Deflate needs the match-record workspace; size it from the largest capacity in the batch and let the
+        // stream-ordered allocator own it for the duration of the launch.
+        if (!device_ready()) return SWC_E_DEVICE;
+        if (!jobs) return SWC_E_INVALID_ARGUMENT;
+        if (opts && opts->device >= 0 && hipSetDevice(opts->device) != hipSuccess) return SWC_E_DEVICE;
+        hipStream_t stream = opts ? static_cast<hipStream_t>(opts->stream) : nullptr;
+        std::vector<swc_job> host(n);
+        if (hipMemcpyAsync(host.data(), jobs, n * sizeof(swc_job), hipMemcpyDeviceToHost, stream) != hipSuccess) return SWC_E_DEVICE;
+        if (hipStreamSynchronize(stream) != hipSuccess) return SWC_E_DEVICE;
+        uint64_t max_cap = 0;
+        for (size_t i = 0; i < n; i++) max_cap = std::max<uint64_t>(max_cap, host[i].out_cap);
+        size_t ws_bytes = swc_batch_workspace_bytes(codec, n, max_cap);
+        void* ws = nullptr;
+        if (hipMallocAsync(&ws, ws_bytes, stream) != hipSuccess) { (void)hipGetLastError(); return SWC_E_DEVICE; }
+        int st = swc_batch_decompress_ws(codec, jobs, n, ws, ws_bytes, opts);
+        (void)hipFreeAsync(ws, stream);
+        return st;
+    }
     return swc_batch_decompress_ws(codec, jobs, n, nullptr, 0, opts);
 }
 

@@ -28,6 +28,7 @@
 #define SWC_INFLATE_LANE_H
 
 #include "swc_common.h"
+#include "lz_resolve.h"
 
 namespace swc {
 namespace inflate {
@@ -168,9 +169,8 @@ SWC_HD void clear_slots(const LaneLds& l, int wlen) {
     for (int d = 0; d <= MAXD + 1; d++) l.set(wlen + d, 0);
 }
 
-// DBG != 0 builds timing-only variants for on-GPU experiments (results are wrong by design):
-//   1 = history loads replaced by constants, 2 = additionally no output stores.
-template <int DBG = 0>
+// Phase 1 of the two-phase Deflate path (see lz_resolve.h): literals go straight to their final position,
+// every match becomes one record of the stream's record list; the output buffer is never read here.
 struct Lane {
     LaneLds l;
     BitReader br;
@@ -178,6 +178,28 @@ struct Lane {
     gptr out;
     uint64_t cap;
     uint64_t pos;  // bytes produced (keeps counting past cap: size pass for SWC_E_CAPACITY)
+    SWC_AS_GLOBAL uint32_t* recs;  // record list in the HBM workspace
+    uint32_t nrec, max_rec;
+    uint64_t last_end;             // position just past the previous record
+
+    SWC_HD void push(uint32_t v) {
+        if (nrec < max_rec) recs[nrec] = v;
+        nrec++;
+    }
+    // Deflate.swift:216-232 deferred: record (literal run, length, distance); phase 2 executes the copy.
+    SWC_HD void emit_match(uint32_t length, uint32_t distance) {
+        if (pos < cap) {  // records exist only for matches that start below the capacity
+            uint64_t run = pos - last_end;
+            while (run >= 255) {
+                uint32_t s = run > lzr::kMaxSkip ? lzr::kMaxSkip : (uint32_t)run;
+                push(lzr::kSkipFlag | s);
+                run -= s;
+            }
+            push(lzr::make_match((uint32_t)run, length, distance));
+            last_end = pos + length;
+        }
+        pos += length;
+    }
 
     // Decode one symbol of the lit/len (LIT=true) or distance alphabet.  Returns the symbol or
     // -1 (DeflateError.symbolNotFound: unassigned path, or the code runs past the end of input).
@@ -336,38 +358,17 @@ struct Lane {
         pos++;
     }
 
-    // Deflate.swift:171-236.  Literal stores and LZ77 copies are interleaved as a two-state machine
-    // so that, within a wave, lanes that are mid-copy do not stall lanes that are decoding.
+    // Deflate.swift:171-236
     SWC_HD int run_block() {
-        uint32_t crem = 0, cdist = 0;
         // ---- interior fast loop: >= 8 input bytes beyond the read-ahead and >= 272 output bytes of
         // room, code sets not over-subscribed => no truncation / capacity / exact-lookup checks.
         if (!lit.oversub && !dist.oversub) {
             while ((uint64_t)br.ppos + 8 <= br.len && pos + 272 <= cap) {
-                if (crem != 0) {
-                    if (DBG == 0) {
-                        if (cdist >= 16) {  // both source words precede the destination: issue both loads, one wait
-                            uint64_t a = load_u64(out + pos - cdist), b = load_u64(out + pos + 8 - cdist);
-                            store_u64(out + pos, a);
-                            store_u64(out + pos + 8, b);
-                        } else {
-                            store_u64(out + pos, load_u64(out + pos - cdist));
-                            if (crem > 8) store_u64(out + pos + 8, load_u64(out + pos + 8 - cdist));
-                        }
-                    } else if (DBG == 1) {
-                        store_u64(out + pos, cdist);
-                        if (crem > 8) store_u64(out + pos + 8, cdist);
-                    }
-                    uint32_t n = crem < 16 ? crem : 16;
-                    pos += n;
-                    crem -= n;
-                    if (crem != 0) continue;
-                }
                 br.refill_fast();
                 int sym = decode_sym<true, false>();
                 if (sym < 0) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;
                 if (sym < 256) {
-                    if (DBG < 2) out[pos] = (uint8_t)sym;
+                    out[pos] = (uint8_t)sym;
                     pos++;
                     continue;
                 }
@@ -383,38 +384,11 @@ struct Lane {
                 uint32_t de = dc < 4 ? 0u : ((uint32_t)dc >> 1) - 1u;
                 uint32_t distance = (dc < 4 ? 1u + (uint32_t)dc : 1u + ((2u + ((uint32_t)dc & 1u)) << de)) + br.bits(de);
                 if ((uint64_t)distance > pos) return SWC_E_REF_TRAP;
-                if (distance >= 8) {
-                    crem = length;
-                    cdist = distance;
-                } else {
-                    uint32_t sh = 8 * distance;
-                    uint64_t w = (DBG == 0 ? load_u64(out + pos - distance) : (uint64_t)distance) & ((1ull << sh) - 1ull);
-                    w |= w << sh;
-                    sh *= 2;
-                    if (sh < 64) { w |= w << sh; sh *= 2; }
-                    if (sh < 64) w |= w << sh;
-                    if (DBG < 2) store_u64(out + pos, w);
-                    uint32_t n = length < 8 ? length : 8;
-                    pos += n;
-                    crem = length - n;
-                    cdist = ((7u + distance) / distance) * distance;
-                }
+                emit_match(length, distance);
             }
         }
         // ---- careful loop: stream tail, output tail, over-subscribed sets, size-counting mode
         for (;;) {
-            if (crem != 0) {
-                uint32_t n = crem < 8 ? crem : 8;
-                if (pos + 8 <= cap) {
-                    store_u64(out + pos, load_u64(out + pos - cdist));
-                } else {
-                    for (uint32_t i = 0; i < n; i++)
-                        if (pos + i < cap) out[pos + i] = out[pos + i - cdist];
-                }
-                pos += n;
-                crem -= n;
-                continue;
-            }
             br.refill();
             int sym = decode_sym<true>();
             if (sym < 0) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :175
@@ -448,30 +422,7 @@ struct Lane {
             }
             // :216-221 out[count - distance] with distance > count is a Swift trap (App. A6)
             if ((uint64_t)distance > pos) return SWC_E_REF_TRAP;
-            if (distance >= 8) {
-                crem = length;
-                cdist = distance;
-            } else {
-                // overlapping copy: replicate the `distance`-byte pattern into 8 bytes, then continue
-                // as a plain copy at the smallest multiple of `distance` that is >= 8.
-                uint32_t n = length < 8 ? length : 8;
-                if (pos + 8 <= cap) {
-                    uint32_t sh = 8 * distance;
-                    uint64_t w = load_u64(out + pos - distance) & ((1ull << sh) - 1ull);
-                    w |= w << sh;
-                    sh *= 2;
-                    if (sh < 64) { w |= w << sh; sh *= 2; }
-                    if (sh < 64) w |= w << sh;
-                    store_u64(out + pos, w);
-                } else {
-                    for (uint32_t i = 0; i < n; i++)
-                        if (pos + i < cap) out[pos + i] = out[pos + i - distance];
-                }
-                pos += n;
-                crem = length - n;
-                uint32_t k = (7u + distance) / distance;  // ceil(8 / distance)
-                cdist = k * distance;
-            }
+            emit_match(length, distance);
         }
     }
 
@@ -523,14 +474,18 @@ struct Lane {
     }
 };
 
-// One lane = one job.  `lds` is this lane's view of the wave's table region.
-template <int DBG = 0>
-SWC_HD void inflate_job(Job& job, LaneLds lds) {
-    Lane<DBG> ln;
+// One lane = one job.  `lds` is this lane's view of the wave's table region; `ws` / `ws_bytes` the
+// stream's area in the HBM workspace (lzr::StreamHeader + records).
+SWC_HD void inflate_job(Job& job, LaneLds lds, uint8_t* ws, size_t ws_bytes) {
+    Lane ln;
     ln.l = lds;
     ln.out = (gptr)job.out;
     ln.cap = job.out_cap;
     ln.pos = 0;
+    ln.nrec = 0;
+    ln.last_end = 0;
+    ln.recs = (SWC_AS_GLOBAL uint32_t*)(ws + sizeof(lzr::StreamHeader));
+    ln.max_rec = ws && ws_bytes > sizeof(lzr::StreamHeader) ? (uint32_t)((ws_bytes - sizeof(lzr::StreamHeader)) / 4) : 0u;
     int st;
     if (job.in_len > 0xFFFFFFF0ull) {
         st = SWC_E_INVALID_ARGUMENT;  // streams are addressed with 32-bit byte offsets on device
@@ -539,7 +494,12 @@ SWC_HD void inflate_job(Job& job, LaneLds lds) {
         ln.br.init((gcptr)job.in, (uint32_t)job.in_len, 0);
         st = ln.run();
     }
+    if (ln.nrec > ln.max_rec) {
+        st = SWC_E_NEED_WORKSPACE;  // the record list outgrew the workspace (sized from out_cap)
+        ln.nrec = ln.max_rec;
+    }
     if (st == SWC_OK && ln.pos > ln.cap) st = SWC_E_CAPACITY;
+    if (ws && ws_bytes >= sizeof(lzr::StreamHeader)) ((SWC_AS_GLOBAL lzr::StreamHeader*)ws)->nrec = ln.nrec;
     uint64_t bits = ln.br.consumed_bits();
     uint64_t consumed = (bits + 7) >> 3;  // callers align() right after (GzipArchive.swift:89)
     job.in_consumed = consumed > job.in_len ? job.in_len : consumed;

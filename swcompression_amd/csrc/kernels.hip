@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 #include "swc_common.h"
 #include "inflate_lane.h"
+#include "lz_resolve.h"
 #include "lz4_lane.h"
 #include "lzma_wave.h"
 #include "bzip2_block.h"
@@ -17,41 +18,49 @@
 
 namespace swc {
 
-// ---- Deflate --------------------------------------------------------------------------------
-// LDS: 152 words/lane -> 38,912 B per wave -> 4 resident waves per CU (160 KiB LDS).
-// G lanes execute each stream redundantly (identical registers, shared LDS tables): G x fewer streams per
-// wave, G x less LDS per wave, so G x more resident waves per SIMD to hide latency.
-template <int G, int DBG>
-__global__ __launch_bounds__(64, 1) void swc_inflate_kernel(Job* __restrict__ jobs, uint32_t n) {
+// ---- Deflate: two phases (inflate_lane.h, lz_resolve.h) ------------------------------------------------
+// Phase 1: one stream per lane.  LDS: 152 words/lane -> 38,912 B per wave -> 4 resident waves per CU.
+// Literals are stored in place, matches become records in the workspace; no output reads.
+__global__ __launch_bounds__(64, 1) void swc_inflate_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    constexpr int kStreams = kWave / G;
-    uint32_t sl = threadIdx.x / G;
-    uint32_t g = blockIdx.x * kStreams + sl;
+    uint32_t g = blockIdx.x * kWave + threadIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
-    inflate::inflate_job<DBG>(job, LaneLds{lds + sl, kStreams});
-    if (threadIdx.x % G == 0) {
-        jobs[g].out_len = job.out_len;
-        jobs[g].in_consumed = job.in_consumed;
-        jobs[g].status = job.status;
-    }
+    inflate::inflate_job(job, LaneLds{lds + threadIdx.x, kWave}, ws ? ws + (size_t)g * ws_stride : nullptr, ws_stride);
+    jobs[g].out_len = job.out_len;
+    jobs[g].in_consumed = job.in_consumed;
+    jobs[g].status = job.status;
 }
 
-static int g_inflate_g = 1, g_inflate_dbg = 0;
-void set_inflate_group(int g) { g_inflate_g = g; }
-void set_inflate_debug(int m) { g_inflate_dbg = m; }
+// Phase 2: one stream per workgroup of T threads, 64 KiB LDS ring -> 2 workgroups per CU.
+template <int T>
+__global__ __launch_bounds__(T) void swc_lz_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, const uint8_t* ws, size_t ws_stride, int dbg) {
+    __shared__ __attribute__((aligned(16))) lzr::Lds<T> lzr_lds;  // static: > 64 KiB needs no opt-in this way
+    uint32_t g = blockIdx.x;
+    if (g >= n) return;
+    Job job = jobs[g];
+    lzr::resolve_job<T>(job, ws + (size_t)g * ws_stride, &lzr_lds, (int)threadIdx.x, dbg);
+}
 
-hipError_t launch_inflate(Job* jobs, size_t n, hipStream_t stream) {
+static int g_resolve_threads = 256, g_resolve_dbg = 0;
+void set_resolve_debug(int m) { g_resolve_dbg = m; }
+void set_resolve_threads(int t) { g_resolve_threads = t; }
+size_t inflate_ws_bytes_per_job(uint64_t cap) { return lzr::ws_bytes_per_job(cap); }
+
+hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    const int G = g_inflate_g;
-    const unsigned streams = kWave / G;
-    dim3 grid((unsigned)((n + streams - 1) / streams)), block(kWave);
-    size_t lds = inflate::kLdsBytesPerWave;
-    if (g_inflate_dbg == 1) hipLaunchKernelGGL((swc_inflate_kernel<1, 1>), grid, block, lds, stream, jobs, (uint32_t)n);
-    else if (g_inflate_dbg == 2) hipLaunchKernelGGL((swc_inflate_kernel<1, 2>), grid, block, lds, stream, jobs, (uint32_t)n);
-    else if (G == 1) hipLaunchKernelGGL((swc_inflate_kernel<1, 0>), grid, block, lds, stream, jobs, (uint32_t)n);
-    else if (G == 2) hipLaunchKernelGGL((swc_inflate_kernel<2, 0>), grid, block, lds / 2, stream, jobs, (uint32_t)n);
-    else hipLaunchKernelGGL((swc_inflate_kernel<4, 0>), grid, block, lds / 4, stream, jobs, (uint32_t)n);
+    size_t stride = ws ? (ws_bytes / n) & ~(size_t)15 : 0;
+    if (stride < sizeof(lzr::StreamHeader)) return hipErrorInvalidValue;
+    dim3 grid((unsigned)((n + kWave - 1) / kWave)), block(kWave);
+    hipLaunchKernelGGL(swc_inflate_kernel, grid, block, inflate::kLdsBytesPerWave, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride);
+    dim3 grid2((unsigned)n);
+    switch (g_resolve_threads) {
+        case 64: hipLaunchKernelGGL(swc_lz_resolve_kernel<64>, grid2, dim3(64), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
+        case 128: hipLaunchKernelGGL(swc_lz_resolve_kernel<128>, grid2, dim3(128), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
+        case 512: hipLaunchKernelGGL(swc_lz_resolve_kernel<512>, grid2, dim3(512), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
+        case 1024: hipLaunchKernelGGL(swc_lz_resolve_kernel<1024>, grid2, dim3(1024), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
+        default: hipLaunchKernelGGL(swc_lz_resolve_kernel<256>, grid2, dim3(256), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
+    }
     return hipGetLastError();
 }
 

@@ -4,13 +4,14 @@
 #include <hip/hip_runtime.h>
 #include "swc_common.h"
 namespace swc {
-hipError_t launch_inflate(Job* jobs, size_t n, hipStream_t stream);
+hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream);
+size_t inflate_ws_bytes_per_job(uint64_t cap);
+void set_resolve_threads(int t);
+void set_resolve_debug(int m);
 hipError_t launch_lz4(Job* jobs, size_t n, hipStream_t stream);
 hipError_t launch_lzma(bool lzma2, Job* jobs, size_t n, void* spill, hipStream_t stream);
 size_t lzma_spill_bytes_per_job();
 hipError_t launch_bzip2(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t bzip2_ws_bytes_per_job(size_t lcap);
-void set_inflate_group(int g);
-void set_inflate_debug(int m);
 }
 #endif

@@ -1,0 +1,479 @@
+// lz_resolve.h -- phase 2 of the Deflate path: LZ77 match resolution, one stream per WORKGROUP, with the
+// sliding window held in LDS.
+//
+// The reference executes every back-reference inline, one byte per `out.append`
+// (Sources/Deflate/Deflate.swift:216-232).  On the MI355X the entropy decode and the copy are split:
+//
+//   phase 1 (inflate_lane.h, one stream per lane) decodes the Huffman symbols, stores every LITERAL at its
+//           final position in the output buffer and appends one 32-bit record per MATCH to the stream's
+//           record list in the HBM workspace -- it never reads the output, so the tens of thousands of
+//           streams that must be in flight to hide the decode latency no longer keep 32 KiB windows alive
+//           in L2 / Infinity Cache (measured before the split: HBM traffic 9-28x the algorithmic bytes,
+//           78 % of wave time in s_waitcnt; profiles/r01_pmc_deflate_lane_per_stream.txt);
+//   phase 2 (this file, one stream per workgroup of T threads) walks the record list in batches of T records:
+//           a workgroup prefix-scan turns (literal run, length) into output positions, the batch's output
+//           span is staged HBM -> LDS with coalesced 16-byte loads, every thread executes one match inside
+//           the 64 KiB LDS ring (dependent matches wait for their producers through a done-bitmap, in
+//           rounds), and the finished span is written back with coalesced 16-byte stores.
+//
+// Record format (u32):  bit 31 = 0:  lit_run[0..7] | (length - 3)[8..15] | (distance - 1)[16..30]
+//                       bit 31 = 1:  skip[0..30]  -- `skip` more literal bytes precede the next record
+// lit_run = literal bytes between the end of the previous record and this match (< 255; longer runs
+// are preceded by skip records).  Records exist only for matches that START below the output capacity.
+//
+// The same source compiles for the host with T = 1 (tests/host_emu): batches of one record.
+#ifndef SWC_LZ_RESOLVE_H
+#define SWC_LZ_RESOLVE_H
+
+#include "swc_common.h"
+
+namespace swc {
+namespace lzr {
+
+constexpr uint32_t kRingBytes = 65536;
+constexpr uint32_t kRingMask = kRingBytes - 1;
+constexpr uint32_t kSpan = 16384;          // output bytes one batch may cover; ring = 32 KiB window + span + slack
+constexpr uint32_t kSkipFlag = 0x80000000u;
+constexpr uint32_t kMaxSkip = 0x7FFFFFFFu;
+
+// Per-stream area in the workspace: 16-byte header, then the records.
+struct StreamHeader {
+    uint32_t nrec;
+    uint32_t pad[3];
+};
+// Records a stream of capacity `cap` can need: one per match (>= 3 output bytes each, started below cap)
+// plus one skip per >= 255 literal bytes, plus slack.
+SWC_HD size_t max_records(uint64_t cap) { return (size_t)(cap / 3 + cap / 255 + 8); }
+SWC_HD size_t ws_bytes_per_job(uint64_t cap) { return (sizeof(StreamHeader) + max_records(cap) * 4 + 15) & ~(size_t)15; }
+
+SWC_HD uint32_t make_match(uint32_t lit_run, uint32_t length, uint32_t distance) { return lit_run | ((length - 3u) << 8) | ((distance - 1u) << 16); }
+
+constexpr uint32_t kReadAhead = 8192;      // literal bytes staged ahead of the batch being resolved
+
+template <int T>
+struct Lds {
+    uint8_t ring[kRingBytes];
+    uint32_t ends[T + 1];                // end of record i, relative to the batch start (0xFFFFFFFF: no record)
+    uint32_t dsts[T];                    // start of match i, relative to the batch start (== ends[i] for skips)
+    uint64_t link[T];                    // (source position relative to the batch start : i32) | (producer : i32) << 32
+    uint32_t periods[T];                 // distance of match i
+    uint32_t done[(T + 31) / 32];
+    uint32_t wave_sum[T / 64 + 1];
+    uint32_t ntake, span;
+};
+
+// Workgroup-collective helpers.  Device: T threads, barriers.  Host emulation: T == 1.
+template <int T>
+struct Group {
+    int tid;
+    Lds<T>* l;
+
+    // Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, which would expose the latency of
+    // the record / literal read-ahead loads and of the write-back stores at every barrier; no thread of the group
+    // ever reads HBM bytes another thread of the group wrote, so LDS ordering is all the resolver needs.
+    SWC_D void sync() const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+    }
+    // inclusive prefix sum over the workgroup (sums stay below 2^32: callers clamp their inputs)
+    SWC_D uint32_t scan_incl(uint32_t x) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+            uint32_t y = __shfl_up(x, o);
+            if (lane >= o) x += y;
+        }
+        if (T > 64) {
+            if (lane == 63) l->wave_sum[wave] = x;
+            sync();
+            uint32_t add = 0;
+            for (int w = 0; w < wave; w++) add += l->wave_sum[w];
+            x += add;
+        }
+#endif
+        return x;
+    }
+    SWC_D void set_done(int i) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __hip_atomic_fetch_or(&l->done[i >> 5], 1u << (i & 31), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        l->done[i >> 5] |= 1u << (i & 31);
+#endif
+    }
+    SWC_D uint32_t done_word(int w) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __hip_atomic_load(&l->done[w], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        return l->done[w];
+#endif
+    }
+    SWC_D uint64_t link_load(int i) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __hip_atomic_load(&l->link[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        return l->link[i];
+#endif
+    }
+    SWC_D void link_store(int i, uint64_t v) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __hip_atomic_store(&l->link[i], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        l->link[i] = v;
+#endif
+    }
+    SWC_D void backoff() const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __builtin_amdgcn_s_sleep(1);
+#endif
+    }
+};
+
+struct u128 {
+    uint32_t x, y, z, w;
+};
+SWC_HD u128 load_16(gcptr p) {  // p is 16-byte aligned
+    return *(const SWC_AS_GLOBAL u128*)p;
+}
+SWC_HD void store_16(gptr p, const u128& v) { *(SWC_AS_GLOBAL u128*)p = v; }
+SWC_HD uint8_t byte_of(const u128& v, int j) {
+    uint32_t w = j < 4 ? v.x : j < 8 ? v.y : j < 12 ? v.z : v.w;
+    return (uint8_t)(w >> (8 * (j & 3)));
+}
+
+template <int T>
+struct Resolver {
+    static constexpr int kPf = (int)(kReadAhead / (16 * T)) > 0 ? (int)(kReadAhead / (16 * T)) : 1;  // read-ahead chunks per thread
+    Group<T> g;
+    gptr out;
+    uint64_t limit;   // bytes of `out` that exist: min(bytes produced, capacity)
+    uint32_t rb;      // low bits of the output address: ring index of position p is (rb + p) & kRingMask, so that
+                      // 16-byte aligned HBM chunks are 16-byte aligned in the ring
+    uint8_t* ring;
+    int dbg;          // experiment switches (tools/exp_deflate.py), 0 in production: 1 no copies, 2 no write-back,
+                      // 4 no literal staging, 8 no dependency search, 16 no record prefetch
+
+    SWC_D uint32_t ridx(uint64_t p) const { return (rb + (uint32_t)p) & kRingMask; }
+    // first position whose address is 16-byte aligned and >= the address of position p
+    SWC_D uint64_t chunk_up(uint64_t p) const {
+        const uint64_t a0 = (uint64_t)(uintptr_t)out;
+        return ((a0 + p + 15) & ~(uint64_t)15) - a0;
+    }
+
+    // One 16-byte chunk (absolute address ca) of the span [lo, hi): HBM -> registers.  The aligned chunk that
+    // holds an edge byte lies in the same 16-byte granule as that byte, so reading it whole is safe on the device;
+    // the host build reads edge chunks bytewise to stay inside the caller's buffer.
+    SWC_D u128 fetch_chunk(uint64_t ca, uint64_t lo, uint64_t hi) const {
+        const uint64_t a0 = (uint64_t)(uintptr_t)out;
+        const int64_t p0 = (int64_t)(ca - a0);
+#if defined(__HIP_DEVICE_COMPILE__)
+        (void)lo; (void)hi;
+        return load_16((gcptr)out + p0);
+#else
+        u128 v = {0, 0, 0, 0};
+        uint8_t* vb = (uint8_t*)&v;
+        for (int j = 0; j < 16; j++) {
+            int64_t p = p0 + j;
+            if (p >= (int64_t)lo && (uint64_t)p < hi) vb[j] = out[p];
+        }
+        return v;
+#endif
+    }
+    SWC_D void stage_chunk(uint64_t ca, const u128& v, uint64_t lo, uint64_t hi) const {
+        const uint64_t a0 = (uint64_t)(uintptr_t)out;
+        const int64_t p0 = (int64_t)(ca - a0);
+        if (p0 >= (int64_t)lo && (uint64_t)p0 + 16 <= hi) {
+            *(u128*)(ring + ((uint32_t)ca & kRingMask)) = v;
+        } else {
+            for (int j = 0; j < 16; j++) {
+                int64_t p = p0 + j;
+                if (p >= (int64_t)lo && (uint64_t)p < hi) ring[ridx((uint64_t)p)] = byte_of(v, j);
+            }
+        }
+    }
+    // HBM -> ring for positions [lo, hi), hi <= limit (synchronous: used when the read-ahead fell short)
+    SWC_D void load_span(uint64_t lo, uint64_t hi) const {
+        if (hi <= lo) return;
+        const uint64_t a0 = (uint64_t)(uintptr_t)out;
+        const uint64_t c0 = (a0 + lo) >> 4, c1 = (a0 + hi - 1) >> 4;
+        for (uint64_t c = c0 + (uint64_t)g.tid; c <= c1; c += T) stage_chunk(c << 4, fetch_chunk(c << 4, lo, hi), lo, hi);
+    }
+    // ring -> HBM for positions [lo, hi), hi <= limit
+    SWC_D void flush_span(uint64_t lo, uint64_t hi) const {
+        if (hi <= lo) return;
+        const uint64_t a0 = (uint64_t)(uintptr_t)out;
+        const uint64_t c0 = (a0 + lo) >> 4, c1 = (a0 + hi - 1) >> 4;
+        for (uint64_t c = c0 + (uint64_t)g.tid; c <= c1; c += T) {
+            const uint64_t ca = c << 4;
+            const int64_t p0 = (int64_t)(ca - a0);
+            gptr dst = out + p0;
+            if (p0 >= (int64_t)lo && (uint64_t)p0 + 16 <= hi) {
+                store_16(dst, *(const u128*)(ring + ((uint32_t)ca & kRingMask)));
+            } else {
+                for (int j = 0; j < 16; j++) {
+                    int64_t p = p0 + j;
+                    if (p >= (int64_t)lo && (uint64_t)p < hi) dst[j] = ring[ridx((uint64_t)p)];
+                }
+            }
+        }
+    }
+
+    // Ring accessors (unaligned LDS accesses are native on gfx950); the rare access that would run off the end of
+    // the ring goes bytewise.
+    SWC_D uint64_t rd(uint32_t x, uint32_t n) const {  // n = 1, 2, 4, 8
+        x &= kRingMask;
+        if (x + n <= kRingBytes) {
+            if (n == 8) return *(const u64_unaligned*)(ring + x);
+            if (n == 4) return *(const u32_unaligned*)(ring + x);
+            if (n == 2) return *(const u16_unaligned*)(ring + x);
+            return ring[x];
+        }
+        uint64_t v = 0;
+        for (uint32_t j = 0; j < n; j++) v |= (uint64_t)ring[(x + j) & kRingMask] << (8 * j);
+        return v;
+    }
+    SWC_D void wr(uint32_t x, uint32_t n, uint64_t v) const {
+        x &= kRingMask;
+        if (x + n <= kRingBytes) {
+            if (n == 8) *(u64_unaligned*)(ring + x) = v;
+            else if (n == 4) *(u32_unaligned*)(ring + x) = (uint32_t)v;
+            else if (n == 2) *(u16_unaligned*)(ring + x) = (uint16_t)v;
+            else ring[x] = (uint8_t)v;
+            return;
+        }
+        for (uint32_t j = 0; j < n; j++) ring[(x + j) & kRingMask] = (uint8_t)(v >> (8 * j));
+    }
+    SWC_D void copy_plain(uint32_t d, uint32_t s, uint32_t n) const {  // s + n <= d: sources never written here
+        uint32_t i = 0;
+        for (; i + 8 <= n; i += 8) wr(d + i, 8, rd(s + i, 8));
+        if (n - i >= 4) { wr(d + i, 4, rd(s + i, 4)); i += 4; }
+        if (n - i >= 2) { wr(d + i, 2, rd(s + i, 2)); i += 2; }
+        if (n - i >= 1) wr(d + i, 1, rd(s + i, 1));
+    }
+    // One match inside the ring: `len` bytes at position dpos; the first min(len, period) bytes (the pattern) come
+    // from position spos (all producers done, spos + pattern <= dpos), the rest repeats the pattern with `period`.
+    SWC_D void copy_match(uint64_t dpos, uint32_t len, int64_t spos, uint32_t period) const {
+        const uint32_t d = ridx(dpos), s = ridx((uint64_t)spos);
+        const uint32_t plen = len < period ? len : period;
+        copy_plain(d, s, plen);
+        if (len <= period) return;
+        uint32_t k = period, back = period;
+        if (period < 8) {
+            // bytewise until the copy distance (a multiple of the period) reaches 8
+            back = ((7u + period) / period) * period;
+            const uint32_t stop = len < back ? len : back;
+            for (; k < stop; k++) wr(d + k, 1, rd(d + k - period, 1));
+        }
+        for (; k + 8 <= len; k += 8) wr(d + k, 8, rd(d + k - back, 8));   // LDS executes a lane's accesses in order
+        if (len - k >= 4) { wr(d + k, 4, rd(d + k - back, 4)); k += 4; }
+        if (len - k >= 2) { wr(d + k, 2, rd(d + k - back, 2)); k += 2; }
+        if (len - k >= 1) wr(d + k, 1, rd(d + k - back, 1));
+    }
+
+    // first index in [0, n) with a[i] > v   (a non-decreasing)
+    SWC_D static int upper_bound(const uint32_t* a, int n, uint32_t v) {
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (a[mid] > v) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    }
+    // first index in [0, n) with a[i] >= v
+    SWC_D static int lower_bound(const uint32_t* a, int n, uint32_t v) {
+        int lo = 0, hi = n;
+        while (lo < hi) {
+            int mid = (lo + hi) >> 1;
+            if (a[mid] >= v) hi = mid; else lo = mid + 1;
+        }
+        return lo;
+    }
+
+    SWC_D void run(const SWC_AS_GLOBAL uint32_t* recs, uint32_t nrec) {
+        Lds<T>* l = g.l;
+        const int tid = g.tid;
+        uint64_t rpos = 0;      // everything below rpos is final in HBM
+        uint64_t ring_hi = 0;   // literals are staged in the ring for positions [.., ring_hi); chunk aligned or == limit
+        uint32_t base = 0;
+        uint32_t r_next = (uint32_t)tid < nrec ? recs[tid] : 0u;   // record prefetch, one batch ahead
+        uint32_t next_base = 0;
+        while (base < nrec) {
+            const bool valid = base + (uint32_t)tid < nrec;
+            uint32_t r;
+            if (next_base == base && !(dbg & 16)) r = r_next;
+            else r = valid ? recs[base + tid] : 0u;
+            next_base = base + T;
+            r_next = next_base + (uint32_t)tid < nrec ? recs[next_base + tid] : 0u;   // in flight while this batch resolves
+            const bool skip = (r & kSkipFlag) != 0;
+            const uint32_t len = ((r >> 8) & 255u) + 3u, dist = ((r >> 16) & 0x7FFFu) + 1u;
+            const uint32_t adv_raw = !valid ? 0u : skip ? (r & kMaxSkip) : (r & 255u) + len;
+            const uint32_t adv = adv_raw > kSpan ? kSpan + 1u : adv_raw;     // keeps the scan below 2^32
+            const uint32_t end_rel = g.scan_incl(adv);
+            const bool take = valid && end_rel <= kSpan;
+            const bool is_match = take && !skip;
+            const uint32_t dst_rel = end_rel - (is_match ? len : 0u);
+            l->ends[tid] = take ? end_rel : 0xFFFFFFFFu;
+            l->dsts[tid] = dst_rel;
+            if (tid == 0) { l->ends[T] = 0xFFFFFFFFu; l->ntake = 0; l->span = adv_raw; }
+            if (tid < (int)((T + 31) / 32)) l->done[tid] = 0;
+            g.sync();
+            if (take && l->ends[tid + 1] == 0xFFFFFFFFu) { l->ntake = (uint32_t)tid + 1u; l->span = end_rel; }
+            g.sync();
+            const int n_take = (int)l->ntake;
+            const uint32_t span = l->span;
+            if (n_take == 0) {
+                // the first record alone outruns the span: a long literal run (already final in HBM).  Skip it and
+                // re-stage the part of the 32 KiB window before the new position that the ring does not hold yet.
+                rpos += span;
+                base += 1;
+                const uint64_t hi = rpos < limit ? rpos : limit;
+                uint64_t lo = hi > 32768 ? hi - 32768 : 0;
+                if (lo < ring_hi) lo = ring_hi;
+                load_span(lo, hi);
+                if (hi > ring_hi) ring_hi = hi;
+                g.sync();
+                continue;
+            }
+            const uint64_t batch_end = rpos + span;
+            const uint64_t hi = batch_end < limit ? batch_end : limit;
+            if (hi > ring_hi && !(dbg & 4)) {   // the read-ahead fell short (first batch, or a batch wider than the read-ahead)
+                uint64_t to = chunk_up(hi);
+                if (to > limit) to = limit;
+                load_span(ring_hi, to);
+                ring_hi = to;
+                g.sync();
+            }
+            // read-ahead for the following batches: HBM -> registers now, registers -> ring after the resolve
+            u128 pf[kPf];
+            uint64_t pf_lo = ring_hi, pf_hi = hi + kReadAhead;
+            if (pf_hi > limit) pf_hi = limit;
+            if (dbg & 4) pf_hi = pf_lo;
+            if (pf_hi > pf_lo) {
+                uint64_t to = chunk_up(pf_hi);
+                pf_hi = to > limit ? limit : to;
+                const uint64_t a0 = (uint64_t)(uintptr_t)out;
+                const uint64_t c0 = (a0 + pf_lo) >> 4, c1 = (a0 + pf_hi - 1) >> 4;
+#pragma unroll
+                for (int k = 0; k < kPf; k++) {
+                    const uint64_t c = c0 + (uint64_t)tid + (uint64_t)k * T;
+                    if (c <= c1) pf[k] = fetch_chunk(c << 4, pf_lo, pf_hi);
+                }
+                if (c1 - c0 + 1 > (uint64_t)kPf * T) pf_hi = ((c0 + (uint64_t)kPf * T) << 4) - a0;  // what kPf chunks per thread cover
+            } else {
+                pf_hi = pf_lo;
+            }
+            // clamp to the bytes that exist (a match that starts below the capacity may end beyond it)
+            uint32_t clen = len;
+            bool pending = is_match;
+            if (pending) {
+                const uint64_t dabs = rpos + dst_rel;
+                if (dabs >= limit) pending = false;
+                else if (dabs + clen > limit) clen = (uint32_t)(limit - dabs);
+            }
+            // Producers of my pattern bytes: records a..b (inclusive) of this batch.  A match whose pattern lies inside
+            // ONE earlier match does not wait for it: it takes over that match's source (pointer jumping), so the
+            // chains that repeated words form (every occurrence copies the previous one) collapse to depth one.
+            int dep_a = 0, dep_b = -1, prod = -1;
+            int32_t s0 = (int32_t)dst_rel - (int32_t)dist;
+            const uint32_t plen = clen < dist ? clen : dist;
+            if (pending) {
+                const int64_t s1 = (int64_t)s0 + plen;  // exclusive
+                if (s1 > 0 && !(dbg & 8)) {
+                    const uint32_t lo_rel = s0 > 0 ? (uint32_t)s0 : 0u;
+                    dep_a = upper_bound(l->ends, n_take, lo_rel);            // first record that ends after my first source byte
+                    dep_b = lower_bound(l->dsts, n_take, (uint32_t)s1) - 1;  // last record that starts before my source end
+                    if (dep_b >= tid) dep_b = tid - 1;
+                    if (dep_a <= dep_b) {
+                        if (dep_a == dep_b && s0 >= 0 && (uint32_t)s0 >= l->dsts[dep_a] && (uint32_t)s1 <= l->ends[dep_a]) prod = dep_a;
+                        else prod = -2;
+                    }
+                }
+            }
+            l->periods[tid] = dist;
+            g.link_store(tid, (uint64_t)(uint32_t)s0 | ((uint64_t)(uint32_t)(pending ? prod : -1) << 32));
+            if (take && !pending) g.set_done(tid);
+            g.sync();
+            while (prod >= 0) {
+                const int i = prod;
+                const uint64_t li = g.link_load(i);
+                const int32_t si = (int32_t)(uint32_t)li, pi = (int32_t)(uint32_t)(li >> 32);
+                const uint32_t per_i = l->periods[i], len_i = l->ends[i] - l->dsts[i];
+                uint32_t o = (uint32_t)s0 - l->dsts[i];
+                bool wait = pi == -2;
+                if (per_i < len_i) {          // the producer repeats its own pattern: map into the pattern if I fit
+                    o %= per_i;
+                    if (o + plen > per_i) wait = true;
+                }
+                if (wait) {                   // the producer itself has to wait, or I straddle its period: wait for it
+                    dep_a = dep_b = i;
+                    prod = -2;
+                    break;
+                }
+                s0 = si + (int32_t)o;
+                prod = pi;
+                g.link_store(tid, (uint64_t)(uint32_t)s0 | ((uint64_t)(uint32_t)prod << 32));
+            }
+            // a waiting match runs once every producer has run; producers are earlier records, so this cannot deadlock
+            while (pending) {
+                bool ready = true;
+                if (prod == -2) {
+                    for (int w = dep_a >> 5; w <= (dep_b >> 5); w++) {
+                        uint32_t m = 0xFFFFFFFFu;
+                        if (w == (dep_a >> 5)) m &= 0xFFFFFFFFu << (dep_a & 31);
+                        if (w == (dep_b >> 5)) m &= 0xFFFFFFFFu >> (31 - (dep_b & 31));
+                        if ((g.done_word(w) & m) != m) { ready = false; break; }
+                    }
+                }
+                if (ready) {
+                    if (!(dbg & 1)) copy_match(rpos + dst_rel, clen, (int64_t)rpos + s0, dist);
+                    g.set_done(tid);
+                    pending = false;
+                } else {
+                    g.backoff();
+                }
+            }
+            g.sync();
+            // consume the loads issued before the resolve (read-ahead literals, next records) BEFORE the write-back
+            // stores are issued: vmcnt retires in order, so a wait placed after the stores would wait for them too
+            if (pf_hi > pf_lo) {
+                const uint64_t a0 = (uint64_t)(uintptr_t)out;
+                const uint64_t c0 = (a0 + pf_lo) >> 4, c1 = (a0 + pf_hi - 1) >> 4;
+#pragma unroll
+                for (int k = 0; k < kPf; k++) {
+                    const uint64_t c = c0 + (uint64_t)tid + (uint64_t)k * T;
+                    if (c <= c1) stage_chunk(c << 4, pf[k], pf_lo, pf_hi);
+                }
+                ring_hi = pf_hi;
+            }
+#if defined(__HIP_DEVICE_COMPILE__)
+            asm volatile("" ::"v"(r_next));
+#endif
+            if (!(dbg & 2)) flush_span(rpos, hi);
+            rpos = batch_end;
+            base += (uint32_t)n_take;
+            g.sync();
+        }
+    }
+};
+
+// One job: `ws` is the stream's workspace area written by phase 1.
+template <int T>
+SWC_D void resolve_job(const Job& job, const uint8_t* ws, Lds<T>* lds, int tid, int dbg = 0) {
+    const SWC_AS_GLOBAL StreamHeader* h = (const SWC_AS_GLOBAL StreamHeader*)ws;
+    const uint32_t nrec = h->nrec;
+    if (nrec == 0) return;
+    Resolver<T> rs;
+    rs.g.tid = tid;
+    rs.g.l = lds;
+    rs.out = (gptr)job.out;
+    rs.limit = job.out_len < job.out_cap ? job.out_len : job.out_cap;
+    rs.rb = (uint32_t)(uintptr_t)job.out;
+    rs.ring = lds->ring;
+    rs.dbg = dbg;
+    rs.run((const SWC_AS_GLOBAL uint32_t*)(ws + sizeof(StreamHeader)), nrec);
+}
+
+}  // namespace lzr
+}  // namespace swc
+#endif

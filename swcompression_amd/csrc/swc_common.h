@@ -63,6 +63,7 @@ typedef const SWC_AS_GLOBAL uint8_t* gcptr;
 typedef SWC_AS_GLOBAL uint8_t* gptr;
 typedef uint32_t __attribute__((aligned(1), may_alias)) u32_unaligned;
 typedef uint64_t __attribute__((aligned(1), may_alias)) u64_unaligned;
+typedef uint16_t __attribute__((aligned(1), may_alias)) u16_unaligned;
 
 // gfx950 global loads/stores are unaligned-capable (hipcc emits plain global_load_dword for these)
 SWC_HD uint32_t load_u32(gcptr p) { return *(const SWC_AS_GLOBAL u32_unaligned*)p; }

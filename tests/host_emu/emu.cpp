@@ -10,13 +10,19 @@
 #include "../../swcompression_amd/csrc/lzma_wave.h"
 #include "../../swcompression_amd/csrc/bzip2_block.h"
 
+// Deflate: phase 1 lane by lane (wave-interleaved tables), then phase 2 with a one-thread "workgroup".
 extern "C" void emu_inflate(swc::Job* jobs, size_t n) {
     std::vector<uint32_t> lds(swc::inflate::kWordsPerLane * swc::kWave);
+    alignas(16) static swc::lzr::Lds<1> rl;
     for (size_t g = 0; g < n; g++) {
         int lane = (int)(g % swc::kWave);
         if (lane == 0) std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);  // LDS is uninitialised on device
         swc::LaneLds l{lds.data() + lane, swc::kWave};
-        swc::inflate::inflate_job(jobs[g], l);
+        size_t wsb = swc::lzr::ws_bytes_per_job(jobs[g].out_cap);
+        std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
+        swc::inflate::inflate_job(jobs[g], l, ws.data(), wsb);
+        std::memset(&rl, 0xEE, sizeof rl);
+        swc::lzr::resolve_job<1>(jobs[g], ws.data(), &rl, 0);
     }
 }
 

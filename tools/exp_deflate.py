@@ -1,4 +1,4 @@
-"""Quick on-GPU experiments for the Deflate kernel (not part of the test suite)."""
+"""Quick on-GPU experiments for the Deflate path (not part of the test suite)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -18,13 +18,12 @@ from swcompression_amd import _lib
 lib = _lib.load()
 units, plains = corpus.build_units("gzip", 2048, 65536)
 raw = [u[10:-8] for u in units]
-for G in (1, 2, 4):
-    assert lib.swc_set_tuning(b"inflate_lanes_per_stream", G) == 0
-    for mode in (0, 1, 2):
-        if G > 1 and mode: continue
-        assert lib.swc_set_tuning(b"inflate_debug_mode", mode) == 0
-        for tile, label in ((32, "64k"), (16, "32k"), (8, "16k"), (2, "4k")):
-            b = DeviceBatch("deflate", raw, [65536] * len(raw), tile=tile)
-            ms = timeit(b)
-            print("G=%d mode=%d jobs=%-6s %8.2f ms  %.1f GB/s out" % (G, mode, label, ms, b.n * 65536 / ms / 1e6), flush=True)
-            del b
+for T in (256, 512, 1024, 128, 64):
+    assert lib.swc_set_tuning(b"resolve_threads", T) == 0
+    for tile, label in ((32, "64k"), (8, "16k"), (2, "4k")):
+        b = DeviceBatch("deflate", raw, [65536] * len(raw), tile=tile)
+        ms = timeit(b)
+        r = b.results()
+        ok = bool((r["status"] == 0).all()) and b.output(5, 65536) == plains[5] and b.output(len(raw) + 7, 65536) == plains[7]
+        print("T=%d jobs=%-6s %8.2f ms  %.1f GB/s out  ok=%s" % (T, label, ms, b.n * 65536 / ms / 1e6, ok), flush=True)
+        del b
