@@ -6,16 +6,20 @@ launches it under torch.distributed.run, one rank per GPU.  A "step" is ONE pass
 batched launch) over the whole synthetic batch with inputs already resident in HBM.  Default workload =
 BASELINE.json configs[1]: 100,000 independent gzip members of 64 KiB (Deflate, dynamic Huffman), host-side
 framing done before the timed region.  Units shard across ranks with no data-path collective
-("weak" scaling: every rank decodes its own 100,000 members); RCCL is used only for the barrier and
-the max-over-ranks time.
+("weak" scaling: every rank decodes its own batch); RCCL is used only for the barrier and the
+max-over-ranks time.  The other BASELINE configs are parity-test cases; `--workload` times them too
+(lz4_4m, bzip2_900k, lzma2_256k) but they are not the headline line.
 
 Prints ONE JSON line: decompressed GiB/s (sum of U over all ranks / max time), plus
-  roofline     -- HBM roofline of the dominant kernel: algorithmic bytes (C + U per unit)
-                  / mean launch duration measured with HIP events on the launch stream, vs 8 TB/s;
+  roofline     -- HBM roofline: algorithmic bytes (C + U per unit) / mean kernel time of a
+                  launch, measured with HIP events on the launch stream (per kernel for the two Deflate
+                  kernels), vs 8 TB/s; `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc
+                  passes of this same command (profiles/*_traffic.json), or null;
   cpu_baseline -- the CPU oracle (a port of the reference's algorithm) timed on a bounded sample of the
                   same workload on this box's host cores (rank 0, N = 1 only).
 """
 import argparse
+import ctypes as C
 import json
 import os
 import sys
@@ -27,8 +31,15 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 WORKLOADS = {
-    # name: (codec, unit kind for corpus.build_units, n_distinct, tile, unit_size, description)
-    "deflate64k": ("deflate", "gzip", 4000, 25, 65536, "100000 x 64 KiB gzip members (BASELINE configs[1])"),
+    # name: codec, corpus kind, n_distinct, tile, unit bytes, description
+    "deflate64k": dict(codec="deflate", kind="gzip", n_distinct=4000, tile=25, unit=65536,
+                       desc="100000 x 64 KiB gzip members (BASELINE configs[1])", kernels="swc_inflate_kernel + swc_lz_resolve_kernel"),
+    "lz4_4m": dict(codec="lz4_block", kind="lz4_block", n_distinct=32, tile=64, unit=4 << 20,
+                   desc="2048 x 4 MiB independent LZ4 blocks (BASELINE configs[2], resident micro-config)", kernels="swc_lz4_lane_kernel"),
+    "bzip2_900k": dict(codec="bzip2_block", kind="bzip2", n_distinct=32, tile=16, unit=899000,
+                       desc="512 x 900 kB bzip2 blocks (BASELINE configs[3] shape)", kernels="swc_bzip2_stage1/2/3_kernel"),
+    "lzma2_256k": dict(codec="lzma2", kind="lzma2", n_distinct=256, tile=16, unit=262144,
+                       desc="4096 x 256 KiB raw-LZMA2 units (BASELINE configs[4] shape)", kernels="swc_lzma_kernel"),
 }
 
 
@@ -44,31 +55,71 @@ def parse_args():
     return ap.parse_args()
 
 
-def strip_framing(kind, units):
-    """Host-side block discovery for the bench corpus: returns the raw codec units and per-unit aux."""
-    if kind == "gzip":
-        # corpus.gzip_member writes a fixed 10-byte header and an 8-byte trailer (CRC-32, ISIZE)
-        return [u[10:-8] for u in units]
-    return units
+def make_batch(name, w, n_distinct, seed, device):
+    """Host-side block discovery for the bench corpus + the device-resident batch."""
+    from swcompression_amd import corpus
+    from swcompression_amd.batch import DeviceBatch
+    units, plains = corpus.build_units(w["kind"], n_distinct, w["unit"], seed=seed)
+    if name == "deflate64k":
+        raw = [u[10:-8] for u in units]  # corpus.gzip_member: fixed 10-byte header, 8-byte trailer (CRC-32, ISIZE)
+        b = DeviceBatch("deflate", raw, [w["unit"]] * n_distinct, tile=w["tile"], device=device)
+    elif name == "lz4_4m":
+        raw = units
+        b = DeviceBatch("lz4_block", raw, [w["unit"]] * n_distinct, tile=w["tile"], device=device)
+    elif name == "bzip2_900k":
+        raw = units  # whole one-block streams: "BZh9" (32 bits) + block magic (48) + block CRC (32) => body at bit 112
+        b = DeviceBatch("bzip2_block", raw, [w["unit"] + 64] * n_distinct, extra=[112] * n_distinct,
+                        dict_values=[int.from_bytes(s[10:14], "big") for s in raw], tile=w["tile"], device=device)
+    else:
+        raw = units
+        db = corpus.lzma2_dict_byte(1 << 20)
+        b = DeviceBatch("lzma2", raw, [w["unit"]] * n_distinct, aux=[db] * n_distinct, tile=w["tile"], device=device)
+    return b, raw, plains
 
 
-def cpu_baseline(workload, units_raw, plains, seconds):
+def cpu_baseline(name, raw, plains, seconds):
     """Times the oracle (single thread, like the reference) on as many units as fit in `seconds`."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
-    fn = {"deflate": O.deflate}[WORKLOADS[workload][0]]
+    from swcompression_amd import corpus
+    if name == "deflate64k":
+        fn = lambda u: O.deflate(u)[:2]
+    elif name == "lz4_4m":
+        O.lib.refcpu_set_max_output(1 << 23)
+        fn = lambda u: O.lz4_block(u)[:2]
+    elif name == "bzip2_900k":
+        fn = lambda u: O.bzip2(u)[:2]
+    else:
+        db = corpus.lzma2_dict_byte(1 << 20)
+        fn = lambda u: O.lzma2(u, db)[:2]
     t0 = time.perf_counter()
-    done = 0
-    nbytes = 0
-    while done < len(units_raw) and time.perf_counter() - t0 < seconds:
-        st, out, _ = fn(units_raw[done])
+    done = nbytes = 0
+    while done < len(raw) and time.perf_counter() - t0 < seconds:
+        st, out = fn(raw[done])
         assert st == 0 and len(out) == len(plains[done])
         nbytes += len(out)
         done += 1
     dt = time.perf_counter() - t0
     return {"value": nbytes / dt / 2**30, "unit": "GiB/s decompressed", "cores": 1, "kind": "port",
-            "sample": "%d of the %d distinct units, %.1f s, oracle/librefcpu.so single thread" % (done, len(units_raw), dt),
-            "compressed_MBps": sum(len(u) for u in units_raw[:done]) / dt / 1e6}
+            "sample": "%d of the %d distinct units, %.1f s, oracle/librefcpu.so single thread" % (done, len(raw), dt),
+            "compressed_MBps": sum(len(u) for u in raw[:done]) / dt / 1e6}
+
+
+def committed_traffic(name):
+    """HBM bytes per launch from the rocprofv3 --pmc passes of this command (tools/pmc_bench.sh), if committed."""
+    best = None
+    pdir = os.path.join(ROOT, "profiles")
+    if os.path.isdir(pdir):
+        for f in sorted(os.listdir(pdir)):
+            if f.endswith("_%s_traffic.json" % name):
+                best = os.path.join(pdir, f)
+    if not best:
+        return None, None
+    try:
+        d = json.load(open(best))
+        return d.get("hbm_bytes_per_launch"), os.path.relpath(best, ROOT)
+    except Exception:
+        return None, None
 
 
 def main():
@@ -87,17 +138,15 @@ def main():
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
 
-    from swcompression_amd import corpus
-    from swcompression_amd.batch import DeviceBatch
-
-    codec, kind, n_distinct, tile, unit_size, desc = WORKLOADS[args.workload]
-    n_distinct = max(64, int(n_distinct * args.scale))
+    from swcompression_amd import _lib
+    lib = _lib.load()
+    w = WORKLOADS[args.workload]
+    n_distinct = max(8, int(w["n_distinct"] * args.scale))
     # every rank decodes its own, differently seeded, batch: independent units, no exchange step
-    units, plains = corpus.build_units(kind, n_distinct, unit_size, seed=2 + 100003 * rank)
-    raw = strip_framing(kind, units)
-    batch = DeviceBatch(codec, raw, [unit_size] * n_distinct, tile=tile, device=device)
-    sum_u = sum(len(p) for p in plains) * tile
-    sum_c = sum(len(r) for r in raw) * tile
+    batch, raw, plains = make_batch(args.workload, w, n_distinct, 2 + 100003 * rank, device)
+    unit = w["unit"]
+    sum_u = sum(len(p) for p in plains) * w["tile"]
+    sum_c = sum(len(r) for r in raw) * w["tile"]
 
     def barrier():
         if world > 1:
@@ -108,7 +157,7 @@ def main():
         batch.launch()
     barrier()
     r = batch.results()
-    if not ((r["status"] == 0).all() and (r["out_len"] == unit_size).all()):
+    if not ((r["status"] == 0).all() and (r["out_len"] == unit).all()):
         raise SystemExit("decode failed: statuses %s" % sorted(set(r["status"].tolist())))
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -120,34 +169,57 @@ def main():
         e.record()
     barrier()
     dt = time.perf_counter() - t0
-    kernel_ms = [s.elapsed_time(e) for s, e in ev]
+    launch_ms = [s.elapsed_time(e) for s, e in ev]
 
     t = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt_max = float(t.item())
 
+    # outside the timed region: per-kernel durations of one more launch (HIP events inside the library, on the launch stream)
+    phases = None
+    if args.workload == "deflate64k":
+        lib.swc_set_tuning(b"phase_timing", 1)
+        acc = [0.0, 0.0]
+        reps = 3
+        for _ in range(reps):
+            batch.launch(sync=True)
+            buf = (C.c_float * 4)()
+            if lib.swc_last_phase_ms(buf, 4) == 2:
+                acc[0] += buf[0] / reps
+                acc[1] += buf[1] / reps
+        lib.swc_set_tuning(b"phase_timing", 0)
+        phases = {"swc_inflate_kernel_ms": acc[0], "swc_lz_resolve_kernel_ms": acc[1]}
+
     # parity spot check outside the timed region: one tile against the plain payloads
     if rank == 0:
         for i in range(0, n_distinct, max(1, n_distinct // 16)):
-            assert batch.output(i, unit_size) == plains[i], "bit-exactness violated on unit %d" % i
+            assert batch.output(i, unit) == plains[i], "bit-exactness violated on unit %d" % i
 
     if rank == 0:
         total_u = sum_u * world * args.steps
-        mean_ms = sum(kernel_ms) / len(kernel_ms)
+        mean_ms = sum(launch_ms) / len(launch_ms)
         achieved = (sum_c + sum_u) / (mean_ms * 1e-3) / 1e9
+        traffic, traffic_src = committed_traffic(args.workload)
+        desc = w["desc"] if args.scale == 1.0 else w["desc"] + " (scaled x%g, not a headline run)" % args.scale
+        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                "kernel": w["kernels"], "kernel_ms": mean_ms, "algorithmic_bytes_per_launch": sum_c + sum_u}
+        if phases:
+            roof["per_kernel_ms"] = phases
+            dom = max(phases, key=phases.get)
+            roof["dominant_kernel"] = dom[:-3]
+            if phases[dom] > 0:
+                roof["dominant_kernel_achieved_GBps"] = (sum_c + sum_u) / (phases[dom] * 1e-3) / 1e9
         line = {
             "metric": "decompressed GiB/s", "value": total_u / dt_max / 2**30, "unit": "GiB/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": desc if args.scale == 1.0 else desc + " (scaled x%g, not a headline run)" % args.scale,
-                       "codec": codec, "units_per_gpu": batch.n, "unit_bytes": unit_size,
+            "config": {"workload": desc, "codec": w["codec"], "units_per_gpu": batch.n, "unit_bytes": unit,
                        "compressed_bytes_per_gpu": sum_c, "decompressed_bytes_per_gpu": sum_u,
-                       "payload": "P-text (Zipf pseudo-words), zlib level 6 as encoder", "parallelism": "%d x independent shards" % world},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
-                         "kernel": "swc_inflate_kernel", "kernel_ms": mean_ms,
-                         "algorithmic_bytes_per_launch": sum_c + sum_u},
+                       "payload": "P-text (Zipf pseudo-words), system encoder (zlib 6 / liblz4 / bz2 9 / xz 6)",
+                       "parallelism": "%d x independent shards" % world},
+            "roofline": roof,
         }
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, raw, plains, args.cpu_seconds)

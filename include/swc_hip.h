@@ -63,11 +63,13 @@ typedef struct swc_batch_opts {
     int32_t reserved;
 } swc_batch_opts;
 
-/* Launches one lane per job.  `jobs` is a device pointer to n swc_job records. */
+/* One launch for all n jobs.  `jobs` is a device pointer to n swc_job records.  Deflate and BZip2 need an HBM
+ * workspace: this entry point allocates it from the stream-ordered pool; swc_batch_decompress_ws takes it
+ * from the caller. */
 int swc_batch_decompress(int codec, swc_job* jobs, size_t n, const swc_batch_opts* opts);
 
-/* Scratch bytes the codec needs per job in HBM (LZMA probability model spill, BZip2 tt[]); 0 for
- * Deflate/LZ4.  Allocated internally by the single-shot calls; batch callers pass it via
+/* Scratch bytes the codec needs in HBM (Deflate match records, LZMA probability model spill, BZip2 tt[]);
+ * 0 for LZ4.  Allocated internally by the single-shot calls; batch callers pass it via
  * swc_batch_decompress_ws. */
 size_t swc_batch_workspace_bytes(int codec, size_t n_jobs, uint64_t max_out_cap);
 int swc_batch_decompress_ws(int codec, swc_job* jobs, size_t n, void* workspace, size_t workspace_bytes,
@@ -135,8 +137,12 @@ void swc_free(void* p);
 /* 1 if a gfx950 device is usable, 0 otherwise (then every decode entry point returns SWC_E_DEVICE) */
 int swc_device_available(void);
 const char* swc_version(void);
-/* Performance knobs (never change results).  "inflate_lanes_per_stream" = 1 | 2 | 4. */
+/* Performance knobs (never change results): "resolve_threads" = 64..1024 (threads per stream in the LZ77 resolve
+ * kernel), "phase_timing" = 0 | 1 (HIP events around the two Deflate kernels of a launch). */
 int swc_set_tuning(const char* key, int value);
+/* With "phase_timing" on: durations (ms) of the kernels of the last Deflate launch, in launch order
+ * (entropy decode, LZ77 resolve).  Returns the number of values written (0 if none). */
+int swc_last_phase_ms(float* ms, int cap);
 
 #ifdef __cplusplus
 }

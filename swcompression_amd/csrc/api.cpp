@@ -153,9 +153,12 @@ extern "C" {
 int swc_set_tuning(const char* key, int value) {
     if (!key) return SWC_E_INVALID_ARGUMENT;
     if (!strcmp(key, "resolve_threads") && (value == 64 || value == 128 || value == 256 || value == 512 || value == 1024)) { set_resolve_threads(value); return SWC_OK; }
+    if (!strcmp(key, "phase_timing") && (value == 0 || value == 1)) { set_phase_timing(value); return SWC_OK; }
     if (!strcmp(key, "resolve_debug") && value >= 0 && value < 32) { set_resolve_debug(value); return SWC_OK; }  // timing experiments only
     return SWC_E_INVALID_ARGUMENT;
 }
+
+int swc_last_phase_ms(float* ms, int cap) { return ms ? last_phase_ms(ms, cap) : 0; }
 
 int swc_device_available(void) { return device_ready() ? 1 : 0; }
 const char* swc_version(void) { return "swc-hip 0.1 (gfx950)"; }

@@ -1,29 +1,29 @@
-// inflate_lane.h -- Deflate decode, one compressed stream per lane.
+// inflate_lane.h -- Deflate entropy decode (phase 1 of the two-phase path), one compressed stream per lane.
 //
 // Replaces the body of Deflate.decompress(_ bitReader:) (reference Sources/Deflate/Deflate.swift:30-249)
 // together with Code.huffmanCodes (Sources/Common/CodingTree/Code.swift:15-39) and DecodingTree
 // (Sources/Common/CodingTree/DecodingTree.swift:15-50).  Semantics -- including the reference's
 // acceptance of incomplete and over-subscribed Huffman sets -- are preserved;
-// the data structures are not: instead of a 2^(maxBits+1) heap walked one bit per step, each lane
-// keeps a compact canonical description of its two alphabets in LDS (152 words per lane, interleaved
-// at wave stride so that arbitrary per-lane indices never bank-conflict) and the 15 left-justified
-// code limits of each alphabet in VGPRs:
+// the data structures are not.  Instead of a 2^(maxBits+1) heap walked one bit per step, each lane keeps
 //
-//   slot[d] (d = 1..15)   = v0[d] << 9 | start[d]   v0 = counter value of the first code of length d
-//                                                    (Code.swift's `symbol` after the shift), start =
-//                                                    index of that code in the (length, symbol)-sorted
-//                                                    symbol array; slot[16] = number of codes
-//   lim[d]                = (first[d] + count[d]) << (15 - d), non-decreasing in d
+//   in LDS (80 words per lane, interleaved at wave stride so that arbitrary per-lane indices never
+//   bank-conflict; 20 KiB per wave => 8 waves = 2 per SIMD resident per CU):
+//       288 + 32 bytes: the lit/len and distance symbols sorted by (code length, symbol); lit/len symbols
+//       are stored modulo 256 -- within one length the symbols >= 256 come last, so bit 8 is an index compare;
+//   in VGPRs, per alphabet (struct Table):
+//       lim[d]  = (first[d] + count[d]) << (15 - d), non-decreasing in d: the code length of the next 15 stream
+//                 bits c15 (bit-reversed, first bit = MSB) is 1 + #{d : c15 >= lim[d]}, found by a 4-step
+//                 binary search over registers;
+//       slot[d] = (start[d] - first[d]) & 0xFFFF | thr[d] << 16: sorted index = slot + (c15 >> (15 - len)),
+//                 symbol >= 256 iff index >= thr.
 //
-// Fast path (set not over-subscribed): code length = 1 + #{d : c15 >= lim[d]} where c15 is the next 15
-// stream bits, bit-reversed (first bit = MSB); sorted index = start[len] + (c15 >> (15-len)) - v0[len].
-// Exact path (over-subscribed sets; also used for the 19-symbol code-length alphabet): for
-// d = 1..15 the heap node at depth d on the path c15 is occupied iff
-// k0 = ((c15 >> (15-d)) - v0[d]) mod 2^d < count[d]; the last writer among k0, k0+2^d, ... wins
-// (DecodingTree.swift:22-32), the shallowest occupied node wins (:45).
+// Exact path (over-subscribed sets, and always for the 19-symbol code-length alphabet): for d = 1..15 the heap
+// node at depth d on the path c15 is occupied iff k0 = ((c15 >> (15-d)) - first[d]) mod 2^d < count[d]; the
+// last writer among k0, k0+2^d, ... wins (DecodingTree.swift:22-32), the shallowest occupied node wins (:45).
 //
-// The dynamic header is decoded twice (count pass, then scatter pass) so that no per-symbol length
-// array has to be kept: 152 words/lane = 38 KiB per wave => 4 waves (256 streams) resident per CU.
+// The dynamic header is decoded twice (count pass into LDS counters that alias the symbol area, then the
+// scatter pass with the per-length running positions packed in registers) so that no per-symbol length array
+// has to be kept.
 #ifndef SWC_INFLATE_LANE_H
 #define SWC_INFLATE_LANE_H
 
@@ -33,14 +33,14 @@
 namespace swc {
 namespace inflate {
 
-constexpr int W_LIT_SYM = 0;     // 96 words : 288 x 9-bit symbols, three per word
-constexpr int W_DIST_SYM = 96;   //  8 words : 32 x 8-bit symbols
-constexpr int W_LIT_LEN = 104;   // 17 words : slot[0..16]
-constexpr int W_DIST_LEN = 121;  // 17 words
-constexpr int W_CL_SYM = 138;    //  5 words : 19 x 8-bit symbols
-constexpr int W_CL_LEN = 143;    //  9 words : slot[0..8]
-constexpr int kWordsPerLane = 152;
-constexpr int kLdsBytesPerWave = kWordsPerLane * 4 * kWave;  // 38,912 B
+constexpr int W_LIT_SYM = 0;     // 72 words : 288 x 8-bit symbols (symbol & 255)
+constexpr int W_DIST_SYM = 72;   //  8 words : 32 x 8-bit symbols
+constexpr int kWordsPerLane = 80;
+constexpr int kLdsBytesPerWave = kWordsPerLane * 4 * kWave;  // 20,480 B
+// count pass only (aliases the symbol area, which is written afterwards):
+constexpr int W_CNT_LIT = 0;     // 16 words : codes per length, lit/len alphabet
+constexpr int W_CNT_LO = 16;     // 16 words : of those, symbols < 256
+constexpr int W_CNT_DIST = 32;   // 16 words : codes per length, distance alphabet
 
 // LSB-first bit reader (BitByteData.LsbBitReader contract) with a 64-bit window
 // and one dword of read-ahead so the HBM/L2 latency of the next refill is hidden behind decode work.
@@ -99,74 +99,99 @@ struct BitReader {
     SWC_HD uint64_t consumed_bits() const { return (uint64_t)(ppos - nextn) * 8 - bc; }
 };
 
-struct Limits {
-    uint32_t lim[16];  // [1..15]; fully unrolled users keep this in VGPRs
+// One canonical Huffman alphabet as Code.swift:15-39 assigns it, in registers (every user is fully unrolled).
+struct Table {
+    uint32_t lim[16];   // [1..15]
+    uint32_t slot[17];  // [1..15]; [16] = number of codes
     bool oversub;
+
+    // derived per-length quantities (exact path only)
+    SWC_HD uint32_t first(int d) const { return d == 1 ? 0u : lim[d - 1] >> (15 - d); }          // code counter of the first code of length d
+    SWC_HD uint32_t start(int d) const { return d == 16 ? slot[16] : (slot[d] + first(d)) & 0xFFFFu; }  // its index in the sorted array
 };
 
-SWC_HD uint32_t lit_sym(const LaneLds& l, uint32_t i) {
-    uint32_t q = (i * 171u) >> 9;  // i / 3 for i < 512
-    return (l.get(W_LIT_SYM + q) >> (9 * (i - 3 * q))) & 511u;
+SWC_HD uint8_t* sym_ptr(const LaneLds& l, int base, uint32_t i) { return (uint8_t*)(l.p + (size_t)(base + (int)(i >> 2)) * l.stride) + (i & 3u); }
+
+// t.slot[i] for i in 0..15 as a 4-level select tree over register values.  The table is taken BY VALUE so that it
+// is scalarised inside this function before the selects are formed, and the selector bits are opaque so that the
+// tree is not re-expressed as sixteen `i == k` compares.
+SWC_HD uint32_t slot_of(Table t, uint32_t i) {
+    uint32_t b8 = i & 8u, b4 = i & 4u, b2 = i & 2u, b1 = i & 1u;
+    SWC_OPAQUE(b8); SWC_OPAQUE(b4); SWC_OPAQUE(b2); SWC_OPAQUE(b1);
+    const bool c8 = b8 != 0, c4 = b4 != 0, c2 = b2 != 0, c1 = b1 != 0;
+    const uint32_t a0 = c8 ? t.slot[8] : t.slot[0], a1 = c8 ? t.slot[9] : t.slot[1], a2 = c8 ? t.slot[10] : t.slot[2];
+    const uint32_t a3 = c8 ? t.slot[11] : t.slot[3], a4 = c8 ? t.slot[12] : t.slot[4], a5 = c8 ? t.slot[13] : t.slot[5];
+    const uint32_t a6 = c8 ? t.slot[14] : t.slot[6], a7 = c8 ? t.slot[15] : t.slot[7];
+    const uint32_t e0 = c4 ? a4 : a0, e1 = c4 ? a5 : a1, e2 = c4 ? a6 : a2, e3 = c4 ? a7 : a3;
+    const uint32_t f0 = c2 ? e2 : e0, f1 = c2 ? e3 : e1;
+    return c1 ? f1 : f0;
 }
-SWC_HD void set_lit_sym(const LaneLds& l, uint32_t i, uint32_t s) {
-    uint32_t q = (i * 171u) >> 9, sh = 9 * (i - 3 * q);
-    uint32_t w = l.get(W_LIT_SYM + q);
-    l.set(W_LIT_SYM + q, (w & ~(511u << sh)) | (s << sh));
-}
-SWC_HD uint32_t byte_sym(const LaneLds& l, int base, uint32_t i) { return (l.get(base + (i >> 2)) >> (8 * (i & 3))) & 255u; }
-SWC_HD void set_byte_sym(const LaneLds& l, int base, uint32_t i, uint32_t s) {
-    uint32_t sh = 8 * (i & 3);
-    uint32_t w = l.get(base + (i >> 2));
-    l.set(base + (i >> 2), (w & ~(255u << sh)) | (s << sh));
+
+// 1 + #{d in 1..15 : c15 >= lim[d]} by binary search (lim is non-decreasing)
+SWC_HD uint32_t code_length(Table t, uint32_t c15) {
+    const uint32_t* L = t.lim;
+    bool b8 = c15 >= L[8];
+    uint32_t m = b8 ? L[12] : L[4];
+    bool b4 = c15 >= m;
+    m = b8 ? (b4 ? L[14] : L[10]) : (b4 ? L[6] : L[2]);
+    bool b2 = c15 >= m;
+    {
+        const uint32_t a = b2 ? L[3] : L[1], b = b2 ? L[7] : L[5];
+        const uint32_t c = b2 ? L[11] : L[9], e = b2 ? L[15] : L[13];
+        const uint32_t ab = b4 ? b : a, ce = b4 ? e : c;
+        m = b8 ? ce : ab;
+    }
+    bool b1 = c15 >= m;
+    return 1u + (b8 ? 8u : 0u) + (b4 ? 4u : 0u) + (b2 ? 2u : 0u) + (b1 ? 1u : 0u);
 }
 
 // Exact heap-equivalent lookup.  Returns the index into the sorted symbol array or -1.
-template <int MAXD>
-SWC_HD int lookup_exact(const LaneLds& l, int wlen, uint32_t c15, uint32_t& len) {
-    uint32_t w = l.get(wlen + 1);
-    for (int d = 1; d <= MAXD; d++) {
-        uint32_t wn = l.get(wlen + d + 1);
-        uint32_t cnt = (wn & 511u) - (w & 511u);
-        uint32_t k0 = ((c15 >> (15 - d)) - (w >> 9)) & ((1u << d) - 1u);
+SWC_HD int lookup_exact(const Table& t, uint32_t c15, uint32_t& len) {
+#pragma unroll
+    for (int d = 1; d <= 15; d++) {
+        const uint32_t st = t.start(d), cnt = (t.start(d + 1) - st) & 0xFFFFu;
+        const uint32_t k0 = ((c15 >> (15 - d)) - t.first(d)) & ((1u << d) - 1u);
         if (k0 < cnt) {
             len = (uint32_t)d;
-            return (int)((w & 511u) + k0 + (((cnt - 1u - k0) >> d) << d));
+            return (int)(st + k0 + (((cnt - 1u - k0) >> d) << d));
         }
-        w = wn;
     }
     return -1;
 }
 
-// slot[1..MAXD] hold per-length COUNTS on entry; on exit slot[d] = v0 << 9 | running index (= start[d])
-// ready for the scatter pass.  Code.swift:23-37 restated per length.
-template <int MAXD>
-SWC_HD void counts_to_slots(const LaneLds& l, int wlen, Limits* lm) {
+// Fill lim[] / slot[] from the per-length counts (Code.swift:23-37 restated per length).  cnt(d), lo(d): number
+// of codes of length d and, of those, symbols < 256.  Returns the start index of every length packed for the
+// scatter pass: run[d / 6] holds six 10-bit fields.
+template <typename CntFn, typename LoFn>
+SWC_HD void build_table(Table& t, CntFn cnt_of, LoFn lo_of, uint64_t run[3]) {
     uint32_t v = 0, off = 0;
     bool over = false;
+    run[0] = run[1] = run[2] = 0;
+    t.lim[0] = 0;
+    t.slot[0] = 0;
 #pragma unroll
-    for (int d = 1; d <= MAXD; d++) {
-        uint32_t cnt = l.get(wlen + d);
-        if (lm) lm->lim[d] = (v + cnt) << (15 - d);
+    for (int d = 1; d <= 15; d++) {
+        const uint32_t cnt = cnt_of(d);
+        t.lim[d] = (v + cnt) << (15 - d);
         if (cnt != 0 && v + cnt > (1u << d)) over = true;
-        l.set(wlen + d, ((v & 0x7FFFu) << 9) | off);
+        t.slot[d] = ((off - v) & 0xFFFFu) | ((off + lo_of(d)) << 16);
+        run[d / 6] |= (uint64_t)off << (10 * (d % 6));
         off += cnt;
         v = (v + cnt) << 1;
     }
-    if (lm) lm->oversub = over;
+    t.slot[16] = off;
+    t.oversub = over;
 }
-// after the scatter pass slot[d].low == start[d+1]; shift back so slot[d].low == start[d], slot[MAXD+1] = total
-template <int MAXD>
-SWC_HD void fixup_slots(const LaneLds& l, int wlen) {
-    uint32_t total = l.get(wlen + MAXD) & 511u;
-    for (int d = MAXD; d >= 1; d--) {
-        uint32_t prev = d > 1 ? (l.get(wlen + d - 1) & 511u) : 0u;
-        l.set(wlen + d, (l.get(wlen + d) & ~511u) | prev);
-    }
-    l.set(wlen + MAXD + 1, total);
-}
-template <int MAXD>
-SWC_HD void clear_slots(const LaneLds& l, int wlen) {
-    for (int d = 0; d <= MAXD + 1; d++) l.set(wlen + d, 0);
+SWC_HD uint32_t run_take(uint64_t run[3], uint32_t d) {  // returns the running index of length d and advances it
+    const uint32_t q = (d * 11u) >> 6, sh = 10u * (d - 6u * q);
+    uint64_t r0 = run[0], r1 = run[1], r2 = run[2];
+    SWC_OPAQUE(r0); SWC_OPAQUE(r1); SWC_OPAQUE(r2);
+    const uint64_t r = q == 0 ? r0 : q == 1 ? r1 : r2;
+    const uint64_t inc = 1ull << sh;
+    run[0] += q == 0 ? inc : 0;
+    run[1] += q == 1 ? inc : 0;
+    run[2] += q == 2 ? inc : 0;
+    return (uint32_t)(r >> sh) & 1023u;
 }
 
 // Phase 1 of the two-phase Deflate path (see lz_resolve.h): literals go straight to their final position,
@@ -174,7 +199,7 @@ SWC_HD void clear_slots(const LaneLds& l, int wlen) {
 struct Lane {
     LaneLds l;
     BitReader br;
-    Limits lit, dist;
+    Table lit, dist;
     gptr out;
     uint64_t cap;
     uint64_t pos;  // bytes produced (keeps counting past cap: size pass for SWC_E_CAPACITY)
@@ -205,40 +230,59 @@ struct Lane {
     // -1 (DeflateError.symbolNotFound: unassigned path, or the code runs past the end of input).
     template <bool LIT, bool CHECKED = true>
     SWC_HD int decode_sym() {
-        const Limits& lm = LIT ? lit : dist;
-        const int wlen = LIT ? W_LIT_LEN : W_DIST_LEN;
-        uint32_t c15 = brev32(br.peek32()) >> 17;
-        uint32_t len;
-        int idx;
-        if (!CHECKED || !lm.oversub) {
-            len = 1;
-#pragma unroll
-            for (int d = 1; d <= 15; d++) len += (c15 >= lm.lim[d]) ? 1u : 0u;
+        const Table& t = LIT ? lit : dist;
+        const uint32_t c15 = brev32(br.peek32()) >> 17;
+        uint32_t len, idx;
+        if (!CHECKED || !t.oversub) {
+            len = code_length(t, c15);
             if (len > 15) return -1;
-            uint32_t w = l.get(wlen + (int)len);
-            idx = (int)((w & 511u) + (c15 >> (15 - len)) - (w >> 9));
         } else {
-            idx = lookup_exact<15>(l, wlen, c15, len);
-            if (idx < 0) return -1;
+            int i = lookup_exact(t, c15, len);
+            if (i < 0) return -1;
+            idx = (uint32_t)i;
         }
+        const uint32_t sl = slot_of(t, len);
+        if (!CHECKED || !t.oversub) idx = (sl + (c15 >> (15 - len))) & 0xFFFFu;
         if (CHECKED && len > br.bc) return -1;  // DecodingTree.swift:39 -- ran out of bits before reaching a leaf
         br.consume(len);
-        return LIT ? (int)lit_sym(l, (uint32_t)idx) : (int)byte_sym(l, W_DIST_SYM, (uint32_t)idx);
+        uint32_t sym = *sym_ptr(l, LIT ? W_LIT_SYM : W_DIST_SYM, idx);
+        if (LIT) sym |= idx >= (sl >> 16) ? 256u : 0u;
+        return (int)sym;
     }
 
-    // Walk the code-length section of a dynamic header (Deflate.swift:117-162).  PASS2 = false counts
-    // codes per length into slot[]; PASS2 = true scatters symbols into the sorted arrays.
+    // The 19-symbol code-length alphabet, in registers: slot[d] = first << 9 | start (d = 1..7), slot[8] = total;
+    // sorted symbols packed 5 bits each.
+    struct ClTable {
+        uint32_t slot[9];
+        uint64_t sym_lo, sym_hi;
+    };
+    SWC_HD static int cl_lookup(const ClTable& t, uint32_t c15, uint32_t& len) {
+#pragma unroll
+        for (int d = 1; d <= 7; d++) {
+            const uint32_t w = t.slot[d], wn = t.slot[d + 1];
+            const uint32_t cnt = (wn & 511u) - (w & 511u);
+            const uint32_t k0 = ((c15 >> (15 - d)) - (w >> 9)) & ((1u << d) - 1u);
+            if (k0 < cnt) {
+                len = (uint32_t)d;
+                return (int)((w & 511u) + k0 + (((cnt - 1u - k0) >> d) << d));
+            }
+        }
+        return -1;
+    }
+
+    // Walk the code-length section of a dynamic header (Deflate.swift:117-162).  PASS2 = false counts codes
+    // per length into the LDS counters; PASS2 = true scatters symbols into the sorted arrays.
     template <bool PASS2>
-    SWC_HD int scan_lengths(int literals, int total) {
+    SWC_HD int scan_lengths(const ClTable& cl, int literals, int total, uint64_t run_lit[3], uint64_t run_dist[3]) {
         int n = 0;
         uint32_t prev = 0;
         while (n < total) {
             br.refill();
             uint32_t c15 = brev32(br.peek32()) >> 17, len;
-            int idx = lookup_exact<7>(l, W_CL_LEN, c15, len);
+            int idx = cl_lookup(cl, c15, len);
             if (idx < 0 || len > br.bc) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :122
             br.consume(len);
-            uint32_t sym = byte_sym(l, W_CL_SYM, (uint32_t)idx);
+            uint32_t sym = (uint32_t)((idx < 12 ? cl.sym_lo >> (5 * idx) : cl.sym_hi >> (5 * (idx - 12))) & 31u);
             int rep;
             uint32_t val;
             if (sym <= 15) {
@@ -260,15 +304,17 @@ struct Lane {
             }
             prev = val;
             if (val != 0) {
-                for (int i = 0; i < rep; i++) {
-                    int s = n + i;
-                    bool is_lit = s < literals;
-                    int slot = (is_lit ? W_LIT_LEN : W_DIST_LEN) + (int)val;
-                    uint32_t w = l.get(slot);
-                    l.set(slot, w + 1);
-                    if (PASS2) {
-                        if (is_lit) set_lit_sym(l, w & 511u, (uint32_t)s);
-                        else set_byte_sym(l, W_DIST_SYM, w & 511u, (uint32_t)(s - literals));
+                if (!PASS2) {
+                    int n_lit = literals - n; n_lit = n_lit < 0 ? 0 : n_lit > rep ? rep : n_lit;
+                    int n_lo = 256 - n;       n_lo = n_lo < 0 ? 0 : n_lo > rep ? rep : n_lo;
+                    if (n_lit) l.set(W_CNT_LIT + (int)val, l.get(W_CNT_LIT + (int)val) + (uint32_t)n_lit);
+                    if (n_lo) l.set(W_CNT_LO + (int)val, l.get(W_CNT_LO + (int)val) + (uint32_t)n_lo);
+                    if (rep - n_lit) l.set(W_CNT_DIST + (int)val, l.get(W_CNT_DIST + (int)val) + (uint32_t)(rep - n_lit));
+                } else {
+                    for (int i = 0; i < rep; i++) {
+                        int s = n + i;
+                        if (s < literals) *sym_ptr(l, W_LIT_SYM, run_take(run_lit, val)) = (uint8_t)s;
+                        else *sym_ptr(l, W_DIST_SYM, run_take(run_dist, val)) = (uint8_t)(s - literals);
                     }
                 }
             }
@@ -286,13 +332,10 @@ struct Lane {
         if (literals > 286) return SWC_E_DEFLATE_WRONG_SYMBOL;  // :94
         int distances = (int)br.bits(5) + 1;
         int ncl = (int)br.bits(4) + 4;
-        // 3*ncl <= 57 bits: gather them through two refills
         br.refill();
-        uint64_t avail = br.bc;
         // bitsLeft covers the whole remaining stream, not just the window (:101)
         uint64_t total_left = (uint64_t)br.len * 8 - br.consumed_bits();
         if (total_left < (uint64_t)(3 * ncl)) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;
-        (void)avail;
         // code-length alphabet: 19 x 3 bits in codeLengthOrders order (Deflate+Constants.swift:175)
         const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
         uint64_t clens = 0;  // 3 bits per symbol, indexed by symbol
@@ -300,57 +343,57 @@ struct Lane {
             br.refill();
             clens |= (uint64_t)br.bits(3) << (3 * order[i]);
         }
-        clear_slots<7>(l, W_CL_LEN);
-        for (int s = 0; s < 19; s++) {
-            uint32_t len = (uint32_t)(clens >> (3 * s)) & 7u;
-            if (len) l.set(W_CL_LEN + (int)len, l.get(W_CL_LEN + (int)len) + 1);
-        }
-        counts_to_slots<7>(l, W_CL_LEN, nullptr);
-        for (int s = 0; s < 19; s++) {
-            uint32_t len = (uint32_t)(clens >> (3 * s)) & 7u;
-            if (len) {
-                uint32_t w = l.get(W_CL_LEN + (int)len);
-                l.set(W_CL_LEN + (int)len, w + 1);
-                set_byte_sym(l, W_CL_SYM, w & 511u, (uint32_t)s);
+        ClTable cl;
+        {
+            uint64_t cnt8 = 0, runp = 0;  // eight 8-bit fields, indexed by length
+            for (int s = 0; s < 19; s++) {
+                uint32_t len = (uint32_t)(clens >> (3 * s)) & 7u;
+                if (len) cnt8 += 1ull << (8 * len);
+            }
+            uint32_t v = 0, off = 0;
+            cl.slot[0] = 0;
+#pragma unroll
+            for (int d = 1; d <= 7; d++) {
+                const uint32_t c = (uint32_t)(cnt8 >> (8 * d)) & 255u;
+                cl.slot[d] = ((v & 0x7FFFu) << 9) | off;
+                runp |= (uint64_t)off << (8 * d);
+                off += c;
+                v = (v + c) << 1;
+            }
+            cl.slot[8] = off;
+            cl.sym_lo = cl.sym_hi = 0;
+            for (int s = 0; s < 19; s++) {
+                uint32_t len = (uint32_t)(clens >> (3 * s)) & 7u;
+                if (len) {
+                    uint32_t pos = (uint32_t)(runp >> (8 * len)) & 255u;
+                    runp += 1ull << (8 * len);
+                    if (pos < 12) cl.sym_lo |= (uint64_t)s << (5 * pos);
+                    else cl.sym_hi |= (uint64_t)s << (5 * (pos - 12));
+                }
             }
         }
-        fixup_slots<7>(l, W_CL_LEN);
-
-        clear_slots<15>(l, W_LIT_LEN);
-        clear_slots<15>(l, W_DIST_LEN);
+        for (int j = 0; j < 48; j++) l.set(j, 0);
+        uint64_t run_lit[3], run_dist[3];
         BitReader save = br;
-        int st = scan_lengths<false>(literals, literals + distances);
+        int st = scan_lengths<false>(cl, literals, literals + distances, run_lit, run_dist);
         if (st) return st;
-        counts_to_slots<15>(l, W_LIT_LEN, &lit);
-        counts_to_slots<15>(l, W_DIST_LEN, &dist);
+        build_table(lit, [&](int d) { return l.get(W_CNT_LIT + d); }, [&](int d) { return l.get(W_CNT_LO + d); }, run_lit);
+        build_table(dist, [&](int d) { return l.get(W_CNT_DIST + d); }, [&](int) { return 0u; }, run_dist);
         br = save;
-        st = scan_lengths<true>(literals, literals + distances);
-        if (st) return st;
-        fixup_slots<15>(l, W_LIT_LEN);
-        fixup_slots<15>(l, W_DIST_LEN);
-        return SWC_OK;
+        return scan_lengths<true>(cl, literals, literals + distances, run_lit, run_dist);
     }
 
     // Deflate.swift:77-81 with the fixed code of Deflate+Constants.swift:11-173
     SWC_HD void build_static() {
-        clear_slots<15>(l, W_LIT_LEN);
-        clear_slots<15>(l, W_DIST_LEN);
-        l.set(W_LIT_LEN + 7, 24);
-        l.set(W_LIT_LEN + 8, 152);
-        l.set(W_LIT_LEN + 9, 112);
-        l.set(W_DIST_LEN + 5, 32);
-        counts_to_slots<15>(l, W_LIT_LEN, &lit);
-        counts_to_slots<15>(l, W_DIST_LEN, &dist);
+        uint64_t run_lit[3], run_dist[3];
+        build_table(lit, [](int d) { return d == 7 ? 24u : d == 8 ? 152u : d == 9 ? 112u : 0u; },
+                    [](int d) { return d == 8 ? 144u : d == 9 ? 112u : 0u; }, run_lit);
+        build_table(dist, [](int d) { return d == 5 ? 32u : 0u; }, [](int) { return 0u; }, run_dist);
         for (uint32_t s = 0; s < 288; s++) {
-            int len = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
-            uint32_t w = l.get(W_LIT_LEN + len);
-            l.set(W_LIT_LEN + len, w + 1);
-            set_lit_sym(l, w & 511u, s);
+            uint32_t len = s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : 8;
+            *sym_ptr(l, W_LIT_SYM, run_take(run_lit, len)) = (uint8_t)s;
         }
-        for (uint32_t s = 0; s < 32; s++) set_byte_sym(l, W_DIST_SYM, s, s);
-        l.set(W_DIST_LEN + 5, l.get(W_DIST_LEN + 5) + 32);
-        fixup_slots<15>(l, W_LIT_LEN);
-        fixup_slots<15>(l, W_DIST_LEN);
+        for (uint32_t s = 0; s < 32; s++) *sym_ptr(l, W_DIST_SYM, s) = (uint8_t)s;
     }
 
     SWC_HD void put_byte(uint8_t b) {

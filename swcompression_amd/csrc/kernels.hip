@@ -19,9 +19,9 @@
 namespace swc {
 
 // ---- Deflate: two phases (inflate_lane.h, lz_resolve.h) ------------------------------------------------
-// Phase 1: one stream per lane.  LDS: 152 words/lane -> 38,912 B per wave -> 4 resident waves per CU.
+// Phase 1: one stream per lane.  LDS: 80 words/lane -> 20,480 B per wave -> 8 resident waves per CU (2 per SIMD).
 // Literals are stored in place, matches become records in the workspace; no output reads.
-__global__ __launch_bounds__(64, 1) void swc_inflate_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride) {
+__global__ __launch_bounds__(64, 2) void swc_inflate_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t g = blockIdx.x * kWave + threadIdx.x;
     if (g >= n) return;
@@ -42,8 +42,28 @@ __global__ __launch_bounds__(T) void swc_lz_resolve_kernel(const Job* __restrict
     lzr::resolve_job<T>(job, ws + (size_t)g * ws_stride, &lzr_lds, (int)threadIdx.x, dbg);
 }
 
-static int g_resolve_threads = 256, g_resolve_dbg = 0;
+static int g_resolve_threads = 512, g_resolve_dbg = 0;
 void set_resolve_debug(int m) { g_resolve_dbg = m; }
+
+// Optional per-phase timing of the last Deflate launch (bench.py: roofline per kernel).  HIP events on the
+// launch stream; off by default so that the production path issues nothing but the two kernels.
+static int g_phase_timing = 0;
+static hipEvent_t g_phase_ev[3];
+static bool g_phase_ev_ok = false, g_phase_valid = false;
+void set_phase_timing(int on) {
+    g_phase_timing = on;
+    if (on && !g_phase_ev_ok) {
+        g_phase_ev_ok = true;
+        for (auto& e : g_phase_ev) if (hipEventCreate(&e) != hipSuccess) g_phase_ev_ok = false;
+    }
+}
+int last_phase_ms(float* ms, int cap) {
+    if (!g_phase_valid || cap < 2) return 0;
+    if (hipEventSynchronize(g_phase_ev[2]) != hipSuccess) return 0;
+    if (hipEventElapsedTime(&ms[0], g_phase_ev[0], g_phase_ev[1]) != hipSuccess) return 0;
+    if (hipEventElapsedTime(&ms[1], g_phase_ev[1], g_phase_ev[2]) != hipSuccess) return 0;
+    return 2;
+}
 void set_resolve_threads(int t) { g_resolve_threads = t; }
 size_t inflate_ws_bytes_per_job(uint64_t cap) { return lzr::ws_bytes_per_job(cap); }
 
@@ -52,15 +72,19 @@ hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStr
     size_t stride = ws ? (ws_bytes / n) & ~(size_t)15 : 0;
     if (stride < sizeof(lzr::StreamHeader)) return hipErrorInvalidValue;
     dim3 grid((unsigned)((n + kWave - 1) / kWave)), block(kWave);
+    const bool timing = g_phase_timing && g_phase_ev_ok;
+    if (timing) (void)hipEventRecord(g_phase_ev[0], stream);
     hipLaunchKernelGGL(swc_inflate_kernel, grid, block, inflate::kLdsBytesPerWave, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride);
+    if (timing) (void)hipEventRecord(g_phase_ev[1], stream);
     dim3 grid2((unsigned)n);
     switch (g_resolve_threads) {
         case 64: hipLaunchKernelGGL(swc_lz_resolve_kernel<64>, grid2, dim3(64), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
         case 128: hipLaunchKernelGGL(swc_lz_resolve_kernel<128>, grid2, dim3(128), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
-        case 512: hipLaunchKernelGGL(swc_lz_resolve_kernel<512>, grid2, dim3(512), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
+        default: hipLaunchKernelGGL(swc_lz_resolve_kernel<512>, grid2, dim3(512), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
         case 1024: hipLaunchKernelGGL(swc_lz_resolve_kernel<1024>, grid2, dim3(1024), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
-        default: hipLaunchKernelGGL(swc_lz_resolve_kernel<256>, grid2, dim3(256), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
+        case 256: hipLaunchKernelGGL(swc_lz_resolve_kernel<256>, grid2, dim3(256), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
     }
+    if (timing) { (void)hipEventRecord(g_phase_ev[2], stream); g_phase_valid = true; }
     return hipGetLastError();
 }
 

@@ -244,12 +244,26 @@ struct Resolver {
         }
         for (uint32_t j = 0; j < n; j++) ring[(x + j) & kRingMask] = (uint8_t)(v >> (8 * j));
     }
-    SWC_D void copy_plain(uint32_t d, uint32_t s, uint32_t n) const {  // s + n <= d: sources never written here
+    // write the low n (< 8) bytes of v at ring index x
+    SWC_D void wr_tail(uint32_t x, uint32_t n, uint64_t v) const {
+        if (n >= 4) { wr(x, 4, v); v >>= 32; x += 4; n -= 4; }
+        if (n >= 2) { wr(x, 2, v); v >>= 16; x += 2; n -= 2; }
+        if (n >= 1) wr(x, 1, v);
+    }
+    // s + n <= d: sources are never written here, so all reads of a step are issued before its writes (one LDS
+    // round trip per 16 bytes).  Reads may run past the n source bytes; the surplus is discarded.
+    SWC_D void copy_plain(uint32_t d, uint32_t s, uint32_t n) const {
         uint32_t i = 0;
-        for (; i + 8 <= n; i += 8) wr(d + i, 8, rd(s + i, 8));
-        if (n - i >= 4) { wr(d + i, 4, rd(s + i, 4)); i += 4; }
-        if (n - i >= 2) { wr(d + i, 2, rd(s + i, 2)); i += 2; }
-        if (n - i >= 1) wr(d + i, 1, rd(s + i, 1));
+        for (; i + 16 <= n; i += 16) {
+            const uint64_t a = rd(s + i, 8), b = rd(s + i + 8, 8);
+            wr(d + i, 8, a);
+            wr(d + i + 8, 8, b);
+        }
+        uint32_t rem = n - i;
+        if (rem == 0) return;
+        uint64_t a = rd(s + i, 8), b = rem > 8 ? rd(s + i + 8, 8) : 0;
+        if (rem >= 8) { wr(d + i, 8, a); a = b; i += 8; rem -= 8; }
+        wr_tail(d + i, rem, a);
     }
     // One match inside the ring: `len` bytes at position dpos; the first min(len, period) bytes (the pattern) come
     // from position spos (all producers done, spos + pattern <= dpos), the rest repeats the pattern with `period`.
@@ -266,9 +280,7 @@ struct Resolver {
             for (; k < stop; k++) wr(d + k, 1, rd(d + k - period, 1));
         }
         for (; k + 8 <= len; k += 8) wr(d + k, 8, rd(d + k - back, 8));   // LDS executes a lane's accesses in order
-        if (len - k >= 4) { wr(d + k, 4, rd(d + k - back, 4)); k += 4; }
-        if (len - k >= 2) { wr(d + k, 2, rd(d + k - back, 2)); k += 2; }
-        if (len - k >= 1) wr(d + k, 1, rd(d + k - back, 1));
+        if (k < len) wr_tail(d + k, len - k, rd(d + k - back, 8));
     }
 
     // first index in [0, n) with a[i] > v   (a non-decreasing)

@@ -21,6 +21,15 @@
 #define SWC_D inline
 #endif
 
+// Makes a value opaque to the optimiser at no run-time cost.  Used where register-resident tables are read through
+// select trees: without it LLVM folds `c ? a[i] : a[j]` into a load at a DYNAMIC offset, which pins the whole
+// table (and the struct around it) in scratch memory instead of VGPRs.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SWC_OPAQUE(x) asm("" : "+v"(x))
+#else
+#define SWC_OPAQUE(x) ((void)0)
+#endif
+
 namespace swc {
 
 constexpr int kWave = 64;  // CDNA wavefront width; LDS tables are interleaved at this stride

@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Turn the counter_collection CSVs of tools/pmc_bench.sh into HBM bytes per launch.
+
+Per launch = sum over the kernels of ONE pass of the hot path (the last dispatch of each swc:: kernel).
+Units/corrections per MI355X_MICROARCH.md (HBM section): FETCH_SIZE / WRITE_SIZE are in KiB-like units of
+1024 B; on gfx950 FETCH_SIZE counts a 128-byte request as 64 bytes for wide coalesced streaming reads, so
+read bytes = FETCH_SIZE * 1024 * 2 is an UPPER estimate for kernels whose reads are narrower (reported both ways)."""
+import collections, csv, glob, json, sys
+
+d, workload, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+per = collections.defaultdict(dict)   # kernel -> counter -> value of the last dispatch
+for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
+    rows = [r for r in csv.DictReader(open(f)) if "swc" in r["Kernel_Name"]]
+    last = {}
+    for r in rows:
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        last[k] = max(last.get(k, 0), int(r["Dispatch_Id"]))
+    acc = collections.defaultdict(float)
+    for r in rows:
+        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+        if int(r["Dispatch_Id"]) == last[k]:
+            acc[(k, r["Counter_Name"])] += float(r["Counter_Value"])
+    for (k, c), v in acc.items():
+        per[k][c] = v
+fetch = sum(v.get("FETCH_SIZE", 0.0) for v in per.values()) * 1024
+write = sum(v.get("WRITE_SIZE", 0.0) for v in per.values()) * 1024
+out = {"workload": workload, "round": tag, "per_kernel_counters": per,
+       "fetch_bytes_raw": fetch, "fetch_bytes_x2_gfx950": fetch * 2, "write_bytes": write,
+       "hbm_bytes_per_launch": fetch * 2 + write,
+       "note": "hbm_bytes_per_launch = FETCH_SIZE*1024*2 (gfx950 half-count correction for wide streaming reads) + WRITE_SIZE*1024; "
+               "WRITE_SIZE uncalibrated; one launch = last dispatch of each swc:: kernel"}
+print(json.dumps(out, indent=1))
