@@ -95,6 +95,11 @@ struct BitReader {
         consume(n);
         return v;
     }
+    // reposition at absolute bit `p` of the stream
+    SWC_HD void seek(uint64_t p) {
+        init(in, len, (uint32_t)(p >> 3));
+        consume((uint32_t)p & 7u);
+    }
     // bits consumed from the start of the stream
     SWC_HD uint64_t consumed_bits() const { return (uint64_t)(ppos - nextn) * 8 - bc; }
 };
@@ -142,6 +147,31 @@ SWC_HD uint32_t code_length(Table t, uint32_t c15) {
         m = b8 ? ce : ab;
     }
     bool b1 = c15 >= m;
+    return 1u + (b8 ? 8u : 0u) + (b4 ? 4u : 0u) + (b2 ? 2u : 0u) + (b1 ? 1u : 0u);
+}
+
+// Code length AND slot word of the code that starts c15, for a set that is not over-subscribed: the slot select
+// tree shares the compare results of the binary search (slot index = length - 1).  length 16 = no such code.
+SWC_HD uint32_t code_length_slot(Table t, uint32_t c15, uint32_t& sl) {
+    const uint32_t* L = t.lim;
+    const uint32_t* S = t.slot + 1;   // S[p] = slot of length p + 1; S[15] = slot[16] (never used: length 16 is rejected)
+    const bool b8 = c15 >= L[8];
+    uint32_t m = b8 ? L[12] : L[4];
+    const uint32_t a0 = b8 ? S[8] : S[0], a1 = b8 ? S[9] : S[1], a2 = b8 ? S[10] : S[2], a3 = b8 ? S[11] : S[3];
+    const uint32_t a4 = b8 ? S[12] : S[4], a5 = b8 ? S[13] : S[5], a6 = b8 ? S[14] : S[6], a7 = b8 ? S[15] : S[7];
+    const bool b4 = c15 >= m;
+    m = b8 ? (b4 ? L[14] : L[10]) : (b4 ? L[6] : L[2]);
+    const uint32_t e0 = b4 ? a4 : a0, e1 = b4 ? a5 : a1, e2 = b4 ? a6 : a2, e3 = b4 ? a7 : a3;
+    const bool b2 = c15 >= m;
+    {
+        const uint32_t a = b2 ? L[3] : L[1], b = b2 ? L[7] : L[5];
+        const uint32_t c = b2 ? L[11] : L[9], e = b2 ? L[15] : L[13];
+        const uint32_t ab = b4 ? b : a, ce = b4 ? e : c;
+        m = b8 ? ce : ab;
+    }
+    const uint32_t f0 = b2 ? e2 : e0, f1 = b2 ? e3 : e1;
+    const bool b1 = c15 >= m;
+    sl = b1 ? f1 : f0;
     return 1u + (b8 ? 8u : 0u) + (b4 ? 4u : 0u) + (b2 ? 2u : 0u) + (b1 ? 1u : 0u);
 }
 
@@ -203,7 +233,7 @@ struct Lane {
     gptr out;
     uint64_t cap;
     uint64_t pos;  // bytes produced (keeps counting past cap: size pass for SWC_E_CAPACITY)
-    SWC_AS_GLOBAL uint32_t* recs;  // record list in the HBM workspace
+    SWC_AS_GLOBAL uint32_t* recs;  // record list in the HBM workspace (the stream's StreamHeader sits 16 bytes before it)
     uint32_t nrec, max_rec;
     uint64_t last_end;             // position just past the previous record
 
@@ -401,71 +431,175 @@ struct Lane {
         pos++;
     }
 
+    SWC_HD static uint32_t funnel(uint32_t hi, uint32_t lo, uint32_t sh) {  // bits [sh, sh + 32) of hi:lo, sh < 32
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+        return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+#endif
+    }
+
+    // Interior fast loop of a block whose code sets are not over-subscribed.
+    //
+    // The body is ONE straight-line, fully predicated schedule -- every lane executes the lit/len decode, the
+    // distance decode, one literal store, one record store and one 8-byte input load per iteration, whatever its
+    // symbol is (a wave executes all of it anyway as soon as one lane holds a match).  With a fixed sequence of
+    // memory instructions the compiler can wait for the input load with an exact s_waitcnt vmcnt(2) instead of
+    // vmcnt(0); measured before: 81 % of wave time was spent at a loop-head vmcnt(0) that drained the stores of the
+    // previous iteration (profiles/r01_pmc_deflate_two_phase_v1.txt).  Stores of lanes that do not own them are
+    // harmless by construction: a match lane writes a garbage byte at its match start (phase 2 overwrites it), a
+    // literal lane writes a garbage record into the NEXT FREE record slot (overwritten by the next real record or
+    // never counted).
+    //
+    // Bit window: four valid dwords d0..d3 (128 bits) + two in flight; bp < 64 at the top of the decode, one
+    // iteration consumes <= 48 bits, so ONE 64-bit shift per iteration always suffices.  Positions are 32 bit.
+    // ANYTHING unusual -- unassigned code, symbol > 285, distance symbol > 29, distance beyond the output, a literal
+    // run of 255+ before a match -- leaves the loop BEFORE consuming the symbol; the caller then decodes that one
+    // symbol with the fully checked step.  Returns true when the end-of-block symbol was consumed.
+    SWC_HD bool fast_loop() {
+        const uint64_t P = br.consumed_bits();
+        uint32_t q = (uint32_t)(P >> 6) << 3, bp = (uint32_t)P & 63u;
+        gcptr in = br.in;
+        const uint32_t len = br.len;
+        if ((uint64_t)q + 48 > len) return false;
+        uint32_t d0 = load_u32(in + q), d1 = load_u32(in + q + 4), d2 = load_u32(in + q + 8), d3 = load_u32(in + q + 12);
+        uint64_t nx = load_u64(in + q + 16);
+        // drain the set-up loads here, once: otherwise the loop-head wait has to cover the entry path too and
+        // degrades to vmcnt(0) for every iteration
+        SWC_OPAQUE(d0); SWC_OPAQUE(d1); SWC_OPAQUE(d2); SWC_OPAQUE(d3); SWC_OPAQUE(nx);
+        uint32_t p = (uint32_t)pos, le = (uint32_t)last_end, nr = nrec;
+        const uint32_t plimit = (uint32_t)(cap - 272);
+        // Memory instructions of lanes that do not need them this iteration are pointed at ONE wave-wide dummy
+        // location (the pad words of the first lane's stream header / the first lane's input): the instruction stays
+        // unconditional -- which is what lets the compiler count it -- but costs a single extra request.
+        gptr dummy_st = (gptr)recs - 12;
+        gcptr dummy_ld = in;
+#if defined(__HIP_DEVICE_COMPILE__)
+        {
+            uint64_t a = (uint64_t)(uintptr_t)dummy_st, b = (uint64_t)(uintptr_t)dummy_ld;
+            a = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)a);
+            b = ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(b >> 32)) << 32) | (uint32_t)__builtin_amdgcn_readfirstlane((int)b);
+            dummy_st = (gptr)(uintptr_t)a;
+            dummy_ld = (gcptr)(uintptr_t)b;
+        }
+#endif
+        bool eob = false;
+        for (;;) {
+            // one 64-bit shift if due, then the unconditional prefetch of the granule after the next one
+            const bool sh = bp >= 64;
+            d0 = sh ? d2 : d0;
+            d1 = sh ? d3 : d1;
+            d2 = sh ? (uint32_t)nx : d2;
+            d3 = sh ? (uint32_t)(nx >> 32) : d3;
+            q += sh ? 8u : 0u;
+            bp -= sh ? 64u : 0u;
+            if (q + 48 > len || p > plimit) break;
+            {
+                const uint64_t t = load_u64(sh ? in + q + 16 : dummy_ld);
+                nx = sh ? t : nx;
+            }
+            // ---- lit/len symbol at bp (< 64)
+            const bool k1 = bp >= 32;
+            const uint32_t pk = funnel(k1 ? d2 : d1, k1 ? d1 : d0, bp & 31u);
+            const uint32_t c15 = brev32(pk) >> 17;
+            uint32_t sl;
+            const uint32_t n = code_length_slot(lit, c15, sl);
+            uint32_t idx = (sl + (c15 >> (15 - (n & 15u)))) & 0xFFFFu;
+            const bool is_lit = idx < (sl >> 16);
+            idx = idx > 319u ? 319u : idx;
+            const uint32_t sym = *sym_ptr(l, W_LIT_SYM, idx);
+            // ---- length + distance (computed by every lane)
+            const uint32_t s = (sym - 1u) & 31u;
+            const uint32_t e = s < 8 || s >= 28 ? 0u : (s >> 2) - 1u;
+            const uint32_t length = (s < 8 ? 3u + s : s >= 28 ? 258u : 3u + ((4u + (s & 3u)) << e)) + ((pk >> n) & ((1u << e) - 1u));
+            const uint32_t bp2 = bp + n + e;  // < 64 + 20
+            const bool m1 = bp2 >= 32, m2 = bp2 >= 64;
+            const uint32_t xlo = m2 ? d2 : m1 ? d1 : d0, xhi = m2 ? d3 : m1 ? d2 : d1;
+            const uint32_t pk2 = funnel(xhi, xlo, bp2 & 31u);
+            const uint32_t c15d = brev32(pk2) >> 17;
+            uint32_t sl2;
+            const uint32_t n2 = code_length_slot(dist, c15d, sl2);
+            uint32_t idx2 = (sl2 + (c15d >> (15 - (n2 & 15u)))) & 0xFFFFu;
+            idx2 = idx2 > 31u ? 31u : idx2;
+            const uint32_t dc = *sym_ptr(l, W_DIST_SYM, idx2);
+            const uint32_t de = dc < 4 ? 0u : ((dc >> 1) - 1u) & 15u;
+            const uint32_t distance = (dc < 4 ? 1u + dc : 1u + ((2u + (dc & 1u)) << de)) + ((pk2 >> n2) & ((1u << de) - 1u));
+            const uint32_t run = p - le;
+            // ---- classify
+            const bool code_ok = n <= 15;
+            const bool is_eob = code_ok && !is_lit && sym == 0;
+            const bool is_match = code_ok && !is_lit && sym != 0 && sym <= 29 && n2 <= 15 && dc <= 29 && distance <= p && run < 255;
+            // ---- unconditional stores (see above), BEFORE the exits so that every path from the input load to its use
+            // in the next iteration passes exactly these two stores.  A lane that leaves below has written one garbage
+            // byte at its next output position and one garbage record into the next free slot; both get overwritten.
+            *(is_lit ? out + p : dummy_st) = (uint8_t)sym;
+            *(is_lit ? (SWC_AS_GLOBAL uint32_t*)(dummy_st + 4) : recs + nr) = lzr::make_match(run, length, distance);
+            if (is_eob) { bp += n; eob = true; break; }
+            if (!(code_ok && is_lit) && !is_match) break;   // leave BEFORE consuming: the checked step handles it
+            p += is_match ? length : 1u;
+            le = is_match ? p : le;
+            nr += is_match ? 1u : 0u;
+            bp += is_match ? n + e + n2 + de : n;
+        }
+        pos = (pos & ~0xFFFFFFFFull) | p;
+        last_end = (last_end & ~0xFFFFFFFFull) | le;
+        nrec = nr;
+        br.seek((uint64_t)q * 8 + bp);
+        return eob;
+    }
+
+    // One symbol with every check of the reference (Deflate.swift:171-236).  Returns SWC_OK to continue, -1 at
+    // the end-of-block symbol, or the error.
+    SWC_HD int careful_step() {
+        br.refill();
+        int sym = decode_sym<true>();
+        if (sym < 0) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :175
+        if (sym < 256) {
+            put_byte((uint8_t)sym);
+            return SWC_OK;
+        }
+        if (sym == 256) return -1;
+        if (sym > 285) return SWC_E_DEFLATE_WRONG_SYMBOL;  // :233
+        uint32_t s = (uint32_t)sym - 257u, length;
+        if (s < 8) {
+            length = 3 + s;
+        } else if (s == 28) {
+            length = 258;
+        } else {
+            uint32_t e = (s >> 2) - 1;  // :188
+            if (br.bc < e) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :192
+            length = 3 + ((4 + (s & 3)) << e) + br.bits(e);  // Constants.lengthBase
+        }
+        br.refill();
+        int dc = decode_sym<false>();
+        if (dc < 0) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :199
+        if (dc > 29) return SWC_E_DEFLATE_WRONG_SYMBOL;     // :201
+        uint32_t distance;
+        if (dc < 4) {
+            distance = 1 + (uint32_t)dc;
+        } else {
+            uint32_t e = ((uint32_t)dc >> 1) - 1;  // :206
+            if (br.bc < e) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :208
+            distance = 1 + ((2 + ((uint32_t)dc & 1)) << e) + br.bits(e);  // Constants.distanceBase
+        }
+        // :216-221 out[count - distance] with distance > count is a Swift trap (App. A6)
+        if ((uint64_t)distance > pos) return SWC_E_REF_TRAP;
+        emit_match(length, distance);
+        return SWC_OK;
+    }
+
     // Deflate.swift:171-236
     SWC_HD int run_block() {
-        // ---- interior fast loop: >= 8 input bytes beyond the read-ahead and >= 272 output bytes of
-        // room, code sets not over-subscribed => no truncation / capacity / exact-lookup checks.
-        if (!lit.oversub && !dist.oversub) {
-            while ((uint64_t)br.ppos + 8 <= br.len && pos + 272 <= cap) {
-                br.refill_fast();
-                int sym = decode_sym<true, false>();
-                if (sym < 0) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;
-                if (sym < 256) {
-                    out[pos] = (uint8_t)sym;
-                    pos++;
-                    continue;
-                }
-                if (sym == 256) return SWC_OK;
-                if (sym > 285) return SWC_E_DEFLATE_WRONG_SYMBOL;
-                uint32_t s = (uint32_t)sym - 257u;
-                uint32_t e = s < 8 || s == 28 ? 0u : (s >> 2) - 1u;
-                uint32_t length = (s < 8 ? 3u + s : s == 28 ? 258u : 3u + ((4u + (s & 3u)) << e)) + br.bits(e);
-                br.refill_fast();
-                int dc = decode_sym<false, false>();
-                if (dc < 0) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;
-                if (dc > 29) return SWC_E_DEFLATE_WRONG_SYMBOL;
-                uint32_t de = dc < 4 ? 0u : ((uint32_t)dc >> 1) - 1u;
-                uint32_t distance = (dc < 4 ? 1u + (uint32_t)dc : 1u + ((2u + ((uint32_t)dc & 1u)) << de)) + br.bits(de);
-                if ((uint64_t)distance > pos) return SWC_E_REF_TRAP;
-                emit_match(length, distance);
-            }
-        }
-        // ---- careful loop: stream tail, output tail, over-subscribed sets, size-counting mode
+        const bool fast_ok = !lit.oversub && !dist.oversub && cap >= 272 && cap <= 0xFFFFFFFFull &&
+                             (size_t)max_rec >= lzr::max_records(cap);  // the fast loop appends records unchecked
         for (;;) {
-            br.refill();
-            int sym = decode_sym<true>();
-            if (sym < 0) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :175
-            if (sym < 256) {
-                put_byte((uint8_t)sym);
-                continue;
+            // the fast loop needs the upper halves of pos / last_end to be stable: both below 2^32 - 272 - 258
+            if (fast_ok && pos + 272 <= cap && (uint64_t)br.ppos + 56 <= br.len) {
+                if (fast_loop()) return SWC_OK;
             }
-            if (sym == 256) return SWC_OK;
-            if (sym > 285) return SWC_E_DEFLATE_WRONG_SYMBOL;  // :233
-            uint32_t s = (uint32_t)sym - 257u, length;
-            if (s < 8) {
-                length = 3 + s;
-            } else if (s == 28) {
-                length = 258;
-            } else {
-                uint32_t e = (s >> 2) - 1;  // :188
-                if (br.bc < e) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :192
-                length = 3 + ((4 + (s & 3)) << e) + br.bits(e);  // Constants.lengthBase
-            }
-            br.refill();
-            int dc = decode_sym<false>();
-            if (dc < 0) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :199
-            if (dc > 29) return SWC_E_DEFLATE_WRONG_SYMBOL;     // :201
-            uint32_t distance;
-            if (dc < 4) {
-                distance = 1 + (uint32_t)dc;
-            } else {
-                uint32_t e = ((uint32_t)dc >> 1) - 1;  // :206
-                if (br.bc < e) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :208
-                distance = 1 + ((2 + ((uint32_t)dc & 1)) << e) + br.bits(e);  // Constants.distanceBase
-            }
-            // :216-221 out[count - distance] with distance > count is a Swift trap (App. A6)
-            if ((uint64_t)distance > pos) return SWC_E_REF_TRAP;
-            emit_match(length, distance);
+            int st = careful_step();
+            if (st == -1) return SWC_OK;
+            if (st) return st;
         }
     }
 
