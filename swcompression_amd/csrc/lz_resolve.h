@@ -76,20 +76,23 @@ struct Group {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
     }
-    // inclusive prefix sum over the workgroup (sums stay below 2^32: callers clamp their inputs)
+    // inclusive prefix sum over the workgroup (sums stay below 2^32: callers clamp their inputs).  Within a wave:
+    // DPP row shifts + row broadcasts (six VALU ops, no LDS round trips); across waves: one LDS exchange.
     SWC_D uint32_t scan_incl(uint32_t x) const {
 #if defined(__HIP_DEVICE_COMPILE__)
         const int lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-        for (int o = 1; o < 64; o <<= 1) {
-            uint32_t y = __shfl_up(x, o);
-            if (lane >= o) x += y;
-        }
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+        x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
         if (T > 64) {
             if (lane == 63) l->wave_sum[wave] = x;
             sync();
             uint32_t add = 0;
-            for (int w = 0; w < wave; w++) add += l->wave_sum[w];
+#pragma unroll
+            for (int w = 0; w < T / 64; w++) add += w < wave ? l->wave_sum[w] : 0u;
             x += add;
         }
 #endif
@@ -155,6 +158,13 @@ struct Resolver {
                       // 4 no literal staging, 8 no dependency search, 16 no record prefetch
 
     SWC_D uint32_t ridx(uint64_t p) const { return (rb + (uint32_t)p) & kRingMask; }
+    SWC_D static uint32_t uniform(uint32_t v) {  // v is the same in every lane: keep it in an SGPR
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#else
+        return v;
+#endif
+    }
     // first position whose address is 16-byte aligned and >= the address of position p
     SWC_D uint64_t chunk_up(uint64_t p) const {
         const uint64_t a0 = (uint64_t)(uintptr_t)out;
@@ -270,6 +280,26 @@ struct Resolver {
     SWC_D void copy_match(uint64_t dpos, uint32_t len, int64_t spos, uint32_t period) const {
         const uint32_t d = ridx(dpos), s = ridx((uint64_t)spos);
         const uint32_t plen = len < period ? len : period;
+        if (len <= period && d + len + 8 <= kRingBytes && s + len + 16 <= kRingBytes) {
+            // common case: plain copy, no access (8-byte over-reads included) leaves the ring => raw accesses
+            uint32_t i = 0;
+            for (; i + 16 <= len; i += 16) {
+                const uint64_t a = *(const u64_unaligned*)(ring + s + i), b = *(const u64_unaligned*)(ring + s + i + 8);
+                *(u64_unaligned*)(ring + d + i) = a;
+                *(u64_unaligned*)(ring + d + i + 8) = b;
+            }
+            uint32_t rem = len - i;
+            if (rem) {
+                uint64_t a = *(const u64_unaligned*)(ring + s + i);
+                const uint64_t b = *(const u64_unaligned*)(ring + s + i + 8);
+                uint32_t x = d + i;
+                if (rem >= 8) { *(u64_unaligned*)(ring + x) = a; a = b; x += 8; rem -= 8; }
+                if (rem >= 4) { *(u32_unaligned*)(ring + x) = (uint32_t)a; a >>= 32; x += 4; rem -= 4; }
+                if (rem >= 2) { *(u16_unaligned*)(ring + x) = (uint16_t)a; a >>= 16; x += 2; rem -= 2; }
+                if (rem) ring[x] = (uint8_t)a;
+            }
+            return;
+        }
         copy_plain(d, s, plen);
         if (len <= period) return;
         uint32_t k = period, back = period;
@@ -283,6 +313,19 @@ struct Resolver {
         if (k < len) wr_tail(d + k, len - k, rd(d + k - back, 8));
     }
 
+    // Both bounds of the producer range in ONE loop with a group-uniform trip count (a = first index with
+    // ends[i] > v1, b = first index with dsts[i] >= v2; arrays non-decreasing): two independent LDS reads per step.
+    SWC_D static void bounds2(const uint32_t* ends, const uint32_t* dsts, int n, int steps, uint32_t v1, uint32_t v2, int& a, int& b) {
+        int lo1 = 0, hi1 = n, lo2 = 0, hi2 = n;
+        for (int it = 0; it < steps; it++) {
+            const int m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
+            const uint32_t e = ends[m1 < n ? m1 : n - 1], d = dsts[m2 < n ? m2 : n - 1];
+            if (lo1 < hi1) { if (e > v1) hi1 = m1; else lo1 = m1 + 1; }
+            if (lo2 < hi2) { if (d >= v2) hi2 = m2; else lo2 = m2 + 1; }
+        }
+        a = lo1;
+        b = lo2;
+    }
     // first index in [0, n) with a[i] > v   (a non-decreasing)
     SWC_D static int upper_bound(const uint32_t* a, int n, uint32_t v) {
         int lo = 0, hi = n;
@@ -310,6 +353,8 @@ struct Resolver {
         uint32_t base = 0;
         uint32_t r_next = (uint32_t)tid < nrec ? recs[tid] : 0u;   // record prefetch, one batch ahead
         uint32_t next_base = 0;
+        constexpr int kSteps = (T >= 1024 ? 11 : T >= 512 ? 10 : T >= 256 ? 9 : T >= 128 ? 8 : T >= 64 ? 7 : 1);
+        if (tid < (int)((T + 31) / 32)) l->done[tid] = 0;
         while (base < nrec) {
             const bool valid = base + (uint32_t)tid < nrec;
             uint32_t r;
@@ -321,19 +366,50 @@ struct Resolver {
             const uint32_t len = ((r >> 8) & 255u) + 3u, dist = ((r >> 16) & 0x7FFFu) + 1u;
             const uint32_t adv_raw = !valid ? 0u : skip ? (r & kMaxSkip) : (r & 255u) + len;
             const uint32_t adv = adv_raw > kSpan ? kSpan + 1u : adv_raw;     // keeps the scan below 2^32
-            const uint32_t end_rel = g.scan_incl(adv);
+            const uint32_t end_rel = g.scan_incl(adv);                       // (barrier A inside)
             const bool take = valid && end_rel <= kSpan;
             const bool is_match = take && !skip;
             const uint32_t dst_rel = end_rel - (is_match ? len : 0u);
             l->ends[tid] = take ? end_rel : 0xFFFFFFFFu;
-            l->dsts[tid] = dst_rel;
+            l->dsts[tid] = take ? dst_rel : 0xFFFFFFFFu;
+            l->periods[tid] = dist;
             if (tid == 0) { l->ends[T] = 0xFFFFFFFFu; l->ntake = 0; l->span = adv_raw; }
-            if (tid < (int)((T + 31) / 32)) l->done[tid] = 0;
-            g.sync();
-            if (take && l->ends[tid + 1] == 0xFFFFFFFFu) { l->ntake = (uint32_t)tid + 1u; l->span = end_rel; }
-            g.sync();
-            const int n_take = (int)l->ntake;
-            const uint32_t span = l->span;
+            g.sync();                                                        // barrier B: batch geometry published
+            if (take && l->ends[tid + 1] == 0xFFFFFFFFu) { l->ntake = (uint32_t)tid + 1u; l->span = end_rel; }  // read after barrier C
+            // clamp to the bytes that exist (a match that starts below the capacity may end beyond it)
+            uint32_t clen = len;
+            bool pending = is_match;
+            if (pending) {
+                const uint64_t dabs = rpos + dst_rel;
+                if (dabs >= limit) pending = false;
+                else if (dabs + clen > limit) clen = (uint32_t)(limit - dabs);
+            }
+            // Producers of my pattern bytes: records a..b (inclusive) of this batch.  A match whose pattern lies inside
+            // ONE earlier match does not wait for it: it takes over that match's source (pointer jumping), so the
+            // chains that repeated words form (every occurrence copies the previous one) collapse to depth one.
+            int dep_a = 0, dep_b = -1, prod = -1;
+            int32_t s0 = (int32_t)dst_rel - (int32_t)dist;
+            const uint32_t plen = clen < dist ? clen : dist;
+            if (pending) {
+                const int64_t s1 = (int64_t)s0 + plen;  // exclusive
+                if (s1 > 0 && !(dbg & 8)) {
+                    const uint32_t lo_rel = s0 > 0 ? (uint32_t)s0 : 0u;
+                    // first record that ends after my first source byte .. last record that starts before my source end
+                    // (records that were not taken hold 0xFFFFFFFF, so the whole array can be searched)
+                    bounds2(l->ends, l->dsts, T, kSteps, lo_rel, (uint32_t)s1, dep_a, dep_b);
+                    dep_b -= 1;
+                    if (dep_b >= tid) dep_b = tid - 1;
+                    if (dep_a <= dep_b) {
+                        if (dep_a == dep_b && s0 >= 0 && (uint32_t)s0 >= l->dsts[dep_a] && (uint32_t)s1 <= l->ends[dep_a]) prod = dep_a;
+                        else prod = -2;
+                    }
+                }
+            }
+            g.link_store(tid, (uint64_t)(uint32_t)s0 | ((uint64_t)(uint32_t)(pending ? prod : -1) << 32));
+            if (take && !pending) g.set_done(tid);
+            g.sync();                                                        // barrier C: links published
+            const int n_take = (int)uniform(l->ntake);
+            const uint32_t span = uniform(l->span);
             if (n_take == 0) {
                 // the first record alone outruns the span: a long literal run (already final in HBM).  Skip it and
                 // re-stage the part of the 32 KiB window before the new position that the ring does not hold yet.
@@ -345,11 +421,12 @@ struct Resolver {
                 load_span(lo, hi);
                 if (hi > ring_hi) ring_hi = hi;
                 g.sync();
+                if (tid < (int)((T + 31) / 32)) l->done[tid] = 0;
                 continue;
             }
             const uint64_t batch_end = rpos + span;
             const uint64_t hi = batch_end < limit ? batch_end : limit;
-            if (hi > ring_hi && !(dbg & 4)) {   // the read-ahead fell short (first batch, or a batch wider than the read-ahead)
+            if (hi > ring_hi && !(dbg & 4)) {   // the read-ahead fell short (first batch, or after a long literal run)
                 uint64_t to = chunk_up(hi);
                 if (to > limit) to = limit;
                 load_span(ring_hi, to);
@@ -375,37 +452,6 @@ struct Resolver {
             } else {
                 pf_hi = pf_lo;
             }
-            // clamp to the bytes that exist (a match that starts below the capacity may end beyond it)
-            uint32_t clen = len;
-            bool pending = is_match;
-            if (pending) {
-                const uint64_t dabs = rpos + dst_rel;
-                if (dabs >= limit) pending = false;
-                else if (dabs + clen > limit) clen = (uint32_t)(limit - dabs);
-            }
-            // Producers of my pattern bytes: records a..b (inclusive) of this batch.  A match whose pattern lies inside
-            // ONE earlier match does not wait for it: it takes over that match's source (pointer jumping), so the
-            // chains that repeated words form (every occurrence copies the previous one) collapse to depth one.
-            int dep_a = 0, dep_b = -1, prod = -1;
-            int32_t s0 = (int32_t)dst_rel - (int32_t)dist;
-            const uint32_t plen = clen < dist ? clen : dist;
-            if (pending) {
-                const int64_t s1 = (int64_t)s0 + plen;  // exclusive
-                if (s1 > 0 && !(dbg & 8)) {
-                    const uint32_t lo_rel = s0 > 0 ? (uint32_t)s0 : 0u;
-                    dep_a = upper_bound(l->ends, n_take, lo_rel);            // first record that ends after my first source byte
-                    dep_b = lower_bound(l->dsts, n_take, (uint32_t)s1) - 1;  // last record that starts before my source end
-                    if (dep_b >= tid) dep_b = tid - 1;
-                    if (dep_a <= dep_b) {
-                        if (dep_a == dep_b && s0 >= 0 && (uint32_t)s0 >= l->dsts[dep_a] && (uint32_t)s1 <= l->ends[dep_a]) prod = dep_a;
-                        else prod = -2;
-                    }
-                }
-            }
-            l->periods[tid] = dist;
-            g.link_store(tid, (uint64_t)(uint32_t)s0 | ((uint64_t)(uint32_t)(pending ? prod : -1) << 32));
-            if (take && !pending) g.set_done(tid);
-            g.sync();
             while (prod >= 0) {
                 const int i = prod;
                 const uint64_t li = g.link_load(i);
@@ -445,7 +491,7 @@ struct Resolver {
                     g.backoff();
                 }
             }
-            g.sync();
+            g.sync();                                                        // barrier D: every copy of the batch is in the ring
             // consume the loads issued before the resolve (read-ahead literals, next records) BEFORE the write-back
             // stores are issued: vmcnt retires in order, so a wait placed after the stores would wait for them too
             if (pf_hi > pf_lo) {
@@ -462,9 +508,10 @@ struct Resolver {
             asm volatile("" ::"v"(r_next));
 #endif
             if (!(dbg & 2)) flush_span(rpos, hi);
+            if (tid < (int)((T + 31) / 32)) l->done[tid] = 0;
             rpos = batch_end;
             base += (uint32_t)n_take;
-            g.sync();
+            // no barrier here: the next batch passes barriers A and B before it touches anything read above
         }
     }
 };

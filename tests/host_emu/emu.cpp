@@ -57,3 +57,18 @@ extern "C" void emu_bzip2_block(swc::Job* jobs, size_t n, size_t lcap) {
         stage3_job(jobs[g], w, crc.data());
     }
 }
+
+// Debug/analysis helper (tools/analyze_records.py): phase 1 only, returns the record list of one stream.
+extern "C" size_t emu_inflate_records(const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, uint32_t* recs_out, size_t max_out) {
+    std::vector<uint32_t> lds(swc::inflate::kWordsPerLane * swc::kWave, 0xDEADBEEFu);
+    swc::LaneLds l{lds.data(), swc::kWave};
+    size_t wsb = swc::lzr::ws_bytes_per_job(cap);
+    std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
+    swc::Job j{};
+    j.in = in; j.in_len = in_len; j.out = out; j.out_cap = cap;
+    swc::inflate::inflate_job(j, l, ws.data(), wsb);
+    uint32_t n = ((swc::lzr::StreamHeader*)ws.data())->nrec;
+    const uint32_t* r = (const uint32_t*)(ws.data() + sizeof(swc::lzr::StreamHeader));
+    for (size_t i = 0; i < n && i < max_out; i++) recs_out[i] = r[i];
+    return n;
+}

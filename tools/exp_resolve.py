@@ -14,9 +14,9 @@ def timeit(b, reps=3):
         s.record(); b.launch(); e.record(); torch.cuda.synchronize(); ts.append(s.elapsed_time(e))
     return min(ts)
 b = DeviceBatch("deflate", raw, [65536] * len(raw), tile=32)
-for T in (512, 1024):
+for T in (512,):
     lib.swc_set_tuning(b"resolve_threads", T)
-    for dbg in (0, 1, 8, 9, 15):
+    for dbg in (0, 1, 2, 4, 8, 9, 15):
         lib.swc_set_tuning(b"resolve_debug", dbg)
         print("T=%d dbg=%2d  total %.2f ms" % (T, dbg, timeit(b)), flush=True)
 lib.swc_set_tuning(b"resolve_debug", 0)
