@@ -235,7 +235,10 @@ struct Lane {
     uint64_t pos;  // bytes produced (keeps counting past cap: size pass for SWC_E_CAPACITY)
     SWC_AS_GLOBAL uint32_t* recs;  // record list in the HBM workspace (the stream's StreamHeader sits 16 bytes before it)
     uint32_t nrec, max_rec;
+    gptr lits;                     // dense literal stream in the HBM workspace (16-byte aligned, capacity cap + 16)
+    uint64_t nlit;
     uint64_t last_end;             // position just past the previous record
+    int dbg = 0;                   // timing experiments only (tools/exp_deflate.py): 1 no literal stores, 2 no record stores
 
     SWC_HD void push(uint32_t v) {
         if (nrec < max_rec) recs[nrec] = v;
@@ -427,7 +430,7 @@ struct Lane {
     }
 
     SWC_HD void put_byte(uint8_t b) {
-        if (pos < cap) out[pos] = b;
+        if (pos < cap) lits[nlit++] = b;
         pos++;
     }
 
@@ -467,12 +470,14 @@ struct Lane {
         // drain the set-up loads here, once: otherwise the loop-head wait has to cover the entry path too and
         // degrades to vmcnt(0) for every iteration
         SWC_OPAQUE(d0); SWC_OPAQUE(d1); SWC_OPAQUE(d2); SWC_OPAQUE(d3); SWC_OPAQUE(nx);
-        uint32_t p = (uint32_t)pos, le = (uint32_t)last_end, nr = nrec;
+        uint32_t p = (uint32_t)pos, le = (uint32_t)last_end, nr = nrec, nl = (uint32_t)nlit;
+        // literals are collected eight at a time and leave as one aligned 8-byte store
+        uint64_t lb = (nl & 7u) ? load_u64(lits + (nl & ~7u)) & ((1ull << (8 * (nl & 7u))) - 1ull) : 0ull;
         const uint32_t plimit = (uint32_t)(cap - 272);
         // Memory instructions of lanes that do not need them this iteration are pointed at ONE wave-wide dummy
-        // location (the pad words of the first lane's stream header / the first lane's input): the instruction stays
+        // location (the first lane's stream header, rewritten when its job ends / the first lane's input): the instruction stays
         // unconditional -- which is what lets the compiler count it -- but costs a single extra request.
-        gptr dummy_st = (gptr)recs - 12;
+        gptr dummy_st = (gptr)recs - 16;   // the 16-byte stream header (rewritten when the job ends)
         gcptr dummy_ld = in;
 #if defined(__HIP_DEVICE_COMPILE__)
         {
@@ -532,18 +537,25 @@ struct Lane {
             // ---- unconditional stores (see above), BEFORE the exits so that every path from the input load to its use
             // in the next iteration passes exactly these two stores.  A lane that leaves below has written one garbage
             // byte at its next output position and one garbage record into the next free slot; both get overwritten.
-            *(is_lit ? out + p : dummy_st) = (uint8_t)sym;
-            *(is_lit ? (SWC_AS_GLOBAL uint32_t*)(dummy_st + 4) : recs + nr) = lzr::make_match(run, length, distance);
+            const bool lit_ok = code_ok && is_lit;
+            lb |= lit_ok ? (uint64_t)sym << (8 * (nl & 7u)) : 0ull;
+            const bool full = lit_ok && (nl & 7u) == 7u;
+            *(SWC_AS_GLOBAL u64_unaligned*)((full && !(dbg & 1)) ? lits + (nl & ~7u) : dummy_st) = lb;
+            *((is_lit || (dbg & 2)) ? (SWC_AS_GLOBAL uint32_t*)(dummy_st + 8) : recs + nr) = lzr::make_match(run, length, distance);
             if (is_eob) { bp += n; eob = true; break; }
             if (!(code_ok && is_lit) && !is_match) break;   // leave BEFORE consuming: the checked step handles it
+            lb = full ? 0ull : lb;
+            nl += is_match ? 0u : 1u;
             p += is_match ? length : 1u;
             le = is_match ? p : le;
             nr += is_match ? 1u : 0u;
             bp += is_match ? n + e + n2 + de : n;
         }
+        if (nl & 7u) store_u64(lits + (nl & ~7u), lb);   // pending literals; the bytes above them are rewritten later
         pos = (pos & ~0xFFFFFFFFull) | p;
         last_end = (last_end & ~0xFFFFFFFFull) | le;
         nrec = nr;
+        nlit = nl;
         br.seek((uint64_t)q * 8 + bp);
         return eob;
     }
@@ -614,12 +626,12 @@ struct Lane {
         if ((length & nlength) != 0) return SWC_E_DEFLATE_WRONG_UNCOMPRESSED_BLOCK_LENGTHS;  // :56
         if (br.len - (p + 4) < length) return SWC_E_DEFLATE_WRONG_UNCOMPRESSED_BLOCK_LENGTHS;  // :59
         q += 4;
+        // stored bytes are literals: they go to the literal stream (as far as the capacity reaches)
+        uint32_t keep = pos >= cap ? 0u : (cap - pos < length ? (uint32_t)(cap - pos) : length);
         uint32_t i = 0;
-        if (pos + length <= cap) {
-            for (; i + 8 <= length; i += 8) store_u64(out + pos + i, load_u64(q + i));
-        }
-        for (; i < length; i++)
-            if (pos + i < cap) out[pos + i] = q[i];
+        for (; i + 8 <= keep; i += 8) store_u64(lits + nlit + i, load_u64(q + i));
+        for (; i < keep; i++) lits[nlit + i] = q[i];
+        nlit += keep;
         pos += length;
         br.init(br.in, br.len, p + 4 + length);
         return SWC_OK;
@@ -651,20 +663,27 @@ struct Lane {
     }
 };
 
-// One lane = one job.  `lds` is this lane's view of the wave's table region; `ws` / `ws_bytes` the
-// stream's area in the HBM workspace (lzr::StreamHeader + records).
-SWC_HD void inflate_job(Job& job, LaneLds lds, uint8_t* ws, size_t ws_bytes) {
+// One lane = one job.  `lds` is this lane's view of the wave's table region; `ws` / `ws_bytes` the stream's area in
+// the HBM workspace: lzr::StreamHeader | records | literal stream (lz_resolve.h).
+SWC_HD void inflate_job(Job& job, LaneLds lds, uint8_t* ws, size_t ws_bytes, int dbg = 0) {
     Lane ln;
+    ln.dbg = dbg;
     ln.l = lds;
     ln.out = (gptr)job.out;
     ln.cap = job.out_cap;
     ln.pos = 0;
     ln.nrec = 0;
+    ln.nlit = 0;
     ln.last_end = 0;
+    const size_t lo = ws ? lzr::lit_offset(ws_bytes, job.out_cap) : 0;
     ln.recs = (SWC_AS_GLOBAL uint32_t*)(ws + sizeof(lzr::StreamHeader));
-    ln.max_rec = ws && ws_bytes > sizeof(lzr::StreamHeader) ? (uint32_t)((ws_bytes - sizeof(lzr::StreamHeader)) / 4) : 0u;
+    ln.max_rec = lo > sizeof(lzr::StreamHeader) ? (uint32_t)((lo - sizeof(lzr::StreamHeader)) / 4) : 0u;
+    ln.lits = (gptr)(ws + lo);
     int st;
-    if (job.in_len > 0xFFFFFFF0ull) {
+    if (lo == 0) {
+        st = SWC_E_NEED_WORKSPACE;   // the workspace area cannot even hold the literal stream of this capacity
+        ln.br.init((gcptr)job.in, 0, 0);
+    } else if (job.in_len > 0xFFFFFFF0ull) {
         st = SWC_E_INVALID_ARGUMENT;  // streams are addressed with 32-bit byte offsets on device
         ln.br.init((gcptr)job.in, 0, 0);
     } else {
@@ -676,7 +695,12 @@ SWC_HD void inflate_job(Job& job, LaneLds lds, uint8_t* ws, size_t ws_bytes) {
         ln.nrec = ln.max_rec;
     }
     if (st == SWC_OK && ln.pos > ln.cap) st = SWC_E_CAPACITY;
-    if (ws && ws_bytes >= sizeof(lzr::StreamHeader)) ((SWC_AS_GLOBAL lzr::StreamHeader*)ws)->nrec = ln.nrec;
+    if (ws && ws_bytes >= sizeof(lzr::StreamHeader)) {
+        SWC_AS_GLOBAL lzr::StreamHeader* h = (SWC_AS_GLOBAL lzr::StreamHeader*)ws;
+        h->nrec = ln.nrec;
+        h->pad0 = 0;
+        h->nlit = ln.nlit;
+    }
     uint64_t bits = ln.br.consumed_bits();
     uint64_t consumed = (bits + 7) >> 3;  // callers align() right after (GzipArchive.swift:89)
     job.in_consumed = consumed > job.in_len ? job.in_len : consumed;

@@ -21,12 +21,12 @@ namespace swc {
 // ---- Deflate: two phases (inflate_lane.h, lz_resolve.h) ------------------------------------------------
 // Phase 1: one stream per lane.  LDS: 80 words/lane -> 20,480 B per wave -> 8 resident waves per CU (2 per SIMD).
 // Literals are stored in place, matches become records in the workspace; no output reads.
-__global__ __launch_bounds__(64, 2) void swc_inflate_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride) {
+__global__ __launch_bounds__(64, 2) void swc_inflate_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t g = blockIdx.x * kWave + threadIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
-    inflate::inflate_job(job, LaneLds{lds + threadIdx.x, kWave}, ws ? ws + (size_t)g * ws_stride : nullptr, ws_stride);
+    inflate::inflate_job(job, LaneLds{lds + threadIdx.x, kWave}, ws ? ws + (size_t)g * ws_stride : nullptr, ws_stride, dbg);
     jobs[g].out_len = job.out_len;
     jobs[g].in_consumed = job.in_consumed;
     jobs[g].status = job.status;
@@ -39,10 +39,11 @@ __global__ __launch_bounds__(T) void swc_lz_resolve_kernel(const Job* __restrict
     uint32_t g = blockIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
-    lzr::resolve_job<T>(job, ws + (size_t)g * ws_stride, &lzr_lds, (int)threadIdx.x, dbg);
+    lzr::resolve_job<T>(job, ws + (size_t)g * ws_stride, ws_stride, &lzr_lds, (int)threadIdx.x, dbg);
 }
 
-static int g_resolve_threads = 512, g_resolve_dbg = 0;
+static int g_resolve_threads = 512, g_resolve_dbg = 0, g_inflate_dbg = 0;
+void set_inflate_debug(int m) { g_inflate_dbg = m; }
 void set_resolve_debug(int m) { g_resolve_dbg = m; }
 
 // Optional per-phase timing of the last Deflate launch (bench.py: roofline per kernel).  HIP events on the
@@ -74,7 +75,7 @@ hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStr
     dim3 grid((unsigned)((n + kWave - 1) / kWave)), block(kWave);
     const bool timing = g_phase_timing && g_phase_ev_ok;
     if (timing) (void)hipEventRecord(g_phase_ev[0], stream);
-    hipLaunchKernelGGL(swc_inflate_kernel, grid, block, inflate::kLdsBytesPerWave, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride);
+    hipLaunchKernelGGL(swc_inflate_kernel, grid, block, inflate::kLdsBytesPerWave, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride, g_inflate_dbg);
     if (timing) (void)hipEventRecord(g_phase_ev[1], stream);
     dim3 grid2((unsigned)n);
     switch (g_resolve_threads) {

@@ -8,6 +8,7 @@ hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStr
 size_t inflate_ws_bytes_per_job(uint64_t cap);
 void set_resolve_threads(int t);
 void set_resolve_debug(int m);
+void set_inflate_debug(int m);
 void set_phase_timing(int on);
 int last_phase_ms(float* ms, int cap);
 hipError_t launch_lz4(Job* jobs, size_t n, hipStream_t stream);

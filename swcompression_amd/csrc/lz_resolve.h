@@ -4,20 +4,21 @@
 // The reference executes every back-reference inline, one byte per `out.append`
 // (Sources/Deflate/Deflate.swift:216-232).  On the MI355X the entropy decode and the copy are split:
 //
-//   phase 1 (inflate_lane.h, one stream per lane) decodes the Huffman symbols, stores every LITERAL at its
-//           final position in the output buffer and appends one 32-bit record per MATCH to the stream's
-//           record list in the HBM workspace -- it never reads the output, so the tens of thousands of
-//           streams that must be in flight to hide the decode latency no longer keep 32 KiB windows alive
-//           in L2 / Infinity Cache (measured before the split: HBM traffic 9-28x the algorithmic bytes,
-//           78 % of wave time in s_waitcnt; profiles/r01_pmc_deflate_lane_per_stream.txt);
+//   phase 1 (inflate_lane.h, one stream per lane) decodes the Huffman symbols and appends every LITERAL to the
+//           stream's dense literal stream and one 32-bit record per MATCH to its record list, both in the HBM
+//           workspace.  It never touches the output buffer, so the tens of thousands of streams that must be in
+//           flight to hide the decode latency neither keep 32 KiB windows alive in L2 / Infinity Cache nor
+//           sprinkle single bytes over every sector of the output (measured before: HBM traffic 7-28x the
+//           algorithmic bytes, profiles/r01_pmc_deflate_lane_per_stream.txt, r01c_deflate64k_traffic.json);
 //   phase 2 (this file, one stream per workgroup of T threads) walks the record list in batches of T records:
-//           a workgroup prefix-scan turns (literal run, length) into output positions, the batch's output
-//           span is staged HBM -> LDS with coalesced 16-byte loads, every thread executes one match inside
-//           the 64 KiB LDS ring (dependent matches wait for their producers through a done-bitmap, in
-//           rounds), and the finished span is written back with coalesced 16-byte stores.
+//           a workgroup prefix-scan turns (literal run, length) into output positions and literal offsets, every
+//           thread drops its literal run into the 64 KiB LDS ring and then executes its match inside the ring
+//           (matches whose source is the output of an earlier match of the batch take over that match's source by
+//           pointer jumping; the rest wait on a done-bitmap), and the finished span leaves with coalesced
+//           16-byte stores -- the only time the output is written.
 //
 // Record format (u32):  bit 31 = 0:  lit_run[0..7] | (length - 3)[8..15] | (distance - 1)[16..30]
-//                       bit 31 = 1:  skip[0..30]  -- `skip` more literal bytes precede the next record
+//                       bit 31 = 1:  skip[0..30]  -- `skip` literal bytes; always handled on its own
 // lit_run = literal bytes between the end of the previous record and this match (< 255; longer runs
 // are preceded by skip records).  Records exist only for matches that START below the output capacity.
 //
@@ -33,33 +34,38 @@ namespace lzr {
 constexpr uint32_t kRingBytes = 65536;
 constexpr uint32_t kRingMask = kRingBytes - 1;
 constexpr uint32_t kSpan = 16384;          // output bytes one batch may cover; ring = 32 KiB window + span + slack
+constexpr uint32_t kLitBuf = 4096;         // literal bytes staged in LDS ahead of the batch being resolved
 constexpr uint32_t kSkipFlag = 0x80000000u;
 constexpr uint32_t kMaxSkip = 0x7FFFFFFFu;
 
-// Per-stream area in the workspace: 16-byte header, then the records.
+// Per-stream area in the workspace: 16-byte header | records | literal stream (at the END of the area).
 struct StreamHeader {
     uint32_t nrec;
-    uint32_t pad[3];
+    uint32_t pad0;
+    uint64_t nlit;    // bytes in the literal stream
 };
 // Records a stream of capacity `cap` can need: one per match (>= 3 output bytes each, started below cap)
 // plus one skip per >= 255 literal bytes, plus slack.
 SWC_HD size_t max_records(uint64_t cap) { return (size_t)(cap / 3 + cap / 255 + 8); }
-SWC_HD size_t ws_bytes_per_job(uint64_t cap) { return (sizeof(StreamHeader) + max_records(cap) * 4 + 15) & ~(size_t)15; }
+SWC_HD size_t lit_bytes(uint64_t cap) { return (size_t)((cap + 16 + 15) & ~(uint64_t)15); }   // +16: 8-byte flushes and reads may overshoot
+SWC_HD size_t ws_bytes_per_job(uint64_t cap) { return ((sizeof(StreamHeader) + max_records(cap) * 4 + 15) & ~(size_t)15) + lit_bytes(cap); }
+// a job's literal stream inside its area of `stride` bytes (0 if the area is too small for it)
+SWC_HD size_t lit_offset(size_t stride, uint64_t cap) { return stride >= lit_bytes(cap) + sizeof(StreamHeader) ? stride - lit_bytes(cap) : 0; }
 
 SWC_HD uint32_t make_match(uint32_t lit_run, uint32_t length, uint32_t distance) { return lit_run | ((length - 3u) << 8) | ((distance - 1u) << 16); }
-
-constexpr uint32_t kReadAhead = 8192;      // literal bytes staged ahead of the batch being resolved
 
 template <int T>
 struct Lds {
     uint8_t ring[kRingBytes];
+    uint8_t litbuf[kLitBuf + 16];        // window of the literal stream, indexed by (literal offset % kLitBuf); +16: unaligned tail reads
     uint32_t ends[T + 1];                // end of record i, relative to the batch start (0xFFFFFFFF: no record)
     uint32_t dsts[T];                    // start of match i, relative to the batch start (== ends[i] for skips)
     uint64_t link[T];                    // (source position relative to the batch start : i32) | (producer : i32) << 32
     uint32_t periods[T];                 // distance of match i
     uint32_t done[(T + 31) / 32];
     uint32_t wave_sum[T / 64 + 1];
-    uint32_t ntake, span;
+    uint32_t wave_sum2[T / 64 + 1];
+    uint32_t ntake, span, litspan;
 };
 
 // Workgroup-collective helpers.  Device: T threads, barriers.  Host emulation: T == 1.
@@ -76,27 +82,38 @@ struct Group {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 #endif
     }
-    // inclusive prefix sum over the workgroup (sums stay below 2^32: callers clamp their inputs).  Within a wave:
-    // DPP row shifts + row broadcasts (six VALU ops, no LDS round trips); across waves: one LDS exchange.
-    SWC_D uint32_t scan_incl(uint32_t x) const {
+    // inclusive prefix sums of two values over the workgroup (sums stay below 2^32: callers clamp their inputs).
+    // Within a wave: DPP row shifts + row broadcasts (six VALU ops per value, no LDS round trips); across waves: one
+    // LDS exchange and one barrier for both.
+    SWC_D static uint32_t wave_scan(uint32_t x) {
 #if defined(__HIP_DEVICE_COMPILE__)
-        const int lane = tid & 63, wave = tid >> 6;
         x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
         x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
         x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
         x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
         x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
         x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
-        if (T > 64) {
-            if (lane == 63) l->wave_sum[wave] = x;
-            sync();
-            uint32_t add = 0;
-#pragma unroll
-            for (int w = 0; w < T / 64; w++) add += w < wave ? l->wave_sum[w] : 0u;
-            x += add;
-        }
 #endif
         return x;
+    }
+    SWC_D void scan2_incl(uint32_t& x, uint32_t& y) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int lane = tid & 63, wave = tid >> 6;
+        x = wave_scan(x);
+        y = wave_scan(y);
+        if (T > 64) {
+            if (lane == 63) { l->wave_sum[wave] = x; l->wave_sum2[wave] = y; }
+            sync();
+            uint32_t ax = 0, ay = 0;
+#pragma unroll
+            for (int w = 0; w < T / 64; w++) {
+                ax += w < wave ? l->wave_sum[w] : 0u;
+                ay += w < wave ? l->wave_sum2[w] : 0u;
+            }
+            x += ax;
+            y += ay;
+        }
+#endif
     }
     SWC_D void set_done(int i) const {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -147,15 +164,18 @@ SWC_HD uint8_t byte_of(const u128& v, int j) {
 
 template <int T>
 struct Resolver {
-    static constexpr int kPf = (int)(kReadAhead / (16 * T)) > 0 ? (int)(kReadAhead / (16 * T)) : 1;  // read-ahead chunks per thread
     Group<T> g;
     gptr out;
+    gcptr lits;       // the stream's dense literal stream (16-byte aligned base)
+    uint64_t nlit;    // bytes in it
+    uint64_t lit_cap; // bytes that may be READ from it (allocation size)
     uint64_t limit;   // bytes of `out` that exist: min(bytes produced, capacity)
     uint32_t rb;      // low bits of the output address: ring index of position p is (rb + p) & kRingMask, so that
                       // 16-byte aligned HBM chunks are 16-byte aligned in the ring
     uint8_t* ring;
-    int dbg;          // experiment switches (tools/exp_deflate.py), 0 in production: 1 no copies, 2 no write-back,
-                      // 4 no literal staging, 8 no dependency search, 16 no record prefetch
+    uint8_t* litbuf;
+    int dbg;          // experiment switches (tools/exp_resolve.py), 0 in production: 1 no copies, 2 no write-back,
+                      // 4 no literal placement, 8 no dependency search
 
     SWC_D uint32_t ridx(uint64_t p) const { return (rb + (uint32_t)p) & kRingMask; }
     SWC_D static uint32_t uniform(uint32_t v) {  // v is the same in every lane: keep it in an SGPR
@@ -165,51 +185,8 @@ struct Resolver {
         return v;
 #endif
     }
-    // first position whose address is 16-byte aligned and >= the address of position p
-    SWC_D uint64_t chunk_up(uint64_t p) const {
-        const uint64_t a0 = (uint64_t)(uintptr_t)out;
-        return ((a0 + p + 15) & ~(uint64_t)15) - a0;
-    }
 
-    // One 16-byte chunk (absolute address ca) of the span [lo, hi): HBM -> registers.  The aligned chunk that
-    // holds an edge byte lies in the same 16-byte granule as that byte, so reading it whole is safe on the device;
-    // the host build reads edge chunks bytewise to stay inside the caller's buffer.
-    SWC_D u128 fetch_chunk(uint64_t ca, uint64_t lo, uint64_t hi) const {
-        const uint64_t a0 = (uint64_t)(uintptr_t)out;
-        const int64_t p0 = (int64_t)(ca - a0);
-#if defined(__HIP_DEVICE_COMPILE__)
-        (void)lo; (void)hi;
-        return load_16((gcptr)out + p0);
-#else
-        u128 v = {0, 0, 0, 0};
-        uint8_t* vb = (uint8_t*)&v;
-        for (int j = 0; j < 16; j++) {
-            int64_t p = p0 + j;
-            if (p >= (int64_t)lo && (uint64_t)p < hi) vb[j] = out[p];
-        }
-        return v;
-#endif
-    }
-    SWC_D void stage_chunk(uint64_t ca, const u128& v, uint64_t lo, uint64_t hi) const {
-        const uint64_t a0 = (uint64_t)(uintptr_t)out;
-        const int64_t p0 = (int64_t)(ca - a0);
-        if (p0 >= (int64_t)lo && (uint64_t)p0 + 16 <= hi) {
-            *(u128*)(ring + ((uint32_t)ca & kRingMask)) = v;
-        } else {
-            for (int j = 0; j < 16; j++) {
-                int64_t p = p0 + j;
-                if (p >= (int64_t)lo && (uint64_t)p < hi) ring[ridx((uint64_t)p)] = byte_of(v, j);
-            }
-        }
-    }
-    // HBM -> ring for positions [lo, hi), hi <= limit (synchronous: used when the read-ahead fell short)
-    SWC_D void load_span(uint64_t lo, uint64_t hi) const {
-        if (hi <= lo) return;
-        const uint64_t a0 = (uint64_t)(uintptr_t)out;
-        const uint64_t c0 = (a0 + lo) >> 4, c1 = (a0 + hi - 1) >> 4;
-        for (uint64_t c = c0 + (uint64_t)g.tid; c <= c1; c += T) stage_chunk(c << 4, fetch_chunk(c << 4, lo, hi), lo, hi);
-    }
-    // ring -> HBM for positions [lo, hi), hi <= limit
+    // ring -> HBM for positions [lo, hi), hi <= limit: 16-byte chunks by absolute address, edge chunks bytewise
     SWC_D void flush_span(uint64_t lo, uint64_t hi) const {
         if (hi <= lo) return;
         const uint64_t a0 = (uint64_t)(uintptr_t)out;
@@ -313,6 +290,42 @@ struct Resolver {
         if (k < len) wr_tail(d + k, len - k, rd(d + k - back, 8));
     }
 
+    // `n` (< 255) literal bytes at literal offset `lo` -> ring at position dpos.  [lw_lo, lw_hi) of the literal stream
+    // is staged in litbuf; anything else is read from HBM.
+    SWC_D void place_literals(uint64_t dpos, uint64_t lo, uint32_t n, uint64_t lw_lo, uint64_t lw_hi) const {
+        const uint32_t d = ridx(dpos);
+        const bool staged = lo >= lw_lo && lo + n + 8 <= lw_hi;
+        for (uint32_t i = 0; i < n; i += 8) {
+            uint64_t v;
+            const uint32_t x = (uint32_t)(lo + i) & (kLitBuf - 1);
+            if (staged && x + 8 <= kLitBuf + 16) v = *(const u64_unaligned*)(litbuf + x);   // litbuf carries 16 mirrored bytes past its end
+            else v = lo + i + 8 <= lit_cap ? load_u64(lits + lo + i) : 0;
+            const uint32_t m = n - i;
+            if (m >= 8) wr(d + i, 8, v);
+            else wr_tail(d + i, m, v);
+        }
+    }
+    // literal stream [lo, lo + n) -> HBM output at position pos (clamped to `limit`), all threads; used for literal
+    // runs of 255+ bytes and for the literals after the last match.  Also refreshes the ring window when `to_ring`.
+    SWC_D void stream_literals(uint64_t pos, uint64_t lo, uint64_t n, bool to_ring) const {
+        if (pos >= limit) return;
+        if (pos + n > limit) n = limit - pos;
+        for (uint64_t i = (uint64_t)g.tid * 8; i < n; i += (uint64_t)T * 8) {
+            const uint64_t m = n - i;
+            if (m >= 8) {
+                const uint64_t v = load_u64(lits + lo + i);
+                store_u64(out + pos + i, v);
+                if (to_ring && n - i <= 32768 + 8) wr(ridx(pos + i), 8, v);
+            } else {
+                for (uint64_t j = 0; j < m; j++) {
+                    const uint8_t b = lits[lo + i + j];
+                    out[pos + i + j] = b;
+                    if (to_ring) ring[ridx(pos + i + j)] = b;
+                }
+            }
+        }
+    }
+
     // Both bounds of the producer range in ONE loop with a group-uniform trip count (a = first index with
     // ends[i] > v1, b = first index with dsts[i] >= v2; arrays non-decreasing): two independent LDS reads per step.
     SWC_D static void bounds2(const uint32_t* ends, const uint32_t* dsts, int n, int steps, uint32_t v1, uint32_t v2, int& a, int& b) {
@@ -326,30 +339,13 @@ struct Resolver {
         a = lo1;
         b = lo2;
     }
-    // first index in [0, n) with a[i] > v   (a non-decreasing)
-    SWC_D static int upper_bound(const uint32_t* a, int n, uint32_t v) {
-        int lo = 0, hi = n;
-        while (lo < hi) {
-            int mid = (lo + hi) >> 1;
-            if (a[mid] > v) hi = mid; else lo = mid + 1;
-        }
-        return lo;
-    }
-    // first index in [0, n) with a[i] >= v
-    SWC_D static int lower_bound(const uint32_t* a, int n, uint32_t v) {
-        int lo = 0, hi = n;
-        while (lo < hi) {
-            int mid = (lo + hi) >> 1;
-            if (a[mid] >= v) hi = mid; else lo = mid + 1;
-        }
-        return lo;
-    }
 
     SWC_D void run(const SWC_AS_GLOBAL uint32_t* recs, uint32_t nrec) {
         Lds<T>* l = g.l;
         const int tid = g.tid;
         uint64_t rpos = 0;      // everything below rpos is final in HBM
-        uint64_t ring_hi = 0;   // literals are staged in the ring for positions [.., ring_hi); chunk aligned or == limit
+        uint64_t lbase = 0;     // literal bytes consumed so far
+        uint64_t lw_lo = 0, lw_hi = 0;   // window of the literal stream staged in litbuf
         uint32_t base = 0;
         uint32_t r_next = (uint32_t)tid < nrec ? recs[tid] : 0u;   // record prefetch, one batch ahead
         uint32_t next_base = 0;
@@ -358,27 +354,36 @@ struct Resolver {
         while (base < nrec) {
             const bool valid = base + (uint32_t)tid < nrec;
             uint32_t r;
-            if (next_base == base && !(dbg & 16)) r = r_next;
+            if (next_base == base) r = r_next;
             else r = valid ? recs[base + tid] : 0u;
             next_base = base + T;
             r_next = next_base + (uint32_t)tid < nrec ? recs[next_base + tid] : 0u;   // in flight while this batch resolves
             const bool skip = (r & kSkipFlag) != 0;
-            const uint32_t len = ((r >> 8) & 255u) + 3u, dist = ((r >> 16) & 0x7FFFu) + 1u;
-            const uint32_t adv_raw = !valid ? 0u : skip ? (r & kMaxSkip) : (r & 255u) + len;
-            const uint32_t adv = adv_raw > kSpan ? kSpan + 1u : adv_raw;     // keeps the scan below 2^32
-            const uint32_t end_rel = g.scan_incl(adv);                       // (barrier A inside)
+            const uint32_t lit_run = r & 255u, len = ((r >> 8) & 255u) + 3u, dist = ((r >> 16) & 0x7FFFu) + 1u;
+            // a skip record never joins a batch: it (and everything after it) is "not taken", and when it comes first
+            // the literal run is streamed on its own below
+            uint32_t end_rel = !valid ? 0u : skip ? kSpan + 1u : lit_run + len;
+            uint32_t lit_end = !valid || skip ? 0u : lit_run;
+            g.scan2_incl(end_rel, lit_end);                                  // (barrier A inside)
             const bool take = valid && end_rel <= kSpan;
-            const bool is_match = take && !skip;
-            const uint32_t dst_rel = end_rel - (is_match ? len : 0u);
+            const uint32_t dst_rel = end_rel - len;
             l->ends[tid] = take ? end_rel : 0xFFFFFFFFu;
             l->dsts[tid] = take ? dst_rel : 0xFFFFFFFFu;
             l->periods[tid] = dist;
-            if (tid == 0) { l->ends[T] = 0xFFFFFFFFu; l->ntake = 0; l->span = adv_raw; }
+            if (tid == 0) { l->ends[T] = 0xFFFFFFFFu; l->ntake = 0; l->span = r & kMaxSkip; l->litspan = 0; }
+            // my literal run goes into the ring now; barrier C orders it before every match copy
+            if (take && lit_run != 0 && !(dbg & 4)) {
+                const uint64_t dabs = rpos + dst_rel - lit_run;
+                if (dabs < limit) {
+                    const uint32_t n = dabs + lit_run > limit ? (uint32_t)(limit - dabs) : lit_run;
+                    place_literals(dabs, lbase + lit_end - lit_run, n, lw_lo, lw_hi);
+                }
+            }
             g.sync();                                                        // barrier B: batch geometry published
-            if (take && l->ends[tid + 1] == 0xFFFFFFFFu) { l->ntake = (uint32_t)tid + 1u; l->span = end_rel; }  // read after barrier C
+            if (take && l->ends[tid + 1] == 0xFFFFFFFFu) { l->ntake = (uint32_t)tid + 1u; l->span = end_rel; l->litspan = lit_end; }  // read after barrier C
             // clamp to the bytes that exist (a match that starts below the capacity may end beyond it)
             uint32_t clen = len;
-            bool pending = is_match;
+            bool pending = take;
             if (pending) {
                 const uint64_t dabs = rpos + dst_rel;
                 if (dabs >= limit) pending = false;
@@ -407,50 +412,31 @@ struct Resolver {
             }
             g.link_store(tid, (uint64_t)(uint32_t)s0 | ((uint64_t)(uint32_t)(pending ? prod : -1) << 32));
             if (take && !pending) g.set_done(tid);
-            g.sync();                                                        // barrier C: links published
+            g.sync();                                                        // barrier C: links and literals published
             const int n_take = (int)uniform(l->ntake);
             const uint32_t span = uniform(l->span);
+            const uint32_t litspan = uniform(l->litspan);
             if (n_take == 0) {
-                // the first record alone outruns the span: a long literal run (already final in HBM).  Skip it and
-                // re-stage the part of the 32 KiB window before the new position that the ring does not hold yet.
+                // record `base` is a skip: a literal run of `span` bytes, streamed straight to the output; the part of
+                // it that the following matches can still reach (32 KiB) is mirrored into the ring
+                stream_literals(rpos, lbase, span, true);
                 rpos += span;
+                lbase += span;
                 base += 1;
-                const uint64_t hi = rpos < limit ? rpos : limit;
-                uint64_t lo = hi > 32768 ? hi - 32768 : 0;
-                if (lo < ring_hi) lo = ring_hi;
-                load_span(lo, hi);
-                if (hi > ring_hi) ring_hi = hi;
                 g.sync();
-                if (tid < (int)((T + 31) / 32)) l->done[tid] = 0;
                 continue;
             }
             const uint64_t batch_end = rpos + span;
             const uint64_t hi = batch_end < limit ? batch_end : limit;
-            if (hi > ring_hi && !(dbg & 4)) {   // the read-ahead fell short (first batch, or after a long literal run)
-                uint64_t to = chunk_up(hi);
-                if (to > limit) to = limit;
-                load_span(ring_hi, to);
-                ring_hi = to;
-                g.sync();
-            }
-            // read-ahead for the following batches: HBM -> registers now, registers -> ring after the resolve
-            u128 pf[kPf];
-            uint64_t pf_lo = ring_hi, pf_hi = hi + kReadAhead;
-            if (pf_hi > limit) pf_hi = limit;
-            if (dbg & 4) pf_hi = pf_lo;
-            if (pf_hi > pf_lo) {
-                uint64_t to = chunk_up(pf_hi);
-                pf_hi = to > limit ? limit : to;
-                const uint64_t a0 = (uint64_t)(uintptr_t)out;
-                const uint64_t c0 = (a0 + pf_lo) >> 4, c1 = (a0 + pf_hi - 1) >> 4;
+            // literal-stream read-ahead for the next batch: one aligned 8-byte load per thread, HBM -> register now,
+            // register -> litbuf after the resolve
+            const uint64_t nw_lo = (lbase + litspan) & ~(uint64_t)7;
+            constexpr int kLitPf = (int)(kLitBuf / 8) > T ? (int)(kLitBuf / 8) / T : 1;   // 8-byte granules per thread
+            uint64_t pfv[kLitPf];
 #pragma unroll
-                for (int k = 0; k < kPf; k++) {
-                    const uint64_t c = c0 + (uint64_t)tid + (uint64_t)k * T;
-                    if (c <= c1) pf[k] = fetch_chunk(c << 4, pf_lo, pf_hi);
-                }
-                if (c1 - c0 + 1 > (uint64_t)kPf * T) pf_hi = ((c0 + (uint64_t)kPf * T) << 4) - a0;  // what kPf chunks per thread cover
-            } else {
-                pf_hi = pf_lo;
+            for (int k = 0; k < kLitPf; k++) {
+                const uint64_t o = ((uint64_t)k * T + (uint64_t)tid) * 8;
+                pfv[k] = o < kLitBuf && nw_lo + o + 8 <= lit_cap ? load_u64(lits + nw_lo + o) : 0;
             }
             while (prod >= 0) {
                 const int i = prod;
@@ -492,45 +478,54 @@ struct Resolver {
                 }
             }
             g.sync();                                                        // barrier D: every copy of the batch is in the ring
-            // consume the loads issued before the resolve (read-ahead literals, next records) BEFORE the write-back
+            // consume the loads issued before the resolve (literal read-ahead, next records) BEFORE the write-back
             // stores are issued: vmcnt retires in order, so a wait placed after the stores would wait for them too
-            if (pf_hi > pf_lo) {
-                const uint64_t a0 = (uint64_t)(uintptr_t)out;
-                const uint64_t c0 = (a0 + pf_lo) >> 4, c1 = (a0 + pf_hi - 1) >> 4;
 #pragma unroll
-                for (int k = 0; k < kPf; k++) {
-                    const uint64_t c = c0 + (uint64_t)tid + (uint64_t)k * T;
-                    if (c <= c1) stage_chunk(c << 4, pf[k], pf_lo, pf_hi);
+            for (int k = 0; k < kLitPf; k++) {
+                const uint64_t o = ((uint64_t)k * T + (uint64_t)tid) * 8;
+                if (o < kLitBuf) {
+                    const uint32_t x = (uint32_t)(nw_lo + o) & (kLitBuf - 1);
+                    *(uint64_t*)(litbuf + x) = pfv[k];
+                    if (x < 16) *(uint64_t*)(litbuf + kLitBuf + x) = pfv[k];   // mirror of the first 16 bytes past the end
                 }
-                ring_hi = pf_hi;
             }
+            lw_lo = nw_lo;
+            lw_hi = nw_lo + kLitBuf;
+            if (lw_hi > lit_cap) lw_hi = lit_cap & ~(uint64_t)7;
 #if defined(__HIP_DEVICE_COMPILE__)
             asm volatile("" ::"v"(r_next));
 #endif
             if (!(dbg & 2)) flush_span(rpos, hi);
             if (tid < (int)((T + 31) / 32)) l->done[tid] = 0;
             rpos = batch_end;
+            lbase += litspan;
             base += (uint32_t)n_take;
             // no barrier here: the next batch passes barriers A and B before it touches anything read above
         }
+        // literals after the last match
+        if (nlit > lbase) stream_literals(rpos, lbase, nlit - lbase, false);
     }
 };
 
-// One job: `ws` is the stream's workspace area written by phase 1.
+// One job: `ws` is the stream's workspace area of `stride` bytes written by phase 1.
 template <int T>
-SWC_D void resolve_job(const Job& job, const uint8_t* ws, Lds<T>* lds, int tid, int dbg = 0) {
+SWC_D void resolve_job(const Job& job, const uint8_t* ws, size_t stride, Lds<T>* lds, int tid, int dbg = 0) {
     const SWC_AS_GLOBAL StreamHeader* h = (const SWC_AS_GLOBAL StreamHeader*)ws;
-    const uint32_t nrec = h->nrec;
-    if (nrec == 0) return;
+    const size_t lo = lit_offset(stride, job.out_cap);
+    if (lo == 0) return;   // no literal stream: phase 1 reported SWC_E_NEED_WORKSPACE for this job
     Resolver<T> rs;
     rs.g.tid = tid;
     rs.g.l = lds;
     rs.out = (gptr)job.out;
+    rs.lits = (gcptr)ws + lo;
+    rs.nlit = h->nlit;
+    rs.lit_cap = lit_bytes(job.out_cap);
     rs.limit = job.out_len < job.out_cap ? job.out_len : job.out_cap;
     rs.rb = (uint32_t)(uintptr_t)job.out;
     rs.ring = lds->ring;
+    rs.litbuf = lds->litbuf;
     rs.dbg = dbg;
-    rs.run((const SWC_AS_GLOBAL uint32_t*)(ws + sizeof(StreamHeader)), nrec);
+    rs.run((const SWC_AS_GLOBAL uint32_t*)(ws + sizeof(StreamHeader)), h->nrec);
 }
 
 }  // namespace lzr

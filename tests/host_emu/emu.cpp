@@ -22,7 +22,7 @@ extern "C" void emu_inflate(swc::Job* jobs, size_t n) {
         std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
         swc::inflate::inflate_job(jobs[g], l, ws.data(), wsb);
         std::memset(&rl, 0xEE, sizeof rl);
-        swc::lzr::resolve_job<1>(jobs[g], ws.data(), &rl, 0);
+        swc::lzr::resolve_job<1>(jobs[g], ws.data(), wsb, &rl, 0);
     }
 }
 

@@ -22,11 +22,16 @@ for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
             acc[(k, r["Counter_Name"])] += float(r["Counter_Value"])
     for (k, c), v in acc.items():
         per[k][c] = v
-fetch = sum(v.get("FETCH_SIZE", 0.0) for v in per.values()) * 1024
+# gfx950 half-count correction: only kernels whose reads are wide coalesced streams (16 B per lane).  Calibrated on
+# this path: the resolve kernel stages U + 4*records bytes with 16-byte loads and reports exactly half of that;
+# the lane-per-stream kernels read scattered dwords and report the compressed bytes 1:1.
+WIDE = ("swc_lz_resolve_kernel",)
+fetch = sum(v.get("FETCH_SIZE", 0.0) * (2 if any(w in k for w in WIDE) else 1) for k, v in per.items()) * 1024
+fetch_raw = sum(v.get("FETCH_SIZE", 0.0) for v in per.values()) * 1024
 write = sum(v.get("WRITE_SIZE", 0.0) for v in per.values()) * 1024
 out = {"workload": workload, "round": tag, "per_kernel_counters": per,
-       "fetch_bytes_raw": fetch, "fetch_bytes_x2_gfx950": fetch * 2, "write_bytes": write,
-       "hbm_bytes_per_launch": fetch * 2 + write,
-       "note": "hbm_bytes_per_launch = FETCH_SIZE*1024*2 (gfx950 half-count correction for wide streaming reads) + WRITE_SIZE*1024; "
-               "WRITE_SIZE uncalibrated; one launch = last dispatch of each swc:: kernel"}
+       "fetch_bytes_raw": fetch_raw, "fetch_bytes_corrected": fetch, "write_bytes": write,
+       "hbm_bytes_per_launch": fetch + write,
+       "note": "hbm_bytes_per_launch = FETCH_SIZE*1024 (x2 for the wide-streaming resolve kernel: gfx950 counts a 128-byte request as 64) "
+               "+ WRITE_SIZE*1024 (uncalibrated); one launch = last dispatch of each swc:: kernel"}
 print(json.dumps(out, indent=1))
