@@ -12,7 +12,7 @@
 //           algorithmic bytes, profiles/r01_pmc_deflate_lane_per_stream.txt, r01c_deflate64k_traffic.json);
 //   phase 2 (this file, one stream per workgroup of T threads) walks the record list in batches of T records:
 //           a workgroup prefix-scan turns (literal run, length) into output positions and literal offsets, every
-//           thread drops its literal run into the 64 KiB LDS ring and then executes its match inside the ring
+//           thread drops its literal run into the 64 KiB LDS window and then executes its match inside the window
 //           (matches whose source is the output of an earlier match of the batch take over that match's source by
 //           pointer jumping; the rest wait on a done-bitmap), and the finished span leaves with coalesced
 //           16-byte stores -- the only time the output is written.
@@ -31,9 +31,9 @@
 namespace swc {
 namespace lzr {
 
-constexpr uint32_t kRingBytes = 65536;
-constexpr uint32_t kRingMask = kRingBytes - 1;
-constexpr uint32_t kSpan = 16384;          // output bytes one batch may cover; ring = 32 KiB window + span + slack
+constexpr uint32_t kWin = 65536;           // LDS window buffer: linear, slid down when a batch might not fit
+constexpr uint32_t kKeep = 32768;          // bytes of history a match can reach (RFC 1951 window)
+constexpr uint32_t kSpan = 16384;          // output bytes one batch may cover
 constexpr uint32_t kLitBuf = 4096;         // literal bytes staged in LDS ahead of the batch being resolved
 constexpr uint32_t kSkipFlag = 0x80000000u;
 constexpr uint32_t kMaxSkip = 0x7FFFFFFFu;
@@ -56,7 +56,7 @@ SWC_HD uint32_t make_match(uint32_t lit_run, uint32_t length, uint32_t distance)
 
 template <int T>
 struct Lds {
-    uint8_t ring[kRingBytes];
+    uint8_t win[kWin + 32];              // +32: 8-byte accesses may run past the last valid byte
     uint8_t litbuf[kLitBuf + 16];        // window of the literal stream, indexed by (literal offset % kLitBuf); +16: unaligned tail reads
     uint32_t ends[T + 1];                // end of record i, relative to the batch start (0xFFFFFFFF: no record)
     uint32_t dsts[T];                    // start of match i, relative to the batch start (== ends[i] for skips)
@@ -170,14 +170,13 @@ struct Resolver {
     uint64_t nlit;    // bytes in it
     uint64_t lit_cap; // bytes that may be READ from it (allocation size)
     uint64_t limit;   // bytes of `out` that exist: min(bytes produced, capacity)
-    uint32_t rb;      // low bits of the output address: ring index of position p is (rb + p) & kRingMask, so that
-                      // 16-byte aligned HBM chunks are 16-byte aligned in the ring
-    uint8_t* ring;
+    uint8_t* win;     // LDS window: position p lives at win[(uint32_t)p + woff]; the mapping keeps 16-byte aligned HBM
+    uint32_t woff;    // chunks 16-byte aligned in LDS and moves down by multiples of 16 when the window slides
     uint8_t* litbuf;
     int dbg;          // experiment switches (tools/exp_resolve.py), 0 in production: 1 no copies, 2 no write-back,
                       // 4 no literal placement, 8 no dependency search
 
-    SWC_D uint32_t ridx(uint64_t p) const { return (rb + (uint32_t)p) & kRingMask; }
+    SWC_D uint32_t idx(uint64_t p) const { return (uint32_t)p + woff; }
     SWC_D static uint32_t uniform(uint32_t v) {  // v is the same in every lane: keep it in an SGPR
 #if defined(__HIP_DEVICE_COMPILE__)
         return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
@@ -185,145 +184,134 @@ struct Resolver {
         return v;
 #endif
     }
+    SWC_D static uint64_t L8(const uint8_t* p) { return *(const u64_unaligned*)p; }
+    SWC_D static void S8(uint8_t* p, uint64_t v) { *(u64_unaligned*)p = v; }
+    // the low n (< 8) bytes of v
+    SWC_D static void Stail(uint8_t* p, uint32_t n, uint64_t v) {
+        if (n >= 4) { *(u32_unaligned*)p = (uint32_t)v; v >>= 32; p += 4; n -= 4; }
+        if (n >= 2) { *(u16_unaligned*)p = (uint16_t)v; v >>= 16; p += 2; n -= 2; }
+        if (n) *p = (uint8_t)v;
+    }
 
-    // ring -> HBM for positions [lo, hi), hi <= limit: 16-byte chunks by absolute address, edge chunks bytewise
+    // window -> HBM for positions [lo, hi), hi <= limit: 16-byte chunks by absolute address, edge chunks bytewise
     SWC_D void flush_span(uint64_t lo, uint64_t hi) const {
         if (hi <= lo) return;
         const uint64_t a0 = (uint64_t)(uintptr_t)out;
         const uint64_t c0 = (a0 + lo) >> 4, c1 = (a0 + hi - 1) >> 4;
         for (uint64_t c = c0 + (uint64_t)g.tid; c <= c1; c += T) {
-            const uint64_t ca = c << 4;
-            const int64_t p0 = (int64_t)(ca - a0);
+            const int64_t p0 = (int64_t)((c << 4) - a0);
             gptr dst = out + p0;
+            const uint8_t* src = win + idx((uint64_t)p0);
             if (p0 >= (int64_t)lo && (uint64_t)p0 + 16 <= hi) {
-                store_16(dst, *(const u128*)(ring + ((uint32_t)ca & kRingMask)));
+                store_16(dst, *(const u128*)src);
             } else {
                 for (int j = 0; j < 16; j++) {
                     int64_t p = p0 + j;
-                    if (p >= (int64_t)lo && (uint64_t)p < hi) dst[j] = ring[ridx((uint64_t)p)];
+                    if (p >= (int64_t)lo && (uint64_t)p < hi) dst[j] = src[j];
                 }
             }
         }
     }
 
-    // Ring accessors (unaligned LDS accesses are native on gfx950); the rare access that would run off the end of
-    // the ring goes bytewise.
-    SWC_D uint64_t rd(uint32_t x, uint32_t n) const {  // n = 1, 2, 4, 8
-        x &= kRingMask;
-        if (x + n <= kRingBytes) {
-            if (n == 8) return *(const u64_unaligned*)(ring + x);
-            if (n == 4) return *(const u32_unaligned*)(ring + x);
-            if (n == 2) return *(const u16_unaligned*)(ring + x);
-            return ring[x];
+    // Slide the window down so that the position `cur` lands just above the kKeep bytes a match can still reach.
+    // Called (group-uniformly) when the next batch might not fit.  Moves by a multiple of 16 bytes.
+    SWC_D void slide(uint64_t cur) {
+        const uint32_t ci = idx(cur);
+        const uint32_t D = (ci - kKeep) & ~15u;
+#if defined(__HIP_DEVICE_COMPILE__)
+        constexpr int kMv = (int)((kKeep / 16 + 2 + T - 1) / T);
+        const uint32_t chunks = (ci - D + 15u) >> 4;
+        u128 t[kMv];
+#pragma unroll
+        for (int k = 0; k < kMv; k++) {
+            const uint32_t c = (uint32_t)g.tid + (uint32_t)k * T;
+            if (c < chunks) t[k] = *(const u128*)(win + D + 16u * c);
         }
-        uint64_t v = 0;
-        for (uint32_t j = 0; j < n; j++) v |= (uint64_t)ring[(x + j) & kRingMask] << (8 * j);
-        return v;
-    }
-    SWC_D void wr(uint32_t x, uint32_t n, uint64_t v) const {
-        x &= kRingMask;
-        if (x + n <= kRingBytes) {
-            if (n == 8) *(u64_unaligned*)(ring + x) = v;
-            else if (n == 4) *(u32_unaligned*)(ring + x) = (uint32_t)v;
-            else if (n == 2) *(u16_unaligned*)(ring + x) = (uint16_t)v;
-            else ring[x] = (uint8_t)v;
-            return;
+        g.sync();
+#pragma unroll
+        for (int k = 0; k < kMv; k++) {
+            const uint32_t c = (uint32_t)g.tid + (uint32_t)k * T;
+            if (c < chunks) *(u128*)(win + 16u * c) = t[k];
         }
-        for (uint32_t j = 0; j < n; j++) ring[(x + j) & kRingMask] = (uint8_t)(v >> (8 * j));
-    }
-    // write the low n (< 8) bytes of v at ring index x
-    SWC_D void wr_tail(uint32_t x, uint32_t n, uint64_t v) const {
-        if (n >= 4) { wr(x, 4, v); v >>= 32; x += 4; n -= 4; }
-        if (n >= 2) { wr(x, 2, v); v >>= 16; x += 2; n -= 2; }
-        if (n >= 1) wr(x, 1, v);
-    }
-    // s + n <= d: sources are never written here, so all reads of a step are issued before its writes (one LDS
-    // round trip per 16 bytes).  Reads may run past the n source bytes; the surplus is discarded.
-    SWC_D void copy_plain(uint32_t d, uint32_t s, uint32_t n) const {
-        uint32_t i = 0;
-        for (; i + 16 <= n; i += 16) {
-            const uint64_t a = rd(s + i, 8), b = rd(s + i + 8, 8);
-            wr(d + i, 8, a);
-            wr(d + i + 8, 8, b);
-        }
-        uint32_t rem = n - i;
-        if (rem == 0) return;
-        uint64_t a = rd(s + i, 8), b = rem > 8 ? rd(s + i + 8, 8) : 0;
-        if (rem >= 8) { wr(d + i, 8, a); a = b; i += 8; rem -= 8; }
-        wr_tail(d + i, rem, a);
-    }
-    // One match inside the ring: `len` bytes at position dpos; the first min(len, period) bytes (the pattern) come
-    // from position spos (all producers done, spos + pattern <= dpos), the rest repeats the pattern with `period`.
-    SWC_D void copy_match(uint64_t dpos, uint32_t len, int64_t spos, uint32_t period) const {
-        const uint32_t d = ridx(dpos), s = ridx((uint64_t)spos);
-        const uint32_t plen = len < period ? len : period;
-        if (len <= period && d + len + 8 <= kRingBytes && s + len + 16 <= kRingBytes) {
-            // common case: plain copy, no access (8-byte over-reads included) leaves the ring => raw accesses
-            uint32_t i = 0;
-            for (; i + 16 <= len; i += 16) {
-                const uint64_t a = *(const u64_unaligned*)(ring + s + i), b = *(const u64_unaligned*)(ring + s + i + 8);
-                *(u64_unaligned*)(ring + d + i) = a;
-                *(u64_unaligned*)(ring + d + i + 8) = b;
-            }
-            uint32_t rem = len - i;
-            if (rem) {
-                uint64_t a = *(const u64_unaligned*)(ring + s + i);
-                const uint64_t b = *(const u64_unaligned*)(ring + s + i + 8);
-                uint32_t x = d + i;
-                if (rem >= 8) { *(u64_unaligned*)(ring + x) = a; a = b; x += 8; rem -= 8; }
-                if (rem >= 4) { *(u32_unaligned*)(ring + x) = (uint32_t)a; a >>= 32; x += 4; rem -= 4; }
-                if (rem >= 2) { *(u16_unaligned*)(ring + x) = (uint16_t)a; a >>= 16; x += 2; rem -= 2; }
-                if (rem) ring[x] = (uint8_t)a;
-            }
-            return;
-        }
-        copy_plain(d, s, plen);
-        if (len <= period) return;
-        uint32_t k = period, back = period;
-        if (period < 8) {
-            // bytewise until the copy distance (a multiple of the period) reaches 8
-            back = ((7u + period) / period) * period;
-            const uint32_t stop = len < back ? len : back;
-            for (; k < stop; k++) wr(d + k, 1, rd(d + k - period, 1));
-        }
-        for (; k + 8 <= len; k += 8) wr(d + k, 8, rd(d + k - back, 8));   // LDS executes a lane's accesses in order
-        if (k < len) wr_tail(d + k, len - k, rd(d + k - back, 8));
+        woff -= D;
+        g.sync();
+#else
+        for (uint32_t i = 0; i + D < ci; i++) win[i] = win[i + D];
+        woff -= D;
+#endif
     }
 
-    // `n` (< 255) literal bytes at literal offset `lo` -> ring at position dpos.  [lw_lo, lw_hi) of the literal stream
-    // is staged in litbuf; anything else is read from HBM.
-    SWC_D void place_literals(uint64_t dpos, uint64_t lo, uint32_t n, uint64_t lw_lo, uint64_t lw_hi) const {
-        const uint32_t d = ridx(dpos);
+    // One match inside the window: `len` bytes at index d; the first min(len, period) bytes (the pattern) come from
+    // index s (all producers done, s + pattern <= d), the rest repeats the pattern with `period`.  Reads may run up to
+    // 15 bytes past their source; the surplus is discarded.
+    SWC_D void copy_match(uint32_t d, uint32_t len, uint32_t s, uint32_t period) const {
+        uint8_t* dp = win + d;
+        const uint8_t* sp = win + s;
+        const uint32_t plen = len < period ? len : period;
+        uint32_t i = 0;
+        for (; i + 16 <= plen; i += 16) {
+            const uint64_t a = L8(sp + i), b = L8(sp + i + 8);
+            S8(dp + i, a);
+            S8(dp + i + 8, b);
+        }
+        uint32_t rem = plen - i;
+        if (rem) {
+            uint64_t a = L8(sp + i);
+            const uint64_t b = L8(sp + i + 8);
+            if (rem >= 8) { S8(dp + i, a); a = b; i += 8; rem -= 8; }
+            Stail(dp + i, rem, a);
+        }
+        if (len <= period) return;
+        // the match overlaps itself: extend the pattern (LDS executes a lane's accesses in order)
+        uint32_t k = period, back = period;
+        if (period < 8) {
+            back = ((7u + period) / period) * period;   // copy distance: a multiple of the period, >= 8
+            const uint32_t stop = len < back ? len : back;
+            for (; k < stop; k++) dp[k] = dp[k - period];
+        }
+        for (; k + 8 <= len; k += 8) S8(dp + k, L8(dp + k - back));
+        if (k < len) Stail(dp + k, len - k, L8(dp + k - back));
+    }
+
+    // `n` (< 255) literal bytes at literal offset `lo` -> window index d.  [lw_lo, lw_hi) of the literal stream is
+    // staged in litbuf; anything else is read from HBM.
+    SWC_D void place_literals(uint32_t d, uint64_t lo, uint32_t n, uint64_t lw_lo, uint64_t lw_hi) const {
         const bool staged = lo >= lw_lo && lo + n + 8 <= lw_hi;
         for (uint32_t i = 0; i < n; i += 8) {
             uint64_t v;
-            const uint32_t x = (uint32_t)(lo + i) & (kLitBuf - 1);
-            if (staged && x + 8 <= kLitBuf + 16) v = *(const u64_unaligned*)(litbuf + x);   // litbuf carries 16 mirrored bytes past its end
+            if (staged) v = L8(litbuf + ((uint32_t)(lo + i) & (kLitBuf - 1)));   // litbuf carries 16 mirrored bytes past its end
             else v = lo + i + 8 <= lit_cap ? load_u64(lits + lo + i) : 0;
             const uint32_t m = n - i;
-            if (m >= 8) wr(d + i, 8, v);
-            else wr_tail(d + i, m, v);
+            if (m >= 8) S8(win + d + i, v);
+            else Stail(win + d + i, m, v);
         }
     }
     // literal stream [lo, lo + n) -> HBM output at position pos (clamped to `limit`), all threads; used for literal
-    // runs of 255+ bytes and for the literals after the last match.  Also refreshes the ring window when `to_ring`.
-    SWC_D void stream_literals(uint64_t pos, uint64_t lo, uint64_t n, bool to_ring) const {
+    // runs of 255+ bytes and for the literals after the last match.
+    SWC_D void stream_literals(uint64_t pos, uint64_t lo, uint64_t n) const {
         if (pos >= limit) return;
         if (pos + n > limit) n = limit - pos;
         for (uint64_t i = (uint64_t)g.tid * 8; i < n; i += (uint64_t)T * 8) {
             const uint64_t m = n - i;
-            if (m >= 8) {
-                const uint64_t v = load_u64(lits + lo + i);
-                store_u64(out + pos + i, v);
-                if (to_ring && n - i <= 32768 + 8) wr(ridx(pos + i), 8, v);
-            } else {
-                for (uint64_t j = 0; j < m; j++) {
-                    const uint8_t b = lits[lo + i + j];
-                    out[pos + i + j] = b;
-                    if (to_ring) ring[ridx(pos + i + j)] = b;
-                }
-            }
+            if (m >= 8) store_u64(out + pos + i, load_u64(lits + lo + i));
+            else for (uint64_t j = 0; j < m; j++) out[pos + i + j] = lits[lo + i + j];
         }
+    }
+    // After a long literal run: point the window at `cur` and refill the kKeep bytes below it from the output (they are
+    // final there: streamed literals, or spans written back earlier by this group -- hence the full barrier).
+    SWC_D void rebuild(uint64_t cur) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __syncthreads();   // includes s_waitcnt vmcnt(0): this group's output stores have reached L2
+#endif
+        const uint32_t a0l = (uint32_t)(uintptr_t)out;
+        woff = kKeep + ((a0l + (uint32_t)cur) & 15u) - (uint32_t)cur;
+        const uint64_t hi = cur < limit ? cur : limit;
+        const uint64_t lo = hi > kKeep ? hi - kKeep : 0;
+        for (uint64_t p = lo + (uint64_t)g.tid * 8; p < hi; p += (uint64_t)T * 8) {
+            if (p + 8 <= hi) S8(win + idx(p), load_u64(out + p));
+            else for (uint64_t j = p; j < hi; j++) win[idx(j)] = out[j];
+        }
+        g.sync();
     }
 
     // Both bounds of the producer range in ONE loop with a group-uniform trip count (a = first index with
@@ -350,8 +338,12 @@ struct Resolver {
         uint32_t r_next = (uint32_t)tid < nrec ? recs[tid] : 0u;   // record prefetch, one batch ahead
         uint32_t next_base = 0;
         constexpr int kSteps = (T >= 1024 ? 11 : T >= 512 ? 10 : T >= 256 ? 9 : T >= 128 ? 8 : T >= 64 ? 7 : 1);
+        woff = (uint32_t)(uintptr_t)out & 15u;
         if (tid < (int)((T + 31) / 32)) l->done[tid] = 0;
         while (base < nrec) {
+            if (idx(rpos) + kSpan + 16 > kWin) slide(rpos);
+            const uint32_t wcur = idx(rpos);                                  // window index of the batch start
+            const uint32_t lim_rel = limit <= rpos ? 0u : limit - rpos > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(limit - rpos);
             const bool valid = base + (uint32_t)tid < nrec;
             uint32_t r;
             if (next_base == base) r = r_next;
@@ -371,24 +363,16 @@ struct Resolver {
             l->dsts[tid] = take ? dst_rel : 0xFFFFFFFFu;
             l->periods[tid] = dist;
             if (tid == 0) { l->ends[T] = 0xFFFFFFFFu; l->ntake = 0; l->span = r & kMaxSkip; l->litspan = 0; }
-            // my literal run goes into the ring now; barrier C orders it before every match copy
+            // my literal run goes into the window now; barrier C orders it before every match copy
             if (take && lit_run != 0 && !(dbg & 4)) {
-                const uint64_t dabs = rpos + dst_rel - lit_run;
-                if (dabs < limit) {
-                    const uint32_t n = dabs + lit_run > limit ? (uint32_t)(limit - dabs) : lit_run;
-                    place_literals(dabs, lbase + lit_end - lit_run, n, lw_lo, lw_hi);
-                }
+                const uint32_t ls = dst_rel - lit_run;
+                if (ls < lim_rel) place_literals(wcur + ls, lbase + lit_end - lit_run, lim_rel - ls < lit_run ? lim_rel - ls : lit_run, lw_lo, lw_hi);
             }
             g.sync();                                                        // barrier B: batch geometry published
             if (take && l->ends[tid + 1] == 0xFFFFFFFFu) { l->ntake = (uint32_t)tid + 1u; l->span = end_rel; l->litspan = lit_end; }  // read after barrier C
             // clamp to the bytes that exist (a match that starts below the capacity may end beyond it)
-            uint32_t clen = len;
-            bool pending = take;
-            if (pending) {
-                const uint64_t dabs = rpos + dst_rel;
-                if (dabs >= limit) pending = false;
-                else if (dabs + clen > limit) clen = (uint32_t)(limit - dabs);
-            }
+            bool pending = take && dst_rel < lim_rel;
+            const uint32_t clen = pending && lim_rel - dst_rel < len ? lim_rel - dst_rel : len;
             // Producers of my pattern bytes: records a..b (inclusive) of this batch.  A match whose pattern lies inside
             // ONE earlier match does not wait for it: it takes over that match's source (pointer jumping), so the
             // chains that repeated words form (every occurrence copies the previous one) collapse to depth one.
@@ -396,7 +380,7 @@ struct Resolver {
             int32_t s0 = (int32_t)dst_rel - (int32_t)dist;
             const uint32_t plen = clen < dist ? clen : dist;
             if (pending) {
-                const int64_t s1 = (int64_t)s0 + plen;  // exclusive
+                const int32_t s1 = s0 + (int32_t)plen;  // exclusive
                 if (s1 > 0 && !(dbg & 8)) {
                     const uint32_t lo_rel = s0 > 0 ? (uint32_t)s0 : 0u;
                     // first record that ends after my first source byte .. last record that starts before my source end
@@ -417,19 +401,19 @@ struct Resolver {
             const uint32_t span = uniform(l->span);
             const uint32_t litspan = uniform(l->litspan);
             if (n_take == 0) {
-                // record `base` is a skip: a literal run of `span` bytes, streamed straight to the output; the part of
-                // it that the following matches can still reach (32 KiB) is mirrored into the ring
-                stream_literals(rpos, lbase, span, true);
+                // record `base` is a skip: a literal run of `span` bytes, streamed straight to the output; the window is
+                // then rebuilt around the new position
+                stream_literals(rpos, lbase, span);
                 rpos += span;
                 lbase += span;
                 base += 1;
-                g.sync();
+                rebuild(rpos);
                 continue;
             }
             const uint64_t batch_end = rpos + span;
             const uint64_t hi = batch_end < limit ? batch_end : limit;
-            // literal-stream read-ahead for the next batch: one aligned 8-byte load per thread, HBM -> register now,
-            // register -> litbuf after the resolve
+            // literal-stream read-ahead for the next batch: aligned 8-byte loads, HBM -> registers now,
+            // registers -> litbuf after the resolve
             const uint64_t nw_lo = (lbase + litspan) & ~(uint64_t)7;
             constexpr int kLitPf = (int)(kLitBuf / 8) > T ? (int)(kLitBuf / 8) / T : 1;   // 8-byte granules per thread
             uint64_t pfv[kLitPf];
@@ -470,14 +454,14 @@ struct Resolver {
                     }
                 }
                 if (ready) {
-                    if (!(dbg & 1)) copy_match(rpos + dst_rel, clen, (int64_t)rpos + s0, dist);
+                    if (!(dbg & 1)) copy_match(wcur + dst_rel, clen, wcur + (uint32_t)s0, dist);
                     g.set_done(tid);
                     pending = false;
                 } else {
                     g.backoff();
                 }
             }
-            g.sync();                                                        // barrier D: every copy of the batch is in the ring
+            g.sync();                                                        // barrier D: every copy of the batch is in the window
             // consume the loads issued before the resolve (literal read-ahead, next records) BEFORE the write-back
             // stores are issued: vmcnt retires in order, so a wait placed after the stores would wait for them too
 #pragma unroll
@@ -500,10 +484,10 @@ struct Resolver {
             rpos = batch_end;
             lbase += litspan;
             base += (uint32_t)n_take;
-            // no barrier here: the next batch passes barriers A and B before it touches anything read above
+            // no barrier here: the next batch passes barriers A and B (or the slide's) before it touches anything read above
         }
         // literals after the last match
-        if (nlit > lbase) stream_literals(rpos, lbase, nlit - lbase, false);
+        if (nlit > lbase) stream_literals(rpos, lbase, nlit - lbase);
     }
 };
 
@@ -521,8 +505,8 @@ SWC_D void resolve_job(const Job& job, const uint8_t* ws, size_t stride, Lds<T>*
     rs.nlit = h->nlit;
     rs.lit_cap = lit_bytes(job.out_cap);
     rs.limit = job.out_len < job.out_cap ? job.out_len : job.out_cap;
-    rs.rb = (uint32_t)(uintptr_t)job.out;
-    rs.ring = lds->ring;
+    rs.win = lds->win;
+    rs.woff = 0;
     rs.litbuf = lds->litbuf;
     rs.dbg = dbg;
     rs.run((const SWC_AS_GLOBAL uint32_t*)(ws + sizeof(StreamHeader)), h->nrec);
