@@ -34,10 +34,11 @@ WORKLOADS = {
     # name: codec, corpus kind, n_distinct, tile, unit bytes, description
     "deflate64k": dict(codec="deflate", kind="gzip", n_distinct=4000, tile=25, unit=65536,
                        desc="100000 x 64 KiB gzip members (BASELINE configs[1])", kernels="swc_inflate_kernel + swc_lz_resolve_kernel"),
-    "lz4_4m": dict(codec="lz4_block", kind="lz4_block", n_distinct=32, tile=64, unit=4 << 20,
-                   desc="2048 x 4 MiB independent LZ4 blocks (BASELINE configs[2], resident micro-config)", kernels="swc_lz4_lane_kernel"),
-    "bzip2_900k": dict(codec="bzip2_block", kind="bzip2", n_distinct=32, tile=16, unit=899000,
-                       desc="512 x 900 kB bzip2 blocks (BASELINE configs[3] shape)", kernels="swc_bzip2_stage1/2/3_kernel"),
+    "lz4_4m": dict(codec="lz4_block", kind="lz4_block", n_distinct=32, tile=256, unit=4 << 20,
+                   desc="8192 x 4 MiB independent LZ4 blocks (BASELINE configs[2], resident micro-config of SURVEY 8d)",
+                   kernels="swc_lz4_parse_kernel + swc_lz4_resolve_kernel"),
+    "bzip2_900k": dict(codec="bzip2_block", kind="bzip2", n_distinct=32, tile=320, unit=899000,
+                       desc="10240 x 900 kB bzip2 blocks (BASELINE configs[3])", kernels="swc_bzip2_stage1/2/3_kernel"),
     "lzma2_256k": dict(codec="lzma2", kind="lzma2", n_distinct=256, tile=16, unit=262144,
                        desc="4096 x 256 KiB raw-LZMA2 units (BASELINE configs[4] shape)", kernels="swc_lzma_kernel"),
 }

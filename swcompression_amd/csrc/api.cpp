@@ -36,7 +36,7 @@ bool device_ready() {
 static hipError_t launch_codec(int codec, Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {
     switch (codec) {
         case SWC_CODEC_DEFLATE: return launch_inflate(jobs, n, ws, ws_bytes, stream);
-        case SWC_CODEC_LZ4_BLOCK: return launch_lz4(jobs, n, stream);
+        case SWC_CODEC_LZ4_BLOCK: return launch_lz4(jobs, n, ws, ws_bytes, stream);
         case SWC_CODEC_LZMA2: return launch_lzma(true, jobs, n, ws_bytes >= n * lzma_spill_bytes_per_job() ? ws : nullptr, stream);
         case SWC_CODEC_LZMA: return launch_lzma(false, jobs, n, ws_bytes >= n * lzma_spill_bytes_per_job() ? ws : nullptr, stream);
         case SWC_CODEC_BZIP2_BLOCK: return launch_bzip2(jobs, n, ws, ws_bytes, stream);
@@ -62,7 +62,7 @@ int run_units(int codec, std::vector<HostUnit>& units) {
     std::vector<size_t> cap(n);
     for (size_t i = 0; i < n; i++) cap[i] = default_cap(codec, units[i]);
 
-    bool want_ws = codec == SWC_CODEC_BZIP2_BLOCK || codec == SWC_CODEC_DEFLATE;  // LZMA: only after a unit reported SWC_E_NEED_WORKSPACE
+    bool want_ws = codec == SWC_CODEC_BZIP2_BLOCK || codec == SWC_CODEC_DEFLATE || codec == SWC_CODEC_LZ4_BLOCK;  // LZMA: only after a unit reported SWC_E_NEED_WORKSPACE
     for (int round = 0; round < 12 && !pending.empty(); round++) {
         const size_t m = pending.size();
         std::vector<size_t> in_off(m), out_off(m), dict_off(m);
@@ -171,7 +171,8 @@ size_t swc_batch_workspace_bytes(int codec, size_t n_jobs, uint64_t max_out_cap)
         case SWC_CODEC_LZMA:
         case SWC_CODEC_LZMA2: return n_jobs * lzma_spill_bytes_per_job();  // optional: only streams with lc+lp > 4 use it
         case SWC_CODEC_BZIP2_BLOCK: return n_jobs * bzip2_ws_bytes_per_job((size_t)max_out_cap + 64);  // L is never longer than the output
-        case SWC_CODEC_DEFLATE: return n_jobs * inflate_ws_bytes_per_job(max_out_cap);  // match records of phase 1 (lz_resolve.h)
+        case SWC_CODEC_DEFLATE: return n_jobs * inflate_ws_bytes_per_job(max_out_cap);  // match records + literal stream of phase 1 (lz_resolve.h)
+        case SWC_CODEC_LZ4_BLOCK: return n_jobs * lz4_ws_bytes_per_job(max_out_cap);     // same layout (lz4_wave.h); without it blocks decode one per lane
         default: return 0;
     }
 }

@@ -250,7 +250,7 @@ struct Lane {
             uint64_t run = pos - last_end;
             while (run >= 255) {
                 uint32_t s = run > lzr::kMaxSkip ? lzr::kMaxSkip : (uint32_t)run;
-                push(lzr::kSkipFlag | s);
+                push(lzr::make_skip(s));
                 run -= s;
             }
             push(lzr::make_match((uint32_t)run, length, distance));

@@ -12,6 +12,7 @@
 #include "inflate_lane.h"
 #include "lz_resolve.h"
 #include "lz4_lane.h"
+#include "lz4_wave.h"
 #include "lzma_wave.h"
 #include "bzip2_block.h"
 #include "launch.h"
@@ -89,21 +90,63 @@ hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStr
     return hipGetLastError();
 }
 
-// ---- LZ4, one block per lane (many small blocks) -------------------------------------------------
-__global__ __launch_bounds__(64) void swc_lz4_lane_kernel(Job* __restrict__ jobs, uint32_t n) {
+// ---- LZ4 -------------------------------------------------------------------------------------------------
+// Blocks without a dictionary prefix take the two-phase path: one block per wavefront for the sequence parse
+// (lz4_wave.h), then the LZ77 resolve kernel of lz_resolve.h with a 64 KiB history (one block per 1024-thread
+// workgroup, 96 KiB LDS window).  Blocks with a dictionary prefix (dependent frames, external dictionaries)
+// stay on the one-block-per-lane decoder (lz4_lane.h).  Each kernel skips the jobs of the other kind.
+__global__ __launch_bounds__(64) void swc_lz4_lane_kernel(Job* __restrict__ jobs, uint32_t n, int only_dict) {
     uint32_t g = blockIdx.x * kWave + threadIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
+    if (only_dict && job.dict == nullptr) return;
     lz4::lz4_block_job(job);
     jobs[g].out_len = job.out_len;
     jobs[g].in_consumed = job.in_consumed;
     jobs[g].status = job.status;
 }
 
-hipError_t launch_lz4(Job* jobs, size_t n, hipStream_t stream) {
+__global__ __launch_bounds__(64) void swc_lz4_parse_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride) {
+    uint32_t g = blockIdx.x;
+    if (g >= n) return;
+    Job job = jobs[g];
+    if (job.dict != nullptr) return;
+    __shared__ __attribute__((aligned(16))) uint8_t iw[lz4w::kInWin + 16];
+    __shared__ uint32_t rbuf[lz4w::kRecBuf];
+    __shared__ __attribute__((aligned(16))) uint8_t lbuf[lz4w::kLitStage + 32 + 64];
+    lz4w::lz4_parse_job<kWave>(job, ws + (size_t)g * ws_stride, ws_stride, (int)threadIdx.x, rbuf, lbuf, iw);
+    if (threadIdx.x == 0) {
+        jobs[g].out_len = job.out_len;
+        jobs[g].in_consumed = job.in_consumed;
+        jobs[g].status = job.status;
+    }
+}
+
+__global__ __launch_bounds__(1024) void swc_lz4_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, const uint8_t* ws, size_t ws_stride) {
+    __shared__ __attribute__((aligned(16))) lzr::Lds<1024, lz4w::kKeep, lz4w::kWin> lds;
+    uint32_t g = blockIdx.x;
+    if (g >= n) return;
+    Job job = jobs[g];
+    if (job.dict != nullptr) return;
+    lzr::resolve_job<1024, lz4w::kKeep, lz4w::kWin>(job, ws + (size_t)g * ws_stride, ws_stride, &lds, (int)threadIdx.x, 0);
+}
+
+size_t lz4_ws_bytes_per_job(uint64_t cap) { return lzr::ws_bytes_per_job(cap); }
+
+hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     dim3 grid((unsigned)((n + kWave - 1) / kWave)), block(kWave);
-    hipLaunchKernelGGL(swc_lz4_lane_kernel, grid, block, 0, stream, jobs, (uint32_t)n);
+    size_t stride = ws ? (ws_bytes / n) & ~(size_t)15 : 0;
+    if (stride < sizeof(lzr::StreamHeader)) {
+        // no workspace: every block on the lane decoder
+        hipLaunchKernelGGL(swc_lz4_lane_kernel, grid, block, 0, stream, jobs, (uint32_t)n, 0);
+        return hipGetLastError();
+    }
+    // The parse is latency bound per block (a serial chase), so all blocks are parsed in ONE launch: the more waves
+    // in flight, the better the latency hides (8,192 blocks = 8 waves per SIMD).
+    hipLaunchKernelGGL(swc_lz4_lane_kernel, grid, block, 0, stream, jobs, (uint32_t)n, 1);
+    hipLaunchKernelGGL(swc_lz4_parse_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride);
+    hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(1024), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride);
     return hipGetLastError();
 }
 

@@ -11,7 +11,8 @@ void set_resolve_debug(int m);
 void set_inflate_debug(int m);
 void set_phase_timing(int on);
 int last_phase_ms(float* ms, int cap);
-hipError_t launch_lz4(Job* jobs, size_t n, hipStream_t stream);
+hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream);
+size_t lz4_ws_bytes_per_job(uint64_t cap);
 hipError_t launch_lzma(bool lzma2, Job* jobs, size_t n, void* spill, hipStream_t stream);
 size_t lzma_spill_bytes_per_job();
 hipError_t launch_bzip2(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream);

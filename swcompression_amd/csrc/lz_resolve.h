@@ -17,10 +17,11 @@
 //           pointer jumping; the rest wait on a done-bitmap), and the finished span leaves with coalesced
 //           16-byte stores -- the only time the output is written.
 //
-// Record format (u32):  bit 31 = 0:  lit_run[0..7] | (length - 3)[8..15] | (distance - 1)[16..30]
-//                       bit 31 = 1:  skip[0..30]  -- `skip` literal bytes; always handled on its own
+// Record format (u32):  lit_run[0..7] < 255:  lit_run | (length - 3)[8..15] | (distance - 1)[16..31]
+//                       lit_run[0..7] = 255:  skip[8..31]  -- `skip` literal bytes; always handled on its own
 // lit_run = literal bytes between the end of the previous record and this match (< 255; longer runs
-// are preceded by skip records).  Records exist only for matches that START below the output capacity.
+// are preceded by skip records); length 3..258 (longer matches are split), distance 1..65536.  Records exist
+// only for matches that START below the output capacity.  The same format and kernel serve LZ4 (lz4_wave.h).
 //
 // The same source compiles for the host with T = 1 (tests/host_emu): batches of one record.
 #ifndef SWC_LZ_RESOLVE_H
@@ -31,12 +32,11 @@
 namespace swc {
 namespace lzr {
 
-constexpr uint32_t kWin = 65536;           // LDS window buffer: linear, slid down when a batch might not fit
-constexpr uint32_t kKeep = 32768;          // bytes of history a match can reach (RFC 1951 window)
 constexpr uint32_t kSpan = 16384;          // output bytes one batch may cover
 constexpr uint32_t kLitBuf = 4096;         // literal bytes staged in LDS ahead of the batch being resolved
-constexpr uint32_t kSkipFlag = 0x80000000u;
-constexpr uint32_t kMaxSkip = 0x7FFFFFFFu;
+constexpr uint32_t kSkipMark = 255u;       // lit_run value of a skip record
+constexpr uint32_t kMaxSkip = 0x00FFFFFFu;
+SWC_HD uint32_t make_skip(uint32_t n) { return kSkipMark | (n << 8); }
 
 // Per-stream area in the workspace: 16-byte header | records | literal stream (at the END of the area).
 struct StreamHeader {
@@ -44,7 +44,7 @@ struct StreamHeader {
     uint32_t pad0;
     uint64_t nlit;    // bytes in the literal stream
 };
-// Records a stream of capacity `cap` can need: one per match (>= 3 output bytes each, started below cap)
+// Records a stream of capacity `cap` can need: one per match piece (>= 3 output bytes each, started below cap)
 // plus one skip per >= 255 literal bytes, plus slack.
 SWC_HD size_t max_records(uint64_t cap) { return (size_t)(cap / 3 + cap / 255 + 8); }
 SWC_HD size_t lit_bytes(uint64_t cap) { return (size_t)((cap + 16 + 15) & ~(uint64_t)15); }   // +16: 8-byte flushes and reads may overshoot
@@ -54,9 +54,10 @@ SWC_HD size_t lit_offset(size_t stride, uint64_t cap) { return stride >= lit_byt
 
 SWC_HD uint32_t make_match(uint32_t lit_run, uint32_t length, uint32_t distance) { return lit_run | ((length - 3u) << 8) | ((distance - 1u) << 16); }
 
-template <int T>
+// T threads per stream; KEEP = bytes of history a match can reach (32 KiB for Deflate, 64 KiB for LZ4); WIN = window buffer
+template <int T, uint32_t KEEP = 32768, uint32_t WIN = 65536>
 struct Lds {
-    uint8_t win[kWin + 32];              // +32: 8-byte accesses may run past the last valid byte
+    uint8_t win[WIN + 32];              // +32: 8-byte accesses may run past the last valid byte
     uint8_t litbuf[kLitBuf + 16];        // window of the literal stream, indexed by (literal offset % kLitBuf); +16: unaligned tail reads
     uint32_t ends[T + 1];                // end of record i, relative to the batch start (0xFFFFFFFF: no record)
     uint32_t dsts[T];                    // start of match i, relative to the batch start (== ends[i] for skips)
@@ -69,10 +70,10 @@ struct Lds {
 };
 
 // Workgroup-collective helpers.  Device: T threads, barriers.  Host emulation: T == 1.
-template <int T>
+template <int T, uint32_t KEEP = 32768, uint32_t WIN = 65536>
 struct Group {
     int tid;
-    Lds<T>* l;
+    Lds<T, KEEP, WIN>* l;
 
     // Workgroup barrier that orders LDS only.  __syncthreads() also drains vmcnt, which would expose the latency of
     // the record / literal read-ahead loads and of the write-back stores at every barrier; no thread of the group
@@ -162,9 +163,10 @@ SWC_HD uint8_t byte_of(const u128& v, int j) {
     return (uint8_t)(w >> (8 * (j & 3)));
 }
 
-template <int T>
+template <int T, uint32_t KEEP = 32768, uint32_t WIN = 65536>
 struct Resolver {
-    Group<T> g;
+    static constexpr uint32_t kKeep = KEEP, kWin = WIN;
+    Group<T, KEEP, WIN> g;
     gptr out;
     gcptr lits;       // the stream's dense literal stream (16-byte aligned base)
     uint64_t nlit;    // bytes in it
@@ -329,7 +331,7 @@ struct Resolver {
     }
 
     SWC_D void run(const SWC_AS_GLOBAL uint32_t* recs, uint32_t nrec) {
-        Lds<T>* l = g.l;
+        Lds<T, KEEP, WIN>* l = g.l;
         const int tid = g.tid;
         uint64_t rpos = 0;      // everything below rpos is final in HBM
         uint64_t lbase = 0;     // literal bytes consumed so far
@@ -350,8 +352,8 @@ struct Resolver {
             else r = valid ? recs[base + tid] : 0u;
             next_base = base + T;
             r_next = next_base + (uint32_t)tid < nrec ? recs[next_base + tid] : 0u;   // in flight while this batch resolves
-            const bool skip = (r & kSkipFlag) != 0;
-            const uint32_t lit_run = r & 255u, len = ((r >> 8) & 255u) + 3u, dist = ((r >> 16) & 0x7FFFu) + 1u;
+            const uint32_t lit_run = r & 255u, len = ((r >> 8) & 255u) + 3u, dist = (r >> 16) + 1u;
+            const bool skip = lit_run == kSkipMark;
             // a skip record never joins a batch: it (and everything after it) is "not taken", and when it comes first
             // the literal run is streamed on its own below
             uint32_t end_rel = !valid ? 0u : skip ? kSpan + 1u : lit_run + len;
@@ -362,7 +364,7 @@ struct Resolver {
             l->ends[tid] = take ? end_rel : 0xFFFFFFFFu;
             l->dsts[tid] = take ? dst_rel : 0xFFFFFFFFu;
             l->periods[tid] = dist;
-            if (tid == 0) { l->ends[T] = 0xFFFFFFFFu; l->ntake = 0; l->span = r & kMaxSkip; l->litspan = 0; }
+            if (tid == 0) { l->ends[T] = 0xFFFFFFFFu; l->ntake = 0; l->span = r >> 8; l->litspan = 0; }
             // my literal run goes into the window now; barrier C orders it before every match copy
             if (take && lit_run != 0 && !(dbg & 4)) {
                 const uint32_t ls = dst_rel - lit_run;
@@ -492,12 +494,12 @@ struct Resolver {
 };
 
 // One job: `ws` is the stream's workspace area of `stride` bytes written by phase 1.
-template <int T>
-SWC_D void resolve_job(const Job& job, const uint8_t* ws, size_t stride, Lds<T>* lds, int tid, int dbg = 0) {
+template <int T, uint32_t KEEP = 32768, uint32_t WIN = 65536>
+SWC_D void resolve_job(const Job& job, const uint8_t* ws, size_t stride, Lds<T, KEEP, WIN>* lds, int tid, int dbg = 0) {
     const SWC_AS_GLOBAL StreamHeader* h = (const SWC_AS_GLOBAL StreamHeader*)ws;
     const size_t lo = lit_offset(stride, job.out_cap);
     if (lo == 0) return;   // no literal stream: phase 1 reported SWC_E_NEED_WORKSPACE for this job
-    Resolver<T> rs;
+    Resolver<T, KEEP, WIN> rs;
     rs.g.tid = tid;
     rs.g.l = lds;
     rs.out = (gptr)job.out;

@@ -7,6 +7,7 @@
 #include <cstring>
 #include "../../swcompression_amd/csrc/inflate_lane.h"
 #include "../../swcompression_amd/csrc/lz4_lane.h"
+#include "../../swcompression_amd/csrc/lz4_wave.h"
 #include "../../swcompression_amd/csrc/lzma_wave.h"
 #include "../../swcompression_amd/csrc/bzip2_block.h"
 
@@ -26,8 +27,21 @@ extern "C" void emu_inflate(swc::Job* jobs, size_t n) {
     }
 }
 
+// LZ4: blocks with a dictionary prefix on the lane decoder, the others through the two-phase path (parse with a
+// one-lane "wavefront", resolve with a one-thread "workgroup").
 extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {
-    for (size_t g = 0; g < n; g++) swc::lz4::lz4_block_job(jobs[g]);
+    static swc::lzr::Lds<1, swc::lz4w::kKeep, swc::lz4w::kWin> rl;
+    for (size_t g = 0; g < n; g++) {
+        if (jobs[g].dict) { swc::lz4::lz4_block_job(jobs[g]); continue; }
+        size_t wsb = swc::lzr::ws_bytes_per_job(jobs[g].out_cap);
+        std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
+        static uint32_t rbuf[swc::lz4w::kRecBuf];
+        static uint8_t lbuf[swc::lz4w::kLitStage + 32 + 64];
+        alignas(16) static uint8_t iw[swc::lz4w::kInWin + 16];
+        swc::lz4w::lz4_parse_job<1>(jobs[g], ws.data(), wsb, 0, rbuf, lbuf, iw);
+        std::memset(&rl, 0xEE, sizeof rl);
+        swc::lzr::resolve_job<1, swc::lz4w::kKeep, swc::lz4w::kWin>(jobs[g], ws.data(), wsb, &rl, 0);
+    }
 }
 
 // LZMA: the wave-uniform decode chain is run as a single logical lane (WAVE = 1); the literal-coder

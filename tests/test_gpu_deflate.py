@@ -177,3 +177,20 @@ def test_config2_full_size_properties():
     for i in range(0, n_distinct, 7):                                  # gzip trailers: CRC-32 + ISIZE
         crc, isize = np.frombuffer(units[i][-8:], dtype="<u4")
         assert isize == 65536 and zlib.crc32(host[i * 65536:(i + 1) * 65536].tobytes()) & 0xFFFFFFFF == crc
+
+
+def test_large_multi_block_streams_two_phase_path():
+    """Streams far larger than the 64 KiB resolve window: multi-block zlib output of 3 MiB text (window slides, matches
+    reach back across block boundaries), 2 MiB of zeros (258-byte matches at distance 1 chain through every batch),
+    incompressible data (stored blocks: literal runs of 64 KiB -> skip records) and a mixed payload."""
+    plains = [corpus.p_text(3 << 20, 21), corpus.p_zero(2 << 20), corpus.p_rand(400000, 8), corpus.p_mix(1 << 20, 4),
+              corpus.p_rep(700000, 6)]
+    streams = [corpus.deflate_raw(p) for p in plains]
+    b = DeviceBatch("deflate", streams, [len(p) for p in plains])
+    b.launch(sync=True)
+    r = b.results()
+    for i, p in enumerate(plains):
+        st, out, cons = O.deflate(streams[i])
+        assert st == 0 and out == p and cons == len(streams[i])
+        assert int(r["status"][i]) == 0 and int(r["out_len"][i]) == len(p) and int(r["in_consumed"][i]) == cons, i
+        assert b.output(i, len(p)) == p, "bytes differ on stream %d" % i

@@ -97,3 +97,28 @@ def test_many_64k_blocks_bit_exact():
     for i in range(len(units)):
         o = int(b._out_off[i])
         assert blob[o:o + 65536].tobytes() == plains[i]
+
+
+def test_large_blocks_two_phase_path():
+    """Blocks far larger than the parse stripes and the resolve window: 4 MiB text (BASELINE config 3 shape), long
+    matches (zeros / repeated phrase: records are split at 258 bytes and chain), incompressible data (one literal run of
+    hundreds of KiB: skip records), and a capacity that is too small."""
+    plains = [corpus.p_text(4 << 20, 11), corpus.p_zero(1 << 20), corpus.p_rand(300000, 5), corpus.p_rep(1 << 20, 3),
+              corpus.p_mix(2 << 20, 9), corpus.p_text(70000, 1), b"a" * 20, corpus.p_text(5 << 20, 2)[:3000000]]
+    blocks = [corpus.lz4_block(p) for p in plains]
+    caps = [len(p) for p in plains]
+    caps[5] = 50000   # too small: SWC_E_CAPACITY with the required size
+    b = DeviceBatch("lz4_block", blocks, caps)
+    b.launch(sync=True)
+    r = b.results()
+    O.lib.refcpu_set_max_output(1 << 23)
+    for i, p in enumerate(plains):
+        st, out = O.lz4_block(blocks[i])[:2]
+        assert st == 0 and out == p
+        if i == 5:
+            assert int(r["status"][i]) == 901 and int(r["out_len"][i]) == len(p)
+            assert b.output(i, 50000) == p[:50000]
+            continue
+        assert int(r["status"][i]) == 0 and int(r["out_len"][i]) == len(p) and int(r["in_consumed"][i]) == len(blocks[i]), i
+        assert b.output(i, len(p)) == p, "bytes differ on block %d" % i
+    O.lib.refcpu_set_max_output(1 << 30)
