@@ -195,10 +195,27 @@ def main():
         lib.swc_set_tuning(b"phase_timing", 0)
         phases = {"swc_inflate_kernel_ms": acc[0], "swc_lz_resolve_kernel_ms": acc[1]}
 
-    # parity spot check outside the timed region: one tile against the plain payloads
+    # parity checks outside the timed region: one tile against the plain payloads, and (gzip workload) EVERY member
+    # against the CRC-32 of its gzip trailer, computed on the device (swc_batch_crc32)
+    crc_check = None
     if rank == 0:
         for i in range(0, n_distinct, max(1, n_distinct // 16)):
             assert batch.output(i, unit) == plains[i], "bit-exactness violated on unit %d" % i
+        if args.workload == "deflate64k":
+            import numpy as np
+            from swcompression_amd import corpus
+            units, _ = corpus.build_units(w["kind"], n_distinct, w["unit"], seed=2 + 100003 * rank)
+            want = np.tile(np.array([np.frombuffer(u[-8:-4], dtype="<u4")[0] for u in units], dtype=np.uint32), w["tile"])
+            batch.crc32()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            got = batch.crc32()
+            e1.record()
+            torch.cuda.synchronize()
+            assert (got == want).all(), "device CRC-32 differs from the gzip trailers"
+            ms = e0.elapsed_time(e1)
+            crc_check = {"members_verified": int(batch.n), "kernel": "swc_crc32_kernel", "ms_incl_readback": ms,
+                         "GBps": sum_u / (ms * 1e-3) / 1e9}
 
     if rank == 0:
         total_u = sum_u * world * args.steps
@@ -225,6 +242,8 @@ def main():
                        "parallelism": "%d x independent shards" % world},
             "roofline": roof,
         }
+        if crc_check:
+            line["crc32_check"] = crc_check
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, raw, plains, args.cpu_seconds)
         print(json.dumps(line))

@@ -63,17 +63,23 @@ typedef struct swc_batch_opts {
     int32_t reserved;
 } swc_batch_opts;
 
-/* One launch for all n jobs.  `jobs` is a device pointer to n swc_job records.  Deflate and BZip2 need an HBM
- * workspace: this entry point allocates it from the stream-ordered pool; swc_batch_decompress_ws takes it
- * from the caller. */
+/* One launch for all n jobs.  `jobs` is a device pointer to n swc_job records.  Deflate needs an HBM workspace:
+ * this entry point allocates it from the stream-ordered pool; swc_batch_decompress_ws takes it from the caller
+ * (required for BZip2, recommended for LZ4). */
 int swc_batch_decompress(int codec, swc_job* jobs, size_t n, const swc_batch_opts* opts);
 
-/* Scratch bytes the codec needs in HBM (Deflate match records, LZMA probability model spill, BZip2 tt[]);
- * 0 for LZ4.  Allocated internally by the single-shot calls; batch callers pass it via
+/* Scratch bytes the codec needs in HBM (Deflate / LZ4: match records + literal stream of the two-phase path,
+ * LZMA: probability model spill, BZip2: tt[]).  LZ4 also runs without it (one block per lane, much slower on
+ * large blocks).  Allocated internally by the single-shot calls; batch callers pass it via
  * swc_batch_decompress_ws. */
 size_t swc_batch_workspace_bytes(int codec, size_t n_jobs, uint64_t max_out_cap);
 int swc_batch_decompress_ws(int codec, swc_job* jobs, size_t n, void* workspace, size_t workspace_bytes,
                             const swc_batch_opts* opts);
+
+/* CRC-32 (CheckSums.crc32, reference Sources/Common/CheckSums.swift:12-28, as checked by GzipArchive.swift:99)
+ * of every job's output, computed on the device after a batch has been decoded: crcs[i] covers
+ * out[0 .. min(out_len, out_cap)).  `jobs` and `crcs` are device pointers. */
+int swc_batch_crc32(const swc_job* jobs, size_t n, uint32_t* crcs, const swc_batch_opts* opts);
 
 /* ------------------------------------------------------------------------------------------------
  * Single-shot calls (host buffers in, malloc()ed host buffer out).

@@ -92,6 +92,17 @@ class DeviceBatch:
         if st:
             raise RuntimeError("swc_batch_decompress failed with status %d" % st)
 
+    def crc32(self):
+        """CRC-32 of every job's output, computed on the device (swc_batch_crc32).  Returns a numpy uint32 array."""
+        torch = self.torch
+        d = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        opts = _lib.SwcBatchOpts(self.device.index if self.device.index is not None else -1,
+                                 torch.cuda.current_stream(self.device).cuda_stream, 1, 0)
+        st = self.lib.swc_batch_crc32(self.d_jobs.data_ptr(), self.n, d.data_ptr(), C.byref(opts))
+        if st:
+            raise RuntimeError("swc_batch_crc32 failed with status %d" % st)
+        return d.cpu().numpy().view(np.uint32)
+
     def results(self):
         """Structured numpy array of the job records after the launch (synchronises)."""
         self.torch.cuda.synchronize(self.device)

@@ -15,6 +15,7 @@
 #include "lz4_wave.h"
 #include "lzma_wave.h"
 #include "bzip2_block.h"
+#include "crc32_group.h"
 #include "launch.h"
 
 namespace swc {
@@ -224,6 +225,22 @@ hipError_t launch_bzip2(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStrea
     hipLaunchKernelGGL(swc_bzip2_stage1_kernel, dim3((unsigned)n), block, bzip2::kStage1LdsBytes, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
     hipLaunchKernelGGL(swc_bzip2_stage2_kernel, dim3((unsigned)n), block, 256 * kWave * 4, stream, (uint32_t)n, (uint8_t*)ws, lcap);
     hipLaunchKernelGGL(swc_bzip2_stage3_kernel, dim3((unsigned)((n + kWave - 1) / kWave)), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
+    return hipGetLastError();
+}
+
+// ---- CRC-32 of every job's output, one stream per 256-thread workgroup -------------------
+__global__ __launch_bounds__(256) void swc_crc32_kernel(const Job* __restrict__ jobs, uint32_t n, uint32_t* __restrict__ crcs) {
+    __shared__ crc::Lds<256> lds;
+    uint32_t g = blockIdx.x;
+    if (g >= n) return;
+    const uint64_t len = jobs[g].out_len < jobs[g].out_cap ? jobs[g].out_len : jobs[g].out_cap;
+    uint32_t c = crc::crc32_group<256>((gcptr)jobs[g].out, len, &lds, (int)threadIdx.x);
+    if (threadIdx.x == 0) crcs[g] = c;
+}
+
+hipError_t launch_crc32(const Job* jobs, size_t n, uint32_t* crcs, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(swc_crc32_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, (uint32_t)n, crcs);
     return hipGetLastError();
 }
 

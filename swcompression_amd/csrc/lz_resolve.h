@@ -316,18 +316,20 @@ struct Resolver {
         g.sync();
     }
 
-    // Both bounds of the producer range in ONE loop with a group-uniform trip count (a = first index with
-    // ends[i] > v1, b = first index with dsts[i] >= v2; arrays non-decreasing): two independent LDS reads per step.
-    SWC_D static void bounds2(const uint32_t* ends, const uint32_t* dsts, int n, int steps, uint32_t v1, uint32_t v2, int& a, int& b) {
-        int lo1 = 0, hi1 = n, lo2 = 0, hi2 = n;
+    // Producer range of a source [v1, v2): a = first record with ends[a] > v1 (binary search, group-uniform trip count),
+    // b = last record with dsts[b] < v2, found by walking forward from a (a source rarely spans more than two records).
+    // Arrays are non-decreasing; records that were not taken hold 0xFFFFFFFF.
+    SWC_D static void producers(const uint32_t* ends, const uint32_t* dsts, int n, int steps, uint32_t v1, uint32_t v2, int& a, int& b) {
+        int lo = 0, hi = n;
         for (int it = 0; it < steps; it++) {
-            const int m1 = (lo1 + hi1) >> 1, m2 = (lo2 + hi2) >> 1;
-            const uint32_t e = ends[m1 < n ? m1 : n - 1], d = dsts[m2 < n ? m2 : n - 1];
-            if (lo1 < hi1) { if (e > v1) hi1 = m1; else lo1 = m1 + 1; }
-            if (lo2 < hi2) { if (d >= v2) hi2 = m2; else lo2 = m2 + 1; }
+            const int m = (lo + hi) >> 1;
+            const uint32_t e = ends[m < n ? m : n - 1];
+            if (lo < hi) { if (e > v1) hi = m; else lo = m + 1; }
         }
-        a = lo1;
-        b = lo2;
+        a = lo;
+        int k = lo;
+        while (k < n && dsts[k] < v2) k++;
+        b = k - 1;
     }
 
     SWC_D void run(const SWC_AS_GLOBAL uint32_t* recs, uint32_t nrec) {
@@ -387,8 +389,7 @@ struct Resolver {
                     const uint32_t lo_rel = s0 > 0 ? (uint32_t)s0 : 0u;
                     // first record that ends after my first source byte .. last record that starts before my source end
                     // (records that were not taken hold 0xFFFFFFFF, so the whole array can be searched)
-                    bounds2(l->ends, l->dsts, T, kSteps, lo_rel, (uint32_t)s1, dep_a, dep_b);
-                    dep_b -= 1;
+                    producers(l->ends, l->dsts, T, kSteps, lo_rel, (uint32_t)s1, dep_a, dep_b);
                     if (dep_b >= tid) dep_b = tid - 1;
                     if (dep_a <= dep_b) {
                         if (dep_a == dep_b && s0 >= 0 && (uint32_t)s0 >= l->dsts[dep_a] && (uint32_t)s1 <= l->ends[dep_a]) prod = dep_a;

@@ -177,6 +177,22 @@ def test_config2_full_size_properties():
     for i in range(0, n_distinct, 7):                                  # gzip trailers: CRC-32 + ISIZE
         crc, isize = np.frombuffer(units[i][-8:], dtype="<u4")
         assert isize == 65536 and zlib.crc32(host[i * 65536:(i + 1) * 65536].tobytes()) & 0xFFFFFFFF == crc
+    # every one of the 100,000 members against its gzip trailer, CRC-32 computed on the device (swc_batch_crc32)
+    want = np.tile(np.array([np.frombuffer(u[-8:-4], dtype="<u4")[0] for u in units], dtype=np.uint32), tile)
+    assert (b.crc32() == want).all()
+
+
+def test_device_crc32_matches_zlib():
+    """swc_batch_crc32 (CheckSums.crc32, reference CheckSums.swift:12-28) on outputs of awkward lengths."""
+    sizes = [0, 1, 2, 3, 4, 5, 7, 255, 256, 257, 1023, 1024, 1025, 4099, 65535, 65536, 65537, 300001, 1 << 20]
+    plains = [corpus.p_mix(n, 40 + i) for i, n in enumerate(sizes)]
+    streams = [corpus.deflate_raw(p) for p in plains]
+    b = DeviceBatch("deflate", streams, [max(len(p), 1) for p in plains])
+    b.launch(sync=True)
+    assert (b.results()["status"] == 0).all()
+    got = b.crc32()
+    for i, p in enumerate(plains):
+        assert int(got[i]) == zlib.crc32(p) & 0xFFFFFFFF, "length %d" % len(p)
 
 
 def test_large_multi_block_streams_two_phase_path():
