@@ -25,11 +25,13 @@ for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
 # gfx950 half-count correction: only kernels whose reads are wide coalesced streams (16 B per lane).  Calibrated on
 # this path: the resolve kernel stages U + 4*records bytes with 16-byte loads and reports exactly half of that;
 # the lane-per-stream kernels read scattered dwords and report the compressed bytes 1:1.
-WIDE = ("swc_lz_resolve_kernel",)
+WIDE = ("swc_lz_resolve_kernel", "swc_lz4_resolve_kernel")
+VERIFY = ("swc_crc32_kernel",)   # runs after the timed region (bench.py verifies every member); reported, not summed
+verify = {k: per.pop(k) for k in list(per) if any(v in k for v in VERIFY)}
 fetch = sum(v.get("FETCH_SIZE", 0.0) * (2 if any(w in k for w in WIDE) else 1) for k, v in per.items()) * 1024
 fetch_raw = sum(v.get("FETCH_SIZE", 0.0) for v in per.values()) * 1024
 write = sum(v.get("WRITE_SIZE", 0.0) for v in per.values()) * 1024
-out = {"workload": workload, "round": tag, "per_kernel_counters": per,
+out = {"workload": workload, "round": tag, "per_kernel_counters": per, "verification_kernels_not_summed": verify,
        "fetch_bytes_raw": fetch_raw, "fetch_bytes_corrected": fetch, "write_bytes": write,
        "hbm_bytes_per_launch": fetch + write,
        "note": "hbm_bytes_per_launch = FETCH_SIZE*1024 (x2 for the wide-streaming resolve kernel: gfx950 counts a 128-byte request as 64) "
