@@ -40,14 +40,30 @@ SWC_HD uint32_t mat_vec(const uint32_t* m, uint32_t x) {
     return y;
 }
 
-// state after the bytes p[0..n) starting from state c (no pre/post inversion)
+SWC_D uint32_t step4(const uint32_t (*tab)[256], uint32_t c, uint32_t data) {
+    const uint32_t w = c ^ data;
+    return tab[3][w & 0xFF] ^ tab[2][(w >> 8) & 0xFF] ^ tab[1][(w >> 16) & 0xFF] ^ tab[0][w >> 24];
+}
+struct q128 { uint32_t x, y, z, w; };
+// state after the bytes p[0..n) starting from state c (no pre/post inversion).  The slices of the threads of a wave are
+// n bytes apart, so every load of a wave touches 64 different lines; the main loop therefore pulls a whole 128-byte line
+// per thread with eight 16-byte loads issued together (the line is fetched once) before it runs the table steps on it.
 SWC_D uint32_t run_bytes(const uint32_t (*tab)[256], gcptr p, uint64_t n, uint32_t c) {
     uint64_t i = 0;
-    while (i < n && ((uintptr_t)(p + i) & 3)) { c = tab[0][(c ^ p[i]) & 0xFF] ^ (c >> 8); i++; }
-    for (; i + 4 <= n; i += 4) {
-        const uint32_t w = c ^ *(const SWC_AS_GLOBAL uint32_t*)(p + i);
-        c = tab[3][w & 0xFF] ^ tab[2][(w >> 8) & 0xFF] ^ tab[1][(w >> 16) & 0xFF] ^ tab[0][w >> 24];
+    while (i < n && ((uintptr_t)(p + i) & 15)) { c = tab[0][(c ^ p[i]) & 0xFF] ^ (c >> 8); i++; }
+    for (; i + 128 <= n; i += 128) {
+        q128 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = *(const SWC_AS_GLOBAL q128*)(p + i + 16 * k);
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            c = step4(tab, c, v[k].x);
+            c = step4(tab, c, v[k].y);
+            c = step4(tab, c, v[k].z);
+            c = step4(tab, c, v[k].w);
+        }
     }
+    for (; i + 4 <= n; i += 4) c = step4(tab, c, *(const SWC_AS_GLOBAL uint32_t*)(p + i));
     for (; i < n; i++) c = tab[0][(c ^ p[i]) & 0xFF] ^ (c >> 8);
     return c;
 }
@@ -68,8 +84,8 @@ SWC_D uint32_t crc32_group(gcptr out, uint64_t len, Lds<T>* l, int tid) {
         for (int t = 1; t < 4; t++) { c = l->tab[0][c & 0xFF] ^ (c >> 8); l->tab[t][i] = c; }
     }
     sync();
-    // slices: thread 0 takes the head of len - (T - 1) * n bytes, threads 1.. take n bytes each (n a multiple of 4)
-    const uint64_t n = T > 1 ? (len / T) & ~(uint64_t)3 : 0;
+    // slices: thread 0 takes the head of len - (T - 1) * n bytes, threads 1.. take n bytes each
+    const uint64_t n = T > 1 ? (len / T) & ~(uint64_t)15 : 0;   // multiple of 16: every slice starts as aligned as the head ends
     const uint64_t head = len - n * (uint64_t)(T - 1);
     uint32_t x;
     if (tid == 0) x = run_bytes(l->tab, out, head, 0xFFFFFFFFu);

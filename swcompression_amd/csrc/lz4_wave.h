@@ -345,15 +345,37 @@ struct Parser {
         // one of the block (guaranteed: it ends inside the loaded bytes), room for W * (13 + 258) output bytes below
         // the capacity, and room for W records
         const bool fast_ok = (size_t)max_rec >= lzr::max_records(cap);
+#if defined(SWC_LZ4_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+        uint64_t t_s = 0, t_c = 0, n_s = 0, n_c = 0, t_f = 0;
+#define SWC_T0 const uint64_t t0_ = __builtin_readcyclecounter();
+#define SWC_T1(acc, cnt) { acc += __builtin_readcyclecounter() - t0_; cnt++; }
+#else
+#define SWC_T0
+#define SWC_T1(acc, cnt)
+#endif
+        int result = SWC_OK;
         for (;;) {
             if (fast_ok && ip + (uint64_t)W + 24 <= n && pos + (uint64_t)W * 272 + 16 <= cap) {
                 if (rb_n + (uint32_t)W > kRecBuf || lb_n + (uint32_t)W * 13 > kLitStage) flush();
-                if (stripe()) continue;
+                SWC_T0
+                const bool took = stripe();
+                SWC_T1(t_s, n_s)
+                if (took) continue;
             }
+            SWC_T0
             const int st = careful_step();
-            if (st == -1) return SWC_OK;
-            if (st) return st;
+            SWC_T1(t_c, n_c)
+            if (st == -1) break;
+            if (st) { result = st; break; }
         }
+#if defined(SWC_LZ4_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+        if (w.lane == 0) {
+            SWC_AS_GLOBAL uint64_t* dbg = (SWC_AS_GLOBAL uint64_t*)(lits + lzr::lit_bytes(cap) - 32);
+            dbg[0] = t_s; dbg[1] = n_s; dbg[2] = t_c; dbg[3] = n_c;
+        }
+        (void)t_f;
+#endif
+        return result;
     }
 };
 

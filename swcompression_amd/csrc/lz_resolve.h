@@ -332,8 +332,17 @@ struct Resolver {
         b = k - 1;
     }
 
+#if defined(SWC_RESOLVE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define SWC_RP(k) { const uint64_t t_ = __builtin_readcyclecounter(); prof[k] += t_ - tlast; tlast = t_; }
+#else
+#define SWC_RP(k)
+#endif
     SWC_D void run(const SWC_AS_GLOBAL uint32_t* recs, uint32_t nrec) {
         Lds<T, KEEP, WIN>* l = g.l;
+#if defined(SWC_RESOLVE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+        uint64_t prof[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t tlast = __builtin_readcyclecounter();
+#endif
         const int tid = g.tid;
         uint64_t rpos = 0;      // everything below rpos is final in HBM
         uint64_t lbase = 0;     // literal bytes consumed so far
@@ -360,7 +369,9 @@ struct Resolver {
             // the literal run is streamed on its own below
             uint32_t end_rel = !valid ? 0u : skip ? kSpan + 1u : lit_run + len;
             uint32_t lit_end = !valid || skip ? 0u : lit_run;
+            SWC_RP(0)   // top: slide, record fetch
             g.scan2_incl(end_rel, lit_end);                                  // (barrier A inside)
+            SWC_RP(1)   // scan + barrier A
             const bool take = valid && end_rel <= kSpan;
             const uint32_t dst_rel = end_rel - len;
             l->ends[tid] = take ? end_rel : 0xFFFFFFFFu;
@@ -372,7 +383,9 @@ struct Resolver {
                 const uint32_t ls = dst_rel - lit_run;
                 if (ls < lim_rel) place_literals(wcur + ls, lbase + lit_end - lit_run, lim_rel - ls < lit_run ? lim_rel - ls : lit_run, lw_lo, lw_hi);
             }
+            SWC_RP(2)   // publish + literal placement
             g.sync();                                                        // barrier B: batch geometry published
+            SWC_RP(3)   // barrier B
             if (take && l->ends[tid + 1] == 0xFFFFFFFFu) { l->ntake = (uint32_t)tid + 1u; l->span = end_rel; l->litspan = lit_end; }  // read after barrier C
             // clamp to the bytes that exist (a match that starts below the capacity may end beyond it)
             bool pending = take && dst_rel < lim_rel;
@@ -397,9 +410,11 @@ struct Resolver {
                     }
                 }
             }
+            SWC_RP(4)   // producer search
             g.link_store(tid, (uint64_t)(uint32_t)s0 | ((uint64_t)(uint32_t)(pending ? prod : -1) << 32));
             if (take && !pending) g.set_done(tid);
             g.sync();                                                        // barrier C: links and literals published
+            SWC_RP(5)   // barrier C
             const int n_take = (int)uniform(l->ntake);
             const uint32_t span = uniform(l->span);
             const uint32_t litspan = uniform(l->litspan);
@@ -445,6 +460,7 @@ struct Resolver {
                 prod = pi;
                 g.link_store(tid, (uint64_t)(uint32_t)s0 | ((uint64_t)(uint32_t)prod << 32));
             }
+            SWC_RP(6)   // prefetch issue + pointer jumping
             // a waiting match runs once every producer has run; producers are earlier records, so this cannot deadlock
             while (pending) {
                 bool ready = true;
@@ -464,7 +480,9 @@ struct Resolver {
                     g.backoff();
                 }
             }
+            SWC_RP(7)   // copies (incl. waiting for producers)
             g.sync();                                                        // barrier D: every copy of the batch is in the window
+            SWC_RP(8)   // barrier D
             // consume the loads issued before the resolve (literal read-ahead, next records) BEFORE the write-back
             // stores are issued: vmcnt retires in order, so a wait placed after the stores would wait for them too
 #pragma unroll
@@ -484,6 +502,7 @@ struct Resolver {
 #endif
             if (!(dbg & 2)) flush_span(rpos, hi);
             if (tid < (int)((T + 31) / 32)) l->done[tid] = 0;
+            SWC_RP(9)   // literal staging + write-back
             rpos = batch_end;
             lbase += litspan;
             base += (uint32_t)n_take;
@@ -491,6 +510,12 @@ struct Resolver {
         }
         // literals after the last match
         if (nlit > lbase) stream_literals(rpos, lbase, nlit - lbase);
+#if defined(SWC_RESOLVE_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+        if ((tid & 63) == 0 && (tid >> 6) < 2) {   // waves 0 and 1 report into the slack at the end of the literal stream
+            SWC_AS_GLOBAL uint64_t* dbg = (SWC_AS_GLOBAL uint64_t*)(const_cast<uint8_t*>((const uint8_t*)lits) + lit_cap - 16) - 10 * (1 + (tid >> 6));
+            for (int k = 0; k < 10; k++) dbg[k] = prof[k];
+        }
+#endif
     }
 };
 
