@@ -39,8 +39,8 @@ WORKLOADS = {
                    kernels="swc_lz4_parse_kernel + swc_lz4_resolve_kernel"),
     "bzip2_900k": dict(codec="bzip2_block", kind="bzip2", n_distinct=32, tile=320, unit=899000,
                        desc="10240 x 900 kB bzip2 blocks (BASELINE configs[3])", kernels="swc_bzip2_stage1/2/3_kernel"),
-    "lzma2_256k": dict(codec="lzma2", kind="lzma2", n_distinct=256, tile=16, unit=262144,
-                       desc="4096 x 256 KiB raw-LZMA2 units (BASELINE configs[4] shape)", kernels="swc_lzma_kernel"),
+    "lzma2_256k": dict(codec="lzma2", kind="lzma2", n_distinct=256, tile=40, unit=262144,
+                       desc="10240 x 256 KiB raw-LZMA2 units (BASELINE configs[4] shape)", kernels="swc_lzma_kernel"),
 }
 
 

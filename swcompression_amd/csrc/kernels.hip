@@ -152,18 +152,21 @@ hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_
 }
 
 // ---- LZMA / LZMA2, one stream per wavefront ---------------------------------------------------------
-// LDS: 28,272 B of u16 probability cells per wave -> 5 streams per CU.  `spill` (may be null) holds
-// kLzmaSpillBytes per job for streams with lc+lp > 4.
+// LDS: the u16 probability cells of one stream.  With the workspace (spill area for big literal coders) at hand the
+// kernel keeps literal coders up to lc + lp = 3 in LDS -- what xz writes -- which is 15,984 B per wave = 10 streams per
+// CU; streams with lc + lp > 3 then run their literal coder out of HBM.  Without a workspace lc + lp = 4 still fits in
+// LDS (28,272 B, 5 streams per CU) and only lc + lp > 4 (legal for .lzma, never produced by xz) reports
+// SWC_E_NEED_WORKSPACE.  `spill` holds kLzmaSpillBytes per job.
 constexpr size_t kLzmaSpillBytes = (size_t)(0x300u << 12) * 2;
 
-template <bool LZMA2>
+template <bool LZMA2, int LDSBITS>
 __global__ __launch_bounds__(64) void swc_lzma_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* spill) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lzma_lds[];
     uint32_t g = blockIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
     SWC_AS_GLOBAL uint16_t* sp = spill ? (SWC_AS_GLOBAL uint16_t*)(spill + (size_t)g * kLzmaSpillBytes) : nullptr;
-    lzma::lzma_job<kWave>(job, LZMA2, lzma_lds, sp, (int)threadIdx.x);
+    lzma::lzma_job<kWave>(job, LZMA2, lzma_lds, sp, (int)threadIdx.x, LDSBITS);
     if (threadIdx.x == 0) {
         jobs[g].out_len = job.out_len;
         jobs[g].in_consumed = job.in_consumed;
@@ -176,8 +179,13 @@ size_t lzma_spill_bytes_per_job() { return kLzmaSpillBytes; }
 hipError_t launch_lzma(bool lzma2, Job* jobs, size_t n, void* spill, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     dim3 grid((unsigned)n), block(kWave);
-    if (lzma2) hipLaunchKernelGGL(swc_lzma_kernel<true>, grid, block, lzma::kLdsBytesPerWave, stream, jobs, (uint32_t)n, (uint8_t*)spill);
-    else hipLaunchKernelGGL(swc_lzma_kernel<false>, grid, block, lzma::kLdsBytesPerWave, stream, jobs, (uint32_t)n, (uint8_t*)spill);
+    if (spill) {
+        if (lzma2) hipLaunchKernelGGL((swc_lzma_kernel<true, 3>), grid, block, lzma::lds_bytes_for(3), stream, jobs, (uint32_t)n, (uint8_t*)spill);
+        else hipLaunchKernelGGL((swc_lzma_kernel<false, 3>), grid, block, lzma::lds_bytes_for(3), stream, jobs, (uint32_t)n, (uint8_t*)spill);
+    } else {
+        if (lzma2) hipLaunchKernelGGL((swc_lzma_kernel<true, 4>), grid, block, lzma::lds_bytes_for(4), stream, jobs, (uint32_t)n, (uint8_t*)nullptr);
+        else hipLaunchKernelGGL((swc_lzma_kernel<false, 4>), grid, block, lzma::lds_bytes_for(4), stream, jobs, (uint32_t)n, (uint8_t*)nullptr);
+    }
     return hipGetLastError();
 }
 

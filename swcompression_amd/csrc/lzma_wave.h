@@ -36,9 +36,12 @@ constexpr int P_POS_DEC = 704;       // [115]  (reference: 1 + 128 - 14 cells, L
 constexpr int P_LEN = 819;           // choice, choice2, low[16][8], mid[16][8], high[256] = 514
 constexpr int P_REP_LEN = 1333;
 constexpr int P_LITERAL = 1847;      // [0x300 << (lc+lp)]
-constexpr int kMaxLdsLitBits = 4;
+constexpr int kMaxLdsLitBits = 4;    // largest lc + lp any build keeps in LDS (host emulation, tests)
 constexpr int kProbCells = P_LITERAL + (0x300 << kMaxLdsLitBits);  // 14,135
-constexpr int kLdsBytesPerWave = ((kProbCells * 2 + 15) / 16) * 16;  // 28,272 B
+// LDS of a wave when literal coders up to lc + lp = `bits` stay in LDS (more bits spill to the HBM workspace):
+// 3 (what xz writes: lc 3, lp 0) -> 15,984 B = 10 streams per CU; 4 -> 28,272 B = 5 streams per CU
+constexpr int lds_bytes_for(int bits) { return (((P_LITERAL + (0x300 << bits)) * 2 + 15) / 16) * 16; }
+constexpr int kLdsBytesPerWave = lds_bytes_for(kMaxLdsLitBits);
 constexpr int LEN_CHOICE = 0, LEN_CHOICE2 = 1, LEN_LOW = 2, LEN_MID = 2 + 128, LEN_HIGH = 2 + 256;
 
 template <int WAVE>
@@ -52,7 +55,8 @@ struct Decoder {
     uint64_t pos;      // bytes produced == dictEnd == out.count of the reference
     int lane;
     // ---- model -----------------------------------------------------------------------------------
-    uint16_t* probs;            // LDS (host: heap) -- kProbCells cells
+    uint16_t* probs;            // LDS (host: heap) -- P_LITERAL + (0x300 << lds_bits) cells
+    int lds_bits;               // literal coders with lc + lp <= lds_bits live in LDS, larger ones in lit_spill
     SWC_AS_GLOBAL uint16_t* lit_spill;  // HBM literal coder when lc+lp > 4, else unused
     bool have_model;
     int lc, lp, pb;
@@ -151,9 +155,9 @@ struct Decoder {
         rep0 = rep1 = rep2 = rep3 = 0;
         need_ws = false;
         const int lit_bits = lc + lp;
-        const int lds_cells = P_LITERAL + (lit_bits <= kMaxLdsLitBits ? (0x300 << lit_bits) : 0);
+        const int lds_cells = P_LITERAL + (lit_bits <= lds_bits ? (0x300 << lit_bits) : 0);
         for (int i = lane; i < lds_cells; i += WAVE) probs[i] = 1024;
-        if (lit_bits > kMaxLdsLitBits) {
+        if (lit_bits > lds_bits) {
             const uint32_t cells = 0x300u << lit_bits;
             if (lit_spill) for (uint32_t i = (uint32_t)lane; i < cells; i += WAVE) lit_spill[i] = 1024;
             else need_ws = true;
@@ -206,7 +210,7 @@ struct Decoder {
         if (!have_model) return SWC_E_REF_TRAP;  // `probabilities` is still empty: index trap at :119
         if (need_ws) return SWC_E_NEED_WORKSPACE;
         const int lit_bits = lc + lp;
-        const bool spill = lit_bits > kMaxLdsLitBits;
+        const bool spill = lit_bits > lds_bits;
 
         for (;;) {
             if (trap) return SWC_E_REF_TRAP;
@@ -386,12 +390,12 @@ struct Decoder {
 // job.aux: LZMA2 = dictionary-size byte; LZMA = lc | lp << 8 | pb << 16.
 // job.dict_len: LZMA = declared uncompressed size (UINT64_MAX = unknown); job.dict (reinterpreted) = dictionary size.
 template <int WAVE>
-SWC_HD void lzma_job(Job& job, bool is_lzma2, uint16_t* probs, SWC_AS_GLOBAL uint16_t* lit_spill, int lane) {
+SWC_HD void lzma_job(Job& job, bool is_lzma2, uint16_t* probs, SWC_AS_GLOBAL uint16_t* lit_spill, int lane, int lds_bits = kMaxLdsLitBits) {
     Decoder<WAVE> d;
     d.in = (gcptr)job.in; d.n = job.in_len; d.ip = 0;
     d.out = (gptr)job.out; d.cap = job.out_cap; d.pos = 0;
     d.lane = lane;
-    d.probs = probs; d.lit_spill = lit_spill;
+    d.probs = probs; d.lit_spill = lit_spill; d.lds_bits = lds_bits;
     d.have_model = false;
     d.lc = 3; d.lp = 0; d.pb = 2;             // LZMAProperties defaults, LZMAProperties.swift:12-18
     d.dict_size = 1u << 24;
