@@ -42,7 +42,8 @@ def build(force=False, verbose=False):
         obj = os.path.join(objdir, os.path.basename(src) + ".o")
         objs.append(obj)
         cmd = [hipcc, "--offload-arch=" + ARCH, "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-c", src, "-o", obj,
-               "-Wall", "-Wno-unused-function"]
+               "-Wall", "-Wno-unused-function"] + os.environ.get("SWC_EXTRA_HIPCC_FLAGS", "").split()
+        # SWC_EXTRA_HIPCC_FLAGS: e.g. -DSWC_ENABLE_ABLATION_KNOBS -DSWC_RESOLVE_PROFILE -DSWC_LZ4_PROFILE for tools/exp_*.py
         if verbose:
             print(" ".join(cmd))
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

@@ -115,8 +115,7 @@ struct Parser {
     uint32_t* rbuf;      // kRecBuf records
     uint8_t* lbuf;       // kLitStage + 32 bytes (+ 64 for `wnd`)
     uint32_t rb_n, lb_n; // staged, not yet in HBM (nrec / nlit count them already)
-    uint8_t* wnd;        // 64 input bytes staged for the checked step
-    uint64_t wbase;
+
     // wave-uniform state
     uint64_t ip, pos, nlit, sequences;
     int64_t last_match_start;
@@ -170,12 +169,25 @@ struct Parser {
     }
 
     SWC_D void push(uint32_t v) {
-        if (nrec < max_rec && w.lane == 0) recs[nrec] = v;
+        if (nrec < max_rec) {   // (beyond the workspace: counted only, the job ends with SWC_E_NEED_WORKSPACE)
+            if (rb_n >= kRecBuf) flush();
+            if (w.lane == 0) rbuf[rb_n] = v;
+            rb_n++;
+        }
         nrec++;
     }
-    // `cnt` literal bytes in[from ..] -> literal stream, all lanes; only the part below the capacity is kept
+    // `cnt` literal bytes in[from ..] -> literal stream, all lanes; only the part below the capacity is kept.  Short runs
+    // that sit in the LDS input window are staged (LDS -> LDS); anything else is flushed around and copied in HBM.
     SWC_D void copy_literals(uint64_t from, uint64_t cnt) {
         uint64_t keep = pos >= cap ? 0 : (cap - pos < cnt ? cap - pos : cnt);
+        if (keep == 0) return;
+        if (keep + lb_n <= kLitStage && from + keep <= iw_hi && from + kInWin >= iw_hi) {
+            for (uint32_t i = (uint32_t)w.lane; i < (uint32_t)keep; i += (uint32_t)W) lbuf[lb_n + i] = iw[(uint32_t)(from + i) & (kInWin - 1)];
+            lb_n += (uint32_t)keep;
+            nlit += keep;
+            return;
+        }
+        flush();
         for (uint64_t i = (uint64_t)w.lane * 8; i < keep; i += (uint64_t)W * 8) {
             if (i + 8 <= keep) store_u64(lits + nlit + i, load_u64(in + from + i));
             else for (uint64_t j = i; j < keep; j++) lits[nlit + j] = in[from + j];
@@ -213,17 +225,13 @@ struct Parser {
 
     // One sequence with every check of the reference (LZ4.swift:341-412).  Returns SWC_OK to continue, -1 when the
     // block ended normally, or the error.
-    // byte `a` of the block (a < n) through a 64-byte window of the input staged in LDS at the start of the step: the
-    // step's reads depend on each other, and each one served from HBM/L2 would cost a memory round trip
+    // byte `a` of the block (a < n): from the LDS input window when it is there (the reads of the checked step depend
+    // on each other; each one served from HBM/L2 would cost a memory round trip)
     SWC_D uint32_t rd(uint64_t a) const {
-        return a - wbase < 64 ? (uint32_t)wnd[a - wbase] : (uint32_t)in[a];
+        return a < iw_hi && a + kInWin >= iw_hi ? (uint32_t)iw[(uint32_t)a & (kInWin - 1)] : (uint32_t)in[a];
     }
     SWC_D int careful_step() {
-        flush();   // this step appends to HBM directly
-        wbase = ip;
-        if (w.lane < 8 && ip + 8 * (uint64_t)w.lane + 8 <= n) *(u64_unaligned*)(wnd + 8 * w.lane) = load_u64(in + ip + 8 * (uint64_t)w.lane);
-        else if (w.lane < 8) for (int j = 0; j < 8; j++) { uint64_t a = ip + 8 * (uint64_t)w.lane + j; wnd[8 * w.lane + j] = a < n ? in[a] : 0; }
-        if (W == 1) for (int k = 1; k < 8; k++) for (int j = 0; j < 8; j++) { uint64_t a = ip + 8 * (uint64_t)k + j; wnd[8 * k + j] = a < n ? in[a] : 0; }
+        if (ip < n) fill_window();
         sequences++;
         if (n - ip < 1) return SWC_E_DATA_TRUNCATED;                               // :344
         const uint32_t token = rd(ip++);
@@ -390,8 +398,7 @@ SWC_D void lz4_parse_job(Job& job, uint8_t* ws, size_t ws_bytes, int lane, uint3
     ps.iw_pf = false;
     ps.rbuf = rbuf;
     ps.lbuf = lbuf;
-    ps.wnd = lbuf + kLitStage + 32;
-    ps.wbase = 0;
+
     ps.rb_n = ps.lb_n = 0;
     ps.in = (gcptr)job.in;
     ps.n = job.in_len;

@@ -1,4 +1,5 @@
-"""Ablation of the Deflate entropy kernel (timing only; results are wrong when dbg != 0)."""
+"""(needs a library built with SWC_EXTRA_HIPCC_FLAGS=-DSWC_ENABLE_ABLATION_KNOBS python -m swcompression_amd.build --force)
+Ablation of the Deflate entropy kernel (timing only; results are wrong when dbg != 0)."""
 import sys, os, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
