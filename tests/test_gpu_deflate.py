@@ -210,3 +210,35 @@ def test_large_multi_block_streams_two_phase_path():
         assert st == 0 and out == p and cons == len(streams[i])
         assert int(r["status"][i]) == 0 and int(r["out_len"][i]) == len(p) and int(r["in_consumed"][i]) == cons, i
         assert b.output(i, len(p)) == p, "bytes differ on stream %d" % i
+
+
+def test_randomised_encoder_settings_batch():
+    """Streams from every zlib strategy / level / window size on every payload class, random sizes, ONE batch: static
+    blocks (Z_FIXED), literal-only blocks (Z_HUFFMAN_ONLY), distance-1 runs (Z_RLE), tiny windows (many short-distance
+    matches), level 1 (long lazy-free matches) ... all through the two-phase path, bit-exact against zlib's own inflate
+    and the oracle's status."""
+    rnd = random.Random(20260926)
+    gens = [corpus.p_text, corpus.p_rep, corpus.p_mix, corpus.p_rand, lambda n, s: corpus.p_zero(n)]
+    strategies = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]
+    plains, streams = [], []
+    for i in range(240):
+        n = rnd.choice([0, 1, 2, 17, 255, 256, 257, 1000, 4095, 20000, 65535, 65536, 65537, 100000, 250000, 600000])
+        p = gens[i % len(gens)](n, 1000 + i)
+        co = zlib.compressobj(rnd.choice([1, 2, 4, 6, 9]), zlib.DEFLATED, -rnd.choice([9, 10, 12, 15]), rnd.choice([1, 4, 8, 9]),
+                              strategies[(i // len(gens)) % len(strategies)])
+        z = co.compress(p[:len(p) // 2]) + co.flush(zlib.Z_FULL_FLUSH if i % 7 == 0 else zlib.Z_NO_FLUSH) + co.compress(p[len(p) // 2:]) + co.flush()
+        assert zlib.decompress(z, -15) == p
+        plains.append(p)
+        streams.append(z)
+    b = DeviceBatch("deflate", streams, [max(len(p), 1) for p in plains])
+    b.launch(sync=True)
+    r = b.results()
+    bad = [i for i in range(len(plains)) if int(r["status"][i]) != 0 or int(r["out_len"][i]) != len(plains[i])]
+    assert not bad, "status/length wrong on streams %s" % bad[:10]
+    for i, p in enumerate(plains):
+        assert b.output(i, len(p)) == p, "bytes differ on stream %d (len %d)" % (i, len(p))
+    want = np.array([zlib.crc32(p) & 0xFFFFFFFF for p in plains], dtype=np.uint32)
+    assert (b.crc32() == want).all()
+    for i in range(0, len(plains), 17):
+        st, out, cons = O.deflate(streams[i])
+        assert (st, out, cons) == (0, plains[i], int(r["in_consumed"][i]))

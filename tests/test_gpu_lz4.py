@@ -122,3 +122,24 @@ def test_large_blocks_two_phase_path():
         assert int(r["status"][i]) == 0 and int(r["out_len"][i]) == len(p) and int(r["in_consumed"][i]) == len(blocks[i]), i
         assert b.output(i, len(p)) == p, "bytes differ on block %d" % i
     O.lib.refcpu_set_max_output(1 << 30)
+
+
+def test_randomised_blocks_two_phase_batch():
+    """Random sizes x payload classes in one batch through the stripe parser and the 64 KiB-history resolve kernel."""
+    rnd = random.Random(4242)
+    gens = [corpus.p_text, corpus.p_rep, corpus.p_mix, corpus.p_rand, lambda n, s: corpus.p_zero(n)]
+    plains = []
+    for i in range(160):
+        n = rnd.choice([1, 5, 12, 13, 64, 65, 300, 4096, 65535, 65536, 70001, 200000, 1 << 20])
+        plains.append(gens[i % len(gens)](n, 500 + i))
+    blocks = [corpus.lz4_block(p) for p in plains]
+    b = DeviceBatch("lz4_block", blocks, [len(p) for p in plains])
+    b.launch(sync=True)
+    r = b.results()
+    O.lib.refcpu_set_max_output(1 << 23)
+    for i, p in enumerate(plains):
+        assert int(r["status"][i]) == 0 and int(r["out_len"][i]) == len(p) and int(r["in_consumed"][i]) == len(blocks[i]), i
+        assert b.output(i, len(p)) == p, "bytes differ on block %d (len %d)" % (i, len(p))
+        if i % 13 == 0:
+            assert O.lz4_block(blocks[i])[:2] == (0, p)
+    O.lib.refcpu_set_max_output(1 << 30)

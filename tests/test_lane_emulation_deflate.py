@@ -72,3 +72,25 @@ def test_wave_tail_and_table_reuse(lanes):
     pairs = (pairs * (lanes // len(pairs) + 1))[:lanes]
     res = E.inflate([z for z, _ in pairs], [len(x) for _, x in pairs])
     assert [r[:2] for r in res] == [(0, x) for _, x in pairs]
+
+
+def test_randomised_encoder_settings():
+    """Every zlib strategy / level / window size on every payload class (static blocks, literal-only blocks, distance-1
+    runs, tiny windows, full flushes): the two-phase path (entropy decode + LZ77 resolve, host build) against zlib."""
+    import zlib
+    from swcompression_amd import corpus
+    rnd = random.Random(99)
+    gens = [corpus.p_text, corpus.p_rep, corpus.p_mix, corpus.p_rand, lambda n, s: corpus.p_zero(n)]
+    strategies = [zlib.Z_DEFAULT_STRATEGY, zlib.Z_FILTERED, zlib.Z_HUFFMAN_ONLY, zlib.Z_RLE, zlib.Z_FIXED]
+    plains, streams = [], []
+    for i in range(75):
+        n = rnd.choice([0, 1, 2, 17, 255, 256, 257, 1000, 4095, 20000, 65535, 65536, 65537, 90000])
+        p = gens[i % len(gens)](n, 2000 + i)
+        co = zlib.compressobj(rnd.choice([1, 2, 4, 6, 9]), zlib.DEFLATED, -rnd.choice([9, 10, 12, 15]), rnd.choice([1, 4, 8, 9]),
+                              strategies[(i // len(gens)) % len(strategies)])
+        z = co.compress(p[:len(p) // 2]) + co.flush(zlib.Z_FULL_FLUSH if i % 7 == 0 else zlib.Z_NO_FLUSH) + co.compress(p[len(p) // 2:]) + co.flush()
+        plains.append(p)
+        streams.append(z)
+    res = E.inflate(streams, [max(len(p), 1) for p in plains])
+    for i, (r, p) in enumerate(zip(res, plains)):
+        assert r[0] == 0 and r[1] == p and r[2] == len(streams[i]), "stream %d (len %d)" % (i, len(p))
