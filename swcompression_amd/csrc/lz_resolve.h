@@ -106,10 +106,18 @@ struct Group {
             if (lane == 63) { l->wave_sum[wave] = x; l->wave_sum2[wave] = y; }
             sync();
             uint32_t ax = 0, ay = 0;
+            if (T <= 512) {
 #pragma unroll
-            for (int w = 0; w < T / 64; w++) {
-                ax += w < wave ? l->wave_sum[w] : 0u;
-                ay += w < wave ? l->wave_sum2[w] : 0u;
+                for (int w = 0; w < T / 64; w++) {
+                    ax += w < wave ? l->wave_sum[w] : 0u;
+                    ay += w < wave ? l->wave_sum2[w] : 0u;
+                }
+            } else {   // 16 waves: a rolled loop keeps the 64-VGPR budget of a 1024-thread group free of spills
+#pragma unroll 1
+                for (int w = 0; w < wave; w++) {
+                    ax += l->wave_sum[w];
+                    ay += l->wave_sum2[w];
+                }
             }
             x += ax;
             y += ay;
