@@ -34,6 +34,7 @@ namespace lzr {
 
 constexpr uint32_t kSpan = 16384;          // output bytes one batch may cover
 constexpr uint32_t kLitBuf = 4096;         // literal bytes staged in LDS ahead of the batch being resolved
+constexpr uint32_t kBucket = 32;           // granularity of the position -> record index of a batch
 constexpr uint32_t kSkipMark = 255u;       // lit_run value of a skip record
 constexpr uint32_t kMaxSkip = 0x00FFFFFFu;
 SWC_HD uint32_t make_skip(uint32_t n) { return kSkipMark | (n << 8); }
@@ -67,6 +68,7 @@ struct Lds {
     uint32_t wave_sum[T / 64 + 1];
     uint32_t wave_sum2[T / 64 + 1];
     uint32_t ntake, span, litspan;
+    uint16_t first[kSpan / kBucket + 2];  // first[b] = first record of the batch that ends after byte kBucket * b of the span
 };
 
 // Workgroup-collective helpers.  Device: T threads, barriers.  Host emulation: T == 1.
@@ -324,18 +326,14 @@ struct Resolver {
         g.sync();
     }
 
-    // Producer range of a source [v1, v2): a = first record with ends[a] > v1 (binary search, group-uniform trip count),
-    // b = last record with dsts[b] < v2, found by walking forward from a (a source rarely spans more than two records).
+    // Producer range of a source [v1, v2) that starts inside the batch span: a = first record with ends[a] > v1 -- from
+    // the bucket index (the first record that ends after the bucket boundary at or below v1), then a short walk -- and
+    // b = last record with dsts[b] < v2, walking forward from a (a source rarely spans more than two records).
     // Arrays are non-decreasing; records that were not taken hold 0xFFFFFFFF.
-    SWC_D static void producers(const uint32_t* ends, const uint32_t* dsts, int n, int steps, uint32_t v1, uint32_t v2, int& a, int& b) {
-        int lo = 0, hi = n;
-        for (int it = 0; it < steps; it++) {
-            const int m = (lo + hi) >> 1;
-            const uint32_t e = ends[m < n ? m : n - 1];
-            if (lo < hi) { if (e > v1) hi = m; else lo = m + 1; }
-        }
-        a = lo;
-        int k = lo;
+    SWC_D static void producers(const uint32_t* ends, const uint32_t* dsts, const uint16_t* first, int n, uint32_t v1, uint32_t v2, int& a, int& b) {
+        int k = first[v1 / kBucket];
+        while (k < n && ends[k] <= v1) k++;
+        a = k;
         while (k < n && dsts[k] < v2) k++;
         b = k - 1;
     }
@@ -357,8 +355,8 @@ struct Resolver {
         uint64_t lw_lo = 0, lw_hi = 0;   // window of the literal stream staged in litbuf
         uint32_t base = 0;
         uint32_t r_next = (uint32_t)tid < nrec ? recs[tid] : 0u;   // record prefetch, one batch ahead
-        uint32_t next_base = 0;
-        constexpr int kSteps = (T >= 1024 ? 11 : T >= 512 ? 10 : T >= 256 ? 9 : T >= 128 ? 8 : T >= 64 ? 7 : 1);
+        SWC_OPAQUE(r_next);   // wait for it HERE: a load still pending at loop entry would put an s_waitcnt vmcnt(0) at the
+                              // loop head, which then drains the write-back stores of the previous batch in every iteration
         woff = (uint32_t)(uintptr_t)out & 15u;
         if (tid < (int)((T + 31) / 32)) l->done[tid] = 0;
         while (base < nrec) {
@@ -366,10 +364,8 @@ struct Resolver {
             const uint32_t wcur = idx(rpos);                                  // window index of the batch start
             const uint32_t lim_rel = limit <= rpos ? 0u : limit - rpos > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)(limit - rpos);
             const bool valid = base + (uint32_t)tid < nrec;
-            uint32_t r;
-            if (next_base == base) r = r_next;
-            else r = valid ? recs[base + tid] : 0u;
-            next_base = base + T;
+            const uint32_t r = r_next;                                        // always the record at base + tid, already landed
+            const uint32_t next_base = base + T;
             r_next = next_base + (uint32_t)tid < nrec ? recs[next_base + tid] : 0u;   // in flight while this batch resolves
             const uint32_t lit_run = r & 255u, len = ((r >> 8) & 255u) + 3u, dist = (r >> 16) + 1u;
             const bool skip = lit_run == kSkipMark;
@@ -386,6 +382,9 @@ struct Resolver {
             l->dsts[tid] = take ? dst_rel : 0xFFFFFFFFu;
             l->periods[tid] = dist;
             if (tid == 0) { l->ends[T] = 0xFFFFFFFFu; l->ntake = 0; l->span = r >> 8; l->litspan = 0; }
+            if (take) {   // position -> record index: I own every bucket boundary inside [my start, my end)
+                for (uint32_t bk = (dst_rel - lit_run + kBucket - 1) / kBucket; bk * kBucket < end_rel; bk++) l->first[bk] = (uint16_t)tid;
+            }
             // my literal run goes into the window now; barrier C orders it before every match copy
             if (take && lit_run != 0 && !(dbg & 4)) {
                 const uint32_t ls = dst_rel - lit_run;
@@ -410,7 +409,7 @@ struct Resolver {
                     const uint32_t lo_rel = s0 > 0 ? (uint32_t)s0 : 0u;
                     // first record that ends after my first source byte .. last record that starts before my source end
                     // (records that were not taken hold 0xFFFFFFFF, so the whole array can be searched)
-                    producers(l->ends, l->dsts, T, kSteps, lo_rel, (uint32_t)s1, dep_a, dep_b);
+                    producers(l->ends, l->dsts, l->first, T, lo_rel, (uint32_t)s1, dep_a, dep_b);
                     if (dep_b >= tid) dep_b = tid - 1;
                     if (dep_a <= dep_b) {
                         if (dep_a == dep_b && s0 >= 0 && (uint32_t)s0 >= l->dsts[dep_a] && (uint32_t)s1 <= l->ends[dep_a]) prod = dep_a;
@@ -434,6 +433,8 @@ struct Resolver {
                 lbase += span;
                 base += 1;
                 rebuild(rpos);
+                r_next = base + (uint32_t)tid < nrec ? recs[base + tid] : 0u;   // the prefetch was for base + T
+                SWC_OPAQUE(r_next);
                 continue;
             }
             const uint64_t batch_end = rpos + span;
@@ -514,6 +515,10 @@ struct Resolver {
             rpos = batch_end;
             lbase += litspan;
             base += (uint32_t)n_take;
+            if (n_take != T) {   // the batch was cut at the span limit or a skip record: the prefetch was for base + T
+                r_next = base + (uint32_t)tid < nrec ? recs[base + tid] : 0u;
+                SWC_OPAQUE(r_next);   // wait here, in the rare path, so that the loop head needs no s_waitcnt vmcnt
+            }
             // no barrier here: the next batch passes barriers A and B (or the slide's) before it touches anything read above
         }
         // literals after the last match

@@ -20,7 +20,7 @@ units, plains = corpus.build_units("gzip", 2048, 65536)
 raw = [u[10:-8] for u in units]
 for T in (512,):
     assert lib.swc_set_tuning(b"resolve_threads", T) == 0
-    for tile, label in ((64, "128k"), (48, "96k"), (32, "64k"), (2, "4k")):
+    for tile, label in ((48, "96k"),):
         b = DeviceBatch("deflate", raw, [65536] * len(raw), tile=tile)
         ms = timeit(b)
         r = b.results()
