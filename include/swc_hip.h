@@ -81,6 +81,22 @@ int swc_batch_decompress_ws(int codec, swc_job* jobs, size_t n, void* workspace,
  * out[0 .. min(out_len, out_cap)).  `jobs` and `crcs` are device pointers. */
 int swc_batch_crc32(const swc_job* jobs, size_t n, uint32_t* crcs, const swc_batch_opts* opts);
 
+/* The other checksums of the archive layer over every job's output (same coverage rule), zero-extended to 64 bits:
+ *   SWC_SUM_CRC32        CheckSums.crc32       CheckSums.swift:12-28  (GzipArchive.swift:99, XZArchive.swift:109-120)
+ *   SWC_SUM_ADLER32      CheckSums.adler32     CheckSums.swift:48-57  (ZlibArchive.swift:38)
+ *   SWC_SUM_CRC64        CheckSums.crc64       CheckSums.swift:39-46  (XZArchive.swift:109-120)
+ *   SWC_SUM_BZIP2_CRC32  CheckSums.bzip2crc32  CheckSums.swift:30-37  (BZip2.swift:81)
+ *   SWC_SUM_XXH32        XxHash32.hash(seed 0) XxHash32.swift:24-83   (LZ4.swift:300,326)
+ * `jobs` and `sums` are device pointers. */
+typedef enum swc_checksum {
+    SWC_SUM_CRC32 = 1,
+    SWC_SUM_ADLER32 = 2,
+    SWC_SUM_CRC64 = 3,
+    SWC_SUM_BZIP2_CRC32 = 4,
+    SWC_SUM_XXH32 = 5
+} swc_checksum;
+int swc_batch_checksum(int kind, const swc_job* jobs, size_t n, uint64_t* sums, const swc_batch_opts* opts);
+
 /* ------------------------------------------------------------------------------------------------
  * Single-shot calls (host buffers in, malloc()ed host buffer out).
  * ---------------------------------------------------------------------------------------------- */

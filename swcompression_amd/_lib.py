@@ -55,6 +55,7 @@ def load():
     sig("swc_last_phase_ms", I, C.POINTER(C.c_float), I)
     sig("swc_batch_decompress", I, I, C.c_void_p, C.c_size_t, C.POINTER(SwcBatchOpts))
     sig("swc_batch_crc32", I, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(SwcBatchOpts))
+    sig("swc_batch_checksum", I, I, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(SwcBatchOpts))
     sig("swc_batch_workspace_bytes", C.c_size_t, I, C.c_size_t, C.c_uint64)
     sig("swc_batch_decompress_ws", I, I, C.c_void_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(SwcBatchOpts))
     for n in ("swc_deflate_decompress", "swc_bzip2_decompress"):

@@ -103,6 +103,20 @@ class DeviceBatch:
             raise RuntimeError("swc_batch_crc32 failed with status %d" % st)
         return d.cpu().numpy().view(np.uint32)
 
+    CHECKSUMS = {"crc32": 1, "adler32": 2, "crc64": 3, "bzip2crc32": 4, "xxh32": 5}
+
+    def checksum(self, kind):
+        """Checksum `kind` (a key of CHECKSUMS, the names of the reference's CheckSums / XxHash32 functions) of every
+        job's output, computed on the device (swc_batch_checksum).  Returns a numpy uint64 array."""
+        torch = self.torch
+        d = torch.empty(self.n, dtype=torch.int64, device=self.device)
+        opts = _lib.SwcBatchOpts(self.device.index if self.device.index is not None else -1,
+                                 torch.cuda.current_stream(self.device).cuda_stream, 1, 0)
+        st = self.lib.swc_batch_checksum(self.CHECKSUMS[kind], self.d_jobs.data_ptr(), self.n, d.data_ptr(), C.byref(opts))
+        if st:
+            raise RuntimeError("swc_batch_checksum failed with status %d" % st)
+        return d.cpu().numpy().view(np.uint64)
+
     def results(self):
         """Structured numpy array of the job records after the launch (synchronises)."""
         self.torch.cuda.synchronize(self.device)

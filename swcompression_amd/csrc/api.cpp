@@ -204,6 +204,16 @@ int swc_batch_crc32(const swc_job* jobs, size_t n, uint32_t* crcs, const swc_bat
     return SWC_OK;
 }
 
+int swc_batch_checksum(int kind, const swc_job* jobs, size_t n, uint64_t* sums, const swc_batch_opts* opts) {
+    if (!device_ready()) return SWC_E_DEVICE;
+    if (kind < SWC_SUM_CRC32 || kind > SWC_SUM_XXH32 || (n && (!jobs || !sums))) return SWC_E_INVALID_ARGUMENT;
+    if (opts && opts->device >= 0 && hipSetDevice(opts->device) != hipSuccess) return SWC_E_DEVICE;
+    hipStream_t stream = opts ? static_cast<hipStream_t>(opts->stream) : nullptr;
+    if (launch_checksum(kind, reinterpret_cast<const Job*>(jobs), n, sums, stream) != hipSuccess) return SWC_E_DEVICE;
+    if (opts && opts->synchronize && hipStreamSynchronize(stream) != hipSuccess) return SWC_E_DEVICE;
+    return SWC_OK;
+}
+
 int swc_batch_decompress(int codec, swc_job* jobs, size_t n, const swc_batch_opts* opts) {
     if (codec == SWC_CODEC_BZIP2_BLOCK) return SWC_E_INVALID_ARGUMENT;  // needs the workspace: use swc_batch_decompress_ws
     if (codec == SWC_CODEC_DEFLATE && n) {

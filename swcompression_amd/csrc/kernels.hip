@@ -16,6 +16,7 @@
 #include "lzma_wave.h"
 #include "bzip2_block.h"
 #include "crc32_group.h"
+#include "checksum_group.h"
 #include "launch.h"
 
 namespace swc {
@@ -249,6 +250,59 @@ __global__ __launch_bounds__(256) void swc_crc32_kernel(const Job* __restrict__ 
 hipError_t launch_crc32(const Job* jobs, size_t n, uint32_t* crcs, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     hipLaunchKernelGGL(swc_crc32_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, (uint32_t)n, crcs);
+    return hipGetLastError();
+}
+
+// ---- the other checksums of the archive layer; sums[g] is zero-extended to 64 bits --------------
+template <typename W, bool MSB>
+__global__ __launch_bounds__(256) void swc_crc_kernel(const Job* __restrict__ jobs, uint32_t n, uint64_t* __restrict__ sums) {
+    __shared__ crc::Lds<256, W> lds;
+    uint32_t g = blockIdx.x;
+    if (g >= n) return;
+    const uint64_t len = jobs[g].out_len < jobs[g].out_cap ? jobs[g].out_len : jobs[g].out_cap;
+    W c = crc::crc_group<256, W, MSB>((gcptr)jobs[g].out, len, &lds, (int)threadIdx.x);
+    if (threadIdx.x == 0) sums[g] = (uint64_t)c;
+}
+
+__global__ __launch_bounds__(256) void swc_adler32_kernel(const Job* __restrict__ jobs, uint32_t n, uint64_t* __restrict__ sums) {
+    __shared__ sums::AdlerLds<256> lds;
+    uint32_t g = blockIdx.x;
+    if (g >= n) return;
+    const uint64_t len = jobs[g].out_len < jobs[g].out_cap ? jobs[g].out_len : jobs[g].out_cap;
+    uint32_t c = sums::adler32_group<256>((gcptr)jobs[g].out, len, &lds, (int)threadIdx.x);
+    if (threadIdx.x == 0) sums[g] = c;
+}
+
+// 16 streams per wave, four lanes each
+__global__ __launch_bounds__(64) void swc_xxh32_kernel(const Job* __restrict__ jobs, uint32_t n, uint64_t* __restrict__ sums) {
+    const uint32_t g = blockIdx.x * 16 + (threadIdx.x >> 2);
+    const int j = (int)(threadIdx.x & 3);
+    const bool live = g < n;
+    gcptr out = live ? (gcptr)jobs[g].out : nullptr;
+    const uint64_t len = live ? (jobs[g].out_len < jobs[g].out_cap ? jobs[g].out_len : jobs[g].out_cap) : 0;
+    auto quad_get = [](uint32_t v, int k) -> uint32_t {
+        switch (k) {   // quad_perm broadcasts
+            case 0: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x00, 0xf, 0xf, false);
+            case 1: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x55, 0xf, 0xf, false);
+            case 2: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xAA, 0xf, 0xf, false);
+            default: return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xFF, 0xf, 0xf, false);
+        }
+    };
+    const uint32_t h = sums::xxh32_quad(out, len, 0u, j, quad_get);
+    if (live && j == 0) sums[g] = h;
+}
+
+hipError_t launch_checksum(int kind, const Job* jobs, size_t n, uint64_t* sums, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const dim3 grid((unsigned)n), block(256);
+    switch (kind) {
+        case 1: hipLaunchKernelGGL((swc_crc_kernel<uint32_t, false>), grid, block, 0, stream, jobs, (uint32_t)n, sums); break;
+        case 2: hipLaunchKernelGGL(swc_adler32_kernel, grid, block, 0, stream, jobs, (uint32_t)n, sums); break;
+        case 3: hipLaunchKernelGGL((swc_crc_kernel<uint64_t, false>), grid, block, 0, stream, jobs, (uint32_t)n, sums); break;
+        case 4: hipLaunchKernelGGL((swc_crc_kernel<uint32_t, true>), grid, block, 0, stream, jobs, (uint32_t)n, sums); break;
+        case 5: hipLaunchKernelGGL(swc_xxh32_kernel, dim3((unsigned)((n + 15) / 16)), dim3(64), 0, stream, jobs, (uint32_t)n, sums); break;
+        default: return hipErrorInvalidValue;
+    }
     return hipGetLastError();
 }
 

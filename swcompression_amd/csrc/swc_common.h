@@ -80,6 +80,17 @@ SWC_HD uint64_t load_u64(gcptr p) { return *(const SWC_AS_GLOBAL u64_unaligned*)
 SWC_HD void store_u32(gptr p, uint32_t v) { *(SWC_AS_GLOBAL u32_unaligned*)p = v; }
 SWC_HD void store_u64(gptr p, uint64_t v) { *(SWC_AS_GLOBAL u64_unaligned*)p = v; }
 
+// Workgroup barrier of the group-per-stream checksum kernels.  The host emulation build runs the T "threads" of a group
+// as real host threads and plugs its own barrier in here (tests/host_emu/emu.cpp).
+#if defined(__HIP_DEVICE_COMPILE__)
+SWC_D void group_sync() { __syncthreads(); }
+#elif defined(SWC_HOST_EMULATION)
+inline thread_local void (*emu_group_sync)() = nullptr;
+SWC_D void group_sync() { if (emu_group_sync) emu_group_sync(); }
+#else
+SWC_D void group_sync() {}
+#endif
+
 // Per-lane view of an LDS region interleaved at wave stride: word j of this lane lives at
 // base[j * 64 + lane], so any per-lane index pattern is bank-conflict free for 32-bit accesses
 // (bank = lane % 32, the two 32-lane halves are serviced separately).

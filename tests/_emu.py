@@ -21,7 +21,7 @@ def build(force=False):
     if not force and os.path.exists(_LIB) and all(os.path.getmtime(_LIB) >= os.path.getmtime(s) for s in srcs):
         return
     subprocess.run(["g++", "-O2", "-g", "-std=c++17", "-DSWC_HOST_EMULATION", "-fPIC", "-shared",
-                    "-Wno-unknown-pragmas", "-o", _LIB, os.path.join(_DIR, "emu.cpp")], check=True)
+                    "-Wno-unknown-pragmas", "-pthread", "-o", _LIB, os.path.join(_DIR, "emu.cpp")], check=True)
 
 
 build()
@@ -85,3 +85,17 @@ def lzma(inputs, caps, props, dict_sizes, sizes):
 def bzip2_block(streams, body_bits, crcs, caps, lcap=1000000):
     """One bzip2 block per job: `streams[i]` is the whole stream, body_bits[i] the bit offset of the block body."""
     return run_batch("emu_bzip2_block", streams, caps, extra=body_bits, dict_ptr_values=crcs, fn_args=(C.c_size_t(lcap),))
+
+
+lib.emu_checksum.argtypes = [C.c_int, C.c_void_p, C.c_size_t]
+lib.emu_checksum.restype = C.c_uint64
+
+
+def checksum(kind, data, misalign=0):
+    """kind: 1 crc32, 2 adler32, 3 crc64, 4 bzip2crc32, 5 xxh32 (swc_checksum of include/swc_hip.h).  The data are
+    placed `misalign` bytes past a 64-byte boundary."""
+    data = bytes(data)
+    buf = C.create_string_buffer(len(data) + 128)
+    base = (C.addressof(buf) + 63) // 64 * 64 + misalign
+    C.memmove(base, data, len(data))
+    return lib.emu_checksum(kind, base, len(data))

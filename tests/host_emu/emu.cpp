@@ -86,3 +86,54 @@ extern "C" size_t emu_inflate_records(const uint8_t* in, size_t in_len, uint8_t*
     for (size_t i = 0; i < n && i < max_out; i++) recs_out[i] = r[i];
     return n;
 }
+
+// ---- checksums: the group kernels run with T real host threads and a pthread barrier behind swc::group_sync ----------
+#include <thread>
+#include <pthread.h>
+#include "../../swcompression_amd/csrc/crc32_group.h"
+#include "../../swcompression_amd/csrc/checksum_group.h"
+
+namespace {
+pthread_barrier_t* g_barrier;
+void barrier_wait() { pthread_barrier_wait(g_barrier); }
+
+template <int T, typename F>
+uint64_t run_group(F body) {
+    pthread_barrier_t bar;
+    pthread_barrier_init(&bar, nullptr, T);
+    g_barrier = &bar;
+    uint64_t result = 0;
+    std::vector<std::thread> th;
+    for (int t = 0; t < T; t++)
+        th.emplace_back([&, t] {
+            swc::emu_group_sync = barrier_wait;
+            uint64_t r = body(t);
+            if (t == 0) result = r;
+        });
+    for (auto& x : th) x.join();
+    pthread_barrier_destroy(&bar);
+    return result;
+}
+}  // namespace
+
+// kind as swc_checksum (include/swc_hip.h); T = 64 emulated threads per group
+extern "C" uint64_t emu_checksum(int kind, const uint8_t* p, size_t n) {
+    using namespace swc;
+    constexpr int T = 64;
+    switch (kind) {
+        case 1: { static crc::Lds<T, uint32_t> l; return run_group<T>([&](int t) { return (uint64_t)crc::crc_group<T, uint32_t, false>(p, n, &l, t); }); }
+        case 2: { static sums::AdlerLds<T> l; return run_group<T>([&](int t) { return (uint64_t)sums::adler32_group<T>(p, n, &l, t); }); }
+        case 3: { static crc::Lds<T, uint64_t> l; return run_group<T>([&](int t) { return (uint64_t)crc::crc_group<T, uint64_t, false>(p, n, &l, t); }); }
+        case 4: { static crc::Lds<T, uint32_t> l; return run_group<T>([&](int t) { return (uint64_t)crc::crc_group<T, uint32_t, true>(p, n, &l, t); }); }
+        case 5: {
+            uint32_t acc[4];
+            const uint32_t seed = 0;
+            for (int j = 0; j < 4; j++) {
+                const uint32_t init = j == 0 ? seed + sums::kP1 + sums::kP2 : j == 1 ? seed + sums::kP2 : j == 2 ? seed : seed - sums::kP1;
+                acc[j] = sums::xxh32_lane(p, n / 16, j, init);
+            }
+            return sums::xxh32_quad(p, n, seed, 0, [&](uint32_t, int k) { return acc[k]; });
+        }
+    }
+    return 0;
+}

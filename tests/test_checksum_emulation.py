@@ -1,0 +1,44 @@
+"""Group-per-stream checksum kernels (crc32_group.h, checksum_group.h) compiled for the host and run with 64 real threads
+per group, against the oracle's byte-at-a-time restatements of CheckSums.swift / XxHash32.swift."""
+import numpy as np
+import pytest
+
+import _emu as E
+import _oracle as O
+
+ORACLE = {1: O.crc32, 2: O.adler32, 3: O.crc64, 4: O.bzip2crc32, 5: O.xxh32}
+NAMES = {1: "crc32", 2: "adler32", 3: "crc64", 4: "bzip2crc32", 5: "xxh32"}
+
+
+def payloads():
+    rng = np.random.Generator(np.random.PCG64(0x5C0DE + 77))
+    out = [b"", b"a", b"123456789", bytes(15), bytes(16), bytes(17)]
+    for n in (63, 64, 65, 127, 128, 1023, 1024, 1025, 4096 + 3, 64 * 16, 64 * 16 + 1, 64 * 2048 + 5, 65536, 200001, 1 << 20):
+        out.append(rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+    out.append(b"\xff" * 300000)   # Adler-32 worst case for the deferred modulo
+    out.append(bytes(100000))
+    return out
+
+
+@pytest.mark.parametrize("kind", sorted(ORACLE))
+def test_group_checksum_matches_oracle(kind):
+    for p in payloads():
+        assert E.checksum(kind, p) == ORACLE[kind](p), "%s, length %d" % (NAMES[kind], len(p))
+
+
+def test_known_answers():
+    # the check values of the CRC catalogue / xxHash specification for "123456789"
+    assert E.checksum(1, b"123456789") == 0xCBF43926
+    assert E.checksum(3, b"123456789") == 0x995DC9BBDF1939FA
+    assert E.checksum(4, b"123456789") == 0xFC891918
+    assert E.checksum(2, b"Wikipedia") == 0x11E60398
+    assert E.checksum(5, b"") == 0x02CC5D05
+
+
+def test_unaligned_starts():
+    rng = np.random.Generator(np.random.PCG64(0x5C0DE + 78))
+    base = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
+    for off in (1, 3, 7, 13):
+        for kind in sorted(ORACLE):
+            p = base[off:off + 66000 + off]
+            assert E.checksum(kind, p, misalign=off) == ORACLE[kind](p)
