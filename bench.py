@@ -109,6 +109,64 @@ def cpu_baseline(name, raw, plains, seconds):
             "compressed_MBps": cbytes / dt / 1e6}
 
 
+def cpu_context(name, raw, plains, seconds):
+    """SURVEY.md 8(d) context lines next to the single-thread baseline: the oracle on all host cores (block-parallel, one
+    unit per task: oracle/rc_pool.c) and, for the gzip workload, the system zlib on one thread."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    from swcompression_amd import corpus
+    codec = {"deflate64k": 1, "lz4_4m": 2, "bzip2_900k": 3, "lzma2_256k": 4}[name]
+    aux = corpus.lzma2_dict_byte(1 << 20) if codec == 4 else 0
+    fn = O.lib.refcpu_timed_pool
+    fn.restype = C.c_double
+    fn.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_double,
+                   C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    cores = os.cpu_count() or 1
+    n = len(raw)
+    ins = (C.c_char_p * n)(*[bytes(r) for r in raw])
+    lens = (C.c_size_t * n)(*[len(r) for r in raw])
+    ob, ib, un = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    dt = fn(codec, aux, ins, lens, n, cores, seconds, C.byref(ob), C.byref(ib), C.byref(un))
+    if dt <= 0:
+        raise SystemExit("oracle pool failed")
+    ctx = {"oracle_all_cores": {"value": ob.value / dt / 2**30, "unit": "GiB/s decompressed", "cores": cores, "kind": "port",
+                                "compressed_MBps": ib.value / dt / 1e6,
+                                "sample": "%d unit decodes in %.1f s, one unit per task over %d threads (oracle/rc_pool.c)"
+                                          % (un.value, dt, cores)}}
+    if name == "deflate64k":
+        import zlib
+        t0 = time.perf_counter()
+        nbytes = i = 0
+        while time.perf_counter() - t0 < min(seconds, 3.0):
+            nbytes += len(zlib.decompress(raw[i % len(raw)], -15))
+            i += 1
+        dt = time.perf_counter() - t0
+        ctx["system_zlib_one_thread"] = {"value": nbytes / dt / 2**30, "unit": "GiB/s decompressed", "cores": 1}
+    return ctx
+
+
+def config1_latency(lib, raw, plains, reps=20):
+    """BASELINE configs[0]: ONE 64 KiB Deflate block through the single-shot C ABI (host buffer in, host buffer out, so
+    the figure includes both PCIe copies, the launch and the synchronisation)."""
+    data = raw[0]
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    used = C.c_size_t()
+    ts = []
+    for k in range(reps + 2):
+        t0 = time.perf_counter()
+        st = lib.swc_deflate_decompress(data, len(data), C.byref(out), C.byref(n), C.byref(used))
+        dt = time.perf_counter() - t0
+        assert st == 0 and n.value == len(plains[0]) and C.string_at(out, n.value) == plains[0]
+        lib.swc_free(out)
+        if k >= 2:
+            ts.append(dt)
+    ts.sort()
+    med = ts[len(ts) // 2]
+    return {"workload": "1 x 64 KiB dynamic-Huffman block, swc_deflate_decompress (BASELINE configs[0])", "median_ms": med * 1e3,
+            "compressed_MBps": len(data) / med / 1e6, "decompressed_MiBps": n.value / med / 2**20, "reps": reps}
+
+
 def committed_traffic(name):
     """HBM bytes per launch from the rocprofv3 --pmc passes of this command (tools/pmc_bench.sh), if committed."""
     best = None
@@ -246,6 +304,9 @@ def main():
             line["crc32_check"] = crc_check
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload, raw, plains, args.cpu_seconds)
+            line["cpu_context"] = cpu_context(args.workload, raw, plains, min(args.cpu_seconds, 5.0))
+        if world == 1 and args.workload == "deflate64k":
+            line["config1_latency"] = config1_latency(lib, raw, plains)
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

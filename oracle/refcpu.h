@@ -88,6 +88,10 @@ int refcpu_lz4_multi_decompress(const uint8_t* in, size_t in_len, const uint8_t*
 int refcpu_lz4_block(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len,
                      uint8_t** out, size_t* out_len);
 
+/* ---- timing harness (rc_pool.c): one independent unit per task over `threads` threads for `seconds` */
+double refcpu_timed_pool(int codec, int aux, const uint8_t* const* ins, const size_t* lens, size_t n, int threads,
+                         double seconds, uint64_t* out_bytes, uint64_t* in_bytes, uint64_t* units);
+
 #ifdef __cplusplus
 }
 #endif
