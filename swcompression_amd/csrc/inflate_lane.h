@@ -455,7 +455,8 @@ struct Lane {
     // never counted).
     //
     // Bit window: four valid dwords d0..d3 (128 bits) + two in flight; bp < 64 at the top of the decode, one
-    // iteration consumes <= 48 bits, so ONE 64-bit shift per iteration always suffices.  Positions are 32 bit.
+    // iteration consumes <= 63 bits (a literal, then a match: 15 + 20 + 28), so ONE 64-bit shift per iteration always
+    // suffices and no code reaches past bit 127.  Positions are 32 bit.
     // ANYTHING unusual -- unassigned code, symbol > 285, distance symbol > 29, distance beyond the output, a literal
     // run of 255+ before a match -- leaves the loop BEFORE consuming the symbol; the caller then decodes that one
     // symbol with the fully checked step.  Returns true when the end-of-block symbol was consumed.
@@ -503,23 +504,36 @@ struct Lane {
                 const uint64_t t = load_u64(sh ? in + q + 16 : dummy_ld);
                 nx = sh ? t : nx;
             }
-            // ---- lit/len symbol at bp (< 64)
+            // ---- symbol A: lit/len code at bp (< 64)
             const bool k1 = bp >= 32;
-            const uint32_t pk = funnel(k1 ? d2 : d1, k1 ? d1 : d0, bp & 31u);
+            const uint32_t pkA = funnel(k1 ? d2 : d1, k1 ? d1 : d0, bp & 31u);
+            const uint32_t c15A = brev32(pkA) >> 17;
+            uint32_t slA;
+            const uint32_t nA = code_length_slot(lit, c15A, slA);
+            uint32_t idxA = (slA + (c15A >> (15 - (nA & 15u)))) & 0xFFFFu;
+            const bool a_lit = nA <= 15 && idxA < (slA >> 16);
+            idxA = idxA > 319u ? 319u : idxA;
+            const uint32_t symA = *sym_ptr(l, W_LIT_SYM, idxA);
+            // ---- symbol M: the lit/len code after A when A is a literal, A itself otherwise (decoded again at the same
+            // position: the schedule stays fixed).  At most ONE match per iteration, and it is always M.
+            const uint32_t bpm = bp + (a_lit ? nA : 0u);   // < 64 + 15
+            const bool j1 = bpm >= 32, j2 = bpm >= 64;
+            const uint32_t pk = funnel(j2 ? d3 : j1 ? d2 : d1, j2 ? d2 : j1 ? d1 : d0, bpm & 31u);
             const uint32_t c15 = brev32(pk) >> 17;
             uint32_t sl;
             const uint32_t n = code_length_slot(lit, c15, sl);
             uint32_t idx = (sl + (c15 >> (15 - (n & 15u)))) & 0xFFFFu;
-            const bool is_lit = idx < (sl >> 16);
+            const bool code_ok = n <= 15;
+            const bool m_lit = code_ok && idx < (sl >> 16);
             idx = idx > 319u ? 319u : idx;
             const uint32_t sym = *sym_ptr(l, W_LIT_SYM, idx);
-            // ---- length + distance (computed by every lane)
+            // ---- length + distance of M (computed by every lane)
             const uint32_t s = (sym - 1u) & 31u;
             const uint32_t e = s < 8 || s >= 28 ? 0u : (s >> 2) - 1u;
             const uint32_t length = (s < 8 ? 3u + s : s >= 28 ? 258u : 3u + ((4u + (s & 3u)) << e)) + ((pk >> n) & ((1u << e) - 1u));
-            const uint32_t bp2 = bp + n + e;  // < 64 + 20
-            const bool m1 = bp2 >= 32, m2 = bp2 >= 64;
-            const uint32_t xlo = m2 ? d2 : m1 ? d1 : d0, xhi = m2 ? d3 : m1 ? d2 : d1;
+            const uint32_t bp2 = bpm + n + e;  // < 79 + 20: the 28 bits of a distance code end below bit 128
+            const bool m1 = bp2 >= 32, m2 = bp2 >= 64, m3 = bp2 >= 96;
+            const uint32_t xlo = m3 ? d3 : m2 ? d2 : m1 ? d1 : d0, xhi = m2 ? d3 : m1 ? d2 : d1;
             const uint32_t pk2 = funnel(xhi, xlo, bp2 & 31u);
             const uint32_t c15d = brev32(pk2) >> 17;
             uint32_t sl2;
@@ -529,27 +543,35 @@ struct Lane {
             const uint32_t dc = *sym_ptr(l, W_DIST_SYM, idx2);
             const uint32_t de = dc < 4 ? 0u : ((dc >> 1) - 1u) & 15u;
             const uint32_t distance = (dc < 4 ? 1u + dc : 1u + ((2u + (dc & 1u)) << de)) + ((pk2 >> n2) & ((1u << de) - 1u));
-            const uint32_t run = p - le;
+            const uint32_t pm = p + (a_lit ? 1u : 0u);   // output position of M
+            const uint32_t run = pm - le;
             // ---- classify
-            const bool code_ok = n <= 15;
-            const bool is_eob = code_ok && !is_lit && sym == 0;
-            const bool is_match = code_ok && !is_lit && sym != 0 && sym <= 29 && n2 <= 15 && dc <= 29 && distance <= p && run < 255;
+            const bool is_eob = code_ok && !m_lit && sym == 0;
+            const bool is_match = code_ok && !m_lit && sym != 0 && sym <= 29 && n2 <= 15 && dc <= 29 && distance <= pm && run < 255;
+            const bool lit2 = a_lit && m_lit;
             // ---- unconditional stores (see above), BEFORE the exits so that every path from the input load to its use
             // in the next iteration passes exactly these two stores.  A lane that leaves below has written one garbage
-            // byte at its next output position and one garbage record into the next free slot; both get overwritten.
-            const bool lit_ok = code_ok && is_lit;
-            lb |= lit_ok ? (uint64_t)sym << (8 * (nl & 7u)) : 0ull;
-            const bool full = lit_ok && (nl & 7u) == 7u;
-            *(SWC_AS_GLOBAL u64_unaligned*)((full && !(dbg & 1)) ? lits + (nl & ~7u) : dummy_st) = lb;
-            *((is_lit || (dbg & 2)) ? (SWC_AS_GLOBAL uint32_t*)(dummy_st + 8) : recs + nr) = lzr::make_match(run, length, distance);
-            if (is_eob) { bp += n; eob = true; break; }
-            if (!(code_ok && is_lit) && !is_match) break;   // leave BEFORE consuming: the checked step handles it
-            lb = full ? 0ull : lb;
-            nl += is_match ? 0u : 1u;
-            p += is_match ? length : 1u;
+            // record into the next free slot, which gets overwritten.  Up to two literals join the pending eight-byte
+            // group; at most one of them completes it.
+            const uint64_t lbA = lb | (a_lit ? (uint64_t)symA << (8 * (nl & 7u)) : 0ull);
+            const bool fullA = a_lit && (nl & 7u) == 7u;
+            const uint32_t nl1 = nl + (a_lit ? 1u : 0u);
+            const uint64_t lbB = (fullA ? 0ull : lbA) | (lit2 ? (uint64_t)sym << (8 * (nl1 & 7u)) : 0ull);
+            const bool fullB = lit2 && (nl1 & 7u) == 7u;
+            *(SWC_AS_GLOBAL u64_unaligned*)(((fullA || fullB) && !(dbg & 1)) ? lits + ((fullA ? nl : nl1) & ~7u) : dummy_st) = fullA ? lbA : lbB;
+            *((m_lit || (dbg & 2)) ? (SWC_AS_GLOBAL uint32_t*)(dummy_st + 8) : recs + nr) = lzr::make_match(run, length, distance);
+            if (!a_lit) {
+                if (is_eob) { bp += n; eob = true; break; }
+                if (!is_match) break;   // leave BEFORE consuming: the checked step handles it
+            }
+            // A literal A is consumed whatever M is; M is consumed when it is a literal or a good match (an end-of-block
+            // code or anything unusual behind a literal becomes A of the next iteration).
+            lb = fullB ? 0ull : lbB;
+            nl = nl1 + (lit2 ? 1u : 0u);
+            p = pm + (lit2 ? 1u : is_match ? length : 0u);
             le = is_match ? p : le;
             nr += is_match ? 1u : 0u;
-            bp += is_match ? n + e + n2 + de : n;
+            bp = bpm + (lit2 ? n : is_match ? n + e + n2 + de : 0u);
         }
         if (nl & 7u) store_u64(lits + (nl & ~7u), lb);   // pending literals; the bytes above them are rewritten later
         pos = (pos & ~0xFFFFFFFFull) | p;

@@ -1,0 +1,77 @@
+// gather_bench.hip -- how fast can the chip chase pointers through per-block permutations?  (BZip2 inverse BWT shape:
+// 10,240 blocks x 900,000 u32 entries.)  Each walker does `steps` dependent 4-byte gathers inside its block's array.
+//   mode 0: one walker (lane) per block          -- the current stage 3
+//   mode 1: W walkers per block, one workgroup of W threads per block
+// Usage: gather_bench <blocks> <n> <W> [lds_kb]
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include <numeric>
+#include <random>
+#include <algorithm>
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); exit(1); } } while (0)
+
+__global__ void replicate(const uint32_t* src, uint32_t* dst, size_t n, size_t blocks) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = n * blocks;
+    for (; i < total; i += (size_t)gridDim.x * blockDim.x) dst[i] = src[i % n];
+}
+
+__global__ void walk_lane_per_block(const uint32_t* P, size_t n, uint32_t blocks, uint32_t steps, uint32_t* sink) {
+    uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= blocks) return;
+    const uint32_t* p = P + (size_t)b * n;
+    uint32_t end = b % n, acc = 0;
+    for (uint32_t i = 0; i < steps; i++) { uint32_t v = p[end]; end = v >> 8; acc += v & 255; }
+    sink[b] = acc + end;
+}
+
+__global__ void walk_group_per_block(const uint32_t* P, size_t n, uint32_t steps, uint32_t* sink) {
+    extern __shared__ uint32_t pad[];
+    const uint32_t* p = P + (size_t)blockIdx.x * n;
+    uint32_t end = (uint32_t)(((uint64_t)threadIdx.x * n) / blockDim.x), acc = 0;
+    for (uint32_t i = 0; i < steps; i++) { uint32_t v = p[end]; end = v >> 8; acc += v & 255; }
+    if (acc + end == 0xFFFFFFFFu) pad[0] = 1;
+    sink[blockIdx.x * blockDim.x + threadIdx.x] = acc + end;
+}
+
+int main(int argc, char** argv) {
+    size_t blocks = argc > 1 ? atol(argv[1]) : 10240, n = argc > 2 ? atol(argv[2]) : 900000;
+    int W = argc > 3 ? atoi(argv[3]) : 64, lds_kb = argc > 4 ? atoi(argv[4]) : 0;
+    std::vector<uint32_t> perm(n), P(n);
+    std::iota(perm.begin(), perm.end(), 0u);
+    std::mt19937 rng(12345);
+    std::shuffle(perm.begin(), perm.end(), rng);
+    for (size_t i = 0; i < n; i++) P[perm[i]] = (perm[(i + 1) % n] << 8) | (uint32_t)(i & 255);   // one n-cycle
+    uint32_t *d_src, *d_P, *d_sink;
+    CK(hipMalloc(&d_src, n * 4));
+    CK(hipMalloc(&d_P, n * blocks * 4));
+    CK(hipMalloc(&d_sink, blocks * 1024 * 4));
+    CK(hipMemcpy(d_src, P.data(), n * 4, hipMemcpyHostToDevice));
+    replicate<<<8192, 256>>>(d_src, d_P, n, blocks);
+    CK(hipDeviceSynchronize());
+    hipEvent_t e0, e1;
+    CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    for (int rep = 0; rep < 2; rep++) {
+        CK(hipEventRecord(e0));
+        uint64_t gathers;
+        if (W == 1) {
+            uint32_t steps = (uint32_t)n / 8;   // an eighth of the walk is enough to time it
+            walk_lane_per_block<<<(unsigned)((blocks + 63) / 64), 64>>>(d_P, n, (uint32_t)blocks, steps, d_sink);
+            gathers = (uint64_t)steps * blocks;
+        } else {
+            uint32_t steps = (uint32_t)(n / W);
+            if (lds_kb) CK(hipFuncSetAttribute((const void*)walk_group_per_block, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb * 1024));
+            walk_group_per_block<<<(unsigned)blocks, W, lds_kb * 1024>>>(d_P, n, steps, d_sink);
+            gathers = (uint64_t)steps * W * blocks;
+        }
+        CK(hipEventRecord(e1));
+        CK(hipEventSynchronize(e1));
+        float ms;
+        CK(hipEventElapsedTime(&ms, e0, e1));
+        printf("blocks=%zu n=%zu W=%d lds=%dKB: %.1f ms, %.2f G gathers/s\n", blocks, n, W, lds_kb, ms, gathers / (ms * 1e-3) / 1e9);
+    }
+    return 0;
+}
