@@ -147,6 +147,28 @@ int swc_xz_split_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size
 int swc_unarchive_many(int kind, const uint8_t* const* archives, const size_t* lens, size_t n,
                        uint8_t** outs, size_t* out_lens, int32_t* statuses);
 
+/* ZipContainer.getEntryData (reference Sources/ZIP/ZipContainer.swift:61-118) for all entries of one container: every
+ * entry is an independent stream whose location and sizes the caller already has from the central directory
+ * (ZipEntryInfoHelper.swift:22-44), so the Deflate (8) and LZMA (14) entries go to the device as ONE batch each; stored (0)
+ * entries are copied, BZip2 (12) entries run their own block discovery.  Per entry: status (DeflateError / BZip2Error /
+ * LZMAError / SWC_E_ZIP_WRONG_SIZE / SWC_E_ZIP_COMPRESSION_NOT_SUPPORTED), crc_error (the caller raises
+ * ZipError.wrongCRC(entries so far), ZipContainer.swift:52-53) and the data (malloc()ed, swc_free). */
+typedef struct swc_zip_entry {
+    uint64_t data_offset;        /* IN : helper.dataOffset                                             */
+    uint64_t comp_size;          /* IN : helper.compSize                                               */
+    uint64_t uncomp_size;        /* IN : helper.uncompSize                                             */
+    uint32_t crc32;              /* IN : helper.entryInfo.crc                                          */
+    uint16_t method;             /* IN : 0 copy, 8 deflate, 12 bzip2, 14 lzma (CompressionMethod+Zip.swift:9-21) */
+    uint8_t has_data_descriptor; /* IN : helper.hasDataDescriptor                                      */
+    uint8_t zip64;               /* IN : helper.zip64FieldsArePresent                                  */
+    int32_t status;              /* OUT                                                                */
+    uint8_t crc_error;           /* OUT                                                                */
+    uint8_t pad[3];
+    uint8_t* data;               /* OUT: entry data (empty on error)                                   */
+    size_t data_len;             /* OUT                                                                */
+} swc_zip_entry;
+int swc_zip_get_entries_data(const uint8_t* container, size_t len, swc_zip_entry* entries, size_t n);
+
 /* checksums used by the framing layer (CheckSums.swift:12-57, XxHash32.swift:24-83, Sha256.swift:28-142) */
 uint32_t swc_crc32(const uint8_t* p, size_t n, uint32_t prev);
 uint32_t swc_adler32(const uint8_t* p, size_t n);

@@ -85,6 +85,11 @@ typedef enum swc_status {
     SWC_E_XZ_WRONG_PADDING = 808,            /* :45 */
     SWC_E_XZ_MULTI_BYTE_INTEGER_ERROR = 809, /* :47 */
 
+    /* ZipError -- Sources/ZIP/ZipError.swift:10-36 (only the cases ZipContainer.getEntryData can produce) */
+    SWC_E_ZIP_WRONG_SIZE = 851,                /* :16 */
+    SWC_E_ZIP_COMPRESSION_NOT_SUPPORTED = 852, /* :26 */
+    SWC_E_ZIP_WRONG_CRC = 853,                 /* :34 carries the entries processed so far (raised by the caller from crc_error) */
+
     SWC_E_REF_TRAP = 900,
     SWC_E_CAPACITY = 901,
     SWC_E_DEVICE = 902,

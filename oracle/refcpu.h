@@ -88,6 +88,11 @@ int refcpu_lz4_multi_decompress(const uint8_t* in, size_t in_len, const uint8_t*
 int refcpu_lz4_block(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len,
                      uint8_t** out, size_t* out_len);
 
+/* ---- ZIP entry data (Sources/ZIP/ZipContainer.swift:61-118); the central-directory walk is the caller's */
+int refcpu_zip_get_entry_data(const uint8_t* d, size_t len, uint64_t data_offset, uint64_t comp_size, uint64_t uncomp_size,
+                              uint32_t crc32, int method, int has_data_descriptor, int zip64, uint8_t** out, size_t* out_len,
+                              int* crc_error);
+
 /* ---- timing harness (rc_pool.c): one independent unit per task over `threads` threads for `seconds` */
 double refcpu_timed_pool(int codec, int aux, const uint8_t* const* ins, const size_t* lens, size_t n, int threads,
                          double seconds, uint64_t* out_bytes, uint64_t* in_bytes, uint64_t* units);

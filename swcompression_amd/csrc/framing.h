@@ -13,5 +13,22 @@ int gzip_parse_header(const uint8_t* d, size_t n, size_t& pos, GzipHeaderInfo* i
 int gzip_member_prepare(const uint8_t* d, size_t n, size_t pos, HostUnit& u);
 int gzip_member_finish(const uint8_t* d, size_t n, size_t data_pos, const HostUnit& u, size_t& next_pos, bool& crc_error);
 int zlib_parse_header(const uint8_t* d, size_t n, size_t& pos);
+// many-archive batching helpers (framing_many.cpp)
+struct Lz4Plan {
+    struct Impl;
+    Impl* impl;
+    int early_status = SWC_OK;
+    size_t first_unit = 0;
+    Lz4Plan();
+    ~Lz4Plan();
+    Lz4Plan(const Lz4Plan&) = delete;
+    Lz4Plan& operator=(const Lz4Plan&) = delete;
+};
+bool lz4_plan_prepare(const uint8_t* in, size_t n, Lz4Plan& plan, std::vector<HostUnit>& units);
+int lz4_plan_finish(const uint8_t* in, size_t n, const Lz4Plan& plan, const std::vector<HostUnit>& units, std::vector<uint8_t>& res);
+void bzip2_collect_candidates(const uint8_t* d, size_t n, std::vector<HostUnit>& units, std::vector<uint64_t>& used);
+int bzip2_finish_stream(const uint8_t* d, size_t n, std::vector<HostUnit>& units, size_t first_unit, const std::vector<uint64_t>& used,
+                        std::vector<uint8_t>& res, size_t& byte_pos);
+size_t lzma2_announced_size(const uint8_t* p, size_t n);
 }
 #endif

@@ -89,12 +89,12 @@ int walk_stream(const uint8_t* d, size_t n, size_t& byte_pos, const std::map<uin
     return SWC_OK;
 }
 
-// Decode every candidate block of `d` on the device in one batch.
-int decode_candidates(const uint8_t* d, size_t n, std::map<uint64_t, Decoded>& blocks) {
+}  // namespace
+
+// Units for every candidate block of `d` (appended to `units`; `used` receives their bit offsets).
+void bzip2_collect_candidates(const uint8_t* d, size_t n, std::vector<HostUnit>& units, std::vector<uint64_t>& used) {
     std::vector<uint64_t> cand;
     scan_block_magics(d, n, 32, cand);
-    std::vector<HostUnit> units;
-    std::vector<uint64_t> used;
     for (uint64_t c : cand) {
         if ((uint64_t)n * 8 - c < 80) continue;                                    // the walk reports wrongMagic there
         HostUnit u;
@@ -106,17 +106,41 @@ int decode_candidates(const uint8_t* d, size_t n, std::map<uint64_t, Decoded>& b
         units.push_back(std::move(u));
         used.push_back(c);
     }
+}
+
+namespace {
+void build_blocks(std::vector<HostUnit>& units, size_t first_unit, const std::vector<uint64_t>& used, std::map<uint64_t, Decoded>& blocks) {
+    for (size_t i = 0; i < used.size(); i++) {
+        HostUnit& u = units[first_unit + i];
+        Decoded dec;
+        dec.status = u.status;
+        dec.out = std::move(u.out);
+        dec.end_bit = u.in_consumed;                                              // bits for this codec
+        blocks.emplace(used[i], std::move(dec));
+    }
+}
+}  // namespace
+
+// The sequential walk of one stream over its decoded candidates units[first_unit .. first_unit + used.size()).
+int bzip2_finish_stream(const uint8_t* d, size_t n, std::vector<HostUnit>& units, size_t first_unit, const std::vector<uint64_t>& used,
+                        std::vector<uint8_t>& res, size_t& byte_pos) {
+    std::map<uint64_t, Decoded> blocks;
+    build_blocks(units, first_unit, used, blocks);
+    return walk_stream(d, n, byte_pos, blocks, res);
+}
+
+namespace {
+
+// Decode every candidate block of `d` on the device in one batch.
+int decode_candidates(const uint8_t* d, size_t n, std::map<uint64_t, Decoded>& blocks) {
+    std::vector<HostUnit> units;
+    std::vector<uint64_t> used;
+    bzip2_collect_candidates(d, n, units, used);
     if (!units.empty()) {
         int st = run_units(SWC_CODEC_BZIP2_BLOCK, units);
         if (st) return st;
     }
-    for (size_t i = 0; i < units.size(); i++) {
-        Decoded dec;
-        dec.status = units[i].status;
-        dec.out = std::move(units[i].out);
-        dec.end_bit = units[i].in_consumed;                                       // bits for this codec
-        blocks.emplace(used[i], std::move(dec));
-    }
+    build_blocks(units, 0, used, blocks);
     return SWC_OK;
 }
 

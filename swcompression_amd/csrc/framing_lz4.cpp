@@ -20,12 +20,9 @@ struct BlockRef {
     bool compressed;
 };
 
-// Decode `blocks` (all independent of each other) on the device and append to `out` in order.
-// Returns the first decode error in stream order, or SWC_OK / SWC_E_DEVICE.
-int decode_independent(const uint8_t* base, const std::vector<BlockRef>& blocks, const uint8_t* dict, size_t dict_len,
-                       bool have_dict, size_t max_block, std::vector<uint8_t>& out) {
-    std::vector<HostUnit> units;
-    units.reserve(blocks.size());
+// Units for the compressed blocks of `blocks` (all independent of each other), in order.
+void independent_units(const uint8_t* base, const std::vector<BlockRef>& blocks, const uint8_t* dict, size_t dict_len,
+                       bool have_dict, size_t max_block, std::vector<HostUnit>& units) {
     for (const BlockRef& b : blocks) {
         if (!b.compressed) continue;
         HostUnit u;
@@ -35,14 +32,14 @@ int decode_independent(const uint8_t* base, const std::vector<BlockRef>& blocks,
         if (have_dict) { u.dict = dict ? dict : reinterpret_cast<const uint8_t*>(""); u.dict_len = dict_len; }
         units.push_back(std::move(u));
     }
-    if (!units.empty()) {
-        int st = run_units(SWC_CODEC_LZ4_BLOCK, units);
-        if (st) return st;
-    }
+}
+// Appends the blocks to `out` in stream order; `units` = the decoded units of independent_units().  Returns the
+// first decode error in stream order.
+int independent_append(const uint8_t* base, const std::vector<BlockRef>& blocks, const HostUnit* units, std::vector<uint8_t>& out) {
     size_t k = 0;
     for (const BlockRef& b : blocks) {
         if (b.compressed) {
-            HostUnit& u = units[k++];
+            const HostUnit& u = units[k++];
             if (u.status) return u.status;
             out.insert(out.end(), u.out.begin(), u.out.end());
         } else {
@@ -50,6 +47,19 @@ int decode_independent(const uint8_t* base, const std::vector<BlockRef>& blocks,
         }
     }
     return SWC_OK;
+}
+// Decode `blocks` on the device in one batch and append to `out` in order.
+// Returns the first decode error in stream order, or SWC_OK / SWC_E_DEVICE.
+int decode_independent(const uint8_t* base, const std::vector<BlockRef>& blocks, const uint8_t* dict, size_t dict_len,
+                       bool have_dict, size_t max_block, std::vector<uint8_t>& out) {
+    std::vector<HostUnit> units;
+    units.reserve(blocks.size());
+    independent_units(base, blocks, dict, dict_len, have_dict, max_block, units);
+    if (!units.empty()) {
+        int st = run_units(SWC_CODEC_LZ4_BLOCK, units);
+        if (st) return st;
+    }
+    return independent_append(base, blocks, units.data(), out);
 }
 
 // process(legacyFrame:) :160-186; p points just after the magic.
@@ -73,29 +83,38 @@ int legacy_frame(const uint8_t* p, size_t n, std::vector<uint8_t>& out, size_t& 
     return SWC_OK;
 }
 
-// process(frame:_:_:) :188-330; p points just after the magic.
-int frame(const uint8_t* p, size_t n, const uint8_t* dict, size_t dict_len, bool have_dict, int64_t ext_dict_id,
-          std::vector<uint8_t>& out, size_t& adv) {
+// process(frame:_:_:) :188-330 in three steps: header + block discovery (host only), block decode, trailer checks.
+struct FrameInfo {
+    bool independent = false, content_size_present = false, content_checksum = false;
+    size_t max_block = 0;
+    uint64_t content_size = 0;
+    std::vector<BlockRef> blocks;
+    int framing = SWC_OK;   // framing error met during discovery: counts only once every block before it decoded cleanly
+    size_t off = 0;         // just past the last block / EndMark
+};
+
+// p points just after the magic.  Returns the header error, or SWC_OK with `fi` filled.
+int frame_parse(const uint8_t* p, size_t n, bool have_dict, int64_t ext_dict_id, FrameInfo& fi) {
     if (n < 7) return SWC_E_DATA_TRUNCATED;                                       // :191
     size_t off = 0;
     const uint32_t flg = p[off++];
     if (!(((flg & 0xC0) >> 6) == 1 && (flg & 0x02) == 0)) return SWC_E_DATA_CORRUPTED;  // :198
-    const bool independent = flg & 0x20, block_checksum = flg & 0x10, content_size_present = flg & 0x08,
-               content_checksum = flg & 0x04, dict_id_present = flg & 0x01;
-    size_t max_block;
+    const bool block_checksum = flg & 0x10, dict_id_present = flg & 0x01;
+    fi.independent = flg & 0x20;
+    fi.content_size_present = flg & 0x08;
+    fi.content_checksum = flg & 0x04;
     switch (p[off++]) {                                                           // :216-228
-        case 0x40: max_block = 64u << 10; break;
-        case 0x50: max_block = 256u << 10; break;
-        case 0x60: max_block = 1u << 20; break;
-        case 0x70: max_block = 4u << 20; break;
+        case 0x40: fi.max_block = 64u << 10; break;
+        case 0x50: fi.max_block = 256u << 10; break;
+        case 0x60: fi.max_block = 1u << 20; break;
+        case 0x70: fi.max_block = 4u << 20; break;
         default: return SWC_E_DATA_CORRUPTED;
     }
-    uint64_t content_size = 0;
-    if (content_size_present) {
+    if (fi.content_size_present) {
         if (n - off < 13) return SWC_E_DATA_TRUNCATED;                            // :234
-        for (int i = 0; i < 8; i++) content_size |= (uint64_t)p[off + i] << (8 * i);
+        for (int i = 0; i < 8; i++) fi.content_size |= (uint64_t)p[off + i] << (8 * i);
         off += 8;
-        if (content_size > (uint64_t)INT64_MAX) return SWC_E_DATA_UNSUPPORTED_FEATURE;  // :240
+        if (fi.content_size > (uint64_t)INT64_MAX) return SWC_E_DATA_UNSUPPORTED_FEATURE;  // :240
     }
     int64_t dict_id = -1;
     if (dict_id_present) {
@@ -109,38 +128,60 @@ int frame(const uint8_t* p, size_t n, const uint8_t* dict, size_t dict_len, bool
     off++;
 
     // block discovery
-    std::vector<BlockRef> blocks;
-    int framing = SWC_OK;
     for (;;) {
-        if (n - off < 4) { framing = SWC_E_DATA_TRUNCATED; break; }               // :279
+        if (n - off < 4) { fi.framing = SWC_E_DATA_TRUNCATED; break; }            // :279
         const uint32_t mark = le32(p + off);
         off += 4;
         if (mark == 0) break;                                                     // EndMark :284
         const size_t bs = mark & 0x7FFFFFFFu;
-        if (bs > max_block) { framing = SWC_E_DATA_CORRUPTED; break; }            // :292
-        if (n - off < bs + (block_checksum ? 4 : 0) + 4) { framing = SWC_E_DATA_TRUNCATED; break; }  // :295
+        if (bs > fi.max_block) { fi.framing = SWC_E_DATA_CORRUPTED; break; }      // :292
+        if (n - off < bs + (block_checksum ? 4 : 0) + 4) { fi.framing = SWC_E_DATA_TRUNCATED; break; }  // :295
         const size_t boff = off;
         off += bs;
         if (block_checksum) {
             const uint32_t c = le32(p + off);
             off += 4;
-            if (swc_xxh32(p + boff, bs, 0) != c) { framing = SWC_E_DATA_CORRUPTED; break; }  // :300
+            if (swc_xxh32(p + boff, bs, 0) != c) { fi.framing = SWC_E_DATA_CORRUPTED; break; }  // :300
         }
-        blocks.push_back({boff, bs, (mark & 0x80000000u) == 0});
+        fi.blocks.push_back({boff, bs, (mark & 0x80000000u) == 0});
     }
+    fi.off = off;
+    return SWC_OK;
+}
 
+// After the blocks were appended to out[start..): deferred framing error, content size and content checksum.
+int frame_tail(const uint8_t* p, size_t n, const FrameInfo& fi, const std::vector<uint8_t>& out, size_t start, size_t& adv) {
+    size_t off = fi.off;
+    if (fi.framing) return fi.framing;
+    if (fi.content_size_present && (uint64_t)(out.size() - start) != fi.content_size) return SWC_E_DATA_CORRUPTED;  // :320
+    if (fi.content_checksum) {
+        if (n - off < 4) return SWC_E_DATA_TRUNCATED;                             // :324
+        const uint32_t c = le32(p + off);
+        off += 4;
+        adv = off;
+        if (swc_xxh32(out.data() + start, out.size() - start, 0) != c) return SWC_E_DATA_CHECKSUM_MISMATCH;  // :326
+    }
+    adv = off;
+    return SWC_OK;
+}
+
+int frame(const uint8_t* p, size_t n, const uint8_t* dict, size_t dict_len, bool have_dict, int64_t ext_dict_id,
+          std::vector<uint8_t>& out, size_t& adv) {
+    FrameInfo fi;
+    int st = frame_parse(p, n, have_dict, ext_dict_id, fi);
+    if (st) return st;
     const size_t start = out.size();
-    if (independent) {
-        int st = decode_independent(p, blocks, dict, dict_len, have_dict, max_block, out);  // :305
+    if (fi.independent) {
+        st = decode_independent(p, fi.blocks, dict, dict_len, have_dict, fi.max_block, out);  // :305
         if (st) return st;
     } else {
         // Dependent blocks: block k references the last 64 KiB produced so far (:306-313) -- a serial chain.
-        for (const BlockRef& b : blocks) {
+        for (const BlockRef& b : fi.blocks) {
             if (!b.compressed) { out.insert(out.end(), p + b.off, p + b.off + b.len); continue; }
             HostUnit u;
             u.in = p + b.off;
             u.in_len = b.len;
-            u.cap_hint = max_block;
+            u.cap_hint = fi.max_block;
             const size_t produced = out.size() - start;
             std::vector<uint8_t> window;
             if (produced == 0 && have_dict) {
@@ -153,23 +194,13 @@ int frame(const uint8_t* p, size_t n, const uint8_t* dict, size_t dict_len, bool
                 u.dict = dl ? window.data() : reinterpret_cast<const uint8_t*>("");
                 u.dict_len = dl;
             }
-            int st = run_one(SWC_CODEC_LZ4_BLOCK, u);
+            st = run_one(SWC_CODEC_LZ4_BLOCK, u);
             if (st) return st;
             if (u.status) return u.status;
             out.insert(out.end(), u.out.begin(), u.out.end());
         }
     }
-    if (framing) return framing;
-    if (content_size_present && (uint64_t)(out.size() - start) != content_size) return SWC_E_DATA_CORRUPTED;  // :320
-    if (content_checksum) {
-        if (n - off < 4) return SWC_E_DATA_TRUNCATED;                             // :324
-        const uint32_t c = le32(p + off);
-        off += 4;
-        adv = off;
-        if (swc_xxh32(out.data() + start, out.size() - start, 0) != c) return SWC_E_DATA_CHECKSUM_MISMATCH;  // :326
-    }
-    adv = off;
-    return SWC_OK;
+    return frame_tail(p, n, fi, out, start, adv);
 }
 
 int skippable(const uint8_t* p, size_t n, size_t& adv) {                          // :148-155
@@ -181,6 +212,31 @@ int skippable(const uint8_t* p, size_t n, size_t& adv) {                        
 }
 
 }  // namespace
+
+// ---- many-archive batching (swc_unarchive_many): an archive that opens with a standard frame of independent blocks
+// contributes its blocks to a shared launch; everything else (skippable / legacy / dependent frames) is not batchable.
+struct Lz4Plan::Impl { FrameInfo fi; };
+Lz4Plan::Lz4Plan() : impl(new Impl) {}
+Lz4Plan::~Lz4Plan() { delete impl; }
+bool lz4_plan_prepare(const uint8_t* in, size_t n, Lz4Plan& plan, std::vector<HostUnit>& units) {
+    if (n < 4 || le32(in) != 0x184D2204u) return false;
+    plan.early_status = frame_parse(in + 4, n - 4, false, -1, plan.impl->fi);
+    if (plan.early_status) return true;                       // header error: final, no units
+    if (!plan.impl->fi.independent) return false;
+    plan.first_unit = units.size();
+    independent_units(in + 4, plan.impl->fi.blocks, nullptr, 0, false, plan.impl->fi.max_block, units);
+    return true;
+}
+int lz4_plan_finish(const uint8_t* in, size_t n, const Lz4Plan& plan, const std::vector<HostUnit>& units, std::vector<uint8_t>& res) {
+    if (plan.early_status) return plan.early_status;
+    int st = independent_append(in + 4, plan.impl->fi.blocks, units.data() + plan.first_unit, res);
+    if (st) { res.clear(); return st; }
+    size_t adv = 0;
+    st = frame_tail(in + 4, n - 4, plan.impl->fi, res, 0, adv);
+    if (st != SWC_OK && st != SWC_E_DATA_CHECKSUM_MISMATCH) res.clear();          // only checksumMismatch carries data
+    return st;
+}
+
 }  // namespace swc
 
 using namespace swc;

@@ -54,6 +54,8 @@ int multibyte(Reader& r, int64_t& v) {  // LittleEndianByteReader+XZ.swift:10-30
     return SWC_OK;
 }
 
+}  // namespace
+
 // Sum of the unpacked sizes announced by the chunk headers (LZMA2Decoder.swift:56-61,84-86) -- an exact
 // output capacity for well-formed streams, a hint otherwise.
 size_t lzma2_announced_size(const uint8_t* p, size_t n) {
@@ -78,6 +80,8 @@ size_t lzma2_announced_size(const uint8_t* p, size_t n) {
     }
     return total;
 }
+
+namespace {
 
 int run_lzma_unit(int codec, HostUnit& u) {
     int st = run_one(codec, u);

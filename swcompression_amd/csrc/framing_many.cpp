@@ -1,0 +1,278 @@
+// framing_many.cpp -- container callers that batch through the engine.
+//
+//   swc_unarchive_many        many independent archives of one kind: block discovery for ALL of them on the host, then
+//                             ONE batched launch, then the per-archive trailer checks in the reference's order.  The
+//                             reference handles such a set one archive (and, inside it, one block) after the other.
+//   swc_zip_get_entries_data  ZipContainer.getEntryData (reference Sources/ZIP/ZipContainer.swift:61-118) for every entry
+//                             of a container at once: each entry is an independent Deflate / BZip2 / LZMA stream whose
+//                             location and sizes the central directory already gave to the caller.
+#include <algorithm>
+#include <memory>
+#include <vector>
+#include "framing.h"
+
+namespace swc {
+namespace {
+
+inline uint32_t le32(const uint8_t* p) { return (uint32_t)p[0] | (uint32_t)p[1] << 8 | (uint32_t)p[2] << 16 | (uint32_t)p[3] << 24; }
+inline uint64_t le64(const uint8_t* p) { return (uint64_t)le32(p) | (uint64_t)le32(p + 4) << 32; }
+
+struct Result {
+    int status = SWC_OK;
+    std::vector<uint8_t> data;
+};
+
+void hand_over(const std::vector<Result>& res, uint8_t** outs, size_t* out_lens, int32_t* statuses) {
+    for (size_t i = 0; i < res.size(); i++) {
+        give(res[i].data, &outs[i], &out_lens[i]);
+        statuses[i] = res[i].status;
+    }
+}
+
+// kinds 1-3 and 7: one unit per archive
+int many_single_unit(int kind, const uint8_t* const* archives, const size_t* lens, size_t n, std::vector<Result>& res) {
+    const int codec = kind == 7 ? SWC_CODEC_LZMA2 : SWC_CODEC_DEFLATE;
+    std::vector<HostUnit> units;
+    std::vector<size_t> owner, data_pos;
+    for (size_t i = 0; i < n; i++) {
+        const uint8_t* d = archives[i];
+        const size_t len = lens[i];
+        HostUnit u;
+        size_t p = 0;
+        int st = SWC_OK;
+        switch (kind) {
+            case 1: st = gzip_member_prepare(d, len, 0, u); p = st ? 0 : (size_t)(u.in - d); break;   // GzipArchive.swift:38-48
+            case 2: st = zlib_parse_header(d, len, p); u.in = d + p; u.in_len = len - p; break;       // ZlibArchive.swift:25-31
+            case 3: u.in = d; u.in_len = len; break;                                                  // Deflate.swift:24-28
+            default:                                                                                  // LZMA2.swift:25-30
+                if (len < 1) { st = SWC_E_LZMA_RANGE_DECODER_INIT_ERROR; break; }
+                u.in = d + 1; u.in_len = len - 1; u.aux = d[0];
+                u.cap_hint = std::max<size_t>(lzma2_announced_size(d + 1, len - 1), 16);
+        }
+        if (st) { res[i].status = st; continue; }
+        units.push_back(std::move(u));
+        owner.push_back(i);
+        data_pos.push_back(p);
+    }
+    if (!units.empty()) {
+        int st = run_units(codec, units);
+        if (st) return st;
+    }
+    for (size_t k = 0; k < units.size(); k++) {
+        HostUnit& u = units[k];
+        Result& r = res[owner[k]];
+        const uint8_t* d = archives[owner[k]];
+        const size_t len = lens[owner[k]];
+        if (kind == 1) {
+            size_t next;
+            bool crc_error;
+            r.status = gzip_member_finish(d, len, data_pos[k], u, next, crc_error);
+            if (r.status) continue;
+            r.data = std::move(u.out);                                       // wrongCRC carries the member (:44)
+            if (crc_error) r.status = SWC_E_GZIP_WRONG_CRC;
+        } else if (kind == 2) {
+            if (u.status) { r.status = u.status; continue; }
+            const size_t q = data_pos[k] + u.in_consumed;
+            r.data = std::move(u.out);                                       // wrongAdler32 carries the data (:34,39)
+            if (len - q < 4) { r.status = SWC_E_ZLIB_WRONG_ADLER32; continue; }
+            const uint32_t stored = (uint32_t)d[q] << 24 | (uint32_t)d[q + 1] << 16 | (uint32_t)d[q + 2] << 8 | d[q + 3];
+            r.status = swc_adler32(r.data.data(), r.data.size()) == stored ? SWC_OK : SWC_E_ZLIB_WRONG_ADLER32;
+        } else {
+            r.status = u.status;
+            if (!u.status) r.data = std::move(u.out);
+        }
+    }
+    return SWC_OK;
+}
+
+// kind 4: LZ4.decompress(data:) per archive; archives that open with a frame of independent blocks share one launch
+int many_lz4(const uint8_t* const* archives, const size_t* lens, size_t n, std::vector<Result>& res) {
+    std::vector<HostUnit> units;
+    std::vector<std::unique_ptr<Lz4Plan>> plans(n);
+    for (size_t i = 0; i < n; i++) {
+        plans[i].reset(new Lz4Plan);
+        if (!lz4_plan_prepare(archives[i], lens[i], *plans[i], units)) plans[i].reset();
+    }
+    if (!units.empty()) {
+        int st = run_units(SWC_CODEC_LZ4_BLOCK, units);
+        if (st) return st;
+    }
+    for (size_t i = 0; i < n; i++) {
+        if (plans[i]) {
+            res[i].status = lz4_plan_finish(archives[i], lens[i], *plans[i], units, res[i].data);
+        } else {   // skippable / legacy / dependent-block frames: the single-archive path
+            uint8_t* o = nullptr;
+            size_t ol = 0, used = 0;
+            res[i].status = swc_lz4_decompress(archives[i], lens[i], nullptr, 0, -1, &o, &ol, &used);
+            if (res[i].status == SWC_E_DEVICE) { swc_free(o); return SWC_E_DEVICE; }
+            res[i].data.assign(o, o + ol);
+            swc_free(o);
+        }
+    }
+    return SWC_OK;
+}
+
+// kind 5: BZip2.decompress(data:) per archive; the candidate blocks of ALL streams share one launch
+int many_bzip2(const uint8_t* const* archives, const size_t* lens, size_t n, std::vector<Result>& res) {
+    std::vector<HostUnit> units;
+    std::vector<std::vector<uint64_t>> used(n);
+    std::vector<size_t> first(n);
+    for (size_t i = 0; i < n; i++) {
+        first[i] = units.size();
+        bzip2_collect_candidates(archives[i], lens[i], units, used[i]);
+    }
+    if (!units.empty()) {
+        int st = run_units(SWC_CODEC_BZIP2_BLOCK, units);
+        if (st) return st;
+    }
+    for (size_t i = 0; i < n; i++) {
+        size_t pos = 0;
+        res[i].status = bzip2_finish_stream(archives[i], lens[i], units, first[i], used[i], res[i].data, pos);
+        if (res[i].status == SWC_E_DEVICE) return SWC_E_DEVICE;
+        if (res[i].status != SWC_OK && res[i].status != SWC_E_BZIP2_WRONG_CRC) res[i].data.clear();   // only wrongCRC carries data
+    }
+    return SWC_OK;
+}
+
+// kind 6: XZArchive.unarchive per archive.  Block boundaries of an .xz stream are only known block by block (or from the
+// index at its end), so every archive takes the single-archive path: one launch per block.
+int many_xz(const uint8_t* const* archives, const size_t* lens, size_t n, std::vector<Result>& res) {
+    for (size_t i = 0; i < n; i++) {
+        uint8_t* o = nullptr;
+        size_t ol = 0;
+        res[i].status = swc_xz_unarchive(archives[i], lens[i], &o, &ol);
+        if (res[i].status == SWC_E_DEVICE) { swc_free(o); return SWC_E_DEVICE; }
+        res[i].data.assign(o, o + ol);
+        swc_free(o);
+    }
+    return SWC_OK;
+}
+
+}  // namespace
+}  // namespace swc
+
+using namespace swc;
+
+extern "C" {
+
+int swc_unarchive_many(int kind, const uint8_t* const* archives, const size_t* lens, size_t n,
+                       uint8_t** outs, size_t* out_lens, int32_t* statuses) {
+    if (kind < 1 || kind > 7 || (n && (!archives || !lens || !outs || !out_lens || !statuses))) return SWC_E_INVALID_ARGUMENT;
+    for (size_t i = 0; i < n; i++) if (lens[i] && !archives[i]) return SWC_E_INVALID_ARGUMENT;
+    if (!device_ready()) return SWC_E_DEVICE;
+    std::vector<Result> res(n);
+    int st;
+    switch (kind) {
+        case 4: st = many_lz4(archives, lens, n, res); break;
+        case 5: st = many_bzip2(archives, lens, n, res); break;
+        case 6: st = many_xz(archives, lens, n, res); break;
+        default: st = many_single_unit(kind, archives, lens, n, res);
+    }
+    if (st) return st;
+    hand_over(res, outs, out_lens, statuses);
+    return SWC_OK;
+}
+
+int swc_zip_get_entries_data(const uint8_t* container, size_t len, swc_zip_entry* entries, size_t n) {
+    if ((len && !container) || (n && !entries)) return SWC_E_INVALID_ARGUMENT;
+    if (!device_ready()) return SWC_E_DEVICE;
+    // ---- units per compression method (ZipContainer.swift:70-93)
+    std::vector<HostUnit> defl, lzma;
+    std::vector<size_t> defl_owner, lzma_owner;
+    std::vector<Result> res(n);
+    std::vector<size_t> real_comp(n, 0);
+    for (size_t i = 0; i < n; i++) {
+        swc_zip_entry& e = entries[i];
+        e.data = nullptr; e.data_len = 0; e.crc_error = 0; e.status = SWC_OK;
+        if (e.data_offset > len) { res[i].status = SWC_E_REF_TRAP; continue; }          // reader offset past the end: trap
+        const uint8_t* p = container + e.data_offset;
+        const size_t avail = len - (size_t)e.data_offset;
+        switch (e.method) {
+            case 0:                                                                     // .copy :70-71
+                if (e.uncomp_size > avail) { res[i].status = SWC_E_REF_TRAP; break; }   // bytes(count:) past the end
+                res[i].data.assign(p, p + e.uncomp_size);
+                real_comp[i] = (size_t)e.uncomp_size;
+                break;
+            case 8: {                                                                   // .deflate :72-78
+                HostUnit u;
+                u.in = p; u.in_len = avail;
+                if (e.uncomp_size <= (uint64_t)avail * 1100 + 4096) u.cap_hint = std::max<size_t>((size_t)e.uncomp_size, 64);
+                defl.push_back(std::move(u));
+                defl_owner.push_back(i);
+                break;
+            }
+            case 12: {                                                                  // .bzip2 :79-86 (one stream: its own discovery)
+                uint8_t* o = nullptr;
+                size_t ol = 0, used = 0;
+                int st = swc_bzip2_decompress(p, avail, &o, &ol, &used);
+                if (st == SWC_E_DEVICE) { swc_free(o); return SWC_E_DEVICE; }
+                if (st == SWC_OK) res[i].data.assign(o, o + ol);
+                swc_free(o);
+                res[i].status = st;                                                      // BZip2Error propagates (wrongCRC too: try, no catch)
+                real_comp[i] = used;
+                break;
+            }
+            case 14: {                                                                  // .lzma :87-89
+                if (avail < 9) { res[i].status = SWC_E_REF_TRAP; break; }               // 4 skipped bytes + properties: reads past the end trap
+                const uint32_t b = p[4];
+                if (b >= 225) { res[i].status = SWC_E_LZMA_WRONG_PROPERTIES; break; }   // LZMAProperties.swift:51
+                if (e.uncomp_size > (uint64_t)INT64_MAX) { res[i].status = SWC_E_REF_TRAP; break; }  // toInt() traps
+                HostUnit u;
+                u.in = p + 9; u.in_len = avail - 9;
+                u.aux = (int32_t)((b % 9) | (((b / 9) % 5) << 8) | (((b / 9) / 5) << 16));
+                u.extra = e.uncomp_size;
+                u.dict_value = le32(p + 5);
+                u.cap_hint = (size_t)e.uncomp_size + 16;
+                lzma.push_back(std::move(u));
+                lzma_owner.push_back(i);
+                break;
+            }
+            default: res[i].status = SWC_E_ZIP_COMPRESSION_NOT_SUPPORTED;               // :90-91
+        }
+    }
+    if (!defl.empty() && run_units(SWC_CODEC_DEFLATE, defl) != SWC_OK) return SWC_E_DEVICE;
+    if (!lzma.empty() && run_units(SWC_CODEC_LZMA, lzma) != SWC_OK) return SWC_E_DEVICE;
+    for (size_t k = 0; k < defl.size(); k++) {
+        const size_t i = defl_owner[k];
+        res[i].status = defl[k].status;
+        if (!defl[k].status) { res[i].data = std::move(defl[k].out); real_comp[i] = defl[k].in_consumed; }
+    }
+    for (size_t k = 0; k < lzma.size(); k++) {
+        const size_t i = lzma_owner[k];
+        res[i].status = lzma[k].status;
+        if (!lzma[k].status) { res[i].data = std::move(lzma[k].out); real_comp[i] = 9 + lzma[k].in_consumed; }
+    }
+    // ---- data descriptor, size and CRC checks (:94-117)
+    for (size_t i = 0; i < n; i++) {
+        swc_zip_entry& e = entries[i];
+        Result& r = res[i];
+        if (r.status == SWC_OK) {
+            uint64_t comp = e.comp_size, uncomp = e.uncomp_size;
+            uint32_t crc = e.crc32;
+            if (e.has_data_descriptor) {
+                size_t q = (size_t)e.data_offset + real_comp[i];
+                const size_t need = 4 + 4 + (e.zip64 ? 16 : 8);
+                if (len - q < 4) r.status = SWC_E_REF_TRAP;
+                else {
+                    if (le32(container + q) == 0x08074b50u) q += 4;                     // optional signature :98-101
+                    if (len < q || len - q < need - 4) r.status = SWC_E_REF_TRAP;
+                    else {
+                        crc = le32(container + q);
+                        if (e.zip64) { comp = le64(container + q + 4); uncomp = le64(container + q + 12); }
+                        else { comp = le32(container + q + 4); uncomp = le32(container + q + 8); }
+                    }
+                }
+            }
+            if (r.status == SWC_OK && !(comp == (uint64_t)real_comp[i] && uncomp == (uint64_t)r.data.size())) r.status = SWC_E_ZIP_WRONG_SIZE;  // :112-113
+            if (r.status == SWC_OK) e.crc_error = crc != swc_crc32(r.data.data(), r.data.size(), 0) ? 1 : 0;  // :114
+        }
+        e.status = r.status;
+        if (r.status != SWC_OK) r.data.clear();
+        size_t dl = 0;
+        give(r.data, &e.data, &dl);
+        e.data_len = dl;
+    }
+    return SWC_OK;
+}
+
+}  // extern "C"

@@ -194,3 +194,19 @@ def sha256(data):
     buf = C.create_string_buffer(32)
     lib.refcpu_sha256(bytes(data), len(data), buf)
     return buf.raw
+
+
+lib.refcpu_zip_get_entry_data.argtypes = [C.c_char_p, C.c_size_t, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint32, C.c_int, C.c_int,
+                                          C.c_int, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t), C.POINTER(C.c_int)]
+lib.refcpu_zip_get_entry_data.restype = C.c_int
+
+
+def zip_entry(container, h):
+    """ZipContainer.getEntryData for one entry helper (dict as produced by swcompression_amd.zipcontainer.ZipContainer.helpers).
+    Returns (status, crc_error, data)."""
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    ce = C.c_int()
+    st = lib.refcpu_zip_get_entry_data(bytes(container), len(container), h["data_offset"], h["comp_size"], h["uncomp_size"], h["crc32"],
+                                       h["method"], int(h["has_data_descriptor"]), int(h["zip64"]), C.byref(out), C.byref(n), C.byref(ce))
+    return st, bool(ce.value), _take(out, n.value)

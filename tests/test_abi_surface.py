@@ -11,6 +11,7 @@ import pytest
 
 import swcompression_amd as swc
 from swcompression_amd import _lib, corpus
+from swcompression_amd.zipcontainer import ZipContainer
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
@@ -62,6 +63,15 @@ def test_code_object_is_gfx950_only():
         assert other not in blob
 
 
+def _one_entry_zip(x):
+    import io
+    import zipfile
+    b = io.BytesIO()
+    with zipfile.ZipFile(b, "w", compression=zipfile.ZIP_DEFLATED) as z:
+        z.writestr("x.txt", x)
+    return b.getvalue()
+
+
 @pytest.mark.skipif(swc.device_available(), reason="GPU present: covered by the gpu tier")
 def test_no_cpu_fallback_without_gpu():
     x = corpus.p_text(1000, 1)
@@ -73,6 +83,9 @@ def test_no_cpu_fallback_without_gpu():
         lambda: swc.LZMA.decompress(corpus.lzma_alone(x)),
         lambda: swc.XZArchive.unarchive(corpus.xz_stream(x)),
         lambda: swc.LZ4.decompress(corpus.lz4_frame(x)),
+        lambda: swc.unarchive_many("gzip", [corpus.gzip_member(x)]),
+        lambda: swc.unarchive_many("bzip2", [corpus.bzip2_stream(x)]),
+        lambda: ZipContainer.open(_one_entry_zip(x)),
     ]
     for c in calls:
         with pytest.raises(swc.DeviceError):

@@ -1,0 +1,126 @@
+"""GPU tier: the container callers that batch through the engine -- swc_unarchive_many for every
+archive kind and swc_zip_get_entries_data -- against the oracle's single-archive restatements of the reference."""
+import struct
+import zipfile
+
+import pytest
+
+import _oracle as O
+import _streams as S
+import _zips as Z
+import swcompression_amd as swc
+from swcompression_amd import corpus
+from swcompression_amd.zipcontainer import ZipContainer
+
+pytestmark = pytest.mark.gpu
+
+
+def _payloads(seed, k=12):
+    sizes = [0, 1, 100, 5000, 65536, 70001, 300000, 17, 4096, 1 << 20, 33333, 250000]
+    return [corpus.p_mix(sizes[i % len(sizes)], seed + i) for i in range(k)]
+
+
+def _damage(b, at=None):
+    d = bytearray(b)
+    d[len(d) // 2 if at is None else at] ^= 0x20
+    return bytes(d)
+
+
+def _check(kind, archives, oracle_fn, carries):
+    got = swc.unarchive_many(kind, archives)
+    assert len(got) == len(archives)
+    for i, (a, (st, data)) in enumerate(zip(archives, got)):
+        est, edata = oracle_fn(a)[:2]
+        assert st == est, "%s archive %d: status %d, oracle %d" % (kind, i, st, est)
+        if est == 0 or est in carries:
+            assert data == edata, "%s archive %d differs" % (kind, i)
+        else:
+            assert data == b""
+
+
+def test_many_gzip_members():
+    ps = _payloads(100)
+    arch = [corpus.gzip_member(p, bgzf=(i % 3 == 0 and len(p) < 60000)) for i, p in enumerate(ps)]
+    arch += [_damage(arch[4]), arch[5][:-3], _damage(arch[6], at=len(arch[6]) - 6), b"", b"\x1f\x8b\x08"]
+    _check("gzip", arch, O.gzip_unarchive, {605})
+
+
+def test_many_zlib_and_raw_deflate():
+    ps = _payloads(200)
+    z = [corpus.zlib_stream(p) for p in ps]
+    z += [_damage(z[4]), z[5][:-2], _damage(z[6], at=len(z[6]) - 2), b"\x78"]
+    _check("zlib", z, O.zlib_unarchive, {705})
+    r = [corpus.deflate_raw(p) for p in ps]
+    r += [_damage(r[4]), r[6][:len(r[6]) // 2], b""]
+    _check("deflate", r, O.deflate, set())
+
+
+def test_many_lzma2():
+    ps = _payloads(300, 8)
+    a = [bytes([corpus.lzma2_dict_byte(1 << 20)]) + corpus.lzma2_raw(p) for p in ps]
+    a += [_damage(a[4]), a[5][:len(a[5]) // 2], b"", b"\x29"]
+    _check("lzma2", a, O.lzma2_data, set())
+
+
+def test_many_lz4_frames():
+    O.lib.refcpu_set_max_output(1 << 24)
+    a = [f for _, f, d, _ in S.lz4_frames() if d is None]
+    a += [corpus.lz4f_frame(p, 4 + i % 4, False, i % 2 == 0, i % 3 == 0, i % 5 == 0) for i, p in enumerate(_payloads(400, 10))]
+    a += [_damage(a[-1]), a[-2][:len(a[-2]) - 5], _damage(a[-3], at=len(a[-3]) - 2), b"", b"\x04\x22\x4d\x18"]
+    _check("lz4", a, O.lz4, {503})
+
+
+def test_many_bzip2_streams():
+    ps = _payloads(500, 8)
+    a = [corpus.bzip2_stream(p, level=1 + i % 9) for i, p in enumerate(ps)]
+    a.append(corpus.bzip2_stream(corpus.p_text(450000, 77), level=1))   # several blocks
+    a += [_damage(a[4]), a[5][:len(a[5]) - 7], b"BZh9", b""]
+    _check("bzip2", a, O.bzip2, {210})
+
+
+def test_many_xz():
+    ps = _payloads(600, 6)
+    a = [corpus.xz_stream(p) for p in ps]
+    a += [_damage(a[3]), a[4][:-5]]
+    _check("xz", a, O.xz_unarchive, {807})
+
+
+@pytest.mark.parametrize("method", [zipfile.ZIP_STORED, zipfile.ZIP_DEFLATED, zipfile.ZIP_BZIP2, zipfile.ZIP_LZMA])
+@pytest.mark.parametrize("streamed", [False, True])
+def test_zip_open_matches_zipfile_and_oracle(method, streamed):
+    c = Z.make_zip(method, streamed=streamed, seed=21)
+    assert ZipContainer.open(c) == Z.reference_extract(c)
+    files = [h for h in ZipContainer.helpers(c) if not h["is_dir"]]
+    assert ZipContainer.entries_data(c, files) == [O.zip_entry(c, h) for h in files]
+
+
+def test_zip_mixed_methods_one_call():
+    c = Z.mixed_zip(seed=31)
+    assert ZipContainer.open(c) == Z.reference_extract(c)
+
+
+def test_zip_damaged_entries_match_oracle():
+    c = Z.make_zip(zipfile.ZIP_DEFLATED, seed=22, with_dir=False)
+    hs = ZipContainer.helpers(c)
+    h = hs[2]
+    variants = [dict(h, crc32=h["crc32"] ^ 1), dict(h, uncomp_size=h["uncomp_size"] + 1), dict(h, comp_size=h["comp_size"] - 1),
+                dict(h, method=9), dict(h, data_offset=len(c) + 5), dict(h, uncomp_size=5), dict(hs[4], uncomp_size=1 << 40)]
+    assert ZipContainer.entries_data(c, variants) == [O.zip_entry(c, v) for v in variants]
+    dmg = bytearray(c)
+    dmg[h["data_offset"] + 40] ^= 0x10
+    assert ZipContainer.entries_data(bytes(dmg), hs) == [O.zip_entry(bytes(dmg), x) for x in hs]
+    lz = Z.make_zip(zipfile.ZIP_LZMA, seed=23, with_dir=False)
+    hl = ZipContainer.helpers(lz)
+    dl = bytearray(lz)
+    dl[hl[2]["data_offset"] + 4] = 230      # invalid LZMA properties byte
+    dl[hl[3]["data_offset"] + 60] ^= 0x08
+    assert ZipContainer.entries_data(bytes(dl), hl) == [O.zip_entry(bytes(dl), x) for x in hl]
+    # ZipContainer.open raises wrongCRC carrying the entries so far (ZipContainer.swift:52-53)
+    bad = bytearray(c)
+    cd = bad.rfind(b"PK\x01\x02")
+    struct.pack_into("<I", bad, cd + 16, 0x12345678)     # CRC-32 of the LAST entry in its central-directory record ...
+    lh = hs[-1]["data_offset"] - 30 - len(hs[-1]["name"])
+    struct.pack_into("<I", bad, lh + 14, 0x12345678)     # ... and in its local header
+    with pytest.raises(swc.ZipError) as ei:
+        ZipContainer.open(bytes(bad))
+    assert ei.value.status == 853 and len(ei.value.data) == len(hs)
