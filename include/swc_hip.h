@@ -188,6 +188,11 @@ int swc_set_tuning(const char* key, int value);
  * (entropy decode, LZ77 resolve).  Returns the number of values written (0 if none). */
 int swc_last_phase_ms(float* ms, int cap);
 
+/* Process-wide launch statistics of the host framing layer (monotonic, for tests and tuning): "launches" = batched
+ * launches issued by the single-shot / many-archive entry points, "units" = units decoded by them, "xz_cache_hits" =
+ * .xz blocks the sequential walk took from the index-driven ahead-of-time batch.  Unknown key: -1. */
+long long swc_stat(const char* key);
+
 #ifdef __cplusplus
 }
 #endif

@@ -3,6 +3,7 @@
 // decode path in this library: without a usable gfx950 device every decode entry point returns
 // SWC_E_DEVICE.
 #include <algorithm>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -52,6 +53,9 @@ static size_t default_cap(int codec, const HostUnit& u) {
         default: return std::max<size_t>(1 << 20, u.in_len * 8);
     }
 }
+
+static std::atomic<long long> g_stats[3];
+void stat_add(int which, long long v) { if (which >= 0 && which < 3) g_stats[which] += v; }
 
 int run_units(int codec, std::vector<HostUnit>& units) {
     if (!device_ready()) return SWC_E_DEVICE;
@@ -105,6 +109,8 @@ int run_units(int codec, std::vector<HostUnit>& units) {
         if (hipMemcpy(d_in.ptr(), stage.data(), in_total, hipMemcpyHostToDevice) != hipSuccess) return SWC_E_DEVICE;
         if (hipMemcpy(d_jobs.ptr(), jobs.data(), m * sizeof(Job), hipMemcpyHostToDevice) != hipSuccess) return SWC_E_DEVICE;
         if (launch_codec(codec, static_cast<Job*>(d_jobs.ptr()), m, d_ws.ptr(), ws_bytes, nullptr) != hipSuccess) return SWC_E_DEVICE;
+        stat_add(0, 1);
+        stat_add(1, (long long)m);
         if (hipDeviceSynchronize() != hipSuccess) return SWC_E_DEVICE;
         if (hipMemcpy(jobs.data(), d_jobs.ptr(), m * sizeof(Job), hipMemcpyDeviceToHost) != hipSuccess) return SWC_E_DEVICE;
         std::vector<uint8_t> out_stage(out_total + 16);
@@ -161,6 +167,14 @@ int swc_set_tuning(const char* key, int value) {
     if (!strcmp(key, "resolve_debug") && value >= 0 && value < 32) { set_resolve_debug(value); return SWC_OK; }
 #endif
     return SWC_E_INVALID_ARGUMENT;
+}
+
+long long swc_stat(const char* key) {
+    if (!key) return -1;
+    if (!strcmp(key, "launches")) return g_stats[0].load();
+    if (!strcmp(key, "units")) return g_stats[1].load();
+    if (!strcmp(key, "xz_cache_hits")) return g_stats[2].load();
+    return -1;
 }
 
 int swc_last_phase_ms(float* ms, int cap) { return ms ? last_phase_ms(ms, cap) : 0; }

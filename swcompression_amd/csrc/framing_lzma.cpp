@@ -9,6 +9,7 @@
 //   DeltaFilter.decode      reference Sources/Common/DeltaFilter.swift:11-33
 // Headers, index, footer, padding and checks are verified on the host; every LZMA2 block body is a
 // unit of the batched device launch.
+#include <map>
 #include <vector>
 #include "framing.h"
 
@@ -104,9 +105,17 @@ void delta_decode(const std::vector<uint8_t>& in, int distance, std::vector<uint
 
 struct Filter { int id; int prop; };
 
+// Blocks decoded ahead of the sequential walk (xz_predecode below): key = offset of the LZMA2 data in the archive.
+struct Predecoded {
+    int prop;
+    std::vector<uint8_t> out;
+    size_t in_consumed;
+};
+typedef std::map<int64_t, Predecoded> BlockCache;
+
 // XZBlock.init (XZBlock.swift:18-97).  Appends the block's data to `out`.
 int xz_block(uint32_t header_size_byte, Reader& r, int check_size, std::vector<uint8_t>& out, int64_t& unpadded_size,
-             int64_t& uncomp_size) {
+             int64_t& uncomp_size, BlockCache* cache) {
     int st;
     const int64_t header_start = r.off - 1;
     const int64_t real_header_size = ((int64_t)header_size_byte + 1) * 4;
@@ -152,7 +161,14 @@ int xz_block(uint32_t header_size_byte, Reader& r, int check_size, std::vector<u
     bool have_cur = false;
     for (int i = filters_count - 1; i >= 0; i--) {
         std::vector<uint8_t> next;
-        if (filters[i].id == 0x21) {
+        BlockCache::iterator hit;
+        if (filters[i].id == 0x21 && !have_cur && cache && (hit = cache->find(r.off)) != cache->end() && hit->second.prop == filters[i].prop) {
+            // decoded ahead from exactly these bytes, cleanly: the same result the launch below would produce
+            r.off += (int64_t)hit->second.in_consumed;
+            next = std::move(hit->second.out);
+            cache->erase(hit);
+            stat_add(2, 1);
+        } else if (filters[i].id == 0x21) {
             HostUnit u;
             u.in = have_cur ? cur.data() : r.d + r.off;
             u.in_len = have_cur ? cur.size() : (size_t)(r.n - r.off);
@@ -189,7 +205,7 @@ int xz_block(uint32_t header_size_byte, Reader& r, int check_size, std::vector<u
 }
 
 // processStream (XZArchive.swift:90-130)
-int xz_stream(Reader& r, std::vector<uint8_t>& out, bool& check_error) {
+int xz_stream(Reader& r, std::vector<uint8_t>& out, bool& check_error, BlockCache* cache) {
     static const uint8_t magic[6] = {0xFD, 0x37, 0x7A, 0x58, 0x5A, 0x00};
     check_error = false;
     if (r.left() < 12) return SWC_E_REF_TRAP;
@@ -244,7 +260,7 @@ int xz_stream(Reader& r, std::vector<uint8_t>& out, bool& check_error) {
         }
         int64_t unpadded, uncomp;
         const size_t bstart = out.size();
-        if ((st = xz_block(hs, r, check_size, out, unpadded, uncomp))) return st;
+        if ((st = xz_block(hs, r, check_size, out, unpadded, uncomp, cache))) return st;
         const uint8_t* bd = out.data() + bstart;
         const size_t bl = out.size() - bstart;
         if (check_type == 0x01) {
@@ -299,13 +315,83 @@ int xz_padding(Reader& r) {                                                     
     return SWC_OK;
 }
 
+// Index-driven block discovery (XZArchive.swift:132-192 read backwards): an .xz stream ends with
+// footer <- index, and the index lists every block's unpadded and uncompressed size, so all blocks of all streams of the
+// archive can be located without decoding anything.  Every block whose only filter is LZMA2 is decoded in ONE batched
+// launch from exactly the bytes the index assigns to it; a result is kept only if it decoded cleanly (then it cannot
+// depend on the bytes behind the block), and the sequential walk below -- which alone decides what the archive means --
+// picks it up when it arrives at the same offset with the same dictionary byte.  Anything inconsistent simply yields
+// no cache entry.
+void xz_predecode(const uint8_t* d, size_t n, BlockCache& cache) {
+    struct Cand { int64_t data_off; size_t len; int prop; };
+    std::vector<Cand> cands;
+    int64_t end = (int64_t)n;
+    for (int streams = 0; streams < 4096 && end >= 32; streams++) {
+        while (end >= 4 && d[end - 1] == 0 && d[end - 2] == 0 && d[end - 3] == 0 && d[end - 4] == 0) end -= 4;   // stream padding
+        if (end < 32 || d[end - 2] != 0x59 || d[end - 1] != 0x5A) break;                      // "YZ"
+        const int64_t backward = ((int64_t)((uint32_t)d[end - 8] | (uint32_t)d[end - 7] << 8 | (uint32_t)d[end - 6] << 16 | (uint32_t)d[end - 5] << 24) + 1) * 4;
+        const int check_type = d[end - 3] & 0x0F;
+        const int check_size = check_type == 0 ? 0 : check_type == 1 ? 4 : check_type == 4 ? 8 : check_type == 10 ? 32 : -1;
+        const int64_t index_start = end - 12 - backward;
+        if (check_size < 0 || index_start < 12 || d[index_start] != 0) break;
+        Reader r{d, (size_t)(end - 12), index_start + 1, false};
+        int64_t records;
+        if (multibyte(r, records) || records < 0 || records > (1 << 20)) break;
+        std::vector<std::pair<int64_t, int64_t>> recs;
+        bool ok = true;
+        int64_t total = 0;
+        for (int64_t k = 0; k < records && ok; k++) {
+            int64_t a, b;
+            ok = !multibyte(r, a) && !multibyte(r, b) && a > 0 && a < ((int64_t)1 << 40);
+            if (ok) { recs.emplace_back(a, b); total += (a + 3) & ~(int64_t)3; }
+        }
+        const int64_t stream_start = index_start - total - 12;
+        if (!ok || stream_start < 0) break;
+        int64_t pos = stream_start + 12;
+        for (auto& rc : recs) {
+            const int64_t hsize = ((int64_t)d[pos] + 1) * 4;
+            const int64_t comp = rc.first - hsize - check_size;
+            // a header this code understands: one filter, LZMA2 with one property byte, optional size fields
+            if (d[pos] != 0 && comp > 0 && pos + rc.first <= index_start && (d[pos + 1] & 0x3F) == 0) {
+                Reader h{d, (size_t)(pos + hsize), pos + 2, false};
+                int64_t tmp, id, ps;
+                bool good = true;
+                if (d[pos + 1] & 0x40) good = good && !multibyte(h, tmp);
+                if (d[pos + 1] & 0x80) good = good && !multibyte(h, tmp);
+                good = good && !multibyte(h, id) && id == 0x21 && !multibyte(h, ps) && ps == 1;
+                const int prop = h.u8();
+                if (good && !h.trap) cands.push_back({pos + hsize, (size_t)comp, prop});
+            }
+            pos += (rc.first + 3) & ~(int64_t)3;
+        }
+        end = stream_start;
+    }
+    if (cands.size() < 2) return;            // a single block gains nothing from being decoded ahead
+    std::vector<HostUnit> units(cands.size());
+    for (size_t k = 0; k < cands.size(); k++) {
+        HostUnit& u = units[k];
+        u.in = d + cands[k].data_off;
+        u.in_len = cands[k].len;
+        u.aux = cands[k].prop;
+        u.cap_hint = std::max<size_t>(lzma2_announced_size(u.in, u.in_len), 16);
+    }
+    if (run_units(SWC_CODEC_LZMA2, units) != SWC_OK) return;
+    for (size_t k = 0; k < cands.size(); k++) {
+        if (units[k].status != SWC_OK) continue;
+        cache[cands[k].data_off] = Predecoded{cands[k].prop, std::move(units[k].out), units[k].in_consumed};
+    }
+}
+
 int xz_run(const uint8_t* in, size_t in_len, std::vector<uint8_t>& all, std::vector<size_t>& sizes) {
+    BlockCache cache_store;
+    xz_predecode(in, in_len, cache_store);
+    BlockCache* cache = &cache_store;
     Reader r{in, in_len, 0, false};
     while (!r.finished()) {
         if (r.left() < 32) { all.clear(); sizes.clear(); return SWC_E_XZ_WRONG_MAGIC; }  // :37
         bool check_error;
         const size_t start = all.size();
-        int st = xz_stream(r, all, check_error);
+        int st = xz_stream(r, all, check_error, cache);
         if (st) { all.clear(); sizes.clear(); return st; }
         sizes.push_back(all.size() - start);
         if (check_error) return SWC_E_XZ_WRONG_CHECK;                             // :44 carries the result so far

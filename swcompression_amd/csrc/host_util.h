@@ -67,5 +67,8 @@ struct HostUnit {
 // SWC_E_CAPACITY with a larger buffer), fetch the results.  Returns SWC_OK or SWC_E_DEVICE.
 int run_units(int codec, std::vector<HostUnit>& units);
 
+// swc_stat counters (api.cpp)
+void stat_add(int which, long long v);   // 0 launches, 1 units, 2 xz_cache_hits
+
 }  // namespace swc
 #endif

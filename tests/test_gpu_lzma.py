@@ -122,6 +122,54 @@ def test_xz_archives():
             assert ei.value.status == st
 
 
+def _xz_multiblock(payload, block_size=65536, check="crc64"):
+    """`xz --block-size` output: ONE stream with many independent blocks, located through the index."""
+    import shutil
+    import subprocess
+    if shutil.which("xz") is None:
+        pytest.skip("xz command not available")
+    return subprocess.run(["xz", "-z", "-c", "-T1", "--block-size=%d" % block_size, "--check=" + check], input=payload,
+                          stdout=subprocess.PIPE, check=True).stdout
+
+
+def test_xz_multi_block_index_driven_discovery():
+    """SURVEY 8d config 5 variant / 8f row 2: the blocks of an `xz --block-size` stream are found through the index and
+    decoded in one launch; the sequential walk then consumes them.  Damaged archives must behave exactly like the oracle's
+    strictly sequential restatement of XZArchive.swift:90-192."""
+    x = corpus.p_text(900000, 8)
+    from swcompression_amd import _lib
+    lib = _lib.load()
+    for chk in ("none", "crc32", "crc64", "sha256"):
+        a = _xz_multiblock(x, 65536, chk)
+        assert O.xz_unarchive(a) == (0, x)
+        hits, launches = lib.swc_stat(b"xz_cache_hits"), lib.swc_stat(b"launches")
+        assert swc.XZArchive.unarchive(a) == x
+        assert lib.swc_stat(b"xz_cache_hits") - hits == 14          # ceil(900000 / 65536) blocks, all taken from the batch
+        assert lib.swc_stat(b"launches") - launches <= 2            # one launch (plus at most one capacity retry), not 14
+    a = _xz_multiblock(x, 131072)
+    two = a + b"\0" * 4 + _xz_multiblock(x[:300000], 32768, "crc32") + lzma.compress(x[:10])
+    assert swc.XZArchive.split_unarchive(two) == [x, x[:300000], x[:10]]
+    rnd = random.Random(11)
+    for k in range(40):
+        b2 = bytearray(a)
+        r = rnd.random()
+        if r < 0.25:
+            b2 = b2[:rnd.randrange(1, len(b2))]
+        elif r < 0.5:
+            b2[len(b2) - 1 - rnd.randrange(60)] ^= 1 << rnd.randrange(8)      # footer / index
+        else:
+            b2[rnd.randrange(len(b2))] ^= 1 << rnd.randrange(8)
+        st, out = O.xz_unarchive(bytes(b2))
+        if st == 0:
+            assert swc.XZArchive.unarchive(bytes(b2)) == out
+        else:
+            with pytest.raises(swc.SWCError) as ei:
+                swc.XZArchive.unarchive(bytes(b2))
+            assert ei.value.status == st, "variant %d" % k
+            if st == 807:
+                assert ei.value.data == out
+
+
 def test_config5_shape_many_256k_units():
     """BASELINE.json config 5 shape at reduced count: independent raw-LZMA2 units of 256 KiB (one 0xE0 chunk each)."""
     units, plains = corpus.build_units("lzma2", 256, 262144)
