@@ -9,10 +9,19 @@
 //            limit compares, the MTF list shift, run fills and L stores are spread over the lanes.
 //   stage 2  one block per WAVEFRONT  stable counting-sort scatter  P[base[c]++] = i << 8 | c  (c = L[i]),
 //            each lane owning a contiguous slice of i (per-lane counters in LDS).
-//   stage 3  one block per LANE       the n dependent gathers  v = P[end]; end = v >> 8; byte = v & 255,
-//            fused with the RLE1 undo (4 equal bytes + count, BZip2.swift:251-267), the MSB-first CRC-32
-//            and the output stores.  n random 4-byte loads per block cannot be parallelised within a block
-//            (single permutation cycle); throughput comes from thousands of blocks in flight.
+//   stage 3a one block per WAVEFRONT  the n dependent gathers  v = P[end]; end = v >> 8; byte = v & 255  form ONE cycle
+//            through the block, which a single walker can only follow at one HBM round trip per byte (measured: 17 G
+//            gathers/s with a lane per block, 46-59 G/s -- the HBM row-activation limit -- with 64+ walkers per block,
+//            tools/micro/gather_bench.hip).  So the cycle is CUT at marked indices (multiples of M, and origPtr): every
+//            lane walks segments from a mark to the next mark, keeping the bytes it meets in the segment's buffer; the
+//            <= 513 segments are then put in cycle order by following segment -> next segment from origPtr, which gives
+//            every segment its offset in the block, and the buffers are copied to their places (segments longer than
+//            their buffer are walked a second time).  A permutation that is not one n-cycle (damaged input) falls back
+//            to the serial walk in stage 3b.
+//   stage 3b one block per LANE       RLE1 undo (4 equal bytes + count, BZip2.swift:251-267) over the walked bytes, output
+//            stores, capacity accounting.
+//   stage 3c one block per WORKGROUP  MSB-first CRC-32 of the output (crc32_group.h) and the comparison with the stored
+//            block CRC (BZip2.swift:81).
 //
 // Reference semantics kept: lengths 0..20 accepted and never validated (App. A B2), surplus selectors
 // ignored / too few => wrongSelector (B3), origPtr unchecked => trap (B4), block size not enforced (B5),
@@ -46,7 +55,11 @@ struct Stage1Lds {
 };
 constexpr int kStage1LdsBytes = (sizeof(Stage1Lds) + 15) / 16 * 16;
 
-// workspace per job (HBM): L[lcap] | selectors[32768] | P[lcap] (u32) | header
+constexpr uint32_t kSegs = 512;        // stage 3a: regular segments per block (+1 for origPtr)
+constexpr uint32_t kSegCapFactor = 3;  // a segment's buffer holds 3 x the mean segment length (5 % are longer)
+constexpr int kParts = 64;             // stage 3a: the RLE1 undo of a block is cut into this many parts
+
+// workspace per job (HBM): L[lcap] (stage 3: the walked bytes T) | selectors[32768] | P[lcap] (u32) | header | segment buffers
 struct BlockHeader {   // stage 1 -> stage 2/3
     uint32_t n;        // length of L
     uint32_t orig_ptr;
@@ -55,12 +68,30 @@ struct BlockHeader {   // stage 1 -> stage 2/3
     uint64_t end_bit;  // absolute bit position just past the block's EOB symbol
     uint32_t counts[256];
 };
-SWC_HD size_t ws_bytes_per_job(size_t lcap) { return ((lcap + 15) & ~(size_t)15) + 32768 + lcap * 4 + sizeof(BlockHeader) + 64; }
+// stage 3a -> 3b, kept in BlockHeader::pad
+constexpr uint32_t kWalkNone = 0;     // nothing walked: stage 3b does the serial walk itself
+constexpr uint32_t kWalkReady = 1;    // L[0..n) holds the bytes in cycle order (only while stage 3a runs)
+constexpr uint32_t kWalkDone = 2;     // stage 3a also undid RLE1: output, out_len and status are final up to the CRC
+// segment geometry for a block of n bytes: marks at multiples of 1 << mbits, at most kSegs of them
+SWC_HD uint32_t seg_mbits(uint32_t n) {
+    uint32_t m = 0;
+    while (((n + (1u << m) - 1) >> m) > kSegs) m++;
+    return m;
+}
+SWC_HD size_t segbuf_bytes(size_t lcap) {   // (regular segments + 1) x capacity, for the largest n = lcap
+    const uint32_t m = seg_mbits((uint32_t)lcap);
+    const size_t regs = (lcap + ((size_t)1 << m) - 1) >> m;
+    return (regs + 1) * ((size_t)kSegCapFactor << m) + 64;
+}
+SWC_HD size_t ws_bytes_per_job(size_t lcap) {
+    return ((lcap + 15) & ~(size_t)15) + 32768 + lcap * 4 + sizeof(BlockHeader) + 64 + ((segbuf_bytes(lcap) + 15) & ~(size_t)15);
+}
 struct Workspace {
     gptr L;
     gptr selectors;
     SWC_AS_GLOBAL uint32_t* P;
     SWC_AS_GLOBAL BlockHeader* hdr;
+    gptr segbuf;
     size_t lcap;
 };
 SWC_HD Workspace carve(uint8_t* base, size_t job, size_t lcap) {
@@ -71,6 +102,7 @@ SWC_HD Workspace carve(uint8_t* base, size_t job, size_t lcap) {
     w.selectors = (gptr)(p + lpad);
     w.P = (SWC_AS_GLOBAL uint32_t*)(p + lpad + 32768);
     w.hdr = (SWC_AS_GLOBAL BlockHeader*)(p + lpad + 32768 + lcap * 4);
+    w.segbuf = (gptr)(p + ((lpad + 32768 + lcap * 4 + sizeof(BlockHeader) + 64 + 15) & ~(size_t)15));
     w.lcap = lcap;
     return w;
 }
@@ -412,56 +444,254 @@ SWC_HD void stage2_job(Workspace ws, uint32_t* cnt, int lane) {
     }
 }
 
-// MSB-first CRC-32 table (CheckSums.swift:95-127 holds the same 256 constants)
-SWC_HD uint32_t crc_table_entry(uint32_t i) {
-    uint32_t b = i << 24;
-    for (int k = 0; k < 8; k++) b = (b & 0x80000000u) ? (b << 1) ^ 0x04C11DB7u : b << 1;
-    return b;
+// ---- stage 3a: cut the cycle, walk the pieces, order them, lay the bytes out in L -------------------------------------
+struct Stage3Lds {
+    uint32_t len[kSegs + 1];    // bytes of segment s
+    uint32_t next[kSegs + 1];   // segment that starts where s ends
+    uint32_t off[kSegs + 1];    // position of segment s in the block
+    uint32_t ticket;            // next segment to hand out
+    uint32_t bad;
+    uint32_t part_at[kParts + 1];   // RLE1 undo: part j covers T[part_at[j] .. part_at[j + 1])
+    uint64_t part_out[kParts + 1];  // ... and produces out[part_out[j] .. part_out[j + 1])
+};
+constexpr int kStage3LdsBytes = (sizeof(Stage3Lds) + 15) / 16 * 16;
+
+SWC_HD uint32_t take_ticket(uint32_t* t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(t, 1u);
+#else
+    return (*t)++;
+#endif
 }
 
-// Stage 3: one block per lane.  `crc_tab` = 256-entry table (LDS on device).
-// job.dict (as integer) = stored block CRC.
-SWC_HD void stage3_job(Job& job, Workspace ws, const uint32_t* crc_tab) {
+// RLE1 undo (BZip2.swift:251-267) as a state machine over the walked bytes T: `run` = equal literals so far (1..4), 0 right
+// after a count byte.  Feed one byte, get the number of output bytes it stands for (1 for a literal, its value for a count).
+struct Rle1 {
+    uint32_t run, prev;
+    SWC_HD uint32_t feed(uint32_t b, bool& is_count) {
+        if (run == 4) { run = 0; is_count = true; return b; }
+        is_count = false;
+        run = (run > 0 && b == prev) ? run + 1 : 1;
+        prev = b;
+        return 1;
+    }
+};
+// Where may a part start?  At p with T[p-3] != T[p-2] != T[p-1]: whatever T[p-2] was (literal or count), T[p-1] is then a
+// literal that starts a run, so the state in front of p is (run 1, prev T[p-1]) -- no history needed.
+SWC_HD uint32_t first_safe_start(gcptr T, uint32_t n, uint32_t from) {
+    uint32_t p = from < 3 ? 3 : from;
+    for (; p < n; p++)
+        if (T[p - 3] != T[p - 2] && T[p - 2] != T[p - 1]) return p;
+    return n;
+}
+
+// T[lo .. hi) eight bytes per load (a byte per load is a memory round trip per byte and lane).
+template <typename F>
+SWC_HD void for_bytes(gcptr T, uint32_t lo, uint32_t hi, F f) {
+    uint32_t i = lo;
+    for (; i < hi && (i & 7u); i++) f((uint32_t)T[i]);
+    for (; i + 8 <= hi; i += 8) {
+        const uint64_t w = load_u64(T + i);
+#pragma unroll
+        for (int k = 0; k < 8; k++) f((uint32_t)(w >> (8 * k)) & 0xFFu);
+    }
+    for (; i < hi; i++) f((uint32_t)T[i]);
+}
+// Output bytes out[pos ..) of ONE writer, eight per store once `pos` reaches a multiple of eight (the bytes below it in
+// that group may belong to another writer); nothing is stored at or beyond `cap`, `pos` keeps counting.
+struct OutPack {
+    gptr out;
+    uint64_t cap, pos, buf, gstart;   // gstart: first position this writer handles in groups
+    bool grouped;
+    SWC_HD void begin(gptr o, uint64_t c, uint64_t p) {
+        out = o; cap = c; pos = p; buf = 0;
+        gstart = (p + 7) & ~(uint64_t)7;
+        grouped = p == gstart;
+    }
+    SWC_HD void put(uint32_t b) {
+        if (pos < cap) {
+            if (!grouped) {
+                out[pos] = (uint8_t)b;
+                grouped = (pos & 7u) == 7u;
+            } else {
+                buf |= (uint64_t)b << (8 * (pos & 7u));
+                if ((pos & 7u) == 7u) { store_u64(out + (pos - 7), buf); buf = 0; }
+            }
+        }
+        pos++;
+    }
+    SWC_HD void finish() {   // the bytes of the last, incomplete group -- if this writer put any below `cap`
+        const uint64_t done = pos < cap ? pos : cap;
+        uint64_t j = done & ~(uint64_t)7;
+        if (j < gstart) j = gstart;
+        for (; j < done; j++) out[j] = (uint8_t)(buf >> (8 * (j & 7u)));
+    }
+};
+
+template <int WAVE>
+SWC_HD void stage3_walk_job(Job& job, Workspace ws, Stage3Lds* l, int lane) {
+    if (lane == 0) ws.hdr->pad = kWalkNone;
+    if (ws.hdr->status != SWC_OK) return;
+    const uint32_t n = ws.hdr->n, orig = ws.hdr->orig_ptr;
+    if (n == 0 || orig >= n) return;                         // empty block / trap: stage 3b reports it
+    const uint32_t mbits = seg_mbits(n), mask = (1u << mbits) - 1u;
+    const uint32_t regs = (n + mask) >> mbits;               // marks 0, M, 2M, ...
+    const bool extra = (orig & mask) != 0;                   // origPtr is a mark of its own
+    const uint32_t segs = regs + (extra ? 1u : 0u);
+    const uint32_t cap = kSegCapFactor << mbits;
+    auto is_mark = [&](uint32_t i) { return (i & mask) == 0 || i == orig; };
+    auto seg_of = [&](uint32_t i) { return (extra && i == orig) ? regs : i >> mbits; };
+    auto start_of = [&](uint32_t sg) { return sg < regs ? sg << mbits : orig; };
+    if (lane == 0) { l->ticket = 0; l->bad = 0; }
+    // ---- every lane walks segments until none is left; the first `cap` bytes of a segment go to its buffer
+    for (;;) {
+        const uint32_t sg = take_ticket(&l->ticket);
+        if (sg >= segs) break;
+        gptr buf = ws.segbuf + (size_t)sg * cap;
+        uint32_t cur = start_of(sg), k = 0;
+        uint64_t acc = 0;                                    // eight bytes per store: a byte per step would be a partial-line
+        do {                                                 // write to HBM each time (655,360 open lines do not stay in L2)
+            const uint32_t v = ws.P[cur];
+            acc |= (uint64_t)(v & 0xFFu) << (8 * (k & 7u));
+            if ((k & 7u) == 7u) {
+                const uint32_t g0 = k - 7;
+                if (g0 + 8 <= cap) store_u64(buf + g0, acc);
+                else for (uint32_t j = 0; j < 8; j++) if (g0 + j < cap) buf[g0 + j] = (uint8_t)(acc >> (8 * j));
+                acc = 0;
+            }
+            k++;
+            cur = v >> 8;
+        } while (!is_mark(cur) && k <= n);
+        for (uint32_t j = k & ~7u; j < k; j++) if (j < cap) buf[j] = (uint8_t)(acc >> (8 * (j & 7u)));   // pending bytes
+        if (k > n) l->bad = 1;                               // cannot happen for a permutation; guards the loops below
+        l->len[sg] = k;
+        l->next[sg] = seg_of(cur);
+    }
+    // ---- cycle order: from origPtr's segment along `next` until the walk is back; one n-cycle <=> the lengths add up to n
+    // exactly when the start comes round again.  (All lanes run this short chain redundantly: <= 513 LDS steps.)
+    if (l->bad) return;
+    const uint32_t s0 = seg_of(orig);
+    uint32_t sg = s0, off = 0, visited = 0;
+    do {
+        l->off[sg] = off;
+        off += l->len[sg];
+        sg = l->next[sg];
+        visited++;
+    } while (sg != s0 && visited <= segs && off <= n);
+    if (!(sg == s0 && off == n && visited == segs)) return;  // several cycles: the reference keeps circling the first one
+    // ---- lay out: buffered prefixes by the whole wave, overlong tails by walking those segments again
+    for (uint32_t q = 0; q < segs; q++) {
+        const uint32_t len = l->len[q], have = len < cap ? len : cap;
+        gcptr src = ws.segbuf + (size_t)q * cap;
+        gptr dst = ws.L + l->off[q];
+        for (uint32_t i = (uint32_t)lane * 8u; i < have; i += (uint32_t)WAVE * 8u) {
+            if (have - i >= 8) store_u64(dst + i, load_u64(src + i));
+            else for (uint32_t j = i; j < have; j++) dst[j] = src[j];
+        }
+    }
+    if (lane == 0) l->ticket = 0;
+    for (;;) {
+        const uint32_t q = take_ticket(&l->ticket);
+        if (q >= segs) break;
+        const uint32_t len = l->len[q];
+        if (len <= cap) continue;
+        gptr dst = ws.L + l->off[q];
+        uint32_t cur = start_of(q);
+        uint64_t acc = 0;
+        for (uint32_t k = 0; k < len; k++) {
+            const uint32_t v = ws.P[cur];
+            acc |= (uint64_t)(v & 0xFFu) << (8 * (k & 7u));
+            if ((k & 7u) == 7u) {
+                if (k - 7 >= cap) store_u64(dst + (k - 7), acc);
+                else for (uint32_t j = 0; j < 8; j++) if (k - 7 + j >= cap) dst[k - 7 + j] = (uint8_t)(acc >> (8 * j));
+                acc = 0;
+            }
+            cur = v >> 8;
+        }
+        for (uint32_t j = len & ~7u; j < len; j++) if (j >= cap) dst[j] = (uint8_t)(acc >> (8 * (j & 7u)));
+    }
+    // ---- RLE1 undo by the whole wave: kParts independent parts (see first_safe_start), sizes first, then the bytes.
+    // (L was written by other lanes of this wave just above: stores and loads of one wave are performed in order.)
+    gcptr T = ws.L;
+    for (int part = lane; part <= kParts; part += WAVE) {
+        uint32_t at;
+        if (part == 0) at = 0;
+        else if (part == kParts) at = n;
+        else at = first_safe_start(T, n, (uint32_t)(((uint64_t)n * (uint32_t)part) / kParts));
+        l->part_at[part] = at;
+    }
+    for (int part = lane; part < kParts; part += WAVE) {
+        const uint32_t lo = l->part_at[part], hi = l->part_at[part + 1];
+        Rle1 f{part == 0 ? 0u : 1u, part == 0 ? 0u : (lo ? (uint32_t)T[lo - 1] : 0u)};
+        uint64_t bytes = 0;
+        for_bytes(T, lo, hi, [&](uint32_t b) { bool c; bytes += f.feed(b, c); });
+        l->part_out[part + 1] = bytes;
+    }
+    if (lane == 0) {
+        l->part_out[0] = 0;
+        for (int j = 1; j <= kParts; j++) l->part_out[j] += l->part_out[j - 1];
+    }
+    gptr out = (gptr)job.out;
+    const uint64_t ocap = job.out_cap;
+    for (int part = lane; part < kParts; part += WAVE) {
+        const uint32_t lo = l->part_at[part], hi = l->part_at[part + 1];
+        Rle1 f{part == 0 ? 0u : 1u, part == 0 ? 0u : (lo ? (uint32_t)T[lo - 1] : 0u)};
+        OutPack o;
+        o.begin(out, ocap, l->part_out[part]);
+        for_bytes(T, lo, hi, [&](uint32_t b) {
+            bool c;
+            const uint32_t prev = f.prev;
+            const uint32_t cnt = f.feed(b, c);
+            const uint32_t v = c ? prev : b;
+            for (uint32_t k = 0; k < cnt; k++) o.put(v);
+        });
+        o.finish();
+    }
+    const uint64_t total = l->part_out[kParts];
+    job.out_len = total;
+    job.status = total > ocap ? SWC_E_CAPACITY : SWC_OK;
+    job.in_consumed = ws.hdr->end_bit;
+    job.aux = 0;
+    if (lane == 0) ws.hdr->pad = kWalkDone;
+}
+
+// ---- stage 3b: RLE1 undo, one block per lane.  job.dict (as integer) = stored block CRC (checked by stage 3c). ----------
+// ---- stage 3b: everything stage 3a left (failed blocks, empty blocks, origPtr out of range, permutations that are not one
+// cycle): the serial walk of BurrowsWheeler.swift:58-62 fused with the RLE1 undo, one block per lane. ---------------------
+SWC_HD bool stage3_expand_needed(Workspace ws) { return ws.hdr->pad != kWalkDone; }
+SWC_HD void stage3_expand_job(Job& job, Workspace ws) {
     const uint32_t st1 = ws.hdr->status;
     job.in_consumed = ws.hdr->end_bit;  // bit position just past the block (BITS for this codec)
+    job.aux = 0;
     if (st1 != SWC_OK) { job.status = (int32_t)st1; job.out_len = 0; return; }
     const uint32_t n = ws.hdr->n;
     gptr out = (gptr)job.out;
     const uint64_t cap = job.out_cap;
-    uint64_t pos = 0;
-    uint32_t crc = 0xFFFFFFFFu;
     int st = SWC_OK;
-    if (n > 0) {  // BurrowsWheeler.swift:30-31: empty input => []
-        uint32_t end = ws.hdr->orig_ptr;
-        uint32_t run = 0, prev = 0;
-        for (uint32_t i = 0; i < n; i++) {
-            if (end >= n) { st = SWC_E_REF_TRAP; break; }  // pointers[end] out of range (App. A B4)
-            const uint32_t v = ws.P[end];
-            end = v >> 8;
-            const uint32_t b = v & 0xFFu;
-            if (run == 4) {
-                // the byte after four equal ones is a repeat count (it exists: this is position i <= n-1)
-                for (uint32_t k = 0; k < b; k++) {
-                    if (pos < cap) out[pos] = (uint8_t)prev;
-                    pos++;
-                    crc = (crc << 8) ^ crc_tab[(crc >> 24) ^ prev];
-                }
-                run = 0;
-                continue;
-            }
-            run = (run > 0 && b == prev) ? run + 1 : 1;
-            prev = b;
-            if (pos < cap) out[pos] = (uint8_t)b;
-            pos++;
-            crc = (crc << 8) ^ crc_tab[(crc >> 24) ^ b];
-        }
+    Rle1 f{0u, 0u};
+    OutPack o;
+    o.begin(out, cap, 0);
+    uint32_t end = ws.hdr->orig_ptr;
+    for (uint32_t i = 0; i < n; i++) {  // n == 0: BurrowsWheeler.swift:30-31, empty input => []
+        if (end >= n) { st = SWC_E_REF_TRAP; break; }  // pointers[end] out of range (App. A B4)
+        const uint32_t v = ws.P[end];
+        end = v >> 8;
+        bool c;
+        const uint32_t prev = f.prev;
+        const uint32_t cnt = f.feed(v & 0xFFu, c);
+        const uint32_t b = c ? prev : (v & 0xFFu);
+        for (uint32_t k = 0; k < cnt; k++) o.put(b);
     }
-    crc = ~crc;
-    if (st == SWC_OK && pos > cap) st = SWC_E_CAPACITY;
-    if (st == SWC_OK && crc != (uint32_t)(uintptr_t)job.dict) st = SWC_E_BZIP2_WRONG_CRC;  // BZip2.swift:81
-    job.out_len = pos;
+    o.finish();
+    if (st == SWC_OK && o.pos > cap) st = SWC_E_CAPACITY;
+    job.out_len = o.pos;
     job.status = st;
+}
+
+// ---- stage 3c: the block CRC (BZip2.swift:81), `crc` = bzip2crc32 of out[0 .. out_len) ---------------------------------
+SWC_HD void stage3_check_crc(Job& job, uint32_t crc) {
     job.aux = (int32_t)crc;
+    if (job.status == SWC_OK && crc != (uint32_t)(uintptr_t)job.dict) job.status = SWC_E_BZIP2_WRONG_CRC;
 }
 
 }  // namespace bzip2

@@ -206,18 +206,49 @@ __global__ __launch_bounds__(64) void swc_bzip2_stage2_kernel(uint32_t n, uint8_
     bzip2::stage2_job<kWave>(bzip2::carve(ws, g, lcap), reinterpret_cast<uint32_t*>(bz_lds), (int)threadIdx.x);
 }
 
-__global__ __launch_bounds__(64) void swc_bzip2_stage3_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t lcap) {
-    __shared__ uint32_t crc_tab[256];
-    for (uint32_t i = threadIdx.x; i < 256; i += kWave) crc_tab[i] = bzip2::crc_table_entry(i);
-    __syncthreads();
-    uint32_t g = blockIdx.x * kWave + threadIdx.x;
+// stage 3a: one block per wave (cut the BWT cycle into segments, walk them with all lanes, order, lay out, undo RLE1)
+__global__ __launch_bounds__(64) void swc_bzip2_walk_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t lcap) {
+    __shared__ bzip2::Stage3Lds lds;
+    uint32_t g = blockIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
-    bzip2::stage3_job(job, bzip2::carve(ws, g, lcap), crc_tab);
+    const bzip2::Workspace w = bzip2::carve(ws, g, lcap);
+    bzip2::stage3_walk_job<kWave>(job, w, &lds, (int)threadIdx.x);
+    if (threadIdx.x == 0 && !bzip2::stage3_expand_needed(w)) {
+        jobs[g].out_len = job.out_len;
+        jobs[g].in_consumed = job.in_consumed;
+        jobs[g].status = job.status;
+        jobs[g].aux = job.aux;
+    }
+}
+
+// stage 3b: one block per lane, only what stage 3a could not finish (serial walk + RLE1 undo)
+__global__ __launch_bounds__(64) void swc_bzip2_expand_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t lcap) {
+    uint32_t g = blockIdx.x * kWave + threadIdx.x;
+    if (g >= n) return;
+    const bzip2::Workspace w = bzip2::carve(ws, g, lcap);
+    if (!bzip2::stage3_expand_needed(w)) return;
+    Job job = jobs[g];
+    bzip2::stage3_expand_job(job, w);
     jobs[g].out_len = job.out_len;
     jobs[g].in_consumed = job.in_consumed;
     jobs[g].status = job.status;
     jobs[g].aux = job.aux;
+}
+
+// stage 3c: one block per workgroup (block CRC, BZip2.swift:81)
+__global__ __launch_bounds__(256) void swc_bzip2_crc_kernel(Job* __restrict__ jobs, uint32_t n) {
+    __shared__ crc::Lds<256, uint32_t> lds;
+    uint32_t g = blockIdx.x;
+    if (g >= n) return;
+    Job job = jobs[g];
+    if (job.status != SWC_OK) return;   // decode errors and SWC_E_CAPACITY stand
+    const uint32_t c = crc::crc_group<256, uint32_t, true>((gcptr)job.out, job.out_len, &lds, (int)threadIdx.x);
+    if (threadIdx.x == 0) {
+        bzip2::stage3_check_crc(job, c);
+        jobs[g].status = job.status;
+        jobs[g].aux = job.aux;
+    }
 }
 
 size_t bzip2_ws_bytes_per_job(size_t lcap) { return bzip2::ws_bytes_per_job(lcap); }
@@ -226,14 +257,21 @@ hipError_t launch_bzip2(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStrea
     if (n == 0) return hipSuccess;
     if (!ws) return hipErrorInvalidValue;
     const size_t per_job = ws_bytes / n;
-    const size_t fixed = 32768 + sizeof(bzip2::BlockHeader) + 64 + 16;
-    if (per_job <= fixed + 5 * 16) return hipErrorInvalidValue;
-    size_t lcap = (per_job - fixed) / 5;
-    if (lcap > 16000000) lcap = 16000000;  // i << 8 | c packing of stage 2
+    // the largest L capacity whose workspace fits (ws_bytes_per_job is monotonic in lcap)
+    if (per_job < bzip2::ws_bytes_per_job(16)) return hipErrorInvalidValue;
+    size_t lo = 16, hi = 16000000;               // upper limit: i << 8 | c packing of stage 2
+    if (bzip2::ws_bytes_per_job(hi) <= per_job) lo = hi;
+    while (hi - lo > 1) {
+        const size_t mid = lo + (hi - lo) / 2;
+        if (bzip2::ws_bytes_per_job(mid) <= per_job) lo = mid; else hi = mid;
+    }
+    const size_t lcap = lo;
     dim3 block(kWave);
     hipLaunchKernelGGL(swc_bzip2_stage1_kernel, dim3((unsigned)n), block, bzip2::kStage1LdsBytes, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
     hipLaunchKernelGGL(swc_bzip2_stage2_kernel, dim3((unsigned)n), block, 256 * kWave * 4, stream, (uint32_t)n, (uint8_t*)ws, lcap);
-    hipLaunchKernelGGL(swc_bzip2_stage3_kernel, dim3((unsigned)((n + kWave - 1) / kWave)), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
+    hipLaunchKernelGGL(swc_bzip2_walk_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
+    hipLaunchKernelGGL(swc_bzip2_expand_kernel, dim3((unsigned)((n + kWave - 1) / kWave)), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
+    hipLaunchKernelGGL(swc_bzip2_crc_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, (uint32_t)n);
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@
 #include "../../swcompression_amd/csrc/lz4_wave.h"
 #include "../../swcompression_amd/csrc/lzma_wave.h"
 #include "../../swcompression_amd/csrc/bzip2_block.h"
+#include "../../swcompression_amd/csrc/crc32_group.h"
 
 // Deflate: phase 1 lane by lane (wave-interleaved tables), then phase 2 with a one-thread "workgroup".
 extern "C" void emu_inflate(swc::Job* jobs, size_t n) {
@@ -59,16 +60,21 @@ extern "C" void emu_lzma(swc::Job* jobs, size_t n, int is_lzma2) {
 extern "C" void emu_bzip2_block(swc::Job* jobs, size_t n, size_t lcap) {
     using namespace swc::bzip2;
     std::vector<uint8_t> ws(ws_bytes_per_job(lcap) + 64);
-    std::vector<uint32_t> cnt(256), crc(256);
-    for (uint32_t i = 0; i < 256; i++) crc[i] = crc_table_entry(i);
+    std::vector<uint32_t> cnt(256);
     Stage1Lds lds;
+    Stage3Lds lds3;
+    static swc::crc::Lds<1, uint32_t> crc_lds;
     for (size_t g = 0; g < n; g++) {
         std::memset(&lds, 0xEE, sizeof lds);
         std::fill(ws.begin(), ws.end(), (uint8_t)0xCD);
         Workspace w = carve(ws.data(), 0, lcap);
         stage1_job<1>(jobs[g], &lds, w, 0);
         stage2_job<1>(w, cnt.data(), 0);
-        stage3_job(jobs[g], w, crc.data());
+        std::memset(&lds3, 0xEE, sizeof lds3);
+        stage3_walk_job<1>(jobs[g], w, &lds3, 0);
+        if (stage3_expand_needed(w)) stage3_expand_job(jobs[g], w);
+        if (jobs[g].status == SWC_OK)
+            stage3_check_crc(jobs[g], swc::crc::crc_group<1, uint32_t, true>(jobs[g].out, jobs[g].out_len, &crc_lds, 0));
     }
 }
 

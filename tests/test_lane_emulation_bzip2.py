@@ -63,3 +63,21 @@ def test_capacity_reports_required_size():
                         [len(x) // 2 for _, x in cases])
     for r, (z, x) in zip(res, cases):
         assert r[0] == 901 and r[3] == len(x) and r[1] == x[:len(x) // 2]
+
+
+def test_block_sizes_around_the_segment_geometry():
+    """Stage 3a cuts the BWT cycle at multiples of M = 2^m (n / M <= 512) and keeps 3 M bytes per segment: sizes around
+    every change of m, tiny blocks (M = 1) and payloads whose RLE1 form differs a lot from the output."""
+    import bz2
+    from swcompression_amd import corpus
+    sizes = list(range(1, 40)) + [255, 256, 257, 511, 512, 513, 514, 600, 1023, 1024, 1025, 1030, 2047, 2048, 2049, 2055, 4095, 4096,
+                                  4097, 8191, 8192, 8193, 8200, 20000, 65535, 65536, 65537]
+    cases = []
+    for i, n in enumerate(sizes):
+        for kind in ("text", "rand", "rep"):
+            x = corpus.PAYLOADS[kind](n, 100 + i)
+            cases.append((bz2.compress(x, 9), x))
+    res = E.bzip2_block([z for z, _ in cases], [112] * len(cases), [int.from_bytes(z[10:14], "big") for z, _ in cases],
+                        [max(len(x), 1) for _, x in cases], lcap=70000)
+    for r, (z, x) in zip(res, cases):
+        assert r[:2] == (0, x), len(x)

@@ -37,6 +37,21 @@ __global__ void walk_group_per_block(const uint32_t* P, size_t n, uint32_t steps
     sink[blockIdx.x * blockDim.x + threadIdx.x] = acc + end;
 }
 
+// mode 2: 32 workgroups of W threads per block, placed on ONE XCD (workgroup w runs on XCD w % 8, observed): the block's
+// pointer array (3.6 MB) stays inside that XCD's 4 MiB L2 while 32 x W walkers chase through it.
+__global__ void walk_xcd_per_block(const uint32_t* P, size_t n, uint32_t steps, uint32_t blocks, uint32_t* sink) {
+    extern __shared__ uint32_t pad[];
+    const uint32_t w = blockIdx.x, x = w & 7, q = w >> 3;
+    const uint32_t b = (q / 32) * 8 + x, sub = q % 32;
+    if (b >= blocks) return;
+    const uint32_t* p = P + (size_t)b * n;
+    const uint32_t walker = sub * blockDim.x + threadIdx.x, walkers = 32 * blockDim.x;
+    uint32_t end = (uint32_t)(((uint64_t)walker * n) / walkers), acc = 0;
+    for (uint32_t i = 0; i < steps; i++) { uint32_t v = p[end]; end = v >> 8; acc += v & 255; }
+    if (acc + end == 0xFFFFFFFFu) pad[0] = 1;
+    sink[(w * blockDim.x + threadIdx.x) & 0xFFFFF] = acc + end;
+}
+
 int main(int argc, char** argv) {
     size_t blocks = argc > 1 ? atol(argv[1]) : 10240, n = argc > 2 ? atol(argv[2]) : 900000;
     int W = argc > 3 ? atoi(argv[3]) : 64, lds_kb = argc > 4 ? atoi(argv[4]) : 0;
@@ -57,7 +72,15 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 2; rep++) {
         CK(hipEventRecord(e0));
         uint64_t gathers;
-        if (W == 1) {
+        if (argc > 5) {   // mode 2: XCD-affine, argv[5] = passes over the block (steps = passes * n / walkers)
+            int passes = atoi(argv[5]);
+            uint32_t walkers = 32 * W;
+            uint32_t steps = (uint32_t)((uint64_t)passes * n / walkers);
+            CK(hipFuncSetAttribute((const void*)walk_xcd_per_block, hipFuncAttributeMaxDynamicSharedMemorySize, lds_kb * 1024));
+            uint32_t groups = (uint32_t)((blocks + 7) / 8) * 32 * 8;
+            walk_xcd_per_block<<<groups, W, lds_kb * 1024>>>(d_P, n, steps, (uint32_t)blocks, d_sink);
+            gathers = (uint64_t)steps * walkers * blocks;
+        } else if (W == 1) {
             uint32_t steps = (uint32_t)n / 8;   // an eighth of the walk is enough to time it
             walk_lane_per_block<<<(unsigned)((blocks + 63) / 64), 64>>>(d_P, n, (uint32_t)blocks, steps, d_sink);
             gathers = (uint64_t)steps * blocks;
