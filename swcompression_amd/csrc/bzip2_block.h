@@ -56,7 +56,10 @@ struct Stage1Lds {
 constexpr int kStage1LdsBytes = (sizeof(Stage1Lds) + 15) / 16 * 16;
 
 constexpr uint32_t kSegs = 512;        // stage 3a: regular segments per block (+1 for origPtr)
-constexpr uint32_t kSegCapFactor = 3;  // a segment's buffer holds 3 x the mean segment length (5 % are longer)
+#ifndef SWC_BZ_SEGCAP
+#define SWC_BZ_SEGCAP 4
+#endif
+constexpr uint32_t kSegCapFactor = SWC_BZ_SEGCAP;  // a segment's buffer holds 4 x the mean segment length (2 % are longer, 9 % of the bytes)
 constexpr int kParts = 64;             // stage 3a: the RLE1 undo of a block is cut into this many parts
 
 // workspace per job (HBM): L[lcap] (stage 3: the walked bytes T) | selectors[32768] | P[lcap] (u32) | header | segment buffers
