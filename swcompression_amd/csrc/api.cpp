@@ -30,6 +30,12 @@ bool device_ready() {
         if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return; }
         // The code object in this library is gfx950 only.
         g_dev_ok = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
+        if (g_dev_ok) {   // keep freed staging buffers of the single-shot calls in the pool instead of returning them to the OS
+            hipMemPool_t pool;
+            uint64_t keep = 1ull << 30;
+            if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+            (void)hipGetLastError();
+        }
     });
     return g_dev_ok;
 }
