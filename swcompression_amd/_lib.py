@@ -77,5 +77,10 @@ def load():
     sig("swc_bzip2_crc32", C.c_uint32, C.c_char_p, C.c_size_t)
     sig("swc_xxh32", C.c_uint32, C.c_char_p, C.c_size_t, C.c_uint32)
     sig("swc_sha256", None, C.c_char_p, C.c_size_t, C.c_char_p)
+    # SWC_TUNING="key=value,key=value": performance knobs for experiments (swc_set_tuning; results never change)
+    for item in filter(None, os.environ.get("SWC_TUNING", "").split(",")):
+        key, _, val = item.partition("=")
+        if lib.swc_set_tuning(key.strip().encode(), int(val)) != 0:
+            raise ValueError("SWC_TUNING: bad entry %r" % item)
     _lib = lib
     return lib

@@ -36,6 +36,9 @@ namespace inflate {
 constexpr int W_LIT_SYM = 0;     // 72 words : 288 x 8-bit symbols (symbol & 255)
 constexpr int W_DIST_SYM = 72;   //  8 words : 32 x 8-bit symbols
 constexpr int kWordsPerLane = 80;
+// wave mode: direct-lookup tables for codes of up to kLut*Bits bits (longer codes take the checked step) and the staged input
+constexpr int kLutLitBits = 10, kLutDistBits = 9, kStageBytes = 512;
+constexpr int kWaveModeLdsBytes = kWordsPerLane * 4 + (4 << kLutLitBits) + (4 << kLutDistBits) + kStageBytes + 16;
 constexpr int kLdsBytesPerWave = kWordsPerLane * 4 * kWave;  // 20,480 B
 // count pass only (aliases the symbol area, which is written afterwards):
 constexpr int W_CNT_LIT = 0;     // 16 words : codes per length, lit/len alphabet
@@ -239,6 +242,15 @@ struct Lane {
     uint64_t nlit;
     uint64_t last_end;             // position just past the previous record
     int dbg = 0;                   // timing experiments only (tools/exp_deflate.py): 1 no literal stores, 2 no record stores
+    // ---- wave mode (one stream per WAVEFRONT, small batches; see wave_loop): all 64 lanes run this object redundantly
+    // on one shared LDS column, `wlane` is the lane's number (-1: lane mode, one stream per lane)
+    int wlane = -1;
+    int wlanes = kWave;            // lanes that share the work of the parallel parts (1 in the host emulation)
+    uint32_t* lut_lit = nullptr;   // LDS, 1 << kLutLitBits entries (wave_loop)
+    uint32_t* lut_dist = nullptr;  // LDS, 1 << kLutDistBits entries
+    uint8_t* stage = nullptr;      // LDS, kStageBytes + 8: a window of the input
+    uint32_t stage_base = 0, stage_len = 0;
+    bool luts_ready = false;
 
     SWC_HD void push(uint32_t v) {
         if (nrec < max_rec) recs[nrec] = v;
@@ -359,6 +371,7 @@ struct Lane {
 
     // Deflate.swift:86-167
     SWC_HD int build_dynamic() {
+        luts_ready = false;
         br.refill();
         if (br.bc < 14) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :86
         int literals = (int)br.bits(5) + 257;
@@ -418,6 +431,7 @@ struct Lane {
 
     // Deflate.swift:77-81 with the fixed code of Deflate+Constants.swift:11-173
     SWC_HD void build_static() {
+        luts_ready = false;
         uint64_t run_lit[3], run_dist[3];
         build_table(lit, [](int d) { return d == 7 ? 24u : d == 8 ? 152u : d == 9 ? 112u : 0u; },
                     [](int d) { return d == 8 ? 144u : d == 9 ? 112u : 0u; }, run_lit);
@@ -582,6 +596,159 @@ struct Lane {
         return eob;
     }
 
+    // ---- wave mode ---------------------------------------------------------------------------------------------------
+    // One stream per lane needs thousands of streams to fill the chip and decodes each of them at ~8 MB/s (one 64 KiB
+    // block: 8.8 ms).  For small batches one stream gets a whole wavefront instead.  The symbol chain itself stays
+    // serial, but the expensive part of a step -- finding the code that starts at a given bit -- is done for 64 bit
+    // positions at once: lane k looks up, in direct tables in LDS, the lit/len code AND the distance code that would
+    // start at bit P + k; the chain then hops from lane to lane with v_readlane (a few cycles) instead of decoding.
+    // Everything unusual (a code longer than the tables, symbols > 285 / 29, distance beyond the output, the end of the
+    // input) stops the hop chain BEFORE that symbol, and the fully checked step decodes it.
+    //
+    // Table entries.  lit/len: [0:3] code length (0: not in the table) [4:6] extra bits [7:8] 1 literal, 2 length,
+    // 3 end of block [9:17] byte / base length.  distance: [0:3] code length [4:7] extra bits [8] symbol <= 29
+    // [9:24] base distance.
+    SWC_HD void build_luts() {
+        const int lanes = wlanes, me = wlane;
+        for (int i = me; i < (1 << kLutLitBits); i += lanes) lut_lit[i] = 0;
+        for (int i = me; i < (1 << kLutDistBits); i += lanes) lut_dist[i] = 0;
+        // sorted index j -> (length d, code first(d) + j - start(d)); the stream carries codes LSB first, so the table
+        // index is the bit-reversed code, replicated over the don't-care bits above it
+        const uint32_t n_lit = lit.slot[16], n_dist = dist.slot[16];
+        for (uint32_t j = (uint32_t)me; j < n_lit; j += (uint32_t)lanes) {
+            uint32_t d = 1, fst = 0, stt = lit.start(1);
+#pragma unroll
+            for (int q = 2; q <= 15; q++)   // the length whose index range holds j (static register indices only)
+                if (j >= lit.start(q)) { d = (uint32_t)q; fst = lit.first(q); stt = lit.start(q); }
+            if (d > (uint32_t)kLutLitBits) continue;
+            const uint32_t code = fst + (j - stt);
+            const uint32_t rev = brev32(code) >> (32 - d);
+            uint32_t sym = *sym_ptr(l, W_LIT_SYM, j);
+            if (j >= (slot_of(lit, d) >> 16)) sym |= 256u;
+            uint32_t entry;
+            if (sym < 256) entry = d | (1u << 7) | (sym << 9);
+            else if (sym == 256) entry = d | (3u << 7);
+            else if (sym <= 285) {
+                const uint32_t t = sym - 257u;
+                const uint32_t e = t < 8 || t == 28 ? 0u : (t >> 2) - 1u;
+                const uint32_t base = t < 8 ? 3u + t : t == 28 ? 258u : 3u + ((4u + (t & 3u)) << e);
+                entry = d | (e << 4) | (2u << 7) | (base << 9);
+            } else entry = 0;   // 286, 287: the checked step reports wrongSymbol
+            if (entry) for (uint32_t m = rev; m < (1u << kLutLitBits); m += 1u << d) lut_lit[m] = entry;
+        }
+        for (uint32_t j = (uint32_t)me; j < n_dist; j += (uint32_t)lanes) {
+            uint32_t d = 1, fst = 0, stt = dist.start(1);
+#pragma unroll
+            for (int q = 2; q <= 15; q++)
+                if (j >= dist.start(q)) { d = (uint32_t)q; fst = dist.first(q); stt = dist.start(q); }
+            if (d > (uint32_t)kLutDistBits) continue;
+            const uint32_t code = fst + (j - stt);
+            const uint32_t rev = brev32(code) >> (32 - d);
+            const uint32_t dc = *sym_ptr(l, W_DIST_SYM, j);
+            if (dc > 29) continue;
+            const uint32_t e = dc < 4 ? 0u : (dc >> 1) - 1u;
+            const uint32_t base = dc < 4 ? 1u + dc : 1u + ((2u + (dc & 1u)) << e);
+            const uint32_t entry = d | (e << 4) | (1u << 8) | (base << 9);
+            for (uint32_t m = rev; m < (1u << kLutDistBits); m += 1u << d) lut_dist[m] = entry;
+        }
+        luts_ready = true;
+    }
+    // (re)stage the input window so that it starts at byte `from`
+    SWC_HD void stage_input(uint32_t from) {
+        const int lanes = wlanes, me = wlane;
+        stage_base = from;
+        const uint32_t left = br.len - from;
+        stage_len = left < (uint32_t)kStageBytes ? left : (uint32_t)kStageBytes;
+        for (uint32_t i = (uint32_t)me * 8u; i < stage_len; i += (uint32_t)lanes * 8u) {
+            uint64_t w = 0;
+            if (stage_len - i >= 8) w = load_u64(br.in + from + i);
+            else for (uint32_t k = 0; k < stage_len - i; k++) w |= (uint64_t)br.in[from + i + k] << (8 * k);
+            *(u64_unaligned*)(stage + i) = w;
+        }
+    }
+    // What lane k sees at bit position P + k: packed lit/len view [0:4] bits incl. extra [5:6] kind [7:15] byte / length
+    // and distance view [0:4] bits incl. extra [5] valid [6:21] distance.
+    SWC_HD void wave_views(uint64_t bitpos, uint32_t& vl, uint32_t& vd) const {
+        const uint64_t w = *(const u64_unaligned*)(stage + ((uint32_t)(bitpos >> 3) - stage_base)) >> ((uint32_t)bitpos & 7u);   // >= 57 bits
+        const uint32_t ll = lut_lit[(uint32_t)w & ((1u << kLutLitBits) - 1u)];
+        const uint32_t dd = lut_dist[(uint32_t)w & ((1u << kLutDistBits) - 1u)];
+        const uint32_t dl = ll & 15u, el = (ll >> 4) & 7u;
+        const uint32_t valL = ((ll >> 9) & 511u) + ((uint32_t)(w >> dl) & ((1u << el) - 1u));
+        vl = (dl + el) | (((ll >> 7) & 3u) << 5) | (valL << 7);
+        const uint32_t dD = dd & 15u, eD = (dd >> 4) & 15u;
+        const uint32_t valD = ((dd >> 9) & 0xFFFFu) + ((uint32_t)(w >> dD) & ((1u << eD) - 1u));
+        vd = (dD + eD) | (((dd >> 8) & 1u) << 5) | (valD << 6);
+    }
+    // In wave mode every lane holds the same decoder state, but the compiler cannot know (the select trees of the
+    // checked path go through opaque registers): readfirstlane marks values as wave-uniform, so that the hop chain below
+    // runs on the scalar unit with scalar branches instead of EXEC-mask bookkeeping around every step.
+    SWC_HD static uint32_t uni(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return (uint32_t)__builtin_amdgcn_readfirstlane((int)x);
+#else
+        return x;
+#endif
+    }
+    SWC_HD static uint64_t uni(uint64_t x) { return ((uint64_t)uni((uint32_t)(x >> 32)) << 32) | uni((uint32_t)x); }
+    SWC_HD static bool uni(bool x) { return uni((uint32_t)x) != 0; }
+
+    // Returns true when the end-of-block symbol was consumed; false: the caller decodes one symbol with careful_step().
+    SWC_HD bool wave_loop() {
+        if (!luts_ready) build_luts();
+        uint64_t P = uni(br.consumed_bits());
+        pos = uni(pos); nlit = uni(nlit); last_end = uni(last_end); nrec = uni(nrec);
+        stage_base = uni(stage_base); stage_len = uni(stage_len);
+        bool eob = false;
+        for (;;) {
+            // the 64 views need input up to bit P + 63 + 64
+            const uint32_t first = (uint32_t)(P >> 3), last = (uint32_t)((P + 63) >> 3) + 8;
+            if ((uint64_t)last > br.len) break;                     // tail of the stream: checked steps
+            if (!(first >= stage_base && last <= stage_base + stage_len) || stage_len == 0) stage_input(first);
+            if (last > stage_base + stage_len) break;
+#if defined(__HIP_DEVICE_COMPILE__)
+            uint32_t my_l, my_d;
+            wave_views(P + (uint64_t)wlane, my_l, my_d);
+            auto view_l = [&](uint32_t r) { return (uint32_t)__builtin_amdgcn_readlane((int)my_l, __builtin_amdgcn_readfirstlane((int)r)); };
+            auto view_d = [&](uint32_t r) { return (uint32_t)__builtin_amdgcn_readlane((int)my_d, __builtin_amdgcn_readfirstlane((int)r)); };
+#else
+            uint32_t all_l[kWave], all_d[kWave];
+            for (int k = 0; k < kWave; k++) wave_views(P + (uint64_t)k, all_l[k], all_d[k]);
+            auto view_l = [&](uint32_t r) { return all_l[r]; };
+            auto view_d = [&](uint32_t r) { return all_d[r]; };
+#endif
+            uint32_t rel = 0;
+            bool stop = false;
+            for (;;) {
+                rel = uni(rel);
+                if (rel >= (uint32_t)kWave) break;
+                const uint32_t a = view_l(rel);
+                const uint32_t kind = (a >> 5) & 3u, na = a & 31u, va = a >> 7;
+                if (kind == 1) {                       // literal
+                    put_byte((uint8_t)va);
+                    rel += na;
+                } else if (kind == 2) {                // length, then a distance code at rel + na
+                    const uint32_t q = rel + na;
+                    if (q >= (uint32_t)kWave) break;   // its distance code lies in the next window
+                    const uint32_t b = view_d(q);
+                    if (uni(!((b >> 5) & 1u) || (uint64_t)(b >> 6) > pos)) { stop = true; break; }
+                    emit_match(va, b >> 6);
+                    rel = q + (b & 31u);
+                } else if (kind == 3) {                // end of block
+                    rel += na;
+                    eob = true;
+                    break;
+                } else {                               // not in the table
+                    stop = true;
+                    break;
+                }
+            }
+            P += rel;
+            if (eob || stop) break;
+        }
+        br.seek(P);
+        return eob;
+    }
+
     // One symbol with every check of the reference (Deflate.swift:171-236).  Returns SWC_OK to continue, -1 at
     // the end-of-block symbol, or the error.
     SWC_HD int careful_step() {
@@ -628,7 +795,9 @@ struct Lane {
                              (size_t)max_rec >= lzr::max_records(cap);  // the fast loop appends records unchecked
         for (;;) {
             // the fast loop needs the upper halves of pos / last_end to be stable: both below 2^32 - 272 - 258
-            if (fast_ok && pos + 272 <= cap && (uint64_t)br.ppos + 56 <= br.len) {
+            if (wlane >= 0) {
+                if (!lit.oversub && !dist.oversub && wave_loop()) return SWC_OK;
+            } else if (fast_ok && pos + 272 <= cap && (uint64_t)br.ppos + 56 <= br.len) {
                 if (fast_loop()) return SWC_OK;
             }
             int st = careful_step();
@@ -687,10 +856,21 @@ struct Lane {
 
 // One lane = one job.  `lds` is this lane's view of the wave's table region; `ws` / `ws_bytes` the stream's area in
 // the HBM workspace: lzr::StreamHeader | records | literal stream (lz_resolve.h).
-SWC_HD void inflate_job(Job& job, LaneLds lds, uint8_t* ws, size_t ws_bytes, int dbg = 0) {
+// Wave mode: `wlane` = this lane's number and `wave_lds` = kWaveModeLdsBytes of LDS shared by the wave (tables, direct
+// lookup tables, staged input); `lds` is then ignored.
+SWC_HD void inflate_job(Job& job, LaneLds lds, uint8_t* ws, size_t ws_bytes, int dbg = 0, int wlane = -1, uint32_t* wave_lds = nullptr,
+                        int wlanes = kWave) {
     Lane ln;
     ln.dbg = dbg;
     ln.l = lds;
+    if (wlane >= 0) {
+        ln.wlane = wlane;
+        ln.wlanes = wlanes;
+        ln.l = LaneLds{wave_lds, 1};
+        ln.lut_lit = wave_lds + kWordsPerLane;
+        ln.lut_dist = ln.lut_lit + (1 << kLutLitBits);
+        ln.stage = (uint8_t*)(ln.lut_dist + (1 << kLutDistBits));
+    }
     ln.out = (gptr)job.out;
     ln.cap = job.out_cap;
     ln.pos = 0;

@@ -35,6 +35,22 @@ __global__ __launch_bounds__(64, 2) void swc_inflate_kernel(Job* __restrict__ jo
     jobs[g].status = job.status;
 }
 
+// Phase 1 for small batches: one stream per WAVEFRONT (inflate_lane.h, wave mode).  A lane decodes a stream at ~8 MB/s,
+// so a launch of the kernel above takes >= 8 ms per 64 KiB however few streams it holds; with 64 speculative decodes per
+// window and a readlane hop per symbol a wave is an order of magnitude faster per stream, and ~5,000 waves fit the chip.
+__global__ __launch_bounds__(64) void swc_inflate_wave_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride, int dbg) {
+    __shared__ __attribute__((aligned(16))) uint32_t wave_lds[inflate::kWaveModeLdsBytes / 4];
+    uint32_t g = blockIdx.x;
+    if (g >= n) return;
+    Job job = jobs[g];
+    inflate::inflate_job(job, LaneLds{nullptr, 0}, ws ? ws + (size_t)g * ws_stride : nullptr, ws_stride, dbg, (int)threadIdx.x, wave_lds, kWave);
+    if (threadIdx.x == 0) {
+        jobs[g].out_len = job.out_len;
+        jobs[g].in_consumed = job.in_consumed;
+        jobs[g].status = job.status;
+    }
+}
+
 // Phase 2: one stream per workgroup of T threads, 64 KiB LDS ring -> 2 workgroups per CU.
 template <int T>
 __global__ __launch_bounds__(T) void swc_lz_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, const uint8_t* ws, size_t ws_stride, int dbg) {
@@ -46,6 +62,8 @@ __global__ __launch_bounds__(T) void swc_lz_resolve_kernel(const Job* __restrict
 }
 
 static int g_resolve_threads = 512, g_resolve_dbg = 0, g_inflate_dbg = 0;
+static int g_wave_max_jobs = 3072;   // batches of up to this many streams take the wave-per-stream phase 1
+void set_inflate_wave_max_jobs(int n) { g_wave_max_jobs = n; }
 void set_inflate_debug(int m) { g_inflate_dbg = m; }
 void set_resolve_debug(int m) { g_resolve_dbg = m; }
 
@@ -78,7 +96,10 @@ hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStr
     dim3 grid((unsigned)((n + kWave - 1) / kWave)), block(kWave);
     const bool timing = g_phase_timing && g_phase_ev_ok;
     if (timing) (void)hipEventRecord(g_phase_ev[0], stream);
-    hipLaunchKernelGGL(swc_inflate_kernel, grid, block, inflate::kLdsBytesPerWave, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride, g_inflate_dbg);
+    if (n <= (size_t)g_wave_max_jobs)
+        hipLaunchKernelGGL(swc_inflate_wave_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride, g_inflate_dbg);
+    else
+        hipLaunchKernelGGL(swc_inflate_kernel, grid, block, inflate::kLdsBytesPerWave, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride, g_inflate_dbg);
     if (timing) (void)hipEventRecord(g_phase_ev[1], stream);
     dim3 grid2((unsigned)n);
     switch (g_resolve_threads) {

@@ -67,6 +67,10 @@ def inflate(inputs, caps):
     return run_batch("emu_inflate", inputs, caps)
 
 
+def inflate_wave(inputs, caps):
+    return run_batch("emu_inflate_wave", inputs, caps)
+
+
 def lz4_block(inputs, caps, dicts=None):
     return run_batch("emu_lz4_block", inputs, caps, dicts=dicts)
 

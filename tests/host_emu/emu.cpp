@@ -28,6 +28,21 @@ extern "C" void emu_inflate(swc::Job* jobs, size_t n) {
     }
 }
 
+// Deflate, wave mode of phase 1 (one stream per wavefront: direct tables + 64 speculative views per window), with the 64
+// views of a window computed one after the other.
+extern "C" void emu_inflate_wave(swc::Job* jobs, size_t n) {
+    std::vector<uint32_t> lds(swc::inflate::kWaveModeLdsBytes / 4 + 8);
+    alignas(16) static swc::lzr::Lds<1> rl;
+    for (size_t g = 0; g < n; g++) {
+        std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);
+        size_t wsb = swc::lzr::ws_bytes_per_job(jobs[g].out_cap);
+        std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
+        swc::inflate::inflate_job(jobs[g], swc::LaneLds{nullptr, 0}, ws.data(), wsb, 0, 0, lds.data(), 1);
+        std::memset(&rl, 0xEE, sizeof rl);
+        swc::lzr::resolve_job<1>(jobs[g], ws.data(), wsb, &rl, 0);
+    }
+}
+
 // LZ4: blocks with a dictionary prefix on the lane decoder, the others through the two-phase path (parse with a
 // one-lane "wavefront", resolve with a one-thread "workgroup").
 extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {

@@ -10,12 +10,20 @@ import _emu as E
 import _oracle as O
 import _streams as S
 
+# phase 1 exists in two forms: one stream per lane (large batches) and one stream per wavefront (small batches)
+MODES = {"lane": E.inflate, "wave": E.inflate_wave}
 
-def _check(inputs, caps=None):
+
+@pytest.fixture(params=sorted(MODES))
+def inflate(request):
+    return MODES[request.param]
+
+
+def _check(inflate, inputs, caps=None):
     exp = [O.deflate(z) for z in inputs]
     if caps is None:
         caps = [max(len(e[1]), 1) for e in exp]
-    res = E.inflate(inputs, caps)
+    res = inflate(inputs, caps)
     for i, (r, e) in enumerate(zip(res, exp)):
         st, out, cons, _ = r
         assert st == e[0], "status mismatch on input %d (%s...)" % (i, inputs[i][:12].hex())
@@ -23,18 +31,18 @@ def _check(inputs, caps=None):
             assert out == e[1] and cons == e[2], "output/consumed mismatch on input %d" % i
 
 
-def test_valid_corpus():
+def test_valid_corpus(inflate):
     pairs = S.valid_deflate_corpus()
-    _check([z for z, _ in pairs])
-    for (z, x), r in zip(pairs, E.inflate([z for z, _ in pairs], [len(x) for _, x in pairs])):
+    _check(inflate, [z for z, _ in pairs])
+    for (z, x), r in zip(pairs, inflate([z for z, _ in pairs], [len(x) for _, x in pairs])):
         assert r[:2] == (0, x)
 
 
-def test_crafted_reference_semantics():
+def test_crafted_reference_semantics(inflate):
     cr = S.crafted_deflate()
     ins = [z for _, z in cr]
     exp = [O.deflate(z) for z in ins]
-    res = E.inflate(ins, [600] * len(ins))
+    res = inflate(ins, [600] * len(ins))
     for (name, _), r, e in zip(cr, res, exp):
         assert r[0] == e[0], name
         # partial output up to the error is not part of the contract, but for these vectors it pins
@@ -46,20 +54,20 @@ def test_crafted_reference_semantics():
     assert by_name["dist-too-far"][0] == 900 and by_name["dist-sym-30"][0] == 103
 
 
-def test_fuzz_status_parity():
+def test_fuzz_status_parity(inflate):
     O.lib.refcpu_set_max_output(1 << 24)
     ins = S.fuzz_deflate()
     exp = [O.deflate(z) for z in ins]
     keep = [i for i, e in enumerate(exp) if e[0] != 901]
     rnd = random.Random(7)
-    _check([ins[i] for i in keep], [max(len(exp[i][1]), 1) + rnd.choice([0, 0, 5]) for i in keep])
+    _check(inflate, [ins[i] for i in keep], [max(len(exp[i][1]), 1) + rnd.choice([0, 0, 5]) for i in keep])
     O.lib.refcpu_set_max_output(1 << 30)
 
 
-def test_capacity_reports_required_size():
+def test_capacity_reports_required_size(inflate):
     pairs = S.valid_deflate_corpus(sizes=(5000, 70000))
     ins = [z for z, _ in pairs]
-    res = E.inflate(ins, [len(x) // 2 for _, x in pairs])
+    res = inflate(ins, [len(x) // 2 for _, x in pairs])
     for (z, x), r in zip(pairs, res):
         assert r[0] == 901 and r[3] == len(x)                      # SWC_E_CAPACITY, out_len = bytes required
         assert r[1] == x[:len(x) // 2]
@@ -74,7 +82,7 @@ def test_wave_tail_and_table_reuse(lanes):
     assert [r[:2] for r in res] == [(0, x) for _, x in pairs]
 
 
-def test_randomised_encoder_settings():
+def test_randomised_encoder_settings(inflate):
     """Every zlib strategy / level / window size on every payload class (static blocks, literal-only blocks, distance-1
     runs, tiny windows, full flushes): the two-phase path (entropy decode + LZ77 resolve, host build) against zlib."""
     import zlib
@@ -91,6 +99,6 @@ def test_randomised_encoder_settings():
         z = co.compress(p[:len(p) // 2]) + co.flush(zlib.Z_FULL_FLUSH if i % 7 == 0 else zlib.Z_NO_FLUSH) + co.compress(p[len(p) // 2:]) + co.flush()
         plains.append(p)
         streams.append(z)
-    res = E.inflate(streams, [max(len(p), 1) for p in plains])
+    res = inflate(streams, [max(len(p), 1) for p in plains])
     for i, (r, p) in enumerate(zip(res, plains)):
         assert r[0] == 0 and r[1] == p and r[2] == len(streams[i]), "stream %d (len %d)" % (i, len(p))
