@@ -183,7 +183,7 @@ int swc_device_available(void);
 const char* swc_version(void);
 /* Performance knobs (never change results): "resolve_threads" = 64..1024 (threads per stream in the LZ77 resolve
  * kernel), "phase_timing" = 0 | 1 (HIP events around the two Deflate kernels of a launch), "inflate_wave_max_jobs" = n
- * (Deflate batches of up to n streams decode one stream per wavefront instead of one per lane; default 3072). */
+ * (Deflate batches of up to n streams decode one stream per wavefront instead of one per lane; default 4096). */
 int swc_set_tuning(const char* key, int value);
 /* With "phase_timing" on: durations (ms) of the kernels of the last Deflate launch, in launch order
  * (entropy decode, LZ77 resolve).  Returns the number of values written (0 if none). */

@@ -38,7 +38,7 @@ __global__ __launch_bounds__(64, 2) void swc_inflate_kernel(Job* __restrict__ jo
 // Phase 1 for small batches: one stream per WAVEFRONT (inflate_lane.h, wave mode).  A lane decodes a stream at ~8 MB/s,
 // so a launch of the kernel above takes >= 8 ms per 64 KiB however few streams it holds; with 64 speculative decodes per
 // window and a readlane hop per symbol a wave is an order of magnitude faster per stream, and ~5,000 waves fit the chip.
-__global__ __launch_bounds__(64) void swc_inflate_wave_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride, int dbg) {
+__global__ __launch_bounds__(64, 4) void swc_inflate_wave_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride, int dbg) {
     __shared__ __attribute__((aligned(16))) uint32_t wave_lds[inflate::kWaveModeLdsBytes / 4];
     uint32_t g = blockIdx.x;
     if (g >= n) return;
@@ -62,7 +62,7 @@ __global__ __launch_bounds__(T) void swc_lz_resolve_kernel(const Job* __restrict
 }
 
 static int g_resolve_threads = 512, g_resolve_dbg = 0, g_inflate_dbg = 0;
-static int g_wave_max_jobs = 3072;   // batches of up to this many streams take the wave-per-stream phase 1
+static int g_wave_max_jobs = 4096;   // batches of up to this many streams take the wave-per-stream phase 1
 void set_inflate_wave_max_jobs(int n) { g_wave_max_jobs = n; }
 void set_inflate_debug(int m) { g_inflate_dbg = m; }
 void set_resolve_debug(int m) { g_resolve_dbg = m; }
