@@ -26,6 +26,17 @@ pytestmark = pytest.mark.gpu
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_inline_vectors.json")))
 
 
+@pytest.fixture(autouse=True, params=["lane", "wave"])
+def phase1_mode(request):
+    """Phase 1 exists as one stream per lane (batches above "inflate_wave_max_jobs") and one stream per wavefront (small
+    batches): every test of this file runs against both, whatever its batch size."""
+    from swcompression_amd import _lib
+    lib = _lib.load()
+    assert lib.swc_set_tuning(b"inflate_wave_max_jobs", 0 if request.param == "lane" else 1 << 30) == 0
+    yield request.param
+    assert lib.swc_set_tuning(b"inflate_wave_max_jobs", 4096) == 0
+
+
 def test_device_present_and_native_library_loaded():
     assert swc.device_available(), "the HIP engine must run on the GPU box (no CPU fallback exists)"
 
