@@ -256,11 +256,14 @@ def build_units(kind, n_distinct, unit_size, payload="text", seed=2, cache=True)
     tag = "%s_%s_%d_%d_%d" % (kind, payload, n_distinct, unit_size, seed)
     path = _cache_path(tag)
     if cache and os.path.exists(path):
-        z = np.load(path)
-        ub, uo, pb, po = z["ub"], z["uo"], z["pb"], z["po"]
-        units = [ub[uo[i]:uo[i + 1]].tobytes() for i in range(n_distinct)]
-        plains = [pb[po[i]:po[i + 1]].tobytes() for i in range(n_distinct)]
-        return units, plains
+        try:
+            z = np.load(path)
+            ub, uo, pb, po = z["ub"], z["uo"], z["pb"], z["po"]
+            units = [ub[uo[i]:uo[i + 1]].tobytes() for i in range(n_distinct)]
+            plains = [pb[po[i]:po[i + 1]].tobytes() for i in range(n_distinct)]
+            return units, plains
+        except Exception:
+            pass  # a damaged cache file (interrupted writer): rebuild below
     gen = PAYLOADS[payload]
     enc = {"deflate": deflate_raw, "gzip": gzip_member, "lz4_block": lz4_block, "bzip2": bzip2_stream,
            "lzma2": lzma2_raw}[kind]
@@ -269,8 +272,10 @@ def build_units(kind, n_distinct, unit_size, payload="text", seed=2, cache=True)
     if cache:
         uo = np.cumsum([0] + [len(u) for u in units])
         po = np.cumsum([0] + [len(p) for p in plains])
-        np.savez(path, ub=np.frombuffer(b"".join(units), dtype=np.uint8), uo=uo,
+        tmp = "%s.%d.tmp.npz" % (path[:-4], os.getpid())   # written aside and renamed: concurrent ranks never see half a file
+        np.savez(tmp, ub=np.frombuffer(b"".join(units), dtype=np.uint8), uo=uo,
                  pb=np.frombuffer(b"".join(plains), dtype=np.uint8), po=po)
+        os.replace(tmp, path)
     return units, plains
 
 
