@@ -52,7 +52,9 @@ static hipError_t launch_codec(int codec, Job* jobs, size_t n, void* ws, size_t 
 }
 
 static size_t default_cap(int codec, const HostUnit& u) {
-    if (u.cap_hint) return u.cap_hint;
+    // A declared size is only a starting point (units that report SWC_E_CAPACITY are relaunched with more): a damaged
+    // size field must not turn into a terabyte allocation and an SWC_E_DEVICE for the whole batch.
+    if (u.cap_hint) return u.cap_exact ? u.cap_hint : std::min<size_t>(u.cap_hint, std::max<size_t>((size_t)64 << 20, u.in_len * 2048));
     switch (codec) {
         case SWC_CODEC_DEFLATE: return std::max<size_t>(65536, u.in_len * 4 + 1024);
         case SWC_CODEC_LZ4_BLOCK: return std::max<size_t>(65536, u.in_len * 4 + 1024);

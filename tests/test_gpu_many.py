@@ -119,6 +119,9 @@ def test_zip_damaged_entries_match_oracle():
     dl[hl[2]["data_offset"] + 4] = 230      # invalid LZMA properties byte
     dl[hl[3]["data_offset"] + 60] ^= 0x08
     assert ZipContainer.entries_data(bytes(dl), hl) == [O.zip_entry(bytes(dl), x) for x in hl]
+    # a damaged size field must not become a terabyte allocation: the declared size is only a starting capacity
+    huge = [dict(hl[1], uncomp_size=1 << 40), dict(hl[4], uncomp_size=(1 << 31) + 5)]
+    assert ZipContainer.entries_data(lz, huge) == [O.zip_entry(lz, x) for x in huge]
     # ZipContainer.open raises wrongCRC carrying the entries so far (ZipContainer.swift:52-53)
     bad = bytearray(c)
     cd = bad.rfind(b"PK\x01\x02")
