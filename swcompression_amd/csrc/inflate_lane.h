@@ -693,13 +693,18 @@ struct Lane {
     SWC_HD static bool uni(bool x) { return uni((uint32_t)x) != 0; }
 
     // Returns true when the end-of-block symbol was consumed; false: the caller decodes one symbol with careful_step().
+    // Inside the loop the positions are 32-bit scalars (the caller guarantees cap < 2^32) and everything that needs more
+    // than one store -- a literal run of 255+ in front of a match, the last bytes below the capacity -- is left to the
+    // checked step, so that a hop is a handful of scalar instructions.
     SWC_HD bool wave_loop() {
         if (!luts_ready) build_luts();
         uint64_t P = uni(br.consumed_bits());
-        pos = uni(pos); nlit = uni(nlit); last_end = uni(last_end); nrec = uni(nrec);
         stage_base = uni(stage_base); stage_len = uni(stage_len);
-        bool eob = false;
-        for (;;) {
+        uint32_t p = uni((uint32_t)pos), nl = uni((uint32_t)nlit), le = uni((uint32_t)last_end), nr = uni(nrec);
+        const uint32_t lim = uni((uint32_t)cap);   // symbols that start at or beyond cap - 258 go to the checked step
+        const uint32_t safe = lim >= 258u ? lim - 258u : 0u;
+        bool eob = false, stop = false;
+        while (!eob && !stop) {
             // the 64 views need input up to bit P + 63 + 64
             const uint32_t first = (uint32_t)(P >> 3), last = (uint32_t)((P + 63) >> 3) + 8;
             if ((uint64_t)last > br.len) break;                     // tail of the stream: checked steps
@@ -708,8 +713,8 @@ struct Lane {
 #if defined(__HIP_DEVICE_COMPILE__)
             uint32_t my_l, my_d;
             wave_views(P + (uint64_t)wlane, my_l, my_d);
-            auto view_l = [&](uint32_t r) { return (uint32_t)__builtin_amdgcn_readlane((int)my_l, __builtin_amdgcn_readfirstlane((int)r)); };
-            auto view_d = [&](uint32_t r) { return (uint32_t)__builtin_amdgcn_readlane((int)my_d, __builtin_amdgcn_readfirstlane((int)r)); };
+            auto view_l = [&](uint32_t r) { return (uint32_t)__builtin_amdgcn_readlane((int)my_l, (int)r); };
+            auto view_d = [&](uint32_t r) { return (uint32_t)__builtin_amdgcn_readlane((int)my_d, (int)r); };
 #else
             uint32_t all_l[kWave], all_d[kWave];
             for (int k = 0; k < kWave; k++) wave_views(P + (uint64_t)k, all_l[k], all_d[k]);
@@ -717,34 +722,45 @@ struct Lane {
             auto view_d = [&](uint32_t r) { return all_d[r]; };
 #endif
             uint32_t rel = 0;
-            bool stop = false;
             for (;;) {
                 rel = uni(rel);
-                if (rel >= (uint32_t)kWave) break;
+                if (rel >= (uint32_t)kWave || p >= safe) { stop = p >= safe; break; }
                 const uint32_t a = view_l(rel);
                 const uint32_t kind = (a >> 5) & 3u, na = a & 31u, va = a >> 7;
                 if (kind == 1) {                       // literal
-                    put_byte((uint8_t)va);
+                    lits[nl] = (uint8_t)va;
+                    nl++;
+                    p++;
                     rel += na;
-                } else if (kind == 2) {                // length, then a distance code at rel + na
+                    continue;
+                }
+                if (kind == 2) {                       // length, then a distance code at rel + na
                     const uint32_t q = rel + na;
                     if (q >= (uint32_t)kWave) break;   // its distance code lies in the next window
                     const uint32_t b = view_d(q);
-                    if (uni(!((b >> 5) & 1u) || (uint64_t)(b >> 6) > pos)) { stop = true; break; }
-                    emit_match(va, b >> 6);
+                    const uint32_t dist = b >> 6, run = p - le;
+                    if (!((b >> 5) & 1u) || dist > p || run >= 255u) { stop = true; break; }
+                    if (nr < max_rec) recs[nr] = lzr::make_match(run, va, dist);
+                    nr++;
+                    p += va;
+                    le = p;
                     rel = q + (b & 31u);
-                } else if (kind == 3) {                // end of block
+                    continue;
+                }
+                if (kind == 3) {                       // end of block
                     rel += na;
                     eob = true;
-                    break;
-                } else {                               // not in the table
-                    stop = true;
-                    break;
+                } else {
+                    stop = true;                       // not in the table
                 }
+                break;
             }
             P += rel;
-            if (eob || stop) break;
         }
+        pos = (pos & ~0xFFFFFFFFull) | p;
+        nlit = (nlit & ~0xFFFFFFFFull) | nl;
+        last_end = (last_end & ~0xFFFFFFFFull) | le;
+        nrec = nr;
         br.seek(P);
         return eob;
     }
@@ -796,7 +812,7 @@ struct Lane {
         for (;;) {
             // the fast loop needs the upper halves of pos / last_end to be stable: both below 2^32 - 272 - 258
             if (wlane >= 0) {
-                if (!lit.oversub && !dist.oversub && wave_loop()) return SWC_OK;
+                if (!lit.oversub && !dist.oversub && cap <= 0xFFFFFFFFull && pos + 258 < cap && wave_loop()) return SWC_OK;
             } else if (fast_ok && pos + 272 <= cap && (uint64_t)br.ppos + 56 <= br.len) {
                 if (fast_loop()) return SWC_OK;
             }
