@@ -169,6 +169,32 @@ typedef struct swc_zip_entry {
 } swc_zip_entry;
 int swc_zip_get_entries_data(const uint8_t* container, size_t len, swc_zip_entry* entries, size_t n);
 
+/* SevenZipFolder.unpack(data:) (reference Sources/7-Zip/7zFolder.swift:138-194) for many folders at once.  The caller has
+ * parsed the archive header and hands over, per folder, its packed stream and the ORDERED coder chain (orderedCoders(),
+ * :88-97) with each coder's unpack size (unpackSize(for:), :129-136).  Folders are independent: stage k of all chains
+ * runs as one batched launch per codec.  method: 0 copy, 1 deflate, 2 bzip2, 3 LZMA2, 4 LZMA, 5 Delta (id 03),
+ * 6 LZ4 (id 04 F7 11 04), 7 an encryption method, 8 anything else.  Per folder: status (the codec's error,
+ * SWC_E_7Z_*), data (malloc()ed, swc_free; empty on error). */
+typedef struct swc_7z_coder {
+    uint32_t method;
+    uint8_t props[5];        /* coder.properties (LZMA2: 1 byte, LZMA: 5, Delta: 1)                          */
+    uint8_t props_len;       /* 0xFF = properties absent                                                     */
+    uint8_t multi_stream;    /* !(numInStreams == 1 || numOutStreams == 1), 7zFolder.swift:141               */
+    uint8_t pad;
+    uint64_t unpack_size;
+} swc_7z_coder;
+typedef struct swc_7z_folder {
+    const uint8_t* data;     /* IN : packed stream of the folder                                             */
+    size_t len;
+    const swc_7z_coder* coders;
+    size_t n_coders;
+    int32_t status;          /* OUT                                                                          */
+    int32_t pad;
+    uint8_t* out;            /* OUT                                                                          */
+    size_t out_len;
+} swc_7z_folder;
+int swc_7z_unpack_folders(swc_7z_folder* folders, size_t n);
+
 /* checksums used by the framing layer (CheckSums.swift:12-57, XxHash32.swift:24-83, Sha256.swift:28-142) */
 uint32_t swc_crc32(const uint8_t* p, size_t n, uint32_t prev);
 uint32_t swc_adler32(const uint8_t* p, size_t n);

@@ -90,6 +90,13 @@ typedef enum swc_status {
     SWC_E_ZIP_COMPRESSION_NOT_SUPPORTED = 852, /* :26 */
     SWC_E_ZIP_WRONG_CRC = 853,                 /* :34 carries the entries processed so far (raised by the caller from crc_error) */
 
+    /* SevenZipError -- Sources/7-Zip/7zError.swift:10-33 (only the cases SevenZipFolder.unpack can produce) */
+    SWC_E_7Z_WRONG_SIZE = 861,                /* :18 */
+    SWC_E_7Z_MULTI_STREAM_NOT_SUPPORTED = 862, /* :24 */
+    SWC_E_7Z_COMPRESSION_NOT_SUPPORTED = 863, /* :28 */
+    SWC_E_7Z_ENCRYPTION_NOT_SUPPORTED = 864,  /* :30 */
+    SWC_E_7Z_INTERNAL_STRUCTURE_ERROR = 865,  /* :32 */
+
     SWC_E_REF_TRAP = 900,
     SWC_E_CAPACITY = 901,
     SWC_E_DEVICE = 902,

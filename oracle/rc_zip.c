@@ -68,3 +68,58 @@ int refcpu_zip_get_entry_data(const uint8_t* d, size_t len, uint64_t data_offset
     *out = data; *out_len = n;
     return st;
 }
+
+/*
+ * SevenZipFolder.unpack(data:)   Sources/7-Zip/7zFolder.swift:138-194
+ * The archive header (coders, bind pairs, unpack sizes) is the caller's; it hands over the ORDERED coder chain.
+ * method: 0 copy, 1 deflate, 2 bzip2, 3 LZMA2, 4 LZMA, 5 Delta, 6 LZ4, 7 encryption, 8 other (as swc_7z_coder).
+ */
+
+int refcpu_7z_unpack_folder(const uint8_t* data, size_t len, const refcpu_7z_coder* coders, size_t n_coders, uint8_t** out, size_t* out_len) {
+    uint8_t* cur = (uint8_t*)malloc(len ? len : 1);
+    size_t cur_len = len;
+    memcpy(cur, data, len);
+    int st = SWC_OK;
+    for (size_t k = 0; k < n_coders && st == SWC_OK; k++) {
+        const refcpu_7z_coder* c = &coders[k];
+        if (c->multi_stream) { st = SWC_E_7Z_MULTI_STREAM_NOT_SUPPORTED; break; }      /* :141-142 */
+        uint8_t* next = NULL;
+        size_t next_len = 0, used = 0;
+        switch (c->method) {
+            case 0: continue;                                                          /* .copy :147-148 (no size check) */
+            case 1: st = refcpu_deflate_decompress(cur, cur_len, &next, &next_len, &used); break;      /* :149-150 */
+            case 2: st = refcpu_bzip2_decompress(cur, cur_len, &next, &next_len, &used); break;        /* :151-152 */
+            case 3:                                                                                    /* :153-159 */
+                if (c->props_len != 1) { st = SWC_E_LZMA2_WRONG_DICTIONARY_SIZE; break; }
+                st = refcpu_lzma2_decompress(cur, cur_len, c->props[0], &next, &next_len, &used);
+                break;
+            case 4: {                                                                                  /* :160-173 */
+                if (c->props_len != 5) { st = SWC_E_LZMA_WRONG_PROPERTIES; break; }
+                unsigned b = c->props[0];
+                if (b >= 225) { st = SWC_E_LZMA_WRONG_PROPERTIES; break; }
+                int64_t dict = (int64_t)((uint32_t)c->props[1] | (uint32_t)c->props[2] << 8 | (uint32_t)c->props[3] << 16 | (uint32_t)c->props[4] << 24);
+                st = refcpu_lzma_decompress(cur, cur_len, (int)(b % 9), (int)((b / 9) % 5), (int)((b / 9) / 5), dict, (int64_t)c->unpack_size,
+                                            &next, &next_len, &used);
+                break;
+            }
+            case 5:                                                                                    /* :175-181 */
+                if (c->props_len != 1) { st = SWC_E_7Z_INTERNAL_STRUCTURE_ERROR; break; }
+                next = (uint8_t*)malloc(cur_len ? cur_len : 1);
+                next_len = cur_len;
+                refcpu_delta_decode(cur, cur_len, (int)(uint8_t)(c->props[0] + 1), next);
+                break;
+            case 6: st = refcpu_lz4_decompress(cur, cur_len, NULL, 0, -1, &next, &next_len, &used); break;  /* :182-183 */
+            case 7: st = SWC_E_7Z_ENCRYPTION_NOT_SUPPORTED; break;                                     /* :185 */
+            default: st = SWC_E_7Z_COMPRESSION_NOT_SUPPORTED;                                          /* :187 */
+        }
+        if (st == SWC_OK && next_len != c->unpack_size) st = SWC_E_7Z_WRONG_SIZE;                       /* :190-191 */
+        if (st != SWC_OK) { refcpu_free(next); break; }
+        refcpu_free(cur);
+        cur = next;
+        cur_len = next_len;
+    }
+    if (st != SWC_OK) { refcpu_free(cur); cur = (uint8_t*)malloc(1); cur_len = 0; }
+    *out = cur;
+    *out_len = cur_len;
+    return st;
+}

@@ -93,6 +93,18 @@ int refcpu_zip_get_entry_data(const uint8_t* d, size_t len, uint64_t data_offset
                               uint32_t crc32, int method, int has_data_descriptor, int zip64, uint8_t** out, size_t* out_len,
                               int* crc_error);
 
+/* ---- 7-Zip folder (Sources/7-Zip/7zFolder.swift:138-194): the ORDERED coder chain with each coder's unpack size.
+ * method: 0 copy, 1 deflate, 2 bzip2, 3 LZMA2, 4 LZMA, 5 Delta, 6 LZ4, 7 encryption, 8 other (layout == swc_7z_coder) */
+typedef struct refcpu_7z_coder {
+    uint32_t method;
+    uint8_t props[5];
+    uint8_t props_len;    /* 0xFF = absent */
+    uint8_t multi_stream;
+    uint8_t pad;
+    uint64_t unpack_size;
+} refcpu_7z_coder;
+int refcpu_7z_unpack_folder(const uint8_t* data, size_t len, const refcpu_7z_coder* coders, size_t n_coders, uint8_t** out, size_t* out_len);
+
 /* ---- timing harness (rc_pool.c): one independent unit per task over `threads` threads for `seconds` */
 double refcpu_timed_pool(int codec, int aux, const uint8_t* const* ins, const size_t* lens, size_t n, int threads,
                          double seconds, uint64_t* out_bytes, uint64_t* in_bytes, uint64_t* units);

@@ -24,7 +24,7 @@ from ._lib import SwcJob, SwcBatchOpts
 
 __all__ = ["Deflate", "GzipArchive", "ZlibArchive", "BZip2", "LZMA", "LZMA2", "LZMAProperties", "XZArchive", "LZ4",
            "SWCError", "DeflateError", "GzipError", "ZlibError", "BZip2Error", "LZMAError", "LZMA2Error", "XZError",
-           "DataError", "ZipError", "ReferenceTrap", "DeviceError", "device_available", "STATUS", "unarchive_many"]
+           "DataError", "ZipError", "SevenZipError", "ReferenceTrap", "DeviceError", "device_available", "STATUS", "unarchive_many"]
 
 # status code -> (exception family, Swift case name); numeric values from include/swc_status.h
 STATUS = {
@@ -49,6 +49,9 @@ STATUS = {
     805: ("XZError", "checkTypeSHA256"), 806: ("XZError", "wrongDataSize"), 807: ("XZError", "wrongCheck"),
     808: ("XZError", "wrongPadding"), 809: ("XZError", "multiByteIntegerError"),
     851: ("ZipError", "wrongSize"), 852: ("ZipError", "compressionNotSupported"), 853: ("ZipError", "wrongCRC"),
+    861: ("SevenZipError", "wrongSize"), 862: ("SevenZipError", "multiStreamNotSupported"),
+    863: ("SevenZipError", "compressionNotSupported"), 864: ("SevenZipError", "encryptionNotSupported"),
+    865: ("SevenZipError", "internalStructureError"),
     900: ("ReferenceTrap", "trap"), 901: ("SWCError", "capacity"), 902: ("DeviceError", "device"),
     903: ("SWCError", "invalidArgument"), 904: ("SWCError", "needWorkspace"),
 }
@@ -72,6 +75,7 @@ class LZMA2Error(SWCError): pass
 class XZError(SWCError): pass
 class DataError(SWCError): pass
 class ZipError(SWCError): pass
+class SevenZipError(SWCError): pass
 class ReferenceTrap(SWCError):
     """Input on which the Swift reference would hit a runtime trap (abort)."""
 class DeviceError(SWCError):
@@ -79,7 +83,7 @@ class DeviceError(SWCError):
 
 
 _FAMILIES = {c.__name__: c for c in (SWCError, DeflateError, GzipError, ZlibError, BZip2Error, LZMAError, LZMA2Error,
-                                     XZError, DataError, ZipError, ReferenceTrap, DeviceError)}
+                                     XZError, DataError, ZipError, SevenZipError, ReferenceTrap, DeviceError)}
 _CARRIES_DATA = {210, 503, 605, 705, 807, 853}
 
 

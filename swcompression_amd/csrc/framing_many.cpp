@@ -275,4 +275,118 @@ int swc_zip_get_entries_data(const uint8_t* container, size_t len, swc_zip_entry
     return SWC_OK;
 }
 
+// SevenZipFolder.unpack(data:) for many folders (reference Sources/7-Zip/7zFolder.swift:138-194).  Stage k of every
+// chain that is still alive is decoded together: one run_units launch per codec and stage.
+int swc_7z_unpack_folders(swc_7z_folder* folders, size_t n) {
+    if (n && !folders) return SWC_E_INVALID_ARGUMENT;
+    size_t max_chain = 0;
+    for (size_t i = 0; i < n; i++) {
+        if ((folders[i].len && !folders[i].data) || (folders[i].n_coders && !folders[i].coders)) return SWC_E_INVALID_ARGUMENT;
+        max_chain = std::max(max_chain, folders[i].n_coders);
+        folders[i].status = SWC_OK; folders[i].out = nullptr; folders[i].out_len = 0;
+    }
+    if (!device_ready()) return SWC_E_DEVICE;
+    std::vector<Result> cur(n);          // decodedData of :139; stage 0 reads the packed stream itself
+    std::vector<char> own(n, 0);         // cur[i].data holds the data (else: still the caller's buffer)
+    auto in_ptr = [&](size_t i) { return own[i] ? cur[i].data.data() : folders[i].data; };
+    auto in_len = [&](size_t i) { return own[i] ? cur[i].data.size() : folders[i].len; };
+    for (size_t stage = 0; stage < max_chain; stage++) {
+        std::vector<size_t> by_method[7];
+        for (size_t i = 0; i < n; i++) {
+            if (cur[i].status != SWC_OK || stage >= folders[i].n_coders) continue;
+            const swc_7z_coder& c = folders[i].coders[stage];
+            if (c.multi_stream) { cur[i].status = SWC_E_7Z_MULTI_STREAM_NOT_SUPPORTED; continue; }          // :141-142
+            switch (c.method) {
+                case 0: break;                                                                             // .copy: continue (:147-148), no size check
+                case 1: case 2: case 6: by_method[c.method].push_back(i); break;
+                case 3: if (c.props_len != 1) cur[i].status = SWC_E_LZMA2_WRONG_DICTIONARY_SIZE;            // :155-157
+                        else by_method[3].push_back(i);
+                        break;
+                case 4: if (c.props_len != 5) cur[i].status = SWC_E_LZMA_WRONG_PROPERTIES;                  // :162-164
+                        else if (c.props[0] >= 225) cur[i].status = SWC_E_LZMA_WRONG_PROPERTIES;            // LZMAProperties.swift:51
+                        else by_method[4].push_back(i);
+                        break;
+                case 5: if (c.props_len != 1) cur[i].status = SWC_E_7Z_INTERNAL_STRUCTURE_ERROR;            // :177-179
+                        else by_method[5].push_back(i);
+                        break;
+                case 7: cur[i].status = SWC_E_7Z_ENCRYPTION_NOT_SUPPORTED; break;                           // :185
+                default: cur[i].status = SWC_E_7Z_COMPRESSION_NOT_SUPPORTED;                                // :187
+            }
+        }
+        std::vector<Result> next(n);
+        std::vector<char> done(n, 0);
+        // Deflate / LZMA2 / LZMA: one unit per folder
+        for (int m : {1, 3, 4}) {
+            const std::vector<size_t>& idx = by_method[m];
+            if (idx.empty()) continue;
+            std::vector<HostUnit> units(idx.size());
+            for (size_t k = 0; k < idx.size(); k++) {
+                const size_t i = idx[k];
+                const swc_7z_coder& c = folders[i].coders[stage];
+                HostUnit& u = units[k];
+                u.in = in_ptr(i); u.in_len = in_len(i);
+                u.cap_hint = std::max<size_t>((size_t)c.unpack_size + 16, 64);
+                if (m == 3) u.aux = c.props[0];
+                if (m == 4) {
+                    const uint32_t b = c.props[0];
+                    u.aux = (int32_t)((b % 9) | (((b / 9) % 5) << 8) | (((b / 9) / 5) << 16));
+                    u.extra = c.unpack_size;                                                               // uncompressedSize: unpackSize :172
+                    u.dict_value = (uint64_t)c.props[1] | (uint64_t)c.props[2] << 8 | (uint64_t)c.props[3] << 16 | (uint64_t)c.props[4] << 24;
+                }
+            }
+            if (run_units(m == 1 ? SWC_CODEC_DEFLATE : m == 3 ? SWC_CODEC_LZMA2 : SWC_CODEC_LZMA, units) != SWC_OK) return SWC_E_DEVICE;
+            for (size_t k = 0; k < idx.size(); k++) {
+                next[idx[k]].status = units[k].status;
+                if (!units[k].status) next[idx[k]].data = std::move(units[k].out);
+                done[idx[k]] = 1;
+            }
+        }
+        // BZip2 / LZ4: block discovery per folder, shared launch (the many-archive paths above)
+        for (int m : {2, 6}) {
+            const std::vector<size_t>& idx = by_method[m];
+            if (idx.empty()) continue;
+            std::vector<const uint8_t*> ptrs(idx.size());
+            std::vector<size_t> lens(idx.size());
+            for (size_t k = 0; k < idx.size(); k++) { ptrs[k] = in_ptr(idx[k]); lens[k] = in_len(idx[k]); }
+            std::vector<Result> r(idx.size());
+            const int st = m == 2 ? many_bzip2(ptrs.data(), lens.data(), idx.size(), r) : many_lz4(ptrs.data(), lens.data(), idx.size(), r);
+            if (st) return st;
+            for (size_t k = 0; k < idx.size(); k++) {
+                if (r[k].status) r[k].data.clear();          // errors thrown out of unpack() carry nothing here
+                next[idx[k]] = std::move(r[k]);
+                done[idx[k]] = 1;
+            }
+        }
+        // Delta filter (DeltaFilter.swift:11-33) on the host
+        for (size_t i : by_method[5]) {
+            const int distance = (uint8_t)(folders[i].coders[stage].props[0] + 1);                          // properties[0] &+ 1 (:181)
+            const uint8_t* src = in_ptr(i);
+            const size_t len = in_len(i);
+            uint8_t delta[256] = {0};
+            int pos = 0;
+            next[i].data.resize(len);
+            for (size_t k = 0; k < len; k++) {
+                const uint8_t tmp = (uint8_t)(src[k] + delta[(distance + pos) % 256]);
+                delta[pos] = tmp;
+                next[i].data[k] = tmp;
+                pos = pos == 0 ? 255 : pos - 1;
+            }
+            done[i] = 1;
+        }
+        for (size_t i = 0; i < n; i++) {
+            if (!done[i]) continue;
+            if (next[i].status == SWC_OK && next[i].data.size() != folders[i].coders[stage].unpack_size) next[i].status = SWC_E_7Z_WRONG_SIZE;  // :190-191
+            cur[i] = std::move(next[i]);
+            own[i] = 1;
+        }
+    }
+    for (size_t i = 0; i < n; i++) {
+        folders[i].status = cur[i].status;
+        if (cur[i].status != SWC_OK) { give_empty(&folders[i].out, &folders[i].out_len); continue; }
+        if (own[i]) give(cur[i].data, &folders[i].out, &folders[i].out_len);
+        else { std::vector<uint8_t> copy(folders[i].data, folders[i].data + folders[i].len); give(copy, &folders[i].out, &folders[i].out_len); }
+    }
+    return SWC_OK;
+}
+
 }  // extern "C"

@@ -210,3 +210,15 @@ def zip_entry(container, h):
     st = lib.refcpu_zip_get_entry_data(bytes(container), len(container), h["data_offset"], h["comp_size"], h["uncomp_size"], h["crc32"],
                                        h["method"], int(h["has_data_descriptor"]), int(h["zip64"]), C.byref(out), C.byref(n), C.byref(ce))
     return st, bool(ce.value), _take(out, n.value)
+
+
+def sevenzip_folder(data, chain):
+    """SevenZipFolder.unpack(data:) for one folder; chain as for swcompression_amd.sevenzip.coder_array.  -> (status, bytes)"""
+    from swcompression_amd.sevenzip import coder_array
+    ca = coder_array(chain)
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    lib.refcpu_7z_unpack_folder.restype = C.c_int
+    lib.refcpu_7z_unpack_folder.argtypes = [C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.POINTER(C.POINTER(C.c_uint8)), C.POINTER(C.c_size_t)]
+    st = lib.refcpu_7z_unpack_folder(bytes(data), len(data), ca, len(chain), C.byref(out), C.byref(n))
+    return st, _take(out, n.value)
