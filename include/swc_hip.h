@@ -40,7 +40,9 @@ typedef enum swc_codec {
     SWC_CODEC_LZ4_BLOCK = 2, /* one LZ4 block           -- LZ4.process(block:_:)    LZ4.swift:332-413        */
     SWC_CODEC_LZMA2 = 3,   /* raw LZMA2 chunk stream   -- LZMA2Decoder.decode()    LZMA2Decoder.swift:34-99 */
     SWC_CODEC_LZMA = 4,    /* raw LZMA1 stream         -- LZMADecoder.decode()     LZMADecoder.swift:107-284*/
-    SWC_CODEC_BZIP2_BLOCK = 5 /* one bzip2 block body  -- BZip2.decode(_:_:)       BZip2.swift:97-270       */
+    SWC_CODEC_BZIP2_BLOCK = 5, /* one bzip2 block body -- BZip2.decode(_:_:)       BZip2.swift:97-270       */
+    SWC_CODEC_DELTA = 6    /* XZ / 7-Zip Delta filter  -- DeltaFilter.decode(_:_:) DeltaFilter.swift:11-33; aux = distance as the
+                              reference passes it (XZBlock.swift:57: property + 1), out may equal in            */
 } swc_codec;
 
 typedef struct swc_job {

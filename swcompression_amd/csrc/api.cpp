@@ -47,6 +47,7 @@ static hipError_t launch_codec(int codec, Job* jobs, size_t n, void* ws, size_t 
         case SWC_CODEC_LZMA2: return launch_lzma(true, jobs, n, ws_bytes >= n * lzma_spill_bytes_per_job() ? ws : nullptr, stream);
         case SWC_CODEC_LZMA: return launch_lzma(false, jobs, n, ws_bytes >= n * lzma_spill_bytes_per_job() ? ws : nullptr, stream);
         case SWC_CODEC_BZIP2_BLOCK: return launch_bzip2(jobs, n, ws, ws_bytes, stream);
+        case SWC_CODEC_DELTA: return launch_delta(jobs, n, stream);
         default: return hipErrorInvalidValue;
     }
 }

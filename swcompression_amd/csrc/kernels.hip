@@ -17,6 +17,7 @@
 #include "bzip2_block.h"
 #include "crc32_group.h"
 #include "checksum_group.h"
+#include "delta_group.h"
 #include "launch.h"
 
 namespace swc {
@@ -349,6 +350,27 @@ __global__ __launch_bounds__(64) void swc_xxh32_kernel(const Job* __restrict__ j
     };
     const uint32_t h = sums::xxh32_quad(out, len, 0u, j, quad_get);
     if (live && j == 0) sums[g] = h;
+}
+
+// ---- Delta filter, one stream per 256-thread workgroup ------------------------------------------
+__global__ __launch_bounds__(256) void swc_delta_kernel(Job* __restrict__ jobs, uint32_t n) {
+    __shared__ delta::Lds<256> lds;
+    uint32_t g = blockIdx.x;
+    if (g >= n) return;
+    Job job = jobs[g];
+    const bool fits = job.in_len <= job.out_cap;
+    if (fits) delta::delta_group<256>((gcptr)job.in, (gptr)job.out, job.in_len, (uint32_t)job.aux, &lds, (int)threadIdx.x);
+    if (threadIdx.x == 0) {
+        jobs[g].out_len = job.in_len;
+        jobs[g].in_consumed = job.in_len;
+        jobs[g].status = fits ? SWC_OK : SWC_E_CAPACITY;
+    }
+}
+
+hipError_t launch_delta(Job* jobs, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(swc_delta_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, (uint32_t)n);
+    return hipGetLastError();
 }
 
 hipError_t launch_checksum(int kind, const Job* jobs, size_t n, uint64_t* sums, hipStream_t stream) {

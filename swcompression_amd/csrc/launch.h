@@ -7,6 +7,7 @@ namespace swc {
 hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream);
 size_t inflate_ws_bytes_per_job(uint64_t cap);
 hipError_t launch_crc32(const Job* jobs, size_t n, uint32_t* crcs, hipStream_t stream);
+hipError_t launch_delta(Job* jobs, size_t n, hipStream_t stream);
 hipError_t launch_checksum(int kind, const Job* jobs, size_t n, uint64_t* sums, hipStream_t stream);
 void set_resolve_threads(int t);
 void set_inflate_wave_max_jobs(int n);

@@ -103,3 +103,19 @@ def checksum(kind, data, misalign=0):
     base = (C.addressof(buf) + 63) // 64 * 64 + misalign
     C.memmove(base, data, len(data))
     return lib.emu_checksum(kind, base, len(data))
+
+
+lib.emu_delta.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_uint]
+lib.emu_delta.restype = None
+
+
+def delta(data, distance, in_place=False):
+    """DeltaFilter.decode by the device group code (256 host threads).  distance as the reference passes it (0..255)."""
+    data = bytes(data)
+    if in_place:
+        buf = C.create_string_buffer(data, max(len(data), 1))
+        lib.emu_delta(C.cast(buf, C.c_char_p), C.cast(buf, C.c_void_p), len(data), distance)
+        return buf.raw[:len(data)]
+    out = C.create_string_buffer(max(len(data), 1))
+    lib.emu_delta(data, C.cast(out, C.c_void_p), len(data), distance)
+    return out.raw[:len(data)]

@@ -158,3 +158,11 @@ extern "C" uint64_t emu_checksum(int kind, const uint8_t* p, size_t n) {
     }
     return 0;
 }
+
+// Delta filter: the group kernel with T real host threads (same barrier plumbing as the checksums)
+#include "../../swcompression_amd/csrc/delta_group.h"
+extern "C" void emu_delta(const uint8_t* in, uint8_t* out, size_t n, unsigned distance) {
+    constexpr int T = 256;
+    static swc::delta::Lds<T> l;
+    run_group<T>([&](int t) { swc::delta::delta_group<T>(in, out, n, distance, &l, t); return (uint64_t)0; });
+}

@@ -42,3 +42,19 @@ def test_unaligned_starts():
         for kind in sorted(ORACLE):
             p = base[off:off + 66000 + off]
             assert E.checksum(kind, p, misalign=off) == ORACLE[kind](p)
+
+
+def test_delta_filter_group_matches_oracle():
+    """delta_group.h against the oracle's restatement of DeltaFilter.swift:11-33: every distance class the
+    scan treats differently (1 chunk per class .. 256 chunks per class), lengths around the chunking, in place."""
+    import ctypes as C
+    rng = np.random.Generator(np.random.PCG64(0x5C0DE + 79))
+    O.lib.refcpu_delta_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p]
+    O.lib.refcpu_delta_decode.restype = None
+    for n in (0, 1, 2, 255, 256, 257, 1000, 65536, 100003):
+        x = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        for dist in (0, 1, 2, 3, 4, 7, 64, 100, 128, 129, 255):
+            want = C.create_string_buffer(max(n, 1))
+            O.lib.refcpu_delta_decode(x, n, dist, C.cast(want, C.c_void_p))
+            assert E.delta(x, dist) == want.raw[:n], (n, dist)
+            assert E.delta(x, dist, in_place=True) == want.raw[:n], (n, dist)

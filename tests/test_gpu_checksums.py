@@ -51,3 +51,46 @@ def test_invalid_kind_is_rejected():
     with pytest.raises(KeyError):
         b.checksum("md5")
     assert b.lib.swc_batch_checksum(99, b.d_jobs.data_ptr(), 1, b.d_jobs.data_ptr(), None) == 903   # SWC_E_INVALID_ARGUMENT
+
+
+def test_delta_filter_codec():
+    """SWC_CODEC_DELTA (DeltaFilter.swift:11-33) through the batch API: every distance, awkward lengths, and in place."""
+    import ctypes as C
+    import _sevenzip as Z7
+    O.lib.refcpu_delta_decode.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_void_p]
+    O.lib.refcpu_delta_decode.restype = None
+    rng = np.random.Generator(np.random.PCG64(0x5C0DE + 93))
+    units, dists = [], []
+    for dist in list(range(0, 256, 7)) + [1, 2, 3, 4, 255]:
+        n = int(rng.choice([0, 1, 255, 256, 257, 5000, 65536, 300001]))
+        units.append(rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+        dists.append(dist)
+    x = corpus.p_text(200000, 5)
+    units.append(Z7.delta_encode(x, 4)); dists.append(4)          # the encoder's inverse: decode gives the text back
+    b = DeviceBatch("delta", units, [max(len(u), 1) for u in units], aux=dists)
+    b.launch(sync=True)
+    r = b.results()
+    assert (r["status"] == 0).all() and (r["out_len"] == [len(u) for u in units]).all()
+    for i, (u, d) in enumerate(zip(units, dists)):
+        want = C.create_string_buffer(max(len(u), 1))
+        O.lib.refcpu_delta_decode(u, len(u), d, C.cast(want, C.c_void_p))
+        assert b.output(i, len(u)) == want.raw[:len(u)], (len(u), d)
+    assert b.output(len(units) - 1, len(x)) == x
+    # in place: out == in (the encoded bytes are put where the outputs were, then decoded over themselves)
+    import torch
+    jobs = b.results().copy()
+    host = b.d_out.cpu().numpy().copy()
+    base = b.d_out.data_ptr()
+    for i, u in enumerate(units):
+        off = int(jobs["out"][i]) - base
+        host[off:off + len(u)] = np.frombuffer(u, dtype=np.uint8)
+    b.d_out.copy_(torch.from_numpy(host))
+    jobs["in"] = jobs["out"]
+    jobs["status"] = 902
+    b.d_jobs.copy_(torch.from_numpy(jobs.view(np.uint8).copy()))
+    b.launch(sync=True)
+    assert (b.results()["status"] == 0).all()
+    for i, (u, d) in enumerate(zip(units, dists)):
+        want = C.create_string_buffer(max(len(u), 1))
+        O.lib.refcpu_delta_decode(u, len(u), d, C.cast(want, C.c_void_p))
+        assert b.output(i, len(u)) == want.raw[:len(u)], ("in place", len(u), d)
