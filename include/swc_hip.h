@@ -149,6 +149,24 @@ int swc_xz_split_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size
 int swc_unarchive_many(int kind, const uint8_t* const* archives, const size_t* lens, size_t n,
                        uint8_t** outs, size_t* out_lens, int32_t* statuses);
 
+/* Block discovery on the host, as a library call (no device needed) -- what swc_unarchive_many / the multi-member entry
+ * points use internally, for callers that stage their data on the device themselves:
+ *   kind 1  BGZF: every gzip member that carries the 'BC' extra field (GzipHeader.swift:110-156): offset / comp_len of its
+ *           Deflate stream, uncomp_len = ISIZE.  SWC_E_INVALID_ARGUMENT if a member lacks the field.
+ *   kind 4  LZ4 frame (LZ4.swift:278-299): the blocks of the frame the buffer opens with; aux = 1 for stored blocks.
+ *   kind 5  bzip2: every BIT offset of the 48-bit block magic (BZip2.swift:74-88) -- candidates, a magic may occur in data.
+ *   kind 6  xz: the LZMA2-only blocks listed by the index of every stream (XZArchive.swift:132-192 read backwards):
+ *           offset / comp_len of the LZMA2 data, uncomp_len, aux = dictionary-size byte.
+ * *n receives the number found; up to `cap` are written. */
+typedef struct swc_block_ref {
+    uint64_t offset;      /* bytes from `in` (kind 5: bits) */
+    uint64_t comp_len;
+    uint64_t uncomp_len;  /* 0 = not known from the framing */
+    uint32_t aux;
+    uint32_t pad;
+} swc_block_ref;
+int swc_index_blocks(int kind, const uint8_t* in, size_t len, swc_block_ref* refs, size_t cap, size_t* n);
+
 /* ZipContainer.getEntryData (reference Sources/ZIP/ZipContainer.swift:61-118) for all entries of one container: every
  * entry is an independent stream whose location and sizes the caller already has from the central directory
  * (ZipEntryInfoHelper.swift:22-44), so the Deflate (8) and LZMA (14) entries go to the device as ONE batch each; stored (0)

@@ -24,7 +24,7 @@ from ._lib import SwcJob, SwcBatchOpts
 
 __all__ = ["Deflate", "GzipArchive", "ZlibArchive", "BZip2", "LZMA", "LZMA2", "LZMAProperties", "XZArchive", "LZ4",
            "SWCError", "DeflateError", "GzipError", "ZlibError", "BZip2Error", "LZMAError", "LZMA2Error", "XZError",
-           "DataError", "ZipError", "SevenZipError", "ReferenceTrap", "DeviceError", "device_available", "STATUS", "unarchive_many"]
+           "DataError", "ZipError", "SevenZipError", "ReferenceTrap", "DeviceError", "device_available", "STATUS", "unarchive_many", "index_blocks"]
 
 # status code -> (exception family, Swift case name); numeric values from include/swc_status.h
 STATUS = {
@@ -257,3 +257,24 @@ def unarchive_many(kind, archives):
     if rc:
         _raise(rc)
     return [(sts[i], _take(outs[i], out_lens[i])) for i in range(n)]
+
+
+class SwcBlockRef(C.Structure):
+    _fields_ = [("offset", C.c_uint64), ("comp_len", C.c_uint64), ("uncomp_len", C.c_uint64), ("aux", C.c_uint32), ("pad", C.c_uint32)]
+
+
+def index_blocks(kind, data):
+    """Host block discovery (swc_index_blocks; no device needed).  kind: 'bgzf' | 'lz4' | 'bzip2' | 'xz'.
+    Returns [(offset, comp_len, uncomp_len, aux)]; offsets are bytes from the start (bzip2: bits)."""
+    kinds = {"bgzf": 1, "lz4": 4, "bzip2": 5, "xz": 6}
+    lib = _lib.load()
+    data = bytes(data)
+    n = C.c_size_t()
+    st = lib.swc_index_blocks(kinds[kind], data, len(data), None, 0, C.byref(n))
+    if st:
+        _raise(st)
+    refs = (SwcBlockRef * max(n.value, 1))()
+    st = lib.swc_index_blocks(kinds[kind], data, len(data), refs, n.value, C.byref(n))
+    if st:
+        _raise(st)
+    return [(r.offset, r.comp_len, r.uncomp_len, r.aux) for r in refs[:n.value]]

@@ -91,6 +91,13 @@ int walk_stream(const uint8_t* d, size_t n, size_t& byte_pos, const std::map<uin
 
 }  // namespace
 
+// Every bit offset at which the block magic occurs (candidates: a magic inside block data is possible).
+void bzip2_magic_index(const uint8_t* in, size_t in_len, std::vector<BlockRef64>& out) {
+    std::vector<uint64_t> cand;
+    scan_block_magics(in, in_len, 32, cand);
+    for (uint64_t c : cand) out.push_back({c, 0, 0, 0});
+}
+
 // Units for every candidate block of `d` (appended to `units`; `used` receives their bit offsets).
 void bzip2_collect_candidates(const uint8_t* d, size_t n, std::vector<HostUnit>& units, std::vector<uint64_t>& used) {
     std::vector<uint64_t> cand;

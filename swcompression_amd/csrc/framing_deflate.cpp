@@ -170,8 +170,76 @@ int swc_gzip_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* 
     return crc_error ? SWC_E_GZIP_WRONG_CRC : SWC_OK;
 }
 
+// BGZF (and any multi-member gzip whose members carry the 'BC' extra field): BSIZE = member size - 1 locates every member
+// without decoding, so ALL members go to the device in one batch.  The result is used only if every member decoded cleanly
+// from exactly the bytes its BSIZE assigns to it -- then the sequential walk of GzipArchive.multiUnarchive (:62-77) would have
+// met the same members at the same offsets; anything else (a member without the field, a decode error, a stream that ends
+// before or after its BSIZE, a CRC / ISIZE mismatch) falls back to that walk, which alone defines errors and partial results.
+}  // extern "C"
+namespace swc {
+// Every member of a BGZF file: offset / length of its Deflate stream and its ISIZE.  False if a member lacks the field.
+bool bgzf_index(const uint8_t* in, size_t in_len, std::vector<BlockRef64>& out) {
+    size_t pos = 0;
+    while (pos < in_len) {
+        if (in_len - pos < 20) return false;
+        size_t p = pos;
+        GzipHeaderInfo info;
+        if (gzip_parse_header(in, in_len, p, &info) != SWC_OK || info.bgzf_bsize == 0) return false;
+        const size_t total = (size_t)info.bgzf_bsize + 1;
+        if (total > in_len - pos || p - pos + 8 > total) return false;
+        const uint8_t* t = in + pos + total - 8;
+        const uint32_t isize = (uint32_t)t[4] | (uint32_t)t[5] << 8 | (uint32_t)t[6] << 16 | (uint32_t)t[7] << 24;
+        out.push_back({p, total - (p - pos) - 8, isize, 0});
+        pos += total;
+    }
+    return true;
+}
+}  // namespace swc
+extern "C" {
+static bool bgzf_multi(const uint8_t* in, size_t in_len, std::vector<uint8_t>& all, std::vector<size_t>& sz) {
+    struct Member { size_t data_pos, data_len, trailer; };
+    std::vector<Member> members;
+    {
+        std::vector<BlockRef64> refs;
+        if (!bgzf_index(in, in_len, refs)) return false;
+        for (const BlockRef64& r : refs) members.push_back({(size_t)r.offset, (size_t)r.comp_len, (size_t)(r.offset + r.comp_len)});
+    }
+    if (members.size() < 2) return false;
+    std::vector<HostUnit> units(members.size());
+    for (size_t k = 0; k < members.size(); k++) {
+        const uint8_t* t = in + members[k].trailer;
+        const uint32_t isize = (uint32_t)t[4] | (uint32_t)t[5] << 8 | (uint32_t)t[6] << 16 | (uint32_t)t[7] << 24;
+        units[k].in = in + members[k].data_pos;
+        units[k].in_len = members[k].data_len;
+        if ((uint64_t)isize <= (uint64_t)members[k].data_len * 1100 + 4096) units[k].cap_hint = std::max<size_t>(isize, 64);
+    }
+    if (run_units(SWC_CODEC_DEFLATE, units) != SWC_OK) return false;
+    for (size_t k = 0; k < members.size(); k++) {
+        const HostUnit& u = units[k];
+        if (u.status != SWC_OK || u.in_consumed != members[k].data_len) return false;
+        size_t next;
+        bool crc_error;
+        if (gzip_member_finish(in, in_len, members[k].data_pos, u, next, crc_error) != SWC_OK || crc_error) return false;
+    }
+    for (const HostUnit& u : units) {
+        all.insert(all.end(), u.out.begin(), u.out.end());
+        sz.push_back(u.out.size());
+    }
+    return true;
+}
+
 int swc_gzip_multi_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_members) {
     if (!out || !out_len || !sizes || !n_members || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
+    {
+        std::vector<uint8_t> fast;
+        std::vector<size_t> fsz;
+        if (bgzf_multi(in, in_len, fast, fsz)) {
+            give(fast, out, out_len);
+            *sizes = give_sizes(fsz);
+            *n_members = fsz.size();
+            return SWC_OK;
+        }
+    }
     // Plain multi-member gzip has no compressed-size field: member k+1 can only be located after
     // member k has been inflated, so members are discovered sequentially here.
     // (BGZF and many-archive batches go through swc_unarchive_many, which launches them together.)

@@ -237,6 +237,15 @@ int lz4_plan_finish(const uint8_t* in, size_t n, const Lz4Plan& plan, const std:
     return st;
 }
 
+// The blocks of the frame `in` opens with (offsets relative to `in`); aux = 1 for stored blocks.  False: not a standard frame.
+bool lz4_frame_index(const uint8_t* in, size_t in_len, std::vector<BlockRef64>& out) {
+    if (in_len < 4 || le32(in) != 0x184D2204u) return false;
+    FrameInfo fi;
+    if (frame_parse(in + 4, in_len - 4, false, -1, fi) != SWC_OK) return false;
+    for (const BlockRef& b : fi.blocks) out.push_back({(uint64_t)b.off + 4, (uint64_t)b.len, 0, b.compressed ? 0u : 1u});
+    return true;
+}
+
 }  // namespace swc
 
 using namespace swc;

@@ -9,6 +9,7 @@
 //   DeltaFilter.decode      reference Sources/Common/DeltaFilter.swift:11-33
 // Headers, index, footer, padding and checks are verified on the host; every LZMA2 block body is a
 // unit of the batched device launch.
+#include <algorithm>
 #include <map>
 #include <vector>
 #include "framing.h"
@@ -322,9 +323,8 @@ int xz_padding(Reader& r) {                                                     
 // depend on the bytes behind the block), and the sequential walk below -- which alone decides what the archive means --
 // picks it up when it arrives at the same offset with the same dictionary byte.  Anything inconsistent simply yields
 // no cache entry.
-void xz_predecode(const uint8_t* d, size_t n, BlockCache& cache) {
-    struct Cand { int64_t data_off; size_t len; int prop; };
-    std::vector<Cand> cands;
+struct Cand { int64_t data_off; size_t len; int prop; int64_t uncomp; };
+static void xz_candidates(const uint8_t* d, size_t n, std::vector<Cand>& cands) {
     int64_t end = (int64_t)n;
     for (int streams = 0; streams < 4096 && end >= 32; streams++) {
         while (end >= 4 && d[end - 1] == 0 && d[end - 2] == 0 && d[end - 3] == 0 && d[end - 4] == 0) end -= 4;   // stream padding
@@ -360,12 +360,17 @@ void xz_predecode(const uint8_t* d, size_t n, BlockCache& cache) {
                 if (d[pos + 1] & 0x80) good = good && !multibyte(h, tmp);
                 good = good && !multibyte(h, id) && id == 0x21 && !multibyte(h, ps) && ps == 1;
                 const int prop = h.u8();
-                if (good && !h.trap) cands.push_back({pos + hsize, (size_t)comp, prop});
+                if (good && !h.trap) cands.push_back({pos + hsize, (size_t)comp, prop, rc.second});
             }
             pos += (rc.first + 3) & ~(int64_t)3;
         }
         end = stream_start;
     }
+}
+
+void xz_predecode(const uint8_t* d, size_t n, BlockCache& cache) {
+    std::vector<Cand> cands;
+    xz_candidates(d, n, cands);
     if (cands.size() < 2) return;            // a single block gains nothing from being decoded ahead
     std::vector<HostUnit> units(cands.size());
     for (size_t k = 0; k < cands.size(); k++) {
@@ -402,6 +407,16 @@ int xz_run(const uint8_t* in, size_t in_len, std::vector<uint8_t>& all, std::vec
 }
 
 }  // namespace
+
+// The LZMA2-only blocks the index of every stream of the archive lists: offset / length of the LZMA2 data, uncompressed
+// size, aux = dictionary-size byte.  (Blocks with other filter chains are left out.)
+void xz_block_index(const uint8_t* in, size_t in_len, std::vector<BlockRef64>& out) {
+    std::vector<Cand> cands;
+    xz_candidates(in, in_len, cands);
+    for (const Cand& c : cands) out.push_back({(uint64_t)c.data_off, (uint64_t)c.len, (uint64_t)c.uncomp, (uint32_t)c.prop});
+    std::sort(out.begin(), out.end(), [](const BlockRef64& a, const BlockRef64& b) { return a.offset < b.offset; });
+}
+
 }  // namespace swc
 
 using namespace swc;

@@ -275,6 +275,25 @@ int swc_zip_get_entries_data(const uint8_t* container, size_t len, swc_zip_entry
     return SWC_OK;
 }
 
+// Host block discovery as a library call: what the batched entry points use internally, for callers
+// that keep their data on the device and build their own job lists.  No device needed.
+int swc_index_blocks(int kind, const uint8_t* in, size_t len, swc_block_ref* refs, size_t cap, size_t* n) {
+    if (!n || (len && !in) || (cap && !refs)) return SWC_E_INVALID_ARGUMENT;
+    std::vector<BlockRef64> v;
+    bool ok = true;
+    switch (kind) {
+        case 1: ok = bgzf_index(in, len, v); break;
+        case 4: ok = lz4_frame_index(in, len, v); break;
+        case 5: bzip2_magic_index(in, len, v); break;
+        case 6: xz_block_index(in, len, v); break;
+        default: return SWC_E_INVALID_ARGUMENT;
+    }
+    if (!ok) { *n = 0; return SWC_E_INVALID_ARGUMENT; }
+    *n = v.size();
+    for (size_t i = 0; i < v.size() && i < cap; i++) refs[i] = swc_block_ref{v[i].offset, v[i].comp_len, v[i].uncomp_len, v[i].aux, 0};
+    return SWC_OK;
+}
+
 // SevenZipFolder.unpack(data:) for many folders (reference Sources/7-Zip/7zFolder.swift:138-194).  Stage k of every
 // chain that is still alive is decoded together: one run_units launch per codec and stage.
 int swc_7z_unpack_folders(swc_7z_folder* folders, size_t n) {

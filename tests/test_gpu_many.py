@@ -3,6 +3,7 @@ archive kind and swc_zip_get_entries_data -- against the oracle's single-archive
 import struct
 import zipfile
 
+import numpy as np
 import pytest
 
 import _oracle as O
@@ -152,3 +153,38 @@ def test_7z_folders_one_call():
     with pytest.raises(swc.SevenZipError) as ei:
         SevenZipFolder.unpack(bad[0][1], bad[0][2])
     assert ei.value.case == "wrongSize"
+
+
+def test_bgzf_members_share_one_launch():
+    """GzipArchive.multiUnarchive (GzipArchive.swift:62-77) on BGZF data: the 'BC' extra field locates every member, so
+    they decode in one launch; damaged files fall back to the sequential walk and must match the oracle exactly."""
+    rng = np.random.Generator(np.random.PCG64(0x5C0DE + 95))
+    parts = [corpus.p_mix(int(rng.integers(1, 50000)), 7000 + i) for i in range(300)] + [b""]
+    members = [corpus.gzip_member(p, bgzf=True) for p in parts]
+    data = b"".join(members)
+    lib = _lib.load()
+    before = lib.swc_stat(b"launches")
+    assert swc.GzipArchive.multi_unarchive(data) == parts
+    assert lib.swc_stat(b"launches") - before <= 2, "BGZF members must share their launch"
+    assert O.gzip_multi_unarchive(data) == (0, parts)
+    # damaged variants: identical outcome to the oracle's strictly sequential restatement
+    off = [0]
+    for m in members:
+        off.append(off[-1] + len(m))
+    variants = []
+    v = bytearray(data); v[off[7] + 30] ^= 0x08; variants.append(bytes(v))                 # inside member 7's Deflate stream
+    v = bytearray(data); v[off[9] + 16] ^= 0x01; variants.append(bytes(v))                 # BSIZE of member 9
+    v = bytearray(data); v[off[11] - 6] ^= 0x01; variants.append(bytes(v))                 # CRC-32 of member 10
+    v = bytearray(data); v[off[12] - 2] ^= 0x01; variants.append(bytes(v))                 # ISIZE of member 11
+    variants.append(data[:off[20]] + corpus.gzip_member(parts[20]) + data[off[21]:])        # one member without the field
+    variants.append(data[:-5])                                                             # truncated
+    for k, bad in enumerate(variants):
+        st, exp = O.gzip_multi_unarchive(bad)
+        if st == 0:
+            assert swc.GzipArchive.multi_unarchive(bad) == exp, k
+        else:
+            with pytest.raises(swc.SWCError) as ei:
+                swc.GzipArchive.multi_unarchive(bad)
+            assert ei.value.status == st, k
+            if st == 605:
+                assert ei.value.data == exp, k
