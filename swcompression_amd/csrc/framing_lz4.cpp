@@ -287,9 +287,60 @@ int swc_lz4_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, si
     return st;
 }
 
+// All frames of a multi-frame buffer in one launch: block sizes are in the block headers, so the frames (standard frames
+// with independent blocks, skippable frames) can be walked without decoding anything.  Used only if every frame then passes
+// its own checks; anything else -- dependent blocks, legacy frames, a dictionary, any error -- goes to the sequential loop
+// below, which alone defines errors and partial results (LZ4.swift:116-146).
+static bool lz4_multi_batched(const uint8_t* in, size_t in_len, std::vector<uint8_t>& all, std::vector<size_t>& sz) {
+    struct Fr { size_t at; FrameInfo fi; size_t first_unit; };
+    std::vector<Fr> frames;
+    std::vector<HostUnit> units;
+    size_t pos = 0;
+    while (pos < in_len) {
+        if (in_len - pos < 4) return false;
+        const uint32_t magic = le32(in + pos);
+        if (magic >= 0x184D2A50u && magic <= 0x184D2A5Fu) {
+            size_t adv = 0;
+            if (skippable(in + pos + 4, in_len - pos - 4, adv) != SWC_OK) return false;
+            pos += 4 + adv;
+            continue;
+        }
+        if (magic != 0x184D2204u) return false;
+        frames.emplace_back();
+        Fr& f = frames.back();
+        f.at = pos + 4;
+        if (frame_parse(in + f.at, in_len - f.at, false, -1, f.fi) != SWC_OK || !f.fi.independent || f.fi.framing != SWC_OK) return false;
+        f.first_unit = units.size();
+        independent_units(in + f.at, f.fi.blocks, nullptr, 0, false, f.fi.max_block, units);
+        pos = f.at + f.fi.off + (f.fi.content_checksum ? 4 : 0);
+        if (pos > in_len) return false;
+    }
+    if (frames.size() < 2) return false;
+    if (!units.empty() && run_units(SWC_CODEC_LZ4_BLOCK, units) != SWC_OK) return false;
+    for (const Fr& f : frames) {
+        const size_t start = all.size();
+        if (independent_append(in + f.at, f.fi.blocks, units.data() + f.first_unit, all) != SWC_OK) return false;
+        size_t adv = 0;
+        std::vector<uint8_t> one(all.begin() + (std::ptrdiff_t)start, all.end());
+        if (frame_tail(in + f.at, in_len - f.at, f.fi, one, 0, adv) != SWC_OK) return false;
+        sz.push_back(all.size() - start);
+    }
+    return true;
+}
+
 int swc_lz4_multi_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len, int64_t dict_id,
                              uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_frames) {
     if (!out || !out_len || !sizes || !n_frames || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
+    if (dict == nullptr) {
+        std::vector<uint8_t> fast;
+        std::vector<size_t> fsz;
+        if (lz4_multi_batched(in, in_len, fast, fsz)) {
+            give(fast, out, out_len);
+            *sizes = give_sizes(fsz);
+            *n_frames = fsz.size();
+            return SWC_OK;
+        }
+    }
     std::vector<uint8_t> all;
     std::vector<size_t> sz;
     const bool have_dict = dict != nullptr;

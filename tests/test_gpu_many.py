@@ -188,3 +188,32 @@ def test_bgzf_members_share_one_launch():
             assert ei.value.status == st, k
             if st == 605:
                 assert ei.value.data == exp, k
+
+
+def test_lz4_multi_frame_one_launch():
+    """LZ4.multiDecompress (LZ4.swift:116-146) on a buffer of many frames: block sizes are in the headers, so all frames
+    share one launch; anything unusual falls back to the sequential loop and must match the oracle."""
+    rng = np.random.Generator(np.random.PCG64(0x5C0DE + 99))
+    parts = [corpus.p_mix(int(rng.integers(0, 300000)), 9000 + i) for i in range(40)]
+    frames = [corpus.lz4f_frame(p, 4 + i % 4, False, i % 2 == 0, i % 3 == 0, i % 5 == 0) for i, p in enumerate(parts)]
+    skip = struct.pack("<II", 0x184D2A51, 3) + b"abc"
+    data = b"".join(f + (skip if i % 7 == 0 else b"") for i, f in enumerate(frames))
+    O.lib.refcpu_set_max_output(1 << 24)
+    lib = _lib.load()
+    before = lib.swc_stat(b"launches")
+    assert swc.LZ4.multi_decompress(data) == parts
+    assert lib.swc_stat(b"launches") - before <= 2, "the frames must share their launch"
+    assert O.lz4_multi(data) == (0, parts)
+    variants = []
+    v = bytearray(data); v[len(frames[0]) + len(skip) + 40] ^= 0x10; variants.append(bytes(v))     # inside frame 1
+    v = bytearray(data); v[len(data) - 2] ^= 0x01; variants.append(bytes(v))                      # last frame's tail
+    variants.append(data + corpus.lz4f_frame(parts[3], 4, True))                                   # a dependent-block frame at the end
+    variants.append(data[:-3])
+    for k, bad in enumerate(variants):
+        st, exp = O.lz4_multi(bad)
+        if st == 0:
+            assert swc.LZ4.multi_decompress(bad) == exp, k
+        else:
+            with pytest.raises(swc.SWCError) as ei:
+                swc.LZ4.multi_decompress(bad)
+            assert ei.value.status == st, k
