@@ -1,11 +1,14 @@
 // kernels.hip -- gfx950 kernels of the many-stream decode engine and their launchers.
 //
-// Execution model: ONE COMPRESSED STREAM PER LANE.  A workgroup is a single 64-lane wavefront; each
-// lane owns one independent unit (deflate stream / LZ4 block / ...) and runs the sequential decoder
-// of <codec>_lane.h with all of its per-stream tables in LDS, interleaved at wave stride
-// (word j of lane l at lds[j*64+l]) so arbitrary per-lane table indices are bank-conflict free.
-// Entropy decoding is inherently serial per stream; the chip is filled by streams, not by
-// splitting a stream: 256 CUs x 4 waves x 64 lanes = 65,536 streams in flight for Deflate.
+// Every unit (a Deflate stream, an LZ4 block, a bzip2 block, an LZMA stream) is independent; the chip is filled by units, and
+// each codec maps a unit to the piece of the machine its serial part needs:
+//   Deflate   phase 1 one stream per LANE (tables in LDS at wave stride + VGPRs) or, for small batches, per WAVEFRONT;
+//             phase 2 (LZ77 resolve) one stream per WORKGROUP with the window in LDS           inflate_lane.h, lz_resolve.h
+//   LZ4       parse one block per wavefront, then the same resolve kernel; dictionary blocks per lane    lz4_wave.h, lz4_lane.h
+//   LZMA      one stream per wavefront, probability model in LDS                                               lzma_wave.h
+//   BZip2     Huffman + MTF per wavefront, counting-sort scatter per wavefront, inverse BWT by all lanes of a wavefront over
+//             a cut cycle, block CRC per workgroup                                                           bzip2_block.h
+//   checksums / Delta filter   one stream per workgroup                     crc32_group.h, checksum_group.h, delta_group.h
 // No MFMA (no dense contraction anywhere on this path), no inter-workgroup communication.
 #include <hip/hip_runtime.h>
 #include "swc_common.h"
@@ -24,7 +27,7 @@ namespace swc {
 
 // ---- Deflate: two phases (inflate_lane.h, lz_resolve.h) ------------------------------------------------
 // Phase 1: one stream per lane.  LDS: 80 words/lane -> 20,480 B per wave -> 8 resident waves per CU (2 per SIMD).
-// Literals are stored in place, matches become records in the workspace; no output reads.
+// Literals go to the dense literal stream, matches become records, both in the workspace; the output is not touched.
 __global__ __launch_bounds__(64, 2) void swc_inflate_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride, int dbg) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
     uint32_t g = blockIdx.x * kWave + threadIdx.x;
