@@ -8,7 +8,9 @@
 // replays the reference's sequential walk over the results: a candidate is used only if the walk
 // arrives exactly at its bit offset, so false positives inside block data are simply never visited
 // and the outcome (bytes, error, error order) is identical to the sequential decoder.
+#include <algorithm>
 #include <map>
+#include <thread>
 #include <vector>
 #include "framing.h"
 
@@ -27,22 +29,39 @@ inline uint64_t read_bits(const uint8_t* d, uint64_t bit, int count) {  // MSB-f
     return v;
 }
 
-// every bit offset (>= from_bit) at which the 48-bit block magic occurs
-void scan_block_magics(const uint8_t* d, size_t n, uint64_t from_bit, std::vector<uint64_t>& out) {
-    const uint64_t total = (uint64_t)n * 8;
-    if (total < 48) return;
-    uint64_t w = 0;
-    uint64_t bit = 0;
-    for (size_t i = 0; i < n; i++) {
-        const uint32_t b = d[i];
-        for (int k = 7; k >= 0; k--, bit++) {
-            w = ((w << 1) | ((b >> k) & 1u)) & 0xFFFFFFFFFFFFull;
-            if (w == kBlockMagic && bit + 1 >= 48) {
-                const uint64_t start = bit + 1 - 48;
-                if (start >= from_bit) out.push_back(start);
-            }
+// every bit offset (>= from_bit) at which the 48-bit block magic occurs, in increasing order.
+// Discovery is the host's share of a bzip2 decode and must not be slower than the device: per BYTE position one big-endian
+// 64-bit window is compared against the magic at its eight bit alignments (48 + 7 bits fit), and large inputs are cut into
+// ranges scanned by several threads (a magic is found by the range that holds its first bit).
+void scan_range(const uint8_t* d, size_t n, size_t lo, size_t hi, uint64_t from_bit, std::vector<uint64_t>& out) {
+    for (size_t i = lo; i < hi; i++) {
+        if (i + 6 > n) break;                        // fewer than 48 bits left
+        uint64_t v = 0;
+        const size_t take = n - i < 8 ? n - i : 8;
+        for (size_t k = 0; k < take; k++) v |= (uint64_t)d[i + k] << (56 - 8 * k);
+        for (int s = 0; s < 8; s++) {
+            if (((v >> (16 - s)) & 0xFFFFFFFFFFFFull) != kBlockMagic) continue;
+            if (s > 0 && i + 7 > n) continue;        // the last bits would lie past the end
+            const uint64_t start = (uint64_t)i * 8 + (uint64_t)s;
+            if (start >= from_bit) out.push_back(start);
         }
     }
+}
+void scan_block_magics(const uint8_t* d, size_t n, uint64_t from_bit, std::vector<uint64_t>& out) {
+    if (n < 6) return;
+    const size_t kMinPerThread = (size_t)4 << 20;
+    size_t threads = n / kMinPerThread;
+    const size_t hw = std::thread::hardware_concurrency();
+    if (threads > 16) threads = 16;
+    if (hw && threads > hw) threads = hw;
+    if (threads < 2) { scan_range(d, n, 0, n, from_bit, out); return; }
+    std::vector<std::vector<uint64_t>> found(threads);
+    std::vector<std::thread> pool;
+    const size_t per = (n + threads - 1) / threads;
+    for (size_t t = 0; t < threads; t++)
+        pool.emplace_back([&, t] { scan_range(d, n, t * per, std::min(n, (t + 1) * per), from_bit, found[t]); });
+    for (auto& th : pool) th.join();
+    for (auto& f : found) out.insert(out.end(), f.begin(), f.end());
 }
 
 struct Decoded {

@@ -66,3 +66,42 @@ def test_xz_blocks_through_the_index():
         out += part
     assert out == x + x[:1000]
     assert swc.index_blocks("xz", b"\\xfd7zXZ\\x00garbage") == []
+
+
+def test_bzip2_magic_scan_against_a_bit_string_search():
+    """The byte-window / multi-thread scan against a plain search over the bit string: magics planted at every bit
+    alignment, at the very end, across the thread-range boundaries of a large buffer, and random data (no false hits)."""
+    magic = "%048d" % int(bin(0x314159265359)[2:])
+    rng = np.random.Generator(np.random.PCG64(0x5C0DE + 101))
+
+    def plant(buf, bit):
+        bits = np.unpackbits(np.frombuffer(bytes(buf[bit // 8:bit // 8 + 7]), dtype=np.uint8))
+        m = np.array([int(c) for c in magic], dtype=np.uint8)
+        bits[bit % 8:bit % 8 + 48] = m
+        buf[bit // 8:bit // 8 + 7] = np.packbits(bits).tobytes()
+
+    def reference(buf):
+        s = "".join("%d" % b for b in np.unpackbits(np.frombuffer(bytes(buf), dtype=np.uint8)))
+        out, at = [], s.find(magic, 32)
+        while at >= 0:
+            out.append(at)
+            at = s.find(magic, at + 1)
+        return out
+
+    for n in (6, 7, 13, 64, 1000):
+        for trial in range(12):
+            buf = bytearray(rng.integers(0, 256, n, dtype=np.uint8).tobytes())
+            if n >= 13:
+                plant(buf, int(rng.integers(32, (n - 7) * 8)))
+            if n >= 64:
+                plant(buf, (n - 6) * 8)          # the last possible position
+                plant(buf, 32 + trial)           # every alignment near the start
+            assert [r[0] for r in swc.index_blocks("bzip2", bytes(buf))] == reference(buf), (n, trial)
+    big = bytearray(rng.integers(0, 256, 9 << 20, dtype=np.uint8).tobytes())   # two scan threads (one per 4 MiB, at least 2)
+    per = (len(big) + 1) // 2
+    for delta_bits in (-47, -8, -1, 0, 3):                                     # magics that straddle / touch the range boundary
+        plant(big, per * 8 + delta_bits + 640 * (delta_bits + 47))
+    plant(big, per * 8 - 20 + 100000)
+    want = reference(big)
+    assert len(want) >= 6
+    assert [r[0] for r in swc.index_blocks("bzip2", bytes(big))] == want
