@@ -257,18 +257,27 @@ struct Lane {
         nrec++;
     }
     // Deflate.swift:216-232 deferred: record (literal run, length, distance); phase 2 executes the copy.
+    // literal-only records for `run` literal bytes that are already in the literal stream
+    SWC_HD void push_lits(uint64_t run) {
+        while (run > 0) {
+            const uint32_t s = run > lzr::kMaxLitOnly ? lzr::kMaxLitOnly : (uint32_t)run;
+            push(lzr::make_lits(s));
+            run -= s;
+        }
+    }
     SWC_HD void emit_match(uint32_t length, uint32_t distance) {
         if (pos < cap) {  // records exist only for matches that start below the capacity
             uint64_t run = pos - last_end;
-            while (run >= 255) {
-                uint32_t s = run > lzr::kMaxSkip ? lzr::kMaxSkip : (uint32_t)run;
-                push(lzr::make_skip(s));
-                run -= s;
-            }
+            if (run > lzr::kLitRunMax) { push_lits(run); run = 0; }
             push(lzr::make_match((uint32_t)run, length, distance));
             last_end = pos + length;
         }
         pos += length;
+    }
+    // the literals behind the last match (kept only below the capacity) become literal-only records
+    SWC_HD void flush_tail() {
+        const uint64_t kept = pos < cap ? pos : cap;
+        if (kept > last_end) { push_lits(kept - last_end); last_end = kept; }
     }
 
     // Decode one symbol of the lit/len (LIT=true) or distance alphabet.  Returns the symbol or
@@ -472,7 +481,7 @@ struct Lane {
     // iteration consumes <= 63 bits (a literal, then a match: 15 + 20 + 28), so ONE 64-bit shift per iteration always
     // suffices and no code reaches past bit 127.  Positions are 32 bit.
     // ANYTHING unusual -- unassigned code, symbol > 285, distance symbol > 29, distance beyond the output, a literal
-    // run of 255+ before a match -- leaves the loop BEFORE consuming the symbol; the caller then decodes that one
+    // run of 128+ before a match -- leaves the loop BEFORE consuming the symbol; the caller then decodes that one
     // symbol with the fully checked step.  Returns true when the end-of-block symbol was consumed.
     SWC_HD bool fast_loop() {
         const uint64_t P = br.consumed_bits();
@@ -561,7 +570,7 @@ struct Lane {
             const uint32_t run = pm - le;
             // ---- classify
             const bool is_eob = code_ok && !m_lit && sym == 0;
-            const bool is_match = code_ok && !m_lit && sym != 0 && sym <= 29 && n2 <= 15 && dc <= 29 && distance <= pm && run < 255;
+            const bool is_match = code_ok && !m_lit && sym != 0 && sym <= 29 && n2 <= 15 && dc <= 29 && distance <= pm && run <= lzr::kLitRunMax;
             const bool lit2 = a_lit && m_lit;
             // ---- unconditional stores (see above), BEFORE the exits so that every path from the input load to its use
             // in the next iteration passes exactly these two stores.  A lane that leaves below has written one garbage
@@ -739,7 +748,7 @@ struct Lane {
                     if (q >= (uint32_t)kWave) break;   // its distance code lies in the next window
                     const uint32_t b = view_d(q);
                     const uint32_t dist = b >> 6, run = p - le;
-                    if (!((b >> 5) & 1u) || dist > p || run >= 255u) { stop = true; break; }
+                    if (!((b >> 5) & 1u) || dist > p || run > lzr::kLitRunMax) { stop = true; break; }
                     if (nr < max_rec) recs[nr] = lzr::make_match(run, va, dist);
                     nr++;
                     p += va;
@@ -907,6 +916,7 @@ SWC_HD void inflate_job(Job& job, LaneLds lds, uint8_t* ws, size_t ws_bytes, int
     } else {
         ln.br.init((gcptr)job.in, (uint32_t)job.in_len, 0);
         st = ln.run();
+        ln.flush_tail();
     }
     if (ln.nrec > ln.max_rec) {
         st = SWC_E_NEED_WORKSPACE;  // the record list outgrew the workspace (sized from out_cap)

@@ -1,0 +1,702 @@
+// inflate_sync.h -- Deflate entropy decode (phase 1), one compressed stream per WAVEFRONT, 64 lanes decoding 64
+// sub-chunks of the stream at once.
+//
+// Replaces the symbol loop of Deflate.decompress(_ bitReader:) (reference Sources/Deflate/Deflate.swift:171-236) and the
+// code-length section of a dynamic header (:86-167).  Huffman decoding is a serial chain -- where a code starts is known
+// only when the previous one has been decoded -- but a decoder started at a WRONG bit offset falls into step with the
+// true symbol sequence after a few symbols (it lands on a new position after every code; about one position in
+// thirteen is a true symbol start).  A wavefront therefore cuts the next kSyncRound bytes of the stream into 64
+// sub-chunks of kSyncChunk bytes, one per lane, and iterates:
+//
+//   pass 1      lane 0 starts at the true position, every other lane at its sub-chunk boundary; all decode (counting
+//               only) until they cross the end of their sub-chunk and note where they ended;
+//   pass 2..    a lane whose start differs from the end of its left neighbour decodes again from there.  After pass 2
+//               nearly every lane is on the true sequence (its garbage decode had synchronised inside the neighbour's
+//               sub-chunk); the loop runs until the chain of (start == left neighbour's end) reaches the end-of-block
+//               symbol or lane 63 -- each pass makes at least one more lane final, so it terminates;
+//   scan        exclusive prefix sums of the per-lane counts (literals, records, output bytes);
+//   emit        every lane decodes its sub-chunk once more and writes its literals to the dense literal stream and one
+//               record per match to the record list (lz_resolve.h) at exact offsets.  A sub-chunk closes its trailing
+//               literals with a literal-only record, so that no lane needs the literal run of its neighbour.
+//
+// All 64 lanes share ONE set of tables in LDS: direct lookup tables (10 / 9 bits) whose entries carry code length,
+// extra bits, kind and base value, plus one entry per symbol for the codes longer than the tables (their length is found
+// by comparing the bit-reversed window against the canonical limits of the lengths 10..15).  The input of a round is
+// staged in LDS with coalesced loads; a lane walks its sub-chunk through a three-dword window.
+//
+// Anything the fast path does not want to decide -- an unassigned or over-subscribed code, symbols 286/287, distance
+// symbols 30/31, a distance beyond the output, the end of the input inside a symbol, the capacity inside a round -- makes
+// it return WITHOUT committing the round; the caller then runs the fully checked one-symbol step of inflate_lane.h,
+// which carries the reference's error taxonomy.  Headers, stored blocks and static tables also stay with inflate_lane.h;
+// the code-length section of a dynamic header is decoded here through a 128-entry table, and its histogram / counting
+// sort run on all lanes.
+#ifndef SWC_INFLATE_SYNC_H
+#define SWC_INFLATE_SYNC_H
+
+#include "inflate_lane.h"
+#include "simt.h"
+
+namespace swc {
+namespace inflate {
+
+constexpr int kSyncLitBits = 10, kSyncDistBits = 9;
+#ifndef SWC_SYNC_CHUNK
+#define SWC_SYNC_CHUNK 96
+#endif
+constexpr uint32_t kSyncChunk = SWC_SYNC_CHUNK;      // input bytes per lane and round (a multiple of 4)
+constexpr uint32_t kSyncRound = 64u * kSyncChunk;
+constexpr uint32_t kSyncStage = kSyncRound + 128u;   // + what the last lane may read past its sub-chunk
+constexpr uint32_t kEntInvalid = 0x80000000u;        // a code of the set, but not a symbol the fast path takes
+constexpr uint32_t kPosFail = 0xFFFFFFFFu;
+static_assert(kSyncChunk % 4 == 0 && kSyncChunk >= 64, "sub-chunks are whole dwords");
+
+// Table entry: [0:3] code length, [4:7] extra bits, [8:9] kind, [10:25] base value, [31] invalid.
+// kind, lit/len table: 1 literal, 2 length, 3 end of block; distance table: 1 distance.
+SWC_HD uint32_t make_entry(uint32_t clen, uint32_t ext, uint32_t kind, uint32_t value) { return clen | (ext << 4) | (kind << 8) | (value << 10); }
+
+// The canonical tables of inflate_lane.h (struct Table) kept in LDS: per length d the left-justified code limit, the slot
+// word (sorted index of the first code - first code | index of the first symbol >= 256 << 16) and the sorted index of the
+// first code; the number of codes; the over-subscription flag.  Lit/len alphabet at kAuxLit, distance alphabet at kAuxDist.
+constexpr int kAuxLim = 0, kAuxSlot = 16, kAuxStart = 32, kAuxCount = 48 /* == start[16] */, kAuxOver = 49, kAuxTable = 52;
+constexpr int kAuxLit = 0, kAuxDist = kAuxTable, kAuxWords = 2 * kAuxTable;
+
+struct SyncLds {
+    uint32_t syms[kWordsPerLane];                                   // the sorted symbol arrays of inflate_lane.h (LaneLds{syms, 1})
+    uint32_t lut[(1 << kSyncLitBits) + (1 << kSyncDistBits)];      // direct tables: lit/len, then distance
+    uint32_t symtab[320];                                           // one entry per sorted symbol: lit/len at 0, distance at 288
+    uint32_t aux[kAuxWords];                                        // the canonical tables (see kAux*)
+    alignas(16) uint8_t stage[kSyncStage];                          // staged input of a round; header build: code lengths, counters, code-length table
+};
+// header scratch inside `stage`
+constexpr uint32_t kHdrLens = 0;       // 320 bytes: code length of symbol s
+constexpr uint32_t kHdrCnt = 320;      // 48 words: codes per length (lit/len, of those symbols < 256, distance)
+constexpr uint32_t kHdrClLut = 512;    // 128 bytes: code-length code, len | symbol << 3 (0xFF: no code)
+
+enum { kSyncEob = 0, kSyncBail = 1, kSyncBailCap = 2 };
+#if defined(SWC_HOST_EMULATION)
+// statistics of the emulated decoder (tests, tools/sync_stats.py): rounds committed, bails, lane-passes, symbol iterations
+inline uint64_t g_sync_stats[8];
+#define SWC_SYNC_STAT(i, n) (g_sync_stats[i] += (n))
+#else
+#define SWC_SYNC_STAT(i, n) ((void)0)
+#endif
+enum { kFlagEob = 1u, kFlagFail = 2u, kFlagTrap = 4u };
+
+SWC_D void lds_atomic_inc(uint32_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    (*p)++;
+#endif
+}
+
+// ---- tables ------------------------------------------------------------------------------------------------------
+// Code.swift:23-37 per length, from the per-length counts: cnt[d] codes of length d, of which lo[d] are symbols < 256
+// (lo == nullptr: none).  Every lane computes and stores the same values.
+SWC_D void table_from_counts(const uint32_t* cnt, const uint32_t* lo, uint32_t* tb) {
+    uint32_t v = 0, off = 0, over = 0;
+    tb[kAuxLim] = 0; tb[kAuxSlot] = 0; tb[kAuxStart] = 0;
+#pragma unroll 1
+    for (int d = 1; d <= 15; d++) {
+        const uint32_t c = cnt[d];
+        tb[kAuxLim + d] = (v + c) << (15 - d);
+        if (c != 0 && v + c > (1u << d)) over = 1;
+        tb[kAuxSlot + d] = ((off - v) & 0xFFFFu) | ((off + (lo ? lo[d] : 0u)) << 16);
+        tb[kAuxStart + d] = off;
+        off += c;
+        v = (v + c) << 1;
+    }
+    tb[kAuxCount] = off;
+    tb[kAuxOver] = over;
+}
+// One symbol of the lit/len (LIT) or distance alphabet from the LDS form of the tables, with the reference's
+// semantics for every code set (Lane::decode_sym<LIT, true>: DecodingTree.swift:36-50 over the heap Code.swift:15-39
+// builds -- for an over-subscribed set the shallowest occupied node wins, the last writer of a node wins).
+// Returns the symbol or -1 (symbolNotFound: unassigned path, or the code runs past the end of the input).
+template <bool LIT>
+SWC_D int decode_sym_lds(BitReader& br, const SyncLds* sl) {
+    const uint32_t* tb = sl->aux + (LIT ? kAuxLit : kAuxDist);
+    const uint32_t c15 = brev32(br.peek32()) >> 17;
+    uint32_t len = 16, idx = 0;
+    if (tb[kAuxOver] == 0) {
+        len = 1;
+#pragma unroll 1
+        for (int d = 1; d <= 15; d++) len += c15 >= tb[kAuxLim + d] ? 1u : 0u;
+        if (len > 15) return -1;
+        idx = (tb[kAuxSlot + len] + (c15 >> (15 - len))) & 0xFFFFu;
+    } else {
+#pragma unroll 1
+        for (uint32_t d = 1; d <= 15; d++) {
+            const uint32_t st = tb[kAuxStart + d], cnt = (tb[kAuxStart + d + 1] - st) & 0xFFFFu;
+            const uint32_t fst = d == 1 ? 0u : tb[kAuxLim + d - 1] >> (15 - d);
+            const uint32_t k0 = ((c15 >> (15 - d)) - fst) & ((1u << d) - 1u);
+            if (k0 < cnt) {
+                len = d;
+                idx = st + k0 + (((cnt - 1u - k0) >> d) << d);
+                break;
+            }
+        }
+        if (len > 15) return -1;
+    }
+    if (len > br.bc) return -1;  // DecodingTree.swift:39 -- ran out of bits before reaching a leaf
+    br.consume(len);
+    const LaneLds l{const_cast<uint32_t*>(sl->syms), 1};
+    uint32_t sym = *sym_ptr(l, LIT ? W_LIT_SYM : W_DIST_SYM, idx);
+    if (LIT) sym |= idx >= (tb[kAuxSlot + len] >> 16) ? 256u : 0u;
+    return (int)sym;
+}
+
+// One symbol with every check of the reference (Deflate.swift:171-236) -- Lane::careful_step over the LDS tables, so
+// that the wave kernel never holds the register form of the tables.  Returns SWC_OK to continue, -1 at the
+// end-of-block symbol, or the error.
+SWC_D int careful_step_lds(Lane& ln, const SyncLds* sl) {
+    BitReader& br = ln.br;
+    br.refill();
+    const int sym = decode_sym_lds<true>(br, sl);
+    if (sym < 0) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :175
+    if (sym < 256) {
+        ln.put_byte((uint8_t)sym);
+        return SWC_OK;
+    }
+    if (sym == 256) return -1;
+    if (sym > 285) return SWC_E_DEFLATE_WRONG_SYMBOL;  // :233
+    const uint32_t s = (uint32_t)sym - 257u;
+    uint32_t length;
+    if (s < 8) {
+        length = 3 + s;
+    } else if (s == 28) {
+        length = 258;
+    } else {
+        const uint32_t e = (s >> 2) - 1;  // :188
+        if (br.bc < e) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :192
+        length = 3 + ((4 + (s & 3)) << e) + br.bits(e);  // Constants.lengthBase
+    }
+    br.refill();
+    const int dc = decode_sym_lds<false>(br, sl);
+    if (dc < 0) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :199
+    if (dc > 29) return SWC_E_DEFLATE_WRONG_SYMBOL;     // :201
+    uint32_t distance;
+    if (dc < 4) {
+        distance = 1 + (uint32_t)dc;
+    } else {
+        const uint32_t e = ((uint32_t)dc >> 1) - 1;  // :206
+        if (br.bc < e) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :208
+        distance = 1 + ((2 + ((uint32_t)dc & 1)) << e) + br.bits(e);  // Constants.distanceBase
+    }
+    // :216-221 out[count - distance] with distance > count is a Swift trap (App. A6)
+    if ((uint64_t)distance > ln.pos) return SWC_E_REF_TRAP;
+    ln.emit_match(length, distance);
+    return SWC_OK;
+}
+
+// Per-symbol entries and direct tables from the canonical tables and the sorted symbol arrays in LDS.  All lanes.
+SWC_D void sync_build_luts(SyncLds* sl) {
+    constexpr int N = kWave;
+    const LaneLds l{sl->syms, 1};
+    SIMT_BEGIN(t, N)
+        for (int i = t; i < (1 << kSyncLitBits) + (1 << kSyncDistBits); i += N) sl->lut[i] = 0;
+    SIMT_END_WAVE
+    SIMT_BEGIN(t, N)
+#pragma unroll 1
+        for (int tbl = 0; tbl < 2; tbl++) {
+            const uint32_t* tb = sl->aux + (tbl ? kAuxDist : kAuxLit);
+            const uint32_t n_sym = tb[kAuxCount], n_max = tbl ? 32u : 288u;
+            const uint32_t lut_bits = tbl ? (uint32_t)kSyncDistBits : (uint32_t)kSyncLitBits;
+            uint32_t* lut = sl->lut + (tbl ? (1 << kSyncLitBits) : 0);
+            for (uint32_t j = (uint32_t)t; j < n_sym && j < n_max; j += (uint32_t)N) {
+                uint32_t d = 1;
+#pragma unroll 1
+                for (uint32_t q = 2; q <= 15; q++) if (j >= tb[kAuxStart + q]) d = q;   // the length whose index range holds j
+                const uint32_t fst = d == 1 ? 0u : tb[kAuxLim + d - 1] >> (15 - d);
+                const uint32_t code = fst + (j - tb[kAuxStart + d]);
+                const uint32_t rev = brev32(code) >> (32 - d);
+                uint32_t entry;
+                if (tbl == 0) {
+                    uint32_t sym = *sym_ptr(l, W_LIT_SYM, j);
+                    if (j >= (tb[kAuxSlot + d] >> 16)) sym |= 256u;
+                    if (sym < 256) entry = make_entry(d, 0, 1, sym);
+                    else if (sym == 256) entry = make_entry(d, 0, 3, 0);
+                    else if (sym <= 285) {
+                        const uint32_t s = sym - 257u;
+                        const uint32_t e = s < 8 || s == 28 ? 0u : (s >> 2) - 1u;
+                        const uint32_t base = s < 8 ? 3u + s : s == 28 ? 258u : 3u + ((4u + (s & 3u)) << e);
+                        entry = make_entry(d, e, 2, base);
+                    } else entry = d | kEntInvalid;   // 286, 287: the checked step reports wrongSymbol
+                } else {
+                    const uint32_t dc = *sym_ptr(l, W_DIST_SYM, j);
+                    if (dc <= 29) {
+                        const uint32_t e = dc < 4 ? 0u : (dc >> 1) - 1u;
+                        const uint32_t base = dc < 4 ? 1u + dc : 1u + ((2u + (dc & 1u)) << e);
+                        entry = make_entry(d, e, 1, base);
+                    } else entry = d | kEntInvalid;   // 30, 31: wrongSymbol
+                }
+                sl->symtab[(tbl ? 288u : 0u) + j] = entry;
+                if (d <= lut_bits)
+                    for (uint32_t m = rev; m < (1u << lut_bits); m += 1u << d) lut[m] = entry;
+            }
+        }
+    SIMT_END_WAVE
+}
+
+// From the code lengths lens[0 .. literals + distances) in the header scratch: histogram, canonical tables, the
+// (length, symbol)-sorted symbol arrays of inflate_lane.h, per-symbol entries and direct tables.  All lanes.
+SWC_D void sync_tables_from_lengths(SyncLds* sl, int literals, int distances) {
+    using simt::PT;
+    constexpr int N = kWave;
+    const uint8_t* lens = sl->stage + kHdrLens;
+    uint32_t* cnt = (uint32_t*)(sl->stage + kHdrCnt);
+    const LaneLds l{sl->syms, 1};
+    const int total = literals + distances;
+    // codes per length of the lit/len alphabet, of those symbols < 256, and of the distance alphabet
+    SIMT_BEGIN(t, N)
+        for (int s = t; s < total; s += N) {
+            const uint32_t v = lens[s];
+            if (v) {
+                if (s < literals) { lds_atomic_inc(&cnt[v]); if (s < 256) lds_atomic_inc(&cnt[16 + v]); }
+                else lds_atomic_inc(&cnt[32 + v]);
+            }
+        }
+    SIMT_END_WAVE
+    table_from_counts(cnt, cnt + 16, sl->aux + kAuxLit);
+    table_from_counts(cnt + 32, nullptr, sl->aux + kAuxDist);
+    simt::wave_fence();
+    // counting sort by (length, symbol): 64 symbols at a time, rank within the length by ballot; cnt[d] / cnt[32 + d]
+    // become the running positions
+    SIMT_BEGIN(t, N)
+        if (t < 16) { cnt[t] = sl->aux[kAuxLit + kAuxStart + t]; cnt[32 + t] = sl->aux[kAuxDist + kAuxStart + t]; }
+    SIMT_END_WAVE
+    PT<uint32_t, N> v;
+    PT<bool, N> p;
+#pragma unroll 1
+    for (int g = 0; g * N < literals + N; g++) {   // the groups of the lit/len alphabet, then the one group of the distance alphabet
+        const bool is_dist = g * N >= literals;
+        const int s0 = is_dist ? literals : g * N, s_end = is_dist ? total : literals;
+        SIMT_BEGIN(t, N) v[t] = s0 + t < s_end ? (uint32_t)lens[s0 + t] : 0u; SIMT_END
+#pragma unroll 1
+        for (uint32_t d = 1; d <= 15; d++) {
+            SIMT_BEGIN(t, N) p[t] = v[t] == d; SIMT_END
+            const uint64_t m = simt::wave_ballot<N>(p);
+            if (m == 0) continue;
+            uint32_t* rp = &cnt[(is_dist ? 32u : 0u) + d];
+            const uint32_t r0 = *rp;
+            SIMT_BEGIN(t, N)
+                if (p[t]) *sym_ptr(l, is_dist ? W_DIST_SYM : W_LIT_SYM, r0 + (uint32_t)simt::popc64(m & ((1ull << t) - 1ull))) = (uint8_t)(s0 + t - (is_dist ? literals : 0));
+            SIMT_END_WAVE
+            *rp = r0 + (uint32_t)simt::popc64(m);
+            simt::wave_fence();
+        }
+    }
+    sync_build_luts(sl);
+}
+
+// ---- one sub-chunk -----------------------------------------------------------------------------------------------
+struct ChunkOut {
+    uint32_t end;     // bit position (relative to the round base) just past the last symbol taken; kPosFail: no valid decode
+    uint32_t nlit, nrec, nout;
+    uint32_t flags;
+};
+
+SWC_HD uint32_t funnel32(uint32_t hi, uint32_t lo, uint32_t sh) {  // bits [sh, sh + 32) of hi:lo, sh < 32
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
+#endif
+}
+SWC_HD uint32_t bfe32(uint32_t v, uint32_t off, uint32_t width) {   // width 0..16, off + width <= 32
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(v, off, width);
+#else
+    return width == 0 ? 0u : (v >> off) & ((1u << width) - 1u);
+#endif
+}
+
+// MODE 0: count.  MODE 1: emit literals and records.  MODE 2: check distances only (output beyond the capacity).
+// Decodes from bit `start` until a lit/len symbol would begin at or beyond `chunk_end`, or the end-of-block symbol.
+template <int MODE>
+SWC_D void decode_chunk(const SyncLds* sl, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr lit_dst, SWC_AS_GLOBAL uint32_t* rec_dst,
+                        uint64_t out_pos0, ChunkOut& r) {
+    const uint32_t* st32 = (const uint32_t*)sl->stage;
+    uint32_t w = start >> 5, bp = start & 31u;
+    uint32_t d0 = st32[w], d1 = st32[w + 1], d2 = st32[w + 2];
+    uint32_t state = 0, plen = 0, run = 0, nlit = 0, nrec = 0, nout = 0, flags = 0;
+    uint64_t lb = 0;
+    uint32_t lbn = 0;
+    // The body is written as selects (one predicated schedule for literal, length, distance): lanes of a wave hold
+    // different kinds of symbols in every iteration, and a branch per kind would run all of them one after the other.
+    for (;;) {
+        const uint32_t posb = (w << 5) + bp;
+        if (state == 0 && posb >= chunk_end) break;
+        SWC_SYNC_STAT(4 + MODE, 1);   // code iterations per mode
+        const uint32_t bits = funnel32(d1, d0, bp);
+        const uint32_t idx = state ? (1u << kSyncLitBits) + (bits & ((1u << kSyncDistBits) - 1u)) : bits & ((1u << kSyncLitBits) - 1u);
+        uint32_t e = sl->lut[idx];
+        if (e == 0) {   // a code longer than the direct table (or no code at all)
+            const uint32_t c15 = brev32(bits) >> 17;
+            const uint32_t* tb = sl->aux + (state ? kAuxDist : kAuxLit);
+            const uint32_t* lim = tb + kAuxLim;
+            uint32_t len = 10;
+#pragma unroll
+            for (int d = 10; d <= 15; d++) len += c15 >= lim[d] ? 1u : 0u;
+            const uint32_t lenc = len > 15 ? 15u : len;
+            const uint32_t slw = tb[kAuxSlot + lenc];
+            uint32_t j = (slw + (c15 >> (15 - lenc))) & 0xFFFFu;
+            const uint32_t jmax = state ? 31u : 287u;
+            j = j > jmax ? jmax : j;
+            e = sl->symtab[(state ? 288u : 0u) + j];
+            e = len > 15 ? kEntInvalid : e;
+        }
+        const uint32_t clen = e & 15u, ext = (e >> 4) & 15u, kind = (e >> 8) & 3u;
+        const uint32_t val = ((e >> 10) & 0xFFFFu) + bfe32(bits, clen, ext);
+        const uint32_t n = clen + ext;
+        // not a symbol the fast path takes, or the symbol runs past the end of the input
+        if ((e & kEntInvalid) || posb + n > in_bits) { flags |= kFlagFail; break; }
+        const bool is_dist = state != 0;
+        const bool is_lit = !is_dist && kind == 1, is_len = !is_dist && kind == 2, is_eob = !is_dist && kind == 3;
+        if (MODE != 0 && is_dist && (uint64_t)val > out_pos0 + nout) { flags |= kFlagTrap; break; }
+        const bool big = is_dist && run > lzr::kLitRunMax;
+        if (MODE == 1) {
+            if (is_lit) {
+                lb |= (uint64_t)val << (8 * lbn);
+                if (++lbn == 8) { store_u64(lit_dst, lb); lit_dst += 8; lb = 0; lbn = 0; }
+            }
+            if (is_dist) {
+                if (big) *rec_dst++ = lzr::make_lits(run);
+                *rec_dst++ = lzr::make_match(big ? 0u : run, plen, val);
+            }
+        }
+        nlit += is_lit ? 1u : 0u;
+        nout += is_lit ? 1u : is_dist ? plen : 0u;
+        nrec += is_dist ? (big ? 2u : 1u) : 0u;
+        run = is_dist ? 0u : run + (is_lit ? 1u : 0u);
+        plen = is_len ? val : plen;
+        state = is_len ? 1u : 0u;
+        bp += n;
+        if (is_eob) { flags |= kFlagEob; break; }
+        const bool sh = bp >= 32;
+        w += sh ? 1u : 0u;
+        bp -= sh ? 32u : 0u;
+        d0 = sh ? d1 : d0;
+        d1 = sh ? d2 : d1;
+        if (sh) d2 = st32[w + 2];
+    }
+    if (run > 0) {   // the sub-chunk closes its literal run itself
+        nrec++;
+        if (MODE == 1) *rec_dst++ = lzr::make_lits(run);
+    }
+    if (MODE == 1) {
+        for (uint32_t i = 0; i < lbn; i++) lit_dst[i] = (uint8_t)(lb >> (8 * i));
+    }
+    r.end = (flags & kFlagFail) ? kPosFail : (w << 5) + bp;
+    r.nlit = nlit; r.nrec = nrec; r.nout = nout;
+    r.flags = flags;
+}
+
+// ---- the rounds of one block ---------------------------------------------------------------------------------------
+// Decodes from the reader's position until the end-of-block symbol (kSyncEob) or until something the fast path leaves
+// to the checked step (kSyncBail; kSyncBailCap: the capacity lies inside the next round).  Commits whole rounds only.
+SWC_D int sync_block(Lane& ln, SyncLds* sl) {
+    using simt::PT;
+    constexpr int N = kWave;
+    ln.flush_tail();   // the literal run in front of the first round becomes a record of its own
+    uint64_t P = simt::uniform(ln.br.consumed_bits());
+    uint64_t pos = simt::uniform(ln.pos), nlit = simt::uniform(ln.nlit);
+    uint32_t nrec = simt::uniform(ln.nrec);
+    const uint32_t in_len = ln.br.len;
+    gcptr in = ln.br.in;
+    int result = kSyncBail;
+    PT<uint32_t, N> start, endp, pe, c_lit, c_rec, c_out, flg, x_lit, x_rec, x_out;
+    PT<bool, N> todo, pb;
+    for (;;) {
+        const uint32_t B = (uint32_t)(P >> 3) & ~3u;
+        const uint32_t q0 = (uint32_t)(P - 8ull * B);
+        const uint64_t left = (uint64_t)(in_len - B) * 8;
+        const uint32_t in_bits = left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)left;
+        // stage [B, B + kSyncStage), zero-filled beyond the input
+        SIMT_BEGIN(t, N)
+            for (uint32_t o = 16u * (uint32_t)t; o < kSyncStage; o += 16u * N) {
+                uint64_t a = 0, b = 0;
+                const uint64_t at = (uint64_t)B + o;
+                if (at + 16 <= in_len) { a = load_u64(in + at); b = load_u64(in + at + 8); }
+                else {
+                    for (uint32_t k = 0; k < 8; k++) if (at + k < in_len) a |= (uint64_t)in[at + k] << (8 * k);
+                    for (uint32_t k = 0; k < 8; k++) if (at + 8 + k < in_len) b |= (uint64_t)in[at + 8 + k] << (8 * k);
+                }
+                *(uint64_t*)(sl->stage + o) = a;
+                *(uint64_t*)(sl->stage + o + 8) = b;
+            }
+            start[t] = t == 0 ? q0 : (uint32_t)t * kSyncChunk * 8u;
+            todo[t] = true;
+        SIMT_END_WAVE
+        uint32_t nv = 0;
+        bool eob = false, bail = false;
+        for (;;) {
+            SWC_SYNC_STAT(2, 1);   // passes
+            SIMT_BEGIN(t, N)
+                if (todo[t]) {
+                    SWC_SYNC_STAT(3, 1);   // lane decodes
+                    ChunkOut r;
+                    decode_chunk<0>(sl, start[t], ((uint32_t)t + 1u) * kSyncChunk * 8u, in_bits, nullptr, nullptr, 0, r);
+                    endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; flg[t] = r.flags;
+                }
+            SIMT_END
+            simt::wave_shift_up<N>(pe, endp, q0);
+            SIMT_BEGIN(t, N) pb[t] = t != 0 && start[t] != pe[t]; SIMT_END
+            const uint64_t m_bad = simt::wave_ballot<N>(pb);
+            const int b = m_bad ? simt::ctz64(m_bad) : 64;               // lanes [0, b) are on the true sequence
+            const uint64_t chain = b == 64 ? ~0ull : (1ull << b) - 1ull;
+            SIMT_BEGIN(t, N) pb[t] = (flg[t] & kFlagEob) != 0; SIMT_END
+            const uint64_t m_eob = simt::wave_ballot<N>(pb) & chain;
+            const int E = m_eob ? simt::ctz64(m_eob) : 64;               // the lane that met the end of the block
+            nv = (uint32_t)(E < 64 ? E + 1 : b);
+            SIMT_BEGIN(t, N) pb[t] = (flg[t] & kFlagFail) != 0; SIMT_END
+            const uint64_t m_fail = simt::wave_ballot<N>(pb) & (nv == 64 ? ~0ull : (1ull << nv) - 1ull);
+            if (m_fail) { bail = true; break; }                          // the true sequence holds something for the checked step
+            if (E < 64) { eob = true; break; }
+            if (b == 64) break;
+            SIMT_BEGIN(t, N)
+                todo[t] = t >= b && start[t] != pe[t] && pe[t] != kPosFail;
+                if (todo[t]) start[t] = pe[t];
+            SIMT_END
+        }
+        if (bail) { SWC_SYNC_STAT(1, 1); break; }
+        SWC_SYNC_STAT(0, 1);   // rounds that converged
+        // exclusive offsets of the lanes [0, nv)
+        SIMT_BEGIN(t, N)
+            const bool v = (uint32_t)t < nv;
+            x_lit[t] = v ? c_lit[t] : 0u; x_rec[t] = v ? c_rec[t] : 0u; x_out[t] = v ? c_out[t] : 0u;
+        SIMT_END
+        simt::wave_scan_incl<N>(x_lit);
+        simt::wave_scan_incl<N>(x_rec);
+        simt::wave_scan_incl<N>(x_out);
+        const uint32_t tot_lit = simt::wave_read<N>(x_lit, N - 1), tot_rec = simt::wave_read<N>(x_rec, N - 1), tot_out = simt::wave_read<N>(x_out, N - 1);
+        const bool beyond = pos >= ln.cap;                               // size pass: nothing is kept, distances are still checked
+        if (!beyond && pos + tot_out > ln.cap) { result = kSyncBailCap; break; }
+        if (!beyond && (uint64_t)nrec + tot_rec > ln.max_rec) break;
+        SIMT_BEGIN(t, N)
+            if ((uint32_t)t < nv) {
+                ChunkOut r;
+                const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
+                const uint64_t p0 = pos + (x_out[t] - c_out[t]);
+                if (beyond) decode_chunk<2>(sl, start[t], ce, in_bits, nullptr, nullptr, p0, r);
+                else decode_chunk<1>(sl, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
+                flg[t] = r.flags;
+            }
+        SIMT_END
+        SIMT_BEGIN(t, N) pb[t] = (uint32_t)t < nv && (flg[t] & kFlagTrap) != 0; SIMT_END
+        if (simt::wave_ballot<N>(pb)) break;                             // a distance beyond the output: the checked step reports it
+        pos += tot_out;
+        if (!beyond) { nlit += tot_lit; nrec += tot_rec; }
+        P = 8ull * B + simt::wave_read<N>(endp, (int)nv - 1);
+        ln.last_end = pos < ln.cap ? pos : (ln.last_end > ln.cap ? ln.last_end : ln.cap);
+        if (eob) { result = kSyncEob; break; }
+    }
+    ln.pos = pos;
+    ln.nlit = nlit;
+    ln.nrec = nrec;
+    ln.br.seek(P);
+    return result;
+}
+
+// ---- the code-length section of a dynamic header (Deflate.swift:86-167), wave-parallel where it can be -----------------
+// Same results and errors as Lane::build_dynamic: the code lengths are decoded once, serially (through a 128-entry
+// table of the code-length code), into an LDS array; the per-length histogram and the counting sort that produces the
+// (length, symbol)-sorted arrays run on all lanes.
+SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl) {
+    using simt::PT;
+    constexpr int N = kWave;
+    BitReader& br = ln.br;
+    ln.luts_ready = false;
+    br.refill();
+    if (br.bc < 14) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :86
+    const int literals = (int)br.bits(5) + 257;
+    if (literals > 286) return SWC_E_DEFLATE_WRONG_SYMBOL;  // :94
+    const int distances = (int)br.bits(5) + 1;
+    const int ncl = (int)br.bits(4) + 4;
+    br.refill();
+    const uint64_t total_left = (uint64_t)br.len * 8 - br.consumed_bits();
+    if (total_left < (uint64_t)(3 * ncl)) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :101
+    const uint8_t order[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+    uint64_t clens = 0;  // 3 bits per symbol, indexed by symbol
+    for (int i = 0; i < ncl; i++) {
+        br.refill();
+        clens |= (uint64_t)br.bits(3) << (3 * order[i]);
+    }
+    Lane::ClTable cl;
+    {
+        uint64_t cnt8 = 0, runp = 0;  // eight 8-bit fields, indexed by length
+        for (int s = 0; s < 19; s++) {
+            const uint32_t len = (uint32_t)(clens >> (3 * s)) & 7u;
+            if (len) cnt8 += 1ull << (8 * len);
+        }
+        uint32_t v = 0, off = 0;
+        cl.slot[0] = 0;
+#pragma unroll
+        for (int d = 1; d <= 7; d++) {
+            const uint32_t c = (uint32_t)(cnt8 >> (8 * d)) & 255u;
+            cl.slot[d] = ((v & 0x7FFFu) << 9) | off;
+            runp |= (uint64_t)off << (8 * d);
+            off += c;
+            v = (v + c) << 1;
+        }
+        cl.slot[8] = off;
+        cl.sym_lo = cl.sym_hi = 0;
+        for (int s = 0; s < 19; s++) {
+            const uint32_t len = (uint32_t)(clens >> (3 * s)) & 7u;
+            if (len) {
+                const uint32_t p = (uint32_t)(runp >> (8 * len)) & 255u;
+                runp += 1ull << (8 * len);
+                if (p < 12) cl.sym_lo |= (uint64_t)s << (5 * p);
+                else cl.sym_hi |= (uint64_t)s << (5 * (p - 12));
+            }
+        }
+    }
+    uint8_t* lens = sl->stage + kHdrLens;
+    uint32_t* cnt = (uint32_t*)(sl->stage + kHdrCnt);
+    uint8_t* cl_lut = sl->stage + kHdrClLut;
+    const int total = literals + distances;
+    SIMT_BEGIN(t, N)
+        for (int i = t; i < 80; i += N) ((uint32_t*)lens)[i] = 0;
+        if (t < 48) cnt[t] = 0;
+        for (int x = t; x < 128; x += N) {   // the code the stream bits x (first bit = bit 0) begin with
+            uint32_t len;
+            const int idx = Lane::cl_lookup(cl, brev32((uint32_t)x) >> 17, len);
+            const uint32_t sym = idx < 0 ? 0u : (uint32_t)((idx < 12 ? cl.sym_lo >> (5 * idx) : cl.sym_hi >> (5 * (idx - 12))) & 31u);
+            cl_lut[x] = idx < 0 ? (uint8_t)0xFF : (uint8_t)(len | (sym << 3));
+        }
+    SIMT_END_WAVE
+    {   // Deflate.swift:117-162, every lane the same
+        int n = 0;
+        uint32_t prev = 0;
+        while (n < total) {
+            br.refill();
+            const uint32_t e = cl_lut[br.peek32() & 127u];
+            if (e == 0xFFu || (e & 7u) > br.bc) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :122
+            br.consume(e & 7u);
+            const uint32_t sym = e >> 3;
+            int rep;
+            uint32_t val;
+            if (sym <= 15) {
+                rep = 1; val = sym;
+            } else if (sym == 16 && n > 0) {
+                if (br.bc < 2) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :132
+                rep = (int)br.bits(2) + 3; val = prev;
+                if (n + rep > total) return SWC_E_DEFLATE_WRONG_SYMBOL;  // :135
+            } else if (sym == 17) {
+                if (br.bc < 3) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :145
+                n += (int)br.bits(3) + 3; prev = 0;
+                continue;
+            } else if (sym == 18) {
+                if (br.bc < 7) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :152
+                n += (int)br.bits(7) + 11; prev = 0;
+                continue;
+            } else {
+                return SWC_E_DEFLATE_WRONG_SYMBOL;  // :155 (symbol 16 first)
+            }
+            prev = val;
+            if (val != 0) for (int i = ln.wlane; i < rep; i += ln.wlanes) lens[n + i] = (uint8_t)val;
+            n += rep;
+        }
+        if (n != total) return SWC_E_DEFLATE_WRONG_SYMBOL;  // :161
+    }
+    simt::wave_fence();
+    sync_tables_from_lengths(sl, literals, distances);
+    return SWC_OK;
+}
+
+// Deflate.swift:77-81 with the fixed code of Deflate+Constants.swift:11-173: the same table build from the fixed lengths
+SWC_D void build_static_par(SyncLds* sl) {
+    constexpr int N = kWave;
+    uint8_t* lens = sl->stage + kHdrLens;
+    uint32_t* cnt = (uint32_t*)(sl->stage + kHdrCnt);
+    SIMT_BEGIN(t, N)
+        if (t < 48) cnt[t] = 0;
+        for (int s = t; s < 320; s += N) lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
+    SIMT_END_WAVE
+    sync_tables_from_lengths(sl, 288, 32);
+}
+
+// ---- the job -------------------------------------------------------------------------------------------------------
+// Deflate.swift:30-249 for one stream on one wavefront.  `ws` / `ws_bytes`: the stream's area in the HBM workspace
+// (lzr::StreamHeader | records | literal stream).  On the device every lane of the wave calls this with its lane number;
+// the host emulation calls it once (lane 0 of 1) and runs the 64 lanes of the parallel parts one after another.
+SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes, int lane, int lanes) {
+    Lane ln;
+    ln.dbg = 0;
+    ln.wlane = lane;
+    ln.wlanes = lanes;
+    ln.l = LaneLds{sl->syms, 1};
+    ln.out = (gptr)job.out;
+    ln.cap = job.out_cap;
+    ln.pos = 0;
+    ln.nrec = 0;
+    ln.nlit = 0;
+    ln.last_end = 0;
+    const size_t lo = ws ? lzr::lit_offset(ws_bytes, job.out_cap) : 0;
+    ln.recs = (SWC_AS_GLOBAL uint32_t*)(ws + sizeof(lzr::StreamHeader));
+    ln.max_rec = lo > sizeof(lzr::StreamHeader) ? (uint32_t)((lo - sizeof(lzr::StreamHeader)) / 4) : 0u;
+    ln.lits = (gptr)(ws + lo);
+    int st = SWC_OK;
+    if (lo == 0) {
+        st = SWC_E_NEED_WORKSPACE;
+        ln.br.init((gcptr)job.in, 0, 0);
+    } else if (job.in_len > 0xFFFFFFF0ull) {
+        st = SWC_E_INVALID_ARGUMENT;  // streams are addressed with 32-bit byte offsets on device
+        ln.br.init((gcptr)job.in, 0, 0);
+    } else {
+        ln.br.init((gcptr)job.in, (uint32_t)job.in_len, 0);
+        if ((uint64_t)ln.br.len * 8 < 10) st = SWC_E_DEFLATE_WRONG_BLOCK_TYPE;  // :36
+        while (st == SWC_OK) {
+            ln.br.refill();
+            if (ln.br.bc < 3) { st = SWC_E_REF_TRAP; break; }   // a second or later block header past the end: LsbBitReader.bit() traps
+            const uint32_t is_last = ln.br.bits(1);
+            const uint32_t type = ln.br.bits(2);
+            if (type == 0) {
+                st = ln.run_stored();
+            } else if (type == 1 || type == 2) {
+                if (type == 1) build_static_par(sl);
+                else st = build_dynamic_par(ln, sl);
+                if (st == SWC_OK) {
+                    bool fast = sl->aux[kAuxLit + kAuxOver] == 0 && sl->aux[kAuxDist + kAuxOver] == 0;
+                    for (;;) {   // Deflate.swift:171-236
+                        if (fast) {
+                            const int r = sync_block(ln, sl);
+                            if (r == kSyncEob) break;
+                            if (r == kSyncBail) fast = false;   // the checked step takes the rest of the block
+                            // kSyncBailCap: checked steps until the capacity is behind us
+                        }
+                        const uint64_t until = fast && ln.pos < ln.cap ? ln.cap : ~0ull;
+                        int s2 = SWC_OK;
+                        do { s2 = careful_step_lds(ln, sl); } while (s2 == SWC_OK && ln.pos < until && until != ~0ull);
+                        if (s2 == -1) break;
+                        if (s2) { st = s2; break; }
+                    }
+                }
+            } else {
+                st = SWC_E_DEFLATE_WRONG_BLOCK_TYPE;  // :239
+            }
+            if (st != SWC_OK || is_last) break;  // :243
+        }
+        ln.flush_tail();
+    }
+    if (ln.nrec > ln.max_rec) {
+        st = SWC_E_NEED_WORKSPACE;  // the record list outgrew the workspace (sized from out_cap)
+        ln.nrec = ln.max_rec;
+    }
+    if (st == SWC_OK && ln.pos > ln.cap) st = SWC_E_CAPACITY;
+    if (ws && ws_bytes >= sizeof(lzr::StreamHeader) && (lane == 0)) {
+        SWC_AS_GLOBAL lzr::StreamHeader* h = (SWC_AS_GLOBAL lzr::StreamHeader*)ws;
+        h->nrec = ln.nrec;
+        h->pad0 = 0;
+        h->nlit = ln.nlit;
+    }
+    const uint64_t bits = ln.br.consumed_bits();
+    const uint64_t consumed = (bits + 7) >> 3;  // callers align() right after (GzipArchive.swift:89)
+    job.in_consumed = consumed > job.in_len ? job.in_len : consumed;
+    job.out_len = ln.pos;
+    job.status = st;
+}
+
+}  // namespace inflate
+}  // namespace swc
+#endif

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 #include "swc_common.h"
 #include "inflate_lane.h"
+#include "inflate_sync.h"
 #include "lz_resolve.h"
 #include "lz4_lane.h"
 #include "lz4_wave.h"
@@ -55,21 +56,42 @@ __global__ __launch_bounds__(64, 4) void swc_inflate_wave_kernel(Job* __restrict
     }
 }
 
-// Phase 2: one stream per workgroup of T threads, 64 KiB LDS ring -> 2 workgroups per CU.
-template <int T>
-__global__ __launch_bounds__(T) void swc_lz_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, const uint8_t* ws, size_t ws_stride, int dbg) {
-    __shared__ __attribute__((aligned(16))) lzr::Lds<T> lzr_lds;  // static: > 64 KiB needs no opt-in this way
+// Phase 1, production form: one stream per WAVEFRONT, 64 sub-chunks of the stream decoded at once (inflate_sync.h).
+// LDS: the shared tables + the staged input of a round, ~14 KiB per wave -> 11 waves per CU.
+#ifndef SWC_SYNC_WAVES_PER_SIMD
+#define SWC_SYNC_WAVES_PER_SIMD 3
+#endif
+__global__ __launch_bounds__(64, SWC_SYNC_WAVES_PER_SIMD) void swc_inflate_sync_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride) {
+    __shared__ __attribute__((aligned(16))) inflate::SyncLds sync_lds;
     uint32_t g = blockIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
-    lzr::resolve_job<T>(job, ws + (size_t)g * ws_stride, ws_stride, &lzr_lds, (int)threadIdx.x, dbg);
+    inflate::inflate_sync_job(job, &sync_lds, ws ? ws + (size_t)g * ws_stride : nullptr, ws_stride, (int)threadIdx.x, kWave);
+    if (threadIdx.x == 0) {
+        jobs[g].out_len = job.out_len;
+        jobs[g].in_consumed = job.in_consumed;
+        jobs[g].status = job.status;
+    }
 }
 
-static int g_resolve_threads = 512, g_resolve_dbg = 0, g_inflate_dbg = 0;
+// Phase 2: one stream per workgroup of 512 threads, 64 KiB LDS ring (32 KiB of history + span + cells) -> 2 workgroups per CU.
+constexpr int kInflateResolveThreads = 512, kInflateRingLog2 = 16;
+constexpr uint32_t kInflateKeep = 32768;
+__global__ __launch_bounds__(kInflateResolveThreads) void swc_lz_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, const uint8_t* ws, size_t ws_stride) {
+    __shared__ __attribute__((aligned(16))) lzr::Lds<kInflateResolveThreads, kInflateRingLog2> lzr_lds;  // static: > 64 KiB needs no opt-in this way
+    uint32_t g = blockIdx.x;
+    if (g >= n) return;
+    Job job = jobs[g];
+    lzr::resolve_job<kInflateResolveThreads, kInflateRingLog2, kInflateKeep>(job, ws + (size_t)g * ws_stride, ws_stride, &lzr_lds);
+}
+
+static int g_inflate_dbg = 0;
+static int g_inflate_mode = 0;   // 0: inflate_sync.h (production); 1: the lane / hop-chain forms of inflate_lane.h (kept for comparison runs)
+void set_inflate_mode(int m) { g_inflate_mode = m; }
 static int g_wave_max_jobs = 4096;   // batches of up to this many streams take the wave-per-stream phase 1
 void set_inflate_wave_max_jobs(int n) { g_wave_max_jobs = n; }
 void set_inflate_debug(int m) { g_inflate_dbg = m; }
-void set_resolve_debug(int m) { g_resolve_dbg = m; }
+void set_resolve_debug(int) {}
 
 // Optional per-phase timing of the last Deflate launch (bench.py: roofline per kernel).  HIP events on the
 // launch stream; off by default so that the production path issues nothing but the two kernels.
@@ -90,7 +112,7 @@ int last_phase_ms(float* ms, int cap) {
     if (hipEventElapsedTime(&ms[1], g_phase_ev[1], g_phase_ev[2]) != hipSuccess) return 0;
     return 2;
 }
-void set_resolve_threads(int t) { g_resolve_threads = t; }
+void set_resolve_threads(int) {}
 size_t inflate_ws_bytes_per_job(uint64_t cap) { return lzr::ws_bytes_per_job(cap); }
 
 hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {
@@ -100,19 +122,14 @@ hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStr
     dim3 grid((unsigned)((n + kWave - 1) / kWave)), block(kWave);
     const bool timing = g_phase_timing && g_phase_ev_ok;
     if (timing) (void)hipEventRecord(g_phase_ev[0], stream);
-    if (n <= (size_t)g_wave_max_jobs)
+    if (g_inflate_mode == 0)
+        hipLaunchKernelGGL(swc_inflate_sync_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride);
+    else if (n <= (size_t)g_wave_max_jobs)
         hipLaunchKernelGGL(swc_inflate_wave_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride, g_inflate_dbg);
     else
         hipLaunchKernelGGL(swc_inflate_kernel, grid, block, inflate::kLdsBytesPerWave, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride, g_inflate_dbg);
     if (timing) (void)hipEventRecord(g_phase_ev[1], stream);
-    dim3 grid2((unsigned)n);
-    switch (g_resolve_threads) {
-        case 64: hipLaunchKernelGGL(swc_lz_resolve_kernel<64>, grid2, dim3(64), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
-        case 128: hipLaunchKernelGGL(swc_lz_resolve_kernel<128>, grid2, dim3(128), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
-        default: hipLaunchKernelGGL(swc_lz_resolve_kernel<512>, grid2, dim3(512), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
-        case 1024: hipLaunchKernelGGL(swc_lz_resolve_kernel<1024>, grid2, dim3(1024), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
-        case 256: hipLaunchKernelGGL(swc_lz_resolve_kernel<256>, grid2, dim3(256), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_resolve_dbg); break;
-    }
+    hipLaunchKernelGGL(swc_lz_resolve_kernel, dim3((unsigned)n), dim3(kInflateResolveThreads), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride);
     if (timing) { (void)hipEventRecord(g_phase_ev[2], stream); g_phase_valid = true; }
     return hipGetLastError();
 }
@@ -149,13 +166,13 @@ __global__ __launch_bounds__(64) void swc_lz4_parse_kernel(Job* __restrict__ job
     }
 }
 
-__global__ __launch_bounds__(1024) void swc_lz4_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, const uint8_t* ws, size_t ws_stride) {
-    __shared__ __attribute__((aligned(16))) lzr::Lds<1024, lz4w::kKeep, lz4w::kWin> lds;
+__global__ __launch_bounds__(lz4w::kResolveThreads) void swc_lz4_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, const uint8_t* ws, size_t ws_stride) {
+    __shared__ __attribute__((aligned(16))) lzr::Lds<lz4w::kResolveThreads, lz4w::kRingLog2> lds;
     uint32_t g = blockIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
     if (job.dict != nullptr) return;
-    lzr::resolve_job<1024, lz4w::kKeep, lz4w::kWin>(job, ws + (size_t)g * ws_stride, ws_stride, &lds, (int)threadIdx.x, 0);
+    lzr::resolve_job<lz4w::kResolveThreads, lz4w::kRingLog2, lz4w::kKeep>(job, ws + (size_t)g * ws_stride, ws_stride, &lds);
 }
 
 size_t lz4_ws_bytes_per_job(uint64_t cap) { return lzr::ws_bytes_per_job(cap); }
@@ -173,7 +190,7 @@ hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_
     // in flight, the better the latency hides (8,192 blocks = 8 waves per SIMD).
     hipLaunchKernelGGL(swc_lz4_lane_kernel, grid, block, 0, stream, jobs, (uint32_t)n, 1);
     hipLaunchKernelGGL(swc_lz4_parse_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride);
-    hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(1024), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride);
+    hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(lz4w::kResolveThreads), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride);
     return hipGetLastError();
 }
 

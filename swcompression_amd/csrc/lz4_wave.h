@@ -30,7 +30,8 @@ namespace swc {
 namespace lz4w {
 
 constexpr uint32_t kKeep = 65536;    // LZ4 offsets reach 65,535 bytes back
-constexpr uint32_t kWin = 98304;     // LDS window of the resolve kernel: history + one batch span + slack
+constexpr int kRingLog2 = 17;        // LDS ring of the resolve kernel: history + one batch span + its cells
+constexpr int kResolveThreads = 1024;
 constexpr uint32_t kRecBuf = 1024;   // records a parse wave stages in LDS between flushes
 constexpr uint32_t kLitStage = 4096; // literal bytes likewise
 constexpr uint32_t kInWin = 1024;    // input window of a parse wave in LDS
@@ -194,29 +195,24 @@ struct Parser {
         }
         nlit += keep;
     }
-    // records of one sequence: `lit` literal bytes (already in the literal stream), then a match
-    SWC_D void emit(uint64_t lit, uint64_t mlen, uint32_t offset) {
-        // pos = position BEFORE the literals
-        uint64_t run = lit;
-        uint64_t p = pos;
-        if (p < cap) {
-            // literal runs of 255+ bytes go into skip records (each below the capacity: literals beyond it are not stored)
-            while (run >= 255 && p < cap) {
-                uint64_t s = run > lzr::kMaxSkip ? lzr::kMaxSkip : run;
-                if (p + s > cap) s = cap - p;
-                if (s < 255) break;
-                push(lzr::make_skip((uint32_t)s));
-                run -= s;
-                p += s;
-            }
+    SWC_D void push_lits(uint64_t n) {
+        while (n > 0) {
+            const uint32_t s = n > lzr::kMaxLitOnly ? lzr::kMaxLitOnly : (uint32_t)n;
+            push(lzr::make_lits(s));
+            n -= s;
         }
-        p = pos + lit;   // match start
-        if (mlen == 0) return;
+    }
+    // records of one sequence: `lit` literal bytes (already in the literal stream as far as they lie below the
+    // capacity), then a match of `mlen` bytes (0: none).  pos = position BEFORE the literals.
+    SWC_D void emit(uint64_t lit, uint64_t mlen, uint32_t offset) {
+        uint64_t run = pos >= cap ? 0 : (cap - pos < lit ? cap - pos : lit);   // literal bytes that were kept
+        uint64_t p = pos + lit;                                                // match start
+        if (mlen == 0 || p >= cap) { push_lits(run); return; }
+        if (run > lzr::kLitRunMax) { push_lits(run); run = 0; }
         uint64_t rem = mlen;
-        // the first piece carries the remaining literal run; a run that still is >= 255 here ended at the capacity
         while (rem > 0) {
-            uint32_t piece = rem > 258 ? (rem - 258 >= 3 ? 258u : 255u) : (uint32_t)rem;
-            if (p < cap) push(lzr::make_match(run < 255 ? (uint32_t)run : 0u, piece, offset));
+            const uint32_t piece = rem > lzr::kMaxLen ? lzr::kMaxLen : (uint32_t)rem;
+            if (p < cap) push(lzr::make_match((uint32_t)run, piece, offset));
             run = 0;
             p += piece;
             rem -= piece;

@@ -1,0 +1,173 @@
+// simt.h -- the small vocabulary the group-per-stream and wave-per-stream kernels are written in.
+//
+// A kernel body is a sequence of REGIONS.  Inside a region every thread of the group runs the same code on its own
+// per-thread values (PT<V, N>) and may read shared (LDS) data that was written BEFORE the region's opening barrier;
+// it may write shared data nobody else reads inside the same region.  Cross-lane steps (scans, ballots, shuffles)
+// sit BETWEEN regions and take whole PT values.
+//
+//   device (gfx950):  a region is a plain block, `t` is threadIdx.x, PT<V, N> is one register value, the closing
+//                     SIMT_END_BARRIER is an LDS-only workgroup barrier (s_waitcnt lgkmcnt(0); s_barrier -- global
+//                     loads and stores stay in flight across it);
+//   host emulation:   a region is a loop over the N threads of the group (in forward, reverse or shuffled order --
+//                     simt::g_order -- so that a region that depends on the order of its threads shows up as a test
+//                     difference), PT<V, N> is an array.  Single-threaded, deterministic, debuggable.
+//
+// The host form is TEST INFRASTRUCTURE (tests/host_emu); the shipped library contains the device form only.
+#ifndef SWC_SIMT_H
+#define SWC_SIMT_H
+
+#include "swc_common.h"
+
+namespace swc {
+namespace simt {
+
+#if defined(__HIP_DEVICE_COMPILE__)
+
+template <typename V, int N>
+struct PT {
+    V v;
+    SWC_D V& operator[](int) { return v; }
+    SWC_D const V& operator[](int) const { return v; }
+};
+SWC_D void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// orders this wave's LDS accesses for the compiler; the LDS executes one wave's instructions in order
+SWC_D void wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#define SIMT_BEGIN(t, N) { const int t = (int)threadIdx.x; (void)t;
+#define SIMT_END }
+#define SIMT_END_BARRIER } ::swc::simt::lds_barrier();
+#define SIMT_END_WAVE } ::swc::simt::wave_fence();
+
+#else
+
+template <typename V, int N>
+struct PT {
+    V v[N];
+    V& operator[](int t) { return v[t]; }
+    const V& operator[](int t) const { return v[t]; }
+};
+inline void lds_barrier() {}
+inline void wave_fence() {}
+inline int g_order = 0;   // 0 forward, 1 reverse, 2 shuffled
+inline int order(int i, int n) {
+    if (g_order == 1) return n - 1 - i;
+    if (g_order == 2 && (n & (n - 1)) == 0) return (i * 37 + 11) & (n - 1);   // odd multiplier: a permutation of 0..n-1
+    return i;
+}
+#define SIMT_BEGIN(t, N) for (int t##_i_ = 0; t##_i_ < (N); t##_i_++) { const int t = ::swc::simt::order(t##_i_, (N)); (void)t;
+#define SIMT_END }
+#define SIMT_END_BARRIER }
+#define SIMT_END_WAVE }
+
+#endif
+
+// ---- cross-lane steps (between regions) ----------------------------------------------------------------------
+
+// inclusive prefix sum within each 64-lane wave: DPP row shifts + row broadcasts, no LDS
+SWC_D uint32_t wave_scan_incl_dev(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+#endif
+    return x;
+}
+
+// Inclusive prefix sums of two values over a group of N threads (N a multiple of 64).  `ws` = 2 * (N / 64) words of
+// LDS.  Contains one barrier when N > 64; on return every thread may read its sums.
+template <int N>
+SWC_D void group_scan2_incl(PT<uint32_t, N>& x, PT<uint32_t, N>& y, uint32_t* ws) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int tid = (int)threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    uint32_t a = wave_scan_incl_dev(x.v), b = wave_scan_incl_dev(y.v);
+    if (N > 64) {
+        if (lane == 63) { ws[wave] = a; ws[N / 64 + wave] = b; }
+        lds_barrier();
+        uint32_t sa = 0, sb = 0;
+#pragma unroll 1
+        for (int w = 0; w < wave; w++) { sa += ws[w]; sb += ws[N / 64 + w]; }
+        a += sa;
+        b += sb;
+    }
+    x.v = a;
+    y.v = b;
+#else
+    (void)ws;
+    uint32_t a = 0, b = 0;
+    for (int t = 0; t < N; t++) {
+        a += x.v[t]; x.v[t] = a;
+        b += y.v[t]; y.v[t] = b;
+    }
+#endif
+}
+
+// ---- one wave (N = 64) ---------------------------------------------------------------------------------------
+template <int N>
+SWC_D uint64_t wave_ballot(const PT<bool, N>& p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ballot(p.v);
+#else
+    uint64_t m = 0;
+    for (int t = 0; t < N; t++) if (p.v[t]) m |= 1ull << t;
+    return m;
+#endif
+}
+template <int N>
+SWC_D void wave_scan_incl(PT<uint32_t, N>& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    x.v = wave_scan_incl_dev(x.v);
+#else
+    uint32_t a = 0;
+    for (int t = 0; t < N; t++) { a += x.v[t]; x.v[t] = a; }
+#endif
+}
+// y[t] = x[t - 1] (lane 0: `fill`)
+template <int N>
+SWC_D void wave_shift_up(PT<uint32_t, N>& y, const PT<uint32_t, N>& x, uint32_t fill) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = (int)threadIdx.x & 63;
+    const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - 1) << 2, (int)x.v);
+    y.v = lane == 0 ? fill : v;
+#else
+    uint32_t prev = fill;
+    for (int t = 0; t < N; t++) { const uint32_t cur = x.v[t]; y.v[t] = prev; prev = cur; }
+#endif
+}
+// value of lane `i` (i the same in every lane)
+template <int N>
+SWC_D uint32_t wave_read(const PT<uint32_t, N>& x, int i) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_readlane((int)x.v, i);
+#else
+    return x.v[i];
+#endif
+}
+SWC_HD int popc64(uint64_t m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popcll(m);
+#else
+    return __builtin_popcountll(m);
+#endif
+}
+SWC_HD int ctz64(uint64_t m) {   // m != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffsll((long long)m) - 1;
+#else
+    return __builtin_ctzll(m);
+#endif
+}
+// make a value that is the same in every lane live in a scalar register
+SWC_D uint32_t uniform(uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_readfirstlane((int)v);
+#else
+    return v;
+#endif
+}
+SWC_D uint64_t uniform(uint64_t v) { return ((uint64_t)uniform((uint32_t)(v >> 32)) << 32) | uniform((uint32_t)v); }
+
+}  // namespace simt
+}  // namespace swc
+#endif

@@ -28,19 +28,26 @@ build()
 lib = C.CDLL(_LIB)
 
 
-def run_batch(fn_name, inputs, caps, aux=None, dicts=None, extra=None, fn_args=(), dict_ptr_values=None):
-    """inputs: list[bytes]; caps: list[int].  Returns list of (status, out_bytes, in_consumed, out_len)."""
+def set_order(order):
+    """Thread order of the emulated SIMT regions (csrc/simt.h): 0 forward, 1 reverse, 2 shuffled."""
+    lib.emu_set_order(C.c_int(order))
+
+
+def run_batch(fn_name, inputs, caps, aux=None, dicts=None, extra=None, fn_args=(), dict_ptr_values=None, misalign=0):
+    """inputs: list[bytes]; caps: list[int].  Returns list of (status, out_bytes, in_consumed, out_len).
+    misalign: the output buffers start that many bytes past a 16-byte boundary."""
     n = len(inputs)
     jobs = (Job * n)()
     keep = []
     for i, (data, cap) in enumerate(zip(inputs, caps)):
         ib = C.create_string_buffer(bytes(data), max(len(data), 1))
-        ob = C.create_string_buffer(max(cap, 1) + 16)  # 16 guard bytes
-        C.memset(C.addressof(ob) + cap, 0xA5, 16)
-        keep.append((ib, ob))
+        ob = C.create_string_buffer(max(cap, 1) + 16 + 48)  # 16 guard bytes on either side + alignment slack
+        o0 = (-C.addressof(ob)) % 16 + 16 + misalign
+        C.memset(C.addressof(ob), 0xA5, len(ob))
+        keep.append((ib, ob, o0))
         jobs[i].in_ = C.addressof(ib)
         jobs[i].in_len = len(data)
-        jobs[i].out = C.addressof(ob)
+        jobs[i].out = C.addressof(ob) + o0
         jobs[i].out_cap = cap
         jobs[i].aux = 0 if aux is None else aux[i]
         if dicts is not None and dicts[i] is not None:
@@ -55,24 +62,29 @@ def run_batch(fn_name, inputs, caps, aux=None, dicts=None, extra=None, fn_args=(
     getattr(lib, fn_name)(jobs, C.c_size_t(n), *fn_args)
     res = []
     for i in range(n):
-        ib, ob = keep[i] if dicts is None else [k for k in keep if isinstance(k, tuple)][i]
+        ib, ob, o0 = keep[i] if dicts is None else [k for k in keep if isinstance(k, tuple)][i]
         cap = caps[i]
-        assert ob.raw[cap:cap + 16] == b"\xA5" * 16, "guard bytes overwritten (job %d)" % i
+        raw = ob.raw
+        assert raw[o0 + cap:o0 + cap + 16] == b"\xA5" * 16 and raw[:o0] == b"\xA5" * o0, "guard bytes overwritten (job %d)" % i
         nout = min(jobs[i].out_len, cap)
-        res.append((jobs[i].status, ob.raw[:nout], jobs[i].in_consumed, jobs[i].out_len))
+        res.append((jobs[i].status, raw[o0:o0 + nout], jobs[i].in_consumed, jobs[i].out_len))
     return res
 
 
-def inflate(inputs, caps):
-    return run_batch("emu_inflate", inputs, caps)
+def inflate(inputs, caps, misalign=0):
+    return run_batch("emu_inflate", inputs, caps, misalign=misalign)
 
 
-def inflate_wave(inputs, caps):
-    return run_batch("emu_inflate_wave", inputs, caps)
+def inflate_wave(inputs, caps, misalign=0):
+    return run_batch("emu_inflate_wave", inputs, caps, misalign=misalign)
 
 
-def lz4_block(inputs, caps, dicts=None):
-    return run_batch("emu_lz4_block", inputs, caps, dicts=dicts)
+def inflate_sync(inputs, caps, misalign=0):
+    return run_batch("emu_inflate_sync", inputs, caps, misalign=misalign)
+
+
+def lz4_block(inputs, caps, dicts=None, misalign=0):
+    return run_batch("emu_lz4_block", inputs, caps, dicts=dicts, misalign=misalign)
 
 
 def lzma2(inputs, caps, dict_bytes):

@@ -6,16 +6,19 @@
 #include <vector>
 #include <cstring>
 #include "../../swcompression_amd/csrc/inflate_lane.h"
+#include "../../swcompression_amd/csrc/inflate_sync.h"
 #include "../../swcompression_amd/csrc/lz4_lane.h"
 #include "../../swcompression_amd/csrc/lz4_wave.h"
 #include "../../swcompression_amd/csrc/lzma_wave.h"
 #include "../../swcompression_amd/csrc/bzip2_block.h"
 #include "../../swcompression_amd/csrc/crc32_group.h"
 
+extern "C" void emu_set_order(int o) { swc::simt::g_order = o; }
+
 // Deflate: phase 1 lane by lane (wave-interleaved tables), then phase 2 with a one-thread "workgroup".
 extern "C" void emu_inflate(swc::Job* jobs, size_t n) {
     std::vector<uint32_t> lds(swc::inflate::kWordsPerLane * swc::kWave);
-    alignas(16) static swc::lzr::Lds<1> rl;
+    alignas(16) static swc::lzr::Lds<512, 16> rl;
     for (size_t g = 0; g < n; g++) {
         int lane = (int)(g % swc::kWave);
         if (lane == 0) std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);  // LDS is uninitialised on device
@@ -24,7 +27,7 @@ extern "C" void emu_inflate(swc::Job* jobs, size_t n) {
         std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
         swc::inflate::inflate_job(jobs[g], l, ws.data(), wsb);
         std::memset(&rl, 0xEE, sizeof rl);
-        swc::lzr::resolve_job<1>(jobs[g], ws.data(), wsb, &rl, 0);
+        swc::lzr::resolve_job<512, 16, 32768>(jobs[g], ws.data(), wsb, &rl);
     }
 }
 
@@ -32,21 +35,40 @@ extern "C" void emu_inflate(swc::Job* jobs, size_t n) {
 // views of a window computed one after the other.
 extern "C" void emu_inflate_wave(swc::Job* jobs, size_t n) {
     std::vector<uint32_t> lds(swc::inflate::kWaveModeLdsBytes / 4 + 8);
-    alignas(16) static swc::lzr::Lds<1> rl;
+    alignas(16) static swc::lzr::Lds<512, 16> rl;
     for (size_t g = 0; g < n; g++) {
         std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);
         size_t wsb = swc::lzr::ws_bytes_per_job(jobs[g].out_cap);
         std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
         swc::inflate::inflate_job(jobs[g], swc::LaneLds{nullptr, 0}, ws.data(), wsb, 0, 0, lds.data(), 1);
         std::memset(&rl, 0xEE, sizeof rl);
-        swc::lzr::resolve_job<1>(jobs[g], ws.data(), wsb, &rl, 0);
+        swc::lzr::resolve_job<512, 16, 32768>(jobs[g], ws.data(), wsb, &rl);
     }
+}
+
+// Deflate, one stream per wavefront with 64 sub-chunks decoded at once (inflate_sync.h): the uniform parts run once, the
+// 64 lanes of every parallel region one after another (csrc/simt.h).
+extern "C" void emu_inflate_sync(swc::Job* jobs, size_t n) {
+    alignas(16) static swc::inflate::SyncLds sl;
+    alignas(16) static swc::lzr::Lds<512, 16> rl;
+    for (size_t g = 0; g < n; g++) {
+        std::memset(&sl, 0xEE, sizeof sl);
+        size_t wsb = swc::lzr::ws_bytes_per_job(jobs[g].out_cap);
+        std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
+        swc::inflate::inflate_sync_job(jobs[g], &sl, ws.data(), wsb, 0, 1);
+        std::memset(&rl, 0xEE, sizeof rl);
+        swc::lzr::resolve_job<512, 16, 32768>(jobs[g], ws.data(), wsb, &rl);
+    }
+}
+
+extern "C" void emu_sync_stats(uint64_t* out, int reset) {
+    for (int i = 0; i < 8; i++) { out[i] = swc::inflate::g_sync_stats[i]; if (reset) swc::inflate::g_sync_stats[i] = 0; }
 }
 
 // LZ4: blocks with a dictionary prefix on the lane decoder, the others through the two-phase path (parse with a
 // one-lane "wavefront", resolve with a one-thread "workgroup").
 extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {
-    static swc::lzr::Lds<1, swc::lz4w::kKeep, swc::lz4w::kWin> rl;
+    alignas(16) static swc::lzr::Lds<swc::lz4w::kResolveThreads, swc::lz4w::kRingLog2> rl;
     for (size_t g = 0; g < n; g++) {
         if (jobs[g].dict) { swc::lz4::lz4_block_job(jobs[g]); continue; }
         size_t wsb = swc::lzr::ws_bytes_per_job(jobs[g].out_cap);
@@ -56,7 +78,7 @@ extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {
         alignas(16) static uint8_t iw[swc::lz4w::kInWin + 16];
         swc::lz4w::lz4_parse_job<1>(jobs[g], ws.data(), wsb, 0, rbuf, lbuf, iw);
         std::memset(&rl, 0xEE, sizeof rl);
-        swc::lzr::resolve_job<1, swc::lz4w::kKeep, swc::lz4w::kWin>(jobs[g], ws.data(), wsb, &rl, 0);
+        swc::lzr::resolve_job<swc::lz4w::kResolveThreads, swc::lz4w::kRingLog2, swc::lz4w::kKeep>(jobs[g], ws.data(), wsb, &rl);
     }
 }
 

@@ -10,8 +10,9 @@ import _emu as E
 import _oracle as O
 import _streams as S
 
-# phase 1 exists in two forms: one stream per lane (large batches) and one stream per wavefront (small batches)
-MODES = {"lane": E.inflate, "wave": E.inflate_wave}
+# phase 1 forms: one stream per lane, one stream per wavefront with a serial hop chain, and one stream per wavefront with 64
+# sub-chunks decoded at once (inflate_sync.h, the production path)
+MODES = {"lane": E.inflate, "wave": E.inflate_wave, "sync": E.inflate_sync}
 
 
 @pytest.fixture(params=sorted(MODES))
@@ -36,6 +37,21 @@ def test_valid_corpus(inflate):
     _check(inflate, [z for z, _ in pairs])
     for (z, x), r in zip(pairs, inflate([z for z, _ in pairs], [len(x) for _, x in pairs])):
         assert r[:2] == (0, x)
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+@pytest.mark.parametrize("misalign", [0, 1, 7, 15])
+def test_resolve_thread_order_and_output_alignment(order, misalign):
+    """Phase 2 (lz_resolve.h) is written as SIMT regions (csrc/simt.h): its result must not depend on the order in which
+    the emulated threads of a region run (a region that reads what another thread of the same region writes would), nor
+    on the alignment of the output buffer (slots are 16-byte aligned HBM chunks)."""
+    pairs = S.valid_deflate_corpus(sizes=(0, 1, 15, 16, 17, 100, 5000, 65536, 70000, 200000))
+    E.set_order(order)
+    try:
+        res = E.inflate([z for z, _ in pairs], [len(x) for _, x in pairs], misalign=misalign)
+    finally:
+        E.set_order(0)
+    assert [r[:2] for r in res] == [(0, x) for _, x in pairs]
 
 
 def test_crafted_reference_semantics(inflate):
