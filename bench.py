@@ -53,6 +53,7 @@ def parse_args():
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the batch (debug only; <1 is not a valid headline run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--tuning", action="append", default=[], help="key=value for swc_set_tuning (comparison runs only)")
     return ap.parse_args()
 
 
@@ -202,6 +203,10 @@ def main():
 
     from swcompression_amd import _lib
     lib = _lib.load()
+    for kv in args.tuning:
+        k, v = kv.split("=")
+        if lib.swc_set_tuning(k.encode(), int(v)) != 0:
+            raise SystemExit("unknown tuning " + kv)
     w = WORKLOADS[args.workload]
     n_distinct = max(8, int(w["n_distinct"] * args.scale))
     # every rank decodes its own, differently seeded, batch: independent units, no exchange step

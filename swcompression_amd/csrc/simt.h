@@ -21,7 +21,12 @@
 namespace swc {
 namespace simt {
 
-#if defined(__HIP_DEVICE_COMPILE__)
+// (hipcc compiles this header twice; the host pass sees the device form of the declarations with empty intrinsics)
+#if defined(__HIPCC__) && !defined(SWC_HOST_EMULATION)
+#define SWC_SIMT_DEVICE_FORM 1
+#endif
+
+#if defined(SWC_SIMT_DEVICE_FORM)
 
 template <typename V, int N>
 struct PT {
@@ -29,9 +34,17 @@ struct PT {
     SWC_D V& operator[](int) { return v; }
     SWC_D const V& operator[](int) const { return v; }
 };
-SWC_D void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+SWC_D void lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
 // orders this wave's LDS accesses for the compiler; the LDS executes one wave's instructions in order
-SWC_D void wave_fence() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+SWC_D void wave_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
 #define SIMT_BEGIN(t, N) { const int t = (int)threadIdx.x; (void)t;
 #define SIMT_END }
 #define SIMT_END_BARRIER } ::swc::simt::lds_barrier();
@@ -93,6 +106,8 @@ SWC_D void group_scan2_incl(PT<uint32_t, N>& x, PT<uint32_t, N>& y, uint32_t* ws
     }
     x.v = a;
     y.v = b;
+#elif defined(SWC_SIMT_DEVICE_FORM)
+    (void)x; (void)y; (void)ws;
 #else
     (void)ws;
     uint32_t a = 0, b = 0;
@@ -108,6 +123,8 @@ template <int N>
 SWC_D uint64_t wave_ballot(const PT<bool, N>& p) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return __ballot(p.v);
+#elif defined(SWC_SIMT_DEVICE_FORM)
+    (void)p; return 0;
 #else
     uint64_t m = 0;
     for (int t = 0; t < N; t++) if (p.v[t]) m |= 1ull << t;
@@ -118,6 +135,8 @@ template <int N>
 SWC_D void wave_scan_incl(PT<uint32_t, N>& x) {
 #if defined(__HIP_DEVICE_COMPILE__)
     x.v = wave_scan_incl_dev(x.v);
+#elif defined(SWC_SIMT_DEVICE_FORM)
+    (void)x;
 #else
     uint32_t a = 0;
     for (int t = 0; t < N; t++) { a += x.v[t]; x.v[t] = a; }
@@ -130,6 +149,8 @@ SWC_D void wave_shift_up(PT<uint32_t, N>& y, const PT<uint32_t, N>& x, uint32_t 
     const int lane = (int)threadIdx.x & 63;
     const uint32_t v = (uint32_t)__builtin_amdgcn_ds_bpermute((lane - 1) << 2, (int)x.v);
     y.v = lane == 0 ? fill : v;
+#elif defined(SWC_SIMT_DEVICE_FORM)
+    (void)y; (void)x; (void)fill;
 #else
     uint32_t prev = fill;
     for (int t = 0; t < N; t++) { const uint32_t cur = x.v[t]; y.v[t] = prev; prev = cur; }
@@ -140,6 +161,8 @@ template <int N>
 SWC_D uint32_t wave_read(const PT<uint32_t, N>& x, int i) {
 #if defined(__HIP_DEVICE_COMPILE__)
     return (uint32_t)__builtin_amdgcn_readlane((int)x.v, i);
+#elif defined(SWC_SIMT_DEVICE_FORM)
+    (void)x; (void)i; return 0;
 #else
     return x.v[i];
 #endif
