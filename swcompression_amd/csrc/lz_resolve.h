@@ -76,8 +76,7 @@ struct Lds {
     alignas(16) uint8_t ring[kRing];                       // byte at virtual position v lives at ring[v % kRing]
     alignas(16) uint8_t litbuf[kLitWin];                   // literal byte at stream offset o lives at litbuf[o % kLitWin]
     alignas(8) uint64_t rec8[T + 1];                       // end | mstart << 16 | litadj << 32 | (distance - 1) << 48, relative to the span
-    uint32_t rq[T + 1];                                    // raw records of the batch
-    uint16_t first[T + 2];                                 // first[k] = record that covers the first in-span byte of slot k
+    uint32_t slotw[T + 1];                                 // per 16-cell slot: record that covers its first in-span cell | record-start flags of its cells << 16
     uint32_t wave_sum[2 * (T / 64) + 2];
     uint32_t ntake, span, litspan;
 };
@@ -100,7 +99,7 @@ struct Resolver {
 
     SWC_D static uint32_t mod_small(uint32_t m, uint32_t d) {   // m % d for m, d < 2^16, d != 0
 #if defined(__HIP_DEVICE_COMPILE__)
-        uint32_t q = (uint32_t)((float)m * __frcp_rn((float)d));
+        uint32_t q = (uint32_t)((float)m * __builtin_amdgcn_rcpf((float)d));   // v_rcp_f32: off by at most one, fixed up below
         uint32_t r = m - q * d;
         if ((int32_t)r < 0) r += d;
         if (r >= d) r -= d;
@@ -109,11 +108,21 @@ struct Resolver {
         return m % d;
 #endif
     }
+    SWC_D static void lds_or(uint32_t* p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        *p |= v;
+#endif
+    }
+    // Cells are read while other threads resolve theirs (R3): a reader may see the source index or the value that
+    // replaced it -- both are right (16-bit LDS accesses are single accesses; every address is read at most once per hop,
+    // so nothing can be cached).  Plain LDS accesses: `volatile` would turn them into flat accesses with a memory wait.
     SWC_D static uint32_t cell_load(const uint8_t* ring, uint32_t cbase, uint32_t ci) {
-        return *(const volatile uint16_t*)(ring + ((cbase + 2u * ci) & kMask));
+        return *(const uint16_t*)(ring + ((cbase + 2u * ci) & kMask));
     }
     SWC_D static void cell_store(uint8_t* ring, uint32_t cbase, uint32_t ci, uint32_t v) {
-        *(volatile uint16_t*)(ring + ((cbase + 2u * ci) & kMask)) = (uint16_t)v;
+        *(uint16_t*)(ring + ((cbase + 2u * ci) & kMask)) = (uint16_t)v;
     }
 
     SWC_D void run(const SWC_AS_GLOBAL uint32_t* recs, uint32_t nrec) {
@@ -128,60 +137,62 @@ struct Resolver {
         PT<u128, T> lit_pf;                 // a 16-byte granule of the literal stream on its way into the window
         PT<uint32_t, T> lit_pf_at;          // its stream offset (0xFFFFFFFF: none)
         PT<uint32_t, T> x, y;               // scan values
-        PT<uint32_t, T> cells[8];           // this thread's 16 cells, two per word
         // prologue: first records, first window of literals
         SIMT_BEGIN(t, T)
             r_next[t] = (uint32_t)t < nrec ? recs[t] : 0u;
             const uint64_t o = 16ull * (uint32_t)t;
             lit_pf_at[t] = 0xFFFFFFFFu;
             if (o + 16 <= lit_cap) *(u128*)(l->litbuf + o) = load_16(lits + o);
+            l->slotw[t] = 0;
+            if (t == 0) l->slotw[T] = 0;
         SIMT_END
         lfill = kLitWin;
         while (base < nrec) {
             const uint32_t vcur = A + (uint32_t)rpos;           // virtual position of the batch start (mod 2^32; the ring mask applies)
-            const uint32_t off = vcur & 15u;                    // bytes of slot 0 that belong to earlier batches
+            const uint32_t off = vcur & 15u;                    // cells of slot 0 that belong to earlier batches
             const uint32_t v0 = vcur - off;
             const uint32_t cbase = (v0 + kCellOff) & kMask;
             // ---- R0: the literal granule prefetched last batch lands in the window; my record; scan inputs
             SIMT_BEGIN(t, T)
                 if (lit_pf_at[t] != 0xFFFFFFFFu) *(u128*)(l->litbuf + (lit_pf_at[t] & kLitMask)) = lit_pf[t];
-                const uint32_t r = r_next[t];
-                const bool valid = base + (uint32_t)t < nrec;
+                const uint32_t r = base + (uint32_t)t < nrec ? r_next[t] : 0u;
                 uint32_t lit = r & 127u;
                 const uint32_t len = (r >> 7) & 511u;
                 if (len == 0) lit += (r >> 16) << 7;
-                x[t] = valid ? lit + len : 0u;
-                y[t] = valid ? lit : 0u;
-                l->rq[t] = valid ? r : 0u;
-                if (t == 0) l->rq[T] = 0u;
+                x[t] = lit + len;
+                y[t] = lit;
+                r_next[t] = r;
             SIMT_END
             simt::group_scan2_incl<T>(x, y, l->wave_sum);       // (barrier A inside)
-            // ---- R1: batch geometry
+            // ---- R1: batch geometry, one record per thread
             SIMT_BEGIN(t, T)
-                const uint32_t r = l->rq[t], rn = l->rq[t + 1];
+                const uint32_t r = r_next[t];
                 uint32_t lit = r & 127u;
                 const uint32_t len = (r >> 7) & 511u;
                 if (len == 0) lit += (r >> 16) << 7;
-                uint32_t litn = rn & 127u;
-                const uint32_t lenn = (rn >> 7) & 511u;
-                if (lenn == 0) litn += (rn >> 16) << 7;
                 const uint32_t end = x[t], lit_end = y[t];
-                const bool take = r != 0u && end <= kSpanMax;
                 const uint32_t start = end - (lit + len), mstart = start + lit;
+                const bool take = r != 0u && end <= kSpanMax;
                 l->rec8[t] = take ? (uint64_t)end | ((uint64_t)mstart << 16) | ((uint64_t)((lit_end - lit - start) & 0xFFFFu) << 32) | ((uint64_t)(r >> 16) << 48)
                                   : 0xFFFFull;
                 if (take) {
-                    // the slots whose first in-span byte I cover
-                    for (uint32_t k = start == 0 ? 0u : (start + off + 15u) >> 4; k == 0 ? start == 0 : 16u * k - off < end; k++) l->first[k] = (uint16_t)t;
-                    const bool next_take = rn != 0u && end + litn + lenn <= kSpanMax;
-                    if (!next_take) { l->ntake = (uint32_t)t + 1u; l->span = end; l->litspan = lit_end; }
+                    // the slots whose first in-span cell I cover, and the flag of my first cell
+                    for (uint32_t k = start == 0 ? 0u : (start + off + 15u) >> 4; k == 0 ? start == 0 : 16u * k - off < end; k++) lds_or(&l->slotw[k], (uint32_t)t);
+                    const uint32_t c0 = start + off;
+                    lds_or(&l->slotw[c0 >> 4], 0x10000u << (c0 & 15u));
+                    if (t == T - 1) { l->ntake = (uint32_t)T; l->span = end; l->litspan = lit_end; }
+                } else if (t != 0 && start <= kSpanMax && base + (uint32_t)t - 1u < nrec) {
+                    // the first record that is not taken (or the first thread past the last record) closes the batch: `start`
+                    // is the end of the record before it, which exists and fits the span, i.e. was taken
+                    l->ntake = (uint32_t)t; l->span = start; l->litspan = lit_end - lit;
                 }
             SIMT_END_BARRIER                                     // barrier B
             const uint32_t ntake = simt::uniform(l->ntake), span = simt::uniform(l->span), litspan = simt::uniform(l->litspan);
             const bool last_batch = base + ntake >= nrec;
+            const uint32_t ncell = span + off;                   // cells [off, ncell) are this batch's bytes, [0, off) belong to earlier ones
             // the literal window after this batch: [lbase + litspan, .. + kLitWin) rounded down to granules
             const uint64_t lfill_next = (lbase + litspan + kLitWin) & ~(uint64_t)15;
-            // ---- R2: prefetch for the next batch, then the slot-centric expansion
+            // ---- R2: prefetch for the next batch, then one CELL per thread and step: which record, literal or match, value or source
             SIMT_BEGIN(t, T)
                 {
                     const uint32_t nx = base + ntake + (uint32_t)t;
@@ -191,101 +202,62 @@ struct Resolver {
                     lit_pf_at[t] = want ? (uint32_t)o : 0xFFFFFFFFu;
                     if (want) lit_pf[t] = load_16(lits + o);
                 }
-                const int32_t lo_rel = 16 * t - (int32_t)off;
-                if (lo_rel < (int32_t)span) {
-                    uint32_t r = l->first[t];
-                    uint64_t rc = l->rec8[r];
-                    uint32_t end = (uint32_t)rc & 0xFFFFu, mstart = (uint32_t)(rc >> 16) & 0xFFFFu, litadj = (uint32_t)(rc >> 32) & 0xFFFFu, dist = (uint32_t)(rc >> 48) + 1u;
-                    uint32_t modr = 0xFFFFFFFFu;
-                    const uint32_t lb = (uint32_t)lbase;
-#pragma unroll
-                    for (int h = 0; h < 8; h++) {
-                        uint32_t pair = 0;
-#pragma unroll
-                        for (int e = 0; e < 2; e++) {
-                            const int j = 2 * h + e;
-                            const int32_t rel = lo_rel + j;
-                            uint32_t cell;
-                            if (rel < 0) {
-                                cell = 0x8000u | l->ring[(v0 + (uint32_t)j) & kMask];
-                            } else if (rel >= (int32_t)span) {
-                                cell = 0x8000u;
-                            } else {
-                                if ((uint32_t)rel >= end) {
-                                    r++;
-                                    rc = l->rec8[r];
-                                    end = (uint32_t)rc & 0xFFFFu; mstart = (uint32_t)(rc >> 16) & 0xFFFFu; litadj = (uint32_t)(rc >> 32) & 0xFFFFu; dist = (uint32_t)(rc >> 48) + 1u;
-                                    modr = 0xFFFFFFFFu;
-                                }
-                                if ((uint32_t)rel < mstart) {
-                                    cell = 0x8000u | l->litbuf[(lb + litadj + (uint32_t)rel) & kLitMask];
-                                } else {
-                                    const uint32_t m = (uint32_t)rel - mstart;
-                                    int32_t s;
-                                    if (m >= dist) {   // the match overlaps itself: map into its first period
-                                        if (modr == 0xFFFFFFFFu) modr = mod_small(m, dist);
-                                        else { modr++; if (modr == dist) modr = 0; }
-                                        s = (int32_t)mstart - (int32_t)dist + (int32_t)modr;
-                                    } else {
-                                        s = rel - (int32_t)dist;
-                                    }
-                                    if (s < 0) cell = 0x8000u | l->ring[(vcur + (uint32_t)s) & kMask];
-                                    else cell = (uint32_t)s + off;
-                                }
-                            }
-#if defined(SWC_DEBUG_POS)
-                            if (rpos + rel == SWC_DEBUG_POS) fprintf(stderr, "pos %llu: rel %d span %u off %u r %u end %u mstart %u litadj %u dist %u cell %04x lbase %llu base %u rpos %llu\n", (unsigned long long)(rpos + rel), rel, span, off, r, end, mstart, litadj, dist, cell, (unsigned long long)lbase, base, (unsigned long long)rpos);
-#endif
-                            pair |= cell << (16 * e);
+                const uint32_t lb = (uint32_t)lbase;
+                for (uint32_t ci = (uint32_t)t; ci < ncell; ci += (uint32_t)T) {
+                    uint32_t cell;
+                    if (ci < off) {
+                        cell = 0x8000u | l->ring[(v0 + ci) & kMask];
+                    } else {
+                        const uint32_t rel = ci - off, k = ci >> 4, j = ci & 15u;
+                        const uint32_t sw = l->slotw[k];
+                        const uint32_t j0 = k == 0 ? off : 0u;   // the slot's first in-span cell: its record is the low half of the slot word
+                        const uint32_t r = (sw & 0xFFFFu) + (uint32_t)simt::popc32((sw >> 16) & ((2u << j) - 1u) & ~((2u << j0) - 1u));
+                        const uint64_t rc = l->rec8[r];
+                        const uint32_t mstart = (uint32_t)(rc >> 16) & 0xFFFFu, litadj = (uint32_t)(rc >> 32) & 0xFFFFu, dist = (uint32_t)(rc >> 48) + 1u;
+                        if (rel < mstart) {
+                            cell = 0x8000u | l->litbuf[(lb + litadj + rel) & kLitMask];
+                        } else {
+                            const uint32_t m = rel - mstart;
+                            // a match that overlaps itself repeats its first period
+                            const int32_t s = m >= dist ? (int32_t)mstart - (int32_t)dist + (int32_t)mod_small(m, dist) : (int32_t)rel - (int32_t)dist;
+                            cell = s < 0 ? 0x8000u | l->ring[(vcur + (uint32_t)s) & kMask] : (uint32_t)s + off;
                         }
-                        cells[h][t] = pair;
                     }
-                    // (the ring wraps at a multiple of 16, not of 32: the halves are placed separately)
-                    *(u128*)(l->ring + ((cbase + 32u * (uint32_t)t) & kMask)) = u128{cells[0][t], cells[1][t], cells[2][t], cells[3][t]};
-                    *(u128*)(l->ring + ((cbase + 32u * (uint32_t)t + 16u) & kMask)) = u128{cells[4][t], cells[5][t], cells[6][t], cells[7][t]};
+                    cell_store(l->ring, cbase, ci, cell);
                 }
             SIMT_END_BARRIER                                     // barrier C
-            // ---- R3: chase, then the slot leaves for the ring and for HBM
+            // ---- R3: one aligned DWORD per thread and step: chase what is unresolved, then the dword leaves for the ring and for HBM
             SIMT_BEGIN(t, T)
-                const int32_t lo_rel = 16 * t - (int32_t)off;
-                if (lo_rel < (int32_t)span) {
-                    uint32_t w[4];
+                if ((uint32_t)t * 16u < ncell) l->slotw[t] = 0;   // (read in R2 only; the next batch sets it after its barrier A)
+                const uint32_t ndw = (ncell + 3u) >> 2;
+                for (uint32_t q = (uint32_t)t; q < ndw; q += (uint32_t)T) {
+                    const uint64_t c4 = *(const uint64_t*)(l->ring + ((cbase + 8u * q) & kMask));
+                    uint32_t word = 0;
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        uint32_t word = 0;
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            const int j = 4 * q + e;
-                            uint32_t c = (cells[j >> 1][t] >> (16 * (j & 1))) & 0xFFFFu;
-                            if (!(c & 0x8000u)) {
-                                uint32_t s = c;
-                                for (;;) {
-                                    c = cell_load(l->ring, cbase, s);
-#if defined(SWC_DEBUG_POS)
-                                    if (rpos + lo_rel + j == SWC_DEBUG_POS) fprintf(stderr, "  hop: cell[%u] = %04x\n", s, c);
-#endif
-                                    if (c & 0x8000u) break;
-                                    s = c;
-                                }
-                                cell_store(l->ring, cbase, 16u * (uint32_t)t + (uint32_t)j, c);
+                    for (int e = 0; e < 4; e++) {
+                        uint32_t c = (uint32_t)(c4 >> (16 * e)) & 0xFFFFu;
+                        if (!(c & 0x8000u) && 4u * q + (uint32_t)e < ncell) {
+                            uint32_t s = c;
+                            for (;;) {
+                                c = cell_load(l->ring, cbase, s);
+                                if (c & 0x8000u) break;
+                                s = c;
                             }
-                            word |= (c & 0xFFu) << (8 * e);
+                            cell_store(l->ring, cbase, 4u * q + (uint32_t)e, c);
                         }
-                        w[q] = word;
+                        word |= (c & 0xFFu) << (8 * e);
                     }
-                    const u128 v{w[0], w[1], w[2], w[3]};
-                    *(u128*)(l->ring + ((v0 + 16u * (uint32_t)t) & kMask)) = v;
-                    const int32_t hi_rel = lo_rel + 16;
-                    const bool complete = hi_rel <= (int32_t)span;
+                    *(uint32_t*)(l->ring + ((v0 + 4u * q) & kMask)) = word;
+                    const bool complete = 4u * q + 4u <= ncell;
                     if (complete || last_batch) {
-                        const int64_t a0 = (int64_t)rpos + lo_rel;   // output position of the slot's first byte
-                        if (complete && a0 >= 0 && (uint64_t)(a0 + 16) <= limit) {
-                            store_16(out + a0, v);
+                        const int64_t a0 = (int64_t)rpos - (int64_t)off + 4 * (int64_t)q;   // output position of the dword's first byte
+                        if (complete && a0 >= 0 && (uint64_t)(a0 + 4) <= limit) {
+                            *(SWC_AS_GLOBAL uint32_t*)(out + a0) = word;
                         } else {
 #pragma unroll 1
-                            for (int j = 0; j < 16; j++) {
-                                const int64_t a = a0 + j;
-                                if (lo_rel + j < (int32_t)span && a >= 0 && (uint64_t)a < limit) out[a] = (uint8_t)(w[j >> 2] >> (8 * (j & 3)));
+                            for (int e = 0; e < 4; e++) {
+                                const int64_t a = a0 + e;
+                                if (4u * q + (uint32_t)e < ncell && a >= 0 && (uint64_t)a < limit) out[a] = (uint8_t)(word >> (8 * e));
                             }
                         }
                     }

@@ -174,6 +174,13 @@ SWC_HD int popc64(uint64_t m) {
     return __builtin_popcountll(m);
 #endif
 }
+SWC_HD int popc32(uint32_t m) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __popc(m);
+#else
+    return __builtin_popcount(m);
+#endif
+}
 SWC_HD int ctz64(uint64_t m) {   // m != 0
 #if defined(__HIP_DEVICE_COMPILE__)
     return __ffsll((long long)m) - 1;
