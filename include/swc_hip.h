@@ -227,10 +227,15 @@ void swc_free(void* p);
 /* 1 if a gfx950 device is usable, 0 otherwise (then every decode entry point returns SWC_E_DEVICE) */
 int swc_device_available(void);
 const char* swc_version(void);
-/* Performance knobs (never change results): "resolve_threads" = 64..1024 (threads per stream in the LZ77 resolve
- * kernel), "phase_timing" = 0 | 1 (HIP events around the two Deflate kernels of a launch), "inflate_wave_max_jobs" = n
- * (Deflate batches of up to n streams decode one stream per wavefront instead of one per lane; default 4096). */
+/* Performance knobs (never change results): "phase_timing" = 0 | 1 (HIP events around the two Deflate kernels of a
+ * launch), "inflate_mode" = 0 | 1 (0, default: phase 1 decodes one stream per wavefront with 64 sub-chunks at once,
+ * inflate_sync.h; 1: the one-stream-per-lane / hop-chain forms of inflate_lane.h, kept for comparison runs, where
+ * "inflate_wave_max_jobs" = n selects the hop-chain form for batches of up to n streams). */
 int swc_set_tuning(const char* key, int value);
+/* Profile builds of the library (-DSWC_PROFILE) only: a device buffer of 32 x uint64 per job of the next Deflate
+ * launches that the kernels fill with cycle counts per stage (tools/exp_profile.py).  NULL switches it off.  A no-op in
+ * the shipped build. */
+int swc_set_profile_buffer(void* device_ptr);
 /* With "phase_timing" on: durations (ms) of the kernels of the last Deflate launch, in launch order
  * (entropy decode, LZ77 resolve).  Returns the number of values written (0 if none). */
 int swc_last_phase_ms(float* ms, int cap);

@@ -70,6 +70,7 @@ def load():
     sig("swc_lz4_multi_decompress", I, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int64, u8pp, szp, szpp, szp)
     sig("swc_zip_get_entries_data", I, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t)
     sig("swc_stat", C.c_longlong, C.c_char_p)
+    sig("swc_set_profile_buffer", C.c_int, C.c_void_p)
     sig("swc_7z_unpack_folders", I, C.c_void_p, C.c_size_t)
     sig("swc_index_blocks", I, I, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, szp)
     sig("swc_unarchive_many", I, I, C.POINTER(C.c_char_p), szp, C.c_size_t, u8pp, szp, C.POINTER(C.c_int32))

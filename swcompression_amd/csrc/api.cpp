@@ -180,6 +180,9 @@ int swc_set_tuning(const char* key, int value) {
     return SWC_E_INVALID_ARGUMENT;
 }
 
+// Profile builds (-DSWC_PROFILE) only: a device buffer of 32 x u64 per job that the Deflate kernels fill with cycle counts.
+int swc_set_profile_buffer(void* device_ptr) { set_profile_buffer(device_ptr); return SWC_OK; }
+
 long long swc_stat(const char* key) {
     if (!key) return -1;
     if (!strcmp(key, "launches")) return g_stats[0].load();

@@ -81,6 +81,20 @@ inline uint64_t g_sync_stats[8];
 #define SWC_SYNC_STAT(i, n) ((void)0)
 #endif
 enum { kFlagEob = 1u, kFlagFail = 2u, kFlagTrap = 4u };
+// profile builds (-DSWC_PROFILE): cycles per part of one stream -- 0 header, 1 tables, 2 staging, 3 count passes, 4 chain
+// logic + scans, 5 emit, 6 checked steps / rest; 7 rounds, 8 passes
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+struct SyncProf {
+    uint64_t acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t tlast = 0;
+};
+#define SWC_SP(pp, k) { const uint64_t t_ = __builtin_readcyclecounter(); (pp).acc[k] += t_ - (pp).tlast; (pp).tlast = t_; }
+#define SWC_SPC(pp, k, n) ((pp).acc[k] += (n))
+#else
+struct SyncProf {};
+#define SWC_SP(pp, k)
+#define SWC_SPC(pp, k, n)
+#endif
 
 SWC_D void lds_atomic_inc(uint32_t* p) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -395,7 +409,7 @@ SWC_D void decode_chunk(const SyncLds* sl, uint32_t start, uint32_t chunk_end, u
 // ---- the rounds of one block ---------------------------------------------------------------------------------------
 // Decodes from the reader's position until the end-of-block symbol (kSyncEob) or until something the fast path leaves
 // to the checked step (kSyncBail; kSyncBailCap: the capacity lies inside the next round).  Commits whole rounds only.
-SWC_D int sync_block(Lane& ln, SyncLds* sl) {
+SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
     using simt::PT;
     constexpr int N = kWave;
     ln.flush_tail();   // the literal run in front of the first round becomes a record of its own
@@ -410,6 +424,8 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl) {
     for (;;) {
         const uint32_t B = (uint32_t)(P >> 3) & ~3u;
         const uint32_t q0 = (uint32_t)(P - 8ull * B);
+        SWC_SP(pf, 6)
+        SWC_SPC(pf, 7, 1);
         const uint64_t left = (uint64_t)(in_len - B) * 8;
         const uint32_t in_bits = left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)left;
         // stage [B, B + kSyncStage), zero-filled beyond the input
@@ -430,8 +446,10 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl) {
         SIMT_END_WAVE
         uint32_t nv = 0;
         bool eob = false, bail = false;
+        SWC_SP(pf, 2)
         for (;;) {
             SWC_SYNC_STAT(2, 1);   // passes
+            SWC_SPC(pf, 8, 1);
             SIMT_BEGIN(t, N)
                 if (todo[t]) {
                     SWC_SYNC_STAT(3, 1);   // lane decodes
@@ -440,6 +458,7 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl) {
                     endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; flg[t] = r.flags;
                 }
             SIMT_END
+            SWC_SP(pf, 3)
             simt::wave_shift_up<N>(pe, endp, q0);
             SIMT_BEGIN(t, N) pb[t] = t != 0 && start[t] != pe[t]; SIMT_END
             const uint64_t m_bad = simt::wave_ballot<N>(pb);
@@ -470,6 +489,7 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl) {
         simt::wave_scan_incl<N>(x_rec);
         simt::wave_scan_incl<N>(x_out);
         const uint32_t tot_lit = simt::wave_read<N>(x_lit, N - 1), tot_rec = simt::wave_read<N>(x_rec, N - 1), tot_out = simt::wave_read<N>(x_out, N - 1);
+        SWC_SP(pf, 4)
         const bool beyond = pos >= ln.cap;                               // size pass: nothing is kept, distances are still checked
         if (!beyond && pos + tot_out > ln.cap) { result = kSyncBailCap; break; }
         if (!beyond && (uint64_t)nrec + tot_rec > ln.max_rec) break;
@@ -483,6 +503,7 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl) {
                 flg[t] = r.flags;
             }
         SIMT_END
+        SWC_SP(pf, 5)
         SIMT_BEGIN(t, N) pb[t] = (uint32_t)t < nv && (flg[t] & kFlagTrap) != 0; SIMT_END
         if (simt::wave_ballot<N>(pb)) break;                             // a distance beyond the output: the checked step reports it
         pos += tot_out;
@@ -502,7 +523,7 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl) {
 // Same results and errors as Lane::build_dynamic: the code lengths are decoded once, serially (through a 128-entry
 // table of the code-length code), into an LDS array; the per-length histogram and the counting sort that produces the
 // (length, symbol)-sorted arrays run on all lanes.
-SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl) {
+SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, SyncProf& pf) {
     using simt::PT;
     constexpr int N = kWave;
     BitReader& br = ln.br;
@@ -600,12 +621,14 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl) {
         if (n != total) return SWC_E_DEFLATE_WRONG_SYMBOL;  // :161
     }
     simt::wave_fence();
+    SWC_SP(pf, 0)
     sync_tables_from_lengths(sl, literals, distances);
     return SWC_OK;
 }
 
 // Deflate.swift:77-81 with the fixed code of Deflate+Constants.swift:11-173: the same table build from the fixed lengths
-SWC_D void build_static_par(SyncLds* sl) {
+SWC_D void build_static_par(SyncLds* sl, SyncProf& pf) {
+    (void)pf;
     constexpr int N = kWave;
     uint8_t* lens = sl->stage + kHdrLens;
     uint32_t* cnt = (uint32_t*)(sl->stage + kHdrCnt);
@@ -620,8 +643,12 @@ SWC_D void build_static_par(SyncLds* sl) {
 // Deflate.swift:30-249 for one stream on one wavefront.  `ws` / `ws_bytes`: the stream's area in the HBM workspace
 // (lzr::StreamHeader | records | literal stream).  On the device every lane of the wave calls this with its lane number;
 // the host emulation calls it once (lane 0 of 1) and runs the 64 lanes of the parallel parts one after another.
-SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes, int lane, int lanes) {
+SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes, int lane, int lanes, uint64_t* prof = nullptr) {
     Lane ln;
+    SyncProf pf;
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    pf.tlast = __builtin_readcyclecounter();
+#endif
     ln.dbg = 0;
     ln.wlane = lane;
     ln.wlanes = lanes;
@@ -654,13 +681,15 @@ SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes,
             if (type == 0) {
                 st = ln.run_stored();
             } else if (type == 1 || type == 2) {
-                if (type == 1) build_static_par(sl);
-                else st = build_dynamic_par(ln, sl);
+                SWC_SP(pf, 6)
+                if (type == 1) build_static_par(sl, pf);
+                else st = build_dynamic_par(ln, sl, pf);
+                SWC_SP(pf, 1)
                 if (st == SWC_OK) {
                     bool fast = sl->aux[kAuxLit + kAuxOver] == 0 && sl->aux[kAuxDist + kAuxOver] == 0;
                     for (;;) {   // Deflate.swift:171-236
                         if (fast) {
-                            const int r = sync_block(ln, sl);
+                            const int r = sync_block(ln, sl, pf);
                             if (r == kSyncEob) break;
                             if (r == kSyncBail) fast = false;   // the checked step takes the rest of the block
                             // kSyncBailCap: checked steps until the capacity is behind us
@@ -690,6 +719,12 @@ SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes,
         h->pad0 = 0;
         h->nlit = ln.nlit;
     }
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    SWC_SP(pf, 6)
+    if (prof && lane == 0) for (int k = 0; k < 10; k++) prof[k] = pf.acc[k];
+#else
+    (void)prof; (void)pf;
+#endif
     const uint64_t bits = ln.br.consumed_bits();
     const uint64_t consumed = (bits + 7) >> 3;  // callers align() right after (GzipArchive.swift:89)
     job.in_consumed = consumed > job.in_len ? job.in_len : consumed;

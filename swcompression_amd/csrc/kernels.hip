@@ -61,12 +61,14 @@ __global__ __launch_bounds__(64, 4) void swc_inflate_wave_kernel(Job* __restrict
 #ifndef SWC_SYNC_WAVES_PER_SIMD
 #define SWC_SYNC_WAVES_PER_SIMD 3
 #endif
-__global__ __launch_bounds__(64, SWC_SYNC_WAVES_PER_SIMD) void swc_inflate_sync_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride) {
+static uint64_t* g_prof = nullptr;   // profile builds (-DSWC_PROFILE): 32 counters per job, [0..16) phase 1, [16..32) phase 2
+void set_profile_buffer(void* p) { g_prof = static_cast<uint64_t*>(p); }
+__global__ __launch_bounds__(64, SWC_SYNC_WAVES_PER_SIMD) void swc_inflate_sync_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride, uint64_t* prof) {
     __shared__ __attribute__((aligned(16))) inflate::SyncLds sync_lds;
     uint32_t g = blockIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
-    inflate::inflate_sync_job(job, &sync_lds, ws ? ws + (size_t)g * ws_stride : nullptr, ws_stride, (int)threadIdx.x, kWave);
+    inflate::inflate_sync_job(job, &sync_lds, ws ? ws + (size_t)g * ws_stride : nullptr, ws_stride, (int)threadIdx.x, kWave, prof ? prof + 32 * (size_t)g : nullptr);
     if (threadIdx.x == 0) {
         jobs[g].out_len = job.out_len;
         jobs[g].in_consumed = job.in_consumed;
@@ -77,12 +79,12 @@ __global__ __launch_bounds__(64, SWC_SYNC_WAVES_PER_SIMD) void swc_inflate_sync_
 // Phase 2: one stream per workgroup of 512 threads, 64 KiB LDS ring (32 KiB of history + span + cells) -> 2 workgroups per CU.
 constexpr int kInflateResolveThreads = 512, kInflateRingLog2 = 16;
 constexpr uint32_t kInflateKeep = 32768;
-__global__ __launch_bounds__(kInflateResolveThreads) void swc_lz_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, const uint8_t* ws, size_t ws_stride) {
+__global__ __launch_bounds__(kInflateResolveThreads) void swc_lz_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, const uint8_t* ws, size_t ws_stride, uint64_t* prof) {
     __shared__ __attribute__((aligned(16))) lzr::Lds<kInflateResolveThreads, kInflateRingLog2> lzr_lds;  // static: > 64 KiB needs no opt-in this way
     uint32_t g = blockIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
-    lzr::resolve_job<kInflateResolveThreads, kInflateRingLog2, kInflateKeep>(job, ws + (size_t)g * ws_stride, ws_stride, &lzr_lds);
+    lzr::resolve_job<kInflateResolveThreads, kInflateRingLog2, kInflateKeep>(job, ws + (size_t)g * ws_stride, ws_stride, &lzr_lds, prof ? prof + 32 * (size_t)g + 16 : nullptr);
 }
 
 static int g_inflate_dbg = 0;
@@ -123,13 +125,13 @@ hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStr
     const bool timing = g_phase_timing && g_phase_ev_ok;
     if (timing) (void)hipEventRecord(g_phase_ev[0], stream);
     if (g_inflate_mode == 0)
-        hipLaunchKernelGGL(swc_inflate_sync_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride);
+        hipLaunchKernelGGL(swc_inflate_sync_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride, g_prof);
     else if (n <= (size_t)g_wave_max_jobs)
         hipLaunchKernelGGL(swc_inflate_wave_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride, g_inflate_dbg);
     else
         hipLaunchKernelGGL(swc_inflate_kernel, grid, block, inflate::kLdsBytesPerWave, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride, g_inflate_dbg);
     if (timing) (void)hipEventRecord(g_phase_ev[1], stream);
-    hipLaunchKernelGGL(swc_lz_resolve_kernel, dim3((unsigned)n), dim3(kInflateResolveThreads), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride);
+    hipLaunchKernelGGL(swc_lz_resolve_kernel, dim3((unsigned)n), dim3(kInflateResolveThreads), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_prof);
     if (timing) { (void)hipEventRecord(g_phase_ev[2], stream); g_phase_valid = true; }
     return hipGetLastError();
 }

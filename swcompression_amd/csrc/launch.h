@@ -14,6 +14,7 @@ void set_inflate_wave_max_jobs(int n);
 void set_resolve_debug(int m);
 void set_inflate_debug(int m);
 void set_inflate_mode(int m);
+void set_profile_buffer(void* p);
 void set_phase_timing(int on);
 int last_phase_ms(float* ms, int cap);
 hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream);

@@ -91,6 +91,12 @@ struct Resolver {
     static_assert(kMaxLitOnly + kLitRunMax + kMaxLen <= kSpanMax, "a record must fit a span");
     static_assert(16u * T <= 0x8000u, "cell indices are 15 bits");
 
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    uint64_t* prof = nullptr;   // 8 counters per stream: cycles of R0+scan, R1, R2, R3, batches (profile builds only)
+#define SWC_RP(k) { const uint64_t t_ = __builtin_readcyclecounter(); pacc[k] += t_ - tlast; tlast = t_; }
+#else
+#define SWC_RP(k)
+#endif
     L* l;
     gptr out;
     gcptr lits;        // the stream's dense literal stream (16-byte aligned base)
@@ -147,6 +153,10 @@ struct Resolver {
             if (t == 0) l->slotw[T] = 0;
         SIMT_END
         lfill = kLitWin;
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+        uint64_t pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        uint64_t tlast = __builtin_readcyclecounter();
+#endif
         while (base < nrec) {
             const uint32_t vcur = A + (uint32_t)rpos;           // virtual position of the batch start (mod 2^32; the ring mask applies)
             const uint32_t off = vcur & 15u;                    // cells of slot 0 that belong to earlier batches
@@ -164,6 +174,7 @@ struct Resolver {
                 r_next[t] = r;
             SIMT_END
             simt::group_scan2_incl<T>(x, y, l->wave_sum);       // (barrier A inside)
+            SWC_RP(0)
             // ---- R1: batch geometry, one record per thread
             SIMT_BEGIN(t, T)
                 const uint32_t r = r_next[t];
@@ -187,6 +198,7 @@ struct Resolver {
                     l->ntake = (uint32_t)t; l->span = start; l->litspan = lit_end - lit;
                 }
             SIMT_END_BARRIER                                     // barrier B
+            SWC_RP(1)
             const uint32_t ntake = simt::uniform(l->ntake), span = simt::uniform(l->span), litspan = simt::uniform(l->litspan);
             const bool last_batch = base + ntake >= nrec;
             const uint32_t ncell = span + off;                   // cells [off, ncell) are this batch's bytes, [0, off) belong to earlier ones
@@ -226,6 +238,7 @@ struct Resolver {
                     cell_store(l->ring, cbase, ci, cell);
                 }
             SIMT_END_BARRIER                                     // barrier C
+            SWC_RP(2)
             // ---- R3: one aligned DWORD per thread and step: chase what is unresolved, then the dword leaves for the ring and for HBM
             SIMT_BEGIN(t, T)
                 if ((uint32_t)t * 16u < ncell) l->slotw[t] = 0;   // (read in R2 only; the next batch sets it after its barrier A)
@@ -263,17 +276,24 @@ struct Resolver {
                     }
                 }
             SIMT_END
+            SWC_RP(3)
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+            pacc[4] += 1; pacc[5] += span; pacc[6] += ntake;
+#endif
             rpos += span;
             lbase += litspan;
             lfill = lfill_next > lfill ? lfill_next : lfill;
             base += ntake;
         }
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+        if (prof && threadIdx.x == 0) for (int k = 0; k < 8; k++) prof[k] = pacc[k];
+#endif
     }
 };
 
 // One job: `ws` is the stream's workspace area of `area` bytes written by phase 1.
 template <int T, int RING_LOG2, uint32_t KEEP>
-SWC_D void resolve_job(const Job& job, const uint8_t* ws, size_t area, Lds<T, RING_LOG2>* lds) {
+SWC_D void resolve_job(const Job& job, const uint8_t* ws, size_t area, Lds<T, RING_LOG2>* lds, uint64_t* prof = nullptr) {
     const SWC_AS_GLOBAL StreamHeader* h = (const SWC_AS_GLOBAL StreamHeader*)ws;
     const size_t lo = lit_offset(area, job.out_cap);
     if (lo == 0) return;   // no literal stream: phase 1 reported SWC_E_NEED_WORKSPACE for this job
@@ -283,6 +303,11 @@ SWC_D void resolve_job(const Job& job, const uint8_t* ws, size_t area, Lds<T, RI
     rs.lits = (gcptr)ws + lo;
     rs.lit_cap = lit_bytes(job.out_cap);
     rs.limit = job.out_len < job.out_cap ? job.out_len : job.out_cap;
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    rs.prof = prof;
+#else
+    (void)prof;
+#endif
     rs.run((const SWC_AS_GLOBAL uint32_t*)(ws + sizeof(StreamHeader)), h->nrec);
 }
 
