@@ -90,6 +90,7 @@ struct Resolver {
     static_assert(48u * T + 16u <= kRing - KEEP, "ring too small for history + span + cells");
     static_assert(kMaxLitOnly + kLitRunMax + kMaxLen <= kSpanMax, "a record must fit a span");
     static_assert(16u * T <= 0x8000u, "cell indices are 15 bits");
+    static_assert(offsetof(L, litbuf) == kRing, "the literal window sits right behind the ring");
 
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     uint64_t* prof = nullptr;   // 8 counters per stream: cycles of R0+scan, R1, R2, R3, batches (profile builds only)
@@ -214,27 +215,25 @@ struct Resolver {
                     lit_pf_at[t] = want ? (uint32_t)o : 0xFFFFFFFFu;
                     if (want) lit_pf[t] = load_16(lits + o);
                 }
+                // One cell per step, as selects: a literal and a match byte whose source lies before the span are both "one
+                // byte at (K + rel) of an LDS buffer" (the literal window sits right behind the ring), so there is ONE data
+                // read whatever the cell is; only the self-overlapping match takes a branch.
                 const uint32_t lb = (uint32_t)lbase;
+                const uint8_t* lds0 = l->ring;                  // litbuf == ring + kRing (struct layout, asserted below)
                 for (uint32_t ci = (uint32_t)t; ci < ncell; ci += (uint32_t)T) {
-                    uint32_t cell;
-                    if (ci < off) {
-                        cell = 0x8000u | l->ring[(v0 + ci) & kMask];
-                    } else {
-                        const uint32_t rel = ci - off, k = ci >> 4, j = ci & 15u;
-                        const uint32_t sw = l->slotw[k];
-                        const uint32_t j0 = k == 0 ? off : 0u;   // the slot's first in-span cell: its record is the low half of the slot word
-                        const uint32_t r = (sw & 0xFFFFu) + (uint32_t)simt::popc32((sw >> 16) & ((2u << j) - 1u) & ~((2u << j0) - 1u));
-                        const uint64_t rc = l->rec8[r];
-                        const uint32_t mstart = (uint32_t)(rc >> 16) & 0xFFFFu, litadj = (uint32_t)(rc >> 32) & 0xFFFFu, dist = (uint32_t)(rc >> 48) + 1u;
-                        if (rel < mstart) {
-                            cell = 0x8000u | l->litbuf[(lb + litadj + rel) & kLitMask];
-                        } else {
-                            const uint32_t m = rel - mstart;
-                            // a match that overlaps itself repeats its first period
-                            const int32_t s = m >= dist ? (int32_t)mstart - (int32_t)dist + (int32_t)mod_small(m, dist) : (int32_t)rel - (int32_t)dist;
-                            cell = s < 0 ? 0x8000u | l->ring[(vcur + (uint32_t)s) & kMask] : (uint32_t)s + off;
-                        }
-                    }
+                    const uint32_t rel = ci - off, k = ci >> 4, j = ci & 15u;
+                    const uint32_t sw = l->slotw[k];
+                    const uint32_t j0 = k == 0 ? off : 0u;   // the slot's first in-span cell: its record is the low half of the slot word
+                    const uint32_t r = (sw & 0xFFFFu) + (uint32_t)simt::popc32((sw >> 16) & ((2u << j) - 1u) & ~((2u << j0) - 1u));
+                    const uint64_t rc = l->rec8[ci < off ? 0u : r];
+                    const uint32_t mstart = (uint32_t)(rc >> 16) & 0xFFFFu, litadj = (uint32_t)(rc >> 32) & 0xFFFFu, dist = (uint32_t)(rc >> 48) + 1u;
+                    const bool lead = ci < off, is_lit = rel < mstart;
+                    const uint32_t m = rel - mstart;
+                    int32_t s = (int32_t)rel - (int32_t)dist;
+                    if (!lead && !is_lit && m >= dist) s = (int32_t)mstart - (int32_t)dist + (int32_t)mod_small(m, dist);   // repeats its first period
+                    const uint32_t a_lit = kRing + ((lb + litadj + rel) & kLitMask), a_ring = (vcur + (uint32_t)s) & kMask, a_lead = (v0 + ci) & kMask;
+                    const uint32_t byte = lds0[lead ? a_lead : is_lit ? a_lit : a_ring];
+                    const uint32_t cell = (lead || is_lit || s < 0) ? 0x8000u | byte : (uint32_t)s + off;
                     cell_store(l->ring, cbase, ci, cell);
                 }
             SIMT_END_BARRIER                                     // barrier C
@@ -245,21 +244,24 @@ struct Resolver {
                 const uint32_t ndw = (ncell + 3u) >> 2;
                 for (uint32_t q = (uint32_t)t; q < ndw; q += (uint32_t)T) {
                     const uint64_t c4 = *(const uint64_t*)(l->ring + ((cbase + 8u * q) & kMask));
-                    uint32_t word = 0;
+                    uint32_t c[4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        uint32_t c = (uint32_t)(c4 >> (16 * e)) & 0xFFFFu;
-                        if (!(c & 0x8000u) && 4u * q + (uint32_t)e < ncell) {
-                            uint32_t s = c;
-                            for (;;) {
-                                c = cell_load(l->ring, cbase, s);
-                                if (c & 0x8000u) break;
-                                s = c;
-                            }
-                            cell_store(l->ring, cbase, 4u * q + (uint32_t)e, c);
-                        }
-                        word |= (c & 0xFFu) << (8 * e);
+                        c[e] = (uint32_t)(c4 >> (16 * e)) & 0xFFFFu;
+                        if (4u * q + (uint32_t)e >= ncell) c[e] = 0x8000u;   // beyond the span: the next batch's cells
                     }
+                    // the four chains advance together: one hop = four independent LDS reads in flight
+                    const uint32_t was = (c[0] & c[1] & c[2] & c[3]) & 0x8000u;
+                    while (!((c[0] & c[1] & c[2] & c[3]) & 0x8000u)) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) if (!(c[e] & 0x8000u)) c[e] = cell_load(l->ring, cbase, c[e]);
+                    }
+                    if (!was) {   // resolved values back into my cells: later readers stop here
+                        const uint64_t v = (uint64_t)c[0] | ((uint64_t)c[1] << 16) | ((uint64_t)c[2] << 32) | ((uint64_t)c[3] << 48);
+                        if (4u * q + 4u <= ncell) *(uint64_t*)(l->ring + ((cbase + 8u * q) & kMask)) = v;
+                        else for (int e = 0; e < 4; e++) if (4u * q + (uint32_t)e < ncell) cell_store(l->ring, cbase, 4u * q + (uint32_t)e, c[e]);
+                    }
+                    const uint32_t word = (c[0] & 0xFFu) | ((c[1] & 0xFFu) << 8) | ((c[2] & 0xFFu) << 16) | ((c[3] & 0xFFu) << 24);
                     *(uint32_t*)(l->ring + ((v0 + 4u * q) & kMask)) = word;
                     const bool complete = 4u * q + 4u <= ncell;
                     if (complete || last_batch) {

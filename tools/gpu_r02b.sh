@@ -8,3 +8,4 @@ d = json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['rooflin
 timeout 900 python bench.py --workload lz4_4m --steps 2 --warmup 1 --no-cpu-baseline > $O/bench_lz4_4m.log 2>&1; echo "bench lz4 rc=$?"; tail -1 $O/bench_lz4_4m.log | python -c "
 import sys, json
 d = json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+if [ "$2" = "prof" ]; then bash tools/gpu_prof2.sh $TAG; fi
