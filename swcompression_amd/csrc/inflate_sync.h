@@ -50,9 +50,9 @@ constexpr uint32_t kEntInvalid = 0x80000000u;        // a code of the set, but n
 constexpr uint32_t kPosFail = 0xFFFFFFFFu;
 static_assert(kSyncChunk % 4 == 0 && kSyncChunk >= 64, "sub-chunks are whole dwords");
 
-// Table entry: [0:3] code length, [4:7] extra bits, [8:9] kind, [10:25] base value, [31] invalid.
-// kind, lit/len table: 1 literal, 2 length, 3 end of block; distance table: 1 distance.
-SWC_HD uint32_t make_entry(uint32_t clen, uint32_t ext, uint32_t kind, uint32_t value) { return clen | (ext << 4) | (kind << 8) | (value << 10); }
+// Table entry: [0:3] code length, [4:7] extra bits, [8:9] kind, [10:25] base value, [26:30] code length + extra bits,
+// [31] invalid.  kind, lit/len table: 1 literal, 2 length, 3 end of block; distance table: 1 distance.
+SWC_HD uint32_t make_entry(uint32_t clen, uint32_t ext, uint32_t kind, uint32_t value) { return clen | (ext << 4) | (kind << 8) | (value << 10) | ((clen + ext) << 26); }
 
 // The canonical tables of inflate_lane.h (struct Table) kept in LDS: per length d the left-justified code limit, the slot
 // word (sorted index of the first code - first code | index of the first symbol >= 256 << 16) and the sorted index of the
@@ -235,14 +235,14 @@ SWC_D void sync_build_luts(SyncLds* sl) {
                         const uint32_t e = s < 8 || s == 28 ? 0u : (s >> 2) - 1u;
                         const uint32_t base = s < 8 ? 3u + s : s == 28 ? 258u : 3u + ((4u + (s & 3u)) << e);
                         entry = make_entry(d, e, 2, base);
-                    } else entry = d | kEntInvalid;   // 286, 287: the checked step reports wrongSymbol
+                    } else entry = d | (d << 26) | kEntInvalid;   // 286, 287: the checked step reports wrongSymbol
                 } else {
                     const uint32_t dc = *sym_ptr(l, W_DIST_SYM, j);
                     if (dc <= 29) {
                         const uint32_t e = dc < 4 ? 0u : (dc >> 1) - 1u;
                         const uint32_t base = dc < 4 ? 1u + dc : 1u + ((2u + (dc & 1u)) << e);
                         entry = make_entry(d, e, 1, base);
-                    } else entry = d | kEntInvalid;   // 30, 31: wrongSymbol
+                    } else entry = d | (d << 26) | kEntInvalid;   // 30, 31: wrongSymbol
                 }
                 sl->symtab[(tbl ? 288u : 0u) + j] = entry;
                 if (d <= lut_bits)
@@ -325,11 +325,56 @@ SWC_HD uint32_t bfe32(uint32_t v, uint32_t off, uint32_t width) {   // width 0..
 #endif
 }
 
+// The canonical limits and slot words of the code lengths 10..15 of both alphabets, in registers while the rounds run:
+// a code longer than the direct tables is resolved with compares and ONE LDS read (its symbol entry).
+// (Scalar members and an opaque selector on purpose: with arrays LLVM folds `st ? a[d] : b[d]` into a dynamically
+// indexed load, which moves the whole table to scratch memory.)
+struct LongCodes {
+    uint32_t l0, l1, l2, l3, l4, l5, m0, m1, m2, m3, m4, m5;   // limits of the lengths 10..15: lit/len, distance
+    uint32_t s0, s1, s2, s3, s4, s5, t0, t1, t2, t3, t4, t5;   // slot words likewise
+    SWC_D void load(const SyncLds* sl) {
+        const uint32_t* a = sl->aux + kAuxLit + kAuxLim + 10;
+        const uint32_t* b = sl->aux + kAuxDist + kAuxLim + 10;
+        const uint32_t* c = sl->aux + kAuxLit + kAuxSlot + 10;
+        const uint32_t* d = sl->aux + kAuxDist + kAuxSlot + 10;
+        l0 = a[0]; l1 = a[1]; l2 = a[2]; l3 = a[3]; l4 = a[4]; l5 = a[5];
+        m0 = b[0]; m1 = b[1]; m2 = b[2]; m3 = b[3]; m4 = b[4]; m5 = b[5];
+        s0 = c[0]; s1 = c[1]; s2 = c[2]; s3 = c[3]; s4 = c[4]; s5 = c[5];
+        t0 = d[0]; t1 = d[1]; t2 = d[2]; t3 = d[3]; t4 = d[4]; t5 = d[5];
+    }
+    // the entry of the code that starts `bits` (state: 0 lit/len, 1 distance); kEntInvalid if there is none
+    SWC_D uint32_t lookup(const SyncLds* sl, uint32_t bits, uint32_t state) const {
+        const uint32_t c15 = brev32(bits) >> 17;
+        uint32_t sel = state;
+        SWC_OPAQUE(sel);
+        const bool st = sel != 0;
+        // the limits do not decrease with the length: count how many the window reaches, keep the slot word of that length
+        const bool g0 = c15 >= (st ? m0 : l0), g1 = c15 >= (st ? m1 : l1), g2 = c15 >= (st ? m2 : l2);
+        const bool g3 = c15 >= (st ? m3 : l3), g4 = c15 >= (st ? m4 : l4), g5 = c15 >= (st ? m5 : l5);
+        const uint32_t len = 10u + (g0 ? 1u : 0u) + (g1 ? 1u : 0u) + (g2 ? 1u : 0u) + (g3 ? 1u : 0u) + (g4 ? 1u : 0u) + (g5 ? 1u : 0u);
+        uint32_t slw = st ? t0 : s0;
+        slw = g0 ? (st ? t1 : s1) : slw;
+        slw = g1 ? (st ? t2 : s2) : slw;
+        slw = g2 ? (st ? t3 : s3) : slw;
+        slw = g3 ? (st ? t4 : s4) : slw;
+        slw = g4 ? (st ? t5 : s5) : slw;
+        const uint32_t lenc = len > 15 ? 15u : len;
+        uint32_t j = (slw + (c15 >> (15 - lenc))) & 0xFFFFu;
+        const uint32_t jmax = st ? 31u : 287u;
+        j = j > jmax ? jmax : j;
+        const uint32_t e = sl->symtab[(st ? 288u : 0u) + j];
+        return len > 15 ? kEntInvalid : e;
+    }
+};
+
 // MODE 0: count.  MODE 1: emit literals and records.  MODE 2: check distances only (output beyond the capacity).
+// MODE 3: walk (where does the decode end?).  BIG: literal runs of more than lzr::kLitRunMax bytes in front of a match
+// get a record of their own (only possible in a sub-chunk that holds more than that many literals: the caller picks).
+// CHK: symbols may run past the end of the input.
 // Decodes from bit `start` until a lit/len symbol would begin at or beyond `chunk_end`, or the end-of-block symbol.
-template <int MODE>
-SWC_D void decode_chunk(const SyncLds* sl, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr lit_dst, SWC_AS_GLOBAL uint32_t* rec_dst,
-                        uint64_t out_pos0, ChunkOut& r) {
+template <int MODE, bool BIG, bool CHK>
+SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr lit_dst,
+                        SWC_AS_GLOBAL uint32_t* rec_dst, uint64_t out_pos0, ChunkOut& r) {
     const uint32_t* st32 = (const uint32_t*)sl->stage;
     uint32_t w = start >> 5, bp = start & 31u;
     uint32_t d0 = st32[w], d1 = st32[w + 1], d2 = st32[w + 2];
@@ -341,49 +386,37 @@ SWC_D void decode_chunk(const SyncLds* sl, uint32_t start, uint32_t chunk_end, u
     for (;;) {
         const uint32_t posb = (w << 5) + bp;
         if (state == 0 && posb >= chunk_end) break;
-        SWC_SYNC_STAT(4 + MODE, 1);   // code iterations per mode
+        SWC_SYNC_STAT(4 + (MODE == 3 ? 0 : MODE), 1);   // code iterations per mode
         const uint32_t bits = funnel32(d1, d0, bp);
         const uint32_t idx = state ? (1u << kSyncLitBits) + (bits & ((1u << kSyncDistBits) - 1u)) : bits & ((1u << kSyncLitBits) - 1u);
         uint32_t e = sl->lut[idx];
-        if (e == 0) {   // a code longer than the direct table (or no code at all)
-            const uint32_t c15 = brev32(bits) >> 17;
-            const uint32_t* tb = sl->aux + (state ? kAuxDist : kAuxLit);
-            const uint32_t* lim = tb + kAuxLim;
-            uint32_t len = 10;
-#pragma unroll
-            for (int d = 10; d <= 15; d++) len += c15 >= lim[d] ? 1u : 0u;
-            const uint32_t lenc = len > 15 ? 15u : len;
-            const uint32_t slw = tb[kAuxSlot + lenc];
-            uint32_t j = (slw + (c15 >> (15 - lenc))) & 0xFFFFu;
-            const uint32_t jmax = state ? 31u : 287u;
-            j = j > jmax ? jmax : j;
-            e = sl->symtab[(state ? 288u : 0u) + j];
-            e = len > 15 ? kEntInvalid : e;
-        }
-        const uint32_t clen = e & 15u, ext = (e >> 4) & 15u, kind = (e >> 8) & 3u;
-        const uint32_t val = ((e >> 10) & 0xFFFFu) + bfe32(bits, clen, ext);
-        const uint32_t n = clen + ext;
+        if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, state); }   // a code longer than the direct table (or no code at all)
+        const uint32_t n = (e >> 26) & 31u, kind = (e >> 8) & 3u;
         // not a symbol the fast path takes, or the symbol runs past the end of the input
-        if ((e & kEntInvalid) || posb + n > in_bits) { flags |= kFlagFail; break; }
+        if ((e & kEntInvalid) || (CHK && posb + n > in_bits)) { flags |= kFlagFail; break; }
         const bool is_dist = state != 0;
-        const bool is_lit = !is_dist && kind == 1, is_len = !is_dist && kind == 2, is_eob = !is_dist && kind == 3;
-        if (MODE != 0 && is_dist && (uint64_t)val > out_pos0 + nout) { flags |= kFlagTrap; break; }
-        const bool big = is_dist && run > lzr::kLitRunMax;
-        if (MODE == 1) {
-            if (is_lit) {
-                lb |= (uint64_t)val << (8 * lbn);
-                if (++lbn == 8) { store_u64(lit_dst, lb); lit_dst += 8; lb = 0; lbn = 0; }
+        const bool is_len = !is_dist && kind == 2, is_eob = !is_dist && kind == 3;
+        if (MODE != 3) {
+            const bool is_lit = !is_dist && kind == 1;
+            const uint32_t val = ((e >> 10) & 0xFFFFu) + bfe32(bits, e & 15u, (e >> 4) & 15u);
+            if (MODE != 0 && is_dist && (uint64_t)val > out_pos0 + nout) { flags |= kFlagTrap; break; }
+            const bool big = BIG && is_dist && run > lzr::kLitRunMax;
+            if (MODE == 1) {
+                if (is_lit) {
+                    lb |= (uint64_t)val << (8 * lbn);
+                    if (++lbn == 8) { store_u64(lit_dst, lb); lit_dst += 8; lb = 0; lbn = 0; }
+                }
+                if (is_dist) {
+                    if (big) *rec_dst++ = lzr::make_lits(run);
+                    *rec_dst++ = lzr::make_match(big ? 0u : run, plen, val);
+                }
             }
-            if (is_dist) {
-                if (big) *rec_dst++ = lzr::make_lits(run);
-                *rec_dst++ = lzr::make_match(big ? 0u : run, plen, val);
-            }
+            nlit += is_lit ? 1u : 0u;
+            nout += is_lit ? 1u : is_dist ? plen : 0u;
+            nrec += is_dist ? (big ? 2u : 1u) : 0u;
+            run = is_dist ? 0u : run + (is_lit ? 1u : 0u);
+            plen = is_len ? val : plen;
         }
-        nlit += is_lit ? 1u : 0u;
-        nout += is_lit ? 1u : is_dist ? plen : 0u;
-        nrec += is_dist ? (big ? 2u : 1u) : 0u;
-        run = is_dist ? 0u : run + (is_lit ? 1u : 0u);
-        plen = is_len ? val : plen;
         state = is_len ? 1u : 0u;
         bp += n;
         if (is_eob) { flags |= kFlagEob; break; }
@@ -394,7 +427,7 @@ SWC_D void decode_chunk(const SyncLds* sl, uint32_t start, uint32_t chunk_end, u
         d1 = sh ? d2 : d1;
         if (sh) d2 = st32[w + 2];
     }
-    if (run > 0) {   // the sub-chunk closes its literal run itself
+    if (MODE != 3 && run > 0) {   // the sub-chunk closes its literal run itself
         nrec++;
         if (MODE == 1) *rec_dst++ = lzr::make_lits(run);
     }
@@ -420,7 +453,9 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
     gcptr in = ln.br.in;
     int result = kSyncBail;
     PT<uint32_t, N> start, endp, pe, c_lit, c_rec, c_out, flg, x_lit, x_rec, x_out;
-    PT<bool, N> todo, pb;
+    PT<bool, N> todo, pb, have;
+    LongCodes lc;
+    lc.load(sl);
     for (;;) {
         const uint32_t B = (uint32_t)(P >> 3) & ~3u;
         const uint32_t q0 = (uint32_t)(P - 8ull * B);
@@ -442,25 +477,26 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                 *(uint64_t*)(sl->stage + o + 8) = b;
             }
             start[t] = t == 0 ? q0 : (uint32_t)t * kSyncChunk * 8u;
-            todo[t] = true;
         SIMT_END_WAVE
         uint32_t nv = 0;
         bool eob = false, bail = false;
+        const bool chk = (uint64_t)B + kSyncStage > in_len;   // only the last rounds of a stream can run out of input
         SWC_SP(pf, 2)
+        // pass 1: where does a decode from my guess end?  (no counting)
+        SWC_SYNC_STAT(2, 1);
+        SWC_SPC(pf, 8, 1);
+        SIMT_BEGIN(t, N)
+            ChunkOut r;
+            const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
+            if (chk) decode_chunk<3, false, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+            else decode_chunk<3, false, false>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+            endp[t] = r.end; flg[t] = 0; have[t] = false;
+        SIMT_END
+        SWC_SP(pf, 3)
         for (;;) {
-            SWC_SYNC_STAT(2, 1);   // passes
-            SWC_SPC(pf, 8, 1);
-            SIMT_BEGIN(t, N)
-                if (todo[t]) {
-                    SWC_SYNC_STAT(3, 1);   // lane decodes
-                    ChunkOut r;
-                    decode_chunk<0>(sl, start[t], ((uint32_t)t + 1u) * kSyncChunk * 8u, in_bits, nullptr, nullptr, 0, r);
-                    endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; flg[t] = r.flags;
-                }
-            SIMT_END
-            SWC_SP(pf, 3)
             simt::wave_shift_up<N>(pe, endp, q0);
-            SIMT_BEGIN(t, N) pb[t] = t != 0 && start[t] != pe[t]; SIMT_END
+            // a lane is final when it has been counted from the end of a final left neighbour
+            SIMT_BEGIN(t, N) pb[t] = !(have[t] && (t == 0 || start[t] == pe[t])); SIMT_END
             const uint64_t m_bad = simt::wave_ballot<N>(pb);
             const int b = m_bad ? simt::ctz64(m_bad) : 64;               // lanes [0, b) are on the true sequence
             const uint64_t chain = b == 64 ? ~0ull : (1ull << b) - 1ull;
@@ -473,10 +509,26 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
             if (m_fail) { bail = true; break; }                          // the true sequence holds something for the checked step
             if (E < 64) { eob = true; break; }
             if (b == 64) break;
+            SWC_SYNC_STAT(2, 1);   // passes
+            SWC_SPC(pf, 8, 1);
             SIMT_BEGIN(t, N)
-                todo[t] = t >= b && start[t] != pe[t] && pe[t] != kPosFail;
-                if (todo[t]) start[t] = pe[t];
+                todo[t] = t == 0 ? !have[t] : pe[t] != kPosFail && (start[t] != pe[t] || !have[t]);
+                if (todo[t]) {
+                    SWC_SYNC_STAT(3, 1);   // lane decodes
+                    if (t != 0) start[t] = pe[t];
+                    ChunkOut r;
+                    const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
+                    if (chk) decode_chunk<0, false, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                    else decode_chunk<0, false, false>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                    if (r.nlit > lzr::kLitRunMax) {   // a literal run may need a record of its own: count those too
+                        if (chk) decode_chunk<0, true, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                        else decode_chunk<0, true, false>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                    }
+                    endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; flg[t] = r.flags;
+                    have[t] = true;
+                }
             SIMT_END
+            SWC_SP(pf, 3)
         }
         if (bail) { SWC_SYNC_STAT(1, 1); break; }
         SWC_SYNC_STAT(0, 1);   // rounds that converged
@@ -498,8 +550,10 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                 ChunkOut r;
                 const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
                 const uint64_t p0 = pos + (x_out[t] - c_out[t]);
-                if (beyond) decode_chunk<2>(sl, start[t], ce, in_bits, nullptr, nullptr, p0, r);
-                else decode_chunk<1>(sl, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
+                const bool bigs = c_lit[t] > lzr::kLitRunMax;
+                if (beyond) decode_chunk<2, false, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, p0, r);
+                else if (bigs || chk) decode_chunk<1, true, true>(sl, lc, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
+                else decode_chunk<1, false, false>(sl, lc, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
                 flg[t] = r.flags;
             }
         SIMT_END
