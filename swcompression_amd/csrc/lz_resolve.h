@@ -220,46 +220,21 @@ struct Resolver {
                 // read whatever the cell is; only the self-overlapping match takes a branch.
                 const uint32_t lb = (uint32_t)lbase;
                 const uint8_t* lds0 = l->ring;                  // litbuf == ring + kRing (struct layout, asserted below)
-                // Four cells per step (T apart): every stage is four independent LDS reads in flight -- the chain slot word
-                // -> record -> data byte is three dependent LDS round trips per cell otherwise.
-                constexpr int U = 4;
-                for (uint32_t c0 = (uint32_t)t; c0 < ncell; c0 += (uint32_t)(U * T)) {
-                    uint32_t ci[U], sw[U], cell[U], addr[U];
-                    uint64_t rc[U];
-                    int32_t sv[U];
-                    bool live[U], direct[U];
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        ci[u] = c0 + (uint32_t)(u * T);
-                        live[u] = ci[u] < ncell;
-                        if (!live[u]) ci[u] = c0;
-                        sw[u] = l->slotw[ci[u] >> 4];
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const uint32_t k = ci[u] >> 4, j = ci[u] & 15u;
-                        const uint32_t j0 = k == 0 ? off : 0u;   // the slot's first in-span cell: its record is the low half of the slot word
-                        const uint32_t r = (sw[u] & 0xFFFFu) + (uint32_t)simt::popc32((sw[u] >> 16) & ((2u << j) - 1u) & ~((2u << j0) - 1u));
-                        rc[u] = l->rec8[ci[u] < off ? 0u : r];
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        const uint32_t rel = ci[u] - off;
-                        const uint32_t mstart = (uint32_t)(rc[u] >> 16) & 0xFFFFu, litadj = (uint32_t)(rc[u] >> 32) & 0xFFFFu, dist = (uint32_t)(rc[u] >> 48) + 1u;
-                        const bool lead = ci[u] < off, is_lit = rel < mstart;
-                        const uint32_t m = rel - mstart;
-                        int32_t s = (int32_t)rel - (int32_t)dist;
-                        if (!lead && !is_lit && m >= dist) s = (int32_t)mstart - (int32_t)dist + (int32_t)mod_small(m, dist);   // repeats its first period
-                        const uint32_t a_lit = kRing + ((lb + litadj + rel) & kLitMask), a_ring = (vcur + (uint32_t)s) & kMask, a_lead = (v0 + ci[u]) & kMask;
-                        addr[u] = lead ? a_lead : is_lit ? a_lit : a_ring;
-                        sv[u] = s;
-                        direct[u] = lead || is_lit || s < 0;
-                    }
-#pragma unroll
-                    for (int u = 0; u < U; u++) cell[u] = lds0[addr[u]];
-#pragma unroll
-                    for (int u = 0; u < U; u++)
-                        if (live[u]) cell_store(l->ring, cbase, ci[u], direct[u] ? 0x8000u | cell[u] : (uint32_t)sv[u] + off);
+                for (uint32_t ci = (uint32_t)t; ci < ncell; ci += (uint32_t)T) {
+                    const uint32_t rel = ci - off, k = ci >> 4, j = ci & 15u;
+                    const uint32_t sw = l->slotw[k];
+                    const uint32_t j0 = k == 0 ? off : 0u;   // the slot's first in-span cell: its record is the low half of the slot word
+                    const uint32_t r = (sw & 0xFFFFu) + (uint32_t)simt::popc32((sw >> 16) & ((2u << j) - 1u) & ~((2u << j0) - 1u));
+                    const uint64_t rc = l->rec8[ci < off ? 0u : r];
+                    const uint32_t mstart = (uint32_t)(rc >> 16) & 0xFFFFu, litadj = (uint32_t)(rc >> 32) & 0xFFFFu, dist = (uint32_t)(rc >> 48) + 1u;
+                    const bool lead = ci < off, is_lit = rel < mstart;
+                    const uint32_t m = rel - mstart;
+                    int32_t s = (int32_t)rel - (int32_t)dist;
+                    if (!lead && !is_lit && m >= dist) s = (int32_t)mstart - (int32_t)dist + (int32_t)mod_small(m, dist);   // repeats its first period
+                    const uint32_t a_lit = kRing + ((lb + litadj + rel) & kLitMask), a_ring = (vcur + (uint32_t)s) & kMask, a_lead = (v0 + ci) & kMask;
+                    const uint32_t byte = lds0[lead ? a_lead : is_lit ? a_lit : a_ring];
+                    const uint32_t cell = (lead || is_lit || s < 0) ? 0x8000u | byte : (uint32_t)s + off;
+                    cell_store(l->ring, cbase, ci, cell);
                 }
             SIMT_END_BARRIER                                     // barrier C
             SWC_RP(2)
@@ -267,56 +242,37 @@ struct Resolver {
             SIMT_BEGIN(t, T)
                 if ((uint32_t)t * 16u < ncell) l->slotw[t] = 0;   // (read in R2 only; the next batch sets it after its barrier A)
                 const uint32_t ndw = (ncell + 3u) >> 2;
-                constexpr int U = 2;   // two dwords (T apart) per step: eight chains advance together
-                for (uint32_t q0 = (uint32_t)t; q0 < ndw; q0 += (uint32_t)(U * T)) {
-                    uint32_t c[U][4], qq[U];
-                    bool live[U];
-                    uint32_t all = 0x8000u;
+                for (uint32_t q = (uint32_t)t; q < ndw; q += (uint32_t)T) {
+                    const uint64_t c4 = *(const uint64_t*)(l->ring + ((cbase + 8u * q) & kMask));
+                    uint32_t c[4];
 #pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        qq[u] = q0 + (uint32_t)(u * T);
-                        live[u] = qq[u] < ndw;
-                        const uint64_t c4 = *(const uint64_t*)(l->ring + ((cbase + 8u * (live[u] ? qq[u] : q0)) & kMask));
-#pragma unroll
-                        for (int e = 0; e < 4; e++) {
-                            c[u][e] = (uint32_t)(c4 >> (16 * e)) & 0xFFFFu;
-                            if (!live[u] || 4u * qq[u] + (uint32_t)e >= ncell) c[u][e] = 0x8000u;   // beyond the span: the next batch's cells
-                            all &= c[u][e];
-                        }
+                    for (int e = 0; e < 4; e++) {
+                        c[e] = (uint32_t)(c4 >> (16 * e)) & 0xFFFFu;
+                        if (4u * q + (uint32_t)e >= ncell) c[e] = 0x8000u;   // beyond the span: the next batch's cells
                     }
-                    const uint32_t was = all;
-                    while (!(all & 0x8000u)) {   // one hop = up to eight independent LDS reads in flight
-                        all = 0x8000u;
+                    // the four chains advance together: one hop = four independent LDS reads in flight
+                    const uint32_t was = (c[0] & c[1] & c[2] & c[3]) & 0x8000u;
+                    while (!((c[0] & c[1] & c[2] & c[3]) & 0x8000u)) {
 #pragma unroll
-                        for (int u = 0; u < U; u++)
-#pragma unroll
-                            for (int e = 0; e < 4; e++) {
-                                if (!(c[u][e] & 0x8000u)) c[u][e] = cell_load(l->ring, cbase, c[u][e]);
-                                all &= c[u][e];
-                            }
+                        for (int e = 0; e < 4; e++) if (!(c[e] & 0x8000u)) c[e] = cell_load(l->ring, cbase, c[e]);
                     }
-#pragma unroll
-                    for (int u = 0; u < U; u++) {
-                        if (!live[u]) continue;
-                        const uint32_t q = qq[u];
-                        if (!(was & 0x8000u)) {   // resolved values back into my cells: later readers stop here
-                            const uint64_t v = (uint64_t)c[u][0] | ((uint64_t)c[u][1] << 16) | ((uint64_t)c[u][2] << 32) | ((uint64_t)c[u][3] << 48);
-                            if (4u * q + 4u <= ncell) *(uint64_t*)(l->ring + ((cbase + 8u * q) & kMask)) = v;
-                            else for (int e = 0; e < 4; e++) if (4u * q + (uint32_t)e < ncell) cell_store(l->ring, cbase, 4u * q + (uint32_t)e, c[u][e]);
-                        }
-                        const uint32_t word = (c[u][0] & 0xFFu) | ((c[u][1] & 0xFFu) << 8) | ((c[u][2] & 0xFFu) << 16) | ((c[u][3] & 0xFFu) << 24);
-                        *(uint32_t*)(l->ring + ((v0 + 4u * q) & kMask)) = word;
-                        const bool complete = 4u * q + 4u <= ncell;
-                        if (complete || last_batch) {
-                            const int64_t a0 = (int64_t)rpos - (int64_t)off + 4 * (int64_t)q;   // output position of the dword's first byte
-                            if (complete && a0 >= 0 && (uint64_t)(a0 + 4) <= limit) {
-                                *(SWC_AS_GLOBAL uint32_t*)(out + a0) = word;
-                            } else {
+                    if (!was) {   // resolved values back into my cells: later readers stop here
+                        const uint64_t v = (uint64_t)c[0] | ((uint64_t)c[1] << 16) | ((uint64_t)c[2] << 32) | ((uint64_t)c[3] << 48);
+                        if (4u * q + 4u <= ncell) *(uint64_t*)(l->ring + ((cbase + 8u * q) & kMask)) = v;
+                        else for (int e = 0; e < 4; e++) if (4u * q + (uint32_t)e < ncell) cell_store(l->ring, cbase, 4u * q + (uint32_t)e, c[e]);
+                    }
+                    const uint32_t word = (c[0] & 0xFFu) | ((c[1] & 0xFFu) << 8) | ((c[2] & 0xFFu) << 16) | ((c[3] & 0xFFu) << 24);
+                    *(uint32_t*)(l->ring + ((v0 + 4u * q) & kMask)) = word;
+                    const bool complete = 4u * q + 4u <= ncell;
+                    if (complete || last_batch) {
+                        const int64_t a0 = (int64_t)rpos - (int64_t)off + 4 * (int64_t)q;   // output position of the dword's first byte
+                        if (complete && a0 >= 0 && (uint64_t)(a0 + 4) <= limit) {
+                            *(SWC_AS_GLOBAL uint32_t*)(out + a0) = word;
+                        } else {
 #pragma unroll 1
-                                for (int e = 0; e < 4; e++) {
-                                    const int64_t a = a0 + e;
-                                    if (4u * q + (uint32_t)e < ncell && a >= 0 && (uint64_t)a < limit) out[a] = (uint8_t)(word >> (8 * e));
-                                }
+                            for (int e = 0; e < 4; e++) {
+                                const int64_t a = a0 + e;
+                                if (4u * q + (uint32_t)e < ncell && a >= 0 && (uint64_t)a < limit) out[a] = (uint8_t)(word >> (8 * e));
                             }
                         }
                     }
