@@ -40,15 +40,9 @@ namespace swc {
 namespace inflate {
 
 constexpr int kSyncLitBits = 10, kSyncDistBits = 9;
-#ifndef SWC_SYNC_CHUNK
-#define SWC_SYNC_CHUNK 96
-#endif
-constexpr uint32_t kSyncChunk = SWC_SYNC_CHUNK;      // input bytes per lane and round (a multiple of 4)
-constexpr uint32_t kSyncRound = 64u * kSyncChunk;
-constexpr uint32_t kSyncStage = kSyncRound + 128u;   // + what the last lane may read past its sub-chunk
+constexpr uint32_t kSyncChunkMin = 64, kSyncChunkMax = 512;   // input bytes per lane and round (a multiple of 16, chosen per round)
 constexpr uint32_t kEntInvalid = 0x80000000u;        // a code of the set, but not a symbol the fast path takes
 constexpr uint32_t kPosFail = 0xFFFFFFFFu;
-static_assert(kSyncChunk % 4 == 0 && kSyncChunk >= 64, "sub-chunks are whole dwords");
 
 // Table entry: [0:3] code length, [4:7] extra bits, [8:9] kind, [10:25] base value, [26:30] code length + extra bits,
 // [31] invalid.  kind, lit/len table: 1 literal, 2 length, 3 end of block; distance table: 1 distance.
@@ -65,12 +59,12 @@ struct SyncLds {
     uint32_t lut[(1 << kSyncLitBits) + (1 << kSyncDistBits)];      // direct tables: lit/len, then distance
     uint32_t symtab[320];                                           // one entry per sorted symbol: lit/len at 0, distance at 288
     uint32_t aux[kAuxWords];                                        // the canonical tables (see kAux*)
-    alignas(16) uint8_t stage[kSyncStage];                          // staged input of a round; header build: code lengths, counters, code-length table
 };
-// header scratch inside `stage`
+// Header scratch: lives in the first bytes of `lut` (the direct tables are built after the header is done with it)
 constexpr uint32_t kHdrLens = 0;       // 320 bytes: code length of symbol s
 constexpr uint32_t kHdrCnt = 320;      // 48 words: codes per length (lit/len, of those symbols < 256, distance)
 constexpr uint32_t kHdrClLut = 512;    // 128 bytes: code-length code, len | symbol << 3 (0xFF: no code)
+SWC_D uint8_t* hdr_scratch(SyncLds* sl) { return (uint8_t*)sl->lut; }
 
 enum { kSyncEob = 0, kSyncBail = 1, kSyncBailCap = 2 };
 #if defined(SWC_HOST_EMULATION)
@@ -257,8 +251,8 @@ SWC_D void sync_build_luts(SyncLds* sl) {
 SWC_D void sync_tables_from_lengths(SyncLds* sl, int literals, int distances) {
     using simt::PT;
     constexpr int N = kWave;
-    const uint8_t* lens = sl->stage + kHdrLens;
-    uint32_t* cnt = (uint32_t*)(sl->stage + kHdrCnt);
+    const uint8_t* lens = hdr_scratch(sl) + kHdrLens;
+    uint32_t* cnt = (uint32_t*)(hdr_scratch(sl) + kHdrCnt);
     const LaneLds l{sl->syms, 1};
     const int total = literals + distances;
     // codes per length of the lit/len alphabet, of those symbols < 256, and of the distance alphabet
@@ -325,6 +319,50 @@ SWC_HD uint32_t bfe32(uint32_t v, uint32_t off, uint32_t width) {   // width 0..
 #endif
 }
 
+// A lane's view of the compressed input: it reads its sub-chunk straight from HBM / L2 in 16-byte granules, one
+// granule ahead of the one it is consuming, and hands out dwords.  (No LDS staging: the kernel is bound by the latency
+// of the dependent table lookups, i.e. by the number of resident waves, and LDS is what limits those.)
+struct Feed {
+    gcptr p;            // byte address of the round base
+    uint32_t avail;     // bytes of input from there
+    uint32_t goff;      // offset of the next granule to request
+    uint32_t a0, a1, a2, a3, b0, b1, b2, b3;   // the granule being handed out, the next one
+    uint32_t k;         // dwords of `a` handed out
+    SWC_D static void load16(gcptr p, uint32_t avail, uint32_t off, uint32_t& x0, uint32_t& x1, uint32_t& x2, uint32_t& x3) {
+        uint64_t lo = 0, hi = 0;
+        if (off + 16 <= avail) { lo = load_u64(p + off); hi = load_u64(p + off + 8); }
+        else {   // the last granules of a stream: zero-filled
+            for (uint32_t i = 0; i < 8; i++) if (off + i < avail) lo |= (uint64_t)p[off + i] << (8 * i);
+            for (uint32_t i = 0; i < 8; i++) if (off + 8 + i < avail) hi |= (uint64_t)p[off + 8 + i] << (8 * i);
+        }
+        x0 = (uint32_t)lo; x1 = (uint32_t)(lo >> 32); x2 = (uint32_t)hi; x3 = (uint32_t)(hi >> 32);
+    }
+    SWC_D uint32_t next() {
+        uint32_t kk = k;
+        SWC_OPAQUE(kk);
+        const uint32_t lo = (kk & 1u) ? a1 : a0, hi = (kk & 1u) ? a3 : a2;
+        const uint32_t v = (kk & 2u) ? hi : lo;
+        k++;
+        if (k == 4) {
+            a0 = b0; a1 = b1; a2 = b2; a3 = b3;
+            k = 0;
+            load16(p, avail, goff, b0, b1, b2, b3);
+            goff += 16;
+        }
+        return v;
+    }
+    // positions the feed at bit `start` (relative to the round base) and fills the three-dword window
+    SWC_D void init(gcptr base, uint32_t avail_, uint32_t start, uint32_t& d0, uint32_t& d1, uint32_t& d2) {
+        p = base; avail = avail_;
+        const uint32_t g = (start >> 7) << 4;
+        load16(p, avail, g, a0, a1, a2, a3);
+        load16(p, avail, g + 16, b0, b1, b2, b3);
+        goff = g + 32;
+        k = (start >> 5) & 3u;
+        d0 = next(); d1 = next(); d2 = next();
+    }
+};
+
 // The canonical limits and slot words of the code lengths 10..15 of both alphabets, in registers while the rounds run:
 // a code longer than the direct tables is resolved with compares and ONE LDS read (its symbol entry).
 // (Scalar members and an opaque selector on purpose: with arrays LLVM folds `st ? a[d] : b[d]` into a dynamically
@@ -373,11 +411,12 @@ struct LongCodes {
 // CHK: symbols may run past the end of the input.
 // Decodes from bit `start` until a lit/len symbol would begin at or beyond `chunk_end`, or the end-of-block symbol.
 template <int MODE, bool BIG, bool CHK>
-SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr lit_dst,
+SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, gcptr base, uint32_t avail, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr lit_dst,
                         SWC_AS_GLOBAL uint32_t* rec_dst, uint64_t out_pos0, ChunkOut& r) {
-    const uint32_t* st32 = (const uint32_t*)sl->stage;
     uint32_t w = start >> 5, bp = start & 31u;
-    uint32_t d0 = st32[w], d1 = st32[w + 1], d2 = st32[w + 2];
+    uint32_t d0, d1, d2;
+    Feed feed;
+    feed.init(base, avail, start, d0, d1, d2);
     uint32_t state = 0, plen = 0, run = 0, nlit = 0, nrec = 0, nout = 0, flags = 0;
     uint64_t lb = 0;
     uint32_t lbn = 0;
@@ -425,7 +464,7 @@ SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, u
         bp -= sh ? 32u : 0u;
         d0 = sh ? d1 : d0;
         d1 = sh ? d2 : d1;
-        if (sh) d2 = st32[w + 2];
+        if (sh) d2 = feed.next();
     }
     if (MODE != 3 && run > 0) {   // the sub-chunk closes its literal run itself
         nrec++;
@@ -459,37 +498,31 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
     for (;;) {
         const uint32_t B = (uint32_t)(P >> 3) & ~3u;
         const uint32_t q0 = (uint32_t)(P - 8ull * B);
+        const uint32_t avail = in_len - B;
+        const uint64_t left = (uint64_t)avail * 8;
+        const uint32_t in_bits = left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)left;
+        // the sub-chunk size of this round: what is left of the input over the 64 lanes (a stream of up to ~30 KB is one
+        // round; lanes past the end of the block decode garbage that nobody looks at)
+        uint32_t S = (avail / 64u + 16u + 15u) & ~15u;
+        S = S < kSyncChunkMin ? kSyncChunkMin : S > kSyncChunkMax ? kSyncChunkMax : S;
+        const uint32_t Sb = S * 8u;
         SWC_SP(pf, 6)
         SWC_SPC(pf, 7, 1);
-        const uint64_t left = (uint64_t)(in_len - B) * 8;
-        const uint32_t in_bits = left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)left;
-        // stage [B, B + kSyncStage), zero-filled beyond the input
         SIMT_BEGIN(t, N)
-            for (uint32_t o = 16u * (uint32_t)t; o < kSyncStage; o += 16u * N) {
-                uint64_t a = 0, b = 0;
-                const uint64_t at = (uint64_t)B + o;
-                if (at + 16 <= in_len) { a = load_u64(in + at); b = load_u64(in + at + 8); }
-                else {
-                    for (uint32_t k = 0; k < 8; k++) if (at + k < in_len) a |= (uint64_t)in[at + k] << (8 * k);
-                    for (uint32_t k = 0; k < 8; k++) if (at + 8 + k < in_len) b |= (uint64_t)in[at + 8 + k] << (8 * k);
-                }
-                *(uint64_t*)(sl->stage + o) = a;
-                *(uint64_t*)(sl->stage + o + 8) = b;
-            }
-            start[t] = t == 0 ? q0 : (uint32_t)t * kSyncChunk * 8u;
-        SIMT_END_WAVE
+            start[t] = t == 0 ? q0 : (uint32_t)t * Sb;
+        SIMT_END
         uint32_t nv = 0;
         bool eob = false, bail = false;
-        const bool chk = (uint64_t)B + kSyncStage > in_len;   // only the last rounds of a stream can run out of input
+        const bool chk = (uint64_t)B + 64ull * S + 64 > in_len;   // only the last round of a stream can run out of input
         SWC_SP(pf, 2)
         // pass 1: where does a decode from my guess end?  (no counting)
         SWC_SYNC_STAT(2, 1);
         SWC_SPC(pf, 8, 1);
         SIMT_BEGIN(t, N)
             ChunkOut r;
-            const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
-            if (chk) decode_chunk<3, false, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
-            else decode_chunk<3, false, false>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+            const uint32_t ce = ((uint32_t)t + 1u) * Sb;
+            if (chk) decode_chunk<3, false, true>(sl, lc, in + B, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+            else decode_chunk<3, false, false>(sl, lc, in + B, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
             endp[t] = r.end; flg[t] = 0; have[t] = false;
         SIMT_END
         SWC_SP(pf, 3)
@@ -517,12 +550,12 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                     SWC_SYNC_STAT(3, 1);   // lane decodes
                     if (t != 0) start[t] = pe[t];
                     ChunkOut r;
-                    const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
-                    if (chk) decode_chunk<0, false, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
-                    else decode_chunk<0, false, false>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                    const uint32_t ce = ((uint32_t)t + 1u) * Sb;
+                    if (chk) decode_chunk<0, false, true>(sl, lc, in + B, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                    else decode_chunk<0, false, false>(sl, lc, in + B, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
                     if (r.nlit > lzr::kLitRunMax) {   // a literal run may need a record of its own: count those too
-                        if (chk) decode_chunk<0, true, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
-                        else decode_chunk<0, true, false>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                        if (chk) decode_chunk<0, true, true>(sl, lc, in + B, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                        else decode_chunk<0, true, false>(sl, lc, in + B, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
                     }
                     endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; flg[t] = r.flags;
                     have[t] = true;
@@ -548,12 +581,12 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
         SIMT_BEGIN(t, N)
             if ((uint32_t)t < nv) {
                 ChunkOut r;
-                const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
+                const uint32_t ce = ((uint32_t)t + 1u) * Sb;
                 const uint64_t p0 = pos + (x_out[t] - c_out[t]);
                 const bool bigs = c_lit[t] > lzr::kLitRunMax;
-                if (beyond) decode_chunk<2, false, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, p0, r);
-                else if (bigs || chk) decode_chunk<1, true, true>(sl, lc, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
-                else decode_chunk<1, false, false>(sl, lc, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
+                if (beyond) decode_chunk<2, false, true>(sl, lc, in + B, avail, start[t], ce, in_bits, nullptr, nullptr, p0, r);
+                else if (bigs || chk) decode_chunk<1, true, true>(sl, lc, in + B, avail, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
+                else decode_chunk<1, false, false>(sl, lc, in + B, avail, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
                 flg[t] = r.flags;
             }
         SIMT_END
@@ -626,9 +659,9 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, SyncProf& pf) {
             }
         }
     }
-    uint8_t* lens = sl->stage + kHdrLens;
-    uint32_t* cnt = (uint32_t*)(sl->stage + kHdrCnt);
-    uint8_t* cl_lut = sl->stage + kHdrClLut;
+    uint8_t* lens = hdr_scratch(sl) + kHdrLens;
+    uint32_t* cnt = (uint32_t*)(hdr_scratch(sl) + kHdrCnt);
+    uint8_t* cl_lut = hdr_scratch(sl) + kHdrClLut;
     const int total = literals + distances;
     SIMT_BEGIN(t, N)
         for (int i = t; i < 80; i += N) ((uint32_t*)lens)[i] = 0;
@@ -684,8 +717,8 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, SyncProf& pf) {
 SWC_D void build_static_par(SyncLds* sl, SyncProf& pf) {
     (void)pf;
     constexpr int N = kWave;
-    uint8_t* lens = sl->stage + kHdrLens;
-    uint32_t* cnt = (uint32_t*)(sl->stage + kHdrCnt);
+    uint8_t* lens = hdr_scratch(sl) + kHdrLens;
+    uint32_t* cnt = (uint32_t*)(hdr_scratch(sl) + kHdrCnt);
     SIMT_BEGIN(t, N)
         if (t < 48) cnt[t] = 0;
         for (int s = t; s < 320; s += N) lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
