@@ -59,6 +59,7 @@ struct SyncLds {
     uint32_t lut[(1 << kSyncLitBits) + (1 << kSyncDistBits)];      // direct tables: lit/len, then distance
     uint32_t symtab[320];                                           // one entry per sorted symbol: lit/len at 0, distance at 288
     uint32_t aux[kAuxWords];                                        // the canonical tables (see kAux*)
+    alignas(16) uint8_t fifo[2 * kWave * 16];                       // per lane: two 16-byte granules of input on their way in (Feed)
 };
 // Header scratch: lives in the first bytes of `lut` (the direct tables are built after the header is done with it)
 constexpr uint32_t kHdrLens = 0;       // 320 bytes: code length of symbol s
@@ -319,24 +320,59 @@ SWC_HD uint32_t bfe32(uint32_t v, uint32_t off, uint32_t width) {   // width 0..
 #endif
 }
 
-// A lane's view of the compressed input: it reads its sub-chunk straight from HBM / L2 in 16-byte granules, one
-// granule ahead of the one it is consuming, and hands out dwords.  (No LDS staging: the kernel is bound by the latency
-// of the dependent table lookups, i.e. by the number of resident waves, and LDS is what limits those.)
+// A lane's view of the compressed input: it reads its sub-chunk straight from HBM / L2 in 16-byte granules and hands out
+// dwords.  (No staging of whole rounds in LDS: the kernel is bound by the latency of the dependent table lookups, i.e. by
+// the number of resident waves, and LDS is what limits those.)  On the device the granule after the one being consumed is
+// on its way into a 2 x 16-byte LDS slot pair of the lane by LDS-DMA (global_load_lds_dwordx4): a register destination
+// would make the compiler wait for the load where it is issued (the loop-carried copy), a DMA is waited for where it is
+// needed -- one granule (about fifteen symbols) later.
 struct Feed {
-    gcptr p;            // byte address of the round base
+    gcptr p;            // byte address of the round base (4-byte aligned on the device)
     uint32_t avail;     // bytes of input from there
     uint32_t goff;      // offset of the next granule to request
-    uint32_t a0, a1, a2, a3, b0, b1, b2, b3;   // the granule being handed out, the next one
-    uint32_t k;         // dwords of `a` handed out
+    uint32_t a0, a1, a2, a3;   // the granule being handed out
+    uint32_t k;         // dwords of it handed out
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t fifo;      // LDS byte address of the wave's slot pair (2 x 64 lanes x 16 bytes)
+    uint32_t lane16;    // 16 * lane
+    uint32_t cur;       // slot that receives / holds the NEXT granule
+    // the last granules of a stream: zero-filled, through registers (kept out of line: nine decode loops call it)
+    __device__ __attribute__((noinline)) static void request_tail(gcptr p, uint32_t avail, uint32_t off, uint32_t lds_dst) {
+        uint32_t w[4] = {0, 0, 0, 0};
+#pragma unroll 1
+        for (uint32_t i = 0; i < 16; i++) if (off + i < avail) w[i >> 2] |= (uint32_t)p[off + i] << (8 * (i & 3u));
+        __attribute__((address_space(3))) uint32_t* l = (__attribute__((address_space(3))) uint32_t*)lds_dst;
+        l[0] = w[0]; l[1] = w[1]; l[2] = w[2]; l[3] = w[3];
+    }
+    // request the granule at `off` into slot `slot` (this lane's 16 bytes of it)
+    SWC_D void request(uint32_t slot, uint32_t off) {
+        const uint32_t dst = fifo + slot * 1024u;   // wave-uniform: the hardware adds 16 * lane
+        if (off + 16 <= avail) {
+            gcptr src = p + off;
+            uint32_t keep;
+            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+        } else {
+            request_tail(p, avail, off, dst + lane16);
+        }
+    }
+    SWC_D void take(uint32_t slot) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA into this slot was issued one granule ago
+        const __attribute__((address_space(3))) uint32_t* l = (const __attribute__((address_space(3))) uint32_t*)(fifo + slot * 1024u + lane16);
+        a0 = l[0]; a1 = l[1]; a2 = l[2]; a3 = l[3];
+    }
+#else
+    uint32_t b0, b1, b2, b3;
     SWC_D static void load16(gcptr p, uint32_t avail, uint32_t off, uint32_t& x0, uint32_t& x1, uint32_t& x2, uint32_t& x3) {
         uint64_t lo = 0, hi = 0;
         if (off + 16 <= avail) { lo = load_u64(p + off); hi = load_u64(p + off + 8); }
-        else {   // the last granules of a stream: zero-filled
+        else {
             for (uint32_t i = 0; i < 8; i++) if (off + i < avail) lo |= (uint64_t)p[off + i] << (8 * i);
             for (uint32_t i = 0; i < 8; i++) if (off + 8 + i < avail) hi |= (uint64_t)p[off + 8 + i] << (8 * i);
         }
         x0 = (uint32_t)lo; x1 = (uint32_t)(lo >> 32); x2 = (uint32_t)hi; x3 = (uint32_t)(hi >> 32);
     }
+#endif
     SWC_D uint32_t next() {
         uint32_t kk = k;
         SWC_OPAQUE(kk);
@@ -344,19 +380,34 @@ struct Feed {
         const uint32_t v = (kk & 2u) ? hi : lo;
         k++;
         if (k == 4) {
-            a0 = b0; a1 = b1; a2 = b2; a3 = b3;
             k = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+            take(cur);             // the granule requested when the last one was taken
+            cur ^= 1u;
+            request(cur, goff);    // into the slot whose granule has just been used up
+#else
+            a0 = b0; a1 = b1; a2 = b2; a3 = b3;
             load16(p, avail, goff, b0, b1, b2, b3);
+#endif
             goff += 16;
         }
         return v;
     }
     // positions the feed at bit `start` (relative to the round base) and fills the three-dword window
-    SWC_D void init(gcptr base, uint32_t avail_, uint32_t start, uint32_t& d0, uint32_t& d1, uint32_t& d2) {
+    SWC_D void init(gcptr base, uint32_t avail_, uint32_t start, uint32_t fifo_lds, uint32_t lane, uint32_t& d0, uint32_t& d1, uint32_t& d2) {
         p = base; avail = avail_;
         const uint32_t g = (start >> 7) << 4;
+#if defined(__HIP_DEVICE_COMPILE__)
+        fifo = fifo_lds; lane16 = 16u * lane;
+        request(0, g);
+        request(1, g + 16);
+        take(0);
+        cur = 1;
+#else
+        (void)fifo_lds; (void)lane;
         load16(p, avail, g, a0, a1, a2, a3);
         load16(p, avail, g + 16, b0, b1, b2, b3);
+#endif
         goff = g + 32;
         k = (start >> 5) & 3u;
         d0 = next(); d1 = next(); d2 = next();
@@ -408,15 +459,14 @@ struct LongCodes {
 // MODE 0: count.  MODE 1: emit literals and records.  MODE 2: check distances only (output beyond the capacity).
 // MODE 3: walk (where does the decode end?).  BIG: literal runs of more than lzr::kLitRunMax bytes in front of a match
 // get a record of their own (only possible in a sub-chunk that holds more than that many literals: the caller picks).
-// CHK: symbols may run past the end of the input.
 // Decodes from bit `start` until a lit/len symbol would begin at or beyond `chunk_end`, or the end-of-block symbol.
-template <int MODE, bool BIG, bool CHK>
-SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, gcptr base, uint32_t avail, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr lit_dst,
+template <int MODE, bool BIG>
+SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t lane, gcptr base, uint32_t avail, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr lit_dst,
                         SWC_AS_GLOBAL uint32_t* rec_dst, uint64_t out_pos0, ChunkOut& r) {
     uint32_t w = start >> 5, bp = start & 31u;
     uint32_t d0, d1, d2;
     Feed feed;
-    feed.init(base, avail, start, d0, d1, d2);
+    feed.init(base, avail, start, (uint32_t)(uintptr_t)sl->fifo, lane, d0, d1, d2);
     uint32_t state = 0, plen = 0, run = 0, nlit = 0, nrec = 0, nout = 0, flags = 0;
     uint64_t lb = 0;
     uint32_t lbn = 0;
@@ -432,7 +482,7 @@ SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, gcptr base, uint3
         if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, state); }   // a code longer than the direct table (or no code at all)
         const uint32_t n = (e >> 26) & 31u, kind = (e >> 8) & 3u;
         // not a symbol the fast path takes, or the symbol runs past the end of the input
-        if ((e & kEntInvalid) || (CHK && posb + n > in_bits)) { flags |= kFlagFail; break; }
+        if ((e & kEntInvalid) || posb + n > in_bits) { flags |= kFlagFail; break; }
         const bool is_dist = state != 0;
         const bool is_len = !is_dist && kind == 2, is_eob = !is_dist && kind == 3;
         if (MODE != 3) {
@@ -496,9 +546,14 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
     LongCodes lc;
     lc.load(sl);
     for (;;) {
-        const uint32_t B = (uint32_t)(P >> 3) & ~3u;
-        const uint32_t q0 = (uint32_t)(P - 8ull * B);
-        const uint32_t avail = in_len - B;
+        // The round base: the 4-byte aligned ADDRESS at or below the current byte (the LDS-DMA of the feed wants dword
+        // addresses).  For a stream that does not start on a dword it lies up to 3 bytes in front of the stream in its
+        // first round; those bytes are skipped by q0 and never looked at.
+        const uint64_t in_addr = (uint64_t)(uintptr_t)in;
+        const int64_t B = (int64_t)(((in_addr + (P >> 3)) & ~(uint64_t)3) - in_addr);
+        gcptr base = in + B;
+        const uint32_t q0 = (uint32_t)((int64_t)P - 8 * B);
+        const uint32_t avail = (uint32_t)((int64_t)in_len - B);
         const uint64_t left = (uint64_t)avail * 8;
         const uint32_t in_bits = left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)left;
         // the sub-chunk size of this round: what is left of the input over the 64 lanes (a stream of up to ~30 KB is one
@@ -513,7 +568,6 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
         SIMT_END
         uint32_t nv = 0;
         bool eob = false, bail = false;
-        const bool chk = (uint64_t)B + 64ull * S + 64 > in_len;   // only the last round of a stream can run out of input
         SWC_SP(pf, 2)
         // pass 1: where does a decode from my guess end?  (no counting)
         SWC_SYNC_STAT(2, 1);
@@ -521,8 +575,7 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
         SIMT_BEGIN(t, N)
             ChunkOut r;
             const uint32_t ce = ((uint32_t)t + 1u) * Sb;
-            if (chk) decode_chunk<3, false, true>(sl, lc, in + B, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
-            else decode_chunk<3, false, false>(sl, lc, in + B, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+            decode_chunk<3, false>(sl, lc, (uint32_t)t, base, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
             endp[t] = r.end; flg[t] = 0; have[t] = false;
         SIMT_END
         SWC_SP(pf, 3)
@@ -551,11 +604,9 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                     if (t != 0) start[t] = pe[t];
                     ChunkOut r;
                     const uint32_t ce = ((uint32_t)t + 1u) * Sb;
-                    if (chk) decode_chunk<0, false, true>(sl, lc, in + B, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
-                    else decode_chunk<0, false, false>(sl, lc, in + B, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                    decode_chunk<0, false>(sl, lc, (uint32_t)t, base, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
                     if (r.nlit > lzr::kLitRunMax) {   // a literal run may need a record of its own: count those too
-                        if (chk) decode_chunk<0, true, true>(sl, lc, in + B, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
-                        else decode_chunk<0, true, false>(sl, lc, in + B, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                        decode_chunk<0, true>(sl, lc, (uint32_t)t, base, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
                     }
                     endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; flg[t] = r.flags;
                     have[t] = true;
@@ -584,9 +635,9 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                 const uint32_t ce = ((uint32_t)t + 1u) * Sb;
                 const uint64_t p0 = pos + (x_out[t] - c_out[t]);
                 const bool bigs = c_lit[t] > lzr::kLitRunMax;
-                if (beyond) decode_chunk<2, false, true>(sl, lc, in + B, avail, start[t], ce, in_bits, nullptr, nullptr, p0, r);
-                else if (bigs || chk) decode_chunk<1, true, true>(sl, lc, in + B, avail, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
-                else decode_chunk<1, false, false>(sl, lc, in + B, avail, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
+                if (beyond) decode_chunk<2, false>(sl, lc, (uint32_t)t, base, avail, start[t], ce, in_bits, nullptr, nullptr, p0, r);
+                else if (bigs) decode_chunk<1, true>(sl, lc, (uint32_t)t, base, avail, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
+                else decode_chunk<1, false>(sl, lc, (uint32_t)t, base, avail, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
                 flg[t] = r.flags;
             }
         SIMT_END
@@ -595,7 +646,7 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
         if (simt::wave_ballot<N>(pb)) break;                             // a distance beyond the output: the checked step reports it
         pos += tot_out;
         if (!beyond) { nlit += tot_lit; nrec += tot_rec; }
-        P = 8ull * B + simt::wave_read<N>(endp, (int)nv - 1);
+        P = (uint64_t)(8 * B + (int64_t)simt::wave_read<N>(endp, (int)nv - 1));
         ln.last_end = pos < ln.cap ? pos : (ln.last_end > ln.cap ? ln.last_end : ln.cap);
         if (eob) { result = kSyncEob; break; }
     }
