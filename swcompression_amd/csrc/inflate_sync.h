@@ -345,15 +345,21 @@ struct Feed {
         l[0] = w[0]; l[1] = w[1]; l[2] = w[2]; l[3] = w[3];
     }
     // request the granule at `off` into slot `slot` (this lane's 16 bytes of it)
+    SWC_D static void dma16(gcptr src, uint32_t lds_uniform) {   // 16 bytes per active lane -> LDS at lds_uniform + 16 * lane
+        uint32_t keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(src), "s"(lds_uniform) : "memory");
+    }
     SWC_D void request(uint32_t slot, uint32_t off) {
-        const uint32_t dst = fifo + slot * 1024u;   // wave-uniform: the hardware adds 16 * lane
+        // the LDS base of a DMA is one value per instruction (M0), the lanes of a wave change slots at their own pace:
+        // one instruction per slot, each under the mask of the lanes that are at that slot
+        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)fifo);
         if (off + 16 <= avail) {
             gcptr src = p + off;
-            uint32_t keep;
-            asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                         : "=&s"(keep) : "v"(src), "s"(dst) : "memory");
+            if (slot == 0) dma16(src, f);
+            else dma16(src, f + 1024u);
         } else {
-            request_tail(p, avail, off, dst + lane16);
+            request_tail(p, avail, off, f + slot * 1024u + lane16);
         }
     }
     SWC_D void take(uint32_t slot) {
