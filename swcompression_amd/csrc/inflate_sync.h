@@ -324,8 +324,11 @@ SWC_HD uint32_t bfe32(uint32_t v, uint32_t off, uint32_t width) {   // width 0..
 // dwords.  (No staging of whole rounds in LDS: the kernel is bound by the latency of the dependent table lookups, i.e. by
 // the number of resident waves, and LDS is what limits those.)  On the device the granule after the one being consumed is
 // on its way into a 2 x 16-byte LDS slot pair of the lane by LDS-DMA (global_load_lds_dwordx4): a register destination
-// would make the compiler wait for the load where it is issued (the loop-carried copy), a DMA is waited for where it is
-// needed -- one granule (about fifteen symbols) later.
+// would make the compiler wait for the load where it is issued (the loop-carried copy).  The lanes of a wave use up
+// their granules at their own pace, but a wait (vmcnt) is per wave -- so requests are made on a fixed beat: every fourth
+// symbol iteration the wave waits for the DMAs of the previous beat (four iterations old: they have landed) and every
+// lane whose slot has become free requests its next granule.  A lane uses up at most 112 bits per beat, i.e. frees at
+// most one slot, and a granule is requested at least two beats before it is taken.
 struct Feed {
     gcptr p;            // byte address of the round base (4-byte aligned on the device)
     uint32_t avail;     // bytes of input from there
@@ -335,7 +338,8 @@ struct Feed {
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t fifo;      // LDS byte address of the wave's slot pair (2 x 64 lanes x 16 bytes)
     uint32_t lane16;    // 16 * lane
-    uint32_t cur;       // slot that receives / holds the NEXT granule
+    uint32_t cur;       // slot that holds the NEXT granule
+    uint32_t freed;     // 1 + slot whose granule has been taken since the last beat (0: none)
     // the last granules of a stream: zero-filled, through registers (kept out of line: nine decode loops call it)
     __device__ __attribute__((noinline)) static void request_tail(gcptr p, uint32_t avail, uint32_t off, uint32_t lds_dst) {
         uint32_t w[4] = {0, 0, 0, 0};
@@ -362,8 +366,17 @@ struct Feed {
             request_tail(p, avail, off, f + slot * 1024u + lane16);
         }
     }
+    SWC_D static void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    // every fourth iteration of the decode loop, all lanes that are still decoding
+    SWC_D void beat() {
+        wait_dma();
+        if (freed) {
+            request(freed - 1u, goff);
+            goff += 16;
+            freed = 0;
+        }
+    }
     SWC_D void take(uint32_t slot) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA into this slot was issued one granule ago
         const __attribute__((address_space(3))) uint32_t* l = (const __attribute__((address_space(3))) uint32_t*)(fifo + slot * 1024u + lane16);
         a0 = l[0]; a1 = l[1]; a2 = l[2]; a3 = l[3];
     }
@@ -388,14 +401,14 @@ struct Feed {
         if (k == 4) {
             k = 0;
 #if defined(__HIP_DEVICE_COMPILE__)
-            take(cur);             // the granule requested when the last one was taken
+            take(cur);             // landed at least one beat ago
+            freed = cur + 1u;      // the next beat requests the granule after the other slot's into it
             cur ^= 1u;
-            request(cur, goff);    // into the slot whose granule has just been used up
 #else
             a0 = b0; a1 = b1; a2 = b2; a3 = b3;
             load16(p, avail, goff, b0, b1, b2, b3);
-#endif
             goff += 16;
+#endif
         }
         return v;
     }
@@ -407,8 +420,10 @@ struct Feed {
         fifo = fifo_lds; lane16 = 16u * lane;
         request(0, g);
         request(1, g + 16);
+        wait_dma();
         take(0);
         cur = 1;
+        freed = 1;   // slot 0: the first beat (iteration 0) requests the third granule into it
 #else
         (void)fifo_lds; (void)lane;
         load16(p, avail, g, a0, a1, a2, a3);
@@ -478,10 +493,13 @@ SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t lane, gc
     uint32_t lbn = 0;
     // The body is written as selects (one predicated schedule for literal, length, distance): lanes of a wave hold
     // different kinds of symbols in every iteration, and a branch per kind would run all of them one after the other.
-    for (;;) {
+    for (uint32_t it = 0;; it++) {
         const uint32_t posb = (w << 5) + bp;
         if (state == 0 && posb >= chunk_end) break;
         SWC_SYNC_STAT(4 + (MODE == 3 ? 0 : MODE), 1);   // code iterations per mode
+#if defined(__HIP_DEVICE_COMPILE__)
+        if ((it & 3u) == 0) feed.beat();
+#endif
         const uint32_t bits = funnel32(d1, d0, bp);
         const uint32_t idx = state ? (1u << kSyncLitBits) + (bits & ((1u << kSyncDistBits) - 1u)) : bits & ((1u << kSyncLitBits) - 1u);
         uint32_t e = sl->lut[idx];
