@@ -40,13 +40,24 @@ namespace swc {
 namespace inflate {
 
 constexpr int kSyncLitBits = 10, kSyncDistBits = 9;
-constexpr uint32_t kSyncChunkMin = 64, kSyncChunkMax = 512;   // input bytes per lane and round (a multiple of 16, chosen per round)
+#ifndef SWC_SYNC_CHUNK
+#define SWC_SYNC_CHUNK 96
+#endif
+constexpr uint32_t kSyncChunk = SWC_SYNC_CHUNK;      // input bytes per lane and round (a multiple of 4)
+constexpr uint32_t kSyncRound = 64u * kSyncChunk;
+constexpr uint32_t kSyncStage = kSyncRound + 128u;   // + what the last lane may read past its sub-chunk
 constexpr uint32_t kEntInvalid = 0x80000000u;        // a code of the set, but not a symbol the fast path takes
 constexpr uint32_t kPosFail = 0xFFFFFFFFu;
+static_assert(kSyncChunk % 4 == 0 && kSyncChunk >= 64, "sub-chunks are whole dwords");
 
-// Table entry: [0:3] code length, [4:7] extra bits, [8:9] kind, [10:25] base value, [26:30] code length + extra bits,
-// [31] invalid.  kind, lit/len table: 1 literal, 2 length, 3 end of block; distance table: 1 distance.
-SWC_HD uint32_t make_entry(uint32_t clen, uint32_t ext, uint32_t kind, uint32_t value) { return clen | (ext << 4) | (kind << 8) | (value << 10) | ((clen + ext) << 26); }
+// Table entry, laid out for a decode loop without branches per kind:
+//   [0:4] bits the symbol takes (code + extra)   [5] length symbol: the next code is a distance   [6] end of block
+//   [7] literal   [8:11] code length   [12:15] extra bits   [16:30] base value   [31] invalid.   0: no entry (long code).
+constexpr uint32_t kEntLen = 1u << 5, kEntEob = 1u << 6, kEntLit = 1u << 7;
+// kind, lit/len table: 1 literal, 2 length, 3 end of block; distance table: 0 distance.
+SWC_HD uint32_t make_entry(uint32_t clen, uint32_t ext, uint32_t kind, uint32_t value) {
+    return (clen + ext) | (kind == 1 ? kEntLit : kind == 2 ? kEntLen : kind == 3 ? kEntEob : 0u) | (clen << 8) | (ext << 12) | (value << 16);
+}
 
 // The canonical tables of inflate_lane.h (struct Table) kept in LDS: per length d the left-justified code limit, the slot
 // word (sorted index of the first code - first code | index of the first symbol >= 256 << 16) and the sorted index of the
@@ -59,13 +70,12 @@ struct SyncLds {
     uint32_t lut[(1 << kSyncLitBits) + (1 << kSyncDistBits)];      // direct tables: lit/len, then distance
     uint32_t symtab[320];                                           // one entry per sorted symbol: lit/len at 0, distance at 288
     uint32_t aux[kAuxWords];                                        // the canonical tables (see kAux*)
-    alignas(16) uint8_t fifo[2 * kWave * 16];                       // per lane: two 16-byte granules of input on their way in (Feed)
+    alignas(16) uint8_t stage[kSyncStage];                          // staged input of a round; header build: code lengths, counters, code-length table
 };
-// Header scratch: lives in the first bytes of `lut` (the direct tables are built after the header is done with it)
+// header scratch inside `stage`
 constexpr uint32_t kHdrLens = 0;       // 320 bytes: code length of symbol s
 constexpr uint32_t kHdrCnt = 320;      // 48 words: codes per length (lit/len, of those symbols < 256, distance)
 constexpr uint32_t kHdrClLut = 512;    // 128 bytes: code-length code, len | symbol << 3 (0xFF: no code)
-SWC_D uint8_t* hdr_scratch(SyncLds* sl) { return (uint8_t*)sl->lut; }
 
 enum { kSyncEob = 0, kSyncBail = 1, kSyncBailCap = 2 };
 #if defined(SWC_HOST_EMULATION)
@@ -230,14 +240,14 @@ SWC_D void sync_build_luts(SyncLds* sl) {
                         const uint32_t e = s < 8 || s == 28 ? 0u : (s >> 2) - 1u;
                         const uint32_t base = s < 8 ? 3u + s : s == 28 ? 258u : 3u + ((4u + (s & 3u)) << e);
                         entry = make_entry(d, e, 2, base);
-                    } else entry = d | (d << 26) | kEntInvalid;   // 286, 287: the checked step reports wrongSymbol
+                    } else entry = d | kEntInvalid;   // 286, 287: the checked step reports wrongSymbol
                 } else {
                     const uint32_t dc = *sym_ptr(l, W_DIST_SYM, j);
                     if (dc <= 29) {
                         const uint32_t e = dc < 4 ? 0u : (dc >> 1) - 1u;
                         const uint32_t base = dc < 4 ? 1u + dc : 1u + ((2u + (dc & 1u)) << e);
-                        entry = make_entry(d, e, 1, base);
-                    } else entry = d | (d << 26) | kEntInvalid;   // 30, 31: wrongSymbol
+                        entry = make_entry(d, e, 0, base);
+                    } else entry = d | kEntInvalid;   // 30, 31: wrongSymbol
                 }
                 sl->symtab[(tbl ? 288u : 0u) + j] = entry;
                 if (d <= lut_bits)
@@ -252,8 +262,8 @@ SWC_D void sync_build_luts(SyncLds* sl) {
 SWC_D void sync_tables_from_lengths(SyncLds* sl, int literals, int distances) {
     using simt::PT;
     constexpr int N = kWave;
-    const uint8_t* lens = hdr_scratch(sl) + kHdrLens;
-    uint32_t* cnt = (uint32_t*)(hdr_scratch(sl) + kHdrCnt);
+    const uint8_t* lens = sl->stage + kHdrLens;
+    uint32_t* cnt = (uint32_t*)(sl->stage + kHdrCnt);
     const LaneLds l{sl->syms, 1};
     const int total = literals + distances;
     // codes per length of the lit/len alphabet, of those symbols < 256, and of the distance alphabet
@@ -320,121 +330,6 @@ SWC_HD uint32_t bfe32(uint32_t v, uint32_t off, uint32_t width) {   // width 0..
 #endif
 }
 
-// A lane's view of the compressed input: it reads its sub-chunk straight from HBM / L2 in 16-byte granules and hands out
-// dwords.  (No staging of whole rounds in LDS: the kernel is bound by the latency of the dependent table lookups, i.e. by
-// the number of resident waves, and LDS is what limits those.)  On the device the granule after the one being consumed is
-// on its way into a 2 x 16-byte LDS slot pair of the lane by LDS-DMA (global_load_lds_dwordx4): a register destination
-// would make the compiler wait for the load where it is issued (the loop-carried copy).  The lanes of a wave use up
-// their granules at their own pace, but a wait (vmcnt) is per wave -- so requests are made on a fixed beat: every fourth
-// symbol iteration the wave waits for the DMAs of the previous beat (four iterations old: they have landed) and every
-// lane whose slot has become free requests its next granule.  A lane uses up at most 112 bits per beat, i.e. frees at
-// most one slot, and a granule is requested at least two beats before it is taken.
-struct Feed {
-    gcptr p;            // byte address of the round base (4-byte aligned on the device)
-    uint32_t avail;     // bytes of input from there
-    uint32_t goff;      // offset of the next granule to request
-    uint32_t a0, a1, a2, a3;   // the granule being handed out
-    uint32_t k;         // dwords of it handed out
-#if defined(__HIP_DEVICE_COMPILE__)
-    uint32_t fifo;      // LDS byte address of the wave's slot pair (2 x 64 lanes x 16 bytes)
-    uint32_t lane16;    // 16 * lane
-    uint32_t cur;       // slot that holds the NEXT granule
-    uint32_t freed;     // 1 + slot whose granule has been taken since the last beat (0: none)
-    // the last granules of a stream: zero-filled, through registers (kept out of line: nine decode loops call it)
-    __device__ __attribute__((noinline)) static void request_tail(gcptr p, uint32_t avail, uint32_t off, uint32_t lds_dst) {
-        uint32_t w[4] = {0, 0, 0, 0};
-#pragma unroll 1
-        for (uint32_t i = 0; i < 16; i++) if (off + i < avail) w[i >> 2] |= (uint32_t)p[off + i] << (8 * (i & 3u));
-        __attribute__((address_space(3))) uint32_t* l = (__attribute__((address_space(3))) uint32_t*)lds_dst;
-        l[0] = w[0]; l[1] = w[1]; l[2] = w[2]; l[3] = w[3];
-    }
-    // request the granule at `off` into slot `slot` (this lane's 16 bytes of it)
-    SWC_D static void dma16(gcptr src, uint32_t lds_uniform) {   // 16 bytes per active lane -> LDS at lds_uniform + 16 * lane
-        uint32_t keep;
-        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                     : "=&s"(keep) : "v"(src), "s"(lds_uniform) : "memory");
-    }
-    SWC_D void request(uint32_t slot, uint32_t off) {
-        // the LDS base of a DMA is one value per instruction (M0), the lanes of a wave change slots at their own pace:
-        // one instruction per slot, each under the mask of the lanes that are at that slot
-        const uint32_t f = (uint32_t)__builtin_amdgcn_readfirstlane((int)fifo);
-        if (off + 16 <= avail) {
-            gcptr src = p + off;
-            if (slot == 0) dma16(src, f);
-            else dma16(src, f + 1024u);
-        } else {
-            request_tail(p, avail, off, f + slot * 1024u + lane16);
-        }
-    }
-    SWC_D static void wait_dma() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
-    // every fourth iteration of the decode loop, all lanes that are still decoding
-    SWC_D void beat() {
-        wait_dma();
-        if (freed) {
-            request(freed - 1u, goff);
-            goff += 16;
-            freed = 0;
-        }
-    }
-    SWC_D void take(uint32_t slot) {
-        const __attribute__((address_space(3))) uint32_t* l = (const __attribute__((address_space(3))) uint32_t*)(fifo + slot * 1024u + lane16);
-        a0 = l[0]; a1 = l[1]; a2 = l[2]; a3 = l[3];
-    }
-#else
-    uint32_t b0, b1, b2, b3;
-    SWC_D static void load16(gcptr p, uint32_t avail, uint32_t off, uint32_t& x0, uint32_t& x1, uint32_t& x2, uint32_t& x3) {
-        uint64_t lo = 0, hi = 0;
-        if (off + 16 <= avail) { lo = load_u64(p + off); hi = load_u64(p + off + 8); }
-        else {
-            for (uint32_t i = 0; i < 8; i++) if (off + i < avail) lo |= (uint64_t)p[off + i] << (8 * i);
-            for (uint32_t i = 0; i < 8; i++) if (off + 8 + i < avail) hi |= (uint64_t)p[off + 8 + i] << (8 * i);
-        }
-        x0 = (uint32_t)lo; x1 = (uint32_t)(lo >> 32); x2 = (uint32_t)hi; x3 = (uint32_t)(hi >> 32);
-    }
-#endif
-    SWC_D uint32_t next() {
-        uint32_t kk = k;
-        SWC_OPAQUE(kk);
-        const uint32_t lo = (kk & 1u) ? a1 : a0, hi = (kk & 1u) ? a3 : a2;
-        const uint32_t v = (kk & 2u) ? hi : lo;
-        k++;
-        if (k == 4) {
-            k = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-            take(cur);             // landed at least one beat ago
-            freed = cur + 1u;      // the next beat requests the granule after the other slot's into it
-            cur ^= 1u;
-#else
-            a0 = b0; a1 = b1; a2 = b2; a3 = b3;
-            load16(p, avail, goff, b0, b1, b2, b3);
-            goff += 16;
-#endif
-        }
-        return v;
-    }
-    // positions the feed at bit `start` (relative to the round base) and fills the three-dword window
-    SWC_D void init(gcptr base, uint32_t avail_, uint32_t start, uint32_t fifo_lds, uint32_t lane, uint32_t& d0, uint32_t& d1, uint32_t& d2) {
-        p = base; avail = avail_;
-        const uint32_t g = (start >> 7) << 4;
-#if defined(__HIP_DEVICE_COMPILE__)
-        fifo = fifo_lds; lane16 = 16u * lane;
-        request(0, g);
-        request(1, g + 16);
-        wait_dma();
-        take(0);
-        cur = 1;
-        freed = 1;   // slot 0: the first beat (iteration 0) requests the third granule into it
-#else
-        (void)fifo_lds; (void)lane;
-        load16(p, avail, g, a0, a1, a2, a3);
-        load16(p, avail, g + 16, b0, b1, b2, b3);
-#endif
-        goff = g + 32;
-        k = (start >> 5) & 3u;
-        d0 = next(); d1 = next(); d2 = next();
-    }
-};
-
 // The canonical limits and slot words of the code lengths 10..15 of both alphabets, in registers while the rounds run:
 // a code longer than the direct tables is resolved with compares and ONE LDS read (its symbol entry).
 // (Scalar members and an opaque selector on purpose: with arrays LLVM folds `st ? a[d] : b[d]` into a dynamically
@@ -453,7 +348,7 @@ struct LongCodes {
         t0 = d[0]; t1 = d[1]; t2 = d[2]; t3 = d[3]; t4 = d[4]; t5 = d[5];
     }
     // the entry of the code that starts `bits` (state: 0 lit/len, 1 distance); kEntInvalid if there is none
-    SWC_D uint32_t lookup(const SyncLds* sl, uint32_t bits, uint32_t state) const {
+    SWC_D uint32_t lookup(const SyncLds* sl, uint32_t bits, uint32_t state) const {   // state: 0 lit/len, anything else distance
         const uint32_t c15 = brev32(bits) >> 17;
         uint32_t sel = state;
         SWC_OPAQUE(sel);
@@ -480,65 +375,68 @@ struct LongCodes {
 // MODE 0: count.  MODE 1: emit literals and records.  MODE 2: check distances only (output beyond the capacity).
 // MODE 3: walk (where does the decode end?).  BIG: literal runs of more than lzr::kLitRunMax bytes in front of a match
 // get a record of their own (only possible in a sub-chunk that holds more than that many literals: the caller picks).
+// CHK: symbols may run past the end of the input.
 // Decodes from bit `start` until a lit/len symbol would begin at or beyond `chunk_end`, or the end-of-block symbol.
-template <int MODE, bool BIG>
-SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t lane, gcptr base, uint32_t avail, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr lit_dst,
+template <int MODE, bool BIG, bool CHK>
+SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr lit_dst,
                         SWC_AS_GLOBAL uint32_t* rec_dst, uint64_t out_pos0, ChunkOut& r) {
+    const uint32_t* st32 = (const uint32_t*)sl->stage;
     uint32_t w = start >> 5, bp = start & 31u;
-    uint32_t d0, d1, d2;
-    Feed feed;
-    feed.init(base, avail, start, (uint32_t)(uintptr_t)sl->fifo, lane, d0, d1, d2);
-    uint32_t state = 0, plen = 0, run = 0, nlit = 0, nrec = 0, nout = 0, flags = 0;
+    uint32_t d0 = st32[w], d1 = st32[w + 1], d2 = st32[w + 2];
+    uint32_t tsel = 0, tmsk = (1u << kSyncLitBits) - 1u;   // the table of the next code: dword offset into `lut` and index mask
+    uint32_t plen = 0, run = 0, nlit = 0, nrec = 0, nout = 0, flags = 0;
     uint64_t lb = 0;
     uint32_t lbn = 0;
-    // The body is written as selects (one predicated schedule for literal, length, distance): lanes of a wave hold
-    // different kinds of symbols in every iteration, and a branch per kind would run all of them one after the other.
-    for (uint32_t it = 0;; it++) {
+    // The wave is bound by the LATENCY of this loop (one dependent LDS lookup per code, few waves per SIMD): the body is
+    // one straight line of selects -- no branch per kind of symbol, the window's next dword is read whether the window
+    // moves on or not, everything rare (long code, end of block, anything invalid) sits behind ONE test.
+    for (;;) {
         const uint32_t posb = (w << 5) + bp;
-        if (state == 0 && posb >= chunk_end) break;
+        if ((uint32_t)(tsel == 0) & (uint32_t)(posb >= chunk_end)) break;   // (bitwise: one compare pair, no nested mask region)
         SWC_SYNC_STAT(4 + (MODE == 3 ? 0 : MODE), 1);   // code iterations per mode
-#if defined(__HIP_DEVICE_COMPILE__)
-        if ((it & 3u) == 0) feed.beat();
-#endif
         const uint32_t bits = funnel32(d1, d0, bp);
-        const uint32_t idx = state ? (1u << kSyncLitBits) + (bits & ((1u << kSyncDistBits) - 1u)) : bits & ((1u << kSyncLitBits) - 1u);
-        uint32_t e = sl->lut[idx];
-        if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, state); }   // a code longer than the direct table (or no code at all)
-        const uint32_t n = (e >> 26) & 31u, kind = (e >> 8) & 3u;
-        // not a symbol the fast path takes, or the symbol runs past the end of the input
-        if ((e & kEntInvalid) || posb + n > in_bits) { flags |= kFlagFail; break; }
-        const bool is_dist = state != 0;
-        const bool is_len = !is_dist && kind == 2, is_eob = !is_dist && kind == 3;
+        uint32_t e = sl->lut[(bits & tmsk) + tsel];
+        const uint32_t nx = st32[w + 3];
+        if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, tsel); }   // a code longer than the direct table (or no code at all)
+        const uint32_t n = e & 31u;
+        if ((e & (kEntInvalid | kEntEob)) || (CHK && posb + n > in_bits)) {
+            // not a symbol the fast path takes / the symbol runs past the end of the input / the end of the block
+            if ((e & kEntInvalid) || (CHK && posb + n > in_bits)) flags |= kFlagFail;
+            else { bp += n; flags |= kFlagEob; }
+            break;
+        }
+        const bool was_dist = tsel != 0;
         if (MODE != 3) {
-            const bool is_lit = !is_dist && kind == 1;
-            const uint32_t val = ((e >> 10) & 0xFFFFu) + bfe32(bits, e & 15u, (e >> 4) & 15u);
-            if (MODE != 0 && is_dist && (uint64_t)val > out_pos0 + nout) { flags |= kFlagTrap; break; }
-            const bool big = BIG && is_dist && run > lzr::kLitRunMax;
+            const uint32_t is_lit = (e >> 7) & 1u;
+            const uint32_t val = ((e >> 16) & 0x7FFFu) + bfe32(bits, (e >> 8) & 15u, (e >> 12) & 15u);
+            if (MODE != 0 && was_dist && (uint64_t)val > out_pos0 + nout) { flags |= kFlagTrap; break; }
+            const bool big = BIG && was_dist && run > lzr::kLitRunMax;
             if (MODE == 1) {
                 if (is_lit) {
                     lb |= (uint64_t)val << (8 * lbn);
                     if (++lbn == 8) { store_u64(lit_dst, lb); lit_dst += 8; lb = 0; lbn = 0; }
                 }
-                if (is_dist) {
+                if (was_dist) {
                     if (big) *rec_dst++ = lzr::make_lits(run);
                     *rec_dst++ = lzr::make_match(big ? 0u : run, plen, val);
                 }
             }
-            nlit += is_lit ? 1u : 0u;
-            nout += is_lit ? 1u : is_dist ? plen : 0u;
-            nrec += is_dist ? (big ? 2u : 1u) : 0u;
-            run = is_dist ? 0u : run + (is_lit ? 1u : 0u);
-            plen = is_len ? val : plen;
+            nlit += is_lit;
+            nout += is_lit + (was_dist ? plen : 0u);
+            nrec += was_dist ? (big ? 2u : 1u) : 0u;
+            run = was_dist ? 0u : run + is_lit;
+            plen = (e & kEntLen) ? val : plen;
         }
-        state = is_len ? 1u : 0u;
+        tsel = (e & kEntLen) << (kSyncLitBits - 5);                         // 0, or 1 << kSyncLitBits: the distance table follows the lit/len table
+        tmsk = ((1u << kSyncLitBits) - 1u) - (tsel >> 1);                   // 10-bit index, or 9-bit
+        static_assert(kSyncDistBits == kSyncLitBits - 1, "the mask arithmetic above");
         bp += n;
-        if (is_eob) { flags |= kFlagEob; break; }
         const bool sh = bp >= 32;
         w += sh ? 1u : 0u;
-        bp -= sh ? 32u : 0u;
+        bp &= 31u;
         d0 = sh ? d1 : d0;
         d1 = sh ? d2 : d1;
-        if (sh) d2 = feed.next();
+        d2 = sh ? nx : d2;
     }
     if (MODE != 3 && run > 0) {   // the sub-chunk closes its literal run itself
         nrec++;
@@ -570,36 +468,39 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
     LongCodes lc;
     lc.load(sl);
     for (;;) {
-        // The round base: the 4-byte aligned ADDRESS at or below the current byte (the LDS-DMA of the feed wants dword
-        // addresses).  For a stream that does not start on a dword it lies up to 3 bytes in front of the stream in its
-        // first round; those bytes are skipped by q0 and never looked at.
-        const uint64_t in_addr = (uint64_t)(uintptr_t)in;
-        const int64_t B = (int64_t)(((in_addr + (P >> 3)) & ~(uint64_t)3) - in_addr);
-        gcptr base = in + B;
-        const uint32_t q0 = (uint32_t)((int64_t)P - 8 * B);
-        const uint32_t avail = (uint32_t)((int64_t)in_len - B);
-        const uint64_t left = (uint64_t)avail * 8;
-        const uint32_t in_bits = left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)left;
-        // the sub-chunk size of this round: what is left of the input over the 64 lanes (a stream of up to ~30 KB is one
-        // round; lanes past the end of the block decode garbage that nobody looks at)
-        uint32_t S = (avail / 64u + 16u + 15u) & ~15u;
-        S = S < kSyncChunkMin ? kSyncChunkMin : S > kSyncChunkMax ? kSyncChunkMax : S;
-        const uint32_t Sb = S * 8u;
+        const uint32_t B = (uint32_t)(P >> 3) & ~3u;
+        const uint32_t q0 = (uint32_t)(P - 8ull * B);
         SWC_SP(pf, 6)
         SWC_SPC(pf, 7, 1);
+        const uint64_t left = (uint64_t)(in_len - B) * 8;
+        const uint32_t in_bits = left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)left;
+        // stage [B, B + kSyncStage), zero-filled beyond the input
         SIMT_BEGIN(t, N)
-            start[t] = t == 0 ? q0 : (uint32_t)t * Sb;
-        SIMT_END
+            for (uint32_t o = 16u * (uint32_t)t; o < kSyncStage; o += 16u * N) {
+                uint64_t a = 0, b = 0;
+                const uint64_t at = (uint64_t)B + o;
+                if (at + 16 <= in_len) { a = load_u64(in + at); b = load_u64(in + at + 8); }
+                else {
+                    for (uint32_t k = 0; k < 8; k++) if (at + k < in_len) a |= (uint64_t)in[at + k] << (8 * k);
+                    for (uint32_t k = 0; k < 8; k++) if (at + 8 + k < in_len) b |= (uint64_t)in[at + 8 + k] << (8 * k);
+                }
+                *(uint64_t*)(sl->stage + o) = a;
+                *(uint64_t*)(sl->stage + o + 8) = b;
+            }
+            start[t] = t == 0 ? q0 : (uint32_t)t * kSyncChunk * 8u;
+        SIMT_END_WAVE
         uint32_t nv = 0;
         bool eob = false, bail = false;
+        const bool chk = (uint64_t)B + kSyncStage > in_len;   // only the last rounds of a stream can run out of input
         SWC_SP(pf, 2)
         // pass 1: where does a decode from my guess end?  (no counting)
         SWC_SYNC_STAT(2, 1);
         SWC_SPC(pf, 8, 1);
         SIMT_BEGIN(t, N)
             ChunkOut r;
-            const uint32_t ce = ((uint32_t)t + 1u) * Sb;
-            decode_chunk<3, false>(sl, lc, (uint32_t)t, base, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+            const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
+            if (chk) decode_chunk<3, false, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+            else decode_chunk<3, false, false>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
             endp[t] = r.end; flg[t] = 0; have[t] = false;
         SIMT_END
         SWC_SP(pf, 3)
@@ -627,10 +528,12 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                     SWC_SYNC_STAT(3, 1);   // lane decodes
                     if (t != 0) start[t] = pe[t];
                     ChunkOut r;
-                    const uint32_t ce = ((uint32_t)t + 1u) * Sb;
-                    decode_chunk<0, false>(sl, lc, (uint32_t)t, base, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                    const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
+                    if (chk) decode_chunk<0, false, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                    else decode_chunk<0, false, false>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
                     if (r.nlit > lzr::kLitRunMax) {   // a literal run may need a record of its own: count those too
-                        decode_chunk<0, true>(sl, lc, (uint32_t)t, base, avail, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                        if (chk) decode_chunk<0, true, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                        else decode_chunk<0, true, false>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
                     }
                     endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; flg[t] = r.flags;
                     have[t] = true;
@@ -656,12 +559,12 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
         SIMT_BEGIN(t, N)
             if ((uint32_t)t < nv) {
                 ChunkOut r;
-                const uint32_t ce = ((uint32_t)t + 1u) * Sb;
+                const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
                 const uint64_t p0 = pos + (x_out[t] - c_out[t]);
                 const bool bigs = c_lit[t] > lzr::kLitRunMax;
-                if (beyond) decode_chunk<2, false>(sl, lc, (uint32_t)t, base, avail, start[t], ce, in_bits, nullptr, nullptr, p0, r);
-                else if (bigs) decode_chunk<1, true>(sl, lc, (uint32_t)t, base, avail, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
-                else decode_chunk<1, false>(sl, lc, (uint32_t)t, base, avail, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
+                if (beyond) decode_chunk<2, false, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, p0, r);
+                else if (bigs || chk) decode_chunk<1, true, true>(sl, lc, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
+                else decode_chunk<1, false, false>(sl, lc, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
                 flg[t] = r.flags;
             }
         SIMT_END
@@ -670,7 +573,7 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
         if (simt::wave_ballot<N>(pb)) break;                             // a distance beyond the output: the checked step reports it
         pos += tot_out;
         if (!beyond) { nlit += tot_lit; nrec += tot_rec; }
-        P = (uint64_t)(8 * B + (int64_t)simt::wave_read<N>(endp, (int)nv - 1));
+        P = 8ull * B + simt::wave_read<N>(endp, (int)nv - 1);
         ln.last_end = pos < ln.cap ? pos : (ln.last_end > ln.cap ? ln.last_end : ln.cap);
         if (eob) { result = kSyncEob; break; }
     }
@@ -734,9 +637,9 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, SyncProf& pf) {
             }
         }
     }
-    uint8_t* lens = hdr_scratch(sl) + kHdrLens;
-    uint32_t* cnt = (uint32_t*)(hdr_scratch(sl) + kHdrCnt);
-    uint8_t* cl_lut = hdr_scratch(sl) + kHdrClLut;
+    uint8_t* lens = sl->stage + kHdrLens;
+    uint32_t* cnt = (uint32_t*)(sl->stage + kHdrCnt);
+    uint8_t* cl_lut = sl->stage + kHdrClLut;
     const int total = literals + distances;
     SIMT_BEGIN(t, N)
         for (int i = t; i < 80; i += N) ((uint32_t*)lens)[i] = 0;
@@ -792,8 +695,8 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, SyncProf& pf) {
 SWC_D void build_static_par(SyncLds* sl, SyncProf& pf) {
     (void)pf;
     constexpr int N = kWave;
-    uint8_t* lens = hdr_scratch(sl) + kHdrLens;
-    uint32_t* cnt = (uint32_t*)(hdr_scratch(sl) + kHdrCnt);
+    uint8_t* lens = sl->stage + kHdrLens;
+    uint32_t* cnt = (uint32_t*)(sl->stage + kHdrCnt);
     SIMT_BEGIN(t, N)
         if (t < 48) cnt[t] = 0;
         for (int s = t; s < 320; s += N) lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);

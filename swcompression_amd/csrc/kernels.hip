@@ -57,10 +57,9 @@ __global__ __launch_bounds__(64, 4) void swc_inflate_wave_kernel(Job* __restrict
 }
 
 // Phase 1, production form: one stream per WAVEFRONT, 64 sub-chunks of the stream decoded at once (inflate_sync.h).
-// LDS: the shared tables + two 16-byte input granules per lane (10 KiB per wave -> 16 waves per CU); the lanes read their
-// sub-chunks straight from HBM / L2.
+// LDS: the shared tables + the staged input of a round, ~14 KiB per wave -> 11 waves per CU.
 #ifndef SWC_SYNC_WAVES_PER_SIMD
-#define SWC_SYNC_WAVES_PER_SIMD 4
+#define SWC_SYNC_WAVES_PER_SIMD 3
 #endif
 static uint64_t* g_prof = nullptr;   // profile builds (-DSWC_PROFILE): 32 counters per job, [0..16) phase 1, [16..32) phase 2
 void set_profile_buffer(void* p) { g_prof = static_cast<uint64_t*>(p); }
