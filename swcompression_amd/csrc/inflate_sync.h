@@ -41,7 +41,7 @@ namespace inflate {
 
 constexpr int kSyncLitBits = 10, kSyncDistBits = 9;
 #ifndef SWC_SYNC_CHUNK
-#define SWC_SYNC_CHUNK 96
+#define SWC_SYNC_CHUNK 64
 #endif
 constexpr uint32_t kSyncChunk = SWC_SYNC_CHUNK;      // input bytes per lane and round (a multiple of 4)
 constexpr uint32_t kSyncRound = 64u * kSyncChunk;
