@@ -24,6 +24,7 @@
 #define SWC_LZ4_WAVE_H
 
 #include "swc_common.h"
+#include "simt.h"
 #include "lz_resolve.h"
 
 namespace swc {
@@ -32,9 +33,23 @@ namespace lz4w {
 constexpr uint32_t kKeep = 65536;    // LZ4 offsets reach 65,535 bytes back
 constexpr int kRingLog2 = 17;        // LDS ring of the resolve kernel: history + one batch span + its cells
 constexpr int kResolveThreads = 1024;
-constexpr uint32_t kRecBuf = 1024;   // records a parse wave stages in LDS between flushes
-constexpr uint32_t kLitStage = 4096; // literal bytes likewise
-constexpr uint32_t kInWin = 1024;    // input window of a parse wave in LDS
+constexpr uint32_t kRecBuf = 256;    // records the checked step stages in LDS between flushes
+constexpr uint32_t kLitStage = 1024; // literal bytes likewise
+constexpr uint32_t kInWin = 1024;    // input window of the checked step in LDS
+#ifndef SWC_LZ4_CHUNK
+#define SWC_LZ4_CHUNK 256
+#endif
+constexpr uint32_t kChunk = SWC_LZ4_CHUNK;            // input bytes per lane and round of the sub-chunk-parallel parse (a multiple of 16)
+constexpr uint32_t kStageBytes = 64u * kChunk + 64u;  // staged input of a round (+ what the last lane reads past its sub-chunk)
+constexpr uint32_t kTailKeep = 16;                    // the sequences that end in the last bytes of a block stay with the checked step
+constexpr uint32_t kPosFail = 0xFFFFFFFFu;
+enum { kLzStop = 1u, kLzFail = 2u, kLzTrap = 4u, kLzTail = 8u };
+#if defined(SWC_HOST_EMULATION)
+inline uint64_t g_lz4_stats[8];   // emulated parser: rounds, lane parses, passes, sequences taken by rounds, checked steps
+#define SWC_LZ4_STAT(i, n) (g_lz4_stats[i] += (n))
+#else
+#define SWC_LZ4_STAT(i, n) ((void)0)
+#endif
 
 template <int W>
 struct Wave {
@@ -87,6 +102,13 @@ SWC_HD int ctz64(uint64_t m) {   // m != 0
     return __ffsll((long long)m) - 1;
 #else
     return __builtin_ctzll(m);
+#endif
+}
+SWC_HD int clz64(uint64_t m) {   // m != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clzll((long long)m);
+#else
+    return __builtin_clzll(m);
 #endif
 }
 SWC_HD int top64(uint64_t m) {   // index of the highest set bit, m != 0
@@ -227,6 +249,7 @@ struct Parser {
         return a < iw_hi && a + kInWin >= iw_hi ? (uint32_t)iw[(uint32_t)a & (kInWin - 1)] : (uint32_t)in[a];
     }
     SWC_D int careful_step() {
+        SWC_LZ4_STAT(4, 1);
         if (ip < n) fill_window();
         sequences++;
         if (n - ip < 1) return SWC_E_DATA_TRUNCATED;                               // :344
@@ -270,122 +293,216 @@ struct Parser {
         return SWC_OK;
     }
 
-    // One stripe of W input bytes starting at ip.  Returns false when nothing could be taken (the caller then runs
-    // the checked step on the sequence at ip).
-    SWC_D bool stripe() {
-        // The stripe's bytes come from a 1 KiB window of the input kept in LDS and refilled 512 bytes at a time, one
-        // refill in flight ahead of the parse: a load straight from HBM would depend on the chase of the previous stripe
-        // and cost a memory round trip per stripe (measured: 2 us per stripe).
-        fill_window();
-        const uint32_t qi = (uint32_t)(ip + (uint64_t)w.lane) & (kInWin - 1);
-        const uint64_t lo = *(const u64_unaligned*)(iw + qi), hi = *(const u64_unaligned*)(iw + qi + 8);
-        const uint32_t token = (uint32_t)lo & 0xFFu, lit = token >> 4, mln = token & 15u;
-        // bytes 1.. of the sequence
-        const uint64_t b1 = (lo >> 8) | (hi << 56), b9 = hi >> 8;
-        const uint32_t osh = 8u * lit;   // bit offset of the 2-byte offset field inside (b1, b9)
-        const uint32_t offset = (uint32_t)((osh < 64 ? (b1 >> osh) | (osh ? b9 << (64 - osh) : 0) : b9 >> (osh - 64)) & 0xFFFFu);
-        // a match length of 19..258 carries ONE extension byte right after the offset; it must sit inside the 16 bytes
-        const uint32_t esh = osh + 16u;
-        const uint32_t ext = (uint32_t)((esh < 64 ? (b1 >> esh) | (b9 << (64 - esh)) : b9 >> (esh - 64)) & 0xFFu);
-        const bool longm = mln == 15;
-        const bool ok = offset != 0 && (longm ? lit <= 12 && ext <= 239 : lit <= 13);
-        const uint32_t mlen = 4 + mln + (longm ? ext : 0u);
-        const uint32_t nxt = (uint32_t)w.lane + 3u + lit + (longm ? 1u : 0u);
-        // follow the chain from lane 0 through the lanes that are ok
-        const uint64_t okmask = w.ballot(ok);
-        uint64_t mask = 0;
-        uint32_t c = 0;
-        while (c < (uint32_t)W && ((okmask >> c) & 1)) {
-            mask |= 1ull << c;
-            c = w.read(nxt, c);
+    // ---- sub-chunk-parallel parse ----------------------------------------------------------------------------------------
+    // Where a sequence starts is known only when the one before it has been parsed, but a parse started at a WRONG byte
+    // falls into step with the true sequence chain after a few sequences (it lands on a new byte after every sequence;
+    // about one byte in eleven is a true sequence start).  The wave stages the next 64 sub-chunks of kChunk bytes in
+    // LDS, lane 0 parses from the true position and every other lane from its sub-chunk boundary, all counting only;
+    // a lane whose start differs from where its left neighbour ended parses again from there, until the chain of
+    // (start == left neighbour's end) covers the round.  Exclusive prefix sums of the counts give every lane the place of
+    // its literals and records; one more parse emits them.  A lane stops IN FRONT OF a sequence it does not take: one
+    // that ends in the last kTailKeep bytes of the block (the end-of-block rules are the checked step's), one that needs
+    // bytes beyond the staged window (a long literal run), one with offset 0; the round then ends with that lane.
+    struct ChunkOut {
+        uint32_t end;      // byte (relative to the round base) of the first sequence NOT taken
+        uint32_t nlit, nrec, nout, nseq;
+        uint32_t lms;      // output offset (inside the sub-chunk) of the last match start
+        uint32_t flags;
+    };
+    SWC_D static uint32_t rd32(const uint8_t* stage, uint32_t a) {   // the four bytes at `a` (aligned LDS reads + a byte shift)
+        const uint32_t* w = (const uint32_t*)(stage + (a & ~3u));
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __builtin_amdgcn_alignbyte(w[1], w[0], a & 3u);
+#else
+        return (uint32_t)((((uint64_t)w[1] << 32) | w[0]) >> (8 * (a & 3u)));
+#endif
+    }
+    // MODE 0: count.  MODE 1: emit literals and records (offsets are checked against the output position).
+    template <int MODE>
+    SWC_D static void parse_chunk(const uint8_t* stage, uint32_t stage_len, uint32_t start, uint32_t chunk_end, uint32_t tail_limit, gptr lit_dst,
+                                  SWC_AS_GLOBAL uint32_t* rec_dst, uint64_t out_pos0, ChunkOut& r) {
+        uint32_t ip = start, nlit = 0, nrec = 0, nout = 0, nseq = 0, lms = 0, flags = 0;
+        while (ip < chunk_end) {
+            if (ip + 8 > stage_len) { flags |= kLzStop; break; }
+            const uint32_t tok32 = rd32(stage, ip);
+            const uint32_t token = tok32 & 0xFFu;
+            uint32_t lit = token >> 4, p = ip + 1;
+            if (lit == 15) {
+                uint32_t b = (tok32 >> 8) & 0xFFu;
+                lit += b; p++;
+                while (b == 255) {
+                    if (p + 8 > stage_len) { flags |= kLzStop; break; }
+                    b = stage[p++];
+                    lit += b;
+                }
+                if (flags) break;
+            }
+            const uint32_t lit_at = p;
+            if (lit > stage_len || p + lit + 8 > stage_len) { flags |= kLzStop; break; }   // the literal run leaves the staged window
+            p += lit;
+            const uint32_t off32 = rd32(stage, p);
+            const uint32_t offset = off32 & 0xFFFFu;
+            p += 2;
+            uint32_t mlen = 4 + (token & 15u);
+            if (mlen == 19) {
+                uint32_t b = (off32 >> 16) & 0xFFu;
+                mlen += b; p++;
+                while (b == 255) {
+                    if (p + 8 > stage_len) { flags |= kLzStop; break; }
+                    b = stage[p++];
+                    mlen += b;
+                }
+                if (flags) break;
+            }
+            if (p > tail_limit) { flags |= kLzStop | kLzTail; break; }   // the checked step takes the end of the block
+            if (offset == 0) { flags |= kLzFail; break; }                  // LZ4.swift:382
+            if (MODE == 1) {
+                if ((uint64_t)offset > out_pos0 + nout + lit) { flags |= kLzTrap; break; }   // :382 offset <= bytes produced
+                uint32_t i = 0;
+                for (; i + 4 <= lit; i += 4) store_u32(lit_dst + i, rd32(stage, lit_at + i));
+                for (; i < lit; i++) lit_dst[i] = stage[lit_at + i];
+                lit_dst += lit;
+                uint32_t run = lit;
+                if (run > lzr::kLitRunMax) {
+                    while (run > 0) { const uint32_t s = run > lzr::kMaxLitOnly ? lzr::kMaxLitOnly : run; *rec_dst++ = lzr::make_lits(s); run -= s; }
+                }
+                uint32_t rem = mlen;
+                while (rem > 0) {
+                    const uint32_t piece = rem > lzr::kMaxLen ? lzr::kMaxLen : rem;
+                    *rec_dst++ = lzr::make_match(run, piece, offset);
+                    run = 0;
+                    rem -= piece;
+                }
+            }
+            nrec += (lit > lzr::kLitRunMax ? (lit + lzr::kMaxLitOnly - 1u) / lzr::kMaxLitOnly : 0u) + (mlen + lzr::kMaxLen - 1u) / lzr::kMaxLen;
+            nlit += lit;
+            lms = nout + lit;
+            nout += lit + mlen;
+            nseq++;
+            ip = p;
         }
-        if (mask == 0) return false;
-        bool mine = (mask >> w.lane) & 1;
-        // output / literal positions of the true starts; offsets must not reach before the block
-        const uint32_t incl_adv = w.scan_incl(mine ? lit + mlen : 0u), incl_lit = w.scan_incl(mine ? lit : 0u);
-        uint32_t my_adv = incl_adv - (mine ? lit + mlen : 0u), my_lit = incl_lit - (mine ? lit : 0u);
-        const uint64_t my_pos = pos + my_adv;
-        const uint64_t bad = w.ballot(mine && (uint64_t)offset > my_pos + lit);
-        uint32_t tot_adv, tot_lit, end_c = c;
-        if (bad) {
-            const int fb = ctz64(bad);
-            if (fb == 0) return false;
-            mask &= (1ull << fb) - 1ull;
-            mine = (mask >> w.lane) & 1;
-            tot_adv = w.read(my_adv, (uint32_t)fb);
-            tot_lit = w.read(my_lit, (uint32_t)fb);
-            end_c = (uint32_t)fb;
-        } else {
-            tot_adv = w.read(incl_adv, (uint32_t)(W - 1));
-            tot_lit = w.read(incl_lit, (uint32_t)(W - 1));
-        }
-        const int last = top64(mask);
-        const uint32_t lms_lo = w.read((uint32_t)(my_pos + lit), (uint32_t)last), lms_hi = w.read((uint32_t)((my_pos + lit) >> 32), (uint32_t)last);
-        if (mine) {
-            const int rank = popc64(mask & ((1ull << w.lane) - 1ull));
-            rbuf[rb_n + (uint32_t)rank] = lzr::make_match(lit, mlen, offset);
-            uint8_t* d = lbuf + lb_n + my_lit;
-            uint64_t v = b1;
-            uint32_t r = lit;
-            if (r >= 8) { *(u64_unaligned*)d = v; v = b9; d += 8; r -= 8; }
-            if (r >= 4) { *(u32_unaligned*)d = (uint32_t)v; v >>= 32; d += 4; r -= 4; }
-            if (r >= 2) { *(u16_unaligned*)d = (uint16_t)v; v >>= 16; d += 2; r -= 2; }
-            if (r) d[0] = (uint8_t)v;
-        }
-        const uint32_t cnt = (uint32_t)popc64(mask);
-        rb_n += cnt;
-        lb_n += tot_lit;
-        nrec += cnt;
-        sequences += cnt;
-        last_match_start = (int64_t)(((uint64_t)lms_hi << 32) | lms_lo);
-        pos += tot_adv;
-        nlit += tot_lit;
-        ip += end_c;
-        return true;
+        r.end = ip; r.nlit = nlit; r.nrec = nrec; r.nout = nout; r.nseq = nseq; r.lms = lms; r.flags = flags;
     }
 
-    SWC_D int run() {
-        // the stripe path needs: 16 loadable bytes after the last stripe byte, no sequence of the stripe being the last
-        // one of the block (guaranteed: it ends inside the loaded bytes), room for W * (13 + 258) output bytes below
-        // the capacity, and room for W records
-        const bool fast_ok = (size_t)max_rec >= lzr::max_records(cap);
-#if defined(SWC_LZ4_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-        uint64_t t_s = 0, t_c = 0, n_s = 0, n_c = 0, t_f = 0;
-#define SWC_T0 const uint64_t t0_ = __builtin_readcyclecounter();
-#define SWC_T1(acc, cnt) { acc += __builtin_readcyclecounter() - t0_; cnt++; }
-#else
-#define SWC_T0
-#define SWC_T1(acc, cnt)
-#endif
+    // Rounds from `ip` on, as long as whole rounds can be committed.  Returns when the checked step has to take over
+    // (the end of the block is near, a sequence that does not fit a round, anything invalid, the capacity).
+    SWC_D void sync_rounds(uint8_t* stage) {
+        using simt::PT;
+        constexpr int N = kWave;
+        flush();
+        PT<uint32_t, N> start, endp, pe, c_lit, c_rec, c_out, c_seq, c_lms, flg, x_lit, x_rec, x_out, x_seq;
+        PT<bool, N> pb, have;
+        for (;;) {
+            if (n - ip < 4 * kChunk) return;                       // the last piece of a block is the checked step's
+            const uint64_t B = ip & ~(uint64_t)3;
+            const uint32_t start0 = (uint32_t)(ip - B);
+            const uint64_t avail = n - B;
+            const uint32_t stage_len = avail < kStageBytes ? (uint32_t)avail : kStageBytes;
+            const uint32_t tail_limit = avail - kTailKeep > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)(avail - kTailKeep);
+            SIMT_BEGIN(t, N)
+                for (uint32_t o = 16u * (uint32_t)t; o < kStageBytes; o += 16u * N) {
+                    uint64_t a = 0, b = 0;
+                    if (o + 16 <= stage_len) { a = load_u64(in + B + o); b = load_u64(in + B + o + 8); }
+                    else {
+                        for (uint32_t k = 0; k < 8; k++) if (o + k < stage_len) a |= (uint64_t)in[B + o + k] << (8 * k);
+                        for (uint32_t k = 0; k < 8; k++) if (o + 8 + k < stage_len) b |= (uint64_t)in[B + o + 8 + k] << (8 * k);
+                    }
+                    *(uint64_t*)(stage + o) = a;
+                    *(uint64_t*)(stage + o + 8) = b;
+                }
+                start[t] = t == 0 ? start0 : (uint32_t)t * kChunk;
+                have[t] = false;
+                endp[t] = kPosFail;
+                flg[t] = 0;
+            SIMT_END_WAVE
+            uint32_t nv = 0;
+            int E = 64;
+            SWC_LZ4_STAT(0, 1);
+            for (;;) {
+                SWC_LZ4_STAT(2, 1);
+                simt::wave_shift_up<N>(pe, endp, start0);
+                // parse (again) where the start is not the left neighbour's end, or nothing has been counted yet
+                SIMT_BEGIN(t, N)
+                    const bool pe_ok = t != 0 && pe[t] != kPosFail;
+                    const bool todo = !have[t] || (pe_ok && start[t] != pe[t]);
+                    if (todo) {
+                        if (pe_ok) start[t] = pe[t];
+                        SWC_LZ4_STAT(1, 1);
+                        ChunkOut r;
+                        const uint32_t ce = t == N - 1 ? stage_len : ((uint32_t)t + 1u) * kChunk;
+                        if (start[t] + 8 > stage_len) { r.end = kPosFail; r.nlit = r.nrec = r.nout = r.nseq = r.lms = 0; r.flags = kLzFail; }
+                        else parse_chunk<0>(stage, stage_len, start[t], ce, tail_limit, nullptr, nullptr, 0, r);
+                        endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; c_seq[t] = r.nseq; c_lms[t] = r.lms; flg[t] = r.flags;
+                        have[t] = true;
+                    }
+                SIMT_END
+                simt::wave_shift_up<N>(pe, endp, start0);
+                SIMT_BEGIN(t, N) pb[t] = t != 0 && start[t] != pe[t]; SIMT_END
+                const uint64_t m_bad = simt::wave_ballot<N>(pb);
+                const int b = m_bad ? simt::ctz64(m_bad) : 64;           // lanes [0, b) are on the true chain
+                SIMT_BEGIN(t, N) pb[t] = flg[t] != 0; SIMT_END
+                const uint64_t m_stop = simt::wave_ballot<N>(pb) & (b == 64 ? ~0ull : (1ull << b) - 1ull);
+                E = m_stop ? simt::ctz64(m_stop) : 64;                   // the lane that stopped in front of a sequence
+                nv = (uint32_t)(E < 64 ? E + 1 : b);
+                if (E < 64 || b == 64) break;
+            }
+            SIMT_BEGIN(t, N)
+                const bool v = (uint32_t)t < nv;
+                x_lit[t] = v ? c_lit[t] : 0u; x_rec[t] = v ? c_rec[t] : 0u; x_out[t] = v ? c_out[t] : 0u; x_seq[t] = v ? c_seq[t] : 0u;
+            SIMT_END
+            simt::wave_scan_incl<N>(x_lit);
+            simt::wave_scan_incl<N>(x_rec);
+            simt::wave_scan_incl<N>(x_out);
+            simt::wave_scan_incl<N>(x_seq);
+            const uint32_t tot_lit = simt::wave_read<N>(x_lit, N - 1), tot_rec = simt::wave_read<N>(x_rec, N - 1);
+            const uint32_t tot_out = simt::wave_read<N>(x_out, N - 1), tot_seq = simt::wave_read<N>(x_seq, N - 1);
+            const uint32_t stop_flags = E < 64 ? simt::wave_read<N>(flg, E) : 0u;
+            if (tot_seq == 0) return;                                         // not even one sequence: the checked step
+            if (pos + tot_out > cap || (uint64_t)nrec + tot_rec > max_rec) return;   // the capacity / the workspace: the checked step counts on
+            SIMT_BEGIN(t, N)
+                if ((uint32_t)t < nv && c_seq[t] != 0) {
+                    ChunkOut r;
+                    const uint32_t ce = t == N - 1 ? stage_len : ((uint32_t)t + 1u) * kChunk;
+                    parse_chunk<1>(stage, stage_len, start[t], ce, tail_limit, lits + nlit + (x_lit[t] - c_lit[t]), recs + nrec + (x_rec[t] - c_rec[t]),
+                                   pos + (x_out[t] - c_out[t]), r);
+                    flg[t] = r.flags;
+                } else flg[t] = 0;
+            SIMT_END
+            SIMT_BEGIN(t, N) pb[t] = (flg[t] & kLzTrap) != 0; SIMT_END
+            if (simt::wave_ballot<N>(pb)) return;                             // an offset beyond the output: the checked step reports it
+            // the last match start of the round: in the last lane that took a sequence
+            SIMT_BEGIN(t, N) pb[t] = (uint32_t)t < nv && c_seq[t] != 0; SIMT_END
+            const uint64_t m_seq = simt::wave_ballot<N>(pb);
+            const int last = 63 - (int)clz64(m_seq);
+            SIMT_BEGIN(t, N) x_seq[t] = (x_out[t] - c_out[t]) + c_lms[t]; SIMT_END
+            last_match_start = (int64_t)(pos + simt::wave_read<N>(x_seq, last));
+            pos += tot_out;
+            nlit += tot_lit;
+            nrec += tot_rec;
+            sequences += tot_seq;
+            SWC_LZ4_STAT(3, tot_seq);
+            ip = B + simt::wave_read<N>(endp, (int)nv - 1);
+            if (stop_flags & (kLzFail | kLzTail)) return;                     // anything invalid / the end of the block: the checked step
+        }
+    }
+
+    SWC_D int run(uint8_t* stage) {
+        // the rounds append records unchecked: the workspace must hold what a block of this capacity can need
+        const bool fast_ok = stage != nullptr && (size_t)max_rec >= lzr::max_records(cap);
         int result = SWC_OK;
         for (;;) {
-            if (fast_ok && ip + (uint64_t)W + 24 <= n && pos + (uint64_t)W * 272 + 16 <= cap) {
-                if (rb_n + (uint32_t)W > kRecBuf || lb_n + (uint32_t)W * 13 > kLitStage) flush();
-                SWC_T0
-                const bool took = stripe();
-                SWC_T1(t_s, n_s)
-                if (took) continue;
-            }
-            SWC_T0
+            if (fast_ok && pos < cap) sync_rounds(stage);
             const int st = careful_step();
-            SWC_T1(t_c, n_c)
             if (st == -1) break;
             if (st) { result = st; break; }
         }
-#if defined(SWC_LZ4_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-        if (w.lane == 0) {
-            SWC_AS_GLOBAL uint64_t* dbg = (SWC_AS_GLOBAL uint64_t*)(lits + lzr::lit_bytes(cap) - 32);
-            dbg[0] = t_s; dbg[1] = n_s; dbg[2] = t_c; dbg[3] = n_c;
-        }
-        (void)t_f;
-#endif
         return result;
     }
 };
 
 // One wavefront = one job (blocks WITHOUT a dictionary prefix; those with one stay on lz4_lane.h).
 template <int W>
-SWC_D void lz4_parse_job(Job& job, uint8_t* ws, size_t ws_bytes, int lane, uint32_t* rbuf, uint8_t* lbuf, uint8_t* iw) {
+SWC_D void lz4_parse_job(Job& job, uint8_t* ws, size_t ws_bytes, int lane, uint32_t* rbuf, uint8_t* lbuf, uint8_t* iw, uint8_t* stage) {
     Parser<W> ps;
     ps.w.lane = lane;
     ps.iw = iw;
@@ -406,7 +523,7 @@ SWC_D void lz4_parse_job(Job& job, uint8_t* ws, size_t ws_bytes, int lane, uint3
     ps.recs = (SWC_AS_GLOBAL uint32_t*)(ws + sizeof(lzr::StreamHeader));
     ps.max_rec = lo > sizeof(lzr::StreamHeader) ? (uint32_t)((lo - sizeof(lzr::StreamHeader)) / 4) : 0u;
     ps.lits = (gptr)(ws + lo);
-    int st = lo == 0 ? SWC_E_NEED_WORKSPACE : ps.run();
+    int st = lo == 0 ? SWC_E_NEED_WORKSPACE : ps.run(stage);
     ps.flush();
     if (ps.nrec > ps.max_rec) {
         st = SWC_E_NEED_WORKSPACE;

@@ -61,6 +61,9 @@ extern "C" void emu_inflate_sync(swc::Job* jobs, size_t n) {
     }
 }
 
+extern "C" void emu_lz4_stats(uint64_t* out, int reset) {
+    for (int i = 0; i < 8; i++) { out[i] = swc::lz4w::g_lz4_stats[i]; if (reset) swc::lz4w::g_lz4_stats[i] = 0; }
+}
 extern "C" void emu_sync_stats(uint64_t* out, int reset) {
     for (int i = 0; i < 8; i++) { out[i] = swc::inflate::g_sync_stats[i]; if (reset) swc::inflate::g_sync_stats[i] = 0; }
 }
@@ -76,7 +79,9 @@ extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {
         static uint32_t rbuf[swc::lz4w::kRecBuf];
         static uint8_t lbuf[swc::lz4w::kLitStage + 32 + 64];
         alignas(16) static uint8_t iw[swc::lz4w::kInWin + 16];
-        swc::lz4w::lz4_parse_job<1>(jobs[g], ws.data(), wsb, 0, rbuf, lbuf, iw);
+        alignas(16) static uint8_t stage[swc::lz4w::kStageBytes];
+        std::memset(stage, 0xEE, sizeof stage);
+        swc::lz4w::lz4_parse_job<1>(jobs[g], ws.data(), wsb, 0, rbuf, lbuf, iw, stage);
         std::memset(&rl, 0xEE, sizeof rl);
         swc::lzr::resolve_job<swc::lz4w::kResolveThreads, swc::lz4w::kRingLog2, swc::lz4w::kKeep>(jobs[g], ws.data(), wsb, &rl);
     }

@@ -37,3 +37,41 @@ def test_capacity_reports_required_size():
     res = E.lz4_block([z for z, _ in cases], [len(e[1]) // 2 for e in exp])
     for r, e in zip(res, exp):
         assert r[0] == 901 and r[3] == len(e[1]) and r[1] == e[1][:len(e[1]) // 2]
+
+
+import pytest
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_large_blocks_sub_chunk_rounds(order):
+    """Blocks large enough for the sub-chunk-parallel rounds of lz4_wave.h (64 lanes x 256 bytes per round): every payload
+    class, then damaged copies (byte flips -- offset 0, offsets beyond the output, broken length extensions -- and
+    truncations) whose status and output must still be the oracle's.  The thread order of the emulated SIMT regions must
+    not matter."""
+    from swcompression_amd import corpus
+    O.lib.refcpu_set_max_output(1 << 23)
+    rnd = random.Random(5 + order)
+    cases = []
+    for kind, size in (("text", 300000), ("mix", 400000), ("rep", 200000), ("zero", 100000), ("rand", 70000), ("text", 1 << 20)):
+        z = corpus.lz4_block(corpus.PAYLOADS[kind](size, 31))
+        cases.append(z)
+        if kind in ("text", "mix") and size <= 400000:
+            for _ in range(6):
+                b = bytearray(z)
+                for _ in range(rnd.choice([1, 1, 3])):
+                    b[rnd.randrange(len(b))] = rnd.choice([0, 0, 255, rnd.randrange(256)])
+                cases.append(bytes(b))
+            cases.append(z[:rnd.randrange(len(z) // 2, len(z))])
+    exp = [O.lz4_block(z) for z in cases]
+    E.set_order(order)
+    try:
+        res = E.lz4_block(cases, [max(len(e[1]), 1) + 64 for e in exp], misalign=order)
+    finally:
+        E.set_order(0)
+    for i, (r, e) in enumerate(zip(res, exp)):
+        if e[0] == 901:
+            continue
+        assert r[0] == e[0], "case %d" % i
+        if e[0] == 0:
+            assert r[1] == e[1] and r[2] == len(cases[i]), "case %d" % i
+    O.lib.refcpu_set_max_output(1 << 30)
