@@ -430,8 +430,8 @@ struct Parser {
                         SWC_LZ4_STAT(1, 1);
                         ChunkOut r;
                         const uint32_t ce = t == N - 1 ? stage_len : ((uint32_t)t + 1u) * kChunk;
-                        if (start[t] + 8 > stage_len) { r.end = kPosFail; r.nlit = r.nrec = r.nout = r.nseq = r.lms = 0; r.flags = kLzFail; }
-                        else parse_chunk<0>(stage, stage_len, start[t], ce, tail_limit, nullptr, nullptr, 0, r);
+                        // (a start within 8 bytes of the staged window's end stops there at once: parse_chunk's first test)
+                        parse_chunk<0>(stage, stage_len, start[t], ce, tail_limit, nullptr, nullptr, 0, r);
                         endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; c_seq[t] = r.nseq; c_lms[t] = r.lms; flg[t] = r.flags;
                         have[t] = true;
                     }
