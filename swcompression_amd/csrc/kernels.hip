@@ -152,7 +152,7 @@ __global__ __launch_bounds__(64) void swc_lz4_lane_kernel(Job* __restrict__ jobs
     jobs[g].status = job.status;
 }
 
-__global__ __launch_bounds__(64) void swc_lz4_parse_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride) {
+__global__ __launch_bounds__(64) void swc_lz4_parse_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride, uint64_t* prof) {
     uint32_t g = blockIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
@@ -161,7 +161,7 @@ __global__ __launch_bounds__(64) void swc_lz4_parse_kernel(Job* __restrict__ job
     __shared__ uint32_t rbuf[lz4w::kRecBuf];
     __shared__ __attribute__((aligned(16))) uint8_t lbuf[lz4w::kLitStage + 32 + 64];
     __shared__ __attribute__((aligned(16))) uint8_t stage[lz4w::kStageBytes];
-    lz4w::lz4_parse_job<kWave>(job, ws + (size_t)g * ws_stride, ws_stride, (int)threadIdx.x, rbuf, lbuf, iw, stage);
+    lz4w::lz4_parse_job<kWave>(job, ws + (size_t)g * ws_stride, ws_stride, (int)threadIdx.x, rbuf, lbuf, iw, stage, prof ? prof + 32 * (size_t)g : nullptr);
     if (threadIdx.x == 0) {
         jobs[g].out_len = job.out_len;
         jobs[g].in_consumed = job.in_consumed;
@@ -192,7 +192,7 @@ hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_
     // The parse is latency bound per block (a serial chase), so all blocks are parsed in ONE launch: the more waves
     // in flight, the better the latency hides (8,192 blocks = 8 waves per SIMD).
     hipLaunchKernelGGL(swc_lz4_lane_kernel, grid, block, 0, stream, jobs, (uint32_t)n, 1);
-    hipLaunchKernelGGL(swc_lz4_parse_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride);
+    hipLaunchKernelGGL(swc_lz4_parse_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride, g_prof);
     hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(lz4w::kResolveThreads), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride);
     return hipGetLastError();
 }

@@ -44,6 +44,11 @@ constexpr uint32_t kStageBytes = 64u * kChunk + 64u;  // staged input of a round
 constexpr uint32_t kTailKeep = 16;                    // the sequences that end in the last bytes of a block stay with the checked step
 constexpr uint32_t kPosFail = 0xFFFFFFFFu;
 enum { kLzStop = 1u, kLzFail = 2u, kLzTrap = 4u, kLzTail = 8u };
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+#define SWC_LP(k) { const uint64_t t_ = __builtin_readcyclecounter(); pacc[k] += t_ - tlast; tlast = t_; }
+#else
+#define SWC_LP(k)
+#endif
 #if defined(SWC_HOST_EMULATION)
 inline uint64_t g_lz4_stats[8];   // emulated parser: rounds, lane parses, passes, sequences taken by rounds, checked steps
 #define SWC_LZ4_STAT(i, n) (g_lz4_stats[i] += (n))
@@ -143,6 +148,10 @@ struct Parser {
     uint64_t ip, pos, nlit, sequences;
     int64_t last_match_start;
     uint32_t nrec;
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    uint64_t pacc[8] = {0, 0, 0, 0, 0, 0, 0, 0};   // cycles: 0 staging, 1 count passes, 2 scans, 3 emit, 4 checked steps; 5 rounds, 6 passes
+    uint64_t tlast = 0;
+#endif
 
     SWC_D uint64_t chunk_load(uint64_t base) const {   // this lane's 8 bytes of the chunk at `base`
         const uint64_t a = base + 8 * (uint64_t)w.lane;
@@ -393,7 +402,8 @@ struct Parser {
         PT<uint32_t, N> start, endp, pe, c_lit, c_rec, c_out, c_seq, c_lms, flg, x_lit, x_rec, x_out, x_seq;
         PT<bool, N> pb, have;
         for (;;) {
-            if (n - ip < 4 * kChunk) return;                       // the last piece of a block is the checked step's
+            if (n - ip < 128) return;                              // the last bytes of a block are the checked step's
+            SWC_LP(4)
             const uint64_t B = ip & ~(uint64_t)3;
             const uint32_t start0 = (uint32_t)(ip - B);
             const uint64_t avail = n - B;
@@ -415,11 +425,18 @@ struct Parser {
                 endp[t] = kPosFail;
                 flg[t] = 0;
             SIMT_END_WAVE
+            SWC_LP(0)
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+            pacc[5]++;
+#endif
             uint32_t nv = 0;
             int E = 64;
             SWC_LZ4_STAT(0, 1);
             for (;;) {
                 SWC_LZ4_STAT(2, 1);
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+                pacc[6]++;
+#endif
                 simt::wave_shift_up<N>(pe, endp, start0);
                 // parse (again) where the start is not the left neighbour's end, or nothing has been counted yet
                 SIMT_BEGIN(t, N)
@@ -446,6 +463,7 @@ struct Parser {
                 nv = (uint32_t)(E < 64 ? E + 1 : b);
                 if (E < 64 || b == 64) break;
             }
+            SWC_LP(1)
             SIMT_BEGIN(t, N)
                 const bool v = (uint32_t)t < nv;
                 x_lit[t] = v ? c_lit[t] : 0u; x_rec[t] = v ? c_rec[t] : 0u; x_out[t] = v ? c_out[t] : 0u; x_seq[t] = v ? c_seq[t] : 0u;
@@ -457,6 +475,7 @@ struct Parser {
             const uint32_t tot_lit = simt::wave_read<N>(x_lit, N - 1), tot_rec = simt::wave_read<N>(x_rec, N - 1);
             const uint32_t tot_out = simt::wave_read<N>(x_out, N - 1), tot_seq = simt::wave_read<N>(x_seq, N - 1);
             const uint32_t stop_flags = E < 64 ? simt::wave_read<N>(flg, E) : 0u;
+            SWC_LP(2)
             if (tot_seq == 0) return;                                         // not even one sequence: the checked step
             if (pos + tot_out > cap || (uint64_t)nrec + tot_rec > max_rec) return;   // the capacity / the workspace: the checked step counts on
             SIMT_BEGIN(t, N)
@@ -468,6 +487,7 @@ struct Parser {
                     flg[t] = r.flags;
                 } else flg[t] = 0;
             SIMT_END
+            SWC_LP(3)
             SIMT_BEGIN(t, N) pb[t] = (flg[t] & kLzTrap) != 0; SIMT_END
             if (simt::wave_ballot<N>(pb)) return;                             // an offset beyond the output: the checked step reports it
             // the last match start of the round: in the last lane that took a sequence
@@ -502,7 +522,7 @@ struct Parser {
 
 // One wavefront = one job (blocks WITHOUT a dictionary prefix; those with one stay on lz4_lane.h).
 template <int W>
-SWC_D void lz4_parse_job(Job& job, uint8_t* ws, size_t ws_bytes, int lane, uint32_t* rbuf, uint8_t* lbuf, uint8_t* iw, uint8_t* stage) {
+SWC_D void lz4_parse_job(Job& job, uint8_t* ws, size_t ws_bytes, int lane, uint32_t* rbuf, uint8_t* lbuf, uint8_t* iw, uint8_t* stage, uint64_t* prof = nullptr) {
     Parser<W> ps;
     ps.w.lane = lane;
     ps.iw = iw;
@@ -523,8 +543,17 @@ SWC_D void lz4_parse_job(Job& job, uint8_t* ws, size_t ws_bytes, int lane, uint3
     ps.recs = (SWC_AS_GLOBAL uint32_t*)(ws + sizeof(lzr::StreamHeader));
     ps.max_rec = lo > sizeof(lzr::StreamHeader) ? (uint32_t)((lo - sizeof(lzr::StreamHeader)) / 4) : 0u;
     ps.lits = (gptr)(ws + lo);
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    ps.tlast = __builtin_readcyclecounter();
+#endif
     int st = lo == 0 ? SWC_E_NEED_WORKSPACE : ps.run(stage);
     ps.flush();
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    { const uint64_t t_ = __builtin_readcyclecounter(); ps.pacc[4] += t_ - ps.tlast; }
+    if (prof && lane == 0) for (int k = 0; k < 8; k++) prof[k] = ps.pacc[k];
+#else
+    (void)prof;
+#endif
     if (ps.nrec > ps.max_rec) {
         st = SWC_E_NEED_WORKSPACE;
         ps.nrec = ps.max_rec;
