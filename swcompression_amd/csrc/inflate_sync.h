@@ -46,6 +46,12 @@ constexpr int kSyncLitBits = 10, kSyncDistBits = 9;
 constexpr uint32_t kSyncChunk = SWC_SYNC_CHUNK;      // input bytes per lane and round (a multiple of 4)
 constexpr uint32_t kSyncRound = 64u * kSyncChunk;
 constexpr uint32_t kSyncStage = kSyncRound + 128u;   // + what the last lane may read past its sub-chunk
+// The staged input is laid out with ONE pad dword behind every sub-chunk: the lanes start a pass at the same offset of
+// their sub-chunks, and with a power-of-two stride all of them would hit the same LDS bank.
+constexpr uint32_t kSyncChunkDwords = kSyncChunk / 4;
+static_assert((kSyncChunkDwords & (kSyncChunkDwords - 1)) == 0, "the pad arithmetic wants a power of two");
+SWC_HD uint32_t stage_slot(uint32_t dword) { return dword + dword / kSyncChunkDwords; }
+constexpr uint32_t kSyncStageLds = kSyncStage + 4u * (kSyncStage / kSyncChunk + 2u);
 constexpr uint32_t kEntInvalid = 0x80000000u;        // a code of the set, but not a symbol the fast path takes
 constexpr uint32_t kPosFail = 0xFFFFFFFFu;
 static_assert(kSyncChunk % 4 == 0 && kSyncChunk >= 64, "sub-chunks are whole dwords");
@@ -70,7 +76,7 @@ struct SyncLds {
     uint32_t lut[(1 << kSyncLitBits) + (1 << kSyncDistBits)];      // direct tables: lit/len, then distance
     uint32_t symtab[320];                                           // one entry per sorted symbol: lit/len at 0, distance at 288
     uint32_t aux[kAuxWords];                                        // the canonical tables (see kAux*)
-    alignas(16) uint8_t stage[kSyncStage];                          // staged input of a round; header build: code lengths, counters, code-length table
+    alignas(16) uint8_t stage[kSyncStageLds];                       // staged input of a round (padded, see stage_slot); header build: code lengths, counters, code-length table
 };
 // header scratch inside `stage`
 constexpr uint32_t kHdrLens = 0;       // 320 bytes: code length of symbol s
@@ -382,7 +388,7 @@ SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, u
                         SWC_AS_GLOBAL uint32_t* rec_dst, uint64_t out_pos0, ChunkOut& r) {
     const uint32_t* st32 = (const uint32_t*)sl->stage;
     uint32_t w = start >> 5, bp = start & 31u;
-    uint32_t d0 = st32[w], d1 = st32[w + 1], d2 = st32[w + 2];
+    uint32_t d0 = st32[stage_slot(w)], d1 = st32[stage_slot(w + 1)], d2 = st32[stage_slot(w + 2)];
     uint32_t tsel = 0, tmsk = (1u << kSyncLitBits) - 1u;   // the table of the next code: dword offset into `lut` and index mask
     uint32_t plen = 0, run = 0, nlit = 0, nrec = 0, nout = 0, flags = 0;
     uint64_t lb = 0;
@@ -396,7 +402,7 @@ SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, u
         SWC_SYNC_STAT(4 + (MODE == 3 ? 0 : MODE), 1);   // code iterations per mode
         const uint32_t bits = funnel32(d1, d0, bp);
         uint32_t e = sl->lut[(bits & tmsk) + tsel];
-        const uint32_t nx = st32[w + 3];
+        const uint32_t nx = st32[stage_slot(w + 3)];
         if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, tsel); }   // a code longer than the direct table (or no code at all)
         const uint32_t n = e & 31u;
         if ((e & (kEntInvalid | kEntEob)) || (CHK && posb + n > in_bits)) {
@@ -484,8 +490,9 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                     for (uint32_t k = 0; k < 8; k++) if (at + k < in_len) a |= (uint64_t)in[at + k] << (8 * k);
                     for (uint32_t k = 0; k < 8; k++) if (at + 8 + k < in_len) b |= (uint64_t)in[at + 8 + k] << (8 * k);
                 }
-                *(uint64_t*)(sl->stage + o) = a;
-                *(uint64_t*)(sl->stage + o + 8) = b;
+                uint32_t* st32 = (uint32_t*)sl->stage;   // (a 16-byte piece never straddles a sub-chunk: the pad keeps its dwords together)
+                const uint32_t d = stage_slot(o >> 2);
+                st32[d] = (uint32_t)a; st32[d + 1] = (uint32_t)(a >> 32); st32[d + 2] = (uint32_t)b; st32[d + 3] = (uint32_t)(b >> 32);
             }
             start[t] = t == 0 ? q0 : (uint32_t)t * kSyncChunk * 8u;
         SIMT_END_WAVE

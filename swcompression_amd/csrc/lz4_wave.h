@@ -41,6 +41,13 @@ constexpr uint32_t kInWin = 1024;    // input window of the checked step in LDS
 #endif
 constexpr uint32_t kChunk = SWC_LZ4_CHUNK;            // input bytes per lane and round of the sub-chunk-parallel parse (a multiple of 16)
 constexpr uint32_t kStageBytes = 64u * kChunk + 64u;  // staged input of a round (+ what the last lane reads past its sub-chunk)
+// The staged input carries ONE pad dword behind every sub-chunk: the lanes of a wave work at similar offsets of their
+// sub-chunks, and with a power-of-two stride they would all hit the same LDS bank.
+constexpr uint32_t kChunkDwords = kChunk / 4;
+static_assert((kChunkDwords & (kChunkDwords - 1)) == 0 && kChunk % 16 == 0, "the pad arithmetic wants a power of two");
+SWC_HD uint32_t stage_slot(uint32_t dword) { return dword + dword / kChunkDwords; }
+SWC_HD uint32_t stage_byte(uint32_t a) { return a + 4u * (a / kChunk); }
+constexpr uint32_t kStageLds = kStageBytes + 4u * (kStageBytes / kChunk + 2u);
 constexpr uint32_t kTailKeep = 16;                    // the sequences that end in the last bytes of a block stay with the checked step
 constexpr uint32_t kPosFail = 0xFFFFFFFFu;
 enum { kLzStop = 1u, kLzFail = 2u, kLzTrap = 4u, kLzTail = 8u };
@@ -319,11 +326,12 @@ struct Parser {
         uint32_t flags;
     };
     SWC_D static uint32_t rd32(const uint8_t* stage, uint32_t a) {   // the four bytes at `a` (aligned LDS reads + a byte shift)
-        const uint32_t* w = (const uint32_t*)(stage + (a & ~3u));
+        const uint32_t* st32 = (const uint32_t*)stage;
+        const uint32_t lo = st32[stage_slot(a >> 2)], hi = st32[stage_slot((a >> 2) + 1u)];
 #if defined(__HIP_DEVICE_COMPILE__)
-        return __builtin_amdgcn_alignbyte(w[1], w[0], a & 3u);
+        return __builtin_amdgcn_alignbyte(hi, lo, a & 3u);
 #else
-        return (uint32_t)((((uint64_t)w[1] << 32) | w[0]) >> (8 * (a & 3u)));
+        return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (a & 3u)));
 #endif
     }
     // MODE 0: count.  MODE 1: emit literals and records (offsets are checked against the output position).
@@ -341,7 +349,7 @@ struct Parser {
                 lit += b; p++;
                 while (b == 255) {
                     if (p + 8 > stage_len) { flags |= kLzStop; break; }
-                    b = stage[p++];
+                    b = stage[stage_byte(p++)];
                     lit += b;
                 }
                 if (flags) break;
@@ -358,7 +366,7 @@ struct Parser {
                 mlen += b; p++;
                 while (b == 255) {
                     if (p + 8 > stage_len) { flags |= kLzStop; break; }
-                    b = stage[p++];
+                    b = stage[stage_byte(p++)];
                     mlen += b;
                 }
                 if (flags) break;
@@ -369,7 +377,7 @@ struct Parser {
                 if ((uint64_t)offset > out_pos0 + nout + lit) { flags |= kLzTrap; break; }   // :382 offset <= bytes produced
                 uint32_t i = 0;
                 for (; i + 4 <= lit; i += 4) store_u32(lit_dst + i, rd32(stage, lit_at + i));
-                for (; i < lit; i++) lit_dst[i] = stage[lit_at + i];
+                for (; i < lit; i++) lit_dst[i] = stage[stage_byte(lit_at + i)];
                 lit_dst += lit;
                 uint32_t run = lit;
                 if (run > lzr::kLitRunMax) {
@@ -417,8 +425,9 @@ struct Parser {
                         for (uint32_t k = 0; k < 8; k++) if (o + k < stage_len) a |= (uint64_t)in[B + o + k] << (8 * k);
                         for (uint32_t k = 0; k < 8; k++) if (o + 8 + k < stage_len) b |= (uint64_t)in[B + o + 8 + k] << (8 * k);
                     }
-                    *(uint64_t*)(stage + o) = a;
-                    *(uint64_t*)(stage + o + 8) = b;
+                    uint32_t* st32 = (uint32_t*)stage;   // (a 16-byte piece never straddles a sub-chunk: the pad keeps its dwords together)
+                    const uint32_t d = stage_slot(o >> 2);
+                    st32[d] = (uint32_t)a; st32[d + 1] = (uint32_t)(a >> 32); st32[d + 2] = (uint32_t)b; st32[d + 3] = (uint32_t)(b >> 32);
                 }
                 start[t] = t == 0 ? start0 : (uint32_t)t * kChunk;
                 have[t] = false;

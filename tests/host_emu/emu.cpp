@@ -79,7 +79,7 @@ extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {
         static uint32_t rbuf[swc::lz4w::kRecBuf];
         static uint8_t lbuf[swc::lz4w::kLitStage + 32 + 64];
         alignas(16) static uint8_t iw[swc::lz4w::kInWin + 16];
-        alignas(16) static uint8_t stage[swc::lz4w::kStageBytes];
+        alignas(16) static uint8_t stage[swc::lz4w::kStageLds];
         std::memset(stage, 0xEE, sizeof stage);
         swc::lz4w::lz4_parse_job<1>(jobs[g], ws.data(), wsb, 0, rbuf, lbuf, iw, stage);
         std::memset(&rl, 0xEE, sizeof rl);
