@@ -335,68 +335,52 @@ struct Parser {
 #endif
     }
     // MODE 0: count.  MODE 1: emit literals and records (offsets are checked against the output position).
+    // The loop takes SHORT sequences only -- at most one extension byte for the literal length and one for the match
+    // length (under 270 literals, under 274 match bytes) -- as one straight line of selects: the wave is bound by the
+    // latency of this loop (two dependent LDS reads per sequence).  Anything else stops the lane in front of the
+    // sequence; the round ends there and the checked step (which copies long literal runs with the whole wave) takes it.
     template <int MODE>
     SWC_D static void parse_chunk(const uint8_t* stage, uint32_t stage_len, uint32_t start, uint32_t chunk_end, uint32_t tail_limit, gptr lit_dst,
                                   SWC_AS_GLOBAL uint32_t* rec_dst, uint64_t out_pos0, ChunkOut& r) {
         uint32_t ip = start, nlit = 0, nrec = 0, nout = 0, nseq = 0, lms = 0, flags = 0;
+        const uint32_t safe = stage_len >= 8 ? stage_len - 8u : 0u;   // a read of four bytes at or below this stays inside the staged window
         while (ip < chunk_end) {
-            if (ip + 8 > stage_len) { flags |= kLzStop; break; }
+            if (ip > safe) { flags |= kLzStop; break; }
             const uint32_t tok32 = rd32(stage, ip);
-            const uint32_t token = tok32 & 0xFFu;
-            uint32_t lit = token >> 4, p = ip + 1;
-            if (lit == 15) {
-                uint32_t b = (tok32 >> 8) & 0xFFu;
-                lit += b; p++;
-                while (b == 255) {
-                    if (p + 8 > stage_len) { flags |= kLzStop; break; }
-                    b = stage[stage_byte(p++)];
-                    lit += b;
-                }
-                if (flags) break;
+            const uint32_t token = tok32 & 0xFFu, b1 = (tok32 >> 8) & 0xFFu;
+            const uint32_t l0 = token >> 4, m0 = token & 15u;
+            const uint32_t lx = l0 == 15 ? 1u : 0u;
+            const uint32_t lit = l0 + (lx ? b1 : 0u);
+            const uint32_t lit_at = ip + 1u + lx;
+            const uint32_t p = lit_at + lit;                       // the offset field (<= ip + 272)
+            const uint32_t pr = p > safe ? safe : p;               // (read something harmless when the lane is about to stop)
+            const uint32_t off32 = rd32(stage, pr);
+            const uint32_t offset = off32 & 0xFFFFu, b2 = (off32 >> 16) & 0xFFu;
+            const uint32_t mx = m0 == 15 ? 1u : 0u;
+            const uint32_t mlen = 4u + m0 + (mx ? b2 : 0u);
+            const uint32_t pn = p + 2u + mx;                       // the next sequence
+            // long lengths, the staged window, the tail of the block, an invalid offset: the lane stops in front of it
+            const bool stop = (lx & (uint32_t)(b1 == 255)) | (mx & (uint32_t)(b2 == 255)) | (uint32_t)(p > safe) | (uint32_t)(pn > tail_limit);
+            if (stop || offset == 0) {
+                flags |= stop ? (pn > tail_limit && p <= safe ? kLzStop | kLzTail : kLzStop) : kLzFail;   // offset 0: LZ4.swift:382
+                break;
             }
-            const uint32_t lit_at = p;
-            if (lit > stage_len || p + lit + 8 > stage_len) { flags |= kLzStop; break; }   // the literal run leaves the staged window
-            p += lit;
-            const uint32_t off32 = rd32(stage, p);
-            const uint32_t offset = off32 & 0xFFFFu;
-            p += 2;
-            uint32_t mlen = 4 + (token & 15u);
-            if (mlen == 19) {
-                uint32_t b = (off32 >> 16) & 0xFFu;
-                mlen += b; p++;
-                while (b == 255) {
-                    if (p + 8 > stage_len) { flags |= kLzStop; break; }
-                    b = stage[stage_byte(p++)];
-                    mlen += b;
-                }
-                if (flags) break;
-            }
-            if (p > tail_limit) { flags |= kLzStop | kLzTail; break; }   // the checked step takes the end of the block
-            if (offset == 0) { flags |= kLzFail; break; }                  // LZ4.swift:382
+            const uint32_t big = lit > lzr::kLitRunMax ? 1u : 0u;
             if (MODE == 1) {
                 if ((uint64_t)offset > out_pos0 + nout + lit) { flags |= kLzTrap; break; }   // :382 offset <= bytes produced
                 uint32_t i = 0;
                 for (; i + 4 <= lit; i += 4) store_u32(lit_dst + i, rd32(stage, lit_at + i));
                 for (; i < lit; i++) lit_dst[i] = stage[stage_byte(lit_at + i)];
                 lit_dst += lit;
-                uint32_t run = lit;
-                if (run > lzr::kLitRunMax) {
-                    while (run > 0) { const uint32_t s = run > lzr::kMaxLitOnly ? lzr::kMaxLitOnly : run; *rec_dst++ = lzr::make_lits(s); run -= s; }
-                }
-                uint32_t rem = mlen;
-                while (rem > 0) {
-                    const uint32_t piece = rem > lzr::kMaxLen ? lzr::kMaxLen : rem;
-                    *rec_dst++ = lzr::make_match(run, piece, offset);
-                    run = 0;
-                    rem -= piece;
-                }
+                if (big) *rec_dst++ = lzr::make_lits(lit);
+                *rec_dst++ = lzr::make_match(big ? 0u : lit, mlen, offset);
             }
-            nrec += (lit > lzr::kLitRunMax ? (lit + lzr::kMaxLitOnly - 1u) / lzr::kMaxLitOnly : 0u) + (mlen + lzr::kMaxLen - 1u) / lzr::kMaxLen;
+            nrec += 1u + big;
             nlit += lit;
             lms = nout + lit;
             nout += lit + mlen;
             nseq++;
-            ip = p;
+            ip = pn;
         }
         r.end = ip; r.nlit = nlit; r.nrec = nrec; r.nout = nout; r.nseq = nseq; r.lms = lms; r.flags = flags;
     }
