@@ -2,21 +2,27 @@
 """bench.py -- headline benchmark of the MI355X decode engine.
 
 Contract (see the task statement): `python bench.py --gpus N --steps K --warmup W`; for N > 1 the driver
-launches it under torch.distributed.run, one rank per GPU.  A "step" is ONE pass of the hot path (one
-batched launch) over the whole synthetic batch with inputs already resident in HBM.  Default workload =
-BASELINE.json configs[1]: 100,000 independent gzip members of 64 KiB (Deflate, dynamic Huffman), host-side
-framing done before the timed region.  Units shard across ranks with no data-path collective
-("weak" scaling: every rank decodes its own batch); RCCL is used only for the barrier and the
-max-over-ranks time.  The other BASELINE configs are parity-test cases; `--workload` times them too
-(lz4_4m, bzip2_900k, lzma2_256k) but they are not the headline line.
+launches it under torch.distributed.run, one rank per GPU.  A "step" is ONE pass of the hot path over the whole
+synthetic batch with inputs already resident in HBM.  Headline workload = BASELINE.json configs[1]: 100,000
+independent gzip members of 64 KiB (Deflate, dynamic Huffman; 4,096 distinct members tiled at distinct device
+addresses), host-side framing done before the timed region; a step is what GzipArchive.unarchive does per member:
+the batched Deflate launch AND the CRC-32 of every member (device kernel), both inside the timed region.
+
+Units shard across ranks with no data-path collective.  `--scaling weak` (default): every rank decodes a full per-GPU
+batch of its own; `--scaling strong`: ONE unit list is cut into contiguous ranges balanced by sum(C + U)
+(swcompression_amd/shard.py) and every rank decodes its range.  RCCL carries only the barrier, the max-over-ranks time
+and the byte totals.
 
 Prints ONE JSON line: decompressed GiB/s (sum of U over all ranks / max time), plus
-  roofline     -- HBM roofline: algorithmic bytes (C + U per unit) / mean kernel time of a
-                  launch, measured with HIP events on the launch stream (per kernel for the two Deflate
-                  kernels), vs 8 TB/s; `traffic` = HBM bytes per launch from the committed rocprofv3 --pmc
-                  passes of this same command (profiles/*_traffic.json), or null;
-  cpu_baseline -- the CPU oracle (a port of the reference's algorithm) timed on a bounded sample of the
-                  same workload on this box's host cores (rank 0, N = 1 only).
+  roofline     -- HBM roofline of the headline: algorithmic bytes (C + U per unit) / mean duration of a
+                  launch, measured with HIP events on the launch stream (per kernel for the Deflate kernels), vs 8 TB/s;
+                  `traffic` / `l2_hit_rate` = HBM bytes per launch and TCC_HIT / (TCC_HIT + TCC_MISS) per kernel from the
+                  committed rocprofv3 --pmc passes of this same command (profiles/*_traffic.json), or null;
+  cpu_baseline -- the CPU oracle (a port of the reference's algorithm) timed on a bounded sample of the same workload
+                  on this box's host cores (rank 0, N = 1 only);
+  per_codec    -- (N = 1) the other BASELINE configs on their stated sizes -- LZ4 8,192 x 4 MiB, BZip2 10,240 x 900 kB,
+                  LZMA2 32,768 x 256 KiB -- each with value / roofline / cpu_baseline, every unit verified on the device.
+`--workload X` times workload X alone as the headline line.
 """
 import argparse
 import ctypes as C
@@ -31,16 +37,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec
 
 WORKLOADS = {
-    # name: codec, corpus kind, n_distinct, tile, unit bytes, description
-    "deflate64k": dict(codec="deflate", kind="gzip", n_distinct=4000, tile=25, unit=65536,
-                       desc="100000 x 64 KiB gzip members (BASELINE configs[1])", kernels="swc_inflate_kernel + swc_lz_resolve_kernel"),
-    "lz4_4m": dict(codec="lz4_block", kind="lz4_block", n_distinct=32, tile=256, unit=4 << 20,
+    "deflate64k": dict(codec="deflate", kind="gzip", n_distinct=4096, n_units=100000, unit=65536,
+                       desc="100000 x 64 KiB gzip members (BASELINE configs[1]; 4096 distinct, tiled at distinct addresses)",
+                       kernels="swc_inflate_sync_kernel + swc_lz_resolve_kernel + swc_crc32_kernel", steps=None),
+    "lz4_4m": dict(codec="lz4_block", kind="lz4_block", n_distinct=32, n_units=8192, unit=4 << 20,
                    desc="8192 x 4 MiB independent LZ4 blocks (BASELINE configs[2], resident micro-config of SURVEY 8d)",
-                   kernels="swc_lz4_parse_kernel + swc_lz4_resolve_kernel"),
-    "bzip2_900k": dict(codec="bzip2_block", kind="bzip2", n_distinct=32, tile=320, unit=899000,
-                       desc="10240 x 900 kB bzip2 blocks (BASELINE configs[3])", kernels="swc_bzip2_stage1/2/3_kernel"),
-    "lzma2_256k": dict(codec="lzma2", kind="lzma2", n_distinct=256, tile=40, unit=262144,
-                       desc="10240 x 256 KiB raw-LZMA2 units (BASELINE configs[4] shape)", kernels="swc_lzma_kernel"),
+                   kernels="swc_lz4_parse_kernel + swc_lz4_resolve_kernel", steps=3),
+    "bzip2_900k": dict(codec="bzip2_block", kind="bzip2", n_distinct=32, n_units=10240, unit=899000,
+                       desc="10240 x 900 kB bzip2 blocks (BASELINE configs[3])", kernels="swc_bzip2_stage1/2 + walk/expand/crc kernels", steps=2),
+    "lzma2_256k": dict(codec="lzma2", kind="lzma2", n_distinct=128, n_units=32768, unit=262144,
+                       desc="32768 x 256 KiB raw-LZMA2 units (BASELINE configs[4])", kernels="swc_lzma_kernel", steps=2),
 }
 
 
@@ -50,33 +56,40 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--workload", default="deflate64k", choices=sorted(WORKLOADS))
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"])
     ap.add_argument("--scale", type=float, default=1.0, help="shrink the batch (debug only; <1 is not a valid headline run)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--no-per-codec", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--tuning", action="append", default=[], help="key=value for swc_set_tuning (comparison runs only)")
     return ap.parse_args()
 
 
-def make_batch(name, w, n_distinct, seed, device):
-    """Host-side block discovery for the bench corpus + the device-resident batch."""
+def make_batch(name, w, n_distinct, seed, device, select):
+    """Host-side block discovery for the bench corpus + the device-resident batch of the units select = (lo, hi) of the
+    tiled unit list (unit i of the list is distinct unit i % n_distinct at its own device address)."""
     from swcompression_amd import corpus
     from swcompression_amd.batch import DeviceBatch
     units, plains = corpus.build_units(w["kind"], n_distinct, w["unit"], seed=seed)
+    trailers = None
+    kw = {}
     if name == "deflate64k":
         raw = [u[10:-8] for u in units]  # corpus.gzip_member: fixed 10-byte header, 8-byte trailer (CRC-32, ISIZE)
-        b = DeviceBatch("deflate", raw, [w["unit"]] * n_distinct, tile=w["tile"], device=device)
+        trailers = [u[-8:] for u in units]
+        caps = [w["unit"]] * n_distinct
     elif name == "lz4_4m":
         raw = units
-        b = DeviceBatch("lz4_block", raw, [w["unit"]] * n_distinct, tile=w["tile"], device=device)
+        caps = [w["unit"]] * n_distinct
     elif name == "bzip2_900k":
         raw = units  # whole one-block streams: "BZh9" (32 bits) + block magic (48) + block CRC (32) => body at bit 112
-        b = DeviceBatch("bzip2_block", raw, [w["unit"] + 64] * n_distinct, extra=[112] * n_distinct,
-                        dict_values=[int.from_bytes(s[10:14], "big") for s in raw], tile=w["tile"], device=device)
+        caps = [w["unit"] + 64] * n_distinct
+        kw = dict(extra=[112] * n_distinct, dict_values=[int.from_bytes(s[10:14], "big") for s in raw])
     else:
         raw = units
-        db = corpus.lzma2_dict_byte(1 << 20)
-        b = DeviceBatch("lzma2", raw, [w["unit"]] * n_distinct, aux=[db] * n_distinct, tile=w["tile"], device=device)
-    return b, raw, plains
+        caps = [w["unit"]] * n_distinct
+        kw = dict(aux=[corpus.lzma2_dict_byte(1 << 20)] * n_distinct)
+    b = DeviceBatch(w["codec"], raw, caps, device=device, select=select, **kw)
+    return b, raw, plains, trailers
 
 
 def cpu_baseline(name, raw, plains, seconds):
@@ -100,6 +113,8 @@ def cpu_baseline(name, raw, plains, seconds):
         i = done % len(raw)
         st, out = fn(raw[i])
         assert st == 0 and len(out) == len(plains[i])
+        if name == "deflate64k":   # GzipArchive.unarchive checks the member's CRC-32 (CheckSums.swift:21-28) inside the call
+            O.crc32(out)
         nbytes += len(out)
         cbytes += len(raw[i])
         done += 1
@@ -111,8 +126,9 @@ def cpu_baseline(name, raw, plains, seconds):
 
 
 def cpu_context(name, raw, plains, seconds):
-    """SURVEY.md 8(d) context lines next to the single-thread baseline: the oracle on all host cores (block-parallel, one
-    unit per task: oracle/rc_pool.c) and, for the gzip workload, the system zlib on one thread."""
+    """SURVEY.md 8(d) context lines next to the single-thread baseline: the oracle with one unit per task on the host
+    threads (oracle/rc_pool.c; the pool is bound by the allocator of the restatement well before 256 threads, so this is
+    a context figure, not a tuned all-core decoder) and, for the gzip workload, the system zlib on one thread."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     from swcompression_amd import corpus
@@ -123,17 +139,17 @@ def cpu_context(name, raw, plains, seconds):
     fn.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_double,
                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
     cores = os.cpu_count() or 1
-    n = len(raw)
-    ins = (C.c_char_p * n)(*[bytes(r) for r in raw])
-    lens = (C.c_size_t * n)(*[len(r) for r in raw])
+    n = min(len(raw), 512)
+    ins = (C.c_char_p * n)(*[bytes(r) for r in raw[:n]])
+    lens = (C.c_size_t * n)(*[len(r) for r in raw[:n]])
     ob, ib, un = C.c_uint64(), C.c_uint64(), C.c_uint64()
     dt = fn(codec, aux, ins, lens, n, cores, seconds, C.byref(ob), C.byref(ib), C.byref(un))
     if dt <= 0:
-        raise SystemExit("oracle pool failed")
-    ctx = {"oracle_all_cores": {"value": ob.value / dt / 2**30, "unit": "GiB/s decompressed", "cores": cores, "kind": "port",
-                                "compressed_MBps": ib.value / dt / 1e6,
-                                "sample": "%d unit decodes in %.1f s, one unit per task over %d threads (oracle/rc_pool.c)"
-                                          % (un.value, dt, cores)}}
+        return {}
+    ctx = {"oracle_one_unit_per_thread": {"value": ob.value / dt / 2**30, "unit": "GiB/s decompressed", "cores": cores, "kind": "port",
+                                          "compressed_MBps": ib.value / dt / 1e6,
+                                          "sample": "%d unit decodes in %.1f s, one unit per task over %d threads (oracle/rc_pool.c); "
+                                                    "allocator-bound, not a tuned all-core decoder" % (un.value, dt, cores)}}
     if name == "deflate64k":
         import zlib
         t0 = time.perf_counter()
@@ -169,7 +185,8 @@ def config1_latency(lib, raw, plains, reps=20):
 
 
 def committed_traffic(name):
-    """HBM bytes per launch from the rocprofv3 --pmc passes of this command (tools/pmc_bench.sh), if committed."""
+    """HBM bytes per launch and L2 hit rates per kernel from the rocprofv3 --pmc passes of this command
+    (tools/pmc_bench.sh), if committed."""
     best = None
     pdir = os.path.join(ROOT, "profiles")
     if os.path.isdir(pdir):
@@ -177,12 +194,152 @@ def committed_traffic(name):
             if f.endswith("_%s_traffic.json" % name):
                 best = os.path.join(pdir, f)
     if not best:
-        return None, None
+        return None, None, None
     try:
         d = json.load(open(best))
-        return d.get("hbm_bytes_per_launch"), os.path.relpath(best, ROOT)
+        hit = {}
+        for k, v in d.get("per_kernel_counters", {}).items():
+            h, m = v.get("TCC_HIT_sum", v.get("TCC_HIT")), v.get("TCC_MISS_sum", v.get("TCC_MISS"))
+            if h is not None and m is not None and h + m > 0:
+                hit[k.split("::")[-1]] = h / (h + m)
+        return d.get("hbm_bytes_per_launch"), os.path.relpath(best, ROOT), (hit or None)
     except Exception:
-        return None, None
+        return None, None, None
+
+
+def verify_all_units(name, batch, raw, plains, trailers):
+    """Every unit of the launch, on the device: a checksum of each job's output against the value computed on the host from
+    the plain payloads (gzip: the CRC-32 of the member's trailer, as GzipArchive.unarchive checks it)."""
+    import numpy as np
+    import zlib
+    r = batch.results()
+    ok = bool((r["status"] == 0).all())
+    if name == "deflate64k":
+        want = np.array([np.frombuffer(t[:4], dtype="<u4")[0] for t in trailers], dtype=np.uint32)
+        isize = np.array([np.frombuffer(t[4:], dtype="<u4")[0] for t in trailers], dtype=np.uint64)
+        ok = ok and bool((r["out_len"] == isize[batch.unit_index]).all())
+        got = batch.crc32()
+        how = "device CRC-32 of every member == its gzip trailer, out_len == ISIZE"
+    elif name == "lz4_4m":
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import _oracle as O
+        want = np.array([O.xxh32(p) for p in plains], dtype=np.uint64)
+        got = batch.checksum("xxh32")
+        how = "device XXH32 of every block == XXH32 of its payload"
+    else:
+        want = np.array([zlib.crc32(p) & 0xFFFFFFFF for p in plains], dtype=np.uint32)
+        got = batch.crc32()
+        how = "device CRC-32 of every unit == CRC-32 of its payload"
+    ok = ok and bool((got == want[batch.unit_index]).all())
+    if not ok:
+        raise SystemExit("verification failed for workload %s" % name)
+    return {"units_verified": int(batch.n), "method": how}
+
+
+def run_workload(name, args, lib, torch, dist, world, rank, device, steps, warmup, with_cpu):
+    w = WORKLOADS[name]
+    n_distinct = max(8, int(w["n_distinct"] * args.scale))
+    n_total = w["n_units"] if args.scale == 1.0 else max(n_distinct, int(w["n_units"] * args.scale))
+    if args.scaling == "strong" and world > 1:
+        # ONE unit list for the whole job, cut into contiguous ranges balanced by sum(C + U)
+        from swcompression_amd import corpus, shard
+        seed = 2
+        units, pl = corpus.build_units(w["kind"], n_distinct, w["unit"], seed=seed)
+        costs = [len(units[i % n_distinct]) + len(pl[i % n_distinct]) for i in range(n_total)]
+        select = shard.balanced_ranges(costs, world)[rank]
+    else:
+        seed = 2 + 100003 * rank   # weak: every rank decodes its own, differently seeded, full batch
+        select = (0, n_total)
+    batch, raw, plains, trailers = make_batch(name, w, n_distinct, seed, device, select)
+    unit = w["unit"]
+    sum_u = int(sum(len(plains[i]) for i in batch.unit_index))
+    sum_c = int(sum(len(raw[i]) for i in batch.unit_index))
+    gzip_crc = name == "deflate64k"
+
+    def step():
+        batch.launch()
+        if gzip_crc:
+            batch.crc32_async()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(warmup):
+        step()
+    barrier()
+    r = batch.results()
+    if not (r["status"] == 0).all():
+        raise SystemExit("decode failed: statuses %s" % sorted(set(r["status"].tolist())))
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    barrier()
+    t0 = time.perf_counter()
+    for s, e in ev:
+        s.record()
+        step()
+        e.record()
+    barrier()
+    dt = time.perf_counter() - t0
+    launch_ms = [s.elapsed_time(e) for s, e in ev]
+
+    if world > 1:
+        tm = torch.tensor([dt], dtype=torch.float64, device=device)
+        ts = torch.tensor([float(sum_u), float(sum_c)], dtype=torch.float64, device=device)
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        dt_max, tot_u = float(tm[0].item()), float(ts[0].item())
+    else:
+        dt_max, tot_u = dt, float(sum_u)
+
+    # outside the timed region: per-kernel durations of more launches (HIP events inside the library, on the launch stream)
+    phases = None
+    if name == "deflate64k":
+        lib.swc_set_tuning(b"phase_timing", 1)
+        acc = [0.0, 0.0]
+        reps = 3
+        for _ in range(reps):
+            batch.launch(sync=True)
+            buf = (C.c_float * 4)()
+            if lib.swc_last_phase_ms(buf, 4) == 2:
+                acc[0] += buf[0] / reps
+                acc[1] += buf[1] / reps
+        lib.swc_set_tuning(b"phase_timing", 0)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            batch.crc32_async()
+        e1.record()
+        torch.cuda.synchronize()
+        phases = {"swc_inflate_sync_kernel_ms": acc[0], "swc_lz_resolve_kernel_ms": acc[1], "swc_crc32_kernel_ms": e0.elapsed_time(e1) / reps}
+
+    verify = verify_all_units(name, batch, raw, plains, trailers)
+
+    mean_ms = sum(launch_ms) / len(launch_ms)
+    achieved = (sum_c + sum_u) / (mean_ms * 1e-3) / 1e9
+    traffic, traffic_src, l2 = committed_traffic(name)
+    desc = w["desc"] if args.scale == 1.0 else w["desc"] + " (scaled x%g, not a headline run)" % args.scale
+    roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+            "traffic": traffic, "traffic_source": traffic_src, "l2_hit_rate": l2, "kernel": w["kernels"], "kernel_ms": mean_ms,
+            "algorithmic_bytes_per_launch": sum_c + sum_u}
+    if phases:
+        roof["per_kernel_ms"] = phases
+        dom = max(phases, key=phases.get)
+        roof["dominant_kernel"] = dom[:-3]
+        if phases[dom] > 0:
+            roof["dominant_kernel_achieved_GBps"] = (sum_c + sum_u) / (phases[dom] * 1e-3) / 1e9
+            roof["dominant_kernel_frac"] = roof["dominant_kernel_achieved_GBps"] / HBM_PEAK_GBS
+        roof["ms_decode_only"] = phases["swc_inflate_sync_kernel_ms"] + phases["swc_lz_resolve_kernel_ms"]
+    res = {"value": tot_u * steps / dt_max / 2**30, "unit": "GiB/s", "steps": steps, "warmup": warmup, "ms_per_step": dt_max / steps * 1e3,
+           "config": {"workload": desc, "codec": w["codec"], "units_per_gpu": int(batch.n), "unit_bytes": unit,
+                      "compressed_bytes_per_gpu": sum_c, "decompressed_bytes_per_gpu": sum_u,
+                      "payload": "P-text (Zipf pseudo-words), system encoder (zlib 6 / liblz4 / bz2 9 / xz 6)",
+                      "parallelism": "%d x independent shards (%s scaling)" % (world, args.scaling)},
+           "roofline": roof, "verify": verify}
+    if with_cpu and rank == 0:
+        res["cpu_baseline"] = cpu_baseline(name, raw, plains, args.cpu_seconds)
+    return res, batch, raw, plains
 
 
 def main():
@@ -207,113 +364,32 @@ def main():
         k, v = kv.split("=")
         if lib.swc_set_tuning(k.encode(), int(v)) != 0:
             raise SystemExit("unknown tuning " + kv)
-    w = WORKLOADS[args.workload]
-    n_distinct = max(8, int(w["n_distinct"] * args.scale))
-    # every rank decodes its own, differently seeded, batch: independent units, no exchange step
-    batch, raw, plains = make_batch(args.workload, w, n_distinct, 2 + 100003 * rank, device)
-    unit = w["unit"]
-    sum_u = sum(len(p) for p in plains) * w["tile"]
-    sum_c = sum(len(r) for r in raw) * w["tile"]
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    for _ in range(args.warmup):
-        batch.launch()
-    barrier()
-    r = batch.results()
-    if not ((r["status"] == 0).all() and (r["out_len"] == unit).all()):
-        raise SystemExit("decode failed: statuses %s" % sorted(set(r["status"].tolist())))
-
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    barrier()
-    t0 = time.perf_counter()
-    for s, e in ev:
-        s.record()
-        batch.launch()
-        e.record()
-    barrier()
-    dt = time.perf_counter() - t0
-    launch_ms = [s.elapsed_time(e) for s, e in ev]
-
-    t = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt_max = float(t.item())
-
-    # outside the timed region: per-kernel durations of one more launch (HIP events inside the library, on the launch stream)
-    phases = None
-    if args.workload == "deflate64k":
-        lib.swc_set_tuning(b"phase_timing", 1)
-        acc = [0.0, 0.0]
-        reps = 3
-        for _ in range(reps):
-            batch.launch(sync=True)
-            buf = (C.c_float * 4)()
-            if lib.swc_last_phase_ms(buf, 4) == 2:
-                acc[0] += buf[0] / reps
-                acc[1] += buf[1] / reps
-        lib.swc_set_tuning(b"phase_timing", 0)
-        phases = {"swc_inflate_kernel_ms": acc[0], "swc_lz_resolve_kernel_ms": acc[1]}
-
-    # parity checks outside the timed region: one tile against the plain payloads, and (gzip workload) EVERY member
-    # against the CRC-32 of its gzip trailer, computed on the device (swc_batch_crc32)
-    crc_check = None
+    with_cpu = world == 1 and not args.no_cpu_baseline
+    head, batch, raw, plains = run_workload(args.workload, args, lib, torch, dist, world, rank, device, args.steps, args.warmup, with_cpu)
+    line = None
     if rank == 0:
-        for i in range(0, n_distinct, max(1, n_distinct // 16)):
-            assert batch.output(i, unit) == plains[i], "bit-exactness violated on unit %d" % i
-        if args.workload == "deflate64k":
-            import numpy as np
-            from swcompression_amd import corpus
-            units, _ = corpus.build_units(w["kind"], n_distinct, w["unit"], seed=2 + 100003 * rank)
-            want = np.tile(np.array([np.frombuffer(u[-8:-4], dtype="<u4")[0] for u in units], dtype=np.uint32), w["tile"])
-            batch.crc32()
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
-            got = batch.crc32()
-            e1.record()
-            torch.cuda.synchronize()
-            assert (got == want).all(), "device CRC-32 differs from the gzip trailers"
-            ms = e0.elapsed_time(e1)
-            crc_check = {"members_verified": int(batch.n), "kernel": "swc_crc32_kernel", "ms_incl_readback": ms,
-                         "GBps": sum_u / (ms * 1e-3) / 1e9}
-
-    if rank == 0:
-        total_u = sum_u * world * args.steps
-        mean_ms = sum(launch_ms) / len(launch_ms)
-        achieved = (sum_c + sum_u) / (mean_ms * 1e-3) / 1e9
-        traffic, traffic_src = committed_traffic(args.workload)
-        desc = w["desc"] if args.scale == 1.0 else w["desc"] + " (scaled x%g, not a headline run)" % args.scale
-        roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": w["kernels"], "kernel_ms": mean_ms, "algorithmic_bytes_per_launch": sum_c + sum_u}
-        if phases:
-            roof["per_kernel_ms"] = phases
-            dom = max(phases, key=phases.get)
-            roof["dominant_kernel"] = dom[:-3]
-            if phases[dom] > 0:
-                roof["dominant_kernel_achieved_GBps"] = (sum_c + sum_u) / (phases[dom] * 1e-3) / 1e9
-        line = {
-            "metric": "decompressed GiB/s", "value": total_u / dt_max / 2**30, "unit": "GiB/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt_max / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
-            "config": {"workload": desc, "codec": w["codec"], "units_per_gpu": batch.n, "unit_bytes": unit,
-                       "compressed_bytes_per_gpu": sum_c, "decompressed_bytes_per_gpu": sum_u,
-                       "payload": "P-text (Zipf pseudo-words), system encoder (zlib 6 / liblz4 / bz2 9 / xz 6)",
-                       "parallelism": "%d x independent shards" % world},
-            "roofline": roof,
-        }
-        if crc_check:
-            line["crc32_check"] = crc_check
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args.workload, raw, plains, args.cpu_seconds)
-            line["cpu_context"] = cpu_context(args.workload, raw, plains, min(args.cpu_seconds, 5.0))
-        if world == 1 and args.workload == "deflate64k" and not args.no_cpu_baseline:
-            # (skipped together with the CPU legs: the profiling commands of tools/gpu_round.sh want nothing but the
-            # batch launches in their kernel statistics)
+        line = {"metric": "decompressed GiB/s", "value": head["value"], "unit": "GiB/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": head["ms_per_step"], "higher_is_better": True, "scaling": args.scaling,
+                "vs_baseline": None, "dtype": "u8", "data": "synthetic", "config": head["config"], "roofline": head["roofline"],
+                "verify": head["verify"]}
+        if "cpu_baseline" in head:
+            line["cpu_baseline"] = head["cpu_baseline"]
+            line["cpu_context"] = cpu_context(args.workload, raw, plains, min(args.cpu_seconds, 4.0))
+        if with_cpu and args.workload == "deflate64k":
+            # (skipped together with the CPU legs: profiling commands want nothing but the batch launches in their statistics)
             line["config1_latency"] = config1_latency(lib, raw, plains)
+    del batch
+    torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and args.workload == "deflate64k" and not args.no_per_codec and args.scale == 1.0:
+        per = {}
+        for name in ("lz4_4m", "bzip2_900k", "lzma2_256k"):
+            res, b, _, _ = run_workload(name, args, lib, torch, dist, world, rank, device, WORKLOADS[name]["steps"], 1, with_cpu)
+            per[name] = res
+            del b
+            torch.cuda.empty_cache()
+        line["per_codec"] = per
+    if rank == 0:
         print(json.dumps(line))
     if world > 1:
         dist.destroy_process_group()

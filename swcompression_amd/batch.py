@@ -26,7 +26,10 @@ class DeviceBatch:
     addresses (inputs are replicated, every job owns its own output range), as SURVEY.md section 8d asks for:
     nothing is served from the 256 MiB Infinity Cache by accident."""
 
-    def __init__(self, codec, units, caps, aux=None, extra=None, dict_values=None, tile=1, device="cuda:0", replicate_inputs=True):
+    def __init__(self, codec, units, caps, aux=None, extra=None, dict_values=None, tile=1, device="cuda:0", replicate_inputs=True,
+                 select=None):
+        """select = (lo, hi): the jobs are the units lo..hi-1 of the TILED unit list (list entry i is distinct unit i % n_distinct
+        in replica i // n_distinct); default: the whole list of n_distinct * tile entries."""
         import torch
         self.torch = torch
         self.lib = _lib.load()
@@ -36,31 +39,36 @@ class DeviceBatch:
         self.device = torch.device(device)
         nd = len(units)
         self.n_distinct = nd
+        lo, hi = (0, nd * tile) if select is None else (int(select[0]), int(select[1]))
         self.tile = tile
-        self.n = nd * tile
+        self.n = hi - lo
         lens = np.array([len(u) for u in units], dtype=np.uint64)
         caps = np.array(caps, dtype=np.uint64)
         in_sz = np.array([_align(int(x)) for x in lens], dtype=np.uint64)
         out_sz = np.array([_align(int(x)) for x in caps], dtype=np.uint64)
         in_off = np.concatenate([[0], np.cumsum(in_sz)[:-1]]).astype(np.uint64)
-        out_off = np.concatenate([[0], np.cumsum(out_sz)[:-1]]).astype(np.uint64)
         in_round = int(in_sz.sum())
-        out_round = int(out_sz.sum())
         host = np.zeros(in_round + 16, dtype=np.uint8)
         for u, o in zip(units, in_off):
             host[int(o):int(o) + len(u)] = np.frombuffer(u, dtype=np.uint8)
-        in_tiles = tile if replicate_inputs else 1
+        idx = np.arange(lo, hi, dtype=np.int64)
+        k_idx = (idx % nd).astype(np.int64) if nd else idx
+        t_idx = (idx // nd).astype(np.uint64) if nd else idx.astype(np.uint64)
+        t0 = int(t_idx.min()) if self.n else 0
+        t1 = int(t_idx.max()) if self.n else 0
+        in_tiles = (t1 - t0 + 1) if replicate_inputs else 1
         self.d_in = torch.empty(in_round * in_tiles + 16, dtype=torch.uint8, device=self.device)
         h = torch.from_numpy(host[:in_round])
         for t in range(in_tiles):
             self.d_in[t * in_round:(t + 1) * in_round].copy_(h)
-        self.d_out = torch.empty(out_round * tile + 16, dtype=torch.uint8, device=self.device)
+        out_each = out_sz[k_idx]
+        out_off = np.concatenate([[0], np.cumsum(out_each)[:-1]]).astype(np.uint64) if self.n else np.zeros(0, dtype=np.uint64)
+        out_total = int(out_each.sum())
+        self.d_out = torch.empty(out_total + 16, dtype=torch.uint8, device=self.device)
         jobs = np.zeros(self.n, dtype=JOB_DTYPE)
-        t_idx = np.repeat(np.arange(tile, dtype=np.uint64), nd)
-        k_idx = np.tile(np.arange(nd), tile)
-        jobs["in"] = self.d_in.data_ptr() + (t_idx * np.uint64(in_round) if replicate_inputs else 0) + in_off[k_idx]
+        jobs["in"] = self.d_in.data_ptr() + ((t_idx - np.uint64(t0)) * np.uint64(in_round) if replicate_inputs else 0) + in_off[k_idx]
         jobs["in_len"] = lens[k_idx]
-        jobs["out"] = self.d_out.data_ptr() + t_idx * np.uint64(out_round) + out_off[k_idx]
+        jobs["out"] = self.d_out.data_ptr() + out_off
         jobs["out_cap"] = caps[k_idx]
         jobs["status"] = 902
         if aux is not None:
@@ -69,7 +77,8 @@ class DeviceBatch:
             jobs["dict_len"] = np.array(extra, dtype=np.uint64)[k_idx]
         if dict_values is not None:  # integer carried in the `dict` field (LZMA: dictionary size, BZip2: stored block CRC)
             jobs["dict"] = np.array(dict_values, dtype=np.uint64)[k_idx]
-        self._out_off = (t_idx * np.uint64(out_round) + out_off[k_idx]).astype(np.int64)
+        self._out_off = out_off.astype(np.int64)
+        self.unit_index = k_idx            # which distinct unit every job decodes
         self.caps = caps[k_idx]
         self.in_lens = lens[k_idx]
         self._jobs_host = jobs
@@ -77,6 +86,7 @@ class DeviceBatch:
         ws = self.lib.swc_batch_workspace_bytes(self.codec, self.n, int(caps.max()) if nd else 0)
         self.d_ws = torch.empty(max(ws, 16), dtype=torch.uint8, device=self.device)
         self.ws_bytes = ws
+        self._crc_buf = None
         torch.cuda.synchronize(self.device)
 
     @property
@@ -102,6 +112,18 @@ class DeviceBatch:
         if st:
             raise RuntimeError("swc_batch_crc32 failed with status %d" % st)
         return d.cpu().numpy().view(np.uint32)
+
+    def crc32_async(self):
+        """swc_batch_crc32 on the current stream, no synchronisation, result left on the device (bench.py: the CRC-32 of
+        every gzip member is part of the timed step)."""
+        torch = self.torch
+        if self._crc_buf is None:
+            self._crc_buf = torch.empty(self.n, dtype=torch.int32, device=self.device)
+        opts = _lib.SwcBatchOpts(self.device.index if self.device.index is not None else -1,
+                                 torch.cuda.current_stream(self.device).cuda_stream, 0, 0)
+        st = self.lib.swc_batch_crc32(self.d_jobs.data_ptr(), self.n, self._crc_buf.data_ptr(), C.byref(opts))
+        if st:
+            raise RuntimeError("swc_batch_crc32 failed with status %d" % st)
 
     CHECKSUMS = {"crc32": 1, "adler32": 2, "crc64": 3, "bzip2crc32": 4, "xxh32": 5}
 

@@ -267,8 +267,12 @@ def build_units(kind, n_distinct, unit_size, payload="text", seed=2, cache=True)
     gen = PAYLOADS[payload]
     enc = {"deflate": deflate_raw, "gzip": gzip_member, "lz4_block": lz4_block, "bzip2": bzip2_stream,
            "lzma2": lzma2_raw}[kind]
-    plains = [gen(unit_size, seed + i) for i in range(n_distinct)]
-    units = [enc(p) for p in plains]
+    # the encoders (zlib / bz2 / lzma / liblz4 through ctypes) release the GIL: a thread pool uses the host cores
+    from concurrent.futures import ThreadPoolExecutor
+    workers = max(1, min(32, (os.cpu_count() or 1)))
+    with ThreadPoolExecutor(workers) as ex:
+        plains = list(ex.map(lambda i: gen(unit_size, seed + i), range(n_distinct)))
+        units = list(ex.map(enc, plains))
     if cache:
         uo = np.cumsum([0] + [len(u) for u in units])
         po = np.cumsum([0] + [len(p) for p in plains])

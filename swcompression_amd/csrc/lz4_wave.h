@@ -343,9 +343,6 @@ struct Parser {
     SWC_D static void parse_chunk(const uint8_t* stage, uint32_t stage_len, uint32_t start, uint32_t chunk_end, uint32_t tail_limit, gptr lit_dst,
                                   SWC_AS_GLOBAL uint32_t* rec_dst, uint64_t out_pos0, ChunkOut& r) {
         uint32_t ip = start, nlit = 0, nrec = 0, nout = 0, nseq = 0, lms = 0, flags = 0;
-        uint64_t acc = 0;            // emit: literal bytes not stored yet (accn of them), a record waiting for its partner
-        uint32_t accn = 0, rpend = 0;
-        bool rpend_has = false;
         const uint32_t safe = stage_len >= 8 ? stage_len - 8u : 0u;   // a read of four bytes at or below this stays inside the staged window
         while (ip < chunk_end) {
             if (ip > safe) { flags |= kLzStop; break; }
@@ -371,29 +368,12 @@ struct Parser {
             const uint32_t big = lit > lzr::kLitRunMax ? 1u : 0u;
             if (MODE == 1) {
                 if ((uint64_t)offset > out_pos0 + nout + lit) { flags |= kLzTrap; break; }   // :382 offset <= bytes produced
-                // literals: up to four bytes per step into an 8-byte accumulator that leaves with ONE store when it is full
-                // (a store per sequence and lane is what bounds this pass: 64 lanes, 64 cache lines per instruction)
-                for (uint32_t i = 0; i < lit; i += 4) {
-                    const uint32_t k = lit - i < 4 ? lit - i : 4u;
-                    const uint64_t v = rd32(stage, lit_at + i) & (k == 4 ? 0xFFFFFFFFu : (1u << (8 * k)) - 1u);
-                    acc |= v << (8 * accn);
-                    accn += k;
-                    if (accn >= 8) {
-                        store_u64(lit_dst, acc);
-                        lit_dst += 8;
-                        accn -= 8;
-                        acc = accn ? v >> (8 * (k - accn)) : 0;
-                    }
-                }
-                // records: two per store
-                if (big) {
-                    const uint32_t rl = lzr::make_lits(lit);
-                    if (rpend_has) { store_u64((gptr)rec_dst, (uint64_t)rpend | ((uint64_t)rl << 32)); rec_dst += 2; rpend_has = false; }
-                    else { rpend = rl; rpend_has = true; }
-                }
-                const uint32_t rm = lzr::make_match(big ? 0u : lit, mlen, offset);
-                if (rpend_has) { store_u64((gptr)rec_dst, (uint64_t)rpend | ((uint64_t)rm << 32)); rec_dst += 2; rpend_has = false; }
-                else { rpend = rm; rpend_has = true; }
+                uint32_t i = 0;
+                for (; i + 4 <= lit; i += 4) store_u32(lit_dst + i, rd32(stage, lit_at + i));
+                for (; i < lit; i++) lit_dst[i] = stage[stage_byte(lit_at + i)];
+                lit_dst += lit;
+                if (big) *rec_dst++ = lzr::make_lits(lit);
+                *rec_dst++ = lzr::make_match(big ? 0u : lit, mlen, offset);
             }
             nrec += 1u + big;
             nlit += lit;
@@ -401,10 +381,6 @@ struct Parser {
             nout += lit + mlen;
             nseq++;
             ip = pn;
-        }
-        if (MODE == 1) {
-            for (uint32_t i = 0; i < accn; i++) lit_dst[i] = (uint8_t)(acc >> (8 * i));
-            if (rpend_has) *rec_dst = rpend;
         }
         r.end = ip; r.nlit = nlit; r.nrec = nrec; r.nout = nout; r.nseq = nseq; r.lms = lms; r.flags = flags;
     }
