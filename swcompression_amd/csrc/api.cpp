@@ -40,10 +40,10 @@ bool device_ready() {
     return g_dev_ok;
 }
 
-static hipError_t launch_codec(int codec, Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {
+static hipError_t launch_codec(int codec, Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream, const uint64_t* ws_off = nullptr) {
     switch (codec) {
-        case SWC_CODEC_DEFLATE: return launch_inflate(jobs, n, ws, ws_bytes, stream);
-        case SWC_CODEC_LZ4_BLOCK: return launch_lz4(jobs, n, ws, ws_bytes, stream);
+        case SWC_CODEC_DEFLATE: return launch_inflate(jobs, n, ws, ws_bytes, stream, ws_off);
+        case SWC_CODEC_LZ4_BLOCK: return launch_lz4(jobs, n, ws, ws_bytes, stream, ws_off);
         case SWC_CODEC_LZMA2: return launch_lzma(true, jobs, n, ws_bytes >= n * lzma_spill_bytes_per_job() ? ws : nullptr, stream);
         case SWC_CODEC_LZMA: return launch_lzma(false, jobs, n, ws_bytes >= n * lzma_spill_bytes_per_job() ? ws : nullptr, stream);
         case SWC_CODEC_BZIP2_BLOCK: return launch_bzip2(jobs, n, ws, ws_bytes, stream);
@@ -66,43 +66,88 @@ static size_t default_cap(int codec, const HostUnit& u) {
 static std::atomic<long long> g_stats[3];
 void stat_add(int which, long long v) { if (which >= 0 && which < 3) g_stats[which] += v; }
 
+// Two page-locked staging buffers per calling thread (0: host -> device, 1: device -> host), grown on demand, released
+// when the thread ends.
+uint8_t* pinned_stage(int which, size_t n) {
+    struct Buf {
+        void* p = nullptr;
+        size_t cap = 0;
+        ~Buf() { if (p) (void)hipHostFree(p); }
+    };
+    static thread_local Buf bufs[2];
+    Buf& b = bufs[which & 1];
+    if (b.cap < n) {
+        if (b.p) { (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+        size_t want = std::max<size_t>(n + n / 4, (size_t)1 << 20);
+        if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; return nullptr; }
+        b.cap = want;
+    }
+    return static_cast<uint8_t*>(b.p);
+}
+
 int run_units(int codec, std::vector<HostUnit>& units) {
     if (!device_ready()) return SWC_E_DEVICE;
     const size_t n = units.size();
     if (n == 0) return SWC_OK;
+    hipStream_t stream = hipStreamPerThread;   // every calling thread stages, launches and waits on its own stream
     std::vector<size_t> pending(n);
     for (size_t i = 0; i < n; i++) pending[i] = i;
     std::vector<size_t> cap(n);
     for (size_t i = 0; i < n; i++) cap[i] = default_cap(codec, units[i]);
 
     bool want_ws = codec == SWC_CODEC_BZIP2_BLOCK || codec == SWC_CODEC_DEFLATE || codec == SWC_CODEC_LZ4_BLOCK;  // LZMA: only after a unit reported SWC_E_NEED_WORKSPACE
+    const bool per_job_ws = codec == SWC_CODEC_DEFLATE || codec == SWC_CODEC_LZ4_BLOCK;   // areas sized from each unit's own capacity
     for (int round = 0; round < 12 && !pending.empty(); round++) {
         const size_t m = pending.size();
         std::vector<size_t> in_off(m), out_off(m), dict_off(m);
-        std::vector<char> in_shared(m, 0);
-        std::map<std::pair<const uint8_t*, size_t>, size_t> seen;  // units that share one input buffer (bzip2 blocks of a stream) are staged once
+        // Host buffers are staged once: units that share a buffer (the bzip2 blocks of a stream) or that are sub-ranges of
+        // one `base` buffer (the entries of a container, the members of a file) address the one staged copy.
+        struct Staged { const uint8_t* p; size_t len, off; };
+        std::vector<Staged> staged;
+        std::map<std::pair<const uint8_t*, size_t>, size_t> seen;
         size_t in_total = 0, out_total = 0;
         for (size_t k = 0; k < m; k++) {
             const HostUnit& u = units[pending[k]];
-            auto key = std::make_pair(u.in, u.in_len);
+            const bool sub = u.base && u.in >= u.base && u.in + u.in_len <= u.base + u.base_len;
+            const uint8_t* b = sub ? u.base : u.in;
+            const size_t bl = sub ? u.base_len : u.in_len;
+            auto key = std::make_pair(b, bl);
             auto it = seen.find(key);
-            if (it != seen.end()) { in_off[k] = it->second; in_shared[k] = 1; }
-            else { in_off[k] = in_total; seen[key] = in_total; in_total += (u.in_len + 15) & ~(size_t)15; }
+            size_t at;
+            if (it != seen.end()) at = it->second;
+            else { at = in_total; seen[key] = at; staged.push_back(Staged{b, bl, at}); in_total += (bl + 15) & ~(size_t)15; }
+            in_off[k] = at + (sub ? (size_t)(u.in - u.base) : 0);
             dict_off[k] = in_total;
             if (u.dict) in_total += (u.dict_len + 15) & ~(size_t)15;
             out_off[k] = out_total;
             out_total += (cap[pending[k]] + 15) & ~(size_t)15;
         }
-        size_t ws_bytes = want_ws ? swc_batch_workspace_bytes(codec, m, *std::max_element(cap.begin(), cap.end())) : 0;
-        DevBuf d_in(in_total + 16), d_out(out_total + 16), d_jobs(m * sizeof(Job)), d_ws(ws_bytes);
+        // workspace: per-job areas (prefix-summed) where the codec sizes them from the capacity, else one size for all
+        std::vector<uint64_t> ws_off;
+        size_t ws_bytes = 0;
+        if (want_ws && per_job_ws) {
+            ws_off.resize(m + 1);
+            for (size_t k = 0; k < m; k++) { ws_off[k] = ws_bytes; ws_bytes += inflate_ws_bytes_per_job(cap[pending[k]]); }
+            ws_off[m] = ws_bytes;
+        } else if (want_ws) {
+            size_t mx = 0;
+            for (size_t k = 0; k < m; k++) mx = std::max(mx, cap[pending[k]]);
+            ws_bytes = swc_batch_workspace_bytes(codec, m, mx);
+        }
+        const size_t jobs_bytes = (m * sizeof(Job) + 15) & ~(size_t)15, off_bytes = ws_off.size() * sizeof(uint64_t);
+        DevBuf d_in(in_total + 16), d_out(out_total + 16), d_jobs(jobs_bytes + off_bytes), d_ws(ws_bytes);
         if (!d_in.ok() || !d_out.ok() || !d_jobs.ok() || !d_ws.ok()) return SWC_E_DEVICE;
 
-        std::vector<uint8_t> stage(in_total + 16);
-        std::vector<Job> jobs(m);
+        // host -> device: inputs, then the job records and the workspace offsets, through the thread's pinned buffer
+        const size_t up_bytes = in_total + 16 + jobs_bytes + off_bytes;
+        std::vector<uint8_t> up_fallback;
+        uint8_t* up = pinned_stage(0, up_bytes);
+        if (!up) { up_fallback.resize(up_bytes); up = up_fallback.data(); }
+        for (const Staged& st : staged) if (st.len) memcpy(up + st.off, st.p, st.len);
+        Job* jobs = reinterpret_cast<Job*>(up + in_total + 16);
         for (size_t k = 0; k < m; k++) {
             const HostUnit& u = units[pending[k]];
-            if (u.in_len && !in_shared[k]) memcpy(stage.data() + in_off[k], u.in, u.in_len);
-            if (u.dict && u.dict_len) memcpy(stage.data() + dict_off[k], u.dict, u.dict_len);
+            if (u.dict && u.dict_len) memcpy(up + dict_off[k], u.dict, u.dict_len);
             Job& j = jobs[k];
             j.in = d_in.u8() + in_off[k];
             j.in_len = u.in_len;
@@ -115,20 +160,26 @@ int run_units(int codec, std::vector<HostUnit>& units) {
             j.dict = u.dict ? d_in.u8() + dict_off[k] : reinterpret_cast<const uint8_t*>((uintptr_t)u.dict_value);
             j.dict_len = u.dict ? u.dict_len : u.extra;
         }
-        if (hipMemcpy(d_in.ptr(), stage.data(), in_total, hipMemcpyHostToDevice) != hipSuccess) return SWC_E_DEVICE;
-        if (hipMemcpy(d_jobs.ptr(), jobs.data(), m * sizeof(Job), hipMemcpyHostToDevice) != hipSuccess) return SWC_E_DEVICE;
-        if (launch_codec(codec, static_cast<Job*>(d_jobs.ptr()), m, d_ws.ptr(), ws_bytes, nullptr) != hipSuccess) return SWC_E_DEVICE;
+        if (off_bytes) memcpy(up + in_total + 16 + jobs_bytes, ws_off.data(), off_bytes);
+        if (hipMemcpyAsync(d_in.ptr(), up, in_total, hipMemcpyHostToDevice, stream) != hipSuccess) return SWC_E_DEVICE;
+        if (hipMemcpyAsync(d_jobs.ptr(), jobs, jobs_bytes + off_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return SWC_E_DEVICE;
+        const uint64_t* d_off = off_bytes ? reinterpret_cast<const uint64_t*>(d_jobs.u8() + jobs_bytes) : nullptr;
+        if (launch_codec(codec, static_cast<Job*>(d_jobs.ptr()), m, d_ws.ptr(), ws_bytes, stream, d_off) != hipSuccess) return SWC_E_DEVICE;
         stat_add(0, 1);
         stat_add(1, (long long)m);
-        if (hipDeviceSynchronize() != hipSuccess) return SWC_E_DEVICE;
-        if (hipMemcpy(jobs.data(), d_jobs.ptr(), m * sizeof(Job), hipMemcpyDeviceToHost) != hipSuccess) return SWC_E_DEVICE;
-        std::vector<uint8_t> out_stage(out_total + 16);
-        if (hipMemcpy(out_stage.data(), d_out.ptr(), out_total, hipMemcpyDeviceToHost) != hipSuccess) return SWC_E_DEVICE;
+        // device -> host: job records first (they say how much of every output exists), then the outputs
+        std::vector<Job> res(m);
+        if (hipMemcpyAsync(res.data(), d_jobs.ptr(), m * sizeof(Job), hipMemcpyDeviceToHost, stream) != hipSuccess) return SWC_E_DEVICE;
+        std::vector<uint8_t> down_fallback;
+        uint8_t* down = pinned_stage(1, out_total + 16);
+        if (!down) { down_fallback.resize(out_total + 16); down = down_fallback.data(); }
+        if (hipMemcpyAsync(down, d_out.ptr(), out_total, hipMemcpyDeviceToHost, stream) != hipSuccess) return SWC_E_DEVICE;
+        if (hipStreamSynchronize(stream) != hipSuccess) return SWC_E_DEVICE;
 
         std::vector<size_t> next;
         for (size_t k = 0; k < m; k++) {
             HostUnit& u = units[pending[k]];
-            const Job& j = jobs[k];
+            const Job& j = res[k];
             if (j.status == SWC_E_NEED_WORKSPACE && !want_ws) {
                 next.push_back(pending[k]);
                 continue;
@@ -148,11 +199,11 @@ int run_units(int codec, std::vector<HostUnit>& units) {
             u.aux_out = j.aux;
             u.in_consumed = (size_t)j.in_consumed;
             size_t produced = (size_t)std::min<uint64_t>(j.out_len, j.out_cap);
-            u.out.assign(out_stage.data() + out_off[k], out_stage.data() + out_off[k] + produced);
+            u.out.assign(down + out_off[k], down + out_off[k] + produced);
         }
         if (!next.empty() && !want_ws)
             for (size_t k = 0; k < m; k++)
-                if (jobs[k].status == SWC_E_NEED_WORKSPACE) { want_ws = true; break; }
+                if (res[k].status == SWC_E_NEED_WORKSPACE) { want_ws = true; break; }
         pending.swap(next);
     }
     for (size_t i : pending) units[i].status = SWC_E_CAPACITY;
@@ -165,7 +216,7 @@ using namespace swc;
 
 extern "C" {
 
-int swc_set_tuning(const char* key, int value) {
+int swc_set_tuning(const char* key, int value) try {
     if (!key) return SWC_E_INVALID_ARGUMENT;
     if (!strcmp(key, "resolve_threads") && (value == 64 || value == 128 || value == 256 || value == 512 || value == 1024)) { set_resolve_threads(value); return SWC_OK; }
     if (!strcmp(key, "inflate_wave_max_jobs") && value >= 0) { set_inflate_wave_max_jobs(value); return SWC_OK; }
@@ -178,6 +229,8 @@ int swc_set_tuning(const char* key, int value) {
     if (!strcmp(key, "resolve_debug") && value >= 0 && value < 32) { set_resolve_debug(value); return SWC_OK; }
 #endif
     return SWC_E_INVALID_ARGUMENT;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    return SWC_E_DEVICE;
 }
 
 // Profile builds (-DSWC_PROFILE) only: a device buffer of 32 x u64 per job that the Deflate kernels fill with cycle counts.
@@ -210,7 +263,7 @@ size_t swc_batch_workspace_bytes(int codec, size_t n_jobs, uint64_t max_out_cap)
 }
 
 int swc_batch_decompress_ws(int codec, swc_job* jobs, size_t n, void* workspace, size_t workspace_bytes,
-                            const swc_batch_opts* opts) {
+                            const swc_batch_opts* opts) try {
     if (!device_ready()) return SWC_E_DEVICE;
     if (n && !jobs) return SWC_E_INVALID_ARGUMENT;
     if (opts && opts->device >= 0 && hipSetDevice(opts->device) != hipSuccess) return SWC_E_DEVICE;
@@ -220,9 +273,11 @@ int swc_batch_decompress_ws(int codec, swc_job* jobs, size_t n, void* workspace,
     if (e != hipSuccess) return SWC_E_DEVICE;
     if (opts && opts->synchronize && hipStreamSynchronize(stream) != hipSuccess) return SWC_E_DEVICE;
     return SWC_OK;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    return SWC_E_DEVICE;
 }
 
-int swc_batch_crc32(const swc_job* jobs, size_t n, uint32_t* crcs, const swc_batch_opts* opts) {
+int swc_batch_crc32(const swc_job* jobs, size_t n, uint32_t* crcs, const swc_batch_opts* opts) try {
     if (!device_ready()) return SWC_E_DEVICE;
     if (n && (!jobs || !crcs)) return SWC_E_INVALID_ARGUMENT;
     if (opts && opts->device >= 0 && hipSetDevice(opts->device) != hipSuccess) return SWC_E_DEVICE;
@@ -230,9 +285,11 @@ int swc_batch_crc32(const swc_job* jobs, size_t n, uint32_t* crcs, const swc_bat
     if (launch_crc32(reinterpret_cast<const Job*>(jobs), n, crcs, stream) != hipSuccess) return SWC_E_DEVICE;
     if (opts && opts->synchronize && hipStreamSynchronize(stream) != hipSuccess) return SWC_E_DEVICE;
     return SWC_OK;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    return SWC_E_DEVICE;
 }
 
-int swc_batch_checksum(int kind, const swc_job* jobs, size_t n, uint64_t* sums, const swc_batch_opts* opts) {
+int swc_batch_checksum(int kind, const swc_job* jobs, size_t n, uint64_t* sums, const swc_batch_opts* opts) try {
     if (!device_ready()) return SWC_E_DEVICE;
     if (kind < SWC_SUM_CRC32 || kind > SWC_SUM_XXH32 || (n && (!jobs || !sums))) return SWC_E_INVALID_ARGUMENT;
     if (opts && opts->device >= 0 && hipSetDevice(opts->device) != hipSuccess) return SWC_E_DEVICE;
@@ -240,13 +297,15 @@ int swc_batch_checksum(int kind, const swc_job* jobs, size_t n, uint64_t* sums, 
     if (launch_checksum(kind, reinterpret_cast<const Job*>(jobs), n, sums, stream) != hipSuccess) return SWC_E_DEVICE;
     if (opts && opts->synchronize && hipStreamSynchronize(stream) != hipSuccess) return SWC_E_DEVICE;
     return SWC_OK;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    return SWC_E_DEVICE;
 }
 
-int swc_batch_decompress(int codec, swc_job* jobs, size_t n, const swc_batch_opts* opts) {
+int swc_batch_decompress(int codec, swc_job* jobs, size_t n, const swc_batch_opts* opts) try {
     if (codec == SWC_CODEC_BZIP2_BLOCK) return SWC_E_INVALID_ARGUMENT;  // needs the workspace: use swc_batch_decompress_ws
-    if (codec == SWC_CODEC_DEFLATE && n) {
-        // Deflate needs the match-record workspace; size it from the largest capacity in the batch and let the
-        // stream-ordered allocator own it for the duration of the launch.
+    if ((codec == SWC_CODEC_DEFLATE || codec == SWC_CODEC_LZ4_BLOCK) && n) {
+        // Deflate and LZ4 need the record / literal workspace: every job gets an area sized from ITS capacity (prefix sums,
+        // computed here from the job records) and the stream-ordered allocator owns it for the duration of the launch.
         if (!device_ready()) return SWC_E_DEVICE;
         if (!jobs) return SWC_E_INVALID_ARGUMENT;
         if (opts && opts->device >= 0 && hipSetDevice(opts->device) != hipSuccess) return SWC_E_DEVICE;
@@ -254,16 +313,25 @@ int swc_batch_decompress(int codec, swc_job* jobs, size_t n, const swc_batch_opt
         std::vector<swc_job> host(n);
         if (hipMemcpyAsync(host.data(), jobs, n * sizeof(swc_job), hipMemcpyDeviceToHost, stream) != hipSuccess) return SWC_E_DEVICE;
         if (hipStreamSynchronize(stream) != hipSuccess) return SWC_E_DEVICE;
-        uint64_t max_cap = 0;
-        for (size_t i = 0; i < n; i++) max_cap = std::max<uint64_t>(max_cap, host[i].out_cap);
-        size_t ws_bytes = swc_batch_workspace_bytes(codec, n, max_cap);
+        std::vector<uint64_t> off(n + 1);
+        uint64_t total = 0;
+        for (size_t i = 0; i < n; i++) { off[i] = total; total += inflate_ws_bytes_per_job(host[i].out_cap); }
+        off[n] = total;
         void* ws = nullptr;
-        if (hipMallocAsync(&ws, ws_bytes, stream) != hipSuccess) { (void)hipGetLastError(); return SWC_E_DEVICE; }
-        int st = swc_batch_decompress_ws(codec, jobs, n, ws, ws_bytes, opts);
+        const size_t off_bytes = (n + 1) * sizeof(uint64_t);
+        if (hipMallocAsync(&ws, total + off_bytes + 16, stream) != hipSuccess) { (void)hipGetLastError(); return SWC_E_DEVICE; }
+        uint8_t* d_off = static_cast<uint8_t*>(ws) + ((total + 15) & ~(uint64_t)15);
+        int st = SWC_OK;
+        if (hipMemcpyAsync(d_off, off.data(), off_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) st = SWC_E_DEVICE;
+        if (st == SWC_OK && hipStreamSynchronize(stream) != hipSuccess) st = SWC_E_DEVICE;   // (`off` lives on this stack frame)
+        if (st == SWC_OK && launch_codec(codec, reinterpret_cast<Job*>(jobs), n, ws, total, stream, reinterpret_cast<const uint64_t*>(d_off)) != hipSuccess) st = SWC_E_DEVICE;
         (void)hipFreeAsync(ws, stream);
+        if (st == SWC_OK && opts && opts->synchronize && hipStreamSynchronize(stream) != hipSuccess) st = SWC_E_DEVICE;
         return st;
     }
     return swc_batch_decompress_ws(codec, jobs, n, nullptr, 0, opts);
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    return SWC_E_DEVICE;
 }
 
 }  // extern "C"

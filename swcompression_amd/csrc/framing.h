@@ -6,6 +6,7 @@
 namespace swc {
 struct GzipHeaderInfo { uint32_t bgzf_bsize; };
 int run_one(int codec, HostUnit& u);
+int run_one_bounded(int codec, HostUnit& u, size_t bound);
 void give(const std::vector<uint8_t>& src, uint8_t** out, size_t* out_len);
 void give_empty(uint8_t** out, size_t* out_len);
 size_t* give_sizes(const std::vector<size_t>& v);

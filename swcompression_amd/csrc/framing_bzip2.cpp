@@ -177,7 +177,7 @@ using namespace swc;
 
 extern "C" {
 
-int swc_bzip2_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t* in_consumed) {
+int swc_bzip2_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t* in_consumed) try {
     if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
     std::map<uint64_t, Decoded> blocks;
     std::vector<uint8_t> res;
@@ -189,9 +189,12 @@ int swc_bzip2_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t
     if (in_consumed) *in_consumed = pos;
     give(res, out, out_len);
     return st;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    if (out && out_len) give_empty(out, out_len);
+    return SWC_E_DEVICE;
 }
 
-int swc_bzip2_multi_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_streams) {
+int swc_bzip2_multi_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_streams) try {
     if (!out || !out_len || !sizes || !n_streams || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
     std::map<uint64_t, Decoded> blocks;
     std::vector<uint8_t> all;
@@ -211,6 +214,11 @@ int swc_bzip2_multi_decompress(const uint8_t* in, size_t in_len, uint8_t** out, 
     *sizes = give_sizes(sz);
     *n_streams = sz.size();
     return st;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    if (out && out_len) give_empty(out, out_len);
+    if (sizes) *sizes = nullptr;
+    if (n_streams) *n_streams = 0;
+    return SWC_E_DEVICE;
 }
 
 }  // extern "C"

@@ -19,6 +19,20 @@ int run_one(int codec, HostUnit& u) {
     return st;
 }
 
+// run_one for a unit that is followed by unrelated data (the next members of a file, the next entries of a container):
+// first with only `bound` bytes of input staged; the result stands if the unit decoded cleanly and ended inside them,
+// anything else is decided by a second run over the whole tail -- so that a walk over M units stages O(file) bytes, not
+// M times the rest of the file, and the outcome is the one the reference (which reads on from one reader) would have.
+int run_one_bounded(int codec, HostUnit& u, size_t bound) {
+    if (u.in_len <= bound) return run_one(codec, u);
+    HostUnit t = u;
+    t.in_len = bound;
+    int st = run_one(codec, t);
+    if (st != SWC_OK) return st;
+    if (t.status == SWC_OK && t.in_consumed + 64 <= bound) { u = std::move(t); return SWC_OK; }
+    return run_one(codec, u);
+}
+
 void give(const std::vector<uint8_t>& src, uint8_t** out, size_t* out_len) {
     uint8_t* p = host_result(src.size());
     if (!src.empty()) memcpy(p, src.data(), src.size());
@@ -143,7 +157,7 @@ using namespace swc;
 
 extern "C" {
 
-int swc_deflate_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t* in_consumed) {
+int swc_deflate_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t* in_consumed) try {
     if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
     HostUnit u;
     u.in = in; u.in_len = in_len;
@@ -153,9 +167,12 @@ int swc_deflate_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size
     if (u.status) { give_empty(out, out_len); return u.status; }       // DeflateError cases carry no data
     give(u.out, out, out_len);
     return SWC_OK;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    if (out && out_len) give_empty(out, out_len);
+    return SWC_E_DEVICE;
 }
 
-int swc_gzip_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) {
+int swc_gzip_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) try {
     if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
     HostUnit u;
     int st = gzip_member_prepare(in, in_len, 0, u);
@@ -168,6 +185,9 @@ int swc_gzip_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* 
     if (st) { give_empty(out, out_len); return st; }
     give(u.out, out, out_len);                                         // wrongCRC carries the member (:44)
     return crc_error ? SWC_E_GZIP_WRONG_CRC : SWC_OK;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    if (out && out_len) give_empty(out, out_len);
+    return SWC_E_DEVICE;
 }
 
 // BGZF (and any multi-member gzip whose members carry the 'BC' extra field): BSIZE = member size - 1 locates every member
@@ -228,7 +248,7 @@ static bool bgzf_multi(const uint8_t* in, size_t in_len, std::vector<uint8_t>& a
     return true;
 }
 
-int swc_gzip_multi_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_members) {
+int swc_gzip_multi_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_members) try {
     if (!out || !out_len || !sizes || !n_members || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
     {
         std::vector<uint8_t> fast;
@@ -245,7 +265,7 @@ int swc_gzip_multi_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, si
     // (BGZF and many-archive batches go through swc_unarchive_many, which launches them together.)
     std::vector<uint8_t> all;
     std::vector<size_t> sz;
-    size_t pos = 0;
+    size_t pos = 0, walk_bound = (size_t)4 << 20;
     int st = SWC_OK;
     while (pos < in_len) {                                             // :66
         HostUnit u;
@@ -253,8 +273,9 @@ int swc_gzip_multi_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, si
         if (st) break;
         u.cap_hint = 0;                                                // ISIZE guess only valid for the last member
         const size_t data_pos = (size_t)(u.in - in);
-        st = run_one(SWC_CODEC_DEFLATE, u);
+        st = run_one_bounded(SWC_CODEC_DEFLATE, u, walk_bound);
         if (st) break;
+        walk_bound = std::max<size_t>(walk_bound, 4 * u.in_consumed + 65536);   // the next member is probably of this size
         bool crc_error;
         st = gzip_member_finish(in, in_len, data_pos, u, pos, crc_error);
         if (st) break;
@@ -267,9 +288,14 @@ int swc_gzip_multi_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, si
     *sizes = give_sizes(sz);
     *n_members = sz.size();
     return st;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    if (out && out_len) give_empty(out, out_len);
+    if (sizes) *sizes = nullptr;
+    if (n_members) *n_members = 0;
+    return SWC_E_DEVICE;
 }
 
-int swc_zlib_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) {
+int swc_zlib_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) try {
     if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
     size_t p = 0;
     int st = zlib_parse_header(in, in_len, p);
@@ -284,6 +310,9 @@ int swc_zlib_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* 
     if (in_len - q < 4) return SWC_E_ZLIB_WRONG_ADLER32;
     uint32_t stored = (uint32_t)in[q] << 24 | (uint32_t)in[q + 1] << 16 | (uint32_t)in[q + 2] << 8 | in[q + 3];
     return swc_adler32(u.out.data(), u.out.size()) == stored ? SWC_OK : SWC_E_ZLIB_WRONG_ADLER32;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    if (out && out_len) give_empty(out, out_len);
+    return SWC_E_DEVICE;
 }
 
 }  // extern "C"

@@ -253,7 +253,7 @@ using namespace swc;
 extern "C" {
 
 int swc_lz4_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len, int64_t dict_id,
-                       uint8_t** out, size_t* out_len, size_t* in_consumed) {
+                       uint8_t** out, size_t* out_len, size_t* in_consumed) try {
     if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
     std::vector<uint8_t> res;
     bool have_dict = dict != nullptr;
@@ -285,6 +285,9 @@ int swc_lz4_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, si
     if (in_consumed) *in_consumed = pos;
     give(res, out, out_len);
     return st;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    if (out && out_len) give_empty(out, out_len);
+    return SWC_E_DEVICE;
 }
 
 // All frames of a multi-frame buffer in one launch: block sizes are in the block headers, so the frames (standard frames
@@ -329,7 +332,7 @@ static bool lz4_multi_batched(const uint8_t* in, size_t in_len, std::vector<uint
 }
 
 int swc_lz4_multi_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len, int64_t dict_id,
-                             uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_frames) {
+                             uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_frames) try {
     if (!out || !out_len || !sizes || !n_frames || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
     if (dict == nullptr) {
         std::vector<uint8_t> fast;
@@ -370,6 +373,11 @@ int swc_lz4_multi_decompress(const uint8_t* in, size_t in_len, const uint8_t* di
     *sizes = give_sizes(sz);
     *n_frames = sz.size();
     return st;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    if (out && out_len) give_empty(out, out_len);
+    if (sizes) *sizes = nullptr;
+    if (n_frames) *n_frames = 0;
+    return SWC_E_DEVICE;
 }
 
 }  // extern "C"

@@ -424,7 +424,7 @@ using namespace swc;
 extern "C" {
 
 int swc_lzma_decompress(const uint8_t* in, size_t in_len, int lc, int lp, int pb, int64_t dict_size,
-                        int64_t uncompressed_size, uint8_t** out, size_t* out_len, size_t* in_consumed) {
+                        int64_t uncompressed_size, uint8_t** out, size_t* out_len, size_t* in_consumed) try {
     if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
     HostUnit u;
     u.in = in; u.in_len = in_len;
@@ -439,9 +439,12 @@ int swc_lzma_decompress(const uint8_t* in, size_t in_len, int lc, int lp, int pb
     if (u.status) { give_empty(out, out_len); return u.status; }                  // LZMAError cases carry no data
     give(u.out, out, out_len);
     return SWC_OK;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    if (out && out_len) give_empty(out, out_len);
+    return SWC_E_DEVICE;
 }
 
-int swc_lzma_alone_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) {
+int swc_lzma_alone_decompress(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) try {
     if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
     if (in_len < 13) { give_empty(out, out_len); return SWC_E_LZMA_WRONG_PROPERTIES; }   // LZMA.swift:27
     const uint32_t b = in[0];
@@ -452,9 +455,12 @@ int swc_lzma_alone_decompress(const uint8_t* in, size_t in_len, uint8_t** out, s
     for (int i = 0; i < 8; i++) us |= (uint64_t)in[5 + i] << (8 * i);
     size_t consumed;
     return swc_lzma_decompress(in + 13, in_len - 13, lc, lp, pb, dict, (int64_t)us, out, out_len, &consumed);
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    if (out && out_len) give_empty(out, out_len);
+    return SWC_E_DEVICE;
 }
 
-int swc_lzma2_decompress(const uint8_t* in, size_t in_len, uint8_t dict_byte, uint8_t** out, size_t* out_len, size_t* in_consumed) {
+int swc_lzma2_decompress(const uint8_t* in, size_t in_len, uint8_t dict_byte, uint8_t** out, size_t* out_len, size_t* in_consumed) try {
     if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
     HostUnit u;
     u.in = in; u.in_len = in_len;
@@ -467,25 +473,34 @@ int swc_lzma2_decompress(const uint8_t* in, size_t in_len, uint8_t dict_byte, ui
     if (u.status) { give_empty(out, out_len); return u.status; }
     give(u.out, out, out_len);
     return SWC_OK;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    if (out && out_len) give_empty(out, out_len);
+    return SWC_E_DEVICE;
 }
 
-int swc_lzma2_decompress_data(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) {
+int swc_lzma2_decompress_data(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) try {
     if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
     if (in_len < 1) { give_empty(out, out_len); return SWC_E_LZMA_RANGE_DECODER_INIT_ERROR; }  // LZMA2.swift:27
     size_t consumed;
     return swc_lzma2_decompress(in + 1, in_len - 1, in[0], out, out_len, &consumed);
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    if (out && out_len) give_empty(out, out_len);
+    return SWC_E_DEVICE;
 }
 
-int swc_xz_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) {
+int swc_xz_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) try {
     if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
     std::vector<uint8_t> all;
     std::vector<size_t> sizes;
     int st = xz_run(in, in_len, all, sizes);
     give(all, out, out_len);
     return st;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    if (out && out_len) give_empty(out, out_len);
+    return SWC_E_DEVICE;
 }
 
-int swc_xz_split_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_streams) {
+int swc_xz_split_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_streams) try {
     if (!out || !out_len || !sizes || !n_streams || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
     std::vector<uint8_t> all;
     std::vector<size_t> sz;
@@ -494,6 +509,11 @@ int swc_xz_split_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size
     *sizes = give_sizes(sz);
     *n_streams = sz.size();
     return st;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    if (out && out_len) give_empty(out, out_len);
+    if (sizes) *sizes = nullptr;
+    if (n_streams) *n_streams = 0;
+    return SWC_E_DEVICE;
 }
 
 }  // extern "C"

@@ -156,7 +156,7 @@ using namespace swc;
 extern "C" {
 
 int swc_unarchive_many(int kind, const uint8_t* const* archives, const size_t* lens, size_t n,
-                       uint8_t** outs, size_t* out_lens, int32_t* statuses) {
+                       uint8_t** outs, size_t* out_lens, int32_t* statuses) try {
     if (kind < 1 || kind > 7 || (n && (!archives || !lens || !outs || !out_lens || !statuses))) return SWC_E_INVALID_ARGUMENT;
     for (size_t i = 0; i < n; i++) if (lens[i] && !archives[i]) return SWC_E_INVALID_ARGUMENT;
     if (!device_ready()) return SWC_E_DEVICE;
@@ -171,9 +171,12 @@ int swc_unarchive_many(int kind, const uint8_t* const* archives, const size_t* l
     if (st) return st;
     hand_over(res, outs, out_lens, statuses);
     return SWC_OK;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    for (size_t i = 0; i < n; i++) { outs[i] = host_result(0); out_lens[i] = 0; statuses[i] = SWC_E_DEVICE; }   // (results are handed over last: nothing of theirs is lost)
+    return SWC_E_DEVICE;
 }
 
-int swc_zip_get_entries_data(const uint8_t* container, size_t len, swc_zip_entry* entries, size_t n) {
+int swc_zip_get_entries_data(const uint8_t* container, size_t len, swc_zip_entry* entries, size_t n) try {
     if ((len && !container) || (n && !entries)) return SWC_E_INVALID_ARGUMENT;
     if (!device_ready()) return SWC_E_DEVICE;
     // ---- units per compression method (ZipContainer.swift:70-93)
@@ -181,6 +184,7 @@ int swc_zip_get_entries_data(const uint8_t* container, size_t len, swc_zip_entry
     std::vector<size_t> defl_owner, lzma_owner;
     std::vector<Result> res(n);
     std::vector<size_t> real_comp(n, 0);
+    for (size_t i = 0; i < n; i++) { entries[i].data = nullptr; entries[i].data_len = 0; }
     for (size_t i = 0; i < n; i++) {
         swc_zip_entry& e = entries[i];
         e.data = nullptr; e.data_len = 0; e.crc_error = 0; e.status = SWC_OK;
@@ -195,7 +199,8 @@ int swc_zip_get_entries_data(const uint8_t* container, size_t len, swc_zip_entry
                 break;
             case 8: {                                                                   // .deflate :72-78
                 HostUnit u;
-                u.in = p; u.in_len = avail;
+                u.in = p; u.in_len = avail;                                             // the reader runs on into whatever follows (:74)
+                u.base = container; u.base_len = len;                                   // ... but the container is staged once for all entries
                 if (e.uncomp_size <= (uint64_t)avail * 1100 + 4096) u.cap_hint = std::max<size_t>((size_t)e.uncomp_size, 64);
                 defl.push_back(std::move(u));
                 defl_owner.push_back(i);
@@ -204,7 +209,16 @@ int swc_zip_get_entries_data(const uint8_t* container, size_t len, swc_zip_entry
             case 12: {                                                                  // .bzip2 :79-86 (one stream: its own discovery)
                 uint8_t* o = nullptr;
                 size_t ol = 0, used = 0;
-                int st = swc_bzip2_decompress(p, avail, &o, &ol, &used);
+                // first over the entry's own bytes (the block-magic scan and the decode of every candidate behind them
+                // would otherwise cover the rest of the container for every entry); anything but a clean decode that ends
+                // inside them is decided by a second run over the whole tail, as the reference's reader would see it
+                const bool sized = !e.has_data_descriptor && e.comp_size > 0 && e.comp_size < avail;
+                int st = swc_bzip2_decompress(p, sized ? (size_t)e.comp_size : avail, &o, &ol, &used);
+                if (sized && st != SWC_OK && st != SWC_E_DEVICE) {
+                    swc_free(o);
+                    o = nullptr;
+                    st = swc_bzip2_decompress(p, avail, &o, &ol, &used);
+                }
                 if (st == SWC_E_DEVICE) { swc_free(o); return SWC_E_DEVICE; }
                 if (st == SWC_OK) res[i].data.assign(o, o + ol);
                 swc_free(o);
@@ -219,6 +233,7 @@ int swc_zip_get_entries_data(const uint8_t* container, size_t len, swc_zip_entry
                 if (e.uncomp_size > (uint64_t)INT64_MAX) { res[i].status = SWC_E_REF_TRAP; break; }  // toInt() traps
                 HostUnit u;
                 u.in = p + 9; u.in_len = avail - 9;
+                u.base = container; u.base_len = len;
                 u.aux = (int32_t)((b % 9) | (((b / 9) % 5) << 8) | (((b / 9) / 5) << 16));
                 u.extra = e.uncomp_size;
                 u.dict_value = le32(p + 5);
@@ -273,11 +288,14 @@ int swc_zip_get_entries_data(const uint8_t* container, size_t len, swc_zip_entry
         e.data_len = dl;
     }
     return SWC_OK;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    for (size_t i = 0; i < n; i++) { entries[i].status = SWC_E_DEVICE; if (!entries[i].data) entries[i].data_len = 0; }
+    return SWC_E_DEVICE;
 }
 
 // Host block discovery as a library call: what the batched entry points use internally, for callers
 // that keep their data on the device and build their own job lists.  No device needed.
-int swc_index_blocks(int kind, const uint8_t* in, size_t len, swc_block_ref* refs, size_t cap, size_t* n) {
+int swc_index_blocks(int kind, const uint8_t* in, size_t len, swc_block_ref* refs, size_t cap, size_t* n) try {
     if (!n || (len && !in) || (cap && !refs)) return SWC_E_INVALID_ARGUMENT;
     std::vector<BlockRef64> v;
     bool ok = true;
@@ -292,11 +310,14 @@ int swc_index_blocks(int kind, const uint8_t* in, size_t len, swc_block_ref* ref
     *n = v.size();
     for (size_t i = 0; i < v.size() && i < cap; i++) refs[i] = swc_block_ref{v[i].offset, v[i].comp_len, v[i].uncomp_len, v[i].aux, 0};
     return SWC_OK;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    if (n) *n = 0;
+    return SWC_E_DEVICE;
 }
 
 // SevenZipFolder.unpack(data:) for many folders (reference Sources/7-Zip/7zFolder.swift:138-194).  Stage k of every
 // chain that is still alive is decoded together: one run_units launch per codec and stage.
-int swc_7z_unpack_folders(swc_7z_folder* folders, size_t n) {
+int swc_7z_unpack_folders(swc_7z_folder* folders, size_t n) try {
     if (n && !folders) return SWC_E_INVALID_ARGUMENT;
     size_t max_chain = 0;
     for (size_t i = 0; i < n; i++) {
@@ -406,6 +427,8 @@ int swc_7z_unpack_folders(swc_7z_folder* folders, size_t n) {
         else { std::vector<uint8_t> copy(folders[i].data, folders[i].data + folders[i].len); give(copy, &folders[i].out, &folders[i].out_len); }
     }
     return SWC_OK;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    return SWC_E_DEVICE;
 }
 
 }  // extern "C"

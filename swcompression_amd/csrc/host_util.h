@@ -12,7 +12,8 @@
 
 namespace swc {
 
-// RAII device allocation from the stream-ordered pool of the default stream (hipMalloc / hipFree cost milliseconds
+// RAII device allocation from the stream-ordered pool, on the calling thread's own stream (hipStreamPerThread: concurrent
+// callers do not serialise on the default stream) (hipMalloc / hipFree cost milliseconds
 // each, which dominated the single-shot calls: 9.4 ms for one 64 KiB block; the pool keeps up to 1 GiB cached, see
 // device_ready()).  ok() is false when the allocation failed (=> SWC_E_DEVICE, never a CPU fallback).
 class DevBuf {
@@ -25,12 +26,12 @@ public:
     bool alloc(size_t n) {
         release();
         if (n == 0) n = 1;
-        if (hipMallocAsync(&p_, n, nullptr) != hipSuccess) { p_ = nullptr; (void)hipGetLastError(); return false; }
+        if (hipMallocAsync(&p_, n, hipStreamPerThread) != hipSuccess) { p_ = nullptr; (void)hipGetLastError(); return false; }
         n_ = n;
         return true;
     }
     void release() {
-        if (p_) (void)hipFreeAsync(p_, nullptr);
+        if (p_) (void)hipFreeAsync(p_, hipStreamPerThread);
         p_ = nullptr; n_ = 0;
     }
     bool ok() const { return p_ != nullptr; }
@@ -42,6 +43,10 @@ private:
     size_t n_;
 };
 
+// Page-locked host staging memory of the calling thread, kept between calls (pageable hipMemcpy was most of a small
+// single-shot call).  nullptr if the allocation fails (the caller falls back to its own pageable buffer).
+uint8_t* pinned_stage(int which, size_t n);
+
 // malloc()ed host result handed to the caller (released with swc_free); never NULL.
 inline uint8_t* host_result(size_t n) { return static_cast<uint8_t*>(malloc(n ? n : 1)); }
 
@@ -51,6 +56,10 @@ bool device_ready();  // api.cpp: true when a gfx950 device is present and selec
 struct HostUnit {
     const uint8_t* in = nullptr;
     size_t in_len = 0;
+    // Optional: the host buffer `in` points into (a container, a multi-member file).  Units with the same base are staged
+    // ONCE and address their sub-range of it -- not each its own copy of everything behind its start.
+    const uint8_t* base = nullptr;
+    size_t base_len = 0;
     size_t cap_hint = 0;         // 0 = use the codec's default policy
     bool cap_exact = false;      // cap_hint is authoritative (declared size): do not grow
     int32_t aux = 0;

@@ -26,6 +26,16 @@
 
 namespace swc {
 
+// A job's area of the workspace: equal strides, or -- `ws_off` given -- prefix-summed per-job sizes (ws_off[n] = total),
+// so that one large unit among many small ones does not size everybody's area.
+struct WsMap {
+    uint8_t* base;
+    size_t stride;
+    const uint64_t* off;
+    __device__ uint8_t* area(uint32_t g) const { return base ? base + (off ? (size_t)off[g] : (size_t)g * stride) : nullptr; }
+    __device__ size_t bytes(uint32_t g) const { return off ? (size_t)(off[g + 1] - off[g]) : stride; }
+};
+
 // ---- Deflate: two phases (inflate_lane.h, lz_resolve.h) ------------------------------------------------
 // Phase 1: one stream per lane.  LDS: 80 words/lane -> 20,480 B per wave -> 8 resident waves per CU (2 per SIMD).
 // Literals go to the dense literal stream, matches become records, both in the workspace; the output is not touched.
@@ -63,12 +73,12 @@ __global__ __launch_bounds__(64, 4) void swc_inflate_wave_kernel(Job* __restrict
 #endif
 static uint64_t* g_prof = nullptr;   // profile builds (-DSWC_PROFILE): 32 counters per job, [0..16) phase 1, [16..32) phase 2
 void set_profile_buffer(void* p) { g_prof = static_cast<uint64_t*>(p); }
-__global__ __launch_bounds__(64, SWC_SYNC_WAVES_PER_SIMD) void swc_inflate_sync_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride, uint64_t* prof) {
+__global__ __launch_bounds__(64, SWC_SYNC_WAVES_PER_SIMD) void swc_inflate_sync_kernel(Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof) {
     __shared__ __attribute__((aligned(16))) inflate::SyncLds sync_lds;
     uint32_t g = blockIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
-    inflate::inflate_sync_job(job, &sync_lds, ws ? ws + (size_t)g * ws_stride : nullptr, ws_stride, (int)threadIdx.x, kWave, prof ? prof + 32 * (size_t)g : nullptr);
+    inflate::inflate_sync_job(job, &sync_lds, wm.area(g), wm.bytes(g), (int)threadIdx.x, kWave, prof ? prof + 32 * (size_t)g : nullptr);
     if (threadIdx.x == 0) {
         jobs[g].out_len = job.out_len;
         jobs[g].in_consumed = job.in_consumed;
@@ -79,12 +89,12 @@ __global__ __launch_bounds__(64, SWC_SYNC_WAVES_PER_SIMD) void swc_inflate_sync_
 // Phase 2: one stream per workgroup of 512 threads, 64 KiB LDS ring (32 KiB of history + span + cells) -> 2 workgroups per CU.
 constexpr int kInflateResolveThreads = 512, kInflateRingLog2 = 16;
 constexpr uint32_t kInflateKeep = 32768;
-__global__ __launch_bounds__(kInflateResolveThreads) void swc_lz_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, const uint8_t* ws, size_t ws_stride, uint64_t* prof) {
+__global__ __launch_bounds__(kInflateResolveThreads) void swc_lz_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof) {
     __shared__ __attribute__((aligned(16))) lzr::Lds<kInflateResolveThreads, kInflateRingLog2> lzr_lds;  // static: > 64 KiB needs no opt-in this way
     uint32_t g = blockIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
-    lzr::resolve_job<kInflateResolveThreads, kInflateRingLog2, kInflateKeep>(job, ws + (size_t)g * ws_stride, ws_stride, &lzr_lds, prof ? prof + 32 * (size_t)g + 16 : nullptr);
+    lzr::resolve_job<kInflateResolveThreads, kInflateRingLog2, kInflateKeep>(job, wm.area(g), wm.bytes(g), &lzr_lds, prof ? prof + 32 * (size_t)g + 16 : nullptr);
 }
 
 static int g_inflate_dbg = 0;
@@ -117,21 +127,22 @@ int last_phase_ms(float* ms, int cap) {
 void set_resolve_threads(int) {}
 size_t inflate_ws_bytes_per_job(uint64_t cap) { return lzr::ws_bytes_per_job(cap); }
 
-hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {
+hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream, const uint64_t* ws_off) {
     if (n == 0) return hipSuccess;
     size_t stride = ws ? (ws_bytes / n) & ~(size_t)15 : 0;
-    if (stride < sizeof(lzr::StreamHeader)) return hipErrorInvalidValue;
+    if (!ws_off && stride < sizeof(lzr::StreamHeader)) return hipErrorInvalidValue;
+    const WsMap wm{(uint8_t*)ws, stride, ws_off};
     dim3 grid((unsigned)((n + kWave - 1) / kWave)), block(kWave);
     const bool timing = g_phase_timing && g_phase_ev_ok;
     if (timing) (void)hipEventRecord(g_phase_ev[0], stream);
     if (g_inflate_mode == 0)
-        hipLaunchKernelGGL(swc_inflate_sync_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride, g_prof);
+        hipLaunchKernelGGL(swc_inflate_sync_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof);
     else if (n <= (size_t)g_wave_max_jobs)
         hipLaunchKernelGGL(swc_inflate_wave_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride, g_inflate_dbg);
     else
         hipLaunchKernelGGL(swc_inflate_kernel, grid, block, inflate::kLdsBytesPerWave, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride, g_inflate_dbg);
     if (timing) (void)hipEventRecord(g_phase_ev[1], stream);
-    hipLaunchKernelGGL(swc_lz_resolve_kernel, dim3((unsigned)n), dim3(kInflateResolveThreads), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride, g_prof);
+    hipLaunchKernelGGL(swc_lz_resolve_kernel, dim3((unsigned)n), dim3(kInflateResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof);
     if (timing) { (void)hipEventRecord(g_phase_ev[2], stream); g_phase_valid = true; }
     return hipGetLastError();
 }
@@ -152,7 +163,7 @@ __global__ __launch_bounds__(64) void swc_lz4_lane_kernel(Job* __restrict__ jobs
     jobs[g].status = job.status;
 }
 
-__global__ __launch_bounds__(64) void swc_lz4_parse_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride, uint64_t* prof) {
+__global__ __launch_bounds__(64) void swc_lz4_parse_kernel(Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof) {
     uint32_t g = blockIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
@@ -161,7 +172,7 @@ __global__ __launch_bounds__(64) void swc_lz4_parse_kernel(Job* __restrict__ job
     __shared__ uint32_t rbuf[lz4w::kRecBuf];
     __shared__ __attribute__((aligned(16))) uint8_t lbuf[lz4w::kLitStage + 32 + 64];
     __shared__ __attribute__((aligned(16))) uint8_t stage[lz4w::kStageLds];
-    lz4w::lz4_parse_job<kWave>(job, ws + (size_t)g * ws_stride, ws_stride, (int)threadIdx.x, rbuf, lbuf, iw, stage, prof ? prof + 32 * (size_t)g : nullptr);
+    lz4w::lz4_parse_job<kWave>(job, wm.area(g), wm.bytes(g), (int)threadIdx.x, rbuf, lbuf, iw, stage, prof ? prof + 32 * (size_t)g : nullptr);
     if (threadIdx.x == 0) {
         jobs[g].out_len = job.out_len;
         jobs[g].in_consumed = job.in_consumed;
@@ -169,22 +180,22 @@ __global__ __launch_bounds__(64) void swc_lz4_parse_kernel(Job* __restrict__ job
     }
 }
 
-__global__ __launch_bounds__(lz4w::kResolveThreads) void swc_lz4_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, const uint8_t* ws, size_t ws_stride) {
+__global__ __launch_bounds__(lz4w::kResolveThreads) void swc_lz4_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm) {
     __shared__ __attribute__((aligned(16))) lzr::Lds<lz4w::kResolveThreads, lz4w::kRingLog2> lds;
     uint32_t g = blockIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
     if (job.dict != nullptr) return;
-    lzr::resolve_job<lz4w::kResolveThreads, lz4w::kRingLog2, lz4w::kKeep>(job, ws + (size_t)g * ws_stride, ws_stride, &lds);
+    lzr::resolve_job<lz4w::kResolveThreads, lz4w::kRingLog2, lz4w::kKeep>(job, wm.area(g), wm.bytes(g), &lds);
 }
 
 size_t lz4_ws_bytes_per_job(uint64_t cap) { return lzr::ws_bytes_per_job(cap); }
 
-hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {
+hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream, const uint64_t* ws_off) {
     if (n == 0) return hipSuccess;
     dim3 grid((unsigned)((n + kWave - 1) / kWave)), block(kWave);
     size_t stride = ws ? (ws_bytes / n) & ~(size_t)15 : 0;
-    if (stride < sizeof(lzr::StreamHeader)) {
+    if (!ws_off && stride < sizeof(lzr::StreamHeader)) {
         // no workspace: every block on the lane decoder
         hipLaunchKernelGGL(swc_lz4_lane_kernel, grid, block, 0, stream, jobs, (uint32_t)n, 0);
         return hipGetLastError();
@@ -192,8 +203,9 @@ hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_
     // The parse is latency bound per block (a serial chase), so all blocks are parsed in ONE launch: the more waves
     // in flight, the better the latency hides (8,192 blocks = 8 waves per SIMD).
     hipLaunchKernelGGL(swc_lz4_lane_kernel, grid, block, 0, stream, jobs, (uint32_t)n, 1);
-    hipLaunchKernelGGL(swc_lz4_parse_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride, g_prof);
-    hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(lz4w::kResolveThreads), 0, stream, jobs, (uint32_t)n, (const uint8_t*)ws, stride);
+    const WsMap wm{(uint8_t*)ws, stride, ws_off};
+    hipLaunchKernelGGL(swc_lz4_parse_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof);
+    hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(lz4w::kResolveThreads), 0, stream, jobs, (uint32_t)n, wm);
     return hipGetLastError();
 }
 

@@ -4,7 +4,8 @@
 #include <hip/hip_runtime.h>
 #include "swc_common.h"
 namespace swc {
-hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream);
+// ws_off != nullptr: device array of n + 1 prefix-summed per-job workspace offsets (then ws_bytes is ignored)
+hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream, const uint64_t* ws_off = nullptr);
 size_t inflate_ws_bytes_per_job(uint64_t cap);
 hipError_t launch_crc32(const Job* jobs, size_t n, uint32_t* crcs, hipStream_t stream);
 hipError_t launch_delta(Job* jobs, size_t n, hipStream_t stream);
@@ -17,7 +18,7 @@ void set_inflate_mode(int m);
 void set_profile_buffer(void* p);
 void set_phase_timing(int on);
 int last_phase_ms(float* ms, int cap);
-hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream);
+hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream, const uint64_t* ws_off = nullptr);
 size_t lz4_ws_bytes_per_job(uint64_t cap);
 hipError_t launch_lzma(bool lzma2, Job* jobs, size_t n, void* spill, hipStream_t stream);
 size_t lzma_spill_bytes_per_job();
