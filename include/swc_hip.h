@@ -227,10 +227,8 @@ void swc_free(void* p);
 /* 1 if a gfx950 device is usable, 0 otherwise (then every decode entry point returns SWC_E_DEVICE) */
 int swc_device_available(void);
 const char* swc_version(void);
-/* Performance knobs (never change results): "phase_timing" = 0 | 1 (HIP events around the two Deflate kernels of a
- * launch), "inflate_mode" = 0 | 1 (0, default: phase 1 decodes one stream per wavefront with 64 sub-chunks at once,
- * inflate_sync.h; 1: the one-stream-per-lane / hop-chain forms of inflate_lane.h, kept for comparison runs, where
- * "inflate_wave_max_jobs" = n selects the hop-chain form for batches of up to n streams). */
+/* Measurement knob (never changes results): "phase_timing" = 0 | 1 (HIP events around the two Deflate kernels of a
+ * launch).  Process-wide; meant for benchmarking. */
 int swc_set_tuning(const char* key, int value);
 /* Profile builds of the library (-DSWC_PROFILE) only: a device buffer of 32 x uint64 per job of the next Deflate
  * launches that the kernels fill with cycle counts per stage (tools/exp_profile.py).  NULL switches it off.  A no-op in

@@ -218,16 +218,7 @@ extern "C" {
 
 int swc_set_tuning(const char* key, int value) try {
     if (!key) return SWC_E_INVALID_ARGUMENT;
-    if (!strcmp(key, "resolve_threads") && (value == 64 || value == 128 || value == 256 || value == 512 || value == 1024)) { set_resolve_threads(value); return SWC_OK; }
-    if (!strcmp(key, "inflate_wave_max_jobs") && value >= 0) { set_inflate_wave_max_jobs(value); return SWC_OK; }
     if (!strcmp(key, "phase_timing") && (value == 0 || value == 1)) { set_phase_timing(value); return SWC_OK; }
-    if (!strcmp(key, "inflate_mode") && (value == 0 || value == 1)) { set_inflate_mode(value); return SWC_OK; }   // 1: lane / hop-chain phase 1 (comparison runs)
-#if defined(SWC_ENABLE_ABLATION_KNOBS)
-    // Timing experiments only (tools/exp_*.py): they switch parts of the kernels OFF, i.e. results are wrong by design.
-    // Compiled out of the shipped library.
-    if (!strcmp(key, "inflate_debug") && value >= 0 && value < 4) { set_inflate_debug(value); return SWC_OK; }
-    if (!strcmp(key, "resolve_debug") && value >= 0 && value < 32) { set_resolve_debug(value); return SWC_OK; }
-#endif
     return SWC_E_INVALID_ARGUMENT;
 } catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
     return SWC_E_DEVICE;

@@ -599,7 +599,6 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, SyncProf& pf) {
     using simt::PT;
     constexpr int N = kWave;
     BitReader& br = ln.br;
-    ln.luts_ready = false;
     br.refill();
     if (br.bc < 14) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :86
     const int literals = (int)br.bits(5) + 257;
@@ -721,7 +720,6 @@ SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes,
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     pf.tlast = __builtin_readcyclecounter();
 #endif
-    ln.dbg = 0;
     ln.wlane = lane;
     ln.wlanes = lanes;
     ln.l = LaneLds{sl->syms, 1};

@@ -2,9 +2,10 @@
 //
 // Every unit (a Deflate stream, an LZ4 block, a bzip2 block, an LZMA stream) is independent; the chip is filled by units, and
 // each codec maps a unit to the piece of the machine its serial part needs:
-//   Deflate   phase 1 one stream per LANE (tables in LDS at wave stride + VGPRs) or, for small batches, per WAVEFRONT;
-//             phase 2 (LZ77 resolve) one stream per WORKGROUP with the window in LDS           inflate_lane.h, lz_resolve.h
-//   LZ4       parse one block per wavefront, then the same resolve kernel; dictionary blocks per lane    lz4_wave.h, lz4_lane.h
+//   Deflate   phase 1 one stream per WAVEFRONT, 64 sub-chunks decoded at once (self-synchronising Huffman decode);
+//             phase 2 (LZ77 resolve) one stream per WORKGROUP, byte cells in LDS   inflate_sync.h, inflate_lane.h, lz_resolve.h
+//   LZ4       parse one block per wavefront (64 sub-chunks at once), then the same resolve kernel; dictionary blocks per lane
+//                                                                                                lz4_wave.h, lz4_lane.h
 //   LZMA      one stream per wavefront, probability model in LDS                                               lzma_wave.h
 //   BZip2     Huffman + MTF per wavefront, counting-sort scatter per wavefront, inverse BWT by all lanes of a wavefront over
 //             a cut cycle, block CRC per workgroup                                                           bzip2_block.h
@@ -36,37 +37,8 @@ struct WsMap {
     __device__ size_t bytes(uint32_t g) const { return off ? (size_t)(off[g + 1] - off[g]) : stride; }
 };
 
-// ---- Deflate: two phases (inflate_lane.h, lz_resolve.h) ------------------------------------------------
-// Phase 1: one stream per lane.  LDS: 80 words/lane -> 20,480 B per wave -> 8 resident waves per CU (2 per SIMD).
-// Literals go to the dense literal stream, matches become records, both in the workspace; the output is not touched.
-__global__ __launch_bounds__(64, 2) void swc_inflate_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride, int dbg) {
-    extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
-    uint32_t g = blockIdx.x * kWave + threadIdx.x;
-    if (g >= n) return;
-    Job job = jobs[g];
-    inflate::inflate_job(job, LaneLds{lds + threadIdx.x, kWave}, ws ? ws + (size_t)g * ws_stride : nullptr, ws_stride, dbg);
-    jobs[g].out_len = job.out_len;
-    jobs[g].in_consumed = job.in_consumed;
-    jobs[g].status = job.status;
-}
-
-// Phase 1 for small batches: one stream per WAVEFRONT (inflate_lane.h, wave mode).  A lane decodes a stream at ~8 MB/s,
-// so a launch of the kernel above takes >= 8 ms per 64 KiB however few streams it holds; with 64 speculative decodes per
-// window and a readlane hop per symbol a wave is an order of magnitude faster per stream, and ~5,000 waves fit the chip.
-__global__ __launch_bounds__(64, 4) void swc_inflate_wave_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t ws_stride, int dbg) {
-    __shared__ __attribute__((aligned(16))) uint32_t wave_lds[inflate::kWaveModeLdsBytes / 4];
-    uint32_t g = blockIdx.x;
-    if (g >= n) return;
-    Job job = jobs[g];
-    inflate::inflate_job(job, LaneLds{nullptr, 0}, ws ? ws + (size_t)g * ws_stride : nullptr, ws_stride, dbg, (int)threadIdx.x, wave_lds, kWave);
-    if (threadIdx.x == 0) {
-        jobs[g].out_len = job.out_len;
-        jobs[g].in_consumed = job.in_consumed;
-        jobs[g].status = job.status;
-    }
-}
-
-// Phase 1, production form: one stream per WAVEFRONT, 64 sub-chunks of the stream decoded at once (inflate_sync.h).
+// ---- Deflate: two phases (inflate_sync.h + inflate_lane.h, lz_resolve.h) -------------------------------------------
+// Phase 1: one stream per WAVEFRONT, 64 sub-chunks of the stream decoded at once (inflate_sync.h).
 // LDS: the shared tables + the staged input of a round, ~14 KiB per wave -> 11 waves per CU.
 #ifndef SWC_SYNC_WAVES_PER_SIMD
 #define SWC_SYNC_WAVES_PER_SIMD 3
@@ -97,13 +69,6 @@ __global__ __launch_bounds__(kInflateResolveThreads) void swc_lz_resolve_kernel(
     lzr::resolve_job<kInflateResolveThreads, kInflateRingLog2, kInflateKeep>(job, wm.area(g), wm.bytes(g), &lzr_lds, prof ? prof + 32 * (size_t)g + 16 : nullptr);
 }
 
-static int g_inflate_dbg = 0;
-static int g_inflate_mode = 0;   // 0: inflate_sync.h (production); 1: the lane / hop-chain forms of inflate_lane.h (kept for comparison runs)
-void set_inflate_mode(int m) { g_inflate_mode = m; }
-static int g_wave_max_jobs = 4096;   // batches of up to this many streams take the wave-per-stream phase 1
-void set_inflate_wave_max_jobs(int n) { g_wave_max_jobs = n; }
-void set_inflate_debug(int m) { g_inflate_dbg = m; }
-void set_resolve_debug(int) {}
 
 // Optional per-phase timing of the last Deflate launch (bench.py: roofline per kernel).  HIP events on the
 // launch stream; off by default so that the production path issues nothing but the two kernels.
@@ -124,7 +89,6 @@ int last_phase_ms(float* ms, int cap) {
     if (hipEventElapsedTime(&ms[1], g_phase_ev[1], g_phase_ev[2]) != hipSuccess) return 0;
     return 2;
 }
-void set_resolve_threads(int) {}
 size_t inflate_ws_bytes_per_job(uint64_t cap) { return lzr::ws_bytes_per_job(cap); }
 
 hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream, const uint64_t* ws_off) {
@@ -132,15 +96,10 @@ hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStr
     size_t stride = ws ? (ws_bytes / n) & ~(size_t)15 : 0;
     if (!ws_off && stride < sizeof(lzr::StreamHeader)) return hipErrorInvalidValue;
     const WsMap wm{(uint8_t*)ws, stride, ws_off};
-    dim3 grid((unsigned)((n + kWave - 1) / kWave)), block(kWave);
+    const dim3 block(kWave);
     const bool timing = g_phase_timing && g_phase_ev_ok;
     if (timing) (void)hipEventRecord(g_phase_ev[0], stream);
-    if (g_inflate_mode == 0)
-        hipLaunchKernelGGL(swc_inflate_sync_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof);
-    else if (n <= (size_t)g_wave_max_jobs)
-        hipLaunchKernelGGL(swc_inflate_wave_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride, g_inflate_dbg);
-    else
-        hipLaunchKernelGGL(swc_inflate_kernel, grid, block, inflate::kLdsBytesPerWave, stream, jobs, (uint32_t)n, (uint8_t*)ws, stride, g_inflate_dbg);
+    hipLaunchKernelGGL(swc_inflate_sync_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof);
     if (timing) (void)hipEventRecord(g_phase_ev[1], stream);
     hipLaunchKernelGGL(swc_lz_resolve_kernel, dim3((unsigned)n), dim3(kInflateResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof);
     if (timing) { (void)hipEventRecord(g_phase_ev[2], stream); g_phase_valid = true; }

@@ -10,11 +10,6 @@ size_t inflate_ws_bytes_per_job(uint64_t cap);
 hipError_t launch_crc32(const Job* jobs, size_t n, uint32_t* crcs, hipStream_t stream);
 hipError_t launch_delta(Job* jobs, size_t n, hipStream_t stream);
 hipError_t launch_checksum(int kind, const Job* jobs, size_t n, uint64_t* sums, hipStream_t stream);
-void set_resolve_threads(int t);
-void set_inflate_wave_max_jobs(int n);
-void set_resolve_debug(int m);
-void set_inflate_debug(int m);
-void set_inflate_mode(int m);
 void set_profile_buffer(void* p);
 void set_phase_timing(int on);
 int last_phase_ms(float* ms, int cap);

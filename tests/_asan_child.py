@@ -49,7 +49,7 @@ for kind, size in (("text", 300000), ("mix", 200000), ("rep", 100000), ("zero", 
     assert run("emu_lz4_block", z, p)[0], ("lz4", kind)
     assert not run("emu_lz4_block", z[:len(z) * 2 // 3], p)[0]      # truncated: an error status, no stray access
     z = corpus.deflate_raw(p, 6)
-    for fn in ("emu_inflate_sync", "emu_inflate"):
+    for fn in ("emu_inflate_sync",):
         assert run(fn, z, p)[0], (fn, kind)
         assert not run(fn, z[:len(z) * 2 // 3], p)[0]
         n += 2

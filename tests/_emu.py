@@ -72,14 +72,7 @@ def run_batch(fn_name, inputs, caps, aux=None, dicts=None, extra=None, fn_args=(
 
 
 def inflate(inputs, caps, misalign=0):
-    return run_batch("emu_inflate", inputs, caps, misalign=misalign)
-
-
-def inflate_wave(inputs, caps, misalign=0):
-    return run_batch("emu_inflate_wave", inputs, caps, misalign=misalign)
-
-
-def inflate_sync(inputs, caps, misalign=0):
+    """Deflate: inflate_sync.h (one stream per wavefront, 64 sub-chunks at once) + lz_resolve.h."""
     return run_batch("emu_inflate_sync", inputs, caps, misalign=misalign)
 
 

@@ -1,6 +1,6 @@
-// emu.cpp -- TEST INFRASTRUCTURE.  Builds the per-lane device decoders of swcompression_amd/csrc for
-// the HOST (g++ -DSWC_HOST_EMULATION) and runs the lanes of each wave one after another, with the
-// same wave-interleaved table layout the kernels use in LDS.  Lets the CPU-only test tier exercise
+// emu.cpp -- TEST INFRASTRUCTURE.  Builds the device decoders of swcompression_amd/csrc for the HOST
+// (g++ -DSWC_HOST_EMULATION): the uniform parts run once, the threads of every SIMT region (csrc/simt.h) one
+// after another in a selectable order.  Lets the CPU-only test tier exercise
 // the exact source the gfx950 kernels are compiled from against the oracle.  Never shipped, never
 // linked into libswc_hip.so.
 #include <vector>
@@ -14,37 +14,6 @@
 #include "../../swcompression_amd/csrc/crc32_group.h"
 
 extern "C" void emu_set_order(int o) { swc::simt::g_order = o; }
-
-// Deflate: phase 1 lane by lane (wave-interleaved tables), then phase 2 with a one-thread "workgroup".
-extern "C" void emu_inflate(swc::Job* jobs, size_t n) {
-    std::vector<uint32_t> lds(swc::inflate::kWordsPerLane * swc::kWave);
-    alignas(16) static swc::lzr::Lds<512, 16> rl;
-    for (size_t g = 0; g < n; g++) {
-        int lane = (int)(g % swc::kWave);
-        if (lane == 0) std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);  // LDS is uninitialised on device
-        swc::LaneLds l{lds.data() + lane, swc::kWave};
-        size_t wsb = swc::lzr::ws_bytes_per_job(jobs[g].out_cap);
-        std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
-        swc::inflate::inflate_job(jobs[g], l, ws.data(), wsb);
-        std::memset(&rl, 0xEE, sizeof rl);
-        swc::lzr::resolve_job<512, 16, 32768>(jobs[g], ws.data(), wsb, &rl);
-    }
-}
-
-// Deflate, wave mode of phase 1 (one stream per wavefront: direct tables + 64 speculative views per window), with the 64
-// views of a window computed one after the other.
-extern "C" void emu_inflate_wave(swc::Job* jobs, size_t n) {
-    std::vector<uint32_t> lds(swc::inflate::kWaveModeLdsBytes / 4 + 8);
-    alignas(16) static swc::lzr::Lds<512, 16> rl;
-    for (size_t g = 0; g < n; g++) {
-        std::fill(lds.begin(), lds.end(), 0xDEADBEEFu);
-        size_t wsb = swc::lzr::ws_bytes_per_job(jobs[g].out_cap);
-        std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
-        swc::inflate::inflate_job(jobs[g], swc::LaneLds{nullptr, 0}, ws.data(), wsb, 0, 0, lds.data(), 1);
-        std::memset(&rl, 0xEE, sizeof rl);
-        swc::lzr::resolve_job<512, 16, 32768>(jobs[g], ws.data(), wsb, &rl);
-    }
-}
 
 // Deflate, one stream per wavefront with 64 sub-chunks decoded at once (inflate_sync.h): the uniform parts run once, the
 // 64 lanes of every parallel region one after another (csrc/simt.h).
@@ -122,13 +91,12 @@ extern "C" void emu_bzip2_block(swc::Job* jobs, size_t n, size_t lcap) {
 
 // Debug/analysis helper (tools/analyze_records.py): phase 1 only, returns the record list of one stream.
 extern "C" size_t emu_inflate_records(const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, uint32_t* recs_out, size_t max_out) {
-    std::vector<uint32_t> lds(swc::inflate::kWordsPerLane * swc::kWave, 0xDEADBEEFu);
-    swc::LaneLds l{lds.data(), swc::kWave};
+    alignas(16) static swc::inflate::SyncLds sl;
     size_t wsb = swc::lzr::ws_bytes_per_job(cap);
     std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
     swc::Job j{};
     j.in = in; j.in_len = in_len; j.out = out; j.out_cap = cap;
-    swc::inflate::inflate_job(j, l, ws.data(), wsb);
+    swc::inflate::inflate_sync_job(j, &sl, ws.data(), wsb, 0, 1);
     uint32_t n = ((swc::lzr::StreamHeader*)ws.data())->nrec;
     const uint32_t* r = (const uint32_t*)(ws.data() + sizeof(swc::lzr::StreamHeader));
     for (size_t i = 0; i < n && i < max_out; i++) recs_out[i] = r[i];

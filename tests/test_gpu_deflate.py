@@ -26,20 +26,6 @@ pytestmark = pytest.mark.gpu
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_inline_vectors.json")))
 
 
-@pytest.fixture(autouse=True, params=["sync", "lane", "wave"])
-def phase1_mode(request):
-    """Phase 1 forms: "sync" = one stream per wavefront, 64 sub-chunks decoded at once (inflate_sync.h, the production
-    path); "lane" / "wave" = the one-stream-per-lane and hop-chain forms of inflate_lane.h (kept for comparison runs).
-    Every test of this file runs against all of them, whatever its batch size."""
-    from swcompression_amd import _lib
-    lib = _lib.load()
-    assert lib.swc_set_tuning(b"inflate_mode", 0 if request.param == "sync" else 1) == 0
-    assert lib.swc_set_tuning(b"inflate_wave_max_jobs", 0 if request.param == "lane" else 1 << 30) == 0
-    yield request.param
-    assert lib.swc_set_tuning(b"inflate_wave_max_jobs", 4096) == 0
-    assert lib.swc_set_tuning(b"inflate_mode", 0) == 0
-
-
 def test_device_present_and_native_library_loaded():
     assert swc.device_available(), "the HIP engine must run on the GPU box (no CPU fallback exists)"
 

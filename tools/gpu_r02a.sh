@@ -4,7 +4,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-r02a}; O=$R/gpurun_out/$TAG; mkdir -p
 timeout 900 python -m pytest tests/test_gpu_deflate.py -x -q > $O/pytest_deflate.log 2>&1; echo "pytest deflate rc=$?"; tail -5 $O/pytest_deflate.log
 timeout 600 python -m pytest tests/test_gpu_lz4.py tests/test_gpu_many.py -x -q > $O/pytest_lz4.log 2>&1; echo "pytest lz4/many rc=$?"; tail -5 $O/pytest_lz4.log
 timeout 600 python bench.py --no-cpu-baseline > $O/bench_deflate64k.log 2>&1; echo "bench rc=$?"; tail -1 $O/bench_deflate64k.log | cut -c1-1200
-timeout 600 python bench.py --no-cpu-baseline --tuning inflate_mode=1 > $O/bench_deflate64k_lane.log 2>&1; echo "bench lane rc=$?"; tail -1 $O/bench_deflate64k_lane.log | cut -c1-1200
+
 timeout 900 python bench.py --workload lz4_4m --steps 3 --warmup 1 --no-cpu-baseline > $O/bench_lz4_4m.log 2>&1; echo "bench lz4 rc=$?"; tail -1 $O/bench_lz4_4m.log | cut -c1-600
 cd /tmp && export TMPDIR=/tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d $O/prof_bench -o bench -- python $R/bench.py --steps 5 --warmup 1 --no-cpu-baseline > $O/prof_bench.log 2>&1; echo "rocprof rc=$?"
