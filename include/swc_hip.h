@@ -157,13 +157,19 @@ int swc_unarchive_many(int kind, const uint8_t* const* archives, const size_t* l
  *   kind 5  bzip2: every BIT offset of the 48-bit block magic (BZip2.swift:74-88) -- candidates, a magic may occur in data.
  *   kind 6  xz: the LZMA2-only blocks listed by the index of every stream (XZArchive.swift:132-192 read backwards):
  *           offset / comp_len of the LZMA2 data, uncomp_len, aux = dictionary-size byte.
+ *   kind 7  raw LZMA2 (first byte = dictionary-size byte): the chunk walk of LZMA2Decoder.decode() / dispatch()
+ *           (LZMA2Decoder.swift:36-74) without the LZMA decode: one ref per chunk, offset of its control byte, comp_len =
+ *           header + payload, uncomp_len, aux = control byte, flags bit 0 = the chunk resets the dictionary (a run of
+ *           chunks that decodes on its own starts here), bit 1 = it carries a properties byte.  The end marker is not
+ *           listed.  Returns SWC_E_LZMA2_WRONG_CONTROL_BYTE (:47-48) or SWC_E_REF_TRAP (a chunk runs past the buffer)
+ *           with the chunks before the error in refs / *n.
  * *n receives the number found; up to `cap` are written. */
 typedef struct swc_block_ref {
     uint64_t offset;      /* bytes from `in` (kind 5: bits) */
     uint64_t comp_len;
     uint64_t uncomp_len;  /* 0 = not known from the framing */
     uint32_t aux;
-    uint32_t pad;
+    uint32_t flags;       /* kind 7 only, else 0 */
 } swc_block_ref;
 int swc_index_blocks(int kind, const uint8_t* in, size_t len, swc_block_ref* refs, size_t cap, size_t* n);
 

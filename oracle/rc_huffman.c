@@ -20,7 +20,11 @@ int rc_tree_build(rc_tree* t, const int* lengths, int n) {
     int max_bits = lengths[0];
     for (int i = 1; i < n; i++) if (lengths[i] > max_bits) max_bits = lengths[i];
     if (max_bits < 0) max_bits = 0; /* every length <= 0: nothing is inserted, 1-node tree */
-    if (max_bits > 20) return SWC_E_REF_TRAP; /* only reachable through bzip2's unchecked FINAL code length (BZip2.swift:185 runs before the deltas): the reference would allocate a >= 2^22-entry tree; classified as trap-class here and in the engine */
+    /* max_bits > 20 is only reachable through bzip2's unchecked FINAL code length (BZip2.swift:185 runs before the deltas of
+     * a symbol, so the last symbol's length is never range-checked).  The reference then builds the tree like any other:
+     * (1 << (maxBits + 1)) - 1 Ints (DecodingTree.swift:19).  Followed up to maxBits 26 (1 GiB of Ints there, 512 MiB of
+     * int32 here); beyond that the allocation is the outcome and the stream is classified trap-class. */
+    if (max_bits > 26) return SWC_E_REF_TRAP;
     int64_t leaf_count = ((int64_t)1 << (max_bits + 1)) - 1; /* DecodingTree.swift:19 */
     int32_t* nodes = (int32_t*)malloc((size_t)leaf_count * sizeof(int32_t));
     if (!nodes) return SWC_E_REF_TRAP;

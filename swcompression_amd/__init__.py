@@ -260,13 +260,14 @@ def unarchive_many(kind, archives):
 
 
 class SwcBlockRef(C.Structure):
-    _fields_ = [("offset", C.c_uint64), ("comp_len", C.c_uint64), ("uncomp_len", C.c_uint64), ("aux", C.c_uint32), ("pad", C.c_uint32)]
+    _fields_ = [("offset", C.c_uint64), ("comp_len", C.c_uint64), ("uncomp_len", C.c_uint64), ("aux", C.c_uint32), ("flags", C.c_uint32)]
 
 
 def index_blocks(kind, data):
-    """Host block discovery (swc_index_blocks; no device needed).  kind: 'bgzf' | 'lz4' | 'bzip2' | 'xz'.
-    Returns [(offset, comp_len, uncomp_len, aux)]; offsets are bytes from the start (bzip2: bits)."""
-    kinds = {"bgzf": 1, "lz4": 4, "bzip2": 5, "xz": 6}
+    """Host block discovery (swc_index_blocks; no device needed).  kind: 'bgzf' | 'lz4' | 'bzip2' | 'xz' | 'lzma2'.
+    Returns [(offset, comp_len, uncomp_len, aux)] -- for 'lzma2' (offset, comp_len, uncomp_len, control byte, flags);
+    offsets are bytes from the start (bzip2: bits)."""
+    kinds = {"bgzf": 1, "lz4": 4, "bzip2": 5, "xz": 6, "lzma2": 7}
     lib = _lib.load()
     data = bytes(data)
     n = C.c_size_t()
@@ -277,4 +278,6 @@ def index_blocks(kind, data):
     st = lib.swc_index_blocks(kinds[kind], data, len(data), refs, n.value, C.byref(n))
     if st:
         _raise(st)
+    if kind == "lzma2":
+        return [(r.offset, r.comp_len, r.uncomp_len, r.aux, r.flags) for r in refs[:n.value]]
     return [(r.offset, r.comp_len, r.uncomp_len, r.aux) for r in refs[:n.value]]

@@ -25,8 +25,9 @@
 //
 // Reference semantics kept: lengths 0..20 accepted and never validated (App. A B2), surplus selectors
 // ignored / too few => wrongSelector (B3), origPtr unchecked => trap (B4), block size not enforced (B5),
-// positional RLE1 rule (B6).  Deviation: a FINAL code length > 20, which only the unchecked
-// last delta can produce, is classified as trap-class instead of building a 2^22+ entry tree.
+// positional RLE1 rule (B6).  A FINAL code length > 20, which only the unchecked last delta can produce (BZip2.swift:185
+// runs before the deltas of a symbol), is decoded like any other up to 26 bits; beyond that the reference's tree
+// (DecodingTree.swift:19: 2^(maxBits+1) Ints) is an allocation of 2 GiB and more, classified trap-class.
 #ifndef SWC_BZIP2_BLOCK_H
 #define SWC_BZIP2_BLOCK_H
 
@@ -37,12 +38,14 @@ namespace bzip2 {
 
 constexpr int kMaxSyms = 258;
 constexpr int kMaxTables = 6;
-constexpr int kMaxLen = 20;
+constexpr int kMaxLen = 26;    // 20 is the checked limit (BZip2.swift:185); the last symbol's length is unchecked
+constexpr int kCheckedLen = 20;
 
 // ---- LDS layout of stage 1 (bytes) ---------------------------------------------------------------
 struct Stage1Lds {
-    uint32_t slot[kMaxTables][kMaxLen + 2];  // slot[d] = v0 << 9 | start, slot[21] = total
-    uint32_t lim[kMaxTables][kMaxLen + 1];   // left-justified (20-bit) limits, non-decreasing
+    uint32_t first[kMaxTables][kMaxLen + 1]; // first[d] = the first code of length d (low d bits matter)
+    uint16_t start[kMaxTables][kMaxLen + 2]; // start[d] = index in sym[] of the first symbol of length d, start[kMaxLen + 1] = total
+    uint32_t lim[kMaxTables][kMaxLen + 1];   // left-justified (kMaxLen-bit) limits, non-decreasing
     uint32_t oversub[kMaxTables];
     uint32_t counts[256];                    // histogram of L
     uint16_t sym[kMaxTables][kMaxSyms + 2];  // (length, symbol)-sorted symbols
@@ -215,12 +218,13 @@ struct Stage1 {
         for (int d = 1; d <= kMaxLen; d++) {
             s->lim[t][d] = (v + cnt[d]) << (kMaxLen - d);
             if (cnt[d] != 0 && v + cnt[d] > (1u << d)) over = true;
-            s->slot[t][d] = ((v & 0xFFFFFu) << 9) | off;
+            s->first[t][d] = v;
+            s->start[t][d] = (uint16_t)off;
             start[d] = off;
             off += cnt[d];
             v = (v + cnt[d]) << 1;
         }
-        s->slot[t][kMaxLen + 1] = off;
+        s->start[t][kMaxLen + 1] = (uint16_t)off;
         s->oversub[t] = over ? 1u : 0u;
         for (int i = 0; i < count; i++) {
             int l = s->lengths[i];
@@ -247,21 +251,18 @@ struct Stage1 {
             }
             (void)my_lim;
             if (len > kMaxLen) return -1;
-            const uint32_t w = s->slot[t][len];
-            idx = (int)((w & 511u) + (c >> (kMaxLen - len)) - (w >> 9));
+            idx = (int)((uint32_t)s->start[t][len] + (c >> (kMaxLen - len)) - s->first[t][len]);
         } else {
-            uint32_t w = s->slot[t][1];
             len = 0;
             for (int d = 1; d <= kMaxLen; d++) {
-                const uint32_t wn = s->slot[t][d + 1];
-                const uint32_t cnt = (wn & 511u) - (w & 511u);
-                const uint32_t k0 = ((c >> (kMaxLen - d)) - (w >> 9)) & ((1u << d) - 1u);
+                const uint32_t st0 = s->start[t][d];
+                const uint32_t cnt = (uint32_t)s->start[t][d + 1] - st0;
+                const uint32_t k0 = ((c >> (kMaxLen - d)) - s->first[t][d]) & ((1u << d) - 1u);
                 if (k0 < cnt) {
                     len = (uint32_t)d;
-                    idx = (int)((w & 511u) + k0 + (((cnt - 1u - k0) >> d) << d));
+                    idx = (int)(st0 + k0 + (((cnt - 1u - k0) >> d) << d));
                     break;
                 }
-                w = wn;
             }
             if (idx < 0) return -1;
         }
@@ -329,7 +330,7 @@ struct Stage1 {
             if (br.bits_left() < 5) return SWC_E_BZIP2_WRONG_HUFFMAN_CODE_LENGTH;
             int length = (int)br.bits(5);
             for (int i = 0; i < used_count; i++) {
-                if (!(length >= 0 && length <= 20)) return SWC_E_BZIP2_WRONG_HUFFMAN_CODE_LENGTH;  // :185
+                if (!(length >= 0 && length <= kCheckedLen)) return SWC_E_BZIP2_WRONG_HUFFMAN_CODE_LENGTH;  // :185
                 for (;;) {
                     br.refill();
                     if (br.bits_left() <= 0) break;
@@ -343,7 +344,7 @@ struct Stage1 {
                     length -= (int)d * 2 - 1;
                 }
                 // a non-final symbol outside 0...20 is rejected at the top of the next iteration (:185); the
-                // FINAL one is never checked: <= 0 is skipped by Code.huffmanCodes, > 20 is trap-class
+                // FINAL one is never checked: <= 0 is skipped by Code.huffmanCodes, 21..26 is built, > 26 is trap-class
                 s->lengths[i] = (int8_t)(length < -128 ? -128 : length > 127 ? 127 : length);
             }
             const int st = build_table(t, used_count);

@@ -32,10 +32,11 @@ int bzip2_finish_stream(const uint8_t* d, size_t n, std::vector<HostUnit>& units
                         std::vector<uint8_t>& res, size_t& byte_pos);
 size_t lzma2_announced_size(const uint8_t* p, size_t n);
 // block discovery for swc_index_blocks (framing_many.cpp)
-struct BlockRef64 { uint64_t offset, comp_len, uncomp_len; uint32_t aux; };
+struct BlockRef64 { uint64_t offset, comp_len, uncomp_len; uint32_t aux; uint32_t flags = 0; };
 bool bgzf_index(const uint8_t* in, size_t in_len, std::vector<BlockRef64>& out);
 bool lz4_frame_index(const uint8_t* in, size_t in_len, std::vector<BlockRef64>& out);
 void bzip2_magic_index(const uint8_t* in, size_t in_len, std::vector<BlockRef64>& out);
 void xz_block_index(const uint8_t* in, size_t in_len, std::vector<BlockRef64>& out);
+int lzma2_chunk_index(const uint8_t* in, size_t in_len, std::vector<BlockRef64>& out);
 }
 #endif

@@ -417,6 +417,40 @@ void xz_block_index(const uint8_t* in, size_t in_len, std::vector<BlockRef64>& o
     std::sort(out.begin(), out.end(), [](const BlockRef64& a, const BlockRef64& b) { return a.offset < b.offset; });
 }
 
+// The chunk walk of LZMA2Decoder.decode() / dispatch() (reference Sources/LZMA2/LZMA2Decoder.swift:36-74) without the
+// LZMA decode: `in` = the dictionary-size byte followed by the chunks (what LZMA2.decompress(data:) takes,
+// LZMA2.swift:26-33).  One ref per chunk: offset of its control byte, comp_len = header + payload, uncomp_len,
+// aux = control byte; flags bit 0 = the chunk resets the dictionary (control 1, or reset 3: an independently decodable
+// run of chunks starts here), bit 1 = it carries a properties byte (reset 2, 3).  Stops at the end marker (control 0),
+// which is not listed.  Errors as the reference raises them: wrongControlByte for 3...0x7F; a chunk that runs past the
+// buffer (the reference would read out of range) is SWC_E_REF_TRAP.  Refs found before the error stay in `out`.
+int lzma2_chunk_index(const uint8_t* in, size_t in_len, std::vector<BlockRef64>& out) {
+    if (in_len < 1) return SWC_E_REF_TRAP;
+    size_t p = 1;
+    for (;;) {
+        if (p >= in_len) return SWC_E_REF_TRAP;
+        const uint8_t control = in[p];
+        if (control == 0) return SWC_OK;
+        if (control == 1 || control == 2) {                   // decodeUncompressed(): 2 size bytes + data (:76-84)
+            if (p + 3 > in_len) return SWC_E_REF_TRAP;
+            const size_t size = ((size_t)in[p + 1] << 8) + in[p + 2] + 1;
+            if (size > in_len - (p + 3)) return SWC_E_REF_TRAP;
+            out.push_back(BlockRef64{p, 3 + size, size, control, control == 1 ? 1u : 0u});
+            p += 3 + size;
+            continue;
+        }
+        if (control < 0x80) return SWC_E_LZMA2_WRONG_CONTROL_BYTE;                                   // :47-48
+        const uint32_t reset = (control & 0x60u) >> 5;                                               // :60
+        const size_t hdr = 5 + (reset >= 2 ? 1 : 0);
+        if (p + hdr > in_len) return SWC_E_REF_TRAP;
+        const size_t unpack = (((size_t)(control & 0x1Fu)) << 16) + ((size_t)in[p + 1] << 8) + in[p + 2] + 1;   // :61-62
+        const size_t comp = ((size_t)in[p + 3] << 8) + in[p + 4] + 1;                                // :63
+        if (comp > in_len - (p + hdr)) return SWC_E_REF_TRAP;
+        out.push_back(BlockRef64{p, hdr + comp, unpack, control, (reset == 3 ? 1u : 0u) | (reset >= 2 ? 2u : 0u)});
+        p += hdr + comp;
+    }
+}
+
 }  // namespace swc
 
 using namespace swc;

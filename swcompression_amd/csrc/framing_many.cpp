@@ -299,17 +299,19 @@ int swc_index_blocks(int kind, const uint8_t* in, size_t len, swc_block_ref* ref
     if (!n || (len && !in) || (cap && !refs)) return SWC_E_INVALID_ARGUMENT;
     std::vector<BlockRef64> v;
     bool ok = true;
+    int st = SWC_OK;
     switch (kind) {
         case 1: ok = bgzf_index(in, len, v); break;
         case 4: ok = lz4_frame_index(in, len, v); break;
         case 5: bzip2_magic_index(in, len, v); break;
         case 6: xz_block_index(in, len, v); break;
+        case 7: st = lzma2_chunk_index(in, len, v); break;
         default: return SWC_E_INVALID_ARGUMENT;
     }
     if (!ok) { *n = 0; return SWC_E_INVALID_ARGUMENT; }
     *n = v.size();
-    for (size_t i = 0; i < v.size() && i < cap; i++) refs[i] = swc_block_ref{v[i].offset, v[i].comp_len, v[i].uncomp_len, v[i].aux, 0};
-    return SWC_OK;
+    for (size_t i = 0; i < v.size() && i < cap; i++) refs[i] = swc_block_ref{v[i].offset, v[i].comp_len, v[i].uncomp_len, v[i].aux, v[i].flags};
+    return st;
 } catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
     if (n) *n = 0;
     return SWC_E_DEVICE;

@@ -366,3 +366,103 @@ def bzip2_fuzz(seed=17, per_base=20, n_random=300):
         body = bytes(rnd.randrange(256) for _ in range(rnd.randrange(0, 90)))
         ins.append(b"BZh9" + bytes.fromhex("314159265359") + body if rnd.random() < 0.8 else body)
     return ins
+
+
+class MsbBitWriter:
+    def __init__(self):
+        self.bits = []
+
+    def put(self, value, n):
+        for k in range(n - 1, -1, -1):
+            self.bits.append((value >> k) & 1)
+
+    def bytes(self):
+        b = self.bits + [0] * (-len(self.bits) % 8)
+        return bytes(sum(bit << (7 - k) for k, bit in enumerate(b[i:i + 8])) for i in range(0, len(b), 8))
+
+
+def _bzip2_crc(data):
+    crc = 0xFFFFFFFF
+    for byte in data:
+        crc ^= byte << 24
+        for _ in range(8):
+            crc = ((crc << 1) ^ 0x04C11DB7) & 0xFFFFFFFF if crc & 0x80000000 else (crc << 1) & 0xFFFFFFFF
+    return crc ^ 0xFFFFFFFF
+
+
+def bzip2_crafted(data, lengths, n_tables=2):
+    """A single-block .bz2 stream of `data` (no byte repeated four times in a row) whose Huffman tables all carry the given code
+    lengths (symbol order RUNA, RUNB, MTF 1.., EOB) -- including sets no encoder produces: the reference checks a length
+    against 0...20 BEFORE applying the deltas of a symbol (BZip2.swift:185), so the LAST symbol's length is never checked.
+    Codes are assigned as Code.huffmanCodes does (Code.swift:15-39)."""
+    assert all(data[i:i + 4] != data[i:i + 1] * 4 for i in range(len(data) - 3))
+    n = len(data)
+    rot = sorted(range(n), key=lambda i: data[i:] + data[:i])
+    last = bytes(data[(i - 1) % n] for i in rot)
+    orig = rot.index(0)
+    used = sorted(set(data))
+    mtf = list(used)
+    syms, run = [], 0
+
+    def flush_run():
+        nonlocal run
+        while run > 0:   # bijective base 2: RUNA = 1, RUNB = 2
+            syms.append(0 if run & 1 else 1)
+            run = (run - 1) >> 1
+
+    for b in last:
+        i = mtf.index(b)
+        if i == 0:
+            run += 1
+            continue
+        flush_run()
+        syms.append(i + 1)
+        mtf.insert(0, mtf.pop(i))
+    flush_run()
+    eob = len(used) + 1
+    syms.append(eob)
+    assert len(lengths) == eob + 1
+    # canonical codes, (length, symbol) order, lengths <= 0 skipped
+    codes, loop_bits, sym = {}, -1, -1
+    for ln, s in sorted((ln, s) for s, ln in enumerate(lengths) if ln > 0):
+        sym += 1
+        if ln != loop_bits:
+            sym <<= ln - loop_bits
+            loop_bits = ln
+        codes[s] = (sym & ((1 << ln) - 1), ln)
+    w = MsbBitWriter()
+    w.put(0x425A6839, 32)
+    w.put(0x314159265359, 48)
+    crc = _bzip2_crc(data)
+    w.put(crc, 32)
+    w.put(0, 1)
+    w.put(orig, 24)
+    groups = [0] * 16
+    for b in used:
+        groups[b >> 4] |= 0x8000 >> (b & 15)
+    w.put(sum(0x8000 >> g for g in range(16) if groups[g]), 16)
+    for g in range(16):
+        if groups[g]:
+            w.put(groups[g], 16)
+    n_sel = (len(syms) + 49) // 50
+    w.put(n_tables, 3)
+    w.put(n_sel, 15)
+    for _ in range(n_sel):
+        w.put(0, 1)   # MTF index 0 every time: table 0
+    for _ in range(n_tables):
+        cur = max(0, min(20, lengths[0]))
+        w.put(cur, 5)
+        for ln in lengths:
+            while cur < ln:
+                w.put(0b10, 2)
+                cur += 1
+            while cur > ln:
+                w.put(0b11, 2)
+                cur -= 1
+            w.put(0, 1)
+    for s in syms:
+        if s in codes:   # a symbol whose length is <= 0 has no code (Code.swift:26); the stream then simply lacks it
+            w.put(*codes[s])
+    w.put(0x177245385090, 48)
+    w.put(crc, 32)
+    return w.bytes()

@@ -52,6 +52,15 @@ def test_trivial_inputs_and_crc_errors():
     _same(bytes(z))
 
 
+def test_unchecked_final_code_length():
+    """The last symbol's code length is never range-checked (BZip2.swift:185): 21..26 bits decode, more is trap-class."""
+    d = b"banana bandana cabana " * 3
+    for eob_len in (20, 21, 22, 26, 27, 0, -3):
+        _same(S.bzip2_crafted(d, [1, 2, 3, 4, 5, 6, 7, eob_len]))
+    _same(S.bzip2_crafted(d, [2, 2, 3, 3, 3, 4, 4, 23]))
+    assert swc.BZip2.decompress(S.bzip2_crafted(d, [1, 2, 3, 4, 5, 6, 7, 24])) == d
+
+
 def test_multi_stream():
     x = corpus.p_text(5000, 4)
     two = bz2.compress(x[:10]) + bz2.compress(x[10:])

@@ -105,3 +105,43 @@ def test_bzip2_magic_scan_against_a_bit_string_search():
     want = reference(big)
     assert len(want) >= 6
     assert [r[0] for r in swc.index_blocks("bzip2", bytes(big))] == want
+
+
+def test_lzma2_chunk_walk():
+    """kind 'lzma2': LZMA2Decoder.decode()/dispatch() (LZMA2Decoder.swift:36-74) as an index: chunk boundaries sum up to the
+    whole stream, unpack sizes to the plain length, and every run of chunks that begins at a dictionary reset decodes on its
+    own (checked with the oracle)."""
+    import _oracle as O
+    x = corpus.p_text(700000, 3) + corpus.p_rand(200000, 4) + corpus.p_text(400000, 5)
+    db = corpus.lzma2_dict_byte(1 << 16)
+    raw = corpus.lzma2_raw(x, dict_size=1 << 16)
+    stream = bytes([db]) + raw
+    refs = swc.index_blocks("lzma2", stream)
+    assert len(refs) > 5
+    assert refs[0][0] == 1 and refs[0][4] & 1                       # the first chunk must reset the dictionary
+    pos = 1
+    for off, comp, unc, control, flags in refs:
+        assert off == pos and stream[off] == control
+        pos += comp
+    assert stream[pos] == 0 and pos == len(stream) - 1              # end marker right behind the last chunk
+    assert sum(r[2] for r in refs) == len(x)
+    assert any(r[3] in (1, 2) for r in refs)                        # the random part is stored uncompressed
+    # independent runs: cut at dictionary resets; each run + end marker is a stream of its own
+    starts = [i for i, r in enumerate(refs) if r[4] & 1]
+    done = 0
+    for a, b in zip(starts, starts[1:] + [len(refs)]):
+        lo, hi = refs[a][0], refs[b - 1][0] + refs[b - 1][1]
+        n = sum(r[2] for r in refs[a:b])
+        st, out, _ = O.lzma2(stream[lo:hi] + b"\x00", db)
+        assert st == 0 and out == x[done:done + n]
+        done += n
+    assert done == len(x)
+    # errors: a control byte in 3...0x7F is LZMA2Error.wrongControlByte; a chunk past the end is trap-class
+    bad = bytearray(stream); bad[refs[1][0]] = 0x40
+    with pytest.raises(swc.SWCError) as ei:
+        swc.index_blocks("lzma2", bytes(bad))
+    assert ei.value.status == O.lzma2(bytes(bad[1:]), db)[0]
+    with pytest.raises(swc.SWCError) as ei:
+        swc.index_blocks("lzma2", stream[:refs[2][0] + 4])
+    assert ei.value.status == 900
+    assert swc.index_blocks("lzma2", bytes([db, 0])) == []

@@ -81,3 +81,26 @@ def test_block_sizes_around_the_segment_geometry():
                         [max(len(x), 1) for _, x in cases], lcap=70000)
     for r, (z, x) in zip(res, cases):
         assert r[:2] == (0, x), len(x)
+
+
+def test_unchecked_final_code_length():
+    """BZip2.swift:185 checks a code length BEFORE the deltas of a symbol, so the last symbol's (EOB's) length can leave
+    0...20.  The reference builds its tree for whatever maxBits results (DecodingTree.swift:19); oracle and engine follow
+    it up to 26 bits and classify longer ones as trap-class."""
+    d = b"banana bandana cabana " * 3
+    cases = []
+    for eob_len in (20, 21, 22, 25, 26, 27, 40, 0, -3):
+        cases.append((S.bzip2_crafted(d, [1, 2, 3, 4, 5, 6, 7, eob_len]), eob_len))
+    cases.append((S.bzip2_crafted(d, [2, 2, 3, 3, 3, 4, 5, 5]), 5))
+    cases.append((S.bzip2_crafted(d, [2, 2, 3, 3, 3, 4, 4, 23]), 23))     # 4-bit codes 1110 and 1111, then EOB = 23 bits past 1111: over-subscribed
+    ins = [z for z, _ in cases]
+    exp = [O.bzip2(z) for z in ins]
+    res = E.bzip2_block(ins, [112] * len(ins), [int.from_bytes(z[10:14], "big") for z in ins], [len(d)] * len(ins))
+    for (z, eob_len), e, r in zip(cases, exp, res):
+        if 1 <= eob_len <= 26 and eob_len != 23:
+            assert e[:2] == (0, d), eob_len
+        if eob_len > 26:
+            assert e[0] == 900
+        assert r[0] == e[0], (eob_len, r[0], e[0])
+        if e[0] == 0:
+            assert r[1] == e[1]
