@@ -148,6 +148,13 @@ int swc_xz_split_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size
  * 3 = raw deflate, 4 = LZ4 frame, 5 = bzip2 stream, 6 = xz stream, 7 = raw LZMA2 (first byte = dict byte). */
 int swc_unarchive_many(int kind, const uint8_t* const* archives, const size_t* lens, size_t n,
                        uint8_t** outs, size_t* out_lens, int32_t* statuses);
+/* The same over several GPUs of one node (the reference has no counterpart: its callers loop over archives on one core).
+ * devices[0..n_devices) are HIP device ordinals (a device may be listed more than once); the archive list is cut into one
+ * contiguous range per entry, balanced by compressed bytes, and every range is decoded on its device by its own host
+ * thread.  The archives are independent, so there is no exchange between devices; results land at their archive's index
+ * exactly as swc_unarchive_many returns them.  SWC_E_DEVICE if an ordinal does not name a gfx950 device. */
+int swc_unarchive_many_devices(int kind, const uint8_t* const* archives, const size_t* lens, size_t n,
+                               const int* devices, size_t n_devices, uint8_t** outs, size_t* out_lens, int32_t* statuses);
 
 /* Block discovery on the host, as a library call (no device needed) -- what swc_unarchive_many / the multi-member entry
  * points use internally, for callers that stage their data on the device themselves:

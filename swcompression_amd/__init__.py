@@ -241,9 +241,11 @@ class LZ4:
         return _call_multi("swc_lz4_multi_decompress", data, d, 0 if d is None else len(d), did)
 
 
-def unarchive_many(kind, archives):
+def unarchive_many(kind, archives, devices=None):
     """Host-side discovery + ONE batched launch for many independent archives.
-    kind: 'gzip' | 'zlib' | 'deflate' | 'lz4' | 'bzip2' | 'xz' | 'lzma2'.  Returns list of (status, bytes)."""
+    kind: 'gzip' | 'zlib' | 'deflate' | 'lz4' | 'bzip2' | 'xz' | 'lzma2'.  Returns list of (status, bytes).
+    devices: a list of device ordinals to spread the archives over (swc_unarchive_many_devices: one contiguous range of
+    the list per device, balanced by compressed bytes, each on its own host thread); default: the current device."""
     kinds = {"gzip": 1, "zlib": 2, "deflate": 3, "lz4": 4, "bzip2": 5, "xz": 6, "lzma2": 7}
     lib = _lib.load()
     n = len(archives)
@@ -253,7 +255,11 @@ def unarchive_many(kind, archives):
     outs = (C.POINTER(C.c_uint8) * n)()
     out_lens = (C.c_size_t * n)()
     sts = (C.c_int32 * n)()
-    rc = lib.swc_unarchive_many(kinds[kind], arr, lens, n, outs, out_lens, sts)
+    if devices is None:
+        rc = lib.swc_unarchive_many(kinds[kind], arr, lens, n, outs, out_lens, sts)
+    else:
+        devs = (C.c_int * len(devices))(*devices)
+        rc = lib.swc_unarchive_many_devices(kinds[kind], arr, lens, n, devs, len(devices), outs, out_lens, sts)
     if rc:
         _raise(rc)
     return [(sts[i], _take(outs[i], out_lens[i])) for i in range(n)]

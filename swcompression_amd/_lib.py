@@ -74,6 +74,8 @@ def load():
     sig("swc_7z_unpack_folders", I, C.c_void_p, C.c_size_t)
     sig("swc_index_blocks", I, I, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, szp)
     sig("swc_unarchive_many", I, I, C.POINTER(C.c_char_p), szp, C.c_size_t, u8pp, szp, C.POINTER(C.c_int32))
+    sig("swc_unarchive_many_devices", I, I, C.POINTER(C.c_char_p), szp, C.c_size_t, C.POINTER(C.c_int), C.c_size_t, u8pp, szp,
+        C.POINTER(C.c_int32))
     sig("swc_crc32", C.c_uint32, C.c_char_p, C.c_size_t, C.c_uint32)
     sig("swc_adler32", C.c_uint32, C.c_char_p, C.c_size_t)
     sig("swc_crc64", C.c_uint64, C.c_char_p, C.c_size_t)

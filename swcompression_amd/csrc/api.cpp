@@ -19,23 +19,35 @@ namespace swc {
 
 static std::once_flag g_dev_once;
 static bool g_dev_ok = false;
+static std::mutex g_dev_mu;
+static std::vector<int> g_dev_state;   // per device: 0 not looked at, 1 gfx950, 2 something else
 
-bool device_ready() {
-    std::call_once(g_dev_once, [] {
-        int n = 0;
-        if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return; }
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
+// The code object in this library is gfx950 only.
+bool device_is_gfx950(int dev) {
+    std::lock_guard<std::mutex> lk(g_dev_mu);
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { (void)hipGetLastError(); return false; }
+    if (dev < 0 || dev >= n) return false;
+    if (g_dev_state.size() < (size_t)n) g_dev_state.resize(n, 0);
+    if (g_dev_state[dev] == 0) {
         hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return; }
-        // The code object in this library is gfx950 only.
-        g_dev_ok = strncmp(prop.gcnArchName, "gfx950", 6) == 0;
-        if (g_dev_ok) {   // keep freed staging buffers of the single-shot calls in the pool instead of returning them to the OS
+        if (hipGetDeviceProperties(&prop, dev) != hipSuccess) { (void)hipGetLastError(); return false; }
+        g_dev_state[dev] = strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 2;
+        if (g_dev_state[dev] == 1) {   // keep freed staging buffers of the single-shot calls in the pool instead of returning them to the OS
             hipMemPool_t pool;
             uint64_t keep = 1ull << 30;
             if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
             (void)hipGetLastError();
         }
+    }
+    return g_dev_state[dev] == 1;
+}
+
+bool device_ready() {
+    std::call_once(g_dev_once, [] {
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return; }
+        g_dev_ok = device_is_gfx950(dev);
     });
     return g_dev_ok;
 }
@@ -79,7 +91,7 @@ uint8_t* pinned_stage(int which, size_t n) {
     if (b.cap < n) {
         if (b.p) { (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
         size_t want = std::max<size_t>(n + n / 4, (size_t)1 << 20);
-        if (hipHostMalloc(&b.p, want, hipHostMallocDefault) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; return nullptr; }
+        if (hipHostMalloc(&b.p, want, hipHostMallocPortable) != hipSuccess) { (void)hipGetLastError(); b.p = nullptr; return nullptr; }
         b.cap = want;
     }
     return static_cast<uint8_t*>(b.p);

@@ -8,6 +8,7 @@
 //                             location and sizes the central directory already gave to the caller.
 #include <algorithm>
 #include <memory>
+#include <thread>
 #include <vector>
 #include "framing.h"
 
@@ -148,6 +149,15 @@ int many_xz(const uint8_t* const* archives, const size_t* lens, size_t n, std::v
     return SWC_OK;
 }
 
+int many_dispatch(int kind, const uint8_t* const* archives, const size_t* lens, size_t n, std::vector<Result>& res) {
+    switch (kind) {
+        case 4: return many_lz4(archives, lens, n, res);
+        case 5: return many_bzip2(archives, lens, n, res);
+        case 6: return many_xz(archives, lens, n, res);
+        default: return many_single_unit(kind, archives, lens, n, res);
+    }
+}
+
 }  // namespace
 }  // namespace swc
 
@@ -161,18 +171,63 @@ int swc_unarchive_many(int kind, const uint8_t* const* archives, const size_t* l
     for (size_t i = 0; i < n; i++) if (lens[i] && !archives[i]) return SWC_E_INVALID_ARGUMENT;
     if (!device_ready()) return SWC_E_DEVICE;
     std::vector<Result> res(n);
-    int st;
-    switch (kind) {
-        case 4: st = many_lz4(archives, lens, n, res); break;
-        case 5: st = many_bzip2(archives, lens, n, res); break;
-        case 6: st = many_xz(archives, lens, n, res); break;
-        default: st = many_single_unit(kind, archives, lens, n, res);
-    }
+    const int st = many_dispatch(kind, archives, lens, n, res);
     if (st) return st;
     hand_over(res, outs, out_lens, statuses);
     return SWC_OK;
 } catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
     for (size_t i = 0; i < n; i++) { outs[i] = host_result(0); out_lens[i] = 0; statuses[i] = SWC_E_DEVICE; }   // (results are handed over last: nothing of theirs is lost)
+    return SWC_E_DEVICE;
+}
+
+// swc_unarchive_many over several GPUs of one node: the archives are independent, so the list is cut into one contiguous
+// range per device, balanced by compressed bytes, and every range runs the single-device path on its own host thread with
+// its own device current (stream, staging buffers and workspace are per thread, api.cpp).  No data-path exchange between
+// devices: results are simply placed at their archive's index.
+int swc_unarchive_many_devices(int kind, const uint8_t* const* archives, const size_t* lens, size_t n,
+                               const int* devices, size_t n_devices, uint8_t** outs, size_t* out_lens, int32_t* statuses) try {
+    if (kind < 1 || kind > 7 || (n && (!archives || !lens || !outs || !out_lens || !statuses)) || !devices || n_devices == 0)
+        return SWC_E_INVALID_ARGUMENT;
+    for (size_t i = 0; i < n; i++) if (lens[i] && !archives[i]) return SWC_E_INVALID_ARGUMENT;
+    if (!device_ready()) return SWC_E_DEVICE;
+    for (size_t d = 0; d < n_devices; d++) if (!device_is_gfx950(devices[d])) return SWC_E_DEVICE;
+    // contiguous ranges of (about) equal compressed bytes; +1 per archive so that empty inputs spread as well
+    std::vector<size_t> cut(n_devices + 1, n);
+    cut[0] = 0;
+    {
+        unsigned __int128 total = 0;
+        for (size_t i = 0; i < n; i++) total += (unsigned __int128)lens[i] + 1;
+        unsigned __int128 acc = 0;
+        size_t d = 1;
+        for (size_t i = 0; i < n && d < n_devices; i++) {
+            acc += (unsigned __int128)lens[i] + 1;
+            while (d < n_devices && acc * n_devices >= total * d) cut[d++] = i + 1;
+        }
+    }
+    std::vector<Result> res(n);
+    std::vector<int> st(n_devices, SWC_OK);
+    std::vector<std::thread> workers;
+    for (size_t d = 0; d < n_devices; d++) {
+        const size_t lo = cut[d], hi = cut[d + 1];
+        if (lo >= hi) continue;
+        workers.emplace_back([&, d, lo, hi] {
+            try {
+                if (hipSetDevice(devices[d]) != hipSuccess) { (void)hipGetLastError(); st[d] = SWC_E_DEVICE; return; }
+                std::vector<Result> part(hi - lo);
+                st[d] = many_dispatch(kind, archives + lo, lens + lo, hi - lo, part);
+                if (st[d] == SWC_OK)
+                    for (size_t i = lo; i < hi; i++) res[i] = std::move(part[i - lo]);
+            } catch (...) {
+                st[d] = SWC_E_DEVICE;
+            }
+        });
+    }
+    for (std::thread& w : workers) w.join();
+    for (size_t d = 0; d < n_devices; d++) if (st[d]) return st[d];
+    hand_over(res, outs, out_lens, statuses);
+    return SWC_OK;
+} catch (...) {
+    for (size_t i = 0; i < n; i++) { outs[i] = host_result(0); out_lens[i] = 0; statuses[i] = SWC_E_DEVICE; }
     return SWC_E_DEVICE;
 }
 

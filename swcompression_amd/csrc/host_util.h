@@ -50,6 +50,7 @@ uint8_t* pinned_stage(int which, size_t n);
 // malloc()ed host result handed to the caller (released with swc_free); never NULL.
 inline uint8_t* host_result(size_t n) { return static_cast<uint8_t*>(malloc(n ? n : 1)); }
 
+bool device_is_gfx950(int dev);  // api.cpp: device `dev` exists and is a gfx950 (also prepares its memory pool, once)
 bool device_ready();  // api.cpp: true when a gfx950 device is present and selected
 
 // One unit of work for the host-side batch runner (host pointers; the runner stages to HBM).

@@ -85,6 +85,7 @@ def test_no_cpu_fallback_without_gpu():
         lambda: swc.LZ4.decompress(corpus.lz4_frame(x)),
         lambda: swc.unarchive_many("gzip", [corpus.gzip_member(x)]),
         lambda: swc.unarchive_many("bzip2", [corpus.bzip2_stream(x)]),
+        lambda: swc.unarchive_many("gzip", [corpus.gzip_member(x)] * 3, devices=[0, 1]),
         lambda: ZipContainer.open(_one_entry_zip(x)),
     ]
     for c in calls:

@@ -217,3 +217,27 @@ def test_lz4_multi_frame_one_launch():
             with pytest.raises(swc.SWCError) as ei:
                 swc.LZ4.multi_decompress(bad)
             assert ei.value.status == st, k
+
+
+def test_many_over_a_device_list():
+    """swc_unarchive_many_devices: the archive list cut into one range per listed device, each decoded by its own host
+    thread.  One GPU here, so the list names device 0 several times -- same code path, same results as the one-device call
+    and as the oracle, in the archives' order; ranges may be empty (more devices than archives)."""
+    ps = _payloads(900, k=40)
+    for kind, enc, ora in (("gzip", corpus.gzip_member, O.gzip_unarchive), ("bzip2", corpus.bzip2_stream, O.bzip2),
+                           ("lz4", corpus.lz4_frame, O.lz4), ("xz", corpus.xz_stream, O.xz_unarchive)):
+        arch = [enc(p) for p in ps]
+        arch[7] = _damage(arch[7])
+        one = swc.unarchive_many(kind, arch)
+        for devs in ([0], [0, 0], [0, 0, 0, 0, 0]):
+            assert swc.unarchive_many(kind, arch, devices=devs) == one
+        for (st, data), a in zip(one, arch):
+            est, edata = ora(a)[:2]
+            assert st == est and (est != 0 or data == edata)
+    few = [corpus.gzip_member(ps[3]), corpus.gzip_member(ps[4])]
+    assert [d for _, d in swc.unarchive_many("gzip", few, devices=[0] * 8)] == [ps[3], ps[4]]
+    assert swc.unarchive_many("gzip", [], devices=[0, 0]) == []
+    with pytest.raises(swc.DeviceError):
+        swc.unarchive_many("gzip", few, devices=[0, 99])       # no such gfx950 device: loud, nothing decoded elsewhere
+    with pytest.raises(swc.SWCError):
+        swc.unarchive_many("gzip", few, devices=[])
