@@ -41,28 +41,28 @@ namespace inflate {
 
 constexpr int kSyncLitBits = 10, kSyncDistBits = 9;
 #ifndef SWC_SYNC_CHUNK
-#define SWC_SYNC_CHUNK 64
+#define SWC_SYNC_CHUNK 68
 #endif
-constexpr uint32_t kSyncChunk = SWC_SYNC_CHUNK;      // input bytes per lane and round (a multiple of 4)
+// Input bytes per lane and round: a whole number of dwords and an ODD number of them (17), so that the lanes, which start
+// a pass at the same offset of their sub-chunks, read 64 different LDS banks without any padding of the staged input.
+constexpr uint32_t kSyncChunk = SWC_SYNC_CHUNK;
 constexpr uint32_t kSyncRound = 64u * kSyncChunk;
-constexpr uint32_t kSyncStage = kSyncRound + 128u;   // + what the last lane may read past its sub-chunk
-// The staged input is laid out with ONE pad dword behind every sub-chunk: the lanes start a pass at the same offset of
-// their sub-chunks, and with a power-of-two stride all of them would hit the same LDS bank.
-constexpr uint32_t kSyncChunkDwords = kSyncChunk / 4;
-static_assert((kSyncChunkDwords & (kSyncChunkDwords - 1)) == 0, "the pad arithmetic wants a power of two");
-SWC_HD uint32_t stage_slot(uint32_t dword) { return dword + dword / kSyncChunkDwords; }
-constexpr uint32_t kSyncStageLds = kSyncStage + 4u * (kSyncStage / kSyncChunk + 2u);
+constexpr uint32_t kSyncStage = (kSyncRound + 128u + 15u) & ~15u;   // + what the last lane may read past its sub-chunk
+constexpr uint32_t kSyncStageLds = kSyncStage + 16u;
 constexpr uint32_t kEntInvalid = 0x80000000u;        // a code of the set, but not a symbol the fast path takes
 constexpr uint32_t kPosFail = 0xFFFFFFFFu;
 static_assert(kSyncChunk % 4 == 0 && kSyncChunk >= 64, "sub-chunks are whole dwords");
 
 // Table entry, laid out for a decode loop without branches per kind:
-//   [0:4] bits the symbol takes (code + extra)   [5] length symbol: the next code is a distance   [6] end of block
-//   [7] literal   [8:11] code length   [12:15] extra bits   [16:30] base value   [31] invalid.   0: no entry (long code).
-constexpr uint32_t kEntLen = 1u << 5, kEntEob = 1u << 6, kEntLit = 1u << 7;
+//   [0:4] bits the symbol takes (code + extra)   [5] end of block   [6:9] code length   [10] length symbol: the next code is
+//   a distance (the bit IS the offset of the distance table in `lut`)   [11:14] extra bits   [15] literal
+//   [16:30] base value   [31] invalid.   0: no entry (long code).
+constexpr uint32_t kEntEob = 1u << 5, kEntLen = 1u << kSyncLitBits, kEntLit = 1u << 15;
+constexpr uint32_t kEntClenShift = 6, kEntExtShift = 11;
+static_assert(kSyncLitBits == 10, "the entry layout keeps bit 10 for the length flag");
 // kind, lit/len table: 1 literal, 2 length, 3 end of block; distance table: 0 distance.
 SWC_HD uint32_t make_entry(uint32_t clen, uint32_t ext, uint32_t kind, uint32_t value) {
-    return (clen + ext) | (kind == 1 ? kEntLit : kind == 2 ? kEntLen : kind == 3 ? kEntEob : 0u) | (clen << 8) | (ext << 12) | (value << 16);
+    return (clen + ext) | (kind == 1 ? kEntLit : kind == 2 ? kEntLen : kind == 3 ? kEntEob : 0u) | (clen << kEntClenShift) | (ext << kEntExtShift) | (value << 16);
 }
 
 // The canonical tables of inflate_lane.h (struct Table) kept in LDS: per length d the left-justified code limit, the slot
@@ -76,7 +76,7 @@ struct SyncLds {
     uint32_t lut[(1 << kSyncLitBits) + (1 << kSyncDistBits)];      // direct tables: lit/len, then distance
     uint32_t symtab[320];                                           // one entry per sorted symbol: lit/len at 0, distance at 288
     uint32_t aux[kAuxWords];                                        // the canonical tables (see kAux*)
-    alignas(16) uint8_t stage[kSyncStageLds];                       // staged input of a round (padded, see stage_slot); header build: code lengths, counters, code-length table
+    alignas(16) uint8_t stage[kSyncStageLds];                       // staged input of a round; header build: code lengths, counters, code-length table
 };
 // header scratch inside `stage`
 constexpr uint32_t kHdrLens = 0;       // 320 bytes: code length of symbol s
@@ -386,23 +386,24 @@ struct LongCodes {
 template <int MODE, bool BIG, bool CHK>
 SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr lit_dst,
                         SWC_AS_GLOBAL uint32_t* rec_dst, uint64_t out_pos0, ChunkOut& r) {
-    const uint32_t* st32 = (const uint32_t*)sl->stage;
-    uint32_t w = start >> 5, bp = start & 31u;
-    uint32_t d0 = st32[stage_slot(w)], d1 = st32[stage_slot(w + 1)], d2 = st32[stage_slot(w + 2)];
+    const uint8_t* stg = sl->stage;
+    uint32_t wa = (start >> 5) << 2, bp = start & 31u;    // the window: dwords at byte offset wa and wa + 4 of the staged input, bit bp of it is next
+    uint32_t d0 = *(const uint32_t*)(stg + wa), d1 = *(const uint32_t*)(stg + wa + 4);
     uint32_t tsel = 0, tmsk = (1u << kSyncLitBits) - 1u;   // the table of the next code: dword offset into `lut` and index mask
     uint32_t plen = 0, run = 0, nlit = 0, nrec = 0, nout = 0, flags = 0;
-    uint64_t lb = 0;
-    uint32_t lbn = 0;
-    // The wave is bound by the LATENCY of this loop (one dependent LDS lookup per code, few waves per SIMD): the body is
-    // one straight line of selects -- no branch per kind of symbol, the window's next dword is read whether the window
-    // moves on or not, everything rare (long code, end of block, anything invalid) sits behind ONE test.
+    uint32_t lb = 0, lbn = 0;                              // literals on their way to the literal stream, four per store
+    const uint32_t room = out_pos0 > 0x40000000ull ? 0x40000000u : (uint32_t)out_pos0;   // output in front of the sub-chunk, as far as a distance can reach
+    // The loop is bound by the number of vector instructions it issues (measured: the SIMDs' VALU pipes are busy 80 % of
+    // the kernel), so the body is one straight line of few selects -- no branch per kind of symbol, the window's next dword
+    // is read whether the window moves on or not, everything rare (long code, end of block, anything invalid) sits behind
+    // ONE test.
     for (;;) {
-        const uint32_t posb = (w << 5) + bp;
+        const uint32_t posb = (wa << 3) + bp;
         if ((uint32_t)(tsel == 0) & (uint32_t)(posb >= chunk_end)) break;   // (bitwise: one compare pair, no nested mask region)
         SWC_SYNC_STAT(4 + (MODE == 3 ? 0 : MODE), 1);   // code iterations per mode
         const uint32_t bits = funnel32(d1, d0, bp);
-        uint32_t e = sl->lut[(bits & tmsk) + tsel];
-        const uint32_t nx = st32[stage_slot(w + 3)];
+        uint32_t e = sl->lut[(bits & tmsk) | tsel];
+        const uint32_t nx = *(const uint32_t*)(stg + wa + 8);
         if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, tsel); }   // a code longer than the direct table (or no code at all)
         const uint32_t n = e & 31u;
         if ((e & (kEntInvalid | kEntEob)) || (CHK && posb + n > in_bits)) {
@@ -413,14 +414,14 @@ SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, u
         }
         const bool was_dist = tsel != 0;
         if (MODE != 3) {
-            const uint32_t is_lit = (e >> 7) & 1u;
-            const uint32_t val = ((e >> 16) & 0x7FFFu) + bfe32(bits, (e >> 8) & 15u, (e >> 12) & 15u);
-            if (MODE != 0 && was_dist && (uint64_t)val > out_pos0 + nout) { flags |= kFlagTrap; break; }
+            const uint32_t is_lit = (e >> 15) & 1u;
+            const uint32_t val = ((e >> 16) & 0x7FFFu) + bfe32(bits, (e >> kEntClenShift) & 15u, (e >> kEntExtShift) & 15u);
+            if (MODE != 0 && was_dist && val > room + nout) { flags |= kFlagTrap; break; }
             const bool big = BIG && was_dist && run > lzr::kLitRunMax;
             if (MODE == 1) {
                 if (is_lit) {
-                    lb |= (uint64_t)val << (8 * lbn);
-                    if (++lbn == 8) { store_u64(lit_dst, lb); lit_dst += 8; lb = 0; lbn = 0; }
+                    lb = funnel32(val, lb, 8);            // the new byte enters at the top: after four the dword is in stream order
+                    if (++lbn == 4) { store_u32(lit_dst, lb); lit_dst += 4; lbn = 0; }
                 }
                 if (was_dist) {
                     if (big) *rec_dst++ = lzr::make_lits(run);
@@ -433,25 +434,24 @@ SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, u
             run = was_dist ? 0u : run + is_lit;
             plen = (e & kEntLen) ? val : plen;
         }
-        tsel = (e & kEntLen) << (kSyncLitBits - 5);                         // 0, or 1 << kSyncLitBits: the distance table follows the lit/len table
-        tmsk = ((1u << kSyncLitBits) - 1u) - (tsel >> 1);                   // 10-bit index, or 9-bit
+        tsel = e & kEntLen;                                                 // 0, or 1 << kSyncLitBits: the distance table follows the lit/len table
+        tmsk = ((1u << kSyncLitBits) - 1u) >> (tsel >> kSyncLitBits);       // 10-bit index, or 9-bit
         static_assert(kSyncDistBits == kSyncLitBits - 1, "the mask arithmetic above");
         bp += n;
         const bool sh = bp >= 32;
-        w += sh ? 1u : 0u;
+        wa += sh ? 4u : 0u;
         bp &= 31u;
         d0 = sh ? d1 : d0;
-        d1 = sh ? d2 : d1;
-        d2 = sh ? nx : d2;
+        d1 = sh ? nx : d1;
     }
     if (MODE != 3 && run > 0) {   // the sub-chunk closes its literal run itself
         nrec++;
         if (MODE == 1) *rec_dst++ = lzr::make_lits(run);
     }
     if (MODE == 1) {
-        for (uint32_t i = 0; i < lbn; i++) lit_dst[i] = (uint8_t)(lb >> (8 * i));
+        for (uint32_t i = 0; i < lbn; i++) lit_dst[i] = (uint8_t)(lb >> (8 * (4u - lbn + i)));   // the pending bytes sit at the top
     }
-    r.end = (flags & kFlagFail) ? kPosFail : (w << 5) + bp;
+    r.end = (flags & kFlagFail) ? kPosFail : (wa << 3) + bp;
     r.nlit = nlit; r.nrec = nrec; r.nout = nout;
     r.flags = flags;
 }
@@ -490,9 +490,8 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                     for (uint32_t k = 0; k < 8; k++) if (at + k < in_len) a |= (uint64_t)in[at + k] << (8 * k);
                     for (uint32_t k = 0; k < 8; k++) if (at + 8 + k < in_len) b |= (uint64_t)in[at + 8 + k] << (8 * k);
                 }
-                uint32_t* st32 = (uint32_t*)sl->stage;   // (a 16-byte piece never straddles a sub-chunk: the pad keeps its dwords together)
-                const uint32_t d = stage_slot(o >> 2);
-                st32[d] = (uint32_t)a; st32[d + 1] = (uint32_t)(a >> 32); st32[d + 2] = (uint32_t)b; st32[d + 3] = (uint32_t)(b >> 32);
+                uint32_t* st32 = (uint32_t*)(sl->stage + o);
+                st32[0] = (uint32_t)a; st32[1] = (uint32_t)(a >> 32); st32[2] = (uint32_t)b; st32[3] = (uint32_t)(b >> 32);
             }
             start[t] = t == 0 ? q0 : (uint32_t)t * kSyncChunk * 8u;
         SIMT_END_WAVE

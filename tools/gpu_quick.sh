@@ -1,6 +1,7 @@
 #!/bin/bash
-R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out; mkdir -p $O; cd $R
-timeout 600 python -m pytest tests/test_gpu_deflate.py -x -q 2>&1 | tail -3
-timeout 300 python tools/exp_deflate.py > $O/exp3.log 2>&1; tail -5 $O/exp3.log
-timeout 600 python bench.py --no-cpu-baseline > $O/bench_q.log 2>&1; tail -1 $O/bench_q.log | python -c "
-import json,sys; d=json.loads(sys.stdin.read()); print('GiB/s=%.1f ms=%.2f'%(d['value'], d['ms_per_step']), d['roofline'].get('per_kernel_ms'))"
+# Quick pass: Deflate parity tests + the headline bench line with per-kernel times.  Usage: gpu_quick.sh <tag>
+R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-quick}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
+timeout 600 python -m pytest tests/test_gpu_deflate.py -x -q > $O/pytest.log 2>&1; echo "pytest rc=$?"; tail -2 $O/pytest.log
+timeout 600 python bench.py --no-cpu-baseline --no-per-codec --steps 5 > $O/bench_deflate64k.log 2>&1; echo "bench rc=$?"; tail -1 $O/bench_deflate64k.log | python -c "
+import sys, json
+d = json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'], d['roofline'].get('per_kernel_ms'))"
