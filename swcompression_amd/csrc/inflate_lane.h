@@ -17,6 +17,7 @@
 
 #include "swc_common.h"
 #include "lz_resolve.h"
+#include "simt.h"
 
 namespace swc {
 namespace inflate {
@@ -26,6 +27,9 @@ constexpr int W_DIST_SYM = 72;   //  8 words : 32 x 8-bit symbols
 constexpr int kWordsPerLane = 80;
 // LSB-first bit reader (BitByteData.LsbBitReader contract) with a 64-bit window
 // and one dword of read-ahead so the HBM/L2 latency of the next refill is hidden behind decode work.
+// One reader per WAVEFRONT: every lane holds the same state.  The prefetched dword is declared wave-uniform where it
+// enters the window (simt::uniform), so the window arithmetic of the serial parts (block headers, code-length section,
+// checked steps) runs on the scalar unit and leaves the vector pipes -- the kernel's bottleneck -- to the other waves.
 struct BitReader {
     gcptr in;
     uint32_t len;    // stream length in bytes
@@ -56,15 +60,15 @@ struct BitReader {
     // after refill(): bc >= 33 unless the stream has fewer bits left
     SWC_HD void refill() {
         if (bc <= 32) {
-            bb |= (uint64_t)nextw << bc;
-            bc += nextn * 8;
+            bb |= (uint64_t)simt::uniform(nextw) << bc;
+            bc += simt::uniform(nextn) * 8;
             prefetch();
         }
     }
     // refill() for the interior of the stream: the caller guarantees ppos + 4 <= len, so nextn == 4
     SWC_HD void refill_fast() {
         if (bc <= 32) {
-            bb |= (uint64_t)nextw << bc;
+            bb |= (uint64_t)simt::uniform(nextw) << bc;
             bc += 32;
             nextw = load_u32(in + ppos);
             ppos += 4;

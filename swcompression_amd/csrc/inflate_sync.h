@@ -87,6 +87,7 @@ enum { kSyncEob = 0, kSyncBail = 1, kSyncBailCap = 2 };
 #if defined(SWC_HOST_EMULATION)
 // statistics of the emulated decoder (tests, tools/sync_stats.py): rounds committed, bails, lane-passes, symbol iterations
 inline uint64_t g_sync_stats[8];
+inline uint64_t g_sync_iters = 0, g_sync_wave[4] = {0, 0, 0, 0}, g_sync_passmax = 0;
 #define SWC_SYNC_STAT(i, n) (g_sync_stats[i] += (n))
 #else
 #define SWC_SYNC_STAT(i, n) ((void)0)
@@ -336,39 +337,26 @@ SWC_HD uint32_t bfe32(uint32_t v, uint32_t off, uint32_t width) {   // width 0..
 #endif
 }
 
-// The canonical limits and slot words of the code lengths 10..15 of both alphabets, in registers while the rounds run:
-// a code longer than the direct tables is resolved with compares and ONE LDS read (its symbol entry).
-// (Scalar members and an opaque selector on purpose: with arrays LLVM folds `st ? a[d] : b[d]` into a dynamically
-// indexed load, which moves the whole table to scratch memory.)
+// A code longer than the direct tables: resolved from the canonical limits and slot words of the lengths 10..15 in LDS
+// (`aux`; a dozen reads the compiler pairs up) with compares, plus ONE read of its symbol entry.  The wave pays for this
+// path whenever ANY lane meets such a code (about one iteration in seven on text), so it is kept short: the alphabet only
+// selects a base address.
 struct LongCodes {
-    uint32_t l0, l1, l2, l3, l4, l5, m0, m1, m2, m3, m4, m5;   // limits of the lengths 10..15: lit/len, distance
-    uint32_t s0, s1, s2, s3, s4, s5, t0, t1, t2, t3, t4, t5;   // slot words likewise
-    SWC_D void load(const SyncLds* sl) {
-        const uint32_t* a = sl->aux + kAuxLit + kAuxLim + 10;
-        const uint32_t* b = sl->aux + kAuxDist + kAuxLim + 10;
-        const uint32_t* c = sl->aux + kAuxLit + kAuxSlot + 10;
-        const uint32_t* d = sl->aux + kAuxDist + kAuxSlot + 10;
-        l0 = a[0]; l1 = a[1]; l2 = a[2]; l3 = a[3]; l4 = a[4]; l5 = a[5];
-        m0 = b[0]; m1 = b[1]; m2 = b[2]; m3 = b[3]; m4 = b[4]; m5 = b[5];
-        s0 = c[0]; s1 = c[1]; s2 = c[2]; s3 = c[3]; s4 = c[4]; s5 = c[5];
-        t0 = d[0]; t1 = d[1]; t2 = d[2]; t3 = d[3]; t4 = d[4]; t5 = d[5];
-    }
-    // the entry of the code that starts `bits` (state: 0 lit/len, 1 distance); kEntInvalid if there is none
-    SWC_D uint32_t lookup(const SyncLds* sl, uint32_t bits, uint32_t state) const {   // state: 0 lit/len, anything else distance
+    SWC_D void load(const SyncLds*) {}
+    // the entry of the code that starts `bits` (state: 0 lit/len, anything else distance); kEntInvalid if there is none
+    SWC_D uint32_t lookup(const SyncLds* sl, uint32_t bits, uint32_t state) const {
         const uint32_t c15 = brev32(bits) >> 17;
-        uint32_t sel = state;
-        SWC_OPAQUE(sel);
-        const bool st = sel != 0;
+        const bool st = state != 0;
+        const uint32_t* tb = sl->aux + (st ? kAuxDist : kAuxLit);
         // the limits do not decrease with the length: count how many the window reaches, keep the slot word of that length
-        const bool g0 = c15 >= (st ? m0 : l0), g1 = c15 >= (st ? m1 : l1), g2 = c15 >= (st ? m2 : l2);
-        const bool g3 = c15 >= (st ? m3 : l3), g4 = c15 >= (st ? m4 : l4), g5 = c15 >= (st ? m5 : l5);
-        const uint32_t len = 10u + (g0 ? 1u : 0u) + (g1 ? 1u : 0u) + (g2 ? 1u : 0u) + (g3 ? 1u : 0u) + (g4 ? 1u : 0u) + (g5 ? 1u : 0u);
-        uint32_t slw = st ? t0 : s0;
-        slw = g0 ? (st ? t1 : s1) : slw;
-        slw = g1 ? (st ? t2 : s2) : slw;
-        slw = g2 ? (st ? t3 : s3) : slw;
-        slw = g3 ? (st ? t4 : s4) : slw;
-        slw = g4 ? (st ? t5 : s5) : slw;
+        uint32_t len = 10u, slw = tb[kAuxSlot + 10];
+#pragma unroll
+        for (int d = 10; d < 15; d++) {
+            const bool g = c15 >= tb[kAuxLim + d];
+            len += g ? 1u : 0u;
+            slw = g ? tb[kAuxSlot + d + 1] : slw;
+        }
+        len += c15 >= tb[kAuxLim + 15] ? 1u : 0u;
         const uint32_t lenc = len > 15 ? 15u : len;
         uint32_t j = (slw + (c15 >> (15 - lenc))) & 0xFFFFu;
         const uint32_t jmax = st ? 31u : 287u;
@@ -401,6 +389,9 @@ SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, u
         const uint32_t posb = (wa << 3) + bp;
         if ((uint32_t)(tsel == 0) & (uint32_t)(posb >= chunk_end)) break;   // (bitwise: one compare pair, no nested mask region)
         SWC_SYNC_STAT(4 + (MODE == 3 ? 0 : MODE), 1);   // code iterations per mode
+#if defined(SWC_HOST_EMULATION)
+        g_sync_iters++;
+#endif
         const uint32_t bits = funnel32(d1, d0, bp);
         uint32_t e = sl->lut[(bits & tmsk) | tsel];
         const uint32_t nx = *(const uint32_t*)(stg + wa + 8);
@@ -504,10 +495,18 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
         SWC_SPC(pf, 8, 1);
         SIMT_BEGIN(t, N)
             ChunkOut r;
+#if defined(SWC_HOST_EMULATION)
+            if (t == 0) g_sync_passmax = 0;
+            const uint64_t it0_ = g_sync_iters;
+#endif
             const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
             if (chk) decode_chunk<3, false, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
             else decode_chunk<3, false, false>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
             endp[t] = r.end; flg[t] = 0; have[t] = false;
+#if defined(SWC_HOST_EMULATION)
+            if (g_sync_iters - it0_ > g_sync_passmax) g_sync_passmax = g_sync_iters - it0_;
+            if (t == N - 1) g_sync_wave[0] += g_sync_passmax;
+#endif
         SIMT_END
         SWC_SP(pf, 3)
         for (;;) {
@@ -530,6 +529,10 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
             SWC_SPC(pf, 8, 1);
             SIMT_BEGIN(t, N)
                 todo[t] = t == 0 ? !have[t] : pe[t] != kPosFail && (start[t] != pe[t] || !have[t]);
+#if defined(SWC_HOST_EMULATION)
+                if (t == 0) g_sync_passmax = 0;
+                const uint64_t it0_ = g_sync_iters;
+#endif
                 if (todo[t]) {
                     SWC_SYNC_STAT(3, 1);   // lane decodes
                     if (t != 0) start[t] = pe[t];
@@ -544,6 +547,10 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                     endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; flg[t] = r.flags;
                     have[t] = true;
                 }
+#if defined(SWC_HOST_EMULATION)
+                if (g_sync_iters - it0_ > g_sync_passmax) g_sync_passmax = g_sync_iters - it0_;
+                if (t == N - 1) g_sync_wave[1] += g_sync_passmax;
+#endif
             SIMT_END
             SWC_SP(pf, 3)
         }
@@ -563,6 +570,10 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
         if (!beyond && pos + tot_out > ln.cap) { result = kSyncBailCap; break; }
         if (!beyond && (uint64_t)nrec + tot_rec > ln.max_rec) break;
         SIMT_BEGIN(t, N)
+#if defined(SWC_HOST_EMULATION)
+            if (t == 0) g_sync_passmax = 0;
+            const uint64_t it0_ = g_sync_iters;
+#endif
             if ((uint32_t)t < nv) {
                 ChunkOut r;
                 const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
@@ -573,6 +584,10 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                 else decode_chunk<1, false, false>(sl, lc, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
                 flg[t] = r.flags;
             }
+#if defined(SWC_HOST_EMULATION)
+            if (g_sync_iters - it0_ > g_sync_passmax) g_sync_passmax = g_sync_iters - it0_;
+            if (t == N - 1) g_sync_wave[2] += g_sync_passmax;
+#endif
         SIMT_END
         SWC_SP(pf, 5)
         SIMT_BEGIN(t, N) pb[t] = (uint32_t)t < nv && (flg[t] & kFlagTrap) != 0; SIMT_END
@@ -661,7 +676,7 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, SyncProf& pf) {
         uint32_t prev = 0;
         while (n < total) {
             br.refill();
-            const uint32_t e = cl_lut[br.peek32() & 127u];
+            const uint32_t e = simt::uniform((uint32_t)cl_lut[br.peek32() & 127u]);   // (scalar from here on: see BitReader)
             if (e == 0xFFu || (e & 7u) > br.bc) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :122
             br.consume(e & 7u);
             const uint32_t sym = e >> 3;
