@@ -22,7 +22,9 @@
 // All 64 lanes share ONE set of tables in LDS: direct lookup tables (10 / 9 bits) whose entries carry code length,
 // extra bits, kind and base value, plus one entry per symbol for the codes longer than the tables (their length is found
 // by comparing the bit-reversed window against the canonical limits of the lengths 10..15).  The input of a round is
-// staged in LDS with coalesced loads; a lane walks its sub-chunk through a three-dword window.
+// staged in LDS with coalesced loads; a lane walks its sub-chunk through a two-dword register window whose next dword is
+// read from LDS every iteration, needed or not.  Sub-chunks are 17 dwords long: an odd stride keeps the 64 lanes on 64
+// different LDS banks without padding.
 //
 // Anything the fast path does not want to decide -- an unassigned or over-subscribed code, symbols 286/287, distance
 // symbols 30/31, a distance beyond the output, the end of the input inside a symbol, the capacity inside a round -- makes
@@ -87,10 +89,18 @@ enum { kSyncEob = 0, kSyncBail = 1, kSyncBailCap = 2 };
 #if defined(SWC_HOST_EMULATION)
 // statistics of the emulated decoder (tests, tools/sync_stats.py): rounds committed, bails, lane-passes, symbol iterations
 inline uint64_t g_sync_stats[8];
-inline uint64_t g_sync_iters = 0, g_sync_wave[4] = {0, 0, 0, 0}, g_sync_passmax = 0;
 #define SWC_SYNC_STAT(i, n) (g_sync_stats[i] += (n))
+// wave-steps: a pass takes as long as its busiest lane.  g_sync_wave[k] adds up, per pass of kind k (0 walk, 1 count,
+// 2 emit), the largest number of code iterations any of the 64 lanes ran (lanes are emulated in ascending order here).
+inline uint64_t g_sync_iters = 0, g_sync_wave[4] = {0, 0, 0, 0}, g_sync_passmax = 0;
+#define SWC_SYNC_ITER() (g_sync_iters++)
+#define SWC_SYNC_LANE_BEGIN(t) if ((t) == 0) g_sync_passmax = 0; const uint64_t it0_ = g_sync_iters;
+#define SWC_SYNC_LANE_END(t, n, k) { if (g_sync_iters - it0_ > g_sync_passmax) g_sync_passmax = g_sync_iters - it0_; if ((t) == (n) - 1) g_sync_wave[k] += g_sync_passmax; }
 #else
 #define SWC_SYNC_STAT(i, n) ((void)0)
+#define SWC_SYNC_ITER() ((void)0)
+#define SWC_SYNC_LANE_BEGIN(t)
+#define SWC_SYNC_LANE_END(t, n, k)
 #endif
 enum { kFlagEob = 1u, kFlagFail = 2u, kFlagTrap = 4u };
 // profile builds (-DSWC_PROFILE): cycles per part of one stream -- 0 header, 1 tables, 2 staging, 3 count passes, 4 chain
@@ -389,9 +399,7 @@ SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, u
         const uint32_t posb = (wa << 3) + bp;
         if ((uint32_t)(tsel == 0) & (uint32_t)(posb >= chunk_end)) break;   // (bitwise: one compare pair, no nested mask region)
         SWC_SYNC_STAT(4 + (MODE == 3 ? 0 : MODE), 1);   // code iterations per mode
-#if defined(SWC_HOST_EMULATION)
-        g_sync_iters++;
-#endif
+        SWC_SYNC_ITER();
         const uint32_t bits = funnel32(d1, d0, bp);
         uint32_t e = sl->lut[(bits & tmsk) | tsel];
         const uint32_t nx = *(const uint32_t*)(stg + wa + 8);
@@ -495,18 +503,12 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
         SWC_SPC(pf, 8, 1);
         SIMT_BEGIN(t, N)
             ChunkOut r;
-#if defined(SWC_HOST_EMULATION)
-            if (t == 0) g_sync_passmax = 0;
-            const uint64_t it0_ = g_sync_iters;
-#endif
+            SWC_SYNC_LANE_BEGIN(t)
             const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
             if (chk) decode_chunk<3, false, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
             else decode_chunk<3, false, false>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
             endp[t] = r.end; flg[t] = 0; have[t] = false;
-#if defined(SWC_HOST_EMULATION)
-            if (g_sync_iters - it0_ > g_sync_passmax) g_sync_passmax = g_sync_iters - it0_;
-            if (t == N - 1) g_sync_wave[0] += g_sync_passmax;
-#endif
+            SWC_SYNC_LANE_END(t, N, 0)
         SIMT_END
         SWC_SP(pf, 3)
         for (;;) {
@@ -529,10 +531,7 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
             SWC_SPC(pf, 8, 1);
             SIMT_BEGIN(t, N)
                 todo[t] = t == 0 ? !have[t] : pe[t] != kPosFail && (start[t] != pe[t] || !have[t]);
-#if defined(SWC_HOST_EMULATION)
-                if (t == 0) g_sync_passmax = 0;
-                const uint64_t it0_ = g_sync_iters;
-#endif
+                SWC_SYNC_LANE_BEGIN(t)
                 if (todo[t]) {
                     SWC_SYNC_STAT(3, 1);   // lane decodes
                     if (t != 0) start[t] = pe[t];
@@ -547,10 +546,7 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                     endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; flg[t] = r.flags;
                     have[t] = true;
                 }
-#if defined(SWC_HOST_EMULATION)
-                if (g_sync_iters - it0_ > g_sync_passmax) g_sync_passmax = g_sync_iters - it0_;
-                if (t == N - 1) g_sync_wave[1] += g_sync_passmax;
-#endif
+                SWC_SYNC_LANE_END(t, N, 1)
             SIMT_END
             SWC_SP(pf, 3)
         }
@@ -570,10 +566,7 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
         if (!beyond && pos + tot_out > ln.cap) { result = kSyncBailCap; break; }
         if (!beyond && (uint64_t)nrec + tot_rec > ln.max_rec) break;
         SIMT_BEGIN(t, N)
-#if defined(SWC_HOST_EMULATION)
-            if (t == 0) g_sync_passmax = 0;
-            const uint64_t it0_ = g_sync_iters;
-#endif
+            SWC_SYNC_LANE_BEGIN(t)
             if ((uint32_t)t < nv) {
                 ChunkOut r;
                 const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
@@ -584,10 +577,7 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                 else decode_chunk<1, false, false>(sl, lc, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
                 flg[t] = r.flags;
             }
-#if defined(SWC_HOST_EMULATION)
-            if (g_sync_iters - it0_ > g_sync_passmax) g_sync_passmax = g_sync_iters - it0_;
-            if (t == N - 1) g_sync_wave[2] += g_sync_passmax;
-#endif
+            SWC_SYNC_LANE_END(t, N, 2)
         SIMT_END
         SWC_SP(pf, 5)
         SIMT_BEGIN(t, N) pb[t] = (uint32_t)t < nv && (flg[t] & kFlagTrap) != 0; SIMT_END

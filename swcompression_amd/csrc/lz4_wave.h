@@ -6,20 +6,25 @@
 // literal stream, every match becomes one or more 32-bit records, and the LZ77 resolve kernel of lz_resolve.h
 // (64 KiB history, one block per workgroup) builds the output.
 //
-// Finding the sequence boundaries is a pointer chase (the start of a sequence is known only after the previous
-// one has been parsed).  A wavefront breaks the chase into stripes of 64 input bytes:
-//   1. every lane assumes that a sequence starts at ITS byte of the stripe and decodes it from one unaligned
-//      16-byte load (token, up to 13 literals, the offset) -- "simple" sequences; anything else (length extension
-//      bytes, offset 0) marks the lane unusual;
-//   2. the true starts are found by following next[] from lane 0 with v_readlane (a few scalar cycles per hop
-//      instead of a memory round trip per sequence);
-//   3. the lanes that are true starts take their output and literal positions from a wave prefix sum, validate
-//      their offset against the bytes produced so far, and write their record and their literals in parallel.
-// An unusual lane, an invalid offset, the tail of the block and the last 17 KiB of output capacity are handled by a
-// fully checked one-sequence step (the reference's control flow line by line, executed wave-uniformly, long
-// literal runs copied by all lanes); it also carries the error taxonomy.
+// Finding the sequence boundaries is a pointer chase (the start of a sequence is known only after the previous one has
+// been parsed), but a parser started at a WRONG byte falls into step with the true sequence chain after a few sequences
+// (every token it lands on sends it forward to another position; true starts are frequent).  So a wavefront parses the
+// block the way inflate_sync.h decodes a Deflate stream, in rounds of 64 sub-chunks of kChunk input bytes:
+//   walk     lane 0 starts at the true position, every other lane at its sub-chunk boundary; each parses "short"
+//            sequences (fewer than 270 literals, match shorter than 274: at most one extension byte each) until it
+//            crosses the end of its sub-chunk, and notes where it ended;
+//   count    a lane whose start differs from its left neighbour's end parses again from there, counting literals,
+//            records and output bytes; repeated until the chain of (start == left neighbour's end) is consistent up to
+//            the first lane that met something the fast path does not take;
+//   scan     exclusive prefix sums of the counts;
+//   emit     every lane of the consistent chain parses once more, copies its literals to the dense literal stream and
+//            writes its records at exact offsets, validating offsets against the bytes produced so far.
+// The input of a round is staged in LDS with coalesced loads (one pad dword behind every sub-chunk keeps the lanes, which
+// work at similar offsets of their sub-chunks, on different banks).  Longer sequences, an invalid offset, the tail of the
+// block and the last 17 KiB of output capacity are handled by a fully checked one-sequence step (the reference's control
+// flow line by line, executed wave-uniformly, long literal runs copied by all lanes); it also carries the error taxonomy.
 //
-// The same source compiles for the host with W = 1 (tests/host_emu): stripes of one byte.
+// The same source compiles for the host (tests/host_emu): the SIMT regions run their 64 lanes one after another.
 #ifndef SWC_LZ4_WAVE_H
 #define SWC_LZ4_WAVE_H
 

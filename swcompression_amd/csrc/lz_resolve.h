@@ -12,19 +12,20 @@
 //           that cover up to 16 T - 16 output bytes (the batch SPAN):
 //             R0/R1  a workgroup prefix scan turns (literal run, length) into output positions and literal offsets;
 //                    every record publishes its geometry (8 bytes) and the 16-byte output slots it owns;
-//             R2     SLOT-CENTRIC expansion: thread t owns the 16 output bytes of slot t.  For each of them it finds the
-//                    record that covers it and either knows the byte at once -- a literal (from the staged literal
-//                    window), or a match byte whose source lies BEFORE the span (final bytes of the LDS ring) -- or notes
-//                    the position inside the span it copies from.  The result is one 16-bit CELL per byte:
-//                    0x8000 | value, or the source cell index;
-//             R3     CHASE: an unresolved cell follows source indices until it meets a value (every chain ends in one:
-//                    sources point strictly backwards and everything that is not an in-span copy was resolved in R2).
-//                    Read-only pointer chasing over static cells -- no waiting on producers, no ordering between
-//                    threads; resolved values are written back so that later readers stop early.  Then the slot's 16
-//                    bytes go to the LDS ring (history of later batches) and to HBM with ONE aligned 16-byte store --
-//                    the only time the output is written.
-//           Three LDS-only barriers per batch.  Every LDS access is naturally aligned (the cells and the ring are
-//           indexed per byte / per aligned slot; no unaligned 8-byte copies).
+//             R2     EXPANSION, one thread per output byte and step: the thread finds the record that covers its byte
+//                    (per 16-byte slot: the record of the slot's first byte + a popcount over the slot's record-start
+//                    flags) and either knows the byte at once -- a literal (from the staged literal window), or a match
+//                    byte whose source lies BEFORE the span (final bytes of the LDS ring) -- or notes the position inside
+//                    the span it copies from (a match that overlaps itself is reduced to its first period).  The result
+//                    is one 16-bit CELL per byte: 0x8000 | value, or the source cell index;
+//             R3     CHASE, one thread per aligned output dword and step: the four cells follow their source indices
+//                    together until each meets a value (every chain ends in one: sources point strictly backwards and
+//                    everything that is not an in-span copy was resolved in R2).  Read-only pointer chasing over static
+//                    cells -- no waiting on producers, no ordering between threads; resolved values are written back so
+//                    that later readers stop early.  Then the dword goes to the LDS ring (history of later batches) and
+//                    to HBM with one aligned store -- the only time the output is written.
+//           Three LDS-only barriers per batch.  Every LDS access is naturally aligned.  The cells of a span live in the
+//           stale part of the ring (behind the history and the span), so the ring is the only large LDS array.
 //
 // Record format (u32):  lit_run[0..6] | length[7..15] | (distance - 1)[16..31]
 //   length 1..511: `lit_run` (0..127) literal bytes, then a match of `length` bytes `distance` (1..65536) back;
