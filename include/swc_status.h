@@ -7,7 +7,10 @@
  *   SWC_E_REF_TRAP  - input on which the reference hits a Swift runtime trap (array index out of
  *                     range, reading past the end of a BitByteData reader, ...). The reference
  *                     would abort the process; we report it. Parity tests treat it as a class.
- *   SWC_E_CAPACITY  - caller-provided output capacity too small (batch API only).
+ *   SWC_E_CAPACITY  - caller-provided output capacity too small (batch API); from the single-shot calls: a unit beyond the
+ *                     engine's limits -- output above 16 GiB (bzip2: 1 GiB per block), or a bzip2 block whose BWT column
+ *                     exceeds 16,000,000 bytes (17 x the largest block an encoder writes; the reference enforces no
+ *                     block size).
  *   SWC_E_DEVICE    - HIP runtime failure (no device, launch error). Never a CPU fallback.
  */
 #ifndef SWC_STATUS_H

@@ -201,13 +201,18 @@ int run_units(int codec, std::vector<HostUnit>& units) {
                 next.push_back(pending[k]);
                 continue;
             }
-            if (j.status == SWC_E_CAPACITY && !u.cap_exact && cap[pending[k]] < ((size_t)1 << 34)) {
+            // (bzip2: a block of the largest BWT column the engine takes expands to at most 52 x 16,000,000 bytes under RLE1)
+            const size_t grow_limit = codec == SWC_CODEC_BZIP2_BLOCK ? (size_t)1 << 30 : (size_t)1 << 34;
+            if (j.status == SWC_E_CAPACITY && !u.cap_exact && cap[pending[k]] < grow_limit) {
                 size_t want = j.out_len > cap[pending[k]] ? (size_t)j.out_len : cap[pending[k]] * 4;
                 cap[pending[k]] = want;
                 next.push_back(pending[k]);
                 continue;
             }
-            u.status = j.status;
+            // a bzip2 block whose BWT column outgrows the largest workspace (16,000,000 bytes, 17 x the largest block an
+            // encoder writes; the reference enforces no block size, App. A B5) is beyond the engine's capacity -- a
+            // documented status, not the internal "needs a workspace"
+            u.status = (j.status == SWC_E_NEED_WORKSPACE && codec == SWC_CODEC_BZIP2_BLOCK) ? (int)SWC_E_CAPACITY : j.status;
             u.aux_out = j.aux;
             u.in_consumed = (size_t)j.in_consumed;
             size_t produced = (size_t)std::min<uint64_t>(j.out_len, j.out_cap);

@@ -121,6 +121,10 @@ void bzip2_magic_index(const uint8_t* in, size_t in_len, std::vector<BlockRef64>
 void bzip2_collect_candidates(const uint8_t* d, size_t n, std::vector<HostUnit>& units, std::vector<uint64_t>& used) {
     std::vector<uint64_t> cand;
     scan_block_magics(d, n, 32, cand);
+    // first capacity of a block: what the stream header's level allows for the BWT column (level x 100,000 bytes,
+    // BZip2+BlockSize.swift:11-33) -- the output is larger only where RLE1 runs expand, and such blocks are relaunched with
+    // the size they report
+    const size_t level = (n >= 4 && d[0] == 0x42 && d[1] == 0x5A && d[2] == 104 && d[3] >= 0x31 && d[3] <= 0x39) ? (size_t)(d[3] - 0x30) : 9;
     for (uint64_t c : cand) {
         if ((uint64_t)n * 8 - c < 80) continue;                                    // the walk reports wrongMagic there
         HostUnit u;
@@ -128,7 +132,7 @@ void bzip2_collect_candidates(const uint8_t* d, size_t n, std::vector<HostUnit>&
         u.in_len = n;
         u.extra = c + 80;                                                         // bit offset of the block body
         u.dict_value = read_bits(d, c + 48, 32);                                  // stored block CRC
-        u.cap_hint = std::min<size_t>(1000000, std::max<size_t>(65536, n * 16));
+        u.cap_hint = std::min<size_t>(level * 100000 + 64, std::max<size_t>(4096, n * 64));
         units.push_back(std::move(u));
         used.push_back(c);
     }

@@ -19,12 +19,12 @@
 //               record per match to the record list (lz_resolve.h) at exact offsets.  A sub-chunk closes its trailing
 //               literals with a literal-only record, so that no lane needs the literal run of its neighbour.
 //
-// All 64 lanes share ONE set of tables in LDS: direct lookup tables (10 / 9 bits) whose entries carry code length,
-// extra bits, kind and base value, plus one entry per symbol for the codes longer than the tables (their length is found
-// by comparing the bit-reversed window against the canonical limits of the lengths 10..15).  The input of a round is
+// All 64 lanes share ONE set of tables in LDS: direct lookup tables (10 / 8 bits) whose entries carry code length,
+// extra bits, kind and base value; a code longer than the tables finds its length by comparing the bit-reversed window
+// against the canonical limits of the lengths 9..15 and its symbol in the sorted symbol array.  The input of a round is
 // staged in LDS with coalesced loads; a lane walks its sub-chunk through a two-dword register window whose next dword is
 // read from LDS every iteration, needed or not.  Sub-chunks are 17 dwords long: an odd stride keeps the 64 lanes on 64
-// different LDS banks without padding.
+// different LDS banks without padding, and everything in LDS together is exactly 10 KB (16 waves per CU).
 //
 // Anything the fast path does not want to decide -- an unassigned or over-subscribed code, symbols 286/287, distance
 // symbols 30/31, a distance beyond the output, the end of the input inside a symbol, the capacity inside a round -- makes
@@ -41,19 +41,22 @@
 namespace swc {
 namespace inflate {
 
-constexpr int kSyncLitBits = 10, kSyncDistBits = 9;
+constexpr int kSyncLitBits = 10, kSyncDistBits = 8;
 #ifndef SWC_SYNC_CHUNK
 #define SWC_SYNC_CHUNK 68
 #endif
 // Input bytes per lane and round: a whole number of dwords and an ODD number of them (17), so that the lanes, which start
 // a pass at the same offset of their sub-chunks, read 64 different LDS banks without any padding of the staged input.
+// With 68 bytes the wave's LDS is EXACTLY 10,240 bytes = 16 waves per CU: the kernel's speed is proportional to the waves
+// a CU holds (measured by padding the LDS: 12 waves 13.7 ms, 9 waves 17.6 ms, 7 waves 22.1 ms; 16 waves 12.05 ms), and
+// shorter sub-chunks cost more in rounds and lane imbalance than further waves bring (60 bytes: 12.85 ms, 52: 13.75 ms).
 constexpr uint32_t kSyncChunk = SWC_SYNC_CHUNK;
 constexpr uint32_t kSyncRound = 64u * kSyncChunk;
-constexpr uint32_t kSyncStage = (kSyncRound + 128u + 15u) & ~15u;   // + what the last lane may read past its sub-chunk
-constexpr uint32_t kSyncStageLds = kSyncStage + 16u;
+constexpr uint32_t kSyncStage = (kSyncRound + 32u + 15u) & ~15u;    // + what the last lane may read past its sub-chunk (a code of <= 48 bits, then the window's two dwords and the next one: < 28 bytes)
+constexpr uint32_t kSyncStageLds = kSyncStage;
 constexpr uint32_t kEntInvalid = 0x80000000u;        // a code of the set, but not a symbol the fast path takes
 constexpr uint32_t kPosFail = 0xFFFFFFFFu;
-static_assert(kSyncChunk % 4 == 0 && kSyncChunk >= 64, "sub-chunks are whole dwords");
+static_assert(kSyncChunk % 4 == 0 && kSyncChunk >= 36, "sub-chunks are whole dwords");
 
 // Table entry, laid out for a decode loop without branches per kind:
 //   [0:4] bits the symbol takes (code + extra)   [5] end of block   [6:9] code length   [10] length symbol: the next code is
@@ -67,19 +70,40 @@ SWC_HD uint32_t make_entry(uint32_t clen, uint32_t ext, uint32_t kind, uint32_t 
     return (clen + ext) | (kind == 1 ? kEntLit : kind == 2 ? kEntLen : kind == 3 ? kEntEob : 0u) | (clen << kEntClenShift) | (ext << kEntExtShift) | (value << 16);
 }
 
+// The entry of lit/len symbol `sym` (0..287) / distance symbol `sym` (0..31) with a code of `d` bits
+// (Deflate+Constants.swift: lengthBase / distanceBase as arithmetic).
+SWC_HD uint32_t entry_of_symbol(bool dist, uint32_t sym, uint32_t d) {
+    if (!dist) {
+        if (sym < 256) return make_entry(d, 0, 1, sym);
+        if (sym == 256) return make_entry(d, 0, 3, 0);
+        if (sym > 285) return d | kEntInvalid;   // 286, 287: the checked step reports wrongSymbol
+        const uint32_t s = sym - 257u;
+        const uint32_t e = s < 8 || s == 28 ? 0u : (s >> 2) - 1u;
+        const uint32_t base = s < 8 ? 3u + s : s == 28 ? 258u : 3u + ((4u + (s & 3u)) << e);
+        return make_entry(d, e, 2, base);
+    }
+    if (sym > 29) return d | kEntInvalid;        // 30, 31: wrongSymbol
+    const uint32_t e = sym < 4 ? 0u : (sym >> 1) - 1u;
+    const uint32_t base = sym < 4 ? 1u + sym : 1u + ((2u + (sym & 1u)) << e);
+    return make_entry(d, e, 0, base);
+}
+
 // The canonical tables of inflate_lane.h (struct Table) kept in LDS: per length d the left-justified code limit, the slot
 // word (sorted index of the first code - first code | index of the first symbol >= 256 << 16) and the sorted index of the
 // first code; the number of codes; the over-subscription flag.  Lit/len alphabet at kAuxLit, distance alphabet at kAuxDist.
 constexpr int kAuxLim = 0, kAuxSlot = 16, kAuxStart = 32, kAuxCount = 48 /* == start[16] */, kAuxOver = 49, kAuxTable = 52;
 constexpr int kAuxLit = 0, kAuxDist = kAuxTable, kAuxWords = 2 * kAuxTable;
 
-struct SyncLds {
+struct SyncLds {   // 10,240 bytes: see kSyncChunk
     uint32_t syms[kWordsPerLane];                                   // the sorted symbol arrays of inflate_lane.h (LaneLds{syms, 1})
     uint32_t lut[(1 << kSyncLitBits) + (1 << kSyncDistBits)];      // direct tables: lit/len, then distance
-    uint32_t symtab[320];                                           // one entry per sorted symbol: lit/len at 0, distance at 288
     uint32_t aux[kAuxWords];                                        // the canonical tables (see kAux*)
+#ifdef SWC_SYNC_LDS_PAD
+    uint8_t occupancy_experiment_pad[SWC_SYNC_LDS_PAD];             // (tools/gpu_chunk_sweep.sh: fewer waves per CU, nothing else changed)
+#endif
     alignas(16) uint8_t stage[kSyncStageLds];                       // staged input of a round; header build: code lengths, counters, code-length table
 };
+static_assert(sizeof(SyncLds) <= 10240, "16 waves per CU: the wave's LDS must stay within 160 KB / 16");
 // header scratch inside `stage`
 constexpr uint32_t kHdrLens = 0;       // 320 bytes: code length of symbol s
 constexpr uint32_t kHdrCnt = 320;      // 48 words: codes per length (lit/len, of those symbols < 256, distance)
@@ -225,7 +249,7 @@ SWC_D int careful_step_lds(Lane& ln, const SyncLds* sl) {
     return SWC_OK;
 }
 
-// Per-symbol entries and direct tables from the canonical tables and the sorted symbol arrays in LDS.  All lanes.
+// Direct tables from the canonical tables and the sorted symbol arrays in LDS.  All lanes.
 SWC_D void sync_build_luts(SyncLds* sl) {
     constexpr int N = kWave;
     const LaneLds l{sl->syms, 1};
@@ -246,27 +270,14 @@ SWC_D void sync_build_luts(SyncLds* sl) {
                 const uint32_t fst = d == 1 ? 0u : tb[kAuxLim + d - 1] >> (15 - d);
                 const uint32_t code = fst + (j - tb[kAuxStart + d]);
                 const uint32_t rev = brev32(code) >> (32 - d);
-                uint32_t entry;
+                uint32_t sym;
                 if (tbl == 0) {
-                    uint32_t sym = *sym_ptr(l, W_LIT_SYM, j);
+                    sym = *sym_ptr(l, W_LIT_SYM, j);
                     if (j >= (tb[kAuxSlot + d] >> 16)) sym |= 256u;
-                    if (sym < 256) entry = make_entry(d, 0, 1, sym);
-                    else if (sym == 256) entry = make_entry(d, 0, 3, 0);
-                    else if (sym <= 285) {
-                        const uint32_t s = sym - 257u;
-                        const uint32_t e = s < 8 || s == 28 ? 0u : (s >> 2) - 1u;
-                        const uint32_t base = s < 8 ? 3u + s : s == 28 ? 258u : 3u + ((4u + (s & 3u)) << e);
-                        entry = make_entry(d, e, 2, base);
-                    } else entry = d | kEntInvalid;   // 286, 287: the checked step reports wrongSymbol
                 } else {
-                    const uint32_t dc = *sym_ptr(l, W_DIST_SYM, j);
-                    if (dc <= 29) {
-                        const uint32_t e = dc < 4 ? 0u : (dc >> 1) - 1u;
-                        const uint32_t base = dc < 4 ? 1u + dc : 1u + ((2u + (dc & 1u)) << e);
-                        entry = make_entry(d, e, 0, base);
-                    } else entry = d | kEntInvalid;   // 30, 31: wrongSymbol
+                    sym = *sym_ptr(l, W_DIST_SYM, j);
                 }
-                sl->symtab[(tbl ? 288u : 0u) + j] = entry;
+                const uint32_t entry = entry_of_symbol(tbl != 0, sym, d);
                 if (d <= lut_bits)
                     for (uint32_t m = rev; m < (1u << lut_bits); m += 1u << d) lut[m] = entry;
             }
@@ -347,10 +358,11 @@ SWC_HD uint32_t bfe32(uint32_t v, uint32_t off, uint32_t width) {   // width 0..
 #endif
 }
 
-// A code longer than the direct tables: resolved from the canonical limits and slot words of the lengths 10..15 in LDS
-// (`aux`; a dozen reads the compiler pairs up) with compares, plus ONE read of its symbol entry.  The wave pays for this
-// path whenever ANY lane meets such a code (about one iteration in seven on text), so it is kept short: the alphabet only
-// selects a base address.
+// A code longer than the direct tables (lit/len: more than 10 bits, distance: more than 8): its length from the canonical
+// limits of the lengths 9..15 in LDS (`aux`; reads the compiler pairs up) with compares, its symbol from the sorted symbol
+// array, its entry by arithmetic -- no per-symbol entry table, which would cost the wave 1.3 KB of LDS.  The wave pays for
+// this path whenever ANY lane meets such a code (about one iteration in seven on text), so the alphabet only selects a base
+// address.
 struct LongCodes {
     SWC_D void load(const SyncLds*) {}
     // the entry of the code that starts `bits` (state: 0 lit/len, anything else distance); kEntInvalid if there is none
@@ -359,9 +371,9 @@ struct LongCodes {
         const bool st = state != 0;
         const uint32_t* tb = sl->aux + (st ? kAuxDist : kAuxLit);
         // the limits do not decrease with the length: count how many the window reaches, keep the slot word of that length
-        uint32_t len = 10u, slw = tb[kAuxSlot + 10];
+        uint32_t len = 9u, slw = tb[kAuxSlot + 9];
 #pragma unroll
-        for (int d = 10; d < 15; d++) {
+        for (int d = 9; d < 15; d++) {
             const bool g = c15 >= tb[kAuxLim + d];
             len += g ? 1u : 0u;
             slw = g ? tb[kAuxSlot + d + 1] : slw;
@@ -371,7 +383,10 @@ struct LongCodes {
         uint32_t j = (slw + (c15 >> (15 - lenc))) & 0xFFFFu;
         const uint32_t jmax = st ? 31u : 287u;
         j = j > jmax ? jmax : j;
-        const uint32_t e = sl->symtab[(st ? 288u : 0u) + j];
+        const LaneLds l{const_cast<uint32_t*>(sl->syms), 1};
+        uint32_t sym = *sym_ptr(l, st ? W_DIST_SYM : W_LIT_SYM, j);
+        if (!st && j >= (slw >> 16)) sym |= 256u;
+        const uint32_t e = entry_of_symbol(st, sym, lenc);
         return len > 15 ? kEntInvalid : e;
     }
 };
@@ -434,8 +449,7 @@ SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, u
             plen = (e & kEntLen) ? val : plen;
         }
         tsel = e & kEntLen;                                                 // 0, or 1 << kSyncLitBits: the distance table follows the lit/len table
-        tmsk = ((1u << kSyncLitBits) - 1u) >> (tsel >> kSyncLitBits);       // 10-bit index, or 9-bit
-        static_assert(kSyncDistBits == kSyncLitBits - 1, "the mask arithmetic above");
+        tmsk = ((1u << kSyncLitBits) - 1u) >> ((tsel >> kSyncLitBits) * (uint32_t)(kSyncLitBits - kSyncDistBits));   // 10-bit index, or 8-bit
         bp += n;
         const bool sh = bp >= 32;
         wa += sh ? 4u : 0u;

@@ -242,39 +242,66 @@ struct Resolver {
             // ---- R3: one aligned DWORD per thread and step: chase what is unresolved, then the dword leaves for the ring and for HBM
             SIMT_BEGIN(t, T)
                 if ((uint32_t)t * 16u < ncell) l->slotw[t] = 0;   // (read in R2 only; the next batch sets it after its barrier A)
-                const uint32_t ndw = (ncell + 3u) >> 2;
-                for (uint32_t q = (uint32_t)t; q < ndw; q += (uint32_t)T) {
-                    const uint64_t c4 = *(const uint64_t*)(l->ring + ((cbase + 8u * q) & kMask));
+                // Dwords [0, nfull) lie inside the span with all four cells; of those, [qmin, qlim) also lie inside the output
+                // and leave with one store at a 32-bit offset from a wave-uniform base (no 64-bit address arithmetic per
+                // thread).  A last, incomplete dword (ncell % 4 != 0) is the business of ONE thread after the loop.
+                const uint32_t nfull = ncell >> 2;
+                const int64_t base64 = (int64_t)rpos - (int64_t)off;             // output position of the span's cell 0 (negative only in the first batch)
+                const uint32_t qmin = base64 < 0 ? (uint32_t)((3 - base64) >> 2) : 0u;
+                const uint64_t room = (int64_t)limit > base64 ? (uint64_t)((int64_t)limit - base64) : 0u;
+                const uint32_t qlim = room >= 0x100000000ull ? 0x40000000u : (uint32_t)room >> 2;
+                gptr obase = (gptr)((SWC_AS_GLOBAL uint8_t*)out + base64);
+                for (uint32_t q = (uint32_t)t; q < nfull; q += (uint32_t)T) {
+                    const uint32_t ca = (cbase + 8u * q) & kMask;
+                    const uint64_t c4 = *(const uint64_t*)(l->ring + ca);
                     uint32_t c[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        c[e] = (uint32_t)(c4 >> (16 * e)) & 0xFFFFu;
-                        if (4u * q + (uint32_t)e >= ncell) c[e] = 0x8000u;   // beyond the span: the next batch's cells
-                    }
+                    for (int e = 0; e < 4; e++) c[e] = (uint32_t)(c4 >> (16 * e)) & 0xFFFFu;
                     // the four chains advance together: one hop = four independent LDS reads in flight
                     const uint32_t was = (c[0] & c[1] & c[2] & c[3]) & 0x8000u;
                     while (!((c[0] & c[1] & c[2] & c[3]) & 0x8000u)) {
 #pragma unroll
                         for (int e = 0; e < 4; e++) if (!(c[e] & 0x8000u)) c[e] = cell_load(l->ring, cbase, c[e]);
                     }
-                    if (!was) {   // resolved values back into my cells: later readers stop here
-                        const uint64_t v = (uint64_t)c[0] | ((uint64_t)c[1] << 16) | ((uint64_t)c[2] << 32) | ((uint64_t)c[3] << 48);
-                        if (4u * q + 4u <= ncell) *(uint64_t*)(l->ring + ((cbase + 8u * q) & kMask)) = v;
-                        else for (int e = 0; e < 4; e++) if (4u * q + (uint32_t)e < ncell) cell_store(l->ring, cbase, 4u * q + (uint32_t)e, c[e]);
-                    }
+                    if (!was)   // resolved values back into my cells: later readers stop here
+                        *(uint64_t*)(l->ring + ca) = (uint64_t)c[0] | ((uint64_t)c[1] << 16) | ((uint64_t)c[2] << 32) | ((uint64_t)c[3] << 48);
                     const uint32_t word = (c[0] & 0xFFu) | ((c[1] & 0xFFu) << 8) | ((c[2] & 0xFFu) << 16) | ((c[3] & 0xFFu) << 24);
                     *(uint32_t*)(l->ring + ((v0 + 4u * q) & kMask)) = word;
-                    const bool complete = 4u * q + 4u <= ncell;
-                    if (complete || last_batch) {
-                        const int64_t a0 = (int64_t)rpos - (int64_t)off + 4 * (int64_t)q;   // output position of the dword's first byte
-                        if (complete && a0 >= 0 && (uint64_t)(a0 + 4) <= limit) {
-                            *(SWC_AS_GLOBAL uint32_t*)(out + a0) = word;
-                        } else {
+                    if (q >= qmin && q < qlim) {
+                        *(SWC_AS_GLOBAL uint32_t*)(obase + (size_t)(4u * q)) = word;
+                    } else {   // the dword straddles the start of the output (first batch) or the limit
 #pragma unroll 1
-                            for (int e = 0; e < 4; e++) {
-                                const int64_t a = a0 + e;
-                                if (4u * q + (uint32_t)e < ncell && a >= 0 && (uint64_t)a < limit) out[a] = (uint8_t)(word >> (8 * e));
-                            }
+                        for (int e = 0; e < 4; e++) {
+                            const int64_t a = base64 + 4 * (int64_t)q + e;
+                            if (a >= 0 && (uint64_t)a < limit) out[a] = (uint8_t)(word >> (8 * e));
+                        }
+                    }
+                }
+                if ((ncell & 3u) != 0u && (uint32_t)t == (nfull & (uint32_t)(T - 1))) {
+                    // the incomplete dword: its cells beyond the span belong to the next batch, which will finish and store
+                    // it -- unless this is the last batch, whose bytes leave one by one
+                    const uint32_t q = nfull;
+                    const uint64_t c4 = *(const uint64_t*)(l->ring + ((cbase + 8u * q) & kMask));
+                    uint32_t c[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        c[e] = (uint32_t)(c4 >> (16 * e)) & 0xFFFFu;
+                        if (4u * q + (uint32_t)e >= ncell) c[e] = 0x8000u;
+                    }
+                    const uint32_t was = (c[0] & c[1] & c[2] & c[3]) & 0x8000u;
+                    while (!((c[0] & c[1] & c[2] & c[3]) & 0x8000u)) {
+#pragma unroll
+                        for (int e = 0; e < 4; e++) if (!(c[e] & 0x8000u)) c[e] = cell_load(l->ring, cbase, c[e]);
+                    }
+                    if (!was)
+                        for (int e = 0; e < 4; e++) if (4u * q + (uint32_t)e < ncell) cell_store(l->ring, cbase, 4u * q + (uint32_t)e, c[e]);
+                    const uint32_t word = (c[0] & 0xFFu) | ((c[1] & 0xFFu) << 8) | ((c[2] & 0xFFu) << 16) | ((c[3] & 0xFFu) << 24);
+                    *(uint32_t*)(l->ring + ((v0 + 4u * q) & kMask)) = word;
+                    if (last_batch) {
+#pragma unroll 1
+                        for (int e = 0; e < 4; e++) {
+                            const int64_t a = base64 + 4 * (int64_t)q + e;
+                            if (4u * q + (uint32_t)e < ncell && a >= 0 && (uint64_t)a < limit) out[a] = (uint8_t)(word >> (8 * e));
                         }
                     }
                 }
