@@ -42,7 +42,7 @@ constexpr uint32_t kRecBuf = 256;    // records the checked step stages in LDS b
 constexpr uint32_t kLitStage = 1024; // literal bytes likewise
 constexpr uint32_t kInWin = 1024;    // input window of the checked step in LDS
 #ifndef SWC_LZ4_CHUNK
-#define SWC_LZ4_CHUNK 256
+#define SWC_LZ4_CHUNK 128
 #endif
 constexpr uint32_t kChunk = SWC_LZ4_CHUNK;            // input bytes per lane and round of the sub-chunk-parallel parse (a multiple of 16)
 constexpr uint32_t kStageBytes = 64u * kChunk + 64u;  // staged input of a round (+ what the last lane reads past its sub-chunk)
