@@ -127,11 +127,8 @@ __global__ __launch_bounds__(64) void swc_lz4_parse_kernel(Job* __restrict__ job
     if (g >= n) return;
     Job job = jobs[g];
     if (job.dict != nullptr) return;
-    __shared__ __attribute__((aligned(16))) uint8_t iw[lz4w::kInWin + 16];
-    __shared__ uint32_t rbuf[lz4w::kRecBuf];
-    __shared__ __attribute__((aligned(16))) uint8_t lbuf[lz4w::kLitStage + 32 + 64];
     __shared__ __attribute__((aligned(16))) uint8_t stage[lz4w::kStageLds];
-    lz4w::lz4_parse_job<kWave>(job, wm.area(g), wm.bytes(g), (int)threadIdx.x, rbuf, lbuf, iw, stage, prof ? prof + 32 * (size_t)g : nullptr);
+    lz4w::lz4_parse_job<kWave>(job, wm.area(g), wm.bytes(g), (int)threadIdx.x, stage, prof ? prof + 32 * (size_t)g : nullptr);
     if (threadIdx.x == 0) {
         jobs[g].out_len = job.out_len;
         jobs[g].in_consumed = job.in_consumed;

@@ -53,6 +53,11 @@ static_assert((kChunkDwords & (kChunkDwords - 1)) == 0 && kChunk % 16 == 0, "the
 SWC_HD uint32_t stage_slot(uint32_t dword) { return dword + dword / kChunkDwords; }
 SWC_HD uint32_t stage_byte(uint32_t a) { return a + 4u * (a / kChunk); }
 constexpr uint32_t kStageLds = kStageBytes + 4u * (kStageBytes / kChunk + 2u);
+// The checked step's three small LDS buffers (input window, staged records, staged literals) live INSIDE the stage: the
+// rounds start with a flush and end before the next checked step, so the two never hold data at the same time, and the
+// wave's LDS is the stage alone (8.5 KB: 19 waves per CU -- the parse is latency-bound, its speed follows the waves a CU holds).
+constexpr uint32_t kScratchWin = 0, kScratchRec = kInWin + 16, kScratchLit = kScratchRec + 4 * kRecBuf, kScratchEnd = kScratchLit + kLitStage + 32 + 64;
+static_assert(kScratchEnd <= kStageLds && kScratchRec % 16 == 0 && kScratchLit % 16 == 0, "the checked step's buffers must fit the stage");
 constexpr uint32_t kTailKeep = 16;                    // the sequences that end in the last bytes of a block stay with the checked step
 constexpr uint32_t kPosFail = 0xFFFFFFFFu;
 enum { kLzStop = 1u, kLzFail = 2u, kLzTrap = 4u, kLzTail = 8u };
@@ -396,6 +401,8 @@ struct Parser {
         using simt::PT;
         constexpr int N = kWave;
         flush();
+        iw_hi = 0;        // the input window of the checked step shares the stage: nothing of it survives a round
+        iw_pf = false;
         PT<uint32_t, N> start, endp, pe, c_lit, c_rec, c_out, c_seq, c_lms, flg, x_lit, x_rec, x_out, x_seq;
         PT<bool, N> pb, have;
         for (;;) {
@@ -520,15 +527,15 @@ struct Parser {
 
 // One wavefront = one job (blocks WITHOUT a dictionary prefix; those with one stay on lz4_lane.h).
 template <int W>
-SWC_D void lz4_parse_job(Job& job, uint8_t* ws, size_t ws_bytes, int lane, uint32_t* rbuf, uint8_t* lbuf, uint8_t* iw, uint8_t* stage, uint64_t* prof = nullptr) {
+SWC_D void lz4_parse_job(Job& job, uint8_t* ws, size_t ws_bytes, int lane, uint8_t* stage, uint64_t* prof = nullptr) {
     Parser<W> ps;
     ps.w.lane = lane;
-    ps.iw = iw;
+    ps.iw = stage + kScratchWin;
     ps.iw_hi = 0;
     ps.iw_next = 0;
     ps.iw_pf = false;
-    ps.rbuf = rbuf;
-    ps.lbuf = lbuf;
+    ps.rbuf = (uint32_t*)(stage + kScratchRec);
+    ps.lbuf = stage + kScratchLit;
 
     ps.rb_n = ps.lb_n = 0;
     ps.in = (gcptr)job.in;

@@ -46,12 +46,9 @@ extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {
         if (jobs[g].dict) { swc::lz4::lz4_block_job(jobs[g]); continue; }
         size_t wsb = swc::lzr::ws_bytes_per_job(jobs[g].out_cap);
         std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
-        static uint32_t rbuf[swc::lz4w::kRecBuf];
-        static uint8_t lbuf[swc::lz4w::kLitStage + 32 + 64];
-        alignas(16) static uint8_t iw[swc::lz4w::kInWin + 16];
         alignas(16) static uint8_t stage[swc::lz4w::kStageLds];
         std::memset(stage, 0xEE, sizeof stage);
-        swc::lz4w::lz4_parse_job<1>(jobs[g], ws.data(), wsb, 0, rbuf, lbuf, iw, stage);
+        swc::lz4w::lz4_parse_job<1>(jobs[g], ws.data(), wsb, 0, stage);
         std::memset(&rl, 0xEE, sizeof rl);
         swc::lzr::resolve_job<swc::lz4w::kResolveThreads, swc::lz4w::kRingLog2, swc::lz4w::kKeep>(jobs[g], ws.data(), wsb, &rl);
     }
