@@ -109,7 +109,21 @@ int run_units(int codec, std::vector<HostUnit>& units) {
 
     bool want_ws = codec == SWC_CODEC_BZIP2_BLOCK || codec == SWC_CODEC_DEFLATE || codec == SWC_CODEC_LZ4_BLOCK;  // LZMA: only after a unit reported SWC_E_NEED_WORKSPACE
     const bool per_job_ws = codec == SWC_CODEC_DEFLATE || codec == SWC_CODEC_LZ4_BLOCK;   // areas sized from each unit's own capacity
-    for (int round = 0; round < 12 && !pending.empty(); round++) {
+    // rounds: 12 relaunches for growing capacities, plus the extra rounds that splitting by workspace size takes
+    for (int round = 0, grow_rounds = 0; grow_rounds < 12 && round < 256 && !pending.empty(); round++) {
+        // Codecs whose workspace areas are one size for the whole launch (bzip2: 9 x the capacity): ONE big unit among many
+        // small ones must not size everybody's area.  The units are taken in order of capacity as long as count x area stays
+        // within a budget; the others wait for the next round.
+        std::vector<size_t> deferred;
+        if (want_ws && !per_job_ws && pending.size() > 1) {
+            std::stable_sort(pending.begin(), pending.end(), [&](size_t a, size_t b) { return cap[a] < cap[b]; });
+            const size_t budget = (size_t)48 << 30;
+            size_t take = 1;
+            while (take < pending.size() && swc_batch_workspace_bytes(codec, take + 1, cap[pending[take]]) <= budget) take++;
+            deferred.assign(pending.begin() + take, pending.end());
+            pending.resize(take);
+        }
+        if (deferred.empty()) grow_rounds++;
         const size_t m = pending.size();
         std::vector<size_t> in_off(m), out_off(m), dict_off(m);
         // Host buffers are staged once: units that share a buffer (the bzip2 blocks of a stream) or that are sub-ranges of
@@ -221,6 +235,7 @@ int run_units(int codec, std::vector<HostUnit>& units) {
         if (!next.empty() && !want_ws)
             for (size_t k = 0; k < m; k++)
                 if (res[k].status == SWC_E_NEED_WORKSPACE) { want_ws = true; break; }
+        next.insert(next.end(), deferred.begin(), deferred.end());
         pending.swap(next);
     }
     for (size_t i : pending) units[i].status = SWC_E_CAPACITY;

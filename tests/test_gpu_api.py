@@ -57,6 +57,21 @@ def test_one_large_unit_among_many_small_ones():
     assert all(d == p for (_, d), p in zip(got, plains))
 
 
+def test_one_large_bzip2_block_among_many_small_streams():
+    """bzip2's workspace areas are one size per launch (9 x the capacity): the launch is split by capacity so that ONE block
+    that expands to 40 MB (a run of zeros: RLE1 packs 40 MB into a single block) does not size the areas of 3,000 small
+    streams (3,000 x 9 x 40 MB would be a terabyte and the whole call would fail)."""
+    import bz2
+    small = [corpus.p_text(1500 + (i % 40) * 50, 900 + i) for i in range(3000)]
+    big = bytes(40 << 20)
+    plains = small[:1000] + [big] + small[1000:]
+    archives = [bz2.compress(p, 9) for p in plains]
+    assert archives[1000].count(bytes.fromhex("314159265359")) == 1
+    got = swc.unarchive_many("bzip2", archives)
+    assert [st for st, _ in got] == [0] * len(archives)
+    assert all(d == p for (_, d), p in zip(got, plains))
+
+
 def test_zip_with_many_entries_stages_the_container_once():
     """Every Deflate entry reads on from its offset to the end of the container (ZipContainer.swift:74), but the container is
     staged once: 3,000 entries in a ~25 MB archive take seconds, not (entries x archive size) of copying."""
