@@ -43,11 +43,10 @@ constexpr int kCheckedLen = 20;
 
 // ---- LDS layout of stage 1 (bytes) ---------------------------------------------------------------
 struct Stage1Lds {
-    uint32_t first[kMaxTables][kMaxLen + 1]; // first[d] = the first code of length d (low d bits matter)
+    uint32_t delta[kMaxTables][kMaxLen + 1]; // delta[d] = start[d] - first[d] (first[d] = the first code of length d): sym index = code + delta
     uint16_t start[kMaxTables][kMaxLen + 2]; // start[d] = index in sym[] of the first symbol of length d, start[kMaxLen + 1] = total
     uint32_t lim[kMaxTables][kMaxLen + 1];   // left-justified (kMaxLen-bit) limits, non-decreasing
     uint32_t oversub[kMaxTables];
-    uint32_t counts[256];                    // histogram of L
     uint16_t sym[kMaxTables][kMaxSyms + 2];  // (length, symbol)-sorted symbols
     int8_t lengths[kMaxSyms + 6];            // scratch while building one table
     uint8_t mtf[256];                        // usedSymbols: the MTF list itself (BZip2.swift:243-245)
@@ -72,7 +71,6 @@ struct BlockHeader {   // stage 1 -> stage 2/3
     uint32_t status;
     uint32_t pad;
     uint64_t end_bit;  // absolute bit position just past the block's EOB symbol
-    uint32_t counts[256];
 };
 // stage 3a -> 3b, kept in BlockHeader::pad
 constexpr uint32_t kWalkNone = 0;     // nothing walked: stage 3b does the serial walk itself
@@ -167,6 +165,7 @@ struct Stage1 {
     Workspace ws;
     int lane;
     uint32_t n_out;     // bytes in L so far
+    uint32_t lcap32;    // min(ws.lcap, 2^32 - 1)
     uint32_t staged;
     bool l_overflow;
 
@@ -179,9 +178,8 @@ struct Stage1 {
         staged = 0;
     }
     SWC_HD void emit(uint8_t b) {
-        if (n_out >= ws.lcap) { l_overflow = true; return; }
+        if (n_out >= lcap32) { l_overflow = true; return; }
         s->stage[staged++] = b;
-        s->counts[b] += 1;
         n_out++;
         if (staged == 64) flush_stage();
     }
@@ -189,7 +187,6 @@ struct Stage1 {
         if (n_out + run > ws.lcap || run > 0xFFFFFFFFull) { l_overflow = true; return; }
         flush_stage();
         for (uint64_t i = (uint64_t)lane; i < run; i += WAVE) ws.L[n_out + i] = b;
-        s->counts[b] += (uint32_t)run;
         n_out += (uint32_t)run;
     }
 
@@ -218,7 +215,7 @@ struct Stage1 {
         for (int d = 1; d <= kMaxLen; d++) {
             s->lim[t][d] = (v + cnt[d]) << (kMaxLen - d);
             if (cnt[d] != 0 && v + cnt[d] > (1u << d)) over = true;
-            s->first[t][d] = v;
+            s->delta[t][d] = off - v;
             s->start[t][d] = (uint16_t)off;
             start[d] = off;
             off += cnt[d];
@@ -234,12 +231,15 @@ struct Stage1 {
     }
 
     // DecodingTree.findNextSymbol for table t: returns the symbol or -1.
-    SWC_HD int decode_symbol(int t, uint32_t my_lim) {
+    // (The symbol loop is bound by the SCALAR instructions it issues -- one block per wave makes it wave-uniform, and all
+    // waves of a CU share one scalar unit -- so everything that does not change between two table switches is kept out of
+    // it: `over` is oversub[t]; the 64-bit "bits left" arithmetic runs only when the window itself is short.)
+    SWC_HD int decode_symbol(int t, uint32_t my_lim, bool over) {
         br.refill();
         const uint32_t c = br.peek(kMaxLen);
         uint32_t len;
         int idx = -1;
-        if (!s->oversub[t]) {
+        if (!over) {
 #if defined(__HIP_DEVICE_COMPILE__)
             if (WAVE > 1) {
                 len = 1 + wave_count(lane >= 1 && lane <= kMaxLen && c >= my_lim);
@@ -251,13 +251,13 @@ struct Stage1 {
             }
             (void)my_lim;
             if (len > kMaxLen) return -1;
-            idx = (int)((uint32_t)s->start[t][len] + (c >> (kMaxLen - len)) - s->first[t][len]);
+            idx = (int)((c >> (kMaxLen - len)) + s->delta[t][len]);
         } else {
             len = 0;
             for (int d = 1; d <= kMaxLen; d++) {
                 const uint32_t st0 = s->start[t][d];
                 const uint32_t cnt = (uint32_t)s->start[t][d + 1] - st0;
-                const uint32_t k0 = ((c >> (kMaxLen - d)) - s->first[t][d]) & ((1u << d) - 1u);
+                const uint32_t k0 = ((c >> (kMaxLen - d)) - (st0 - s->delta[t][d])) & ((1u << d) - 1u);   // (first[d] = start[d] - delta[d])
                 if (k0 < cnt) {
                     len = (uint32_t)d;
                     idx = (int)(st0 + k0 + (((cnt - 1u - k0) >> d) << d));
@@ -266,7 +266,7 @@ struct Stage1 {
             }
             if (idx < 0) return -1;
         }
-        if ((int64_t)len > br.bits_left()) return -1;  // DecodingTree.swift:39
+        if (len > br.bc && (int64_t)len > br.bits_left()) return -1;  // DecodingTree.swift:39 (bits_left() >= bc)
         br.consume(len);
         return (int)s->sym[t][idx];
     }
@@ -288,7 +288,7 @@ struct Stage1 {
         return el;
     }
 
-    // BZip2.swift:97-246.  Returns an swc_status; on success L/counts/n/origPtr are complete.
+    // BZip2.swift:97-246.  Returns an swc_status; on success L/n/origPtr are complete.
     SWC_HD int run(uint32_t& orig_ptr) {
         if (br.bits_left() < 41) return SWC_E_BZIP2_WRONG_MAGIC;  // :103
         if (br.bits(1) != 0) return SWC_E_BZIP2_RANDOMIZED_BLOCK;  // :106
@@ -356,29 +356,36 @@ struct Stage1 {
         int selector_index = 1;
         int table = selector_at(0);
         uint32_t my_lim = (lane >= 1 && lane <= kMaxLen) ? s->lim[table][lane] : 0xFFFFFFFFu;
+        bool over = s->oversub[table] != 0;
         uint64_t run_length = 0, repeat_power = 1;
+        bool in_run = false;   // RUNA / RUNB symbols since the last byte symbol (then run_length may be non-zero)
         for (;;) {
             if (decoded >= 50) {
                 if (!(selector_index < n_selectors)) return SWC_E_BZIP2_WRONG_SELECTOR;  // :214
                 table = selector_at(selector_index);
                 my_lim = (lane >= 1 && lane <= kMaxLen) ? s->lim[table][lane] : 0xFFFFFFFFu;
+                over = s->oversub[table] != 0;
                 selector_index++;
                 decoded = 0;
             }
-            const int symbol = decode_symbol(table, my_lim);
+            const int symbol = decode_symbol(table, my_lim, over);
             if (symbol == -1) return SWC_E_BZIP2_SYMBOL_NOT_FOUND;  // :222
             decoded++;
             if (symbol == 0 || symbol == 1) {  // RUNA / RUNB :226-230 (wrapping, like &+ and smart shifts)
                 run_length += repeat_power << symbol;
                 repeat_power <<= 1;
+                in_run = true;
                 continue;
             }
-            if ((int64_t)run_length > 0) {
-                if (n_used == 0) return SWC_E_REF_TRAP;  // usedSymbols[0] on an empty array
-                emit_run(s->mtf[0], run_length);
-                if (l_overflow) return SWC_E_NEED_WORKSPACE;
-                run_length = 0;
-                repeat_power = 1;
+            if (in_run) {   // (without a RUNA / RUNB since the last test run_length is what that test left: not positive)
+                in_run = false;
+                if ((int64_t)run_length > 0) {
+                    if (n_used == 0) return SWC_E_REF_TRAP;  // usedSymbols[0] on an empty array
+                    emit_run(s->mtf[0], run_length);
+                    if (l_overflow) return SWC_E_NEED_WORKSPACE;
+                    run_length = 0;
+                    repeat_power = 1;
+                }
             }
             if (symbol == used_count - 1) break;  // :239 end of block
             emit(mtf_to_front((uint32_t)symbol - 1));
@@ -397,9 +404,9 @@ SWC_HD void stage1_job(const Job& job, Stage1Lds* lds, Workspace ws, int lane) {
     d.ws = ws;
     d.lane = lane;
     d.n_out = 0;
+    d.lcap32 = ws.lcap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ws.lcap;
     d.staged = 0;
     d.l_overflow = false;
-    for (int i = lane; i < 256; i += WAVE) lds->counts[i] = 0;
     uint32_t orig_ptr = 0;
     int st;
     if (job.dict_len > job.in_len * 8) {
@@ -415,11 +422,10 @@ SWC_HD void stage1_job(const Job& job, Stage1Lds* lds, Workspace ws, int lane) {
         ws.hdr->status = (uint32_t)st;
         ws.hdr->end_bit = d.br.position();
     }
-    for (int i = lane; i < 256; i += WAVE) ws.hdr->counts[i] = lds->counts[i];
 }
 
 // Stage 2: P[base[c]++] = i << 8 | c in increasing i (BurrowsWheeler.swift:38-53), lane-sliced.
-// `cnt` is LDS: uint32_t[256 * WAVE].
+// `cnt` is LDS: uint32_t[256 * WAVE + 256] (per-lane counters, then the totals per byte value).
 template <int WAVE>
 SWC_HD void stage2_job(Workspace ws, uint32_t* cnt, int lane) {
     if (ws.hdr->status != SWC_OK) return;
@@ -431,10 +437,18 @@ SWC_HD void stage2_job(Workspace ws, uint32_t* cnt, int lane) {
     for (int c = 0; c < 256; c++) cnt[c * WAVE + lane] = 0;
     for (uint32_t i = lo; i < hi; i++) cnt[(uint32_t)ws.L[i] * WAVE + lane] += 1;
     // exclusive scan over (symbol, lane) in symbol-major order; lane l owns symbols l, l+WAVE, ...
-    // first the per-symbol bases from the histogram of stage 1
+    // first the histogram of L (stage 1 does not keep one: a counter update per symbol costs its serial loop more than
+    // these 256 x WAVE additions cost here), then the per-symbol bases
+    uint32_t* tot = cnt + 256 * WAVE;
+    for (int c = lane; c < 256; c += WAVE) {
+        uint32_t t = 0;
+        for (int l = 0; l < WAVE; l++) t += cnt[c * WAVE + l];
+        tot[c] = t;
+    }
+    // (tot[] was written by other lanes of this wave: LDS accesses of one wave are performed in order)
     for (int c = lane; c < 256; c += WAVE) {
         uint32_t base = 0;
-        for (int k = 0; k < c; k++) base += ws.hdr->counts[k];
+        for (int k = 0; k < c; k++) base += tot[k];
         for (int l = 0; l < WAVE; l++) {
             const uint32_t t = cnt[c * WAVE + l];
             cnt[c * WAVE + l] = base;

@@ -213,10 +213,10 @@ __global__ __launch_bounds__(64) void swc_bzip2_stage1_kernel(const Job* __restr
 }
 
 __global__ __launch_bounds__(64) void swc_bzip2_stage2_kernel(uint32_t n, uint8_t* ws, size_t lcap) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t bz_lds[];
+    __shared__ __attribute__((aligned(16))) uint32_t bz_cnt[256 * kWave + 256];   // 65 KiB, static: more than 64 KiB of dynamic LDS would need an opt-in
     uint32_t g = blockIdx.x;
     if (g >= n) return;
-    bzip2::stage2_job<kWave>(bzip2::carve(ws, g, lcap), reinterpret_cast<uint32_t*>(bz_lds), (int)threadIdx.x);
+    bzip2::stage2_job<kWave>(bzip2::carve(ws, g, lcap), bz_cnt, (int)threadIdx.x);
 }
 
 // stage 3a: one block per wave (cut the BWT cycle into segments, walk them with all lanes, order, lay out, undo RLE1)
@@ -281,7 +281,7 @@ hipError_t launch_bzip2(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStrea
     const size_t lcap = lo;
     dim3 block(kWave);
     hipLaunchKernelGGL(swc_bzip2_stage1_kernel, dim3((unsigned)n), block, bzip2::kStage1LdsBytes, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
-    hipLaunchKernelGGL(swc_bzip2_stage2_kernel, dim3((unsigned)n), block, 256 * kWave * 4, stream, (uint32_t)n, (uint8_t*)ws, lcap);
+    hipLaunchKernelGGL(swc_bzip2_stage2_kernel, dim3((unsigned)n), block, 0, stream, (uint32_t)n, (uint8_t*)ws, lcap);
     hipLaunchKernelGGL(swc_bzip2_walk_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
     hipLaunchKernelGGL(swc_bzip2_expand_kernel, dim3((unsigned)((n + kWave - 1) / kWave)), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
     hipLaunchKernelGGL(swc_bzip2_crc_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, (uint32_t)n);

@@ -69,7 +69,7 @@ extern "C" void emu_lzma(swc::Job* jobs, size_t n, int is_lzma2) {
 extern "C" void emu_bzip2_block(swc::Job* jobs, size_t n, size_t lcap) {
     using namespace swc::bzip2;
     std::vector<uint8_t> ws(ws_bytes_per_job(lcap) + 64);
-    std::vector<uint32_t> cnt(256);
+    std::vector<uint32_t> cnt(256 + 256);
     Stage1Lds lds;
     Stage3Lds lds3;
     static swc::crc::Lds<1, uint32_t> crc_lds;
