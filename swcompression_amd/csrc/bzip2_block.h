@@ -4,9 +4,13 @@
 // (Sources/BZip2/BurrowsWheeler.swift:29-64) and CheckSums.bzip2crc32 (Sources/Common/CheckSums.swift:30-37):
 //
 //   stage 1  one block per WAVEFRONT  symbol map, selectors (MTF), 2-6 Huffman tables, symbol loop with
-//            RUNA/RUNB runs and inverse MTF  ->  the BWT last column L[0..n) in the HBM workspace plus the
-//            per-byte histogram.  The decode chain is serial, so it runs wave-uniform; the 20 code-length
-//            limit compares, the MTF list shift, run fills and L stores are spread over the lanes.
+//            RUNA/RUNB runs and inverse MTF  ->  the BWT last column L[0..n) in the HBM workspace.  The decode chain
+//            is serial and a wave follows it at the LATENCY of one symbol, so the symbol loop keeps everything it
+//            touches per symbol in REGISTERS spread over the 64 lanes -- the code-length limits and index deltas of
+//            the active table (lane d: length d), its symbols (two per lane and register), the MTF list (four bytes
+//            per lane, shifted with one cross-lane move), the staged output (a byte per lane) -- and reads them with
+//            ballots and v_readlane: no LDS round trip in the chain.  The tables of all 2-6 codes stay in LDS and are
+//            loaded into the registers at a table switch (every 50 symbols).
 //   stage 2  one block per WAVEFRONT  stable counting-sort scatter  P[base[c]++] = i << 8 | c  (c = L[i]),
 //            each lane owning a contiguous slice of i (per-lane counters in LDS).
 //   stage 3a one block per WAVEFRONT  the n dependent gathers  v = P[end]; end = v >> 8; byte = v & 255  form ONE cycle
@@ -32,6 +36,7 @@
 #define SWC_BZIP2_BLOCK_H
 
 #include "swc_common.h"
+#include "simt.h"
 
 namespace swc {
 namespace bzip2 {
@@ -49,9 +54,8 @@ struct Stage1Lds {
     uint32_t oversub[kMaxTables];
     uint16_t sym[kMaxTables][kMaxSyms + 2];  // (length, symbol)-sorted symbols
     int8_t lengths[kMaxSyms + 6];            // scratch while building one table
-    uint8_t mtf[256];                        // usedSymbols: the MTF list itself (BZip2.swift:243-245)
+    alignas(4) uint8_t mtf[256];             // usedSymbols as the header leaves it (BZip2.swift:128-137); the symbol loop keeps the list in registers
     uint8_t tmtf[8];                         // selector MTF
-    uint8_t stage[64];                       // L staging for coalesced stores
     uint32_t tcnt[kMaxLen + 2];              // scratch while building one table
     uint32_t tstart[kMaxLen + 2];
 };
@@ -111,15 +115,18 @@ SWC_HD Workspace carve(uint8_t* base, size_t job, size_t lcap) {
     return w;
 }
 
-// MSB-first bit reader (BitByteData.MsbBitReader contract), wave-uniform.
+// MSB-first bit reader (BitByteData.MsbBitReader contract), wave-uniform, with one dword of read-ahead so that the
+// memory latency of a refill is hidden behind the symbols decoded from the window.
 struct MsbReader {
     gcptr in;
     uint64_t n;        // bytes
     uint64_t next;     // next byte to load
     uint64_t bb;       // next bit at bit 63
     uint32_t bc;
+    uint32_t pw;       // the dword at `next`, already loaded (pw_ok)
+    bool pw_ok;
     SWC_HD void init(gcptr p, uint64_t nbytes, uint64_t start_bit) {
-        in = p; n = nbytes; next = start_bit >> 3; bb = 0; bc = 0;
+        in = p; n = nbytes; next = start_bit >> 3; bb = 0; bc = 0; pw = 0; pw_ok = false;
         refill();
         uint32_t skip = (uint32_t)(start_bit & 7);
         if (skip > bc) skip = bc;
@@ -129,12 +136,15 @@ struct MsbReader {
     SWC_HD void refill() {
         if (bc <= 32) {
             if (next + 4 <= n) {
-                uint32_t w = load_u32(in + next);
+                uint32_t w = simt::uniform(pw_ok ? pw : load_u32(in + next));
                 w = (w >> 24) | ((w >> 8) & 0xFF00u) | ((w << 8) & 0xFF0000u) | (w << 24);
                 bb |= (uint64_t)w << (32 - bc);
                 bc += 32;
                 next += 4;
+                pw_ok = next + 4 <= n;
+                if (pw_ok) pw = load_u32(in + next);
             } else {
+                pw_ok = false;
                 while (bc <= 56 && next < n) {
                     bb |= (uint64_t)in[next++] << (56 - bc);
                     bc += 8;
@@ -166,29 +176,6 @@ struct Stage1 {
     int lane;
     uint32_t n_out;     // bytes in L so far
     uint32_t lcap32;    // min(ws.lcap, 2^32 - 1)
-    uint32_t staged;
-    bool l_overflow;
-
-    SWC_HD void flush_stage() {
-        if (WAVE == 1) {
-            for (uint32_t i = 0; i < staged; i++) ws.L[n_out - staged + i] = s->stage[i];
-        } else {
-            if ((uint32_t)lane < staged) ws.L[n_out - staged + lane] = s->stage[lane];
-        }
-        staged = 0;
-    }
-    SWC_HD void emit(uint8_t b) {
-        if (n_out >= lcap32) { l_overflow = true; return; }
-        s->stage[staged++] = b;
-        n_out++;
-        if (staged == 64) flush_stage();
-    }
-    SWC_HD void emit_run(uint8_t b, uint64_t run) {
-        if (n_out + run > ws.lcap || run > 0xFFFFFFFFull) { l_overflow = true; return; }
-        flush_stage();
-        for (uint64_t i = (uint64_t)lane; i < run; i += WAVE) ws.L[n_out + i] = b;
-        n_out += (uint32_t)run;
-    }
 
     // Selectors were stored to HBM by lane 0; lane 0 reads them back (same-lane store -> load order is
     // architectural) and the value is broadcast, so no cross-lane memory visibility is assumed.
@@ -271,23 +258,6 @@ struct Stage1 {
         return (int)s->sym[t][idx];
     }
 
-    // usedSymbols.remove(at: idx) + insert(at: 0)  (BZip2.swift:243-244), spread over the lanes
-    SWC_HD uint8_t mtf_to_front(uint32_t idx) {
-        const uint8_t el = s->mtf[idx];
-        if (WAVE == 1) {
-            for (uint32_t j = idx; j > 0; j--) s->mtf[j] = s->mtf[j - 1];
-        } else {
-            for (int base = (int)((idx == 0 ? 0 : idx - 1) / WAVE) * WAVE; base >= 0 && idx > 0; base -= WAVE) {
-                const uint32_t j = (uint32_t)base + (uint32_t)lane;
-                uint8_t t = 0;
-                if (j < idx) t = s->mtf[j];
-                if (j < idx) s->mtf[j + 1] = t;
-            }
-        }
-        s->mtf[0] = el;
-        return el;
-    }
-
     // BZip2.swift:97-246.  Returns an swc_status; on success L/n/origPtr are complete.
     SWC_HD int run(uint32_t& orig_ptr) {
         if (br.bits_left() < 41) return SWC_E_BZIP2_WRONG_MAGIC;  // :103
@@ -350,12 +320,41 @@ struct Stage1 {
             const int st = build_table(t, used_count);
             if (st) return st;
         }
-        // ---- symbol loop :205-246
+        return symbol_loop(n_selectors, used_count, n_used);
+    }
+
+    // ---- symbol loop :205-246, state in registers (see the header comment) ---------------------------------------------
+    SWC_HD int symbol_loop(int n_selectors, int used_count, int n_used) {
+        using simt::PT;
+        constexpr int N = 64;
         if (n_selectors == 0) return SWC_E_REF_TRAP;  // selectors[0] on an empty array (App. A B3)
+        PT<uint32_t, N> my_lim, my_delta, sym_a, sym_b, sym_c, mtf, stg, tmp, prev;
+        PT<bool, N> pb;
+        SIMT_BEGIN(t, N)
+            mtf[t] = *(const uint32_t*)(s->mtf + 4 * t);   // lane t: list positions 4t .. 4t + 3, position 4t in the low byte
+            stg[t] = 0;
+        SIMT_END
+        auto load_table = [&](int tb) {   // lane d: limit and index delta of code length d; lane t: symbols t, t + 64, ... of the sorted array
+            SIMT_BEGIN(t, N)
+                const bool len_lane = t >= 1 && t <= kMaxLen;
+                my_lim[t] = len_lane ? s->lim[tb][t] : 0xFFFFFFFFu;
+                my_delta[t] = len_lane ? s->delta[tb][t] : 0u;
+                const uint16_t* sy = s->sym[tb];
+                sym_a[t] = (uint32_t)sy[t] | ((uint32_t)sy[t + 64] << 16);
+                sym_b[t] = (uint32_t)sy[t + 128] | ((uint32_t)sy[t + 192] << 16);
+                sym_c[t] = t < kMaxSyms + 2 - 256 ? (uint32_t)sy[256 + t] : 0u;
+            SIMT_END
+        };
+        uint32_t sbase = 0;   // L[sbase .. n_out) is staged: lane k holds byte sbase + k
+        auto flush = [&]() {
+            const uint32_t cnt = n_out - sbase;
+            SIMT_BEGIN(t, N) if ((uint32_t)t < cnt) ws.L[sbase + (uint32_t)t] = (uint8_t)stg[t]; SIMT_END
+            sbase = n_out;
+        };
         int decoded = 0;
         int selector_index = 1;
         int table = selector_at(0);
-        uint32_t my_lim = (lane >= 1 && lane <= kMaxLen) ? s->lim[table][lane] : 0xFFFFFFFFu;
+        load_table(table);
         bool over = s->oversub[table] != 0;
         uint64_t run_length = 0, repeat_power = 1;
         bool in_run = false;   // RUNA / RUNB symbols since the last byte symbol (then run_length may be non-zero)
@@ -363,13 +362,28 @@ struct Stage1 {
             if (decoded >= 50) {
                 if (!(selector_index < n_selectors)) return SWC_E_BZIP2_WRONG_SELECTOR;  // :214
                 table = selector_at(selector_index);
-                my_lim = (lane >= 1 && lane <= kMaxLen) ? s->lim[table][lane] : 0xFFFFFFFFu;
+                load_table(table);
                 over = s->oversub[table] != 0;
                 selector_index++;
                 decoded = 0;
             }
-            const int symbol = decode_symbol(table, my_lim, over);
-            if (symbol == -1) return SWC_E_BZIP2_SYMBOL_NOT_FOUND;  // :222
+            int symbol;
+            if (!over) {   // DecodingTree.findNextSymbol for a prefix-free set: length by ballot, index and symbol by readlane
+                br.refill();
+                const uint32_t c = br.peek(kMaxLen);
+                SIMT_BEGIN(t, N) pb[t] = c >= my_lim[t]; SIMT_END
+                const uint32_t len = 1u + (uint32_t)simt::popc64(simt::wave_ballot<N>(pb));
+                if (len > (uint32_t)kMaxLen) return SWC_E_BZIP2_SYMBOL_NOT_FOUND;  // :222
+                const uint32_t idx = (c >> (kMaxLen - len)) + simt::wave_read<N>(my_delta, (int)len);
+                if (len > br.bc && (int64_t)len > br.bits_left()) return SWC_E_BZIP2_SYMBOL_NOT_FOUND;  // DecodingTree.swift:39
+                br.consume(len);
+                SIMT_BEGIN(t, N) tmp[t] = idx < 128u ? sym_a[t] : idx < 256u ? sym_b[t] : sym_c[t]; SIMT_END
+                const uint32_t w = simt::wave_read<N>(tmp, (int)(idx & 63u));
+                symbol = (int)(((idx & 64u) != 0u && idx < 256u) ? w >> 16 : w & 0xFFFFu);
+            } else {       // over-subscribed set (never written by an encoder): the heap semantics, from LDS
+                symbol = decode_symbol(table, 0u, true);
+                if (symbol == -1) return SWC_E_BZIP2_SYMBOL_NOT_FOUND;  // :222
+            }
             decoded++;
             if (symbol == 0 || symbol == 1) {  // RUNA / RUNB :226-230 (wrapping, like &+ and smart shifts)
                 run_length += repeat_power << symbol;
@@ -381,17 +395,47 @@ struct Stage1 {
                 in_run = false;
                 if ((int64_t)run_length > 0) {
                     if (n_used == 0) return SWC_E_REF_TRAP;  // usedSymbols[0] on an empty array
-                    emit_run(s->mtf[0], run_length);
-                    if (l_overflow) return SWC_E_NEED_WORKSPACE;
+                    if ((uint64_t)n_out + run_length > ws.lcap || run_length > 0xFFFFFFFFull) return SWC_E_NEED_WORKSPACE;
+                    flush();
+                    const uint32_t b = simt::wave_read<N>(mtf, 0) & 255u;
+                    const uint32_t run = (uint32_t)run_length;
+                    SIMT_BEGIN(t, N) for (uint32_t i = (uint32_t)t; i < run; i += (uint32_t)N) ws.L[n_out + i] = (uint8_t)b; SIMT_END
+                    n_out += run;
+                    sbase = n_out;
                     run_length = 0;
                     repeat_power = 1;
                 }
             }
             if (symbol == used_count - 1) break;  // :239 end of block
-            emit(mtf_to_front((uint32_t)symbol - 1));
-            if (l_overflow) return SWC_E_NEED_WORKSPACE;
+            // usedSymbols.remove(at: m) + insert(at: 0)  (BZip2.swift:243-244): positions 0 .. m - 1 move up by one
+            const uint32_t m = (uint32_t)symbol - 1u;
+            const uint32_t q = m >> 2, r = m & 3u;
+            const uint32_t el = (simt::wave_read<N>(mtf, (int)q) >> (8u * r)) & 255u;
+            if (m != 0u) {
+                if (q != 0u) simt::wave_shift_up<N>(prev, mtf, 0u);
+                SIMT_BEGIN(t, N)
+                    const uint32_t cur = mtf[t];
+                    const uint32_t up = (cur << 8) | ((q != 0u && t != 0) ? prev[t] >> 24 : 0u);   // every byte one position up
+                    uint32_t nv = cur;
+                    if ((uint32_t)t < q) nv = up;
+                    else if ((uint32_t)t == q) {
+                        const uint32_t mask = r == 3u ? 0xFFFFFFFFu : (1u << (8u * (r + 1u))) - 1u;   // positions 4q .. m
+                        nv = (up & mask) | (cur & ~mask);
+                    }
+                    if (t == 0) nv = (nv & ~0xFFu) | el;
+                    mtf[t] = nv;
+                SIMT_END
+            }
+            // L[n_out] = el, staged a byte per lane
+            if (n_out >= lcap32) return SWC_E_NEED_WORKSPACE;
+            {
+                const uint32_t k = n_out - sbase;
+                SIMT_BEGIN(t, N) if ((uint32_t)t == k) stg[t] = el; SIMT_END
+            }
+            n_out++;
+            if (n_out - sbase == (uint32_t)N) flush();
         }
-        flush_stage();
+        flush();
         return SWC_OK;
     }
 };
@@ -405,8 +449,6 @@ SWC_HD void stage1_job(const Job& job, Stage1Lds* lds, Workspace ws, int lane) {
     d.lane = lane;
     d.n_out = 0;
     d.lcap32 = ws.lcap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ws.lcap;
-    d.staged = 0;
-    d.l_overflow = false;
     uint32_t orig_ptr = 0;
     int st;
     if (job.dict_len > job.in_len * 8) {
