@@ -466,41 +466,81 @@ SWC_HD void stage1_job(const Job& job, Stage1Lds* lds, Workspace ws, int lane) {
     }
 }
 
-// Stage 2: P[base[c]++] = i << 8 | c in increasing i (BurrowsWheeler.swift:38-53), lane-sliced.
-// `cnt` is LDS: uint32_t[256 * WAVE + 256] (per-lane counters, then the totals per byte value).
-template <int WAVE>
-SWC_HD void stage2_job(Workspace ws, uint32_t* cnt, int lane) {
+// Stage 2: P[base[c]++] = i << 8 | c in increasing i (BurrowsWheeler.swift:38-53) -- a STABLE counting sort by the 64
+// lanes of a wave.  L is read 64 consecutive bytes at a time (one coalesced load); inside such a group a lane finds the
+// lanes that hold the same byte value with eight ballots (one per bit of the value), its rank among them (the order of
+// i is the order of the lanes) and their number; the first lane of every value adds the number to the value's counter.
+// One pass counts, a wave scan turns the 256 counters into start positions, a second pass scatters.  `cnt`: 256 words
+// of LDS (the earlier form -- a private slice of L and 256 private counters per lane -- needed 64 KiB and read L with
+// 64 different lines per load).
+struct Match {   // of one group of 64 bytes
+    simt::PT<uint32_t, 64> rank, count;
+};
+SWC_HD void match_bytes(const simt::PT<uint32_t, 64>& sym, const simt::PT<bool, 64>& act, Match& m) {
+    using simt::PT;
+    constexpr int N = 64;
+    PT<bool, N> pb;
+    uint64_t bal[8];
+    SIMT_BEGIN(t, N) pb[t] = act[t]; SIMT_END
+    const uint64_t m_act = simt::wave_ballot<N>(pb);
+#pragma unroll
+    for (int b = 0; b < 8; b++) {
+        SIMT_BEGIN(t, N) pb[t] = act[t] && ((sym[t] >> b) & 1u) != 0u; SIMT_END
+        bal[b] = simt::wave_ballot<N>(pb);
+    }
+    SIMT_BEGIN(t, N)
+        uint64_t same = m_act;
+#pragma unroll
+        for (int b = 0; b < 8; b++) same &= ((sym[t] >> b) & 1u) ? bal[b] : ~bal[b];
+        m.rank[t] = (uint32_t)simt::popc64(same & ((1ull << t) - 1ull));
+        m.count[t] = (uint32_t)simt::popc64(same);
+    SIMT_END
+}
+SWC_HD void stage2_job(Workspace ws, uint32_t* cnt) {
+    using simt::PT;
+    constexpr int N = 64;
     if (ws.hdr->status != SWC_OK) return;
     const uint32_t n = ws.hdr->n;
     if (n == 0) return;
-    const uint32_t chunk = (n + WAVE - 1) / WAVE;
-    const uint32_t lo = (uint32_t)lane * chunk < n ? (uint32_t)lane * chunk : n;
-    const uint32_t hi = lo + chunk < n ? lo + chunk : n;
-    for (int c = 0; c < 256; c++) cnt[c * WAVE + lane] = 0;
-    for (uint32_t i = lo; i < hi; i++) cnt[(uint32_t)ws.L[i] * WAVE + lane] += 1;
-    // exclusive scan over (symbol, lane) in symbol-major order; lane l owns symbols l, l+WAVE, ...
-    // first the histogram of L (stage 1 does not keep one: a counter update per symbol costs its serial loop more than
-    // these 256 x WAVE additions cost here), then the per-symbol bases
-    uint32_t* tot = cnt + 256 * WAVE;
-    for (int c = lane; c < 256; c += WAVE) {
-        uint32_t t = 0;
-        for (int l = 0; l < WAVE; l++) t += cnt[c * WAVE + l];
-        tot[c] = t;
+    PT<uint32_t, N> sym, nsym, s4;
+    PT<bool, N> act;
+    Match m;
+    SIMT_BEGIN(t, N)
+        for (int c = t; c < 256; c += N) cnt[c] = 0;
+        nsym[t] = (uint32_t)t < n ? (uint32_t)ws.L[t] : 0u;
+    SIMT_END_WAVE
+    // ---- count
+    for (uint32_t i0 = 0; i0 < n; i0 += N) {
+        SIMT_BEGIN(t, N)
+            const uint32_t i = i0 + (uint32_t)t;
+            act[t] = i < n;
+            sym[t] = nsym[t];
+            nsym[t] = i + N < n ? (uint32_t)ws.L[i + N] : 0u;   // the next group is on its way while this one is ranked
+        SIMT_END
+        match_bytes(sym, act, m);
+        SIMT_BEGIN(t, N) if (act[t] && m.rank[t] == 0u) cnt[sym[t]] += m.count[t]; SIMT_END_WAVE
     }
-    // (tot[] was written by other lanes of this wave: LDS accesses of one wave are performed in order)
-    for (int c = lane; c < 256; c += WAVE) {
-        uint32_t base = 0;
-        for (int k = 0; k < c; k++) base += tot[k];
-        for (int l = 0; l < WAVE; l++) {
-            const uint32_t t = cnt[c * WAVE + l];
-            cnt[c * WAVE + l] = base;
-            base += t;
-        }
-    }
-    for (uint32_t i = lo; i < hi; i++) {
-        const uint32_t c = ws.L[i];
-        const uint32_t j = cnt[c * WAVE + lane]++;
-        ws.P[j] = (i << 8) | c;
+    // ---- counters -> start positions (exclusive prefix sum over the byte values; lane t owns the values 4t .. 4t + 3)
+    SIMT_BEGIN(t, N) s4[t] = cnt[4 * t] + cnt[4 * t + 1] + cnt[4 * t + 2] + cnt[4 * t + 3]; SIMT_END
+    simt::wave_scan_incl<N>(s4);
+    SIMT_BEGIN(t, N)
+        uint32_t base = s4[t] - (cnt[4 * t] + cnt[4 * t + 1] + cnt[4 * t + 2] + cnt[4 * t + 3]);
+        for (int k = 0; k < 4; k++) { const uint32_t c = cnt[4 * t + k]; cnt[4 * t + k] = base; base += c; }
+        nsym[t] = (uint32_t)t < n ? (uint32_t)ws.L[t] : 0u;
+    SIMT_END_WAVE
+    // ---- scatter
+    for (uint32_t i0 = 0; i0 < n; i0 += N) {
+        SIMT_BEGIN(t, N)
+            const uint32_t i = i0 + (uint32_t)t;
+            act[t] = i < n;
+            sym[t] = nsym[t];
+            nsym[t] = i + N < n ? (uint32_t)ws.L[i + N] : 0u;
+        SIMT_END
+        match_bytes(sym, act, m);
+        SIMT_BEGIN(t, N)
+            if (act[t]) ws.P[cnt[sym[t]] + m.rank[t]] = ((i0 + (uint32_t)t) << 8) | sym[t];
+        SIMT_END_WAVE
+        SIMT_BEGIN(t, N) if (act[t] && m.rank[t] == 0u) cnt[sym[t]] += m.count[t]; SIMT_END_WAVE
     }
 }
 

@@ -213,10 +213,10 @@ __global__ __launch_bounds__(64) void swc_bzip2_stage1_kernel(const Job* __restr
 }
 
 __global__ __launch_bounds__(64) void swc_bzip2_stage2_kernel(uint32_t n, uint8_t* ws, size_t lcap) {
-    __shared__ __attribute__((aligned(16))) uint32_t bz_cnt[256 * kWave + 256];   // 65 KiB, static: more than 64 KiB of dynamic LDS would need an opt-in
+    __shared__ uint32_t bz_cnt[256];
     uint32_t g = blockIdx.x;
     if (g >= n) return;
-    bzip2::stage2_job<kWave>(bzip2::carve(ws, g, lcap), bz_cnt, (int)threadIdx.x);
+    bzip2::stage2_job(bzip2::carve(ws, g, lcap), bz_cnt);
 }
 
 // stage 3a: one block per wave (cut the BWT cycle into segments, walk them with all lanes, order, lay out, undo RLE1)

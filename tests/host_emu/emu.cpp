@@ -78,7 +78,7 @@ extern "C" void emu_bzip2_block(swc::Job* jobs, size_t n, size_t lcap) {
         std::fill(ws.begin(), ws.end(), (uint8_t)0xCD);
         Workspace w = carve(ws.data(), 0, lcap);
         stage1_job<1>(jobs[g], &lds, w, 0);
-        stage2_job<1>(w, cnt.data(), 0);
+        stage2_job(w, cnt.data());
         std::memset(&lds3, 0xEE, sizeof lds3);
         stage3_walk_job<1>(jobs[g], w, &lds3, 0);
         if (stage3_expand_needed(w)) stage3_expand_job(jobs[g], w);
