@@ -44,7 +44,7 @@ WORKLOADS = {
                    desc="8192 x 4 MiB independent LZ4 blocks (BASELINE configs[2], resident micro-config of SURVEY 8d)",
                    kernels="swc_lz4_parse_kernel + swc_lz4_resolve_kernel", steps=3),
     "bzip2_900k": dict(codec="bzip2_block", kind="bzip2", n_distinct=32, n_units=10240, unit=899000,
-                       desc="10240 x 900 kB bzip2 blocks (BASELINE configs[3])", kernels="swc_bzip2_stage1/2 + walk/expand/crc kernels", steps=2),
+                       desc="10240 x 900 kB bzip2 blocks (BASELINE configs[3])", kernels="swc_bzip2_block_kernel (stage 1 + stage 2 + walk) + expand/crc kernels", steps=2),
     "lzma2_256k": dict(codec="lzma2", kind="lzma2", n_distinct=128, n_units=32768, unit=262144,
                        desc="32768 x 256 KiB raw-LZMA2 units (BASELINE configs[4])", kernels="swc_lzma_kernel", steps=2),
 }

@@ -203,30 +203,25 @@ hipError_t launch_lzma(bool lzma2, Job* jobs, size_t n, void* spill, hipStream_t
     return hipGetLastError();
 }
 
-// ---- BZip2: three stages per block (see bzip2_block.h) ---------------------------------------------
-__global__ __launch_bounds__(64) void swc_bzip2_stage1_kernel(const Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t lcap) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t bz_lds[];
-    uint32_t g = blockIdx.x;
-    if (g >= n) return;
-    Job job = jobs[g];
-    bzip2::stage1_job<kWave>(job, reinterpret_cast<bzip2::Stage1Lds*>(bz_lds), bzip2::carve(ws, g, lcap), (int)threadIdx.x);
-}
-
-__global__ __launch_bounds__(64) void swc_bzip2_stage2_kernel(uint32_t n, uint8_t* ws, size_t lcap) {
-    __shared__ uint32_t bz_cnt[256];
-    uint32_t g = blockIdx.x;
-    if (g >= n) return;
-    bzip2::stage2_job(bzip2::carve(ws, g, lcap), bz_cnt);
-}
-
-// stage 3a: one block per wave (cut the BWT cycle into segments, walk them with all lanes, order, lay out, undo RLE1)
-__global__ __launch_bounds__(64) void swc_bzip2_walk_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t lcap) {
-    __shared__ bzip2::Stage3Lds lds;
+// ---- BZip2: three stages per block (see bzip2_block.h), ONE kernel ----------------------------------------------
+// A wavefront takes its block through stage 1 (Huffman + MTF: bound by the CU's scalar unit, which all resident waves
+// share), stage 2 (counting-sort scatter) and stage 3a (the segmented walk of the BWT cycle: bound by the latency of
+// random HBM accesses) back to back.  As separate launches the three ran one after the other, each limited by its own
+// resource while the others idled; in one kernel the waves of a CU are at different stages at any time, so the scalar
+// work of some overlaps the memory waits of the others.  LDS: the three stages' areas share one allocation.
+constexpr size_t kBzLdsBytes = bzip2::kStage1LdsBytes > sizeof(bzip2::Stage3Lds) ? (size_t)bzip2::kStage1LdsBytes : sizeof(bzip2::Stage3Lds);
+static_assert(kBzLdsBytes >= 256 * sizeof(uint32_t), "stage 2 counters");
+__global__ __launch_bounds__(64) void swc_bzip2_block_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t lcap) {
+    __shared__ __attribute__((aligned(16))) uint8_t bz_lds[kBzLdsBytes];
     uint32_t g = blockIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
     const bzip2::Workspace w = bzip2::carve(ws, g, lcap);
-    bzip2::stage3_walk_job<kWave>(job, w, &lds, (int)threadIdx.x);
+    bzip2::stage1_job<kWave>(job, reinterpret_cast<bzip2::Stage1Lds*>(bz_lds), w, (int)threadIdx.x);
+    __threadfence_block();   // L and the block header, written by some lanes, are read by all of them from here on
+    bzip2::stage2_job(w, reinterpret_cast<uint32_t*>(bz_lds));
+    __threadfence_block();   // likewise the pointer array P
+    bzip2::stage3_walk_job<kWave>(job, w, reinterpret_cast<bzip2::Stage3Lds*>(bz_lds), (int)threadIdx.x);
     if (threadIdx.x == 0 && !bzip2::stage3_expand_needed(w)) {
         jobs[g].out_len = job.out_len;
         jobs[g].in_consumed = job.in_consumed;
@@ -280,9 +275,7 @@ hipError_t launch_bzip2(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStrea
     }
     const size_t lcap = lo;
     dim3 block(kWave);
-    hipLaunchKernelGGL(swc_bzip2_stage1_kernel, dim3((unsigned)n), block, bzip2::kStage1LdsBytes, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
-    hipLaunchKernelGGL(swc_bzip2_stage2_kernel, dim3((unsigned)n), block, 0, stream, (uint32_t)n, (uint8_t*)ws, lcap);
-    hipLaunchKernelGGL(swc_bzip2_walk_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
+    hipLaunchKernelGGL(swc_bzip2_block_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
     hipLaunchKernelGGL(swc_bzip2_expand_kernel, dim3((unsigned)((n + kWave - 1) / kWave)), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
     hipLaunchKernelGGL(swc_bzip2_crc_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, (uint32_t)n);
     return hipGetLastError();
