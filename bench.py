@@ -63,6 +63,9 @@ def parse_args():
     ap.add_argument("--streamed-only", action="store_true", help="only the streamed configs[2] mode (waves through pinned host buffers)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--tuning", action="append", default=[], help="key=value for swc_set_tuning (comparison runs only)")
+    ap.add_argument("--rehearse-on-one-gpu", action="store_true",
+                    help="multi-rank REHEARSAL on a box with one GPU: all ranks share cuda:0 and the bookkeeping collectives run over gloo "
+                         "(exercises sharding, barriers and the max-over-ranks clock; the figure it prints is not a scaling result)")
     return ap.parse_args()
 
 
@@ -286,8 +289,9 @@ def run_workload(name, args, lib, torch, dist, world, rank, device, steps, warmu
     launch_ms = [s.elapsed_time(e) for s, e in ev]
 
     if world > 1:
-        tm = torch.tensor([dt], dtype=torch.float64, device=device)
-        ts = torch.tensor([float(sum_u), float(sum_c)], dtype=torch.float64, device=device)
+        cdev = "cpu" if args.rehearse_on_one_gpu else device
+        tm = torch.tensor([dt], dtype=torch.float64, device=cdev)
+        ts = torch.tensor([float(sum_u), float(sum_c)], dtype=torch.float64, device=cdev)
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         dist.all_reduce(ts, op=dist.ReduceOp.SUM)
         dt_max, tot_u = float(tm[0].item()), float(ts[0].item())
@@ -417,11 +421,16 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the engine has no CPU path")
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = "cuda:%d" % local_rank
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device(device))  # "nccl" IS RCCL on ROCm
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device(device))  # "nccl" IS RCCL on ROCm
 
     from swcompression_amd import _lib
     lib = _lib.load()
