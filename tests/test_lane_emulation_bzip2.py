@@ -104,3 +104,21 @@ def test_unchecked_final_code_length():
         assert r[0] == e[0], (eob_len, r[0], e[0])
         if e[0] == 0:
             assert r[1] == e[1]
+
+
+def test_lane_order_does_not_matter():
+    """The stage-1 symbol loop and the stage-2 counting sort are written as SIMT regions over 64 lanes (csrc/simt.h): the host
+    build runs a region's lanes in forward, reverse or shuffled order, and a region that depends on the order of its lanes
+    would show up as a difference here."""
+    import bz2
+    from swcompression_amd import corpus
+    cases = [(bz2.compress(corpus.PAYLOADS[k](n, 7), 9), corpus.PAYLOADS[k](n, 7)) for k in ("text", "mix", "zero", "rand") for n in (1, 300, 70000)]
+    try:
+        for order in (0, 1, 2):
+            E.set_order(order)
+            res = E.bzip2_block([z for z, _ in cases], [112] * len(cases), [int.from_bytes(z[10:14], "big") for z, _ in cases],
+                                [max(len(x), 1) for _, x in cases])
+            for r, (z, x) in zip(res, cases):
+                assert r[:2] == (0, x), order
+    finally:
+        E.set_order(0)
