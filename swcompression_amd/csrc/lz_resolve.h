@@ -76,10 +76,10 @@ struct Lds {
     static constexpr uint32_t kLitWin = 16u * T;          // bytes of the literal stream staged ahead
     alignas(16) uint8_t ring[kRing];                       // byte at virtual position v lives at ring[v % kRing]
     alignas(16) uint8_t litbuf[kLitWin];                   // literal byte at stream offset o lives at litbuf[o % kLitWin]
-    alignas(8) uint64_t rec8[T + 1];                       // end | mstart << 16 | litadj << 32 | (distance - 1) << 48, relative to the span
+    alignas(8) uint64_t rec8[T + 18];                      // per record, in CELL indices (span-relative + off): mstart | thr << 16 | distance << 32 | litkey << 48 (see R1)
     uint32_t slotw[T + 1];                                 // per 16-cell slot: record that covers its first in-span cell | record-start flags of its cells << 16
     uint32_t wave_sum[2 * (T / 64) + 2];
-    uint32_t ntake, span, litspan;
+    uint32_t ntake, span, litspan, overlap;
 };
 
 template <int T, int RING_LOG2, uint32_t KEEP>
@@ -133,6 +133,44 @@ struct Resolver {
         *(uint16_t*)(ring + ((cbase + 2u * ci) & kMask)) = (uint16_t)v;
     }
 
+    // ---- R2, one CELL per thread and step.  Everything is a select over precomputed per-record geometry (rec8): which record
+    // (slot word + popcount), literal or match (ci < mstart), the ONE LDS byte read (literal window or ring), value or source
+    // index (ci >= thr).  The trip count is the same for every thread (cells past the span get harmless garbage), so the loop has
+    // no per-thread exit and no exec-mask region.  OVERLAP: the batch holds a match that overlaps itself (length > distance):
+    // such bytes are reduced to their first period so that chains stay short (one division per cell in this variant only).
+    template <bool OVERLAP>
+    SWC_D void expand_cells(int t, uint32_t ncell, uint32_t off, uint32_t v0, uint32_t cbase, uint32_t lb) const {
+        const uint8_t* lds0 = l->ring;                      // litbuf == ring + kRing (struct layout, asserted above)
+        const uint32_t j = (uint32_t)t & 15u;
+        const uint32_t m_rest = ((2u << j) - 1u) & ~1u;     // record starts in cells (0, j] of my slot
+        uint32_t m = (uint32_t)t < 16u ? ((2u << j) - 1u) & ~((2u << off) - 1u) : m_rest;   // slot 0: starts in (off, j]
+        const uint32_t iters = (ncell + (uint32_t)T - 1u) / (uint32_t)T;
+        uint32_t ci = (uint32_t)t;
+#pragma unroll 2
+        for (uint32_t it = 0; it < iters; it++, ci += (uint32_t)T) {
+            const uint32_t sw = l->slotw[ci >> 4];
+            const uint32_t r = (sw & 0xFFFFu) + (uint32_t)simt::popc32((sw >> 16) & m);
+            m = m_rest;
+            const uint64_t rc = l->rec8[r];
+            const uint32_t w0 = (uint32_t)rc, w1 = (uint32_t)(rc >> 32);
+            const uint32_t mstart = w0 & 0xFFFFu, thr = w0 >> 16, dist = w1 & 0xFFFFu, lkey = w1 >> 16;
+            const bool is_lit = ci < mstart;
+            uint32_t x = ci - dist;                          // the cell this byte copies (when it is a match byte)
+            bool inspan = ci >= thr;
+            if (OVERLAP) {
+                const uint32_t mo = ci - mstart;
+                if (!is_lit && mo >= dist) x = mstart - dist + mod_small(mo & 0xFFFFu, dist);   // repeats its first period
+                inspan = !is_lit && (int32_t)x >= (int32_t)off;
+            }
+            const uint32_t a_lit = kRing + ((ci + lkey) & kLitMask), a_ring = (v0 + x) & kMask;
+            const uint32_t byte = lds0[is_lit ? a_lit : a_ring];
+            cell_store(l->ring, cbase, ci, inspan ? x : 0x8000u | byte);
+        }
+        // cells of slot 0 in front of the span belong to earlier batches: final bytes of the ring (written after the loop: the
+        // loop left garbage there)
+        if ((uint32_t)t < off) cell_store(l->ring, cbase, (uint32_t)t, 0x8000u | lds0[(v0 + (uint32_t)t) & kMask]);
+    }
+
     SWC_D void run(const SWC_AS_GLOBAL uint32_t* recs, uint32_t nrec) {
         using simt::PT;
         if (nrec == 0) return;
@@ -153,6 +191,7 @@ struct Resolver {
             if (o + 16 <= lit_cap) *(u128*)(l->litbuf + o) = load_16(lits + o);
             l->slotw[t] = 0;
             if (t == 0) l->slotw[T] = 0;
+            if (t < 18) l->rec8[T + t] = 0xFFFFull;
         SIMT_END
         lfill = kLitWin;
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -174,10 +213,12 @@ struct Resolver {
                 x[t] = lit + len;
                 y[t] = lit;
                 r_next[t] = r;
+                if (t == 0) l->overlap = 0;
             SIMT_END
             simt::group_scan2_incl<T>(x, y, l->wave_sum);       // (barrier A inside)
             SWC_RP(0)
-            // ---- R1: batch geometry, one record per thread
+            // ---- R1: batch geometry, one record per thread, in CELL indices (span-relative position + off)
+            const uint32_t lbk = (uint32_t)lbase;
             SIMT_BEGIN(t, T)
                 const uint32_t r = r_next[t];
                 uint32_t lit = r & 127u;
@@ -186,13 +227,21 @@ struct Resolver {
                 const uint32_t end = x[t], lit_end = y[t];
                 const uint32_t start = end - (lit + len), mstart = start + lit;
                 const bool take = r != 0u && end <= kSpanMax;
-                l->rec8[t] = take ? (uint64_t)end | ((uint64_t)mstart << 16) | ((uint64_t)((lit_end - lit - start) & 0xFFFFu) << 32) | ((uint64_t)(r >> 16) << 48)
+                // mstart: first match cell; thr: first cell that copies from INSIDE the span (a match cell at or past distance + off;
+                // 0xFFFF: none); litkey: (stream offset of the record's first literal) - (its first cell), modulo the literal window
+                const uint32_t dist = len ? (r >> 16) + 1u : 1u;
+                const uint32_t mstart_c = mstart + off;
+                uint32_t thr = dist + off > mstart_c ? dist + off : mstart_c;
+                if (len == 0 || thr > 0xFFFFu) thr = 0xFFFFu;
+                const uint32_t lkey = (lbk + (lit_end - lit) - (start + off)) & kLitMask;
+                l->rec8[t] = take ? (uint64_t)mstart_c | ((uint64_t)thr << 16) | ((uint64_t)(dist & 0xFFFFu) << 32) | ((uint64_t)lkey << 48)
                                   : 0xFFFFull;
                 if (take) {
                     // the slots whose first in-span cell I cover, and the flag of my first cell
                     for (uint32_t k = start == 0 ? 0u : (start + off + 15u) >> 4; k == 0 ? start == 0 : 16u * k - off < end; k++) lds_or(&l->slotw[k], (uint32_t)t);
                     const uint32_t c0 = start + off;
                     lds_or(&l->slotw[c0 >> 4], 0x10000u << (c0 & 15u));
+                    if (len > dist) l->overlap = 1;          // (every writer stores the same value)
                     if (t == T - 1) { l->ntake = (uint32_t)T; l->span = end; l->litspan = lit_end; }
                 } else if (t != 0 && start <= kSpanMax && base + (uint32_t)t - 1u < nrec) {
                     // the first record that is not taken (or the first thread past the last record) closes the batch: `start`
@@ -202,11 +251,12 @@ struct Resolver {
             SIMT_END_BARRIER                                     // barrier B
             SWC_RP(1)
             const uint32_t ntake = simt::uniform(l->ntake), span = simt::uniform(l->span), litspan = simt::uniform(l->litspan);
+            const bool overlap = simt::uniform(l->overlap) != 0u;
             const bool last_batch = base + ntake >= nrec;
             const uint32_t ncell = span + off;                   // cells [off, ncell) are this batch's bytes, [0, off) belong to earlier ones
             // the literal window after this batch: [lbase + litspan, .. + kLitWin) rounded down to granules
             const uint64_t lfill_next = (lbase + litspan + kLitWin) & ~(uint64_t)15;
-            // ---- R2: prefetch for the next batch, then one CELL per thread and step: which record, literal or match, value or source
+            // ---- R2: prefetch for the next batch, then the cells
             SIMT_BEGIN(t, T)
                 {
                     const uint32_t nx = base + ntake + (uint32_t)t;
@@ -216,27 +266,8 @@ struct Resolver {
                     lit_pf_at[t] = want ? (uint32_t)o : 0xFFFFFFFFu;
                     if (want) lit_pf[t] = load_16(lits + o);
                 }
-                // One cell per step, as selects: a literal and a match byte whose source lies before the span are both "one
-                // byte at (K + rel) of an LDS buffer" (the literal window sits right behind the ring), so there is ONE data
-                // read whatever the cell is; only the self-overlapping match takes a branch.
-                const uint32_t lb = (uint32_t)lbase;
-                const uint8_t* lds0 = l->ring;                  // litbuf == ring + kRing (struct layout, asserted below)
-                for (uint32_t ci = (uint32_t)t; ci < ncell; ci += (uint32_t)T) {
-                    const uint32_t rel = ci - off, k = ci >> 4, j = ci & 15u;
-                    const uint32_t sw = l->slotw[k];
-                    const uint32_t j0 = k == 0 ? off : 0u;   // the slot's first in-span cell: its record is the low half of the slot word
-                    const uint32_t r = (sw & 0xFFFFu) + (uint32_t)simt::popc32((sw >> 16) & ((2u << j) - 1u) & ~((2u << j0) - 1u));
-                    const uint64_t rc = l->rec8[ci < off ? 0u : r];
-                    const uint32_t mstart = (uint32_t)(rc >> 16) & 0xFFFFu, litadj = (uint32_t)(rc >> 32) & 0xFFFFu, dist = (uint32_t)(rc >> 48) + 1u;
-                    const bool lead = ci < off, is_lit = rel < mstart;
-                    const uint32_t m = rel - mstart;
-                    int32_t s = (int32_t)rel - (int32_t)dist;
-                    if (!lead && !is_lit && m >= dist) s = (int32_t)mstart - (int32_t)dist + (int32_t)mod_small(m, dist);   // repeats its first period
-                    const uint32_t a_lit = kRing + ((lb + litadj + rel) & kLitMask), a_ring = (vcur + (uint32_t)s) & kMask, a_lead = (v0 + ci) & kMask;
-                    const uint32_t byte = lds0[lead ? a_lead : is_lit ? a_lit : a_ring];
-                    const uint32_t cell = (lead || is_lit || s < 0) ? 0x8000u | byte : (uint32_t)s + off;
-                    cell_store(l->ring, cbase, ci, cell);
-                }
+                if (overlap) expand_cells<true>(t, ncell, off, v0, cbase, lbk);
+                else expand_cells<false>(t, ncell, off, v0, cbase, lbk);
             SIMT_END_BARRIER                                     // barrier C
             SWC_RP(2)
             // ---- R3: one aligned DWORD per thread and step: chase what is unresolved, then the dword leaves for the ring and for HBM
@@ -257,11 +288,15 @@ struct Resolver {
                     uint32_t c[4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) c[e] = (uint32_t)(c4 >> (16 * e)) & 0xFFFFu;
-                    // the four chains advance together: one hop = four independent LDS reads in flight
+                    // the four chains advance together: one hop = four independent LDS reads in flight.  A cell that is already a
+                    // value re-reads a harmless address and keeps its value (selects, no branch per cell).
                     const uint32_t was = (c[0] & c[1] & c[2] & c[3]) & 0x8000u;
                     while (!((c[0] & c[1] & c[2] & c[3]) & 0x8000u)) {
+                        uint32_t n[4];
 #pragma unroll
-                        for (int e = 0; e < 4; e++) if (!(c[e] & 0x8000u)) c[e] = cell_load(l->ring, cbase, c[e]);
+                        for (int e = 0; e < 4; e++) n[e] = cell_load(l->ring, cbase, c[e] & 0x7FFFu);
+#pragma unroll
+                        for (int e = 0; e < 4; e++) c[e] = (c[e] & 0x8000u) ? c[e] : n[e];
                     }
                     if (!was)   // resolved values back into my cells: later readers stop here
                         *(uint64_t*)(l->ring + ca) = (uint64_t)c[0] | ((uint64_t)c[1] << 16) | ((uint64_t)c[2] << 32) | ((uint64_t)c[3] << 48);
