@@ -105,6 +105,7 @@ struct Lane {
     gptr lits;                     // dense literal stream in the HBM workspace (16-byte aligned, capacity cap + 16)
     uint64_t nlit;
     uint64_t last_end;             // position just past the previous record
+    gptr prov = nullptr;           // scratch of the wave-parallel rounds (lzr::kProvBytes), or none
     int wlane = 0;                 // this lane's number in the wave (the uniform parts run on every lane)
     int wlanes = kWave;            // lanes that share the work of the parallel parts (1 in the host emulation)
 

@@ -469,20 +469,133 @@ SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, u
     r.flags = flags;
 }
 
+// ---- one sub-chunk, decoded ONCE into the round's scratch ------------------------------------------------------------------
+// The count pass and the emit pass of a round in one: the lane decodes its sub-chunk from `start` and writes its literals
+// and records to its column of the stream's scratch area (lz_resolve.h: rows across the lanes, sized for the worst case, so
+// the loop needs no bounds test), counting as it goes; the round then scans the counts and COPIES every lane's piece to its
+// final offset (copy_prov) instead of decoding a third time.  What the lane cannot know yet -- the output position of its
+// sub-chunk -- enters only through `need`: the largest (distance - output bytes of the sub-chunk in front of the match),
+// checked after the scan.  Literals gather in a 64-bit accumulator (the new byte enters at the top) and leave as a group of
+// eight; the group store and the record store share ONE conditional region of the loop, each aimed at row 0 when it is not
+// its turn.  The loop has no variant for the end of the input: it stops at the last bit, and a symbol that ran past it is
+// caught by the final position.  `run0`: literals in front of the sub-chunk that no record covers yet (lane 0 of the first
+// round of a block).  A sub-chunk that ends at the end-of-block symbol leaves its trailing literals uncovered (`tail`), every
+// other one closes them with a literal-only record.
+struct ProvOut {
+    uint32_t end, nlit, nrec, nout, flags, tail;
+    int32_t need;
+};
+enum { kFlagSlow = 8u };   // the sub-chunk needs the general path (a literal run that no single record can carry)
+constexpr uint32_t kProvRecRow = 64u * 4u, kProvLitRow = 64u * 8u;   // bytes from one row of the scratch to the next
+
+// prec / plit: this lane's slot in row 0 of the record / literal rows
+SWC_D void decode_chunk_prov(const SyncLds* sl, const LongCodes lc, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr plit,
+                             gptr prec, uint32_t run0, ProvOut& r) {
+    const uint8_t* stg = sl->stage;
+    uint32_t wa = (start >> 5) << 2, bp = start & 31u;
+    uint32_t d0 = *(const uint32_t*)(stg + wa), d1 = *(const uint32_t*)(stg + wa + 4);
+    uint32_t tsel = 0, tmsk = (1u << kSyncLitBits) - 1u;
+    uint32_t plen = 0, run = run0, nlit = 0, nout = 0, flags = 0;
+    uint32_t roff = kProvRecRow, loff = kProvLitRow;       // byte offsets of the next record / literal group (row 1 is the first)
+    uint32_t lb0 = 0, lb1 = 0;                             // pending literals: the newest at the top of lb1:lb0
+    int32_t need = -0x40000000;
+    if (chunk_end > in_bits) chunk_end = in_bits;          // (the zero fill behind the input is not worth decoding)
+    if (start >= in_bits) flags = kFlagFail;               // nothing left for this sub-chunk: the checked step says what that means
+    for (;;) {
+        const uint32_t posb = (wa << 3) + bp;
+        if ((uint32_t)(tsel == 0) & (uint32_t)(posb >= chunk_end)) break;
+        SWC_SYNC_STAT(5, 1);
+        SWC_SYNC_ITER();
+        const uint32_t bits = funnel32(d1, d0, bp);
+        uint32_t e = sl->lut[(bits & tmsk) | tsel];
+        const uint32_t nx = *(const uint32_t*)(stg + wa + 8);
+        if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, tsel); }
+        const uint32_t n = e & 31u;
+        if (e & (kEntInvalid | kEntEob)) {
+            if (e & kEntInvalid) flags |= kFlagFail;
+            else { bp += n; flags |= kFlagEob; }
+            break;
+        }
+        const bool was_dist = tsel != 0;
+        const uint32_t is_lit = (e >> 15) & 1u;
+        const uint32_t val = ((e >> 16) & 0x7FFFu) + bfe32(bits, (e >> kEntClenShift) & 15u, (e >> kEntExtShift) & 15u);
+        // literal: into the accumulator (a shift by 0 leaves it alone)
+        const uint32_t sh8 = is_lit << 3;
+        lb0 = funnel32(lb1, lb0, sh8);
+        lb1 = funnel32(val, lb1, sh8);
+        nlit += is_lit;
+        const bool full = (is_lit & (uint32_t)((nlit & 7u) == 0u)) != 0u;   // the eighth literal of a group has just entered
+        const int32_t nd = (int32_t)val - (int32_t)nout;   // a distance needs this much output in front of the sub-chunk
+        need = was_dist && nd > need ? nd : need;
+        if (was_dist | full) {
+            store_u64(plit + (full ? loff : 0u), ((uint64_t)lb1 << 32) | lb0);
+            store_u32(prec + (was_dist ? roff : 0u), lzr::make_match(run, plen, val));
+            loff += full ? kProvLitRow : 0u;
+            roff += was_dist ? kProvRecRow : 0u;
+        }
+        nout += is_lit + (was_dist ? plen : 0u);
+        run = was_dist ? 0u : run + is_lit;
+        const bool is_len = (e & kEntLen) != 0u;
+        plen = is_len ? val : plen;
+        tsel = e & kEntLen;
+        tmsk = is_len ? (1u << kSyncDistBits) - 1u : (1u << kSyncLitBits) - 1u;
+        bp += n;
+        const bool sh = bp >= 32;
+        wa += sh ? 4u : 0u;
+        bp &= 31u;
+        d0 = sh ? d1 : d0;
+        d1 = sh ? nx : d1;
+    }
+    if (nlit & 7u) {   // the last, incomplete group: its bytes sit at the top of the accumulator
+        const uint32_t dn = (8u - (nlit & 7u)) << 3;
+        store_u64(plit + loff, (((uint64_t)lb1 << 32) | lb0) >> dn);
+    }
+    uint32_t tail = 0;
+    if (run > 0) {
+        if (flags & kFlagEob) tail = run;
+        else { store_u32(prec + roff, lzr::make_lits(run)); roff += kProvRecRow; }
+    }
+    const uint32_t endb = (wa << 3) + bp;
+    if (endb > in_bits) flags |= kFlagFail;                // a symbol ran past the end of the input
+    if (nlit + run0 > lzr::kLitRunMax) flags |= kFlagSlow;  // (conservative: only then can a run exceed what a match record carries)
+    r.end = (flags & kFlagFail) ? kPosFail : endb;
+    r.nlit = nlit; r.nrec = roff / kProvRecRow - 1u; r.nout = nout; r.flags = flags; r.tail = tail; r.need = need;
+}
+
+// A lane's piece of the round moves from its column of the scratch to its final place: `nrec` records to `rdst` (dword
+// aligned), `nlit` literal bytes to `ldst` (any alignment).  The loads of a step read one row: coalesced.
+SWC_D void copy_prov(gcptr plit, gcptr prec, uint32_t nlit, uint32_t nrec, gptr ldst, SWC_AS_GLOBAL uint32_t* rdst) {
+    for (uint32_t i = 0; i < nrec; i++) rdst[i] = load_u32(prec + (size_t)(i + 1u) * kProvRecRow);
+    uint32_t k = 0;
+    for (; k + 8 <= nlit; k += 8) store_u64(ldst + k, load_u64(plit + (size_t)((k >> 3) + 1u) * kProvLitRow));
+    if (k < nlit) {
+        uint64_t v = load_u64(plit + (size_t)((k >> 3) + 1u) * kProvLitRow);
+        for (; k < nlit; k++, v >>= 8) ldst[k] = (uint8_t)v;
+    }
+}
+
 // ---- the rounds of one block ---------------------------------------------------------------------------------------
 // Decodes from the reader's position until the end-of-block symbol (kSyncEob) or until something the fast path leaves
 // to the checked step (kSyncBail; kSyncBailCap: the capacity lies inside the next round).  Commits whole rounds only.
 SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
     using simt::PT;
     constexpr int N = kWave;
-    ln.flush_tail();   // the literal run in front of the first round becomes a record of its own
+    // Literals in front of the block that no record covers yet (the tail of the previous block, stored bytes): the first
+    // sub-chunk of the block takes a short run into its first record; a long one becomes a record of its own here.
+    uint32_t pending = 0;
+    {
+        const uint64_t kept = ln.pos < ln.cap ? ln.pos : ln.cap;
+        const uint64_t open = kept > ln.last_end ? kept - ln.last_end : 0;
+        if (ln.prov != nullptr && open <= 64) pending = (uint32_t)open;
+        else ln.flush_tail();
+    }
     uint64_t P = simt::uniform(ln.br.consumed_bits());
     uint64_t pos = simt::uniform(ln.pos), nlit = simt::uniform(ln.nlit);
     uint32_t nrec = simt::uniform(ln.nrec);
     const uint32_t in_len = ln.br.len;
     gcptr in = ln.br.in;
     int result = kSyncBail;
-    PT<uint32_t, N> start, endp, pe, c_lit, c_rec, c_out, flg, x_lit, x_rec, x_out;
+    PT<uint32_t, N> start, endp, pe, c_lit, c_rec, c_out, flg, x_lit, x_rec, x_out, c_tail, c_need;
     PT<bool, N> todo, pb, have;
     LongCodes lc;
     lc.load(sl);
@@ -525,6 +638,99 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
             SWC_SYNC_LANE_END(t, N, 0)
         SIMT_END
         SWC_SP(pf, 3)
+        // ---- the round in ONE more decode (the common case): every lane decodes its sub-chunk from the end of its left
+        // neighbour into its scratch (decode_chunk_prov), the chain is checked as below, the pieces are copied to their
+        // offsets.  Anything unusual -- a symbol for the checked step, a literal run too long for one record, the capacity
+        // or the workspace inside the round, a distance beyond the output -- abandons the attempt BEFORE anything is
+        // committed; the general passes below then take the round.
+        if (ln.prov != nullptr && pos < ln.cap) {
+            bool ok = true;
+            for (;;) {
+                simt::wave_shift_up<N>(pe, endp, q0);
+                SIMT_BEGIN(t, N) pb[t] = !(have[t] && (t == 0 || start[t] == pe[t])); SIMT_END
+                const uint64_t m_bad = simt::wave_ballot<N>(pb);
+                const int b = m_bad ? simt::ctz64(m_bad) : 64;
+                const uint64_t chain = b == 64 ? ~0ull : (1ull << b) - 1ull;
+                SIMT_BEGIN(t, N) pb[t] = (flg[t] & kFlagEob) != 0; SIMT_END
+                const uint64_t m_eob = simt::wave_ballot<N>(pb) & chain;
+                const int E = m_eob ? simt::ctz64(m_eob) : 64;
+                nv = (uint32_t)(E < 64 ? E + 1 : b);
+                SIMT_BEGIN(t, N) pb[t] = (flg[t] & (kFlagFail | kFlagSlow)) != 0; SIMT_END
+                if (simt::wave_ballot<N>(pb) & (nv == 64 ? ~0ull : (1ull << nv) - 1ull)) { ok = false; break; }
+                if (E < 64) { eob = true; break; }
+                if (b == 64) break;
+                SWC_SYNC_STAT(2, 1);
+                SWC_SPC(pf, 8, 1);
+                SIMT_BEGIN(t, N)
+                    todo[t] = t == 0 ? !have[t] : pe[t] != kPosFail && (start[t] != pe[t] || !have[t]);
+                    SWC_SYNC_LANE_BEGIN(t)
+                    if (todo[t]) {
+                        SWC_SYNC_STAT(3, 1);
+                        if (t != 0) start[t] = pe[t];
+                        ProvOut r;
+                        const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
+                        if (start[t] + kSyncChunk * 8u < ce) {
+                            // my left neighbour stopped in front of my sub-chunk: at the end-of-block symbol or at something for
+                            // the checked step.  Nothing of mine belongs to the block (and a decode from there could run through
+                            // several sub-chunks: the scratch is sized for one).
+                            r.end = kPosFail; r.nlit = r.nrec = r.nout = r.tail = 0; r.flags = kFlagFail; r.need = 0;
+                        } else
+                        decode_chunk_prov(sl, lc, start[t], ce, in_bits, ln.prov + lzr::kProvRecBytes + 8u * (uint32_t)t, ln.prov + 4u * (uint32_t)t, t == 0 ? pending : 0u, r);
+                        endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; flg[t] = r.flags;
+                        c_tail[t] = r.tail; c_need[t] = (uint32_t)r.need;
+                        have[t] = true;
+                    }
+                    SWC_SYNC_LANE_END(t, N, 1)
+                SIMT_END
+                SWC_SP(pf, 3)
+            }
+            if (ok) {
+                SIMT_BEGIN(t, N)
+                    const bool v = (uint32_t)t < nv;
+                    x_lit[t] = v ? c_lit[t] : 0u; x_rec[t] = v ? c_rec[t] : 0u; x_out[t] = v ? c_out[t] : 0u;
+                SIMT_END
+                simt::wave_scan_incl<N>(x_lit);
+                simt::wave_scan_incl<N>(x_rec);
+                simt::wave_scan_incl<N>(x_out);
+                const uint32_t tot_lit = simt::wave_read<N>(x_lit, N - 1), tot_rec = simt::wave_read<N>(x_rec, N - 1), tot_out = simt::wave_read<N>(x_out, N - 1);
+                SWC_SP(pf, 4)
+                // every distance must reach back no further than the output in front of its match
+                SIMT_BEGIN(t, N)
+                    const uint64_t p0 = pos + (x_out[t] - c_out[t]);
+                    const int32_t room = p0 > 0x40000000ull ? 0x40000000 : (int32_t)p0;
+                    pb[t] = (uint32_t)t < nv && (int32_t)c_need[t] > room;
+                SIMT_END
+                if (simt::wave_ballot<N>(pb)) ok = false;
+                if (pos + tot_out > ln.cap || (uint64_t)nrec + tot_rec > ln.max_rec) ok = false;
+                if (ok) {
+                    SIMT_BEGIN(t, N)
+                        if ((uint32_t)t < nv) {
+                            copy_prov(ln.prov + lzr::kProvRecBytes + 8u * (uint32_t)t, ln.prov + 4u * (uint32_t)t, c_lit[t], c_rec[t],
+                                      ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]));
+                        }
+                    SIMT_END
+                    SWC_SP(pf, 5)
+                    SWC_SYNC_STAT(0, 1);
+                    pos += tot_out;
+                    nlit += tot_lit;
+                    nrec += tot_rec;
+                    P = 8ull * B + simt::wave_read<N>(endp, (int)nv - 1);
+                    ln.last_end = pos - (eob ? simt::wave_read<N>(c_tail, (int)nv - 1) : 0u);
+                    pending = 0;
+                    if (eob) { result = kSyncEob; break; }
+                    continue;
+                }
+            }
+            // abandoned: the general passes start over
+            SIMT_BEGIN(t, N) have[t] = false; flg[t] = 0; SIMT_END
+            eob = false;
+        }
+        if (pending) {   // (first round only: nothing has been committed, so the lane's counters are the block's)
+            ln.pos = pos; ln.nlit = nlit; ln.nrec = nrec;
+            ln.flush_tail();
+            nrec = ln.nrec;
+            pending = 0;
+        }
         for (;;) {
             simt::wave_shift_up<N>(pe, endp, q0);
             // a lane is final when it has been counted from the end of a final left neighbour
@@ -551,7 +757,8 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                     if (t != 0) start[t] = pe[t];
                     ChunkOut r;
                     const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
-                    if (chk) decode_chunk<0, false, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                    if (start[t] + kSyncChunk * 8u < ce) { r.end = kPosFail; r.nlit = r.nrec = r.nout = 0; r.flags = kFlagFail; }   // (see the pass above)
+                    else if (chk) decode_chunk<0, false, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
                     else decode_chunk<0, false, false>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
                     if (r.nlit > lzr::kLitRunMax) {   // a literal run may need a record of its own: count those too
                         if (chk) decode_chunk<0, true, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
@@ -749,7 +956,13 @@ SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes,
     ln.last_end = 0;
     const size_t lo = ws ? lzr::lit_offset(ws_bytes, job.out_cap) : 0;
     ln.recs = (SWC_AS_GLOBAL uint32_t*)(ws + sizeof(lzr::StreamHeader));
-    ln.max_rec = lo > sizeof(lzr::StreamHeader) ? (uint32_t)((lo - sizeof(lzr::StreamHeader)) / 4) : 0u;
+    size_t rec_end = lo;   // the lanes' scratch (lzr::kProvBytes) sits between the record list and the literal stream, if the area has room for it
+    ln.prov = nullptr;
+    if (lo >= sizeof(lzr::StreamHeader) + 256 + lzr::kProvBytes) {
+        rec_end = (lo - lzr::kProvBytes) & ~(size_t)15;
+        ln.prov = (gptr)(ws + rec_end);
+    }
+    ln.max_rec = rec_end > sizeof(lzr::StreamHeader) ? (uint32_t)((rec_end - sizeof(lzr::StreamHeader)) / 4) : 0u;
     ln.lits = (gptr)(ws + lo);
     int st = SWC_OK;
     if (lo == 0) {

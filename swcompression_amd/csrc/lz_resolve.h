@@ -59,7 +59,13 @@ struct StreamHeader {
 // wave-parallel Deflate decode: a tail record closes >= 50 bits of input) plus slack.
 SWC_HD size_t max_records(uint64_t cap) { return (size_t)(cap / 3 + cap / 32 + 64); }
 SWC_HD size_t lit_bytes(uint64_t cap) { return (size_t)((cap + 32 + 15) & ~(uint64_t)15); }   // +32: wide flushes and reads may overshoot
-SWC_HD size_t ws_bytes_per_job(uint64_t cap) { return ((sizeof(StreamHeader) + max_records(cap) * 4 + 15) & ~(size_t)15) + lit_bytes(cap); }
+// Scratch of the wave-parallel Deflate decode (inflate_sync.h): the records and literals of the 64 sub-chunks of the current
+// round before their final offsets are known, as ROWS across the lanes -- row k holds the k-th record (4 bytes) / the k-th
+// group of eight literals of every lane, so that the 64 lanes, which advance at about the same rate, fill whole cache lines
+// together and read them back with coalesced loads.  Sized for the worst case (a sub-chunk of 1-bit codes); row 0 of each
+// part is the target of stores that must not happen.  Sits between the record list and the literal stream.
+constexpr size_t kProvRecRows = 301, kProvLitRows = 77, kProvRecBytes = kProvRecRows * 64 * 4, kProvBytes = kProvRecBytes + kProvLitRows * 64 * 8;
+SWC_HD size_t ws_bytes_per_job(uint64_t cap) { return ((sizeof(StreamHeader) + max_records(cap) * 4 + 15) & ~(size_t)15) + kProvBytes + lit_bytes(cap); }
 // a job's literal stream inside its area of `stride` bytes (0 if the area is too small for it)
 SWC_HD size_t lit_offset(size_t stride, uint64_t cap) { return stride >= lit_bytes(cap) + sizeof(StreamHeader) ? (stride - lit_bytes(cap)) & ~(size_t)15 : 0; }
 
@@ -296,7 +302,7 @@ struct Resolver {
 #pragma unroll
                         for (int e = 0; e < 4; e++) n[e] = cell_load(l->ring, cbase, c[e] & 0x7FFFu);
 #pragma unroll
-                        for (int e = 0; e < 4; e++) c[e] = (c[e] & 0x8000u) ? c[e] : n[e];
+                        for (int e = 0; e < 4; e++) c[e] = c[e] < 0x8000u ? n[e] : c[e];
                     }
                     if (!was)   // resolved values back into my cells: later readers stop here
                         *(uint64_t*)(l->ring + ca) = (uint64_t)c[0] | ((uint64_t)c[1] << 16) | ((uint64_t)c[2] << 32) | ((uint64_t)c[3] << 48);

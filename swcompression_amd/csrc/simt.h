@@ -98,9 +98,15 @@ SWC_D void group_scan2_incl(PT<uint32_t, N>& x, PT<uint32_t, N>& y, uint32_t* ws
     if (N > 64) {
         if (lane == 63) { ws[wave] = a; ws[N / 64 + wave] = b; }
         lds_barrier();
+        // the totals of the waves in front of mine: all partial sums are read at once (wave-uniform addresses: one broadcast read
+        // each, no chain of dependent reads) and added under a compare with my wave number
         uint32_t sa = 0, sb = 0;
-#pragma unroll 1
-        for (int w = 0; w < wave; w++) { sa += ws[w]; sb += ws[N / 64 + w]; }
+#pragma unroll
+        for (int w = 0; w < N / 64 - 1; w++) {
+            const uint32_t va = ws[w], vb = ws[N / 64 + w];
+            sa += w < wave ? va : 0u;
+            sb += w < wave ? vb : 0u;
+        }
         a += sa;
         b += sb;
     }
