@@ -127,8 +127,8 @@ inline uint64_t g_sync_iters = 0, g_sync_wave[4] = {0, 0, 0, 0}, g_sync_passmax 
 #define SWC_SYNC_LANE_END(t, n, k)
 #endif
 enum { kFlagEob = 1u, kFlagFail = 2u, kFlagTrap = 4u };
-// profile builds (-DSWC_PROFILE): cycles per part of one stream -- 0 header, 1 tables, 2 staging, 3 count passes, 4 chain
-// logic + scans, 5 emit, 6 checked steps / rest; 7 rounds, 8 passes
+// profile builds (-DSWC_PROFILE): cycles per part of one stream -- 0 header, 1 tables, 2 staging, 3 decode passes, 4 chain
+// logic + scans, 5 copy / emit, 6 checked steps / rest; 7 rounds, 8 passes, 9 walk pass
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 struct SyncProf {
     uint64_t acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
@@ -488,19 +488,61 @@ struct ProvOut {
 enum { kFlagSlow = 8u };   // the sub-chunk needs the general path (a literal run that no single record can carry)
 constexpr uint32_t kProvRecRow = 64u * 4u, kProvLitRow = 64u * 8u;   // bytes from one row of the scratch to the next
 
+// The two loops below have ONE exit, at the top: the end-of-block symbol and anything the fast path does not take raise their
+// flag and pull the end of the sub-chunk to zero, so that the next test at the top leaves (their side effects are neutral: an
+// end-of-block entry is neither literal nor length, and a lane that raised the fail flag is discarded).  A loop with several
+// exits costs the wavefront a dozen scalar instructions of mask bookkeeping per iteration.
+constexpr uint32_t kEntStop = kEntInvalid | kEntEob;
+SWC_HD uint32_t flags_of_stop_bits(uint32_t stop) { return ((stop >> 5) & 1u) /* kFlagEob */ | ((stop >> 30) & 2u) /* kFlagFail */; }
+
+// Where does a decode from `start` end?  (The walk pass: no counting.)  Returns the bit position just past the last symbol
+// taken, or kPosFail.
+SWC_D uint32_t walk_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, uint32_t chunk_end, uint32_t in_bits) {
+    const uint8_t* stg = sl->stage;
+    uint32_t wa = (start >> 5) << 2, bp = start & 31u;
+    uint32_t d0 = *(const uint32_t*)(stg + wa), d1 = *(const uint32_t*)(stg + wa + 4);
+    uint32_t tsel = 0, tmsk = (1u << kSyncLitBits) - 1u, stop = 0;
+    if (chunk_end > in_bits) chunk_end = in_bits;          // (the zero fill behind the input is not worth decoding)
+    if (start >= in_bits) { stop = kEntInvalid; chunk_end = 0; }
+    for (;;) {
+        const uint32_t posb = (wa << 3) + bp;
+        if ((uint32_t)(tsel == 0) & (uint32_t)(posb >= chunk_end)) break;
+        SWC_SYNC_STAT(4, 1);
+        SWC_SYNC_ITER();
+        const uint32_t bits = funnel32(d1, d0, bp);
+        uint32_t e = sl->lut[(bits & tmsk) | tsel];
+        const uint32_t nx = *(const uint32_t*)(stg + wa + 8);
+        if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, tsel); }
+        const uint32_t st = e & kEntStop;
+        stop |= st;
+        chunk_end = st ? 0u : chunk_end;
+        const bool is_len = (e & kEntLen) != 0u;
+        tsel = e & kEntLen;
+        tmsk = is_len ? (1u << kSyncDistBits) - 1u : (1u << kSyncLitBits) - 1u;
+        bp += (e & kEntInvalid) ? 0u : e & 31u;
+        const bool sh = bp >= 32;
+        wa += sh ? 4u : 0u;
+        bp &= 31u;
+        d0 = sh ? d1 : d0;
+        d1 = sh ? nx : d1;
+    }
+    const uint32_t endb = (wa << 3) + bp;
+    return (stop & kEntInvalid) || endb > in_bits ? kPosFail : endb;
+}
+
 // prec / plit: this lane's slot in row 0 of the record / literal rows
 SWC_D void decode_chunk_prov(const SyncLds* sl, const LongCodes lc, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr plit,
                              gptr prec, uint32_t run0, ProvOut& r) {
     const uint8_t* stg = sl->stage;
     uint32_t wa = (start >> 5) << 2, bp = start & 31u;
     uint32_t d0 = *(const uint32_t*)(stg + wa), d1 = *(const uint32_t*)(stg + wa + 4);
-    uint32_t tsel = 0, tmsk = (1u << kSyncLitBits) - 1u;
-    uint32_t plen = 0, run = run0, nlit = 0, nout = 0, flags = 0;
+    uint32_t tsel = 0, tmsk = (1u << kSyncLitBits) - 1u, stop = 0;
+    uint32_t plen = 0, run = run0, nlit = 0, nout = 0;
     uint32_t roff = kProvRecRow, loff = kProvLitRow;       // byte offsets of the next record / literal group (row 1 is the first)
     uint32_t lb0 = 0, lb1 = 0;                             // pending literals: the newest at the top of lb1:lb0
     int32_t need = -0x40000000;
     if (chunk_end > in_bits) chunk_end = in_bits;          // (the zero fill behind the input is not worth decoding)
-    if (start >= in_bits) flags = kFlagFail;               // nothing left for this sub-chunk: the checked step says what that means
+    if (start >= in_bits) { stop = kEntInvalid; chunk_end = 0; }   // nothing left for this sub-chunk: the checked step says what that means
     for (;;) {
         const uint32_t posb = (wa << 3) + bp;
         if ((uint32_t)(tsel == 0) & (uint32_t)(posb >= chunk_end)) break;
@@ -510,12 +552,9 @@ SWC_D void decode_chunk_prov(const SyncLds* sl, const LongCodes lc, uint32_t sta
         uint32_t e = sl->lut[(bits & tmsk) | tsel];
         const uint32_t nx = *(const uint32_t*)(stg + wa + 8);
         if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, tsel); }
-        const uint32_t n = e & 31u;
-        if (e & (kEntInvalid | kEntEob)) {
-            if (e & kEntInvalid) flags |= kFlagFail;
-            else { bp += n; flags |= kFlagEob; }
-            break;
-        }
+        const uint32_t st = e & kEntStop;
+        stop |= st;
+        chunk_end = st ? 0u : chunk_end;
         const bool was_dist = tsel != 0;
         const uint32_t is_lit = (e >> 15) & 1u;
         const uint32_t val = ((e >> 16) & 0x7FFFu) + bfe32(bits, (e >> kEntClenShift) & 15u, (e >> kEntExtShift) & 15u);
@@ -539,7 +578,7 @@ SWC_D void decode_chunk_prov(const SyncLds* sl, const LongCodes lc, uint32_t sta
         plen = is_len ? val : plen;
         tsel = e & kEntLen;
         tmsk = is_len ? (1u << kSyncDistBits) - 1u : (1u << kSyncLitBits) - 1u;
-        bp += n;
+        bp += (e & kEntInvalid) ? 0u : e & 31u;
         const bool sh = bp >= 32;
         wa += sh ? 4u : 0u;
         bp &= 31u;
@@ -550,6 +589,7 @@ SWC_D void decode_chunk_prov(const SyncLds* sl, const LongCodes lc, uint32_t sta
         const uint32_t dn = (8u - (nlit & 7u)) << 3;
         store_u64(plit + loff, (((uint64_t)lb1 << 32) | lb0) >> dn);
     }
+    uint32_t flags = flags_of_stop_bits(stop);
     uint32_t tail = 0;
     if (run > 0) {
         if (flags & kFlagEob) tail = run;
@@ -565,12 +605,33 @@ SWC_D void decode_chunk_prov(const SyncLds* sl, const LongCodes lc, uint32_t sta
 // A lane's piece of the round moves from its column of the scratch to its final place: `nrec` records to `rdst` (dword
 // aligned), `nlit` literal bytes to `ldst` (any alignment).  The loads of a step read one row: coalesced.
 SWC_D void copy_prov(gcptr plit, gcptr prec, uint32_t nlit, uint32_t nrec, gptr ldst, SWC_AS_GLOBAL uint32_t* rdst) {
-    for (uint32_t i = 0; i < nrec; i++) rdst[i] = load_u32(prec + (size_t)(i + 1u) * kProvRecRow);
-    uint32_t k = 0;
-    for (; k + 8 <= nlit; k += 8) store_u64(ldst + k, load_u64(plit + (size_t)((k >> 3) + 1u) * kProvLitRow));
-    if (k < nlit) {
-        uint64_t v = load_u64(plit + (size_t)((k >> 3) + 1u) * kProvLitRow);
-        for (; k < nlit; k++, v >>= 8) ldst[k] = (uint8_t)v;
+    // Eight loads in flight per step (the scratch was written a moment ago, but a load still takes its few hundred cycles:
+    // one load per step would expose that latency forty times per round).  Rows past the lane's count hold something and
+    // exist (the scratch is sized for the worst case): they are loaded and not stored.
+    for (uint32_t i = 0; i < nrec; i += 8) {
+        uint32_t v[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t row = i + k + 1u < (uint32_t)lzr::kProvRecRows ? i + k + 1u : (uint32_t)lzr::kProvRecRows - 1u;
+            v[k] = load_u32(prec + (size_t)row * kProvRecRow);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) if (i + k < nrec) rdst[i + k] = v[k];
+    }
+    const uint32_t ngrp = (nlit + 7u) >> 3;
+    for (uint32_t g = 0; g < ngrp; g += 4) {
+        uint64_t v[4];
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t row = g + k + 1u < (uint32_t)lzr::kProvLitRows ? g + k + 1u : (uint32_t)lzr::kProvLitRows - 1u;
+            v[k] = load_u64(plit + (size_t)row * kProvLitRow);
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 4; k++) {
+            const uint32_t at = 8u * (g + k);
+            if (at + 8u <= nlit) store_u64(ldst + at, v[k]);
+            else if (at < nlit) { uint64_t w = v[k]; for (uint32_t q = at; q < nlit; q++, w >>= 8) ldst[q] = (uint8_t)w; }
+        }
     }
 }
 
@@ -632,12 +693,11 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
             ChunkOut r;
             SWC_SYNC_LANE_BEGIN(t)
             const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
-            if (chk) decode_chunk<3, false, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
-            else decode_chunk<3, false, false>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+            r.end = walk_chunk(sl, lc, start[t], ce, in_bits);
             endp[t] = r.end; flg[t] = 0; have[t] = false;
             SWC_SYNC_LANE_END(t, N, 0)
         SIMT_END
-        SWC_SP(pf, 3)
+        SWC_SP(pf, 9)
         // ---- the round in ONE more decode (the common case): every lane decodes its sub-chunk from the end of its left
         // neighbour into its scratch (decode_chunk_prov), the chain is checked as below, the pieces are copied to their
         // offsets.  Anything unusual -- a symbol for the checked step, a literal run too long for one record, the capacity

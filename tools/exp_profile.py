@@ -13,10 +13,10 @@ lib.swc_set_profile_buffer(prof.data_ptr())
 b.launch(sync=True)
 b.launch(sync=True)
 p = prof.cpu().numpy().reshape(b.n, 32).astype(np.float64)
-n1 = ["header", "tables", "staging", "count passes", "chain+scans", "emit", "rest"]
-t1 = p[:, :7].sum(axis=1).mean()
+n1 = ["header", "tables", "staging", "decode passes", "chain+scans", "copy/emit", "rest"]
+t1 = p[:, :7].sum(axis=1).mean() + p[:, 9].mean()
 print("phase 1 (inflate_sync): %.0f kcycles per stream; rounds %.2f passes %.2f; %%: " % (t1 / 1e3, p[:, 7].mean(), p[:, 8].mean())
-      + ", ".join("%s %.1f" % (n, 100 * p[:, k].mean() / t1) for k, n in enumerate(n1)))
+      + ", ".join("%s %.1f" % (n, 100 * p[:, k].mean() / t1) for k, n in enumerate(n1)) + ", walk %.1f" % (100 * p[:, 9].mean() / t1))
 n2 = ["R0+scan", "R1", "R2 expand", "R3 chase+out"]
 t2 = p[:, 16:20].sum(axis=1).mean()
 print("phase 2 (lz_resolve): %.0f kcycles per stream; batches %.2f span/batch %.0f records/batch %.0f; %%: "
