@@ -605,32 +605,46 @@ SWC_D void decode_chunk_prov(const SyncLds* sl, const LongCodes lc, uint32_t sta
 // A lane's piece of the round moves from its column of the scratch to its final place: `nrec` records to `rdst` (dword
 // aligned), `nlit` literal bytes to `ldst` (any alignment).  The loads of a step read one row: coalesced.
 SWC_D void copy_prov(gcptr plit, gcptr prec, uint32_t nlit, uint32_t nrec, gptr ldst, SWC_AS_GLOBAL uint32_t* rdst) {
-    // Eight loads in flight per step (the scratch was written a moment ago, but a load still takes its few hundred cycles:
-    // one load per step would expose that latency forty times per round).  Rows past the lane's count hold something and
-    // exist (the scratch is sized for the worst case): they are loaded and not stored.
-    for (uint32_t i = 0; i < nrec; i += 8) {
-        uint32_t v[8];
+    // Sixteen records and eight literal groups are loaded per step, all before the first store (the scratch of all resident
+    // waves exceeds the L2, so a load takes its several hundred cycles: one load per step would expose that latency forty
+    // times per round).  Rows past the lane's count hold something and exist (the scratch is sized for the worst case): they
+    // are loaded and not stored.
+    const uint32_t ngrp = (nlit + 7u) >> 3;
+    for (uint32_t i = 0, g = 0; i < nrec || g < ngrp; i += 16, g += 8) {
+        uint32_t v[16];
+        uint64_t w[8];
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {
+        for (uint32_t k = 0; k < 16; k++) {
             const uint32_t row = i + k + 1u < (uint32_t)lzr::kProvRecRows ? i + k + 1u : (uint32_t)lzr::kProvRecRows - 1u;
             v[k] = load_u32(prec + (size_t)row * kProvRecRow);
         }
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) if (i + k < nrec) rdst[i + k] = v[k];
-    }
-    const uint32_t ngrp = (nlit + 7u) >> 3;
-    for (uint32_t g = 0; g < ngrp; g += 4) {
-        uint64_t v[4];
-#pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
+        for (uint32_t k = 0; k < 8; k++) {
             const uint32_t row = g + k + 1u < (uint32_t)lzr::kProvLitRows ? g + k + 1u : (uint32_t)lzr::kProvLitRows - 1u;
-            v[k] = load_u64(plit + (size_t)row * kProvLitRow);
+            w[k] = load_u64(plit + (size_t)row * kProvLitRow);
+        }
+        // (wide stores: the lanes' destinations lie apart, so the memory pipeline takes a store lane by lane -- four records or
+        // two groups per lane and instruction instead of one)
+#pragma unroll
+        for (uint32_t k = 0; k < 16; k += 4) {
+            if (i + k + 4u <= nrec) store_u128_a4((gptr)(rdst + i + k), v[k], v[k + 1], v[k + 2], v[k + 3]);
+            else {
+#pragma unroll
+                for (uint32_t q = 0; q < 4; q++) if (i + k + q < nrec) rdst[i + k + q] = v[k + q];
+            }
         }
 #pragma unroll
-        for (uint32_t k = 0; k < 4; k++) {
+        for (uint32_t k = 0; k < 8; k += 2) {
             const uint32_t at = 8u * (g + k);
-            if (at + 8u <= nlit) store_u64(ldst + at, v[k]);
-            else if (at < nlit) { uint64_t w = v[k]; for (uint32_t q = at; q < nlit; q++, w >>= 8) ldst[q] = (uint8_t)w; }
+            if (at + 16u <= nlit) store_u128_a4(ldst + at, (uint32_t)w[k], (uint32_t)(w[k] >> 32), (uint32_t)w[k + 1], (uint32_t)(w[k + 1] >> 32));
+            else {
+#pragma unroll
+                for (uint32_t q = 0; q < 2; q++) {
+                    const uint32_t aq = at + 8u * q;
+                    if (aq + 8u <= nlit) store_u64(ldst + aq, w[k + q]);
+                    else if (aq < nlit) { uint64_t x = w[k + q]; for (uint32_t z = aq; z < nlit; z++, x >>= 8) ldst[z] = (uint8_t)x; }
+                }
+            }
         }
     }
 }

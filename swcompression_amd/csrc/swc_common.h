@@ -79,6 +79,8 @@ SWC_HD uint32_t load_u32(gcptr p) { return *(const SWC_AS_GLOBAL u32_unaligned*)
 SWC_HD uint64_t load_u64(gcptr p) { return *(const SWC_AS_GLOBAL u64_unaligned*)p; }
 SWC_HD void store_u32(gptr p, uint32_t v) { *(SWC_AS_GLOBAL u32_unaligned*)p = v; }
 SWC_HD void store_u64(gptr p, uint64_t v) { *(SWC_AS_GLOBAL u64_unaligned*)p = v; }
+struct __attribute__((packed, may_alias)) u128_any { uint32_t x, y, z, w; };
+SWC_HD void store_u128_a4(gptr p, uint32_t x, uint32_t y, uint32_t z, uint32_t w) { *(SWC_AS_GLOBAL u128_any*)p = u128_any{x, y, z, w}; }   // 16 bytes at any alignment
 
 // Workgroup barrier of the group-per-stream checksum kernels.  The host emulation build runs the T "threads" of a group
 // as real host threads and plugs its own barrier in here (tests/host_emu/emu.cpp).
