@@ -42,9 +42,6 @@ namespace swc {
 namespace inflate {
 
 constexpr int kSyncLitBits = 10, kSyncDistBits = 8;
-#ifndef SWC_SYNC_CHUNK
-#define SWC_SYNC_CHUNK 68
-#endif
 // Input bytes per lane and round: a whole number of dwords and an ODD number of them (17), so that the lanes, which start
 // a pass at the same offset of their sub-chunks, read 64 different LDS banks without any padding of the staged input.
 // With 68 bytes the wave's LDS is EXACTLY 10,240 bytes = 16 waves per CU: the kernel's speed is proportional to the waves
@@ -103,7 +100,9 @@ struct SyncLds {   // 10,240 bytes: see kSyncChunk
 #endif
     alignas(16) uint8_t stage[kSyncStageLds];                       // staged input of a round; header build: code lengths, counters, code-length table
 };
+#if SWC_SYNC_CHUNK == 68
 static_assert(sizeof(SyncLds) <= 10240, "16 waves per CU: the wave's LDS must stay within 160 KB / 16");
+#endif
 // header scratch inside `stage`
 constexpr uint32_t kHdrLens = 0;       // 320 bytes: code length of symbol s
 constexpr uint32_t kHdrCnt = 320;      // 48 words: codes per length (lit/len, of those symbols < 256, distance)

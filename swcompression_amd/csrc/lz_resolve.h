@@ -64,7 +64,11 @@ SWC_HD size_t lit_bytes(uint64_t cap) { return (size_t)((cap + 32 + 15) & ~(uint
 // group of eight literals of every lane, so that the 64 lanes, which advance at about the same rate, fill whole cache lines
 // together and read them back with coalesced loads.  Sized for the worst case (a sub-chunk of 1-bit codes); row 0 of each
 // part is the target of stores that must not happen.  Sits between the record list and the literal stream.
-constexpr size_t kProvRecRows = 301, kProvLitRows = 77, kProvRecBytes = kProvRecRows * 64 * 4, kProvBytes = kProvRecBytes + kProvLitRows * 64 * 8;
+#ifndef SWC_SYNC_CHUNK
+#define SWC_SYNC_CHUNK 68   // input bytes per lane and round of the wave-parallel decode (inflate_sync.h: kSyncChunk)
+#endif
+// a sub-chunk decodes at most 8 * SWC_SYNC_CHUNK + 48 bits: a match takes two bits or more, a literal one
+constexpr size_t kProvRecRows = (8 * SWC_SYNC_CHUNK + 48) / 2 + 5, kProvLitRows = (8 * SWC_SYNC_CHUNK + 48) / 8 + 3, kProvRecBytes = kProvRecRows * 64 * 4, kProvBytes = kProvRecBytes + kProvLitRows * 64 * 8;
 SWC_HD size_t ws_bytes_per_job(uint64_t cap) { return ((sizeof(StreamHeader) + max_records(cap) * 4 + 15) & ~(size_t)15) + kProvBytes + lit_bytes(cap); }
 // a job's literal stream inside its area of `stride` bytes (0 if the area is too small for it)
 SWC_HD size_t lit_offset(size_t stride, uint64_t cap) { return stride >= lit_bytes(cap) + sizeof(StreamHeader) ? (stride - lit_bytes(cap)) & ~(size_t)15 : 0; }
@@ -79,10 +83,11 @@ SWC_HD void store_16(gptr p, const u128& v) { *(SWC_AS_GLOBAL u128*)p = v; }
 template <int T, int RING_LOG2>
 struct Lds {
     static constexpr uint32_t kRing = 1u << RING_LOG2;
-    static constexpr uint32_t kLitWin = 16u * T;          // bytes of the literal stream staged ahead
+    static constexpr uint32_t kRpt = 2;                   // records per thread and batch
+    static constexpr uint32_t kLitWin = 8u * T;           // bytes of the literal stream staged ahead (a batch takes less than that many literals)
     alignas(16) uint8_t ring[kRing];                       // byte at virtual position v lives at ring[v % kRing]
     alignas(16) uint8_t litbuf[kLitWin];                   // literal byte at stream offset o lives at litbuf[o % kLitWin]
-    alignas(8) uint64_t rec8[T + 18];                      // per record, in CELL indices (span-relative + off): mstart | thr << 16 | distance << 32 | litkey << 48 (see R1)
+    alignas(8) uint64_t rec8[kRpt * T + 18];                      // per record, in CELL indices (span-relative + off): mstart | thr << 16 | distance << 32 | litkey << 48 (see R1)
     uint32_t slotw[T + 1];                                 // per 16-cell slot: record that covers its first in-span cell | record-start flags of its cells << 16
     uint32_t wave_sum[2 * (T / 64) + 2];
     uint32_t ntake, span, litspan, overlap;
@@ -91,11 +96,14 @@ struct Lds {
 template <int T, int RING_LOG2, uint32_t KEEP>
 struct Resolver {
     using L = Lds<T, RING_LOG2>;
-    static constexpr uint32_t kRing = L::kRing, kMask = kRing - 1u, kLitWin = L::kLitWin, kLitMask = kLitWin - 1u;
+    static constexpr uint32_t kRing = L::kRing, kMask = kRing - 1u, kLitWin = L::kLitWin, kLitMask = kLitWin - 1u, kRpt = L::kRpt;
+    static constexpr uint32_t kLitCap = kLitWin - 16u;    // literal bytes one batch may take: what the window holds whatever its granule alignment
     static constexpr uint32_t kSpanMax = 16u * T - 16u;   // output bytes one batch may cover: at most T slots whatever the alignment
     static constexpr uint32_t kCellOff = 16u * T + 16u;   // cells of the span live in the stale part of the ring, past the span
     static_assert(48u * T + 16u <= kRing - KEEP, "ring too small for history + span + cells");
     static_assert(kMaxLitOnly + kLitRunMax + kMaxLen <= kSpanMax, "a record must fit a span");
+    static_assert(kMaxLitOnly + kLitRunMax <= kLitCap, "a record's literals must fit the literal window");
+    static_assert(kRpt * T <= 0x10000u, "record indices are 16 bits");
     static_assert(16u * T <= 0x8000u, "cell indices are 15 bits");
     static_assert(offsetof(L, litbuf) == kRing, "the literal window sits right behind the ring");
 
@@ -185,19 +193,20 @@ struct Resolver {
         uint64_t lbase = 0;   // literal bytes consumed by earlier batches
         uint64_t lfill = 0;   // the literal window holds stream bytes [lfill - kLitWin, lfill)
         uint32_t base = 0;    // first record of the batch
-        PT<uint32_t, T> r_next;             // the record at base + t, prefetched during the previous batch
+        PT<uint32_t, T> r_nx0, r_nx1;       // the records at base + 2 t and base + 2 t + 1, prefetched during the previous batch
         PT<u128, T> lit_pf;                 // a 16-byte granule of the literal stream on its way into the window
         PT<uint32_t, T> lit_pf_at;          // its stream offset (0xFFFFFFFF: none)
-        PT<uint32_t, T> x, y;               // scan values
+        PT<uint32_t, T> x, y, xb, yb;       // scan values (of the thread's pair of records; xb / yb: the second record alone)
         // prologue: first records, first window of literals
         SIMT_BEGIN(t, T)
-            r_next[t] = (uint32_t)t < nrec ? recs[t] : 0u;
+            r_nx0[t] = 2u * (uint32_t)t < nrec ? recs[2u * (uint32_t)t] : 0u;
+            r_nx1[t] = 2u * (uint32_t)t + 1u < nrec ? recs[2u * (uint32_t)t + 1u] : 0u;
             const uint64_t o = 16ull * (uint32_t)t;
             lit_pf_at[t] = 0xFFFFFFFFu;
-            if (o + 16 <= lit_cap) *(u128*)(l->litbuf + o) = load_16(lits + o);
+            if (o + 16 <= kLitWin && o + 16 <= lit_cap) *(u128*)(l->litbuf + o) = load_16(lits + o);
             l->slotw[t] = 0;
             if (t == 0) l->slotw[T] = 0;
-            if (t < 18) l->rec8[T + t] = 0xFFFFull;
+            if (t < 18) l->rec8[kRpt * T + t] = 0xFFFFull;
         SIMT_END
         lfill = kLitWin;
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -209,50 +218,60 @@ struct Resolver {
             const uint32_t off = vcur & 15u;                    // cells of slot 0 that belong to earlier batches
             const uint32_t v0 = vcur - off;
             const uint32_t cbase = (v0 + kCellOff) & kMask;
-            // ---- R0: the literal granule prefetched last batch lands in the window; my record; scan inputs
+            // ---- R0: the literal granule prefetched last batch lands in the window; my two records; scan inputs
             SIMT_BEGIN(t, T)
                 if (lit_pf_at[t] != 0xFFFFFFFFu) *(u128*)(l->litbuf + (lit_pf_at[t] & kLitMask)) = lit_pf[t];
-                const uint32_t r = base + (uint32_t)t < nrec ? r_next[t] : 0u;
-                uint32_t lit = r & 127u;
-                const uint32_t len = (r >> 7) & 511u;
-                if (len == 0) lit += (r >> 16) << 7;
-                x[t] = lit + len;
-                y[t] = lit;
-                r_next[t] = r;
+                uint32_t xs = 0, ys = 0;
+#pragma unroll
+                for (uint32_t k = 0; k < kRpt; k++) {
+                    const uint32_t r = k ? r_nx1[t] : r_nx0[t];
+                    uint32_t lit = r & 127u;
+                    const uint32_t len = (r >> 7) & 511u;
+                    if (len == 0) lit += (r >> 16) << 7;
+                    xs += lit + len;
+                    ys += lit;
+                    if (k == kRpt - 1) { xb[t] = lit + len; yb[t] = lit; }
+                }
+                x[t] = xs;
+                y[t] = ys;
                 if (t == 0) l->overlap = 0;
             SIMT_END
             simt::group_scan2_incl<T>(x, y, l->wave_sum);       // (barrier A inside)
             SWC_RP(0)
-            // ---- R1: batch geometry, one record per thread, in CELL indices (span-relative position + off)
+            // ---- R1: batch geometry, two records per thread, in CELL indices (span-relative position + off)
             const uint32_t lbk = (uint32_t)lbase;
             SIMT_BEGIN(t, T)
-                const uint32_t r = r_next[t];
-                uint32_t lit = r & 127u;
-                const uint32_t len = (r >> 7) & 511u;
-                if (len == 0) lit += (r >> 16) << 7;
-                const uint32_t end = x[t], lit_end = y[t];
-                const uint32_t start = end - (lit + len), mstart = start + lit;
-                const bool take = r != 0u && end <= kSpanMax;
-                // mstart: first match cell; thr: first cell that copies from INSIDE the span (a match cell at or past distance + off;
-                // 0xFFFF: none); litkey: (stream offset of the record's first literal) - (its first cell), modulo the literal window
-                const uint32_t dist = len ? (r >> 16) + 1u : 1u;
-                const uint32_t mstart_c = mstart + off;
-                uint32_t thr = dist + off > mstart_c ? dist + off : mstart_c;
-                if (len == 0 || thr > 0xFFFFu) thr = 0xFFFFu;
-                const uint32_t lkey = (lbk + (lit_end - lit) - (start + off)) & kLitMask;
-                l->rec8[t] = take ? (uint64_t)mstart_c | ((uint64_t)thr << 16) | ((uint64_t)(dist & 0xFFFFu) << 32) | ((uint64_t)lkey << 48)
-                                  : 0xFFFFull;
-                if (take) {
-                    // the slots whose first in-span cell I cover, and the flag of my first cell
-                    for (uint32_t k = start == 0 ? 0u : (start + off + 15u) >> 4; k == 0 ? start == 0 : 16u * k - off < end; k++) lds_or(&l->slotw[k], (uint32_t)t);
-                    const uint32_t c0 = start + off;
-                    lds_or(&l->slotw[c0 >> 4], 0x10000u << (c0 & 15u));
-                    if (len > dist) l->overlap = 1;          // (every writer stores the same value)
-                    if (t == T - 1) { l->ntake = (uint32_t)T; l->span = end; l->litspan = lit_end; }
-                } else if (t != 0 && start <= kSpanMax && base + (uint32_t)t - 1u < nrec) {
-                    // the first record that is not taken (or the first thread past the last record) closes the batch: `start`
-                    // is the end of the record before it, which exists and fits the span, i.e. was taken
-                    l->ntake = (uint32_t)t; l->span = start; l->litspan = lit_end - lit;
+#pragma unroll
+                for (uint32_t k = 0; k < kRpt; k++) {
+                    const uint32_t i = kRpt * (uint32_t)t + k;     // my record of the batch
+                    const uint32_t r = k ? r_nx1[t] : r_nx0[t];
+                    uint32_t lit = r & 127u;
+                    const uint32_t len = (r >> 7) & 511u;
+                    if (len == 0) lit += (r >> 16) << 7;
+                    const uint32_t end = k ? x[t] : x[t] - xb[t], lit_end = k ? y[t] : y[t] - yb[t];
+                    const uint32_t start = end - (lit + len), mstart = start + lit;
+                    const bool take = r != 0u && end <= kSpanMax && lit_end <= kLitCap;
+                    // mstart: first match cell; thr: first cell that copies from INSIDE the span (a match cell at or past distance +
+                    // off; 0xFFFF: none); litkey: (stream offset of the record's first literal) - (its first cell), modulo the window
+                    const uint32_t dist = len ? (r >> 16) + 1u : 1u;
+                    const uint32_t mstart_c = mstart + off;
+                    uint32_t thr = dist + off > mstart_c ? dist + off : mstart_c;
+                    if (len == 0 || thr > 0xFFFFu) thr = 0xFFFFu;
+                    const uint32_t lkey = (lbk + (lit_end - lit) - (start + off)) & kLitMask;
+                    l->rec8[i] = take ? (uint64_t)mstart_c | ((uint64_t)thr << 16) | ((uint64_t)(dist & 0xFFFFu) << 32) | ((uint64_t)lkey << 48)
+                                      : 0xFFFFull;
+                    if (take) {
+                        // the slots whose first in-span cell I cover, and the flag of my first cell
+                        for (uint32_t q = start == 0 ? 0u : (start + off + 15u) >> 4; q == 0 ? start == 0 : 16u * q - off < end; q++) lds_or(&l->slotw[q], i);
+                        const uint32_t c0 = start + off;
+                        lds_or(&l->slotw[c0 >> 4], 0x10000u << (c0 & 15u));
+                        if (len > dist) l->overlap = 1;      // (every writer stores the same value)
+                        if (i == kRpt * T - 1) { l->ntake = kRpt * (uint32_t)T; l->span = end; l->litspan = lit_end; }
+                    } else if (i != 0 && start <= kSpanMax && lit_end - lit <= kLitCap && base + i - 1u < nrec) {
+                        // the first record that is not taken (or the first one past the last record) closes the batch: `start` is
+                        // the end of the record before it, which exists and fits span and window, i.e. was taken
+                        l->ntake = i; l->span = start; l->litspan = lit_end - lit;
+                    }
                 }
             SIMT_END_BARRIER                                     // barrier B
             SWC_RP(1)
@@ -265,8 +284,9 @@ struct Resolver {
             // ---- R2: prefetch for the next batch, then the cells
             SIMT_BEGIN(t, T)
                 {
-                    const uint32_t nx = base + ntake + (uint32_t)t;
-                    r_next[t] = nx < nrec ? recs[nx] : 0u;
+                    const uint32_t nx = base + ntake + kRpt * (uint32_t)t;
+                    r_nx0[t] = nx < nrec ? recs[nx] : 0u;
+                    r_nx1[t] = nx + 1u < nrec ? recs[nx + 1u] : 0u;
                     const uint64_t o = lfill + 16ull * (uint32_t)t;
                     const bool want = o < lfill_next && o + 16 <= lit_cap;
                     lit_pf_at[t] = want ? (uint32_t)o : 0xFFFFFFFFu;
