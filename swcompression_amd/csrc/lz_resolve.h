@@ -93,6 +93,12 @@ struct Lds {
     uint32_t ntake, span, litspan, overlap;
 };
 
+#ifndef SWC_RESOLVE_EARLY
+#define SWC_RESOLVE_EARLY 0
+#endif
+#if defined(SWC_HOST_EMULATION)
+inline uint64_t g_resolve_stats[4];   // dwords of all spans, dwords whose four cells are values after the expansion
+#endif
 template <int T, int RING_LOG2, uint32_t KEEP>
 struct Resolver {
     using L = Lds<T, RING_LOG2>;
@@ -147,42 +153,74 @@ struct Resolver {
         *(uint16_t*)(ring + ((cbase + 2u * ci) & kMask)) = (uint16_t)v;
     }
 
-    // ---- R2, one CELL per thread and step.  Everything is a select over precomputed per-record geometry (rec8): which record
-    // (slot word + popcount), literal or match (ci < mstart), the ONE LDS byte read (literal window or ring), value or source
-    // index (ci >= thr).  The trip count is the same for every thread (cells past the span get harmless garbage), so the loop has
-    // no per-thread exit and no exec-mask region.  OVERLAP: the batch holds a match that overlaps itself (length > distance):
-    // such bytes are reduced to their first period so that chains stay short (one division per cell in this variant only).
+    // ---- R2, one aligned DWORD (four cells) per thread and step.  Everything is a select over precomputed per-record geometry
+    // (rec8): which record (the slot word, read once for the four cells, + a popcount each), literal or match (ci < mstart), the
+    // ONE LDS byte read per cell (literal window or ring), value or source index (ci >= thr).  The trip count is the same for
+    // every thread (cells past the span get harmless garbage), so the loop has no per-thread exit.  A dword whose four cells are
+    // values at once -- literals, match bytes from before the span -- leaves for the ring and for HBM right here and is marked
+    // (kCellDone in its first cell): R3 only looks at it.  OVERLAP: the batch holds a match that overlaps itself (length >
+    // distance): such bytes are reduced to their first period so that chains stay short (one division per cell in this variant
+    // only).  early_lim: dwords [4, early_lim) may leave early (whole dwords of the span below the output limit; the first four
+    // may hold cells of earlier batches, which are set after the loop).
+    static constexpr uint32_t kCellDone = 0x4000u;
     template <bool OVERLAP>
-    SWC_D void expand_cells(int t, uint32_t ncell, uint32_t off, uint32_t v0, uint32_t cbase, uint32_t lb) const {
+    SWC_D void expand_cells(int t, uint32_t ncell, uint32_t off, uint32_t v0, uint32_t cbase, uint32_t lb, uint32_t early_lim, gptr obase) const {
         const uint8_t* lds0 = l->ring;                      // litbuf == ring + kRing (struct layout, asserted above)
-        const uint32_t j = (uint32_t)t & 15u;
-        const uint32_t m_rest = ((2u << j) - 1u) & ~1u;     // record starts in cells (0, j] of my slot
-        uint32_t m = (uint32_t)t < 16u ? ((2u << j) - 1u) & ~((2u << off) - 1u) : m_rest;   // slot 0: starts in (off, j]
-        const uint32_t iters = (ncell + (uint32_t)T - 1u) / (uint32_t)T;
-        uint32_t ci = (uint32_t)t;
-#pragma unroll 2
-        for (uint32_t it = 0; it < iters; it++, ci += (uint32_t)T) {
-            const uint32_t sw = l->slotw[ci >> 4];
-            const uint32_t r = (sw & 0xFFFFu) + (uint32_t)simt::popc32((sw >> 16) & m);
-            m = m_rest;
-            const uint64_t rc = l->rec8[r];
-            const uint32_t w0 = (uint32_t)rc, w1 = (uint32_t)(rc >> 32);
-            const uint32_t mstart = w0 & 0xFFFFu, thr = w0 >> 16, dist = w1 & 0xFFFFu, lkey = w1 >> 16;
-            const bool is_lit = ci < mstart;
-            uint32_t x = ci - dist;                          // the cell this byte copies (when it is a match byte)
-            bool inspan = ci >= thr;
-            if (OVERLAP) {
-                const uint32_t mo = ci - mstart;
-                if (!is_lit && mo >= dist) x = mstart - dist + mod_small(mo & 0xFFFFu, dist);   // repeats its first period
-                inspan = !is_lit && (int32_t)x >= (int32_t)off;
+        const uint32_t jb = 4u * ((uint32_t)t & 3u);
+        uint32_t m_rest[4], m[4];
+#pragma unroll
+        for (uint32_t c = 0; c < 4; c++) {
+            m_rest[c] = ((2u << (jb + c)) - 1u) & ~1u;      // record starts in cells (0, j] of my slot
+            m[c] = (uint32_t)t < 4u ? ((2u << (jb + c)) - 1u) & ~((2u << off) - 1u) : m_rest[c];   // slot 0: starts in (off, j]
+        }
+        const uint32_t nq = (ncell + 3u) >> 2;
+        const uint32_t iters = (nq + (uint32_t)T - 1u) / (uint32_t)T;
+        uint32_t q = (uint32_t)t;
+        for (uint32_t it = 0; it < iters; it++, q += (uint32_t)T) {
+            const uint32_t sw = l->slotw[q >> 2];
+            uint32_t cell[4];
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                const uint32_t ci = 4u * q + c;
+                const uint32_t r = (sw & 0xFFFFu) + (uint32_t)simt::popc32((sw >> 16) & m[c]);
+                m[c] = m_rest[c];
+                const uint64_t rc = l->rec8[r];
+                const uint32_t w0 = (uint32_t)rc, w1 = (uint32_t)(rc >> 32);
+                const uint32_t mstart = w0 & 0xFFFFu, thr = w0 >> 16, dist = w1 & 0xFFFFu, lkey = w1 >> 16;
+                const bool is_lit = ci < mstart;
+                uint32_t x = ci - dist;                      // the cell this byte copies (when it is a match byte)
+                bool inspan = ci >= thr;
+                if (OVERLAP) {
+                    const uint32_t mo = ci - mstart;
+                    if (!is_lit && mo >= dist) x = mstart - dist + mod_small(mo & 0xFFFFu, dist);   // repeats its first period
+                    inspan = !is_lit && (int32_t)x >= (int32_t)off;
+                }
+                const uint32_t a_lit = kRing + ((ci + lkey) & kLitMask), a_ring = (v0 + x) & kMask;
+                const uint32_t byte = lds0[is_lit ? a_lit : a_ring];
+                cell[c] = inspan ? x : 0x8000u | byte;
             }
-            const uint32_t a_lit = kRing + ((ci + lkey) & kLitMask), a_ring = (v0 + x) & kMask;
-            const uint32_t byte = lds0[is_lit ? a_lit : a_ring];
-            cell_store(l->ring, cbase, ci, inspan ? x : 0x8000u | byte);
+            const bool early = SWC_RESOLVE_EARLY && ((cell[0] & cell[1] & cell[2] & cell[3]) & 0x8000u) != 0u && q >= 4u && q < early_lim;
+#if defined(SWC_HOST_EMULATION)
+            if (q < (ncell >> 2)) { g_resolve_stats[0]++; g_resolve_stats[1] += early ? 1 : 0; }
+#endif
+            if (early) {
+                const uint32_t word = (cell[0] & 0xFFu) | ((cell[1] & 0xFFu) << 8) | ((cell[2] & 0xFFu) << 16) | ((cell[3] & 0xFFu) << 24);
+                *(uint32_t*)(l->ring + ((v0 + 4u * q) & kMask)) = word;
+                *(SWC_AS_GLOBAL uint32_t*)(obase + (size_t)(4u * q)) = word;
+                cell[0] |= kCellDone;
+            }
+            *(uint64_t*)(l->ring + ((cbase + 8u * q) & kMask)) = (uint64_t)cell[0] | ((uint64_t)cell[1] << 16) | ((uint64_t)cell[2] << 32) | ((uint64_t)cell[3] << 48);
         }
         // cells of slot 0 in front of the span belong to earlier batches: final bytes of the ring (written after the loop: the
         // loop left garbage there)
-        if ((uint32_t)t < off) cell_store(l->ring, cbase, (uint32_t)t, 0x8000u | lds0[(v0 + (uint32_t)t) & kMask]);
+        // (by the thread that wrote the dword in the loop: its own LDS accesses stay in order)
+        if ((uint32_t)t < 4u) {
+#pragma unroll
+            for (uint32_t c = 0; c < 4; c++) {
+                const uint32_t ci = 4u * (uint32_t)t + c;
+                if (ci < off) cell_store(l->ring, cbase, ci, 0x8000u | lds0[(v0 + ci) & kMask]);
+            }
+        }
     }
 
     SWC_D void run(const SWC_AS_GLOBAL uint32_t* recs, uint32_t nrec) {
@@ -281,6 +319,15 @@ struct Resolver {
             const uint32_t ncell = span + off;                   // cells [off, ncell) are this batch's bytes, [0, off) belong to earlier ones
             // the literal window after this batch: [lbase + litspan, .. + kLitWin) rounded down to granules
             const uint64_t lfill_next = (lbase + litspan + kLitWin) & ~(uint64_t)15;
+            // Dwords [0, nfull) lie inside the span with all four cells; of those, [qmin, qlim) also lie inside the output and leave
+            // with one store at a 32-bit offset from a wave-uniform base (no 64-bit address arithmetic per thread).
+            const uint32_t nfull = ncell >> 2;
+            const int64_t base64 = (int64_t)rpos - (int64_t)off;                 // output position of the span's cell 0 (negative only in the first batch)
+            const uint32_t qmin = base64 < 0 ? (uint32_t)((3 - base64) >> 2) : 0u;
+            const uint64_t room = (int64_t)limit > base64 ? (uint64_t)((int64_t)limit - base64) : 0u;
+            const uint32_t qlim = room >= 0x100000000ull ? 0x40000000u : (uint32_t)room >> 2;
+            gptr obase = (gptr)((SWC_AS_GLOBAL uint8_t*)out + base64);
+            const uint32_t early_lim = nfull < qlim ? nfull : qlim;
             // ---- R2: prefetch for the next batch, then the cells
             SIMT_BEGIN(t, T)
                 {
@@ -292,25 +339,18 @@ struct Resolver {
                     lit_pf_at[t] = want ? (uint32_t)o : 0xFFFFFFFFu;
                     if (want) lit_pf[t] = load_16(lits + o);
                 }
-                if (overlap) expand_cells<true>(t, ncell, off, v0, cbase, lbk);
-                else expand_cells<false>(t, ncell, off, v0, cbase, lbk);
+                if (overlap) expand_cells<true>(t, ncell, off, v0, cbase, lbk, early_lim, obase);
+                else expand_cells<false>(t, ncell, off, v0, cbase, lbk, early_lim, obase);
             SIMT_END_BARRIER                                     // barrier C
             SWC_RP(2)
             // ---- R3: one aligned DWORD per thread and step: chase what is unresolved, then the dword leaves for the ring and for HBM
             SIMT_BEGIN(t, T)
                 if ((uint32_t)t * 16u < ncell) l->slotw[t] = 0;   // (read in R2 only; the next batch sets it after its barrier A)
-                // Dwords [0, nfull) lie inside the span with all four cells; of those, [qmin, qlim) also lie inside the output
-                // and leave with one store at a 32-bit offset from a wave-uniform base (no 64-bit address arithmetic per
-                // thread).  A last, incomplete dword (ncell % 4 != 0) is the business of ONE thread after the loop.
-                const uint32_t nfull = ncell >> 2;
-                const int64_t base64 = (int64_t)rpos - (int64_t)off;             // output position of the span's cell 0 (negative only in the first batch)
-                const uint32_t qmin = base64 < 0 ? (uint32_t)((3 - base64) >> 2) : 0u;
-                const uint64_t room = (int64_t)limit > base64 ? (uint64_t)((int64_t)limit - base64) : 0u;
-                const uint32_t qlim = room >= 0x100000000ull ? 0x40000000u : (uint32_t)room >> 2;
-                gptr obase = (gptr)((SWC_AS_GLOBAL uint8_t*)out + base64);
+                // (a last, incomplete dword -- ncell % 4 != 0 -- is the business of ONE thread after the loop)
                 for (uint32_t q = (uint32_t)t; q < nfull; q += (uint32_t)T) {
                     const uint32_t ca = (cbase + 8u * q) & kMask;
                     const uint64_t c4 = *(const uint64_t*)(l->ring + ca);
+                    if (((uint32_t)c4 & (0x8000u | kCellDone)) == (0x8000u | kCellDone)) continue;   // left in R2 (a value with the mark)
                     uint32_t c[4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) c[e] = (uint32_t)(c4 >> (16 * e)) & 0xFFFFu;

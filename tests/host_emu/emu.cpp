@@ -33,6 +33,7 @@ extern "C" void emu_inflate_sync(swc::Job* jobs, size_t n) {
 extern "C" void emu_lz4_stats(uint64_t* out, int reset) {
     for (int i = 0; i < 8; i++) { out[i] = swc::lz4w::g_lz4_stats[i]; if (reset) swc::lz4w::g_lz4_stats[i] = 0; }
 }
+extern "C" void emu_resolve_stats(uint64_t* out) { for (int i = 0; i < 4; i++) { out[i] = swc::lzr::g_resolve_stats[i]; swc::lzr::g_resolve_stats[i] = 0; } }
 extern "C" void emu_sync_wave(uint64_t* out) { for (int i = 0; i < 4; i++) { out[i] = swc::inflate::g_sync_wave[i]; swc::inflate::g_sync_wave[i] = 0; } }
 extern "C" void emu_sync_stats(uint64_t* out, int reset) {
     for (int i = 0; i < 8; i++) { out[i] = swc::inflate::g_sync_stats[i]; if (reset) swc::inflate::g_sync_stats[i] = 0; }
