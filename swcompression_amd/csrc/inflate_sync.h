@@ -503,27 +503,27 @@ SWC_D uint32_t walk_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start,
     uint32_t tsel = 0, tmsk = (1u << kSyncLitBits) - 1u, stop = 0;
     if (chunk_end > in_bits) chunk_end = in_bits;          // (the zero fill behind the input is not worth decoding)
     if (start >= in_bits) { stop = kEntInvalid; chunk_end = 0; }
-    for (;;) {
-        const uint32_t posb = (wa << 3) + bp;
-        if ((uint32_t)(tsel == 0) & (uint32_t)(posb >= chunk_end)) break;
-        SWC_SYNC_STAT(4, 1);
-        SWC_SYNC_ITER();
-        const uint32_t bits = funnel32(d1, d0, bp);
-        uint32_t e = sl->lut[(bits & tmsk) | tsel];
-        const uint32_t nx = *(const uint32_t*)(stg + wa + 8);
-        if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, tsel); }
-        const uint32_t st = e & kEntStop;
-        stop |= st;
-        chunk_end = st ? 0u : chunk_end;
-        const bool is_len = (e & kEntLen) != 0u;
-        tsel = e & kEntLen;
-        tmsk = is_len ? (1u << kSyncDistBits) - 1u : (1u << kSyncLitBits) - 1u;
-        bp += (e & kEntInvalid) ? 0u : e & 31u;
-        const bool sh = bp >= 32;
-        wa += sh ? 4u : 0u;
-        bp &= 31u;
-        d0 = sh ? d1 : d0;
-        d1 = sh ? nx : d1;
+    if (start < chunk_end) {   // (tested at the bottom: one mask update and one branch per iteration)
+        do {
+            SWC_SYNC_STAT(4, 1);
+            SWC_SYNC_ITER();
+            const uint32_t bits = funnel32(d1, d0, bp);
+            uint32_t e = sl->lut[(bits & tmsk) | tsel];
+            const uint32_t nx = *(const uint32_t*)(stg + wa + 8);
+            if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, tsel); }
+            const uint32_t st = e & kEntStop;
+            stop |= st;
+            chunk_end = st ? 0u : chunk_end;
+            const bool is_len = (e & kEntLen) != 0u;
+            tsel = e & kEntLen;
+            tmsk = is_len ? (1u << kSyncDistBits) - 1u : (1u << kSyncLitBits) - 1u;
+            bp += (e & kEntInvalid) ? 0u : e & 31u;
+            const bool sh = bp >= 32;
+            wa += sh ? 4u : 0u;
+            bp &= 31u;
+            d0 = sh ? d1 : d0;
+            d1 = sh ? nx : d1;
+        } while ((uint32_t)(tsel != 0) | (uint32_t)((wa << 3) + bp < chunk_end));
     }
     const uint32_t endb = (wa << 3) + bp;
     return (stop & kEntInvalid) || endb > in_bits ? kPosFail : endb;
@@ -542,9 +542,7 @@ SWC_D void decode_chunk_prov(const SyncLds* sl, const LongCodes lc, uint32_t sta
     int32_t need = -0x40000000;
     if (chunk_end > in_bits) chunk_end = in_bits;          // (the zero fill behind the input is not worth decoding)
     if (start >= in_bits) { stop = kEntInvalid; chunk_end = 0; }   // nothing left for this sub-chunk: the checked step says what that means
-    for (;;) {
-        const uint32_t posb = (wa << 3) + bp;
-        if ((uint32_t)(tsel == 0) & (uint32_t)(posb >= chunk_end)) break;
+    if (start < chunk_end) do {   // (tested at the bottom: one mask update and one branch per iteration)
         SWC_SYNC_STAT(5, 1);
         SWC_SYNC_ITER();
         const uint32_t bits = funnel32(d1, d0, bp);
@@ -583,7 +581,7 @@ SWC_D void decode_chunk_prov(const SyncLds* sl, const LongCodes lc, uint32_t sta
         bp &= 31u;
         d0 = sh ? d1 : d0;
         d1 = sh ? nx : d1;
-    }
+    } while ((uint32_t)(tsel != 0) | (uint32_t)((wa << 3) + bp < chunk_end));
     if (nlit & 7u) {   // the last, incomplete group: its bytes sit at the top of the accumulator
         const uint32_t dn = (8u - (nlit & 7u)) << 3;
         store_u64(plit + loff, (((uint64_t)lb1 << 32) | lb0) >> dn);
