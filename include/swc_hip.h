@@ -240,15 +240,18 @@ void swc_free(void* p);
 /* 1 if a gfx950 device is usable, 0 otherwise (then every decode entry point returns SWC_E_DEVICE) */
 int swc_device_available(void);
 const char* swc_version(void);
-/* Measurement knob (never changes results): "phase_timing" = 0 | 1 (HIP events around the two Deflate kernels of a
- * launch).  Process-wide; meant for benchmarking. */
+/* Measurement knob (never changes results): "phase_timing" = 0 | 1 (HIP events between the kernels of the batch
+ * launches of the CALLING THREAD -- like the launch stream and the staging buffers, measurement state is per thread).
+ * Meant for benchmarking. */
 int swc_set_tuning(const char* key, int value);
 /* Profile builds of the library (-DSWC_PROFILE) only: a device buffer of 32 x uint64 per job of the next Deflate
  * launches that the kernels fill with cycle counts per stage (tools/exp_profile.py).  NULL switches it off.  A no-op in
  * the shipped build. */
 int swc_set_profile_buffer(void* device_ptr);
-/* With "phase_timing" on: durations (ms) of the kernels of the last Deflate launch, in launch order
- * (entropy decode, LZ77 resolve).  Returns the number of values written (0 if none). */
+/* With "phase_timing" on: durations (ms) of the kernels of the calling thread's last batch launch, in launch order --
+ * Deflate: entropy decode, LZ77 resolve; LZ4: dictionary-block kernel, parse, resolve; BZip2: block kernel (Huffman + MTF,
+ * counting sort, walk), serial fallback, block CRC; LZMA / LZMA2: the one kernel.  Returns the number of values written
+ * (0 if none or if `cap` is too small; at most 4). */
 int swc_last_phase_ms(float* ms, int cap);
 
 /* Process-wide launch statistics of the host framing layer (monotonic, for tests and tuning): "launches" = batched

@@ -6,6 +6,7 @@
  * the oracle's ordinary single-unit entry point until the time budget is used.  Used by bench.py's cpu_context leg.
  */
 #define _POSIX_C_SOURCE 200809L
+#include <malloc.h>
 #include <pthread.h>
 #include <stdlib.h>
 #include <time.h>
@@ -61,6 +62,13 @@ static void* worker(void* p) {
 double refcpu_timed_pool(int codec, int aux, const uint8_t* const* ins, const size_t* lens, size_t n, int threads,
                          double seconds, uint64_t* out_bytes, uint64_t* in_bytes, uint64_t* units) {
     if (n == 0 || threads < 1) return -1.0;
+    /* The restatement allocates like the reference does -- three decoding trees of up to 2^16 Ints per Deflate block, an
+     * output array that grows by doubling -- and with glibc's defaults every such block above 128 KiB is its own mmap /
+     * munmap: 256 threads then queue on the process's address-space lock, not on the decode (round 2: 12x on 256
+     * threads).  Keep freed memory in per-thread arenas instead. */
+    mallopt(M_MMAP_THRESHOLD, 1 << 30);
+    mallopt(M_TRIM_THRESHOLD, 1 << 30);
+    mallopt(M_ARENA_MAX, threads + 1);
     size_t warm = 0;
     if (decode_one(codec, aux, ins[0], lens[0], &warm) != SWC_OK) return -1.0;   /* also builds the lazy static tables */
     pthread_t* th = (pthread_t*)calloc((size_t)threads, sizeof(pthread_t));

@@ -283,6 +283,22 @@ def build_units(kind, n_distinct, unit_size, payload="text", seed=2, cache=True)
     return units, plains
 
 
+def build_units_mixed(kind, parts, unit_size, seed=2, cache=True):
+    """Units of several payload classes in one list: parts = [("text", 192), ("mix", 64), ...] (class, count).  The
+    classes are interleaved so that any contiguous range of the list (a rank's shard) holds all of them."""
+    lists = []
+    for k, (payload, n) in enumerate(parts):
+        u, p = build_units(kind, n, unit_size, payload=payload, seed=seed + 100003 * k, cache=cache)
+        lists.append(list(zip(u, p)))
+    total = sum(len(x) for x in lists)
+    out, taken = [], [0] * len(lists)
+    for i in range(total):   # proportional interleave
+        k = max(range(len(lists)), key=lambda j: (len(lists[j]) * (i + 1) / total - taken[j]) if taken[j] < len(lists[j]) else -1e9)
+        out.append(lists[k][taken[k]])
+        taken[k] += 1
+    return [u for u, _ in out], [p for _, p in out]
+
+
 class _LZ4F_frameInfo(ctypes.Structure):
     _fields_ = [("blockSizeID", ctypes.c_int), ("blockMode", ctypes.c_int), ("contentChecksumFlag", ctypes.c_int),
                 ("frameType", ctypes.c_int), ("contentSize", ctypes.c_ulonglong), ("dictID", ctypes.c_uint),

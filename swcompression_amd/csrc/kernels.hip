@@ -39,11 +39,13 @@ struct WsMap {
 
 // ---- Deflate: two phases (inflate_sync.h + inflate_lane.h, lz_resolve.h) -------------------------------------------
 // Phase 1: one stream per WAVEFRONT, 64 sub-chunks of the stream decoded at once (inflate_sync.h).
-// LDS: the shared tables + the staged input of a round, ~14 KiB per wave -> 11 waves per CU.
+// LDS: the shared tables + the staged input of a round, exactly 10 KiB per wave -> 16 waves per CU.
 #ifndef SWC_SYNC_WAVES_PER_SIMD
 #define SWC_SYNC_WAVES_PER_SIMD 3
 #endif
-static uint64_t* g_prof = nullptr;   // profile builds (-DSWC_PROFILE): 32 counters per job, [0..16) phase 1, [16..32) phase 2
+// Measurement state belongs to the CALLING THREAD, like the launch stream and the staging buffers (api.cpp): two threads
+// that bench at once do not see each other's events.
+static thread_local uint64_t* g_prof = nullptr;   // profile builds (-DSWC_PROFILE): 32 counters per job, [0..16) phase 1, [16..32) phase 2
 void set_profile_buffer(void* p) { g_prof = static_cast<uint64_t*>(p); }
 __global__ __launch_bounds__(64, SWC_SYNC_WAVES_PER_SIMD) void swc_inflate_sync_kernel(Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof) {
     __shared__ __attribute__((aligned(16))) inflate::SyncLds sync_lds;
@@ -70,24 +72,31 @@ __global__ __launch_bounds__(kInflateResolveThreads) void swc_lz_resolve_kernel(
 }
 
 
-// Optional per-phase timing of the last Deflate launch (bench.py: roofline per kernel).  HIP events on the
-// launch stream; off by default so that the production path issues nothing but the two kernels.
-static int g_phase_timing = 0;
-static hipEvent_t g_phase_ev[3];
-static bool g_phase_ev_ok = false, g_phase_valid = false;
+// Optional per-kernel timing of the calling thread's last batch launch (bench.py: roofline per kernel).  HIP events on the
+// launch stream between the kernels; off by default so that the production path issues nothing but the kernels.
+constexpr int kMaxPhases = 4;
+struct PhaseTimer {
+    int on = 0, n = 0;
+    bool ok = false, valid = false;
+    hipEvent_t ev[kMaxPhases + 1];
+    void begin(hipStream_t s) { n = 0; valid = false; mark(s); }
+    void mark(hipStream_t s) {   // after every kernel of the launch
+        if (on && ok && n <= kMaxPhases) { (void)hipEventRecord(ev[n], s); n++; valid = n >= 2; }
+    }
+};
+static thread_local PhaseTimer g_pt;
 void set_phase_timing(int on) {
-    g_phase_timing = on;
-    if (on && !g_phase_ev_ok) {
-        g_phase_ev_ok = true;
-        for (auto& e : g_phase_ev) if (hipEventCreate(&e) != hipSuccess) g_phase_ev_ok = false;
+    g_pt.on = on;
+    if (on && !g_pt.ok) {
+        g_pt.ok = true;
+        for (auto& e : g_pt.ev) if (hipEventCreate(&e) != hipSuccess) g_pt.ok = false;
     }
 }
 int last_phase_ms(float* ms, int cap) {
-    if (!g_phase_valid || cap < 2) return 0;
-    if (hipEventSynchronize(g_phase_ev[2]) != hipSuccess) return 0;
-    if (hipEventElapsedTime(&ms[0], g_phase_ev[0], g_phase_ev[1]) != hipSuccess) return 0;
-    if (hipEventElapsedTime(&ms[1], g_phase_ev[1], g_phase_ev[2]) != hipSuccess) return 0;
-    return 2;
+    if (!g_pt.valid || cap < g_pt.n - 1) return 0;
+    if (hipEventSynchronize(g_pt.ev[g_pt.n - 1]) != hipSuccess) return 0;
+    for (int i = 0; i + 1 < g_pt.n; i++) if (hipEventElapsedTime(&ms[i], g_pt.ev[i], g_pt.ev[i + 1]) != hipSuccess) return 0;
+    return g_pt.n - 1;
 }
 size_t inflate_ws_bytes_per_job(uint64_t cap) { return lzr::ws_bytes_per_job(cap); }
 
@@ -97,12 +106,11 @@ hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStr
     if (!ws_off && stride < sizeof(lzr::StreamHeader)) return hipErrorInvalidValue;
     const WsMap wm{(uint8_t*)ws, stride, ws_off};
     const dim3 block(kWave);
-    const bool timing = g_phase_timing && g_phase_ev_ok;
-    if (timing) (void)hipEventRecord(g_phase_ev[0], stream);
+    g_pt.begin(stream);
     hipLaunchKernelGGL(swc_inflate_sync_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof);
-    if (timing) (void)hipEventRecord(g_phase_ev[1], stream);
+    g_pt.mark(stream);
     hipLaunchKernelGGL(swc_lz_resolve_kernel, dim3((unsigned)n), dim3(kInflateResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof);
-    if (timing) { (void)hipEventRecord(g_phase_ev[2], stream); g_phase_valid = true; }
+    g_pt.mark(stream);
     return hipGetLastError();
 }
 
@@ -158,10 +166,14 @@ hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_
     }
     // The parse is latency bound per block (a serial chase), so all blocks are parsed in ONE launch: the more waves
     // in flight, the better the latency hides (8,192 blocks = 8 waves per SIMD).
+    g_pt.begin(stream);
     hipLaunchKernelGGL(swc_lz4_lane_kernel, grid, block, 0, stream, jobs, (uint32_t)n, 1);
+    g_pt.mark(stream);
     const WsMap wm{(uint8_t*)ws, stride, ws_off};
     hipLaunchKernelGGL(swc_lz4_parse_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof);
+    g_pt.mark(stream);
     hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(lz4w::kResolveThreads), 0, stream, jobs, (uint32_t)n, wm);
+    g_pt.mark(stream);
     return hipGetLastError();
 }
 
@@ -193,6 +205,7 @@ size_t lzma_spill_bytes_per_job() { return kLzmaSpillBytes; }
 hipError_t launch_lzma(bool lzma2, Job* jobs, size_t n, void* spill, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     dim3 grid((unsigned)n), block(kWave);
+    g_pt.begin(stream);
     if (spill) {
         if (lzma2) hipLaunchKernelGGL((swc_lzma_kernel<true, 3>), grid, block, lzma::lds_bytes_for(3), stream, jobs, (uint32_t)n, (uint8_t*)spill);
         else hipLaunchKernelGGL((swc_lzma_kernel<false, 3>), grid, block, lzma::lds_bytes_for(3), stream, jobs, (uint32_t)n, (uint8_t*)spill);
@@ -200,6 +213,7 @@ hipError_t launch_lzma(bool lzma2, Job* jobs, size_t n, void* spill, hipStream_t
         if (lzma2) hipLaunchKernelGGL((swc_lzma_kernel<true, 4>), grid, block, lzma::lds_bytes_for(4), stream, jobs, (uint32_t)n, (uint8_t*)nullptr);
         else hipLaunchKernelGGL((swc_lzma_kernel<false, 4>), grid, block, lzma::lds_bytes_for(4), stream, jobs, (uint32_t)n, (uint8_t*)nullptr);
     }
+    g_pt.mark(stream);
     return hipGetLastError();
 }
 
@@ -275,9 +289,13 @@ hipError_t launch_bzip2(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStrea
     }
     const size_t lcap = lo;
     dim3 block(kWave);
+    g_pt.begin(stream);
     hipLaunchKernelGGL(swc_bzip2_block_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
+    g_pt.mark(stream);
     hipLaunchKernelGGL(swc_bzip2_expand_kernel, dim3((unsigned)((n + kWave - 1) / kWave)), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
+    g_pt.mark(stream);
     hipLaunchKernelGGL(swc_bzip2_crc_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, (uint32_t)n);
+    g_pt.mark(stream);
     return hipGetLastError();
 }
 

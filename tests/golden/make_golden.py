@@ -90,6 +90,15 @@ def main():
             {"input": "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789", "hash": "9c285e64"},
             {"input": "1234567890" * 8, "hash": "9c05f475"},
         ],
+        "sha256": [  # Tests/Sha256Tests.swift:12-64 (Sources/Common/Sha256.swift:28-142, the XZ check type 0x0A)
+            {"input": "", "hash": "e3b0c44298fc1c149afbf4c8996fb92427ae41e4649b934ca495991b7852b855"},
+            {"input": "a", "hash": "ca978112ca1bbdcafac231b39a23dc4da786eff8147c4e72b9807785afee48bb"},
+            {"input": "abc", "hash": "ba7816bf8f01cfea414140de5dae2223b00361a396177a9cb410ff61f20015ad"},
+            {"input": "message digest", "hash": "f7846f55cf23e14eebeab5b4e1550cad5b509e3348fbc4efa3a1413d393cb650"},
+            {"input": "abcdefghijklmnopqrstuvwxyz", "hash": "71c480df93d6ae2f1efad1447c66c9525e316218cf51fc8d9ed832f2daf18b73"},
+            {"input": "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789", "hash": "db4bfcbd4da0cd85a60c3c37d3fbd8805c77f15fc6b1fdfe614ee0a7c8fdb4c0"},
+            {"input": "1234567890" * 8, "hash": "f371bc4a311f2b009eef952dd83ca80e2b60026c8e935592d0f9c308453c813e"},
+        ],
         # inputs every codec must reject (Tests/BZip2Tests.swift:61-79, LzmaTests.swift:42-57, LZ4Tests.swift:87-108,
         # GzipTests.swift:174-188, XzTests.swift:112-120, ZlibTests.swift:45-57)
         "must_throw": {"empty": "", "single_zero": "00"},

@@ -45,6 +45,51 @@ def test_sixteen_threads_share_the_library():
     assert not errors, errors[:3]
 
 
+def test_sixteen_threads_every_codec():
+    """The same promise for the other entry points (BZip2.swift:22-26, LZMA.swift:25-34, LZ4.swift:73-91, XZArchive.swift:27-51
+    are as re-entrant as Deflate.decompress): sixteen threads, each walking through bzip2 / LZMA / LZMA2 / LZ4 / xz / zlib
+    single-shot calls on different inputs at the same time -- valid ones, and a damaged one per codec whose error must be the
+    right class."""
+    import lzma as pylzma
+    payloads = [corpus.p_mix(2500 + 6007 * i, 800 + i) for i in range(16)]
+    bz = [corpus.bzip2_stream(p) for p in payloads]
+    la = [corpus.lzma_alone(p) for p in payloads]
+    l2 = [corpus.lzma2_raw(p) for p in payloads]
+    db = corpus.lzma2_dict_byte(1 << 20)
+    l4 = [corpus.lz4_frame(p, block_size_code=4, content_checksum=True, xxh32=O.xxh32) for p in payloads]
+    xz = [corpus.xz_stream(p, check=pylzma.CHECK_SHA256 if i % 2 else pylzma.CHECK_CRC64) for i, p in enumerate(payloads)]
+    zl = [corpus.zlib_stream(p) for p in payloads]
+    for i, p in enumerate(payloads):   # the oracle first, single-threaded
+        assert O.bzip2(bz[i])[:2] == (0, p) and O.lzma2(l2[i], db)[:2] == (0, p) and O.lz4(l4[i])[:2] == (0, p)
+    errors = []
+
+    def worker(i):
+        try:
+            for rep in range(6):
+                j = (i + 3 * rep) % 16
+                assert swc.BZip2.decompress(bz[j]) == payloads[j]
+                assert swc.LZMA.decompress(la[j]) == payloads[j]
+                assert swc.LZMA2.decompress_raw(l2[j], db) == payloads[j]
+                assert swc.LZ4.decompress(l4[j]) == payloads[j]
+                assert swc.XZArchive.unarchive(xz[j]) == payloads[j]
+                assert swc.ZlibArchive.unarchive(zl[j]) == payloads[j]
+                with pytest.raises(swc.BZip2Error):
+                    swc.BZip2.decompress(bz[j][:-6] + bytes(6))          # stream CRC
+                with pytest.raises(swc.SWCError):
+                    swc.LZ4.decompress(l4[j][:len(l4[j]) // 2])
+                with pytest.raises(swc.SWCError):
+                    swc.XZArchive.unarchive(xz[j][:-9] + b"\0" + xz[j][-8:])
+        except BaseException as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(16)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:3]
+
+
 def test_one_large_unit_among_many_small_ones():
     """Workspace areas are sized per unit (prefix sums), not n x the largest capacity: 4,000 small streams and one of
     64 MiB decode in one call (n x 2.35 x 64 MiB would be more than half a terabyte)."""
