@@ -150,9 +150,12 @@ int swc_unarchive_many(int kind, const uint8_t* const* archives, const size_t* l
                        uint8_t** outs, size_t* out_lens, int32_t* statuses);
 /* The same over several GPUs of one node (the reference has no counterpart: its callers loop over archives on one core).
  * devices[0..n_devices) are HIP device ordinals (a device may be listed more than once); the archive list is cut into one
- * contiguous range per entry, balanced by compressed bytes, and every range is decoded on its device by its own host
- * thread.  The archives are independent, so there is no exchange between devices; results land at their archive's index
- * exactly as swc_unarchive_many returns them.  SWC_E_DEVICE if an ordinal does not name a gfx950 device. */
+ * contiguous range per entry, balanced by compressed + uncompressed bytes (the uncompressed size where the framing declares
+ * it -- gzip ISIZE, LZ4 content size -- else the compressed size again), and every range is decoded on its device by that
+ * device's worker thread (one per device for the life of the process: its stream and page-locked staging buffers are set up
+ * once).  The archives are independent, so there is no exchange between devices; results land at their archive's index
+ * exactly as swc_unarchive_many returns them.  SWC_E_DEVICE if an ordinal does not name a gfx950 device (the calling
+ * thread's own current device does not matter). */
 int swc_unarchive_many_devices(int kind, const uint8_t* const* archives, const size_t* lens, size_t n,
                                const int* devices, size_t n_devices, uint8_t** outs, size_t* out_lens, int32_t* statuses);
 

@@ -88,6 +88,10 @@ uint8_t* pinned_stage(int which, size_t n) {
     };
     static thread_local Buf bufs[2];
     Buf& b = bufs[which & 1];
+    if (which & 2) {   // trim request (pinned_trim)
+        if (b.cap > ((size_t)256 << 20)) { (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+        return nullptr;
+    }
     if (b.cap < n) {
         if (b.p) { (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
         size_t want = std::max<size_t>(n + n / 4, (size_t)1 << 20);
@@ -96,8 +100,19 @@ uint8_t* pinned_stage(int which, size_t n) {
     }
     return static_cast<uint8_t*>(b.p);
 }
+// A thread that staged a multi-gigabyte container once would hold that much page-locked memory until it ends: buffers above
+// the limit are released when the call that needed them is over (round-2 advisor).
+static void pinned_trim() {
+    for (int w = 0; w < 2; w++) (void)pinned_stage(w | 2, 0);
+}
 
+static int run_units_impl(int codec, std::vector<HostUnit>& units);
 int run_units(int codec, std::vector<HostUnit>& units) {
+    const int st = run_units_impl(codec, units);
+    pinned_trim();
+    return st;
+}
+static int run_units_impl(int codec, std::vector<HostUnit>& units) {
     if (!device_ready()) return SWC_E_DEVICE;
     const size_t n = units.size();
     if (n == 0) return SWC_OK;
@@ -106,6 +121,7 @@ int run_units(int codec, std::vector<HostUnit>& units) {
     for (size_t i = 0; i < n; i++) pending[i] = i;
     std::vector<size_t> cap(n);
     for (size_t i = 0; i < n; i++) cap[i] = default_cap(codec, units[i]);
+    std::vector<size_t> ws_extra(n, 0);   // Deflate / LZ4: record room beyond what the capacity implies (a unit that reported SWC_E_NEED_WORKSPACE)
 
     bool want_ws = codec == SWC_CODEC_BZIP2_BLOCK || codec == SWC_CODEC_DEFLATE || codec == SWC_CODEC_LZ4_BLOCK;  // LZMA: only after a unit reported SWC_E_NEED_WORKSPACE
     const bool per_job_ws = codec == SWC_CODEC_DEFLATE || codec == SWC_CODEC_LZ4_BLOCK;   // areas sized from each unit's own capacity
@@ -117,7 +133,10 @@ int run_units(int codec, std::vector<HostUnit>& units) {
         std::vector<size_t> deferred;
         if (want_ws && !per_job_ws && pending.size() > 1) {
             std::stable_sort(pending.begin(), pending.end(), [&](size_t a, size_t b) { return cap[a] < cap[b]; });
-            const size_t budget = (size_t)48 << 30;
+            // (what the device has free right now, not a constant: other threads and other entries of a device list launch too)
+            size_t free_b = 0, total_b = 0;
+            if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)16 << 30; }
+            const size_t budget = std::min<size_t>((size_t)48 << 30, free_b / 2);
             size_t take = 1;
             while (take < pending.size() && swc_batch_workspace_bytes(codec, take + 1, cap[pending[take]]) <= budget) take++;
             deferred.assign(pending.begin() + take, pending.end());
@@ -153,7 +172,7 @@ int run_units(int codec, std::vector<HostUnit>& units) {
         size_t ws_bytes = 0;
         if (want_ws && per_job_ws) {
             ws_off.resize(m + 1);
-            for (size_t k = 0; k < m; k++) { ws_off[k] = ws_bytes; ws_bytes += inflate_ws_bytes_per_job(cap[pending[k]]); }
+            for (size_t k = 0; k < m; k++) { ws_off[k] = ws_bytes; ws_bytes += inflate_ws_bytes_per_job(cap[pending[k]]) + ws_extra[pending[k]]; }
             ws_off[m] = ws_bytes;
         } else if (want_ws) {
             size_t mx = 0;
@@ -207,6 +226,14 @@ int run_units(int codec, std::vector<HostUnit>& units) {
             HostUnit& u = units[pending[k]];
             const Job& j = res[k];
             if (j.status == SWC_E_NEED_WORKSPACE && !want_ws) {
+                next.push_back(pending[k]);
+                continue;
+            }
+            if (j.status == SWC_E_NEED_WORKSPACE && per_job_ws && ws_extra[pending[k]] == 0) {
+                // The record list is sized from the capacity (one record per three output bytes and some); a stream can need
+                // more -- many tiny blocks, matches of the shortest codes.  Once more with room for a record per two input
+                // bits, which no stream exceeds (round-2 advisor: the internal status must not escape).
+                ws_extra[pending[k]] = ((u.in_len * 16 + ((size_t)64 << 10)) + 15) & ~(size_t)15;
                 next.push_back(pending[k]);
                 continue;
             }

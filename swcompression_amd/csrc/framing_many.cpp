@@ -9,6 +9,11 @@
 #include <algorithm>
 #include <memory>
 #include <thread>
+#include <mutex>
+#include <condition_variable>
+#include <deque>
+#include <functional>
+#include <map>
 #include <vector>
 #include "framing.h"
 
@@ -181,38 +186,93 @@ int swc_unarchive_many(int kind, const uint8_t* const* archives, const size_t* l
 }
 
 // swc_unarchive_many over several GPUs of one node: the archives are independent, so the list is cut into one contiguous
-// range per device, balanced by compressed bytes, and every range runs the single-device path on its own host thread with
-// its own device current (stream, staging buffers and workspace are per thread, api.cpp).  No data-path exchange between
-// devices: results are simply placed at their archive's index.
+// range per device, balanced by compressed + declared uncompressed bytes (sum(C + U); U where the framing
+// declares it -- the ISIZE of a gzip member, the content size of an LZ4 frame -- else C stands for both), and every range runs
+// the single-device path on that device's WORKER thread with the device current (stream, staging buffers and workspace are
+// per thread, api.cpp).  The workers live as long as the process, one per device ever named: a call does not pay for thread
+// start-up, and the page-locked staging buffers of a device are allocated once, not per call (round-2 review).  No
+// data-path exchange between devices: results are simply placed at their archive's index.
+namespace {
+struct DeviceWorker {
+    std::mutex m;
+    std::condition_variable cv;
+    std::deque<std::function<void()>> q;
+    explicit DeviceWorker(int device) {
+        std::thread([this, device] {
+            (void)hipSetDevice(device);
+            for (;;) {
+                std::function<void()> f;
+                {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [this] { return !q.empty(); });
+                    f = std::move(q.front());
+                    q.pop_front();
+                }
+                f();
+            }
+        }).detach();   // (ends with the process: a joinable static thread would have to outlive the HIP runtime's own teardown)
+    }
+    void post(std::function<void()> f) {
+        { std::lock_guard<std::mutex> lk(m); q.push_back(std::move(f)); }
+        cv.notify_one();
+    }
+};
+DeviceWorker& worker_of(int device) {
+    static std::mutex m;
+    static std::map<int, DeviceWorker*> pool;   // (never destroyed: see above)
+    std::lock_guard<std::mutex> lk(m);
+    auto it = pool.find(device);
+    if (it == pool.end()) it = pool.emplace(device, new DeviceWorker(device)).first;
+    return *it->second;
+}
+// the uncompressed size the framing declares, 0 if it declares none (or nonsense: a hint for the balance only)
+uint64_t declared_size(int kind, const uint8_t* p, size_t len) {
+    if (kind == 1 && len >= 18) return (uint64_t)p[len - 4] | ((uint64_t)p[len - 3] << 8) | ((uint64_t)p[len - 2] << 16) | ((uint64_t)p[len - 1] << 24);   // ISIZE (GzipArchive.swift:94)
+    if (kind == 4 && len >= 15 && p[0] == 0x04 && p[1] == 0x22 && p[2] == 0x4D && p[3] == 0x18 && (p[4] & 0x08)) {   // LZ4 frame with the content-size field (LZ4.swift:205-213)
+        uint64_t v = 0;
+        for (int i = 7; i >= 0; i--) v = (v << 8) | p[6 + i];
+        return v < ((uint64_t)1 << 40) ? v : 0;
+    }
+    return 0;
+}
+}  // namespace
+
 int swc_unarchive_many_devices(int kind, const uint8_t* const* archives, const size_t* lens, size_t n,
                                const int* devices, size_t n_devices, uint8_t** outs, size_t* out_lens, int32_t* statuses) try {
     if (kind < 1 || kind > 7 || (n && (!archives || !lens || !outs || !out_lens || !statuses)) || !devices || n_devices == 0)
         return SWC_E_INVALID_ARGUMENT;
     for (size_t i = 0; i < n; i++) if (lens[i] && !archives[i]) return SWC_E_INVALID_ARGUMENT;
-    if (!device_ready()) return SWC_E_DEVICE;
+    // only the LISTED devices matter (the calling thread's current device may be something else altogether)
     for (size_t d = 0; d < n_devices; d++) if (!device_is_gfx950(devices[d])) return SWC_E_DEVICE;
-    // contiguous ranges of (about) equal compressed bytes; +1 per archive so that empty inputs spread as well
+    // contiguous ranges of (about) equal cost C + U; +1 per archive so that empty inputs spread as well
     std::vector<size_t> cut(n_devices + 1, n);
     cut[0] = 0;
     {
+        std::vector<uint64_t> cost(n);
         unsigned __int128 total = 0;
-        for (size_t i = 0; i < n; i++) total += (unsigned __int128)lens[i] + 1;
+        for (size_t i = 0; i < n; i++) {
+            const uint64_t u = declared_size(kind, archives[i], lens[i]);
+            cost[i] = (uint64_t)lens[i] + (u ? u : (uint64_t)lens[i]) + 1;
+            total += cost[i];
+        }
         unsigned __int128 acc = 0;
         size_t d = 1;
         for (size_t i = 0; i < n && d < n_devices; i++) {
-            acc += (unsigned __int128)lens[i] + 1;
+            acc += cost[i];
             while (d < n_devices && acc * n_devices >= total * d) cut[d++] = i + 1;
         }
     }
     std::vector<Result> res(n);
     std::vector<int> st(n_devices, SWC_OK);
-    std::vector<std::thread> workers;
+    std::mutex done_m;
+    std::condition_variable done_cv;
+    size_t outstanding = 0;
     for (size_t d = 0; d < n_devices; d++) {
         const size_t lo = cut[d], hi = cut[d + 1];
         if (lo >= hi) continue;
-        workers.emplace_back([&, d, lo, hi] {
+        { std::lock_guard<std::mutex> lk(done_m); outstanding++; }
+        worker_of(devices[d]).post([&, d, lo, hi] {
             try {
-                if (hipSetDevice(devices[d]) != hipSuccess) { (void)hipGetLastError(); st[d] = SWC_E_DEVICE; return; }
                 std::vector<Result> part(hi - lo);
                 st[d] = many_dispatch(kind, archives + lo, lens + lo, hi - lo, part);
                 if (st[d] == SWC_OK)
@@ -220,9 +280,14 @@ int swc_unarchive_many_devices(int kind, const uint8_t* const* archives, const s
             } catch (...) {
                 st[d] = SWC_E_DEVICE;
             }
+            { std::lock_guard<std::mutex> lk(done_m); outstanding--; }
+            done_cv.notify_all();
         });
     }
-    for (std::thread& w : workers) w.join();
+    {   // (every posted task is waited for before anything of this frame goes away, whatever happened above)
+        std::unique_lock<std::mutex> lk(done_m);
+        done_cv.wait(lk, [&] { return outstanding == 0; });
+    }
     for (size_t d = 0; d < n_devices; d++) if (st[d]) return st[d];
     hand_over(res, outs, out_lens, statuses);
     return SWC_OK;

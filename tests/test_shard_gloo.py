@@ -94,3 +94,62 @@ def test_world2_gloo_shards_and_bookkeeping(with_error):
         sys.path.insert(0, ROOT)
         from swcompression_amd import corpus
         assert tot0 == sum(len(corpus.p_text(3000 + 517 * i, 40 + i)) for i in range(23)) + 999
+
+
+def _worker_few_units(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import _emu
+        from swcompression_amd import corpus
+        from swcompression_amd.shard import decode_sharded
+        # three units for four ranks, one of them carrying nearly all the bytes: at least one rank gets an EMPTY range
+        plains = [corpus.p_text(200, 1), corpus.p_text(90000, 2), corpus.p_text(300, 3)]
+        units = [corpus.deflate_raw(p) for p in plains]
+        caps = [len(p) for p in plains]
+
+        class R:
+            pass
+
+        def emu_decode(codec, u, c, **kw):
+            res = _emu.inflate(u, c)
+            r = R()
+            r.statuses = np.array([x[0] for x in res])
+            r.out_lens = np.array([x[3] for x in res])
+            r.outs = [x[1] for x in res]
+            return r
+
+        lo, hi, local, book = decode_sharded("deflate", units, caps, decode_fn=emu_decode)
+        outs = local.outs if local is not None else []
+        ok = all(outs[i] == plains[lo + i] for i in range(hi - lo))
+        q.put((rank, lo, hi, ok, book.bytes_per_rank, book.base, book.first_error_unit, book.error_status, book.total_bytes))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_world4_gloo_with_an_empty_range():
+    """Four ranks, three units: ranks with nothing to decode still take part in every bookkeeping collective, and everyone
+    ends up with the same table (bytes per rank, global output bases, no error)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_few_units, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=180) for _ in range(4))
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    ranges = [(lo, hi) for _, lo, hi, *_ in res]
+    assert ranges[0][0] == 0 and ranges[-1][1] == 3 and all(ranges[i][1] == ranges[i + 1][0] for i in range(3))
+    assert any(lo == hi for lo, hi in ranges)                          # somebody had nothing to do
+    assert all(r[3] for r in res)
+    tables = {(tuple(r[4]), tuple(r[5]), r[6], r[7], r[8]) for r in res}
+    assert len(tables) == 1
+    bpr, base, fe, es, tot = next(iter(tables))
+    assert tot == 200 + 90000 + 300 and fe is None and es == 0 and list(base) == [sum(bpr[:i]) for i in range(4)]
