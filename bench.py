@@ -43,11 +43,11 @@ WORKLOADS = {
     "lz4_4m": dict(codec="lz4_block", kind="lz4_block", parts=[("text", 192), ("mix", 64)], n_units=8192, unit=4 << 20,
                    desc="8192 x 4 MiB independent LZ4 blocks (BASELINE configs[2], resident micro-config of SURVEY 8d; 256 distinct: 192 P-text + 64 P-mix)",
                    kernels=["swc_lz4_lane_kernel", "swc_lz4_parse_kernel", "swc_lz4_resolve_kernel"], steps=3),
-    "bzip2_900k": dict(codec="bzip2_block", kind="bzip2", parts=[("text", 224), ("mix", 32)], n_units=10240, unit=899000,
-                       desc="10240 x 900 kB bzip2 blocks (BASELINE configs[3]; 256 distinct: 224 P-text + 32 P-mix)",
+    "bzip2_900k": dict(codec="bzip2_block", kind="bzip2", parts=[("text", 256)], n_units=10240, unit=899000,
+                       desc="10240 x 900 kB bzip2 blocks (BASELINE configs[3]; 256 distinct P-text payloads as SURVEY 8d states)",
                        kernels=["swc_bzip2_block_kernel", "swc_bzip2_expand_kernel", "swc_bzip2_crc_kernel"], steps=2),
-    "lzma2_256k": dict(codec="lzma2", kind="lzma2", parts=[("text", 224), ("mix", 32)], n_units=32768, unit=262144,
-                       desc="32768 x 256 KiB raw-LZMA2 units (BASELINE configs[4]; 256 distinct: 224 P-text + 32 P-mix)",
+    "lzma2_256k": dict(codec="lzma2", kind="lzma2", parts=[("text", 256)], n_units=32768, unit=262144,
+                       desc="32768 x 256 KiB raw-LZMA2 units (BASELINE configs[4]; 256 distinct P-text payloads as SURVEY 8d states)",
                        kernels=["swc_lzma_kernel"], steps=2),
 }
 PAYLOAD_NOTE = ("P-text = Zipf pseudo-words, P-mix = 4 KiB pieces of text / repeated phrase / uniform random bytes (the random pieces come out as "
@@ -138,6 +138,33 @@ def cpu_baseline(name, raw, plains, seconds):
             "compressed_MBps": cbytes / dt / 1e6}
 
 
+def host_cpus():
+    """What the box really grants this process: logical CPUs, the affinity mask, and the cgroup CPU quota (a container can
+    show 256 logical CPUs and be throttled to a dozen: the all-core line scales with the quota, not with the thread count)."""
+    info = {"logical": os.cpu_count() or 1}
+    try:
+        info["affinity"] = len(os.sched_getaffinity(0))
+    except (AttributeError, OSError):
+        info["affinity"] = info["logical"]
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = int(txt[0]) / int(txt[1])
+            else:
+                q = int(txt[0])
+                if q > 0:
+                    quota = q / int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read().split()[0])
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    info["cgroup_quota_cpus"] = quota
+    info["usable"] = int(min(info["affinity"], quota)) if quota else info["affinity"]
+    return info
+
+
 def cpu_context(name, raw, plains, seconds):
     """SURVEY.md 8(d) lines next to the single-thread baseline: `all_cores` = the oracle with one unit per task on every host
     thread of the box (oracle/rc_pool.c; the reference decodes one unit per call on one thread, so "all host cores" is one
@@ -152,7 +179,8 @@ def cpu_context(name, raw, plains, seconds):
     fn.restype = C.c_double
     fn.argtypes = [C.c_int, C.c_int, C.POINTER(C.c_char_p), C.POINTER(C.c_size_t), C.c_size_t, C.c_int, C.c_double,
                    C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
-    cores = os.cpu_count() or 1
+    cpus = host_cpus()
+    cores = cpus["affinity"]
     n = min(len(raw), 512)
     ins = (C.c_char_p * n)(*[bytes(r) for r in raw[:n]])
     lens = (C.c_size_t * n)(*[len(r) for r in raw[:n]])
@@ -160,8 +188,8 @@ def cpu_context(name, raw, plains, seconds):
     dt = fn(codec, aux, ins, lens, n, cores, seconds, C.byref(ob), C.byref(ib), C.byref(un))
     ctx = {}
     if dt > 0:
-        ctx["all_cores"] = {"value": ob.value / dt / 2**30, "unit": "GiB/s decompressed", "cores": cores, "kind": "port",
-                            "compressed_MBps": ib.value / dt / 1e6,
+        ctx["all_cores"] = {"value": ob.value / dt / 2**30, "unit": "GiB/s decompressed", "cores": cpus["usable"], "threads": cores, "host_cpus": cpus,
+                            "kind": "port", "compressed_MBps": ib.value / dt / 1e6,
                             "sample": "%d unit decodes in %.1f s, one unit per task over %d threads (oracle/rc_pool.c)" % (un.value, dt, cores)}
     import bz2
     import lzma

@@ -69,7 +69,7 @@ def test_sixteen_threads_every_codec():
                 j = (i + 3 * rep) % 16
                 assert swc.BZip2.decompress(bz[j]) == payloads[j]
                 assert swc.LZMA.decompress(la[j]) == payloads[j]
-                assert swc.LZMA2.decompress_raw(l2[j], db) == payloads[j]
+                assert swc.LZMA2.decompress_raw(l2[j], db) == (payloads[j], len(l2[j]))
                 assert swc.LZ4.decompress(l4[j]) == payloads[j]
                 assert swc.XZArchive.unarchive(xz[j]) == payloads[j]
                 assert swc.ZlibArchive.unarchive(zl[j]) == payloads[j]
