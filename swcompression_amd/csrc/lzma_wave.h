@@ -70,9 +70,32 @@ struct Decoder {
     bool overflow;              // out_cap exhausted: LZMA needs the bytes it wrote, so decoding stops
     bool need_ws;               // lc+lp > 4 but no HBM workspace was supplied
 
+    // The next 256 input bytes sit in a register spread over the lanes (lane i: the dword at win_base + 4 i): the range coder
+    // takes a byte about once per four output bytes, and a global load in its serial chain costs the wave a memory round trip
+    // each time.  One coalesced load refills the window every 256 bytes.  (Host build, WAVE = 1: plain reads.)
+    uint64_t win_base;          // input offset of lane 0's dword (a multiple of 4); ~0: no window loaded
+    uint32_t win;               // this lane's dword
+    uint32_t prev_byte;         // out[pos - 1] (0 when the dictionary is empty): the literal coder's context, kept in a register
+    SWC_HD void win_load(uint64_t at) {
+        win_base = at & ~(uint64_t)3;
+        const uint64_t o = win_base + 4ull * (uint32_t)lane;
+        uint32_t w = 0;
+        if (o + 4 <= n) w = load_u32(in + o);
+        else for (uint32_t k = 0; k < 4; k++) if (o + k < n) w |= (uint32_t)in[o + k] << (8 * k);
+        win = w;
+    }
     SWC_HD uint8_t next_byte() {  // LittleEndianByteReader.byte(): past the end is a trap (App. A L4)
         if (ip >= n) { trap = true; return 0; }
-        return in[ip++];
+        if (WAVE == 1) return in[ip++];
+        if (ip - win_base >= 4ull * WAVE) win_load(ip);
+        const uint32_t k = (uint32_t)(ip - win_base);
+        ip++;
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)win, __builtin_amdgcn_readfirstlane((int)(k >> 2)));   // (the index is the same in every lane: said so, or the compiler loops over the lanes)
+#else
+        const uint32_t w = win;
+#endif
+        return (uint8_t)(w >> (8 * (k & 3u)));
     }
     SWC_HD void normalize() {     // LZMARangeDecoder.swift:38-43
         if (range < (1u << 24)) {
@@ -80,8 +103,10 @@ struct Decoder {
             code = (code << 8) | next_byte();
         }
     }
-    SWC_HD int bit(uint16_t* p) {  // LZMARangeDecoder.swift:65-80
-        uint32_t pr = *p;
+    SWC_HD int bit(uint16_t* p) { return bit_with(*p, p); }
+    // The decision with the cell's value already in hand: walking a bit tree, the two cells the NEXT decision can use are
+    // read while this one is computed (tree(), the literal loops), so that the LDS latency leaves the serial chain.
+    SWC_HD int bit_with(uint32_t pr, uint16_t* p) {  // LZMARangeDecoder.swift:65-80
         uint32_t bound = (range >> 11) * pr;
         int sym;
         if (code < bound) {
@@ -129,7 +154,14 @@ struct Decoder {
     }
     SWC_HD int tree(uint16_t* p, int nbits) {  // LZMABitTreeDecoder.swift:18-24
         int m = 1;
-        for (int i = 0; i < nbits; i++) m = (m << 1) + bit(&p[m]);
+        uint32_t pr = p[1];
+        for (int i = 0; i < nbits; i++) {
+            uint32_t p0 = 0, p1 = 0;
+            if (i + 1 < nbits) { p0 = p[2 * m]; p1 = p[2 * m + 1]; }   // both children, before the decision that picks one
+            const int b = bit_with(pr, &p[m]);
+            pr = b ? p1 : p0;
+            m = (m << 1) + b;
+        }
         return m - (1 << nbits);
     }
     SWC_HD int tree_reverse(uint16_t* p, int limit, int start, int bits) {  // :26-43
@@ -170,6 +202,7 @@ struct Decoder {
     SWC_HD void put(uint8_t b) {
         if (pos < cap) { if (lane == 0) out[pos] = b; }
         else overflow = true;
+        prev_byte = b;
         pos++;
         if (pos - dict_start == dict_size) dict_start++;
     }
@@ -185,12 +218,18 @@ struct Decoder {
     SWC_HD void copy_match(uint64_t distance, uint32_t len) {
         if (pos + len <= cap) {
             gptr dst = out + pos;
+            uint32_t last = 0;   // the byte this lane wrote last: the lane that wrote dst[len - 1] holds the new prev_byte
             if (distance >= len) {
-                for (uint32_t i = (uint32_t)lane; i < len; i += WAVE) dst[i] = dst[(int64_t)i - (int64_t)distance];
+                for (uint32_t i = (uint32_t)lane; i < len; i += WAVE) { last = dst[(int64_t)i - (int64_t)distance]; dst[i] = (uint8_t)last; }
             } else {
                 // overlapping: every byte is a copy of one of the `distance` bytes before `pos`
-                for (uint32_t i = (uint32_t)lane; i < len; i += WAVE) dst[i] = dst[(int64_t)(i % (uint32_t)distance) - (int64_t)distance];
+                for (uint32_t i = (uint32_t)lane; i < len; i += WAVE) { last = dst[(int64_t)(i % (uint32_t)distance) - (int64_t)distance]; dst[i] = (uint8_t)last; }
             }
+#if defined(__HIP_DEVICE_COMPILE__)
+            prev_byte = (uint32_t)__builtin_amdgcn_readlane((int)last, __builtin_amdgcn_readfirstlane((int)((len - 1u) % (uint32_t)WAVE)));
+#else
+            prev_byte = last;
+#endif
         } else {
             overflow = true;
         }
@@ -220,23 +259,40 @@ struct Decoder {
             if (bit(&probs[P_IS_MATCH + (state << 4) + pos_state]) == 0) {
                 if (trap) return SWC_E_REF_TRAP;
                 if (uncompressed_size == 0) return SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :121
-                const uint32_t prev = pos == dict_start ? 0u : byte_at(1);
+                const uint32_t prev = pos == dict_start ? 0u : prev_byte;
                 const uint32_t lit_state = (uint32_t)(((pos & ((1u << lp) - 1)) << lc) + (prev >> (8 - lc)));
                 int symbol = 1;
                 if (!spill) {
                     uint16_t* lpb = &probs[P_LITERAL + lit_state * 0x300];
+                    uint32_t pr;
                     if (state >= 7) {
                         uint32_t match_byte = byte_at(rep0 + 1);
                         if (trap) return SWC_E_REF_TRAP;
+                        int match_bit = (match_byte >> 7) & 1;
+                        pr = lpb[((1 + match_bit) << 8) + symbol];
+                        bool matched = true;
                         do {
-                            const int match_bit = (match_byte >> 7) & 1;
                             match_byte = (match_byte << 1) & 0xFF;
-                            const int b = bit(&lpb[((1 + match_bit) << 8) + symbol]);
+                            const int next_mb = (match_byte >> 7) & 1;
+                            // the cell of the next decision, for either outcome of this one: bit == match bit stays in the
+                            // matched coder (with the next match bit), the other outcome falls to the plain coder
+                            const uint32_t same = lpb[((1 + next_mb) << 8) + (((symbol << 1) | match_bit) & 0xFF)];   // (& 0xFF: the last level reads a cell it does not use)
+                            const uint32_t diff = lpb[(symbol << 1) | (match_bit ^ 1)];
+                            const int b = bit_with(pr, &lpb[((1 + match_bit) << 8) + symbol]);
                             symbol = (symbol << 1) | b;
-                            if (match_bit != b) break;
-                        } while (symbol < 0x100);
+                            matched = match_bit == b;
+                            pr = matched ? same : diff;
+                            match_bit = next_mb;
+                        } while (matched && symbol < 0x100);
+                    } else {
+                        pr = lpb[symbol];
                     }
-                    while (symbol < 0x100) symbol = (symbol << 1) | bit(&lpb[symbol]);
+                    while (symbol < 0x100) {
+                        const uint32_t p0 = lpb[(symbol << 1) & 0x1FF], p1 = lpb[((symbol << 1) | 1) & 0x1FF];   // (& 0x1FF: the last level reads cells it does not use)
+                        const int b = bit_with(pr, &lpb[symbol]);
+                        pr = b ? p1 : p0;
+                        symbol = (symbol << 1) | b;
+                    }
                 } else {
                     SWC_AS_GLOBAL uint16_t* lpb = lit_spill + (size_t)lit_state * 0x300;
                     if (state >= 7) {
@@ -352,6 +408,7 @@ struct Decoder {
                 if (n - ip < size) return SWC_E_REF_TRAP;                // byte() past the end inside the copy loop
                 if (pos + size <= cap) {
                     for (uint64_t i = (uint64_t)lane; i < size; i += WAVE) out[pos + i] = in[ip + i];
+                    prev_byte = in[ip + size - 1];
                 } else {
                     overflow = true;
                 }
@@ -405,6 +462,7 @@ SWC_HD void lzma_job(Job& job, bool is_lzma2, uint16_t* probs, SWC_AS_GLOBAL uin
     d.rep0 = d.rep1 = d.rep2 = d.rep3 = 0;
     d.state = 0;
     d.trap = false; d.overflow = false; d.need_ws = false;
+    d.win_base = ~(uint64_t)0 - 4096; d.win = 0; d.prev_byte = 0;
     int st;
     if (is_lzma2) {
         st = d.decode_lzma2((uint8_t)job.aux);
