@@ -116,9 +116,10 @@ hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStr
 
 // ---- LZ4 -------------------------------------------------------------------------------------------------
 // Blocks without a dictionary prefix take the two-phase path: one block per wavefront for the sequence parse
-// (lz4_wave.h), then the LZ77 resolve kernel of lz_resolve.h with a 64 KiB history (one block per 1024-thread
-// workgroup, 96 KiB LDS window).  Blocks with a dictionary prefix (dependent frames, external dictionaries)
-// stay on the one-block-per-lane decoder (lz4_lane.h).  Each kernel skips the jobs of the other kind.
+// (lz4_wave.h), then the LZ77 resolve kernel of lz_resolve.h in the Deflate configuration (one block per 512-thread
+// workgroup, 64 KiB ring with 32 KiB of history, two workgroups per CU; match bytes from further back come from the
+// output buffer).  Blocks with a dictionary prefix (dependent frames, external dictionaries) stay on the
+// one-block-per-lane decoder (lz4_lane.h).  Each kernel skips the jobs of the other kind.
 __global__ __launch_bounds__(64) void swc_lz4_lane_kernel(Job* __restrict__ jobs, uint32_t n, int only_dict) {
     uint32_t g = blockIdx.x * kWave + threadIdx.x;
     if (g >= n) return;
@@ -150,7 +151,7 @@ __global__ __launch_bounds__(lz4w::kResolveThreads) void swc_lz4_resolve_kernel(
     if (g >= n) return;
     Job job = jobs[g];
     if (job.dict != nullptr) return;
-    lzr::resolve_job<lz4w::kResolveThreads, lz4w::kRingLog2, lz4w::kKeep>(job, wm.area(g), wm.bytes(g), &lds);
+    lzr::resolve_job<lz4w::kResolveThreads, lz4w::kRingLog2, lz4w::kKeep, true>(job, wm.area(g), wm.bytes(g), &lds);
 }
 
 size_t lz4_ws_bytes_per_job(uint64_t cap) { return lzr::ws_bytes_per_job(cap); }

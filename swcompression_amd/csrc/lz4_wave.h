@@ -35,9 +35,14 @@
 namespace swc {
 namespace lz4w {
 
-constexpr uint32_t kKeep = 65536;    // LZ4 offsets reach 65,535 bytes back
-constexpr int kRingLog2 = 17;        // LDS ring of the resolve kernel: history + one batch span + its cells
-constexpr int kResolveThreads = 1024;
+// The resolve kernel runs LZ4 blocks in the configuration of the Deflate path -- 512 threads, a 64 KiB ring with 32 KiB of
+// history, two workgroups per CU -- although LZ4 offsets reach 65,535 bytes back: the few match bytes whose source is older
+// than the ring's history (3 % on text) are read from the output buffer (lz_resolve.h: FAR).  A ring with the whole 64 KiB
+// of history needs 128 KiB of LDS: one workgroup per CU, nothing to run while it waits at a barrier (round 2: half the
+// per-byte speed of the Deflate resolve).
+constexpr uint32_t kKeep = 32768;
+constexpr int kRingLog2 = 16;
+constexpr int kResolveThreads = 512;
 constexpr uint32_t kRecBuf = 256;    // records the checked step stages in LDS between flushes
 constexpr uint32_t kLitStage = 1024; // literal bytes likewise
 constexpr uint32_t kInWin = 1024;    // input window of the checked step in LDS

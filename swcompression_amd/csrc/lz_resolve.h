@@ -90,16 +90,10 @@ struct Lds {
     alignas(8) uint64_t rec8[kRpt * T + 18];                      // per record, in CELL indices (span-relative + off): mstart | thr << 16 | distance << 32 | litkey << 48 (see R1)
     uint32_t slotw[T + 1];                                 // per 16-cell slot: record that covers its first in-span cell | record-start flags of its cells << 16
     uint32_t wave_sum[2 * (T / 64) + 2];
-    uint32_t ntake, span, litspan, overlap;
+    uint32_t ntake, span, litspan, overlap, nfar;
 };
 
-#ifndef SWC_RESOLVE_EARLY
-#define SWC_RESOLVE_EARLY 0
-#endif
-#if defined(SWC_HOST_EMULATION)
-inline uint64_t g_resolve_stats[4];   // dwords of all spans, dwords whose four cells are values after the expansion
-#endif
-template <int T, int RING_LOG2, uint32_t KEEP>
+template <int T, int RING_LOG2, uint32_t KEEP, bool FAR = false>
 struct Resolver {
     using L = Lds<T, RING_LOG2>;
     static constexpr uint32_t kRing = L::kRing, kMask = kRing - 1u, kLitWin = L::kLitWin, kLitMask = kLitWin - 1u, kRpt = L::kRpt;
@@ -156,15 +150,24 @@ struct Resolver {
     // ---- R2, one aligned DWORD (four cells) per thread and step.  Everything is a select over precomputed per-record geometry
     // (rec8): which record (the slot word, read once for the four cells, + a popcount each), literal or match (ci < mstart), the
     // ONE LDS byte read per cell (literal window or ring), value or source index (ci >= thr).  The trip count is the same for
-    // every thread (cells past the span get harmless garbage), so the loop has no per-thread exit.  A dword whose four cells are
-    // values at once -- literals, match bytes from before the span -- leaves for the ring and for HBM right here and is marked
-    // (kCellDone in its first cell): R3 only looks at it.  OVERLAP: the batch holds a match that overlaps itself (length >
-    // distance): such bytes are reduced to their first period so that chains stay short (one division per cell in this variant
-    // only).  early_lim: dwords [4, early_lim) may leave early (whole dwords of the span below the output limit; the first four
-    // may hold cells of earlier batches, which are set after the loop).
-    static constexpr uint32_t kCellDone = 0x4000u;
+    // every thread (cells past the span get harmless garbage), so the loop has no per-thread exit.  OVERLAP: the batch holds a
+    // match that overlaps itself (length > distance): such bytes are reduced to their first period so that chains stay short
+    // (one division per cell in this variant only).  FAR (LZ4: offsets reach 65,535 bytes back, the ring keeps KEEP = 32 KiB so
+    // that two workgroups fit a CU): a match byte whose source lies in front of the ring's history goes onto the FAR LIST and
+    // gets its value from the output buffer in HBM after the loop (expand_far) -- 3 % of the match bytes of text.
+    struct FarEntry { uint32_t ci; int32_t x; };
+    static constexpr uint32_t kFarOff = kCellOff + 32u * T;                        // the list lives in the stale part of the ring behind the cells
+    static constexpr uint32_t kFarCap = (kRing - KEEP - (48u * T + 16u)) / 8u;
+    SWC_D FarEntry* far_ptr(uint32_t v0, uint32_t i) const { return (FarEntry*)(l->ring + ((v0 + kFarOff + 8u * i) & kMask)); }
+    SWC_D static uint32_t lds_inc(uint32_t* p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        return (*p)++;
+#endif
+    }
     template <bool OVERLAP>
-    SWC_D void expand_cells(int t, uint32_t ncell, uint32_t off, uint32_t v0, uint32_t cbase, uint32_t lb, uint32_t early_lim, gptr obase) const {
+    SWC_D void expand_cells(int t, uint32_t ncell, uint32_t off, uint32_t v0, uint32_t cbase, gcptr obase) const {
         const uint8_t* lds0 = l->ring;                      // litbuf == ring + kRing (struct layout, asserted above)
         const uint32_t jb = 4u * ((uint32_t)t & 3u);
         uint32_t m_rest[4], m[4];
@@ -196,30 +199,34 @@ struct Resolver {
                     inspan = !is_lit && (int32_t)x >= (int32_t)off;
                 }
                 const uint32_t a_lit = kRing + ((ci + lkey) & kLitMask), a_ring = (v0 + x) & kMask;
-                const uint32_t byte = lds0[is_lit ? a_lit : a_ring];
+                uint32_t byte = lds0[is_lit ? a_lit : a_ring];
+                if (FAR) {
+                    if (!is_lit && (int32_t)x < -(int32_t)KEEP && ci < ncell) {   // the source is older than the ring's history
+                        const uint32_t slot = lds_inc(&l->nfar);
+                        if (slot < kFarCap) *far_ptr(v0, slot) = FarEntry{ci, (int32_t)x};
+                        else byte = obase[(int64_t)(int32_t)x];             // (a batch of nothing but far matches: read it here and now)
+                    }
+                }
                 cell[c] = inspan ? x : 0x8000u | byte;
-            }
-            const bool early = SWC_RESOLVE_EARLY && ((cell[0] & cell[1] & cell[2] & cell[3]) & 0x8000u) != 0u && q >= 4u && q < early_lim;
-#if defined(SWC_HOST_EMULATION)
-            if (q < (ncell >> 2)) { g_resolve_stats[0]++; g_resolve_stats[1] += early ? 1 : 0; }
-#endif
-            if (early) {
-                const uint32_t word = (cell[0] & 0xFFu) | ((cell[1] & 0xFFu) << 8) | ((cell[2] & 0xFFu) << 16) | ((cell[3] & 0xFFu) << 24);
-                *(uint32_t*)(l->ring + ((v0 + 4u * q) & kMask)) = word;
-                *(SWC_AS_GLOBAL uint32_t*)(obase + (size_t)(4u * q)) = word;
-                cell[0] |= kCellDone;
             }
             *(uint64_t*)(l->ring + ((cbase + 8u * q) & kMask)) = (uint64_t)cell[0] | ((uint64_t)cell[1] << 16) | ((uint64_t)cell[2] << 32) | ((uint64_t)cell[3] << 48);
         }
         // cells of slot 0 in front of the span belong to earlier batches: final bytes of the ring (written after the loop: the
-        // loop left garbage there)
-        // (by the thread that wrote the dword in the loop: its own LDS accesses stay in order)
+        // loop left garbage there; by the thread that wrote the dword in the loop: its own LDS accesses stay in order)
         if ((uint32_t)t < 4u) {
 #pragma unroll
             for (uint32_t c = 0; c < 4; c++) {
                 const uint32_t ci = 4u * (uint32_t)t + c;
                 if (ci < off) cell_store(l->ring, cbase, ci, 0x8000u | lds0[(v0 + ci) & kMask]);
             }
+        }
+    }
+    // The far list: every entry's byte from the output written by earlier batches (all of their stores have completed: the
+    // caller waited), into its cell as a value.
+    SWC_D void expand_far(int t, uint32_t nfar, uint32_t v0, uint32_t cbase, gcptr obase) const {
+        for (uint32_t e = (uint32_t)t; e < nfar; e += (uint32_t)T) {
+            const FarEntry f = *far_ptr(v0, e);
+            cell_store(l->ring, cbase, f.ci, 0x8000u | (uint32_t)obase[(int64_t)f.x]);
         }
     }
 
@@ -272,7 +279,7 @@ struct Resolver {
                 }
                 x[t] = xs;
                 y[t] = ys;
-                if (t == 0) l->overlap = 0;
+                if (t == 0) { l->overlap = 0; l->nfar = 0; }
             SIMT_END
             simt::group_scan2_incl<T>(x, y, l->wave_sum);       // (barrier A inside)
             SWC_RP(0)
@@ -327,7 +334,6 @@ struct Resolver {
             const uint64_t room = (int64_t)limit > base64 ? (uint64_t)((int64_t)limit - base64) : 0u;
             const uint32_t qlim = room >= 0x100000000ull ? 0x40000000u : (uint32_t)room >> 2;
             gptr obase = (gptr)((SWC_AS_GLOBAL uint8_t*)out + base64);
-            const uint32_t early_lim = nfull < qlim ? nfull : qlim;
             // ---- R2: prefetch for the next batch, then the cells
             SIMT_BEGIN(t, T)
                 {
@@ -339,9 +345,20 @@ struct Resolver {
                     lit_pf_at[t] = want ? (uint32_t)o : 0xFFFFFFFFu;
                     if (want) lit_pf[t] = load_16(lits + o);
                 }
-                if (overlap) expand_cells<true>(t, ncell, off, v0, cbase, lbk, early_lim, obase);
-                else expand_cells<false>(t, ncell, off, v0, cbase, lbk, early_lim, obase);
-            SIMT_END_BARRIER                                     // barrier C
+                if (overlap) expand_cells<true>(t, ncell, off, v0, cbase, (gcptr)obase);
+                else expand_cells<false>(t, ncell, off, v0, cbase, (gcptr)obase);
+            SIMT_END_BARRIER                                     // barrier C (FAR: the list is complete; else: the cells are)
+            if (FAR) {
+                const uint32_t nfar = simt::uniform(l->nfar);
+                if (nfar) {   // (same in every thread)
+                    // the sources were written by earlier batches of THIS workgroup, at least KEEP bytes ago, with plain stores by
+                    // any of its threads: every thread waits for its own stores, the barrier makes that all of them
+                    SIMT_BEGIN(t, T) (void)t; SIMT_END_SYNC
+                    SIMT_BEGIN(t, T)
+                        expand_far(t, nfar < kFarCap ? nfar : kFarCap, v0, cbase, (gcptr)obase);
+                    SIMT_END_BARRIER
+                }
+            }
             SWC_RP(2)
             // ---- R3: one aligned DWORD per thread and step: chase what is unresolved, then the dword leaves for the ring and for HBM
             SIMT_BEGIN(t, T)
@@ -350,7 +367,6 @@ struct Resolver {
                 for (uint32_t q = (uint32_t)t; q < nfull; q += (uint32_t)T) {
                     const uint32_t ca = (cbase + 8u * q) & kMask;
                     const uint64_t c4 = *(const uint64_t*)(l->ring + ca);
-                    if (((uint32_t)c4 & (0x8000u | kCellDone)) == (0x8000u | kCellDone)) continue;   // left in R2 (a value with the mark)
                     uint32_t c[4];
 #pragma unroll
                     for (int e = 0; e < 4; e++) c[e] = (uint32_t)(c4 >> (16 * e)) & 0xFFFFu;
@@ -423,12 +439,12 @@ struct Resolver {
 };
 
 // One job: `ws` is the stream's workspace area of `area` bytes written by phase 1.
-template <int T, int RING_LOG2, uint32_t KEEP>
+template <int T, int RING_LOG2, uint32_t KEEP, bool FAR = false>
 SWC_D void resolve_job(const Job& job, const uint8_t* ws, size_t area, Lds<T, RING_LOG2>* lds, uint64_t* prof = nullptr) {
     const SWC_AS_GLOBAL StreamHeader* h = (const SWC_AS_GLOBAL StreamHeader*)ws;
     const size_t lo = lit_offset(area, job.out_cap);
     if (lo == 0) return;   // no literal stream: phase 1 reported SWC_E_NEED_WORKSPACE for this job
-    Resolver<T, RING_LOG2, KEEP> rs;
+    Resolver<T, RING_LOG2, KEEP, FAR> rs;
     rs.l = lds;
     rs.out = (gptr)job.out;
     rs.lits = (gcptr)ws + lo;

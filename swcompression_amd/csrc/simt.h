@@ -49,6 +49,9 @@ SWC_D void wave_fence() {
 #define SIMT_END }
 #define SIMT_END_BARRIER } ::swc::simt::lds_barrier();
 #define SIMT_END_WAVE } ::swc::simt::wave_fence();
+// closes a region after which the threads of the group read GLOBAL memory that others of them wrote: all of the thread's
+// memory operations done, then the workgroup barrier (the LDS-only barrier above leaves global stores in flight on purpose)
+#define SIMT_END_SYNC } __syncthreads();
 
 #else
 
@@ -70,6 +73,7 @@ inline int order(int i, int n) {
 #define SIMT_END }
 #define SIMT_END_BARRIER }
 #define SIMT_END_WAVE }
+#define SIMT_END_SYNC }
 
 #endif
 

@@ -33,7 +33,6 @@ extern "C" void emu_inflate_sync(swc::Job* jobs, size_t n) {
 extern "C" void emu_lz4_stats(uint64_t* out, int reset) {
     for (int i = 0; i < 8; i++) { out[i] = swc::lz4w::g_lz4_stats[i]; if (reset) swc::lz4w::g_lz4_stats[i] = 0; }
 }
-extern "C" void emu_resolve_stats(uint64_t* out) { for (int i = 0; i < 4; i++) { out[i] = swc::lzr::g_resolve_stats[i]; swc::lzr::g_resolve_stats[i] = 0; } }
 extern "C" void emu_sync_wave(uint64_t* out) { for (int i = 0; i < 4; i++) { out[i] = swc::inflate::g_sync_wave[i]; swc::inflate::g_sync_wave[i] = 0; } }
 extern "C" void emu_sync_stats(uint64_t* out, int reset) {
     for (int i = 0; i < 8; i++) { out[i] = swc::inflate::g_sync_stats[i]; if (reset) swc::inflate::g_sync_stats[i] = 0; }
@@ -51,7 +50,7 @@ extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {
         std::memset(stage, 0xEE, sizeof stage);
         swc::lz4w::lz4_parse_job<1>(jobs[g], ws.data(), wsb, 0, stage);
         std::memset(&rl, 0xEE, sizeof rl);
-        swc::lzr::resolve_job<swc::lz4w::kResolveThreads, swc::lz4w::kRingLog2, swc::lz4w::kKeep>(jobs[g], ws.data(), wsb, &rl);
+        swc::lzr::resolve_job<swc::lz4w::kResolveThreads, swc::lz4w::kRingLog2, swc::lz4w::kKeep, true>(jobs[g], ws.data(), wsb, &rl);
     }
 }
 

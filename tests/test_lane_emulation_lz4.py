@@ -75,3 +75,43 @@ def test_large_blocks_sub_chunk_rounds(order):
         if e[0] == 0:
             assert r[1] == e[1] and r[2] == len(cases[i]), "case %d" % i
     O.lib.refcpu_set_max_output(1 << 30)
+
+
+@pytest.mark.parametrize("order", [0, 2])
+def test_matches_older_than_the_ring_history(order):
+    """The resolve kernel keeps 32 KiB of history in LDS; LZ4 offsets reach 65,535 bytes back.  Match bytes whose source is
+    older than the ring's history take the far path of lz_resolve.h (the output buffer): some of them among near ones
+    (the far list), whole batches of nothing else (the list overflows: read in place), sources that straddle the
+    32 KiB line, and far matches that overlap a span's own output."""
+    from swcompression_amd import corpus
+    rnd = random.Random(77)
+    a = corpus.p_rand(40000, 1)
+    b = corpus.p_rand(21000, 2)
+    t = corpus.p_text(50000, 3)
+    payloads = [
+        a + b + a,                                   # one giant match 61,000 back: 40,000 far bytes in a row
+        a + t + a[:500] + t[:30000] + a[10000:10400],    # far matches among near ones
+        a[:33000] + a[:33000] + a[:33000],           # distance 33,000: just past the history, back to back
+        t + a[:32700] + t[:5000] + a[100:9000],      # sources on both sides of the 32 KiB line
+    ]
+    for k in range(6):                               # random mixtures of near and far copies
+        parts = [corpus.p_rand(rnd.randrange(1000, 50000), 10 + k)]
+        for _ in range(12):
+            src = b"".join(parts)
+            if rnd.random() < 0.5 and len(src) > 200:
+                back = rnd.randrange(100, min(len(src), 65000))
+                ln = rnd.randrange(4, min(back, 3000) + 1)
+                parts.append(src[len(src) - back:len(src) - back + ln])
+            else:
+                parts.append(corpus.p_text(rnd.randrange(10, 4000), 100 + k))
+        payloads.append(b"".join(parts))
+    blocks = [corpus.lz4_block(p) for p in payloads]
+    exp = [O.lz4_block(z) for z in blocks]
+    assert all(e[:2] == (0, p) for e, p in zip(exp, payloads))
+    E.set_order(order)
+    try:
+        res = E.lz4_block(blocks, [len(p) for p in payloads], misalign=order)
+    finally:
+        E.set_order(0)
+    for i, (r, p) in enumerate(zip(res, payloads)):
+        assert r[0] == 0 and r[1] == p and r[2] == len(blocks[i]), "payload %d" % i
