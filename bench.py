@@ -67,14 +67,17 @@ def parse_args():
     ap.add_argument("--streamed-only", action="store_true", help="only the streamed configs[2] mode (waves through pinned host buffers)")
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     ap.add_argument("--tuning", action="append", default=[], help="key=value for swc_set_tuning (comparison runs only)")
+    ap.add_argument("--parts", default=None, help="payload classes of the distinct units, e.g. text:256 or text:192,mix:64 (comparison runs only; "
+                                                    "the default is the workload's own mixture)")
     ap.add_argument("--rehearse-on-one-gpu", action="store_true",
                     help="multi-rank REHEARSAL on a box with one GPU: all ranks share cuda:0 and the bookkeeping collectives run over gloo "
                          "(exercises sharding, barriers and the max-over-ranks clock; the figure it prints is not a scaling result)")
     return ap.parse_args()
 
 
-def scaled_parts(w, scale):
-    return [(cls, max(2, int(n * scale))) for cls, n in w["parts"]] if scale != 1.0 else list(w["parts"])
+def scaled_parts(w, scale, override=None):
+    parts = [(c, int(k)) for c, k in (x.split(":") for x in override.split(","))] if override else list(w["parts"])
+    return [(cls, max(2, int(n * scale))) for cls, n in parts] if scale != 1.0 else parts
 
 
 def make_batch(name, w, parts, seed, device, select):
@@ -301,7 +304,7 @@ def verify_all_units(name, batch, raw, plains, trailers):
 
 def run_workload(name, args, lib, torch, dist, world, rank, device, steps, warmup, with_cpu):
     w = WORKLOADS[name]
-    parts = scaled_parts(w, args.scale)
+    parts = scaled_parts(w, args.scale, args.parts if name == args.workload else None)
     n_distinct = sum(n for _, n in parts)
     n_total = w["n_units"] if args.scale == 1.0 else max(n_distinct, int(w["n_units"] * args.scale))
     if args.scaling == "strong" and world > 1:
@@ -398,6 +401,8 @@ def run_workload(name, args, lib, torch, dist, world, rank, device, steps, warmu
     achieved = (sum_c + sum_u) / (mean_ms * 1e-3) / 1e9
     traffic, traffic_src, l2 = committed_traffic(name)
     desc = w["desc"] if args.scale == 1.0 else w["desc"] + " (scaled x%g, not a headline run)" % args.scale
+    if args.parts and name == args.workload:
+        desc += " (payload classes overridden: %s)" % args.parts
     roof = {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
             "traffic": traffic, "traffic_source": traffic_src, "l2_hit_rate": l2,
             "kernel": " + ".join(w["kernels"] + (["swc_crc32_kernel"] if gzip_crc else [])), "kernel_ms": mean_ms,

@@ -90,13 +90,14 @@ struct Lds {
     alignas(8) uint64_t rec8[kRpt * T + 18];                      // per record, in CELL indices (span-relative + off): mstart | thr << 16 | distance << 32 | litkey << 48 (see R1)
     uint32_t slotw[T + 1];                                 // per 16-cell slot: record that covers its first in-span cell | record-start flags of its cells << 16
     uint32_t wave_sum[2 * (T / 64) + 2];
-    uint32_t ntake, span, litspan, overlap, nfar;
+    uint32_t ntake, span, litspan, overlap, nfar, first_rec, nbig, bigbytes;
 };
 
 template <int T, int RING_LOG2, uint32_t KEEP, bool FAR = false>
 struct Resolver {
     using L = Lds<T, RING_LOG2>;
     static constexpr uint32_t kRing = L::kRing, kMask = kRing - 1u, kLitWin = L::kLitWin, kLitMask = kLitWin - 1u, kRpt = L::kRpt;
+    static constexpr uint32_t kBigLit = 1024;             // a literal-only record of at least this many bytes opens a run that is copied, not expanded
     static constexpr uint32_t kLitCap = kLitWin - 16u;    // literal bytes one batch may take: what the window holds whatever its granule alignment
     static constexpr uint32_t kSpanMax = 16u * T - 16u;   // output bytes one batch may cover: at most T slots whatever the alignment
     static constexpr uint32_t kCellOff = 16u * T + 16u;   // cells of the span live in the stale part of the ring, past the span
@@ -128,6 +129,13 @@ struct Resolver {
         return r;
 #else
         return m % d;
+#endif
+    }
+    SWC_D static void lds_min(uint32_t* p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __hip_atomic_fetch_min(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        if (v < *p) *p = v;
 #endif
     }
     SWC_D static void lds_or(uint32_t* p, uint32_t v) {
@@ -279,10 +287,82 @@ struct Resolver {
                 }
                 x[t] = xs;
                 y[t] = ys;
-                if (t == 0) { l->overlap = 0; l->nfar = 0; }
+                if (t == 0) { l->overlap = 0; l->nfar = 0; l->first_rec = r_nx0[t]; l->nbig = kRpt * (uint32_t)T; }
             SIMT_END
             simt::group_scan2_incl<T>(x, y, l->wave_sum);       // (barrier A inside)
             SWC_RP(0)
+            // ---- long runs of plain literals (stored blocks, incompressible data) do not go through cells: the run of
+            // literal-only records the batch starts with is copied from the literal stream to the output and the ring, eight
+            // bytes per thread and step.  (Through the cells such data ran at a third of the speed of text: the literal window
+            // halves the batches, and every byte pays the full price of the expansion.)
+            {
+                const uint32_t fr = simt::uniform(l->first_rec);
+                if (((fr >> 7) & 511u) == 0u && (fr & 127u) + ((fr >> 16) << 7) >= kBigLit) {
+                    SIMT_BEGIN(t, T)
+#pragma unroll
+                        for (uint32_t k = 0; k < kRpt; k++) {
+                            const uint32_t r = k ? r_nx1[t] : r_nx0[t];
+                            const bool big = base + kRpt * (uint32_t)t + k < nrec && ((r >> 7) & 511u) == 0u && (r & 127u) + ((r >> 16) << 7) >= kBigLit;
+                            if (!big) lds_min(&l->nbig, kRpt * (uint32_t)t + k);
+                        }
+                    SIMT_END_BARRIER
+                    const uint32_t nb = simt::uniform(l->nbig);          // records of the run (>= 1: the first one is big)
+                    SIMT_BEGIN(t, T)
+                        if (kRpt * (uint32_t)t <= nb - 1u && nb - 1u < kRpt * (uint32_t)t + kRpt)
+                            l->bigbytes = ((nb - 1u) & 1u) ? y[t] : y[t] - yb[t];   // literal bytes up to and including record nb - 1
+                    SIMT_END_BARRIER
+                    const uint32_t nbytes = simt::uniform(l->bigbytes);
+                    const uint32_t V = A + (uint32_t)rpos;                 // virtual position of the first byte
+                    const uint32_t head = (0u - V) & 7u, nhead = head < nbytes ? head : nbytes;
+                    const uint32_t npiece = (nbytes - nhead) >> 3, ntail = (nbytes - nhead) & 7u;
+                    gcptr src = lits + lbase;
+                    SIMT_BEGIN(t, T)
+                        l->slotw[t] = 0;
+                        if (t == 0) l->slotw[T] = 0;
+                        // (the batch before may have left the bytes of its last, incomplete dword to its successor: they are in the
+                        // ring only)
+                        if ((uint32_t)t < (V & 3u) && (uint64_t)((V & 3u) - (uint32_t)t) <= rpos) {
+                            const uint32_t back = (V & 3u) - (uint32_t)t;
+                            if (rpos - back < limit) out[rpos - back] = l->ring[(V - back) & kMask];
+                        }
+                        // the bytes up to the first 8-aligned position and behind the last one, one thread each
+                        // (a run longer than the ring wraps around it: only its last kRing bytes are written there -- a byte that
+                        // a later byte of the run replaces belongs to another thread, and the two would race)
+                        if ((uint32_t)t < nhead) {
+                            const uint32_t b = src[t];
+                            if (nbytes - (uint32_t)t <= kRing) l->ring[(V + (uint32_t)t) & kMask] = (uint8_t)b;
+                            if (rpos + (uint32_t)t < limit) out[rpos + (uint32_t)t] = (uint8_t)b;
+                        }
+                        if ((uint32_t)t < ntail) {
+                            const uint32_t i = nhead + 8u * npiece + (uint32_t)t;
+                            const uint32_t b = src[i];
+                            l->ring[(V + i) & kMask] = (uint8_t)b;
+                            if (rpos + i < limit) out[rpos + i] = (uint8_t)b;
+                        }
+                        for (uint32_t p = (uint32_t)t; p < npiece; p += (uint32_t)T) {
+                            const uint32_t i = nhead + 8u * p;
+                            const uint64_t v = load_u64(src + i);
+                            if (nbytes - i <= kRing) *(uint64_t*)(l->ring + ((V + i) & kMask)) = v;
+                            if (rpos + i + 8u <= limit) store_u64(out + rpos + i, v);
+                            else for (uint32_t e = 0; e < 8; e++) if (rpos + i + e < limit) out[rpos + i + e] = (uint8_t)(v >> (8 * e));
+                        }
+                    SIMT_END
+                    rpos += nbytes;
+                    lbase += nbytes;
+                    base += nb;
+                    // the records and the literal window of what follows (their prefetches were aimed elsewhere)
+                    lfill = (lbase & ~(uint64_t)15) + kLitWin;
+                    SIMT_BEGIN(t, T)
+                        const uint32_t nx = base + kRpt * (uint32_t)t;
+                        r_nx0[t] = nx < nrec ? recs[nx] : 0u;
+                        r_nx1[t] = nx + 1u < nrec ? recs[nx + 1u] : 0u;
+                        lit_pf_at[t] = 0xFFFFFFFFu;
+                        const uint64_t o = (lbase & ~(uint64_t)15) + 16ull * (uint32_t)t;
+                        if (16u * (uint32_t)t < kLitWin && o + 16 <= lit_cap) *(u128*)(l->litbuf + ((uint32_t)o & kLitMask)) = load_16(lits + o);
+                    SIMT_END_BARRIER
+                    continue;
+                }
+            }
             // ---- R1: batch geometry, two records per thread, in CELL indices (span-relative position + off)
             const uint32_t lbk = (uint32_t)lbase;
             SIMT_BEGIN(t, T)

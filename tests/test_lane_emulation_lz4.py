@@ -115,3 +115,19 @@ def test_matches_older_than_the_ring_history(order):
         E.set_order(0)
     for i, (r, p) in enumerate(zip(res, payloads)):
         assert r[0] == 0 and r[1] == p and r[2] == len(blocks[i]), "payload %d" % i
+
+
+@pytest.mark.parametrize("misalign", range(16))
+def test_long_literal_runs_at_every_output_alignment(misalign):
+    """Runs of plain literals (incompressible data: literal-only records of 2,048 bytes, stored Deflate blocks) are copied
+    by the resolve kernel, not expanded: a run longer than the 64 KiB ring wraps around it, runs begin and end at any byte
+    of the output, and what follows them picks up the ring and the bytes of an incomplete dword."""
+    from swcompression_amd import corpus
+    pays = [corpus.p_rand(70000, 31), corpus.p_text(3001, 1) + corpus.p_rand(66000, 2) + corpus.p_text(5003, 3) + corpus.p_rand(1500, 4) + corpus.p_text(777, 5),
+            corpus.p_mix(150000, 6)]
+    blocks = [corpus.lz4_block(p) for p in pays]
+    for r, p, z in zip(E.lz4_block(blocks, [len(p) for p in pays], misalign=misalign), pays, blocks):
+        assert r[0] == 0 and r[1] == p and r[2] == len(z)
+    streams = [corpus.deflate_raw(p) for p in pays]
+    for r, p in zip(E.inflate(streams, [len(p) for p in pays], misalign=misalign), pays):
+        assert r[0] == 0 and r[1] == p
