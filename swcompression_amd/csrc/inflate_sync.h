@@ -51,20 +51,21 @@ constexpr uint32_t kSyncChunk = SWC_SYNC_CHUNK;
 constexpr uint32_t kSyncRound = 64u * kSyncChunk;
 constexpr uint32_t kSyncStage = (kSyncRound + 32u + 15u) & ~15u;    // + what the last lane may read past its sub-chunk (a code of <= 48 bits, then the window's two dwords and the next one: < 28 bytes)
 constexpr uint32_t kSyncStageLds = kSyncStage;
-constexpr uint32_t kEntInvalid = 0x80000000u;        // a code of the set, but not a symbol the fast path takes
+constexpr uint32_t kEntInvalid = 0x80000000u;        // bit 31 = STOP: the decode loops end at this entry -- the end-of-block symbol (with kEntEob), or a code
+                                                      // of the set that is not a symbol the fast path takes (without; such an entry counts no bits)
 constexpr uint32_t kPosFail = 0xFFFFFFFFu;
 static_assert(kSyncChunk % 4 == 0 && kSyncChunk >= 36, "sub-chunks are whole dwords");
 
 // Table entry, laid out for a decode loop without branches per kind:
 //   [0:4] bits the symbol takes (code + extra)   [5] end of block   [6:9] code length   [10] length symbol: the next code is
 //   a distance (the bit IS the offset of the distance table in `lut`)   [11:14] extra bits   [15] literal
-//   [16:30] base value   [31] invalid.   0: no entry (long code).
+//   [16:30] base value   [31] stop (end of block, or invalid).   0: no entry (long code).
 constexpr uint32_t kEntEob = 1u << 5, kEntLen = 1u << kSyncLitBits, kEntLit = 1u << 15;
 constexpr uint32_t kEntClenShift = 6, kEntExtShift = 11;
 static_assert(kSyncLitBits == 10, "the entry layout keeps bit 10 for the length flag");
 // kind, lit/len table: 1 literal, 2 length, 3 end of block; distance table: 0 distance.
 SWC_HD uint32_t make_entry(uint32_t clen, uint32_t ext, uint32_t kind, uint32_t value) {
-    return (clen + ext) | (kind == 1 ? kEntLit : kind == 2 ? kEntLen : kind == 3 ? kEntEob : 0u) | (clen << kEntClenShift) | (ext << kEntExtShift) | (value << 16);
+    return (clen + ext) | (kind == 1 ? kEntLit : kind == 2 ? kEntLen : kind == 3 ? kEntEob | kEntInvalid : 0u) | (clen << kEntClenShift) | (ext << kEntExtShift) | (value << 16);
 }
 
 // The entry of lit/len symbol `sym` (0..287) / distance symbol `sym` (0..31) with a code of `d` bits
@@ -73,13 +74,13 @@ SWC_HD uint32_t entry_of_symbol(bool dist, uint32_t sym, uint32_t d) {
     if (!dist) {
         if (sym < 256) return make_entry(d, 0, 1, sym);
         if (sym == 256) return make_entry(d, 0, 3, 0);
-        if (sym > 285) return d | kEntInvalid;   // 286, 287: the checked step reports wrongSymbol
+        if (sym > 285) return kEntInvalid;       // 286, 287: the checked step reports wrongSymbol
         const uint32_t s = sym - 257u;
         const uint32_t e = s < 8 || s == 28 ? 0u : (s >> 2) - 1u;
         const uint32_t base = s < 8 ? 3u + s : s == 28 ? 258u : 3u + ((4u + (s & 3u)) << e);
         return make_entry(d, e, 2, base);
     }
-    if (sym > 29) return d | kEntInvalid;        // 30, 31: wrongSymbol
+    if (sym > 29) return kEntInvalid;            // 30, 31: wrongSymbol
     const uint32_t e = sym < 4 ? 0u : (sym >> 1) - 1u;
     const uint32_t base = sym < 4 ? 1u + sym : 1u + ((2u + (sym & 1u)) << e);
     return make_entry(d, e, 0, base);
@@ -419,9 +420,9 @@ SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, u
         const uint32_t nx = *(const uint32_t*)(stg + wa + 8);
         if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, tsel); }   // a code longer than the direct table (or no code at all)
         const uint32_t n = e & 31u;
-        if ((e & (kEntInvalid | kEntEob)) || (CHK && posb + n > in_bits)) {
+        if ((e & kEntInvalid) || (CHK && posb + n > in_bits)) {
             // not a symbol the fast path takes / the symbol runs past the end of the input / the end of the block
-            if ((e & kEntInvalid) || (CHK && posb + n > in_bits)) flags |= kFlagFail;
+            if (!(e & kEntEob) || (CHK && posb + n > in_bits)) flags |= kFlagFail;
             else { bp += n; flags |= kFlagEob; }
             break;
         }
@@ -491,8 +492,9 @@ constexpr uint32_t kProvRecRow = 64u * 4u, kProvLitRow = 64u * 8u;   // bytes fr
 // flag and pull the end of the sub-chunk to zero, so that the next test at the top leaves (their side effects are neutral: an
 // end-of-block entry is neither literal nor length, and a lane that raised the fail flag is discarded).  A loop with several
 // exits costs the wavefront a dozen scalar instructions of mask bookkeeping per iteration.
-constexpr uint32_t kEntStop = kEntInvalid | kEntEob;
-SWC_HD uint32_t flags_of_stop_bits(uint32_t stop) { return ((stop >> 5) & 1u) /* kFlagEob */ | ((stop >> 30) & 2u) /* kFlagFail */; }
+// `seen`: the OR of all entries a loop took.  Only the entry that stopped it has bit 31, only the end-of-block entry bit 5.
+SWC_HD uint32_t flags_of_seen(uint32_t seen) { return (seen & kEntEob) ? kFlagEob : (seen & kEntInvalid) ? kFlagFail : 0u; }
+SWC_HD uint32_t sext_bit31(uint32_t e) { return (uint32_t)((int32_t)e >> 31); }   // all ones for a stop entry
 
 // Where does a decode from `start` end?  (The walk pass: no counting.)  Returns the bit position just past the last symbol
 // taken, or kPosFail.
@@ -500,10 +502,11 @@ SWC_D uint32_t walk_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start,
     const uint8_t* stg = sl->stage;
     uint32_t wa = (start >> 5) << 2, bp = start & 31u;
     uint32_t d0 = *(const uint32_t*)(stg + wa), d1 = *(const uint32_t*)(stg + wa + 4);
-    uint32_t tsel = 0, tmsk = (1u << kSyncLitBits) - 1u, stop = 0;
+    uint32_t tsel = 0, tmsk = (1u << kSyncLitBits) - 1u, seen = 0;
     if (chunk_end > in_bits) chunk_end = in_bits;          // (the zero fill behind the input is not worth decoding)
-    if (start >= in_bits) { stop = kEntInvalid; chunk_end = 0; }
+    if (start >= in_bits) { seen = kEntInvalid; chunk_end = 0; }
     if (start < chunk_end) {   // (tested at the bottom: one mask update and one branch per iteration)
+        bool go;
         do {
             SWC_SYNC_STAT(4, 1);
             SWC_SYNC_ITER();
@@ -511,37 +514,40 @@ SWC_D uint32_t walk_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start,
             uint32_t e = sl->lut[(bits & tmsk) | tsel];
             const uint32_t nx = *(const uint32_t*)(stg + wa + 8);
             if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, tsel); }
-            const uint32_t st = e & kEntStop;
-            stop |= st;
-            chunk_end = st ? 0u : chunk_end;
+            seen |= e;
+            chunk_end &= ~sext_bit31(e);
             const bool is_len = (e & kEntLen) != 0u;
             tsel = e & kEntLen;
             tmsk = is_len ? (1u << kSyncDistBits) - 1u : (1u << kSyncLitBits) - 1u;
-            bp += (e & kEntInvalid) ? 0u : e & 31u;
+            bp += e & 31u;
             const bool sh = bp >= 32;
             wa += sh ? 4u : 0u;
             bp &= 31u;
             d0 = sh ? d1 : d0;
             d1 = sh ? nx : d1;
-        } while ((uint32_t)(tsel != 0) | (uint32_t)((wa << 3) + bp < chunk_end));
+            go = is_len || (wa << 3) + bp < chunk_end;
+        } while (go);
     }
     const uint32_t endb = (wa << 3) + bp;
-    return (stop & kEntInvalid) || endb > in_bits ? kPosFail : endb;
+    return flags_of_seen(seen) == kFlagFail || endb > in_bits ? kPosFail : endb;
 }
 
-// prec / plit: this lane's slot in row 0 of the record / literal rows
-SWC_D void decode_chunk_prov(const SyncLds* sl, const LongCodes lc, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr plit,
-                             gptr prec, uint32_t run0, ProvOut& r) {
+// prov: the stream's scratch; lane: my column of its rows
+SWC_D void decode_chunk_prov(const SyncLds* sl, const LongCodes lc, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr prov,
+                             uint32_t lane, uint32_t run0, ProvOut& r) {
+    // (one base pointer for the wave and 32-bit offsets per lane: the stores take the base from scalar registers)
+    const uint32_t rdummy = 4u * lane, ldummy = (uint32_t)lzr::kProvRecBytes + 8u * lane;
     const uint8_t* stg = sl->stage;
     uint32_t wa = (start >> 5) << 2, bp = start & 31u;
     uint32_t d0 = *(const uint32_t*)(stg + wa), d1 = *(const uint32_t*)(stg + wa + 4);
-    uint32_t tsel = 0, tmsk = (1u << kSyncLitBits) - 1u, stop = 0;
-    uint32_t plen = 0, run = run0, nlit = 0, nout = 0;
-    uint32_t roff = kProvRecRow, loff = kProvLitRow;       // byte offsets of the next record / literal group (row 1 is the first)
+    uint32_t tsel = 0, tmsk = (1u << kSyncLitBits) - 1u, seen = 0;
+    uint32_t plen = 0, run = run0, nlit = 0, nout = 0, pend = 0;   // pend: literals in the accumulator (nlit mod 8)
+    uint32_t roff = rdummy + kProvRecRow, loff = ldummy + kProvLitRow;   // byte offsets of my next record / literal group in the scratch (row 1 is the first)
     uint32_t lb0 = 0, lb1 = 0;                             // pending literals: the newest at the top of lb1:lb0
     int32_t need = -0x40000000;
     if (chunk_end > in_bits) chunk_end = in_bits;          // (the zero fill behind the input is not worth decoding)
-    if (start >= in_bits) { stop = kEntInvalid; chunk_end = 0; }   // nothing left for this sub-chunk: the checked step says what that means
+    if (start >= in_bits) { seen = kEntInvalid; chunk_end = 0; }   // nothing left for this sub-chunk: the checked step says what that means
+    bool go = false;
     if (start < chunk_end) do {   // (tested at the bottom: one mask update and one branch per iteration)
         SWC_SYNC_STAT(5, 1);
         SWC_SYNC_ITER();
@@ -549,9 +555,8 @@ SWC_D void decode_chunk_prov(const SyncLds* sl, const LongCodes lc, uint32_t sta
         uint32_t e = sl->lut[(bits & tmsk) | tsel];
         const uint32_t nx = *(const uint32_t*)(stg + wa + 8);
         if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, tsel); }
-        const uint32_t st = e & kEntStop;
-        stop |= st;
-        chunk_end = st ? 0u : chunk_end;
+        seen |= e;
+        chunk_end &= ~sext_bit31(e);
         const bool was_dist = tsel != 0;
         const uint32_t is_lit = (e >> 15) & 1u;
         const uint32_t val = ((e >> 16) & 0x7FFFu) + bfe32(bits, (e >> kEntClenShift) & 15u, (e >> kEntExtShift) & 15u);
@@ -560,12 +565,15 @@ SWC_D void decode_chunk_prov(const SyncLds* sl, const LongCodes lc, uint32_t sta
         lb0 = funnel32(lb1, lb0, sh8);
         lb1 = funnel32(val, lb1, sh8);
         nlit += is_lit;
-        const bool full = (is_lit & (uint32_t)((nlit & 7u) == 0u)) != 0u;   // the eighth literal of a group has just entered
+        pend += is_lit;
+        const uint32_t full8 = pend & 8u;                  // the eighth literal of a group has just entered
+        pend &= 7u;
+        const bool full = full8 != 0u;
         const int32_t nd = (int32_t)val - (int32_t)nout;   // a distance needs this much output in front of the sub-chunk
         need = was_dist && nd > need ? nd : need;
-        if (was_dist | full) {
-            store_u64(plit + (full ? loff : 0u), ((uint64_t)lb1 << 32) | lb0);
-            store_u32(prec + (was_dist ? roff : 0u), lzr::make_match(run, plen, val));
+        if ((tsel | full8) != 0u) {
+            store_u64(prov + (full ? loff : ldummy), ((uint64_t)lb1 << 32) | lb0);
+            store_u32(prov + (was_dist ? roff : rdummy), lzr::make_match(run, plen, val));
             loff += full ? kProvLitRow : 0u;
             roff += was_dist ? kProvRecRow : 0u;
         }
@@ -575,28 +583,29 @@ SWC_D void decode_chunk_prov(const SyncLds* sl, const LongCodes lc, uint32_t sta
         plen = is_len ? val : plen;
         tsel = e & kEntLen;
         tmsk = is_len ? (1u << kSyncDistBits) - 1u : (1u << kSyncLitBits) - 1u;
-        bp += (e & kEntInvalid) ? 0u : e & 31u;
+        bp += e & 31u;
         const bool sh = bp >= 32;
         wa += sh ? 4u : 0u;
         bp &= 31u;
         d0 = sh ? d1 : d0;
         d1 = sh ? nx : d1;
-    } while ((uint32_t)(tsel != 0) | (uint32_t)((wa << 3) + bp < chunk_end));
+        go = is_len || (wa << 3) + bp < chunk_end;
+    } while (go);
     if (nlit & 7u) {   // the last, incomplete group: its bytes sit at the top of the accumulator
         const uint32_t dn = (8u - (nlit & 7u)) << 3;
-        store_u64(plit + loff, (((uint64_t)lb1 << 32) | lb0) >> dn);
+        store_u64(prov + loff, (((uint64_t)lb1 << 32) | lb0) >> dn);
     }
-    uint32_t flags = flags_of_stop_bits(stop);
+    uint32_t flags = flags_of_seen(seen);
     uint32_t tail = 0;
     if (run > 0) {
         if (flags & kFlagEob) tail = run;
-        else { store_u32(prec + roff, lzr::make_lits(run)); roff += kProvRecRow; }
+        else { store_u32(prov + roff, lzr::make_lits(run)); roff += kProvRecRow; }
     }
     const uint32_t endb = (wa << 3) + bp;
     if (endb > in_bits) flags |= kFlagFail;                // a symbol ran past the end of the input
     if (nlit + run0 > lzr::kLitRunMax) flags |= kFlagSlow;  // (conservative: only then can a run exceed what a match record carries)
     r.end = (flags & kFlagFail) ? kPosFail : endb;
-    r.nlit = nlit; r.nrec = roff / kProvRecRow - 1u; r.nout = nout; r.flags = flags; r.tail = tail; r.need = need;
+    r.nlit = nlit; r.nrec = (roff - rdummy) / kProvRecRow - 1u; r.nout = nout; r.flags = flags; r.tail = tail; r.need = need;
 }
 
 // A lane's piece of the round moves from its column of the scratch to its final place: `nrec` records to `rdst` (dword
@@ -746,7 +755,7 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                             // several sub-chunks: the scratch is sized for one).
                             r.end = kPosFail; r.nlit = r.nrec = r.nout = r.tail = 0; r.flags = kFlagFail; r.need = 0;
                         } else
-                        decode_chunk_prov(sl, lc, start[t], ce, in_bits, ln.prov + lzr::kProvRecBytes + 8u * (uint32_t)t, ln.prov + 4u * (uint32_t)t, t == 0 ? pending : 0u, r);
+                        decode_chunk_prov(sl, lc, start[t], ce, in_bits, ln.prov, (uint32_t)t, t == 0 ? pending : 0u, r);
                         endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; flg[t] = r.flags;
                         c_tail[t] = r.tail; c_need[t] = (uint32_t)r.need;
                         have[t] = true;
