@@ -965,9 +965,19 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, SyncProf& pf) {
     {   // Deflate.swift:117-162, every lane the same
         int n = 0;
         uint32_t prev = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+        // the 128-entry table of the code-length code sits in two registers spread over the lanes (lane i: entries i and
+        // 64 + i): the serial loop below looks its entry up with a cross-lane read instead of an LDS round trip per symbol
+        const uint32_t lut_lo = cl_lut[threadIdx.x & 63u], lut_hi = cl_lut[64u + (threadIdx.x & 63u)];
+#endif
         while (n < total) {
             br.refill();
+#if defined(__HIP_DEVICE_COMPILE__)
+            const uint32_t x7 = simt::uniform(br.peek32() & 127u);
+            const uint32_t e = x7 < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)lut_lo, (int)x7) : (uint32_t)__builtin_amdgcn_readlane((int)lut_hi, (int)(x7 - 64u));
+#else
             const uint32_t e = simt::uniform((uint32_t)cl_lut[br.peek32() & 127u]);   // (scalar from here on: see BitReader)
+#endif
             if (e == 0xFFu || (e & 7u) > br.bc) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :122
             br.consume(e & 7u);
             const uint32_t sym = e >> 3;

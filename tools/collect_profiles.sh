@@ -1,0 +1,11 @@
+#!/bin/bash
+# Copies the summaries of a tools/gpu_final.sh run into profiles/ under the round's tag.  Usage: collect_profiles.sh <tag>
+R=$(cd "$(dirname "$0")/.." && pwd); TAG=${1:?tag}; O=$R/gpurun_out/$TAG; P=$R/profiles
+cp $O/bench_full.json $P/${TAG}_bench_full.json 2>/dev/null
+cp $O/pytest_gpu.log $P/${TAG}_pytest_gpu.log 2>/dev/null
+for W in deflate64k lz4_4m bzip2_900k lzma2_256k; do
+  cp $O/kernel_stats_$W.txt $P/${TAG}_kernel_stats_$W.txt 2>/dev/null
+  cp $O/${W}_traffic.json $P/${TAG}_${W}_traffic.json 2>/dev/null
+  cp $O/sq_counters_$W.txt $P/${TAG}_sq_counters_$W.txt 2>/dev/null
+done
+ls $P | grep "^$TAG"
