@@ -12,6 +12,8 @@
 //   checksums / Delta filter   one stream per workgroup                     crc32_group.h, checksum_group.h, delta_group.h
 // No MFMA (no dense contraction anywhere on this path), no inter-workgroup communication.
 #include <hip/hip_runtime.h>
+#include <cstddef>
+#include <mutex>
 #include "swc_common.h"
 #include "inflate_lane.h"
 #include "inflate_sync.h"
@@ -21,6 +23,7 @@
 #include "lzma_wave.h"
 #include "bzip2_block.h"
 #include "crc32_group.h"
+#include "crc32_wave.h"
 #include "checksum_group.h"
 #include "delta_group.h"
 #include "launch.h"
@@ -300,19 +303,77 @@ hipError_t launch_bzip2(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStrea
     return hipGetLastError();
 }
 
-// ---- CRC-32 of every job's output, one stream per 256-thread workgroup -------------------
+// ---- CRC-32 of every job's output -----------------------------------------------------------------
+// Two kernels, both launched over all n jobs, each taking the jobs of its size class (the sizes are on the device; a wave or
+// group whose job belongs to the other kernel ends at once): one stream per WAVE below 1 MB (crc32_wave.h: no per-stream
+// set-up, no barrier after the constants are in LDS), one stream per 256-thread group above (crc32_group.h).
+constexpr uint64_t kCrcGroupLen = 1u << 20;
+__device__ crcw::WaveConsts g_crc_consts;
+__global__ __launch_bounds__(256) void swc_crc32_consts_kernel() { crcw::build_consts<256>(&g_crc_consts, (int)threadIdx.x); }
+
 __global__ __launch_bounds__(256) void swc_crc32_kernel(const Job* __restrict__ jobs, uint32_t n, uint32_t* __restrict__ crcs) {
-    __shared__ crc::Lds<256> lds;
-    uint32_t g = blockIdx.x;
+    __shared__ crcw::WaveConsts lds;
+    {   // tables, G tables and fold matrices: 2240 words
+        const uint32_t* src = (const uint32_t*)&g_crc_consts;
+        uint32_t* dst = (uint32_t*)&lds;
+        constexpr int kWords = (int)(offsetof(crcw::WaveConsts, sq) / 4);
+        for (int i = (int)threadIdx.x; i < kWords; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (g >= n) return;
     const uint64_t len = jobs[g].out_len < jobs[g].out_cap ? jobs[g].out_len : jobs[g].out_cap;
-    uint32_t c = crc::crc32_group<256>((gcptr)jobs[g].out, len, &lds, (int)threadIdx.x);
-    if (threadIdx.x == 0) crcs[g] = c;
+    if (len >= kCrcGroupLen) return;
+    const uint32_t c = crcw::crc32_wave((gcptr)jobs[g].out, simt::uniform(len), &lds);
+    if ((threadIdx.x & 63) == 0) crcs[g] = c;
+}
+
+// A fixed number of groups, each looking after a contiguous range of jobs: one parallel read of the lengths, then the streams
+// of a megabyte and more one after the other (none in a batch of small members: the groups end after that one read).
+constexpr int kCrcGroupGrid = 2048;
+__global__ __launch_bounds__(256) void swc_crc32_group_kernel(const Job* __restrict__ jobs, uint32_t n, uint32_t* __restrict__ crcs) {
+    __shared__ crc::Lds<256> lds;
+    __shared__ uint32_t big[256];
+    __shared__ uint32_t nbig;
+    const uint32_t per = (n + gridDim.x - 1) / gridDim.x;
+    const uint32_t lo = blockIdx.x * per, hi = lo + per < n ? lo + per : n;
+    for (uint32_t base = lo; base < hi; base += 256) {
+        if (threadIdx.x == 0) nbig = 0;
+        __syncthreads();
+        const uint32_t g = base + threadIdx.x;
+        if (g < hi) {
+            const uint64_t len = jobs[g].out_len < jobs[g].out_cap ? jobs[g].out_len : jobs[g].out_cap;
+            if (len >= kCrcGroupLen) big[atomicAdd(&nbig, 1u)] = g;
+        }
+        __syncthreads();
+        const uint32_t cnt = nbig;
+        for (uint32_t i = 0; i < cnt; i++) {
+            const uint32_t j = big[i];
+            const uint64_t len = jobs[j].out_len < jobs[j].out_cap ? jobs[j].out_len : jobs[j].out_cap;
+            const uint32_t c = crc::crc32_group<256>((gcptr)jobs[j].out, len, &lds, (int)threadIdx.x);
+            if (threadIdx.x == 0) crcs[j] = c;
+            __syncthreads();
+        }
+    }
 }
 
 hipError_t launch_crc32(const Job* jobs, size_t n, uint32_t* crcs, hipStream_t stream) {
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(swc_crc32_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, (uint32_t)n, crcs);
+    {   // the constants, once per device (the first call on a device builds them on the caller's stream; later launches on any
+        // stream of the device come after it in host time and, through the wait below, in device time)
+        static std::mutex mu;
+        static bool built[64] = {};
+        int dev = 0;
+        if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return hipErrorInvalidDevice;
+        std::lock_guard<std::mutex> lk(mu);
+        if (!built[dev]) {
+            hipLaunchKernelGGL(swc_crc32_consts_kernel, dim3(1), dim3(256), 0, stream);
+            if (hipStreamSynchronize(stream) != hipSuccess) return hipErrorUnknown;
+            built[dev] = true;
+        }
+    }
+    hipLaunchKernelGGL(swc_crc32_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, stream, jobs, (uint32_t)n, crcs);
+    hipLaunchKernelGGL(swc_crc32_group_kernel, dim3((unsigned)(n < (size_t)kCrcGroupGrid ? n : (size_t)kCrcGroupGrid)), dim3(256), 0, stream, jobs, (uint32_t)n, crcs);
     return hipGetLastError();
 }
 

@@ -166,6 +166,18 @@ SWC_D void wave_shift_up(PT<uint32_t, N>& y, const PT<uint32_t, N>& x, uint32_t 
     for (int t = 0; t < N; t++) { const uint32_t cur = x.v[t]; y.v[t] = prev; prev = cur; }
 #endif
 }
+// y[t] = x[t + s] (the last s lanes: unspecified on the device, zero in the emulation)
+template <int N>
+SWC_D void wave_shift_down(PT<uint32_t, N>& y, const PT<uint32_t, N>& x, int s) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = (int)threadIdx.x & 63;
+    y.v = (uint32_t)__builtin_amdgcn_ds_bpermute(((lane + s) & 63) << 2, (int)x.v);
+#elif defined(SWC_SIMT_DEVICE_FORM)
+    (void)y; (void)x; (void)s;
+#else
+    for (int t = 0; t < N; t++) y.v[t] = t + s < N ? x.v[t + s] : 0u;
+#endif
+}
 // value of lane `i` (i the same in every lane)
 template <int N>
 SWC_D uint32_t wave_read(const PT<uint32_t, N>& x, int i) {

@@ -110,6 +110,19 @@ def checksum(kind, data, misalign=0):
     return lib.emu_checksum(kind, base, len(data))
 
 
+lib.emu_crc32_wave.argtypes = [C.c_void_p, C.c_size_t]
+lib.emu_crc32_wave.restype = C.c_uint32
+
+
+def crc32_wave(data, misalign=0):
+    """CRC-32 by the wave-per-stream code of the device (crc32_wave.h), the data `misalign` bytes past a 64-byte boundary."""
+    data = bytes(data)
+    buf = C.create_string_buffer(len(data) + 128)
+    base = (C.addressof(buf) + 63) // 64 * 64 + misalign
+    C.memmove(base, data, len(data))
+    return lib.emu_crc32_wave(base, len(data))
+
+
 lib.emu_delta.argtypes = [C.c_char_p, C.c_void_p, C.c_size_t, C.c_uint]
 lib.emu_delta.restype = None
 

@@ -130,6 +130,15 @@ uint64_t run_group(F body) {
 }
 }  // namespace
 
+// the wave-per-stream CRC-32 (crc32_wave.h): constants built once, the 64 lanes run one after the other
+#include "../../swcompression_amd/csrc/crc32_wave.h"
+extern "C" uint32_t emu_crc32_wave(const uint8_t* p, size_t n) {
+    static swc::crcw::WaveConsts consts;
+    static bool built = false;
+    if (!built) { swc::crcw::build_consts<1>(&consts, 0); built = true; }
+    return swc::crcw::crc32_wave(p, n, &consts);
+}
+
 // kind as swc_checksum (include/swc_hip.h); T = 64 emulated threads per group
 extern "C" uint64_t emu_checksum(int kind, const uint8_t* p, size_t n) {
     using namespace swc;

@@ -26,6 +26,28 @@ def test_group_checksum_matches_oracle(kind):
         assert E.checksum(kind, p) == ORACLE[kind](p), "%s, length %d" % (NAMES[kind], len(p))
 
 
+def test_wave_crc32_matches_oracle():
+    """crc32_wave.h (one stream per wave, the kernel behind swc_batch_crc32 for members below 1 MB): every length around the
+    front padding to 2 KB rows and around the four bytes that carry the initial value, every start alignment."""
+    rng = np.random.Generator(np.random.PCG64(0x5C0DE + 80))
+    base = rng.integers(0, 256, 70000, dtype=np.uint8).tobytes()
+    assert E.crc32_wave(b"123456789") == 0xCBF43926
+    lengths = list(range(0, 80)) + [2044, 2045, 2046, 2047, 2048, 2049, 2050, 2051, 2052, 2053, 4095, 4096, 4097, 6143, 6144, 6150, 65535, 65536, 65537, 69999]
+    for n in lengths:
+        assert E.crc32_wave(base[:n]) == O.crc32(base[:n]), n
+    for off in range(1, 17):
+        p = base[off:off + 5000 + 3 * off]
+        assert E.crc32_wave(p, misalign=off) == O.crc32(p), off
+    for p in payloads():
+        assert E.crc32_wave(p) == O.crc32(p), len(p)
+    for order in (1, 2):
+        E.set_order(order)
+        try:
+            assert E.crc32_wave(base[:9001]) == O.crc32(base[:9001])
+        finally:
+            E.set_order(0)
+
+
 def test_known_answers():
     # the check values of the CRC catalogue / xxHash specification for "123456789"
     assert E.checksum(1, b"123456789") == 0xCBF43926

@@ -22,7 +22,9 @@ def _decoded_batch(plains):
 
 def test_every_checksum_on_awkward_lengths():
     sizes = [0, 1, 2, 3, 4, 5, 7, 15, 16, 17, 31, 32, 33, 255, 256, 257, 1023, 1024, 1025, 4095, 4096, 4099, 65535, 65536,
-             65537, 300001, 1 << 20, (1 << 21) + 11]
+             65537, 300001, 1 << 20, (1 << 21) + 11,
+             # swc_batch_crc32: around the rows of 2 KB of the wave kernel and around its hand-over to the group kernel at 1 MB
+             2044, 2045, 2047, 2048, 2049, 2051, 6144, 6145, (1 << 20) - 1, (1 << 20) + 1, 3 << 20]
     plains = [corpus.p_mix(n, 140 + i) for i, n in enumerate(sizes)]
     plains.append(b"\xff" * 700001)    # Adler-32: largest per-byte increments
     plains.append(bytes(500000))
@@ -31,6 +33,9 @@ def test_every_checksum_on_awkward_lengths():
         got = b.checksum(kind)
         for i, p in enumerate(plains):
             assert int(got[i]) == fn(p), "%s, length %d" % (kind, len(p))
+    got = b.crc32()   # swc_batch_crc32: its own pair of kernels
+    for i, p in enumerate(plains):
+        assert int(got[i]) == ORACLE["crc32"](p), "swc_batch_crc32, length %d" % len(p)
 
 
 def test_checksums_of_many_members():
