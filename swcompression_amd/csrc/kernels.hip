@@ -148,7 +148,7 @@ __global__ __launch_bounds__(64) void swc_lz4_parse_kernel(Job* __restrict__ job
     }
 }
 
-__global__ __launch_bounds__(lz4w::kResolveThreads) void swc_lz4_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm) {
+__global__ __launch_bounds__(lz4w::kResolveThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void swc_lz4_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm) {
     __shared__ __attribute__((aligned(16))) lzr::Lds<lz4w::kResolveThreads, lz4w::kRingLog2> lds;
     uint32_t g = blockIdx.x;
     if (g >= n) return;
@@ -190,13 +190,13 @@ hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_
 constexpr size_t kLzmaSpillBytes = (size_t)(0x300u << 12) * 2;
 
 template <bool LZMA2, int LDSBITS>
-__global__ __launch_bounds__(64) void swc_lzma_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* spill) {
+__global__ __launch_bounds__(64) void swc_lzma_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* spill, uint64_t* prof) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lzma_lds[];
     uint32_t g = blockIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
     SWC_AS_GLOBAL uint16_t* sp = spill ? (SWC_AS_GLOBAL uint16_t*)(spill + (size_t)g * kLzmaSpillBytes) : nullptr;
-    lzma::lzma_job<kWave>(job, LZMA2, lzma_lds, sp, (int)threadIdx.x, LDSBITS);
+    lzma::lzma_job<kWave>(job, LZMA2, lzma_lds, sp, (int)threadIdx.x, LDSBITS, prof ? prof + 32 * (size_t)g : nullptr);
     if (threadIdx.x == 0) {
         jobs[g].out_len = job.out_len;
         jobs[g].in_consumed = job.in_consumed;
@@ -211,11 +211,11 @@ hipError_t launch_lzma(bool lzma2, Job* jobs, size_t n, void* spill, hipStream_t
     dim3 grid((unsigned)n), block(kWave);
     g_pt.begin(stream);
     if (spill) {
-        if (lzma2) hipLaunchKernelGGL((swc_lzma_kernel<true, 3>), grid, block, lzma::lds_bytes_for(3), stream, jobs, (uint32_t)n, (uint8_t*)spill);
-        else hipLaunchKernelGGL((swc_lzma_kernel<false, 3>), grid, block, lzma::lds_bytes_for(3), stream, jobs, (uint32_t)n, (uint8_t*)spill);
+        if (lzma2) hipLaunchKernelGGL((swc_lzma_kernel<true, 3>), grid, block, lzma::lds_bytes_for(3), stream, jobs, (uint32_t)n, (uint8_t*)spill, g_prof);
+        else hipLaunchKernelGGL((swc_lzma_kernel<false, 3>), grid, block, lzma::lds_bytes_for(3), stream, jobs, (uint32_t)n, (uint8_t*)spill, g_prof);
     } else {
-        if (lzma2) hipLaunchKernelGGL((swc_lzma_kernel<true, 4>), grid, block, lzma::lds_bytes_for(4), stream, jobs, (uint32_t)n, (uint8_t*)nullptr);
-        else hipLaunchKernelGGL((swc_lzma_kernel<false, 4>), grid, block, lzma::lds_bytes_for(4), stream, jobs, (uint32_t)n, (uint8_t*)nullptr);
+        if (lzma2) hipLaunchKernelGGL((swc_lzma_kernel<true, 4>), grid, block, lzma::lds_bytes_for(4), stream, jobs, (uint32_t)n, (uint8_t*)nullptr, g_prof);
+        else hipLaunchKernelGGL((swc_lzma_kernel<false, 4>), grid, block, lzma::lds_bytes_for(4), stream, jobs, (uint32_t)n, (uint8_t*)nullptr, g_prof);
     }
     g_pt.mark(stream);
     return hipGetLastError();

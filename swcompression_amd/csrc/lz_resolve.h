@@ -90,7 +90,7 @@ struct Lds {
     alignas(8) uint64_t rec8[kRpt * T + 18];                      // per record, in CELL indices (span-relative + off): mstart | thr << 16 | distance << 32 | litkey << 48 (see R1)
     uint32_t slotw[T + 1];                                 // per 16-cell slot: record that covers its first in-span cell | record-start flags of its cells << 16
     uint32_t wave_sum[2 * (T / 64) + 2];
-    uint32_t ntake, span, litspan, overlap, nfar, first_rec, nbig, bigbytes;
+    uint32_t ntake, span, litspan, overlap, first_rec, nbig, bigbytes;
 };
 
 template <int T, int RING_LOG2, uint32_t KEEP, bool FAR = false>
@@ -161,19 +161,12 @@ struct Resolver {
     // every thread (cells past the span get harmless garbage), so the loop has no per-thread exit.  OVERLAP: the batch holds a
     // match that overlaps itself (length > distance): such bytes are reduced to their first period so that chains stay short
     // (one division per cell in this variant only).  FAR (LZ4: offsets reach 65,535 bytes back, the ring keeps KEEP = 32 KiB so
-    // that two workgroups fit a CU): a match byte whose source lies in front of the ring's history goes onto the FAR LIST and
-    // gets its value from the output buffer in HBM after the loop (expand_far) -- 3 % of the match bytes of text.
-    struct FarEntry { uint32_t ci; int32_t x; };
-    static constexpr uint32_t kFarOff = kCellOff + 32u * T;                        // the list lives in the stale part of the ring behind the cells
-    static constexpr uint32_t kFarCap = (kRing - KEEP - (48u * T + 16u)) / 8u;
-    SWC_D FarEntry* far_ptr(uint32_t v0, uint32_t i) const { return (FarEntry*)(l->ring + ((v0 + kFarOff + 8u * i) & kMask)); }
-    SWC_D static uint32_t lds_inc(uint32_t* p) {
-#if defined(__HIP_DEVICE_COMPILE__)
-        return __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-        return (*p)++;
-#endif
-    }
+    // that two workgroups fit a CU): a match byte whose source lies in front of the ring's history -- 3 % of the match bytes of
+    // text -- is read from the output buffer in HBM.  The loads are issued where the cell is worked out and consumed after the
+    // last step (the loop is unrolled to its four steps for that: the values wait in registers), so their latency runs under
+    // the remaining steps and is paid at most once per batch.  The bytes were stored by earlier batches of this workgroup at
+    // least KEEP bytes = four batches ago, by any of its threads; run() makes every wave wait for its own stores once per
+    // batch (two barriers before anybody's far loads of the next batch), which covers them.
     template <bool OVERLAP>
     SWC_D void expand_cells(int t, uint32_t ncell, uint32_t off, uint32_t v0, uint32_t cbase, gcptr obase) const {
         const uint8_t* lds0 = l->ring;                      // litbuf == ring + kRing (struct layout, asserted above)
@@ -185,9 +178,10 @@ struct Resolver {
             m[c] = (uint32_t)t < 4u ? ((2u << (jb + c)) - 1u) & ~((2u << off) - 1u) : m_rest[c];   // slot 0: starts in (off, j]
         }
         const uint32_t nq = (ncell + 3u) >> 2;
-        const uint32_t iters = (nq + (uint32_t)T - 1u) / (uint32_t)T;
-        uint32_t q = (uint32_t)t;
-        for (uint32_t it = 0; it < iters; it++, q += (uint32_t)T) {
+        const uint32_t iters = (nq + (uint32_t)T - 1u) / (uint32_t)T;   // <= 4: a span has at most 16 T - 16 + 15 cells
+        uint32_t far_val[4][4];
+        uint32_t far_mask = 0;
+        auto step = [&](uint32_t q, int it) {
             const uint32_t sw = l->slotw[q >> 2];
             uint32_t cell[4];
 #pragma unroll
@@ -207,17 +201,42 @@ struct Resolver {
                     inspan = !is_lit && (int32_t)x >= (int32_t)off;
                 }
                 const uint32_t a_lit = kRing + ((ci + lkey) & kLitMask), a_ring = (v0 + x) & kMask;
-                uint32_t byte = lds0[is_lit ? a_lit : a_ring];
+                const uint32_t byte = lds0[is_lit ? a_lit : a_ring];
                 if (FAR) {
                     if (!is_lit && (int32_t)x < -(int32_t)KEEP && ci < ncell) {   // the source is older than the ring's history
-                        const uint32_t slot = lds_inc(&l->nfar);
-                        if (slot < kFarCap) *far_ptr(v0, slot) = FarEntry{ci, (int32_t)x};
-                        else byte = obase[(int64_t)(int32_t)x];             // (a batch of nothing but far matches: read it here and now)
+                        far_val[it][c] = obase[(int64_t)(int32_t)x];
+                        far_mask |= 1u << (4 * it + (int)c);
                     }
                 }
                 cell[c] = inspan ? x : 0x8000u | byte;
             }
             *(uint64_t*)(l->ring + ((cbase + 8u * q) & kMask)) = (uint64_t)cell[0] | ((uint64_t)cell[1] << 16) | ((uint64_t)cell[2] << 32) | ((uint64_t)cell[3] << 48);
+        };
+        if (FAR) {
+#pragma unroll
+            for (int it = 0; it < 4; it++) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) far_val[it][c] = 0;
+            }
+#pragma unroll
+            for (int it = 0; it < 4; it++)
+                if ((uint32_t)it < iters) step((uint32_t)t + (uint32_t)it * (uint32_t)T, it);
+#pragma unroll
+            for (int it = 0; it < 4; it++) {   // (keeps the compiler from waiting for each load where it is issued)
+#pragma unroll
+                for (int c = 0; c < 4; c++) SWC_OPAQUE(far_val[it][c]);
+            }
+            if (far_mask != 0u) {
+#pragma unroll
+                for (int it = 0; it < 4; it++) {
+#pragma unroll
+                    for (int c = 0; c < 4; c++)
+                        if (far_mask & (1u << (4 * it + c))) cell_store(l->ring, cbase, 4u * ((uint32_t)t + (uint32_t)it * (uint32_t)T) + (uint32_t)c, 0x8000u | far_val[it][c]);
+                }
+            }
+        } else {
+            uint32_t q = (uint32_t)t;
+            for (uint32_t it = 0; it < iters; it++, q += (uint32_t)T) step(q, 0);
         }
         // cells of slot 0 in front of the span belong to earlier batches: final bytes of the ring (written after the loop: the
         // loop left garbage there; by the thread that wrote the dword in the loop: its own LDS accesses stay in order)
@@ -229,15 +248,6 @@ struct Resolver {
             }
         }
     }
-    // The far list: every entry's byte from the output written by earlier batches (all of their stores have completed: the
-    // caller waited), into its cell as a value.
-    SWC_D void expand_far(int t, uint32_t nfar, uint32_t v0, uint32_t cbase, gcptr obase) const {
-        for (uint32_t e = (uint32_t)t; e < nfar; e += (uint32_t)T) {
-            const FarEntry f = *far_ptr(v0, e);
-            cell_store(l->ring, cbase, f.ci, 0x8000u | (uint32_t)obase[(int64_t)f.x]);
-        }
-    }
-
     SWC_D void run(const SWC_AS_GLOBAL uint32_t* recs, uint32_t nrec) {
         using simt::PT;
         if (nrec == 0) return;
@@ -287,7 +297,7 @@ struct Resolver {
                 }
                 x[t] = xs;
                 y[t] = ys;
-                if (t == 0) { l->overlap = 0; l->nfar = 0; l->first_rec = r_nx0[t]; l->nbig = kRpt * (uint32_t)T; }
+                if (t == 0) { l->overlap = 0; l->first_rec = r_nx0[t]; l->nbig = kRpt * (uint32_t)T; }
             SIMT_END
             simt::group_scan2_incl<T>(x, y, l->wave_sum);       // (barrier A inside)
             SWC_RP(0)
@@ -416,6 +426,7 @@ struct Resolver {
             gptr obase = (gptr)((SWC_AS_GLOBAL uint8_t*)out + base64);
             // ---- R2: prefetch for the next batch, then the cells
             SIMT_BEGIN(t, T)
+                if (FAR) simt::vmem_fence();   // my stores of the batches before are done (see expand_cells); nothing else is in flight here
                 {
                     const uint32_t nx = base + ntake + kRpt * (uint32_t)t;
                     r_nx0[t] = nx < nrec ? recs[nx] : 0u;
@@ -427,18 +438,7 @@ struct Resolver {
                 }
                 if (overlap) expand_cells<true>(t, ncell, off, v0, cbase, (gcptr)obase);
                 else expand_cells<false>(t, ncell, off, v0, cbase, (gcptr)obase);
-            SIMT_END_BARRIER                                     // barrier C (FAR: the list is complete; else: the cells are)
-            if (FAR) {
-                const uint32_t nfar = simt::uniform(l->nfar);
-                if (nfar) {   // (same in every thread)
-                    // the sources were written by earlier batches of THIS workgroup, at least KEEP bytes ago, with plain stores by
-                    // any of its threads: every thread waits for its own stores, the barrier makes that all of them
-                    SIMT_BEGIN(t, T) (void)t; SIMT_END_SYNC
-                    SIMT_BEGIN(t, T)
-                        expand_far(t, nfar < kFarCap ? nfar : kFarCap, v0, cbase, (gcptr)obase);
-                    SIMT_END_BARRIER
-                }
-            }
+            SIMT_END_BARRIER                                     // barrier C: the cells are complete
             SWC_RP(2)
             // ---- R3: one aligned DWORD per thread and step: chase what is unresolved, then the dword leaves for the ring and for HBM
             SIMT_BEGIN(t, T)

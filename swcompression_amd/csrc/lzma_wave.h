@@ -44,8 +44,25 @@ constexpr int lds_bytes_for(int bits) { return (((P_LITERAL + (0x300 << bits)) *
 constexpr int kLdsBytesPerWave = lds_bytes_for(kMaxLdsLitBits);
 constexpr int LEN_CHOICE = 0, LEN_CHOICE2 = 1, LEN_LOW = 2, LEN_MID = 2 + 128, LEN_HIGH = 2 + 256;
 
+// cycle accounting of profile builds (-DSWC_PROFILE, tools/exp_profile_lzma.py): a scope adds its cycles to one slot
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+struct ProfScope {
+    uint64_t* slot; uint64_t t0;
+    __device__ ProfScope(uint64_t* s) : slot(s), t0(__builtin_readcyclecounter()) {}
+    __device__ ~ProfScope() { *slot += __builtin_readcyclecounter() - t0; }
+};
+#define SWC_LZMA_PROF(k) ProfScope prof_scope_##k(&pacc[k]);
+#define SWC_LZMA_COUNT(k, n) (pacc[k] += (n))
+#else
+#define SWC_LZMA_PROF(k)
+#define SWC_LZMA_COUNT(k, n) ((void)0)
+#endif
+
 template <int WAVE>
 struct Decoder {
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    uint64_t pacc[16] = {};   // 0 decode() 1 copy_match 2 byte_at 3 literal symbols (incl. 2) 4 length + distance 5 matches 6 literals 7 short reps
+#endif
     // ---- I/O -----------------------------------------------------------------------------------
     gcptr in;
     uint64_t n;        // input bytes
@@ -72,8 +89,16 @@ struct Decoder {
 
     // The next 256 input bytes sit in a register spread over the lanes (lane i: the dword at win_base + 4 i): the range coder
     // takes a byte about once per four output bytes, and a global load in its serial chain costs the wave a memory round trip
-    // each time.  One coalesced load refills the window every 256 bytes.  (Host build, WAVE = 1: plain reads.)
-    uint64_t win_base;          // input offset of lane 0's dword (a multiple of 4); ~0: no window loaded
+    // each time.  The window is refilled (one coalesced load) at ONE place per symbol -- the top of the symbol loop, and of the
+    // LZMA2 chunk loop -- whenever fewer than kSymbolBytes bytes of it are left: a symbol normalises at most 48 times (isMatch 1,
+    // isRep 1, length 10, slot 6, 26 direct bits, 4 align bits), a chunk header has 6 bytes and a properties byte.  next_byte() is
+    // then a cross-lane read and nothing else: it is inlined at every one of the ~50 decision sites of decode(), and with a
+    // refill (a dword load, a byte loop for the tail of the input, the bounds checks) at each of them the kernel was 48 KB of
+    // code -- more than the waves of two CUs, all at different places of it, can keep in the 64 KB instruction cache they share.
+    // Bytes past the end of the input read as zero and `ip` keeps counting: trapped() (checked where the old `trap` flag was:
+    // before anything of the symbol is written) is the reference's trap of LittleEndianByteReader.byte() (App. A L4).
+    static constexpr uint32_t kSymbolBytes = 48;
+    uint64_t win_base;          // input offset of lane 0's dword (a multiple of 4); far away: no window loaded
     uint32_t win;               // this lane's dword
     uint32_t prev_byte;         // out[pos - 1] (0 when the dictionary is empty): the literal coder's context, kept in a register
     SWC_HD void win_load(uint64_t at) {
@@ -84,11 +109,13 @@ struct Decoder {
         else for (uint32_t k = 0; k < 4; k++) if (o + k < n) w |= (uint32_t)in[o + k] << (8 * k);
         win = w;
     }
-    SWC_HD uint8_t next_byte() {  // LittleEndianByteReader.byte(): past the end is a trap (App. A L4)
-        if (ip >= n) { trap = true; return 0; }
-        if (WAVE == 1) return in[ip++];
-        if (ip - win_base >= 4ull * WAVE) win_load(ip);
-        const uint32_t k = (uint32_t)(ip - win_base);
+    SWC_HD void ensure_window() {
+        if (WAVE != 1 && ip - win_base > 4ull * WAVE - kSymbolBytes) win_load(ip);
+    }
+    SWC_HD bool trapped() const { return trap || ip > n; }
+    SWC_HD uint8_t next_byte() {
+        if (WAVE == 1) { const uint64_t i = ip++; return i < n ? in[i] : (uint8_t)0; }
+        const uint32_t k = (uint32_t)(ip - win_base);   // < 4 * WAVE: ensure_window() ran within the last kSymbolBytes bytes
         ip++;
 #if defined(__HIP_DEVICE_COMPILE__)
         const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)win, __builtin_amdgcn_readfirstlane((int)(k >> 2)));   // (the index is the same in every lane: said so, or the compiler loops over the lanes)
@@ -200,6 +227,7 @@ struct Decoder {
 
     // put(): LZMADecoder.swift:288-294.  One byte, written by lane 0.
     SWC_HD void put(uint8_t b) {
+        SWC_LZMA_PROF(9)
         if (pos < cap) { if (lane == 0) out[pos] = b; }
         else overflow = true;
         prev_byte = b;
@@ -208,6 +236,7 @@ struct Decoder {
     }
     // byte(at:): LZMADecoder.swift:296-298 -- out[distance <= dictEnd ? dictEnd - distance : dictSize - distance + dictEnd]
     SWC_HD uint8_t byte_at(uint64_t distance) {
+        SWC_LZMA_PROF(2)
         uint64_t idx;
         if (distance <= pos) idx = pos - distance;
         else { trap = true; return 0; }  // the wrap branch indexes at or past out.count (dictSize >= distance): Swift trap
@@ -216,6 +245,8 @@ struct Decoder {
     }
     // `len` bytes from `distance` back, spread over the wave (LZMADecoder.swift:278-282).
     SWC_HD void copy_match(uint64_t distance, uint32_t len) {
+        SWC_LZMA_PROF(1)
+        SWC_LZMA_COUNT(5, 1);
         if (pos + len <= cap) {
             gptr dst = out + pos;
             uint32_t last = 0;   // the byte this lane wrote last: the lane that wrote dst[len - 1] holds the new prev_byte
@@ -240,7 +271,9 @@ struct Decoder {
 
     // LZMADecoder.swift:107-284.  Returns an swc_status.
     SWC_HD int decode() {
+        SWC_LZMA_PROF(0)
         if (n - ip < 5) return SWC_E_LZMA_RANGE_DECODER_INIT_ERROR;  // LZMARangeDecoder.swift:21
+        ensure_window();
         const uint8_t first = next_byte();
         code = 0;
         for (int i = 0; i < 4; i++) code = (code << 8) | next_byte();  // uint32().byteSwapped
@@ -252,13 +285,18 @@ struct Decoder {
         const bool spill = lit_bits > lds_bits;
 
         for (;;) {
-            if (trap) return SWC_E_REF_TRAP;
+            if (trapped()) return SWC_E_REF_TRAP;
             if (overflow) return SWC_E_CAPACITY;
+            ensure_window();
             if (uncompressed_size == 0 && code == 0) break;  // :114
             const int pos_state = (int)(pos & ((1u << pb) - 1));
-            if (bit(&probs[P_IS_MATCH + (state << 4) + pos_state]) == 0) {
-                if (trap) return SWC_E_REF_TRAP;
+            int is_match;
+            { SWC_LZMA_PROF(8) is_match = bit(&probs[P_IS_MATCH + (state << 4) + pos_state]); }
+            if (is_match == 0) {
+                if (trapped()) return SWC_E_REF_TRAP;
                 if (uncompressed_size == 0) return SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :121
+                SWC_LZMA_PROF(3)
+                SWC_LZMA_COUNT(6, 1);
                 const uint32_t prev = pos == dict_start ? 0u : prev_byte;
                 const uint32_t lit_state = (uint32_t)(((pos & ((1u << lp) - 1)) << lc) + (prev >> (8 - lc)));
                 int symbol = 1;
@@ -266,8 +304,10 @@ struct Decoder {
                     uint16_t* lpb = &probs[P_LITERAL + lit_state * 0x300];
                     uint32_t pr;
                     if (state >= 7) {
+                        SWC_LZMA_PROF(10)
+                        SWC_LZMA_COUNT(11, 1);
                         uint32_t match_byte = byte_at(rep0 + 1);
-                        if (trap) return SWC_E_REF_TRAP;
+                        if (trapped()) return SWC_E_REF_TRAP;
                         int match_bit = (match_byte >> 7) & 1;
                         pr = lpb[((1 + match_bit) << 8) + symbol];
                         bool matched = true;
@@ -297,7 +337,7 @@ struct Decoder {
                     SWC_AS_GLOBAL uint16_t* lpb = lit_spill + (size_t)lit_state * 0x300;
                     if (state >= 7) {
                         uint32_t match_byte = byte_at(rep0 + 1);
-                        if (trap) return SWC_E_REF_TRAP;
+                        if (trapped()) return SWC_E_REF_TRAP;
                         do {
                             const int match_bit = (match_byte >> 7) & 1;
                             match_byte = (match_byte << 1) & 0xFF;
@@ -308,26 +348,29 @@ struct Decoder {
                     }
                     while (symbol < 0x100) symbol = (symbol << 1) | bit_spill(&lpb[symbol]);
                 }
-                if (trap) return SWC_E_REF_TRAP;
+                if (trapped()) return SWC_E_REF_TRAP;
                 uncompressed_size -= 1;
                 put((uint8_t)(symbol - 0x100));
                 state = state < 4 ? 0 : state < 10 ? state - 3 : state - 6;
                 continue;
             }
-            if (trap) return SWC_E_REF_TRAP;
+            if (trapped()) return SWC_E_REF_TRAP;
 
             uint32_t len;
+            {
+            SWC_LZMA_PROF(4)
             if (bit(&probs[P_IS_REP + state]) != 0) {
-                if (trap) return SWC_E_REF_TRAP;
+                if (trapped()) return SWC_E_REF_TRAP;
                 if (uncompressed_size == 0) return SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :178
                 if (pos == dict_start) return SWC_E_LZMA_WINDOW_IS_EMPTY;                  // :181
                 if (bit(&probs[P_IS_REP_G0 + state]) == 0) {
                     if ((state << 4) + pos_state >= 191) return SWC_E_REF_TRAP;            // reference index 241+... == 432
                     if (bit(&probs[P_IS_REP0_LONG + (state << 4) + pos_state]) == 0) {
-                        if (trap) return SWC_E_REF_TRAP;
+                        if (trapped()) return SWC_E_REF_TRAP;
                         state = state < 7 ? 9 : 11;
+                        SWC_LZMA_COUNT(7, 1);
                         const uint8_t b = byte_at(rep0 + 1);
-                        if (trap) return SWC_E_REF_TRAP;
+                        if (trapped()) return SWC_E_REF_TRAP;
                         put(b);
                         uncompressed_size -= 1;
                         continue;
@@ -369,7 +412,7 @@ struct Decoder {
                     }
                     rep0 = dist;
                 }
-                if (trap) return SWC_E_REF_TRAP;
+                if (trapped()) return SWC_E_REF_TRAP;
                 if (rep0 == 0xFFFFFFFFull) {                                               // :260 end marker
                     if (code != 0) return SWC_E_LZMA_RANGE_DECODER_FINISH_ERROR;           // :261
                     break;
@@ -377,14 +420,15 @@ struct Decoder {
                 if (uncompressed_size == 0) return SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :266
                 if (rep0 >= dict_size || (rep0 > pos && pos < dict_size)) return SWC_E_LZMA_NOT_ENOUGH_TO_REPEAT;  // :269
             }
-            if (trap) return SWC_E_REF_TRAP;
+            }
+            if (trapped()) return SWC_E_REF_TRAP;
             len += 2;
             if (uncompressed_size > -1 && uncompressed_size < (int64_t)len) return SWC_E_LZMA_REPEAT_WILL_EXCEED;  // :275
             if (rep0 + 1 > pos) return SWC_E_REF_TRAP;  // byte(at:) would index past out.count (App. A L2)
             copy_match(rep0 + 1, len);
             uncompressed_size -= len;
         }
-        if (trap) return SWC_E_REF_TRAP;
+        if (trapped()) return SWC_E_REF_TRAP;
         if (overflow) return SWC_E_CAPACITY;
         return SWC_OK;
     }
@@ -397,13 +441,14 @@ struct Decoder {
         uint32_t ds = (uint32_t)(2 | (bits & 1)) << (bits / 2 + 11);
         dict_size = ds < 4096 ? 4096 : ds;                               // didSet clamp, LZMAProperties.swift:26-32
         for (;;) {
+            ensure_window();
             const uint32_t control = next_byte();                        // :36
-            if (trap) return SWC_E_REF_TRAP;
+            if (trapped()) return SWC_E_REF_TRAP;
             if (control == 0) return SWC_OK;
             if (control == 1 || control == 2) {
                 if (control == 1) reset_dictionary();
                 const uint32_t b1 = next_byte(), b2 = next_byte();       // decodeUncompressed :84-89
-                if (trap) return SWC_E_REF_TRAP;
+                if (trapped()) return SWC_E_REF_TRAP;
                 const uint64_t size = ((uint64_t)b1 << 8) + b2 + 1;
                 if (n - ip < size) return SWC_E_REF_TRAP;                // byte() past the end inside the copy loop
                 if (pos + size <= cap) {
@@ -424,12 +469,12 @@ struct Decoder {
             const int64_t unpack = ((int64_t)(control & 0x1F) << 16) + ((int64_t)u1 << 8) + u2 + 1;
             const uint32_t c1 = next_byte(), c2 = next_byte();
             const int64_t comp = ((int64_t)c1 << 8) + c2 + 1;
-            if (trap) return SWC_E_REF_TRAP;
+            if (trapped()) return SWC_E_REF_TRAP;
             if (reset == 1) {
                 reset_state_and_decoders();
             } else if (reset >= 2) {                                     // updateProperties :95-99
                 const uint32_t pbyte = next_byte();
-                if (trap) return SWC_E_REF_TRAP;
+                if (trapped()) return SWC_E_REF_TRAP;
                 if (pbyte >= 225) return SWC_E_LZMA_WRONG_PROPERTIES;
                 lc = pbyte % 9; pb = (pbyte / 9) / 5; lp = (pbyte / 9) % 5;
                 reset_state_and_decoders();
@@ -447,7 +492,7 @@ struct Decoder {
 // job.aux: LZMA2 = dictionary-size byte; LZMA = lc | lp << 8 | pb << 16.
 // job.dict_len: LZMA = declared uncompressed size (UINT64_MAX = unknown); job.dict (reinterpreted) = dictionary size.
 template <int WAVE>
-SWC_HD void lzma_job(Job& job, bool is_lzma2, uint16_t* probs, SWC_AS_GLOBAL uint16_t* lit_spill, int lane, int lds_bits = kMaxLdsLitBits) {
+SWC_HD void lzma_job(Job& job, bool is_lzma2, uint16_t* probs, SWC_AS_GLOBAL uint16_t* lit_spill, int lane, int lds_bits = kMaxLdsLitBits, uint64_t* prof = nullptr) {
     Decoder<WAVE> d;
     d.in = (gcptr)job.in; d.n = job.in_len; d.ip = 0;
     d.out = (gptr)job.out; d.cap = job.out_cap; d.pos = 0;
@@ -478,8 +523,13 @@ SWC_HD void lzma_job(Job& job, bool is_lzma2, uint16_t* probs, SWC_AS_GLOBAL uin
         }
     }
     job.out_len = d.pos;
-    job.in_consumed = d.ip;
+    job.in_consumed = d.ip < d.n ? d.ip : d.n;   // (a read past the end keeps counting, see next_byte())
     job.status = st;
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+    if (prof && lane == 0) for (int k = 0; k < 16; k++) prof[k] = d.pacc[k];
+#else
+    (void)prof;
+#endif
 }
 
 }  // namespace lzma

@@ -45,6 +45,12 @@ SWC_D void wave_fence() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
 }
+// all of this wave's vector-memory operations (loads and stores) have completed
+SWC_D void vmem_fence() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+}
 #define SIMT_BEGIN(t, N) { const int t = (int)threadIdx.x; (void)t;
 #define SIMT_END }
 #define SIMT_END_BARRIER } ::swc::simt::lds_barrier();
@@ -63,6 +69,7 @@ struct PT {
 };
 inline void lds_barrier() {}
 inline void wave_fence() {}
+inline void vmem_fence() {}
 inline int g_order = 0;   // 0 forward, 1 reverse, 2 shuffled
 inline int order(int i, int n) {
     if (g_order == 1) return n - 1 - i;
