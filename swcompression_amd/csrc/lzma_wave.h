@@ -130,10 +130,8 @@ struct Decoder {
             code = (code << 8) | next_byte();
         }
     }
-    SWC_HD int bit(uint16_t* p) { return bit_with(*p, p); }
-    // The decision with the cell's value already in hand: walking a bit tree, the two cells the NEXT decision can use are
-    // read while this one is computed (tree(), the literal loops), so that the LDS latency leaves the serial chain.
-    SWC_HD int bit_with(uint32_t pr, uint16_t* p) {  // LZMARangeDecoder.swift:65-80
+    SWC_HD int bit(uint16_t* p) {  // LZMARangeDecoder.swift:65-80
+        const uint32_t pr = *p;
         uint32_t bound = (range >> 11) * pr;
         int sym;
         if (code < bound) {
@@ -181,14 +179,7 @@ struct Decoder {
     }
     SWC_HD int tree(uint16_t* p, int nbits) {  // LZMABitTreeDecoder.swift:18-24
         int m = 1;
-        uint32_t pr = p[1];
-        for (int i = 0; i < nbits; i++) {
-            uint32_t p0 = 0, p1 = 0;
-            if (i + 1 < nbits) { p0 = p[2 * m]; p1 = p[2 * m + 1]; }   // both children, before the decision that picks one
-            const int b = bit_with(pr, &p[m]);
-            pr = b ? p1 : p0;
-            m = (m << 1) + b;
-        }
+        for (int i = 0; i < nbits; i++) m = (m << 1) + bit(&p[m]);
         return m - (1 << nbits);
     }
     SWC_HD int tree_reverse(uint16_t* p, int limit, int start, int bits) {  // :26-43
@@ -302,37 +293,20 @@ struct Decoder {
                 int symbol = 1;
                 if (!spill) {
                     uint16_t* lpb = &probs[P_LITERAL + lit_state * 0x300];
-                    uint32_t pr;
                     if (state >= 7) {
                         SWC_LZMA_PROF(10)
                         SWC_LZMA_COUNT(11, 1);
                         uint32_t match_byte = byte_at(rep0 + 1);
                         if (trapped()) return SWC_E_REF_TRAP;
-                        int match_bit = (match_byte >> 7) & 1;
-                        pr = lpb[((1 + match_bit) << 8) + symbol];
-                        bool matched = true;
                         do {
+                            const int match_bit = (match_byte >> 7) & 1;
                             match_byte = (match_byte << 1) & 0xFF;
-                            const int next_mb = (match_byte >> 7) & 1;
-                            // the cell of the next decision, for either outcome of this one: bit == match bit stays in the
-                            // matched coder (with the next match bit), the other outcome falls to the plain coder
-                            const uint32_t same = lpb[((1 + next_mb) << 8) + (((symbol << 1) | match_bit) & 0xFF)];   // (& 0xFF: the last level reads a cell it does not use)
-                            const uint32_t diff = lpb[(symbol << 1) | (match_bit ^ 1)];
-                            const int b = bit_with(pr, &lpb[((1 + match_bit) << 8) + symbol]);
+                            const int b = bit(&lpb[((1 + match_bit) << 8) + symbol]);
                             symbol = (symbol << 1) | b;
-                            matched = match_bit == b;
-                            pr = matched ? same : diff;
-                            match_bit = next_mb;
-                        } while (matched && symbol < 0x100);
-                    } else {
-                        pr = lpb[symbol];
+                            if (match_bit != b) break;
+                        } while (symbol < 0x100);
                     }
-                    while (symbol < 0x100) {
-                        const uint32_t p0 = lpb[(symbol << 1) & 0x1FF], p1 = lpb[((symbol << 1) | 1) & 0x1FF];   // (& 0x1FF: the last level reads cells it does not use)
-                        const int b = bit_with(pr, &lpb[symbol]);
-                        pr = b ? p1 : p0;
-                        symbol = (symbol << 1) | b;
-                    }
+                    while (symbol < 0x100) symbol = (symbol << 1) | bit(&lpb[symbol]);
                 } else {
                     SWC_AS_GLOBAL uint16_t* lpb = lit_spill + (size_t)lit_state * 0x300;
                     if (state >= 7) {

@@ -8,6 +8,8 @@
 // (the shape of a literal) over a model in LDS and random input bytes, per wave W = 1 / 2 / 3 waves per SIMD:
 //   0  as the library's Decoder::bit() is written: wave-uniform C++, branch per decision, model cell read inside the chain
 //   1  the same with both children of a node read BEFORE the decision that picks one (the library's tree(), round 3)
+//   3  form 0 with every value read from LDS declared wave-uniform (v_readfirstlane): range, code, the tree index and all
+//      branches on them move to the scalar unit (s_cmp / s_cbranch instead of exec-mask regions)
 //   2  branch-free and pinned to the vector pipes: every value a VGPR, selects instead of branches, children and the next input
 //      byte prefetched -- the chain is then ~9 dependent VALU instructions per decision
 // Usage: lzma_chain [trees]
@@ -36,7 +38,24 @@ __global__ __launch_bounds__(64) void chain(unsigned long long* cycles, unsigned
     State s{0xFFFFFFFFu, 0x12345678u ^ blockIdx.x, 0};
     unsigned acc = 0;
     const unsigned long long t0 = __builtin_readcyclecounter();
-    if (MODE == 0 || MODE == 1) {
+    if (MODE == 3) {
+        unsigned range = __builtin_amdgcn_readfirstlane(s.range), code = __builtin_amdgcn_readfirstlane(s.code), ip = 0;
+        for (int t = 0; t < trees; t++) {
+            unsigned short* p = probs + 1847 + (acc & 7) * 0x300;
+            unsigned m = 1;
+            for (int i = 0; i < 8; i++) {
+                const unsigned pr = __builtin_amdgcn_readfirstlane((unsigned)p[m]);
+                const unsigned bound = (range >> 11) * pr;
+                unsigned b;
+                if (code < bound) { p[m] = (unsigned short)(pr + ((2048u - pr) >> 5)); range = bound; b = 0; }
+                else { p[m] = (unsigned short)(pr - (pr >> 5)); code -= bound; range -= bound; b = 1; }
+                if (range < (1u << 24)) { range <<= 8; code = (code << 8) | __builtin_amdgcn_readfirstlane((unsigned)in[(ip++) & (kIn - 1)]); }
+                m = 2 * m + b;
+            }
+            acc = __builtin_amdgcn_readfirstlane(acc * 31 + m);
+        }
+        s.range = range; s.code = code; s.ip = ip;
+    } else if (MODE == 0 || MODE == 1) {
         for (int t = 0; t < trees; t++) {
             unsigned short* p = probs + 1847 + (acc & 7) * 0x300;     // a literal coder picked by what came before
             unsigned m = 1;
@@ -99,9 +118,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dc, sizeof(unsigned long long) * cus * 16));
     CK(hipMalloc(&ds, sizeof(unsigned) * cus * 16));
     std::vector<unsigned long long> h(cus * 16);
-    const char* names[3] = {"0 library form (uniform C++, cell read in the chain)", "1 + children read before the decision", "2 branch-free, all VGPR, children + input prefetched"};
+    const char* names[4] = {"0 library form (uniform C++, cell read in the chain)", "1 + children read before the decision", "2 branch-free, all VGPR, children + input prefetched", "3 form 0 on the scalar unit (readfirstlane per cell)"};
     printf("%d trees of 8 decisions per wave; cycles per DECISION (median over waves)\n%-58s %10s %10s %10s\n", trees, "form", "4 waves/CU", "8 waves/CU", "10 waves/CU");
-    for (int mode = 0; mode < 3; mode++) {
+    for (int mode = 0; mode < 4; mode++) {
         printf("%-58s", names[mode]);
         for (int wpc : {4, 8, 10}) {
             const int grid = cus * wpc;
@@ -109,6 +128,7 @@ int main(int argc, char** argv) {
                 if (mode == 0) hipLaunchKernelGGL(chain<0>, dim3(grid), dim3(64), 0, 0, dc, ds, trees);
                 if (mode == 1) hipLaunchKernelGGL(chain<1>, dim3(grid), dim3(64), 0, 0, dc, ds, trees);
                 if (mode == 2) hipLaunchKernelGGL(chain<2>, dim3(grid), dim3(64), 0, 0, dc, ds, trees);
+                if (mode == 3) hipLaunchKernelGGL(chain<3>, dim3(grid), dim3(64), 0, 0, dc, ds, trees);
                 CK(hipDeviceSynchronize());
             }
             CK(hipMemcpy(h.data(), dc, sizeof(unsigned long long) * grid, hipMemcpyDeviceToHost));
