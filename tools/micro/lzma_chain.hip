@@ -10,6 +10,9 @@
 //   1  the same with both children of a node read BEFORE the decision that picks one (the library's tree(), round 3)
 //   3  form 0 with every value read from LDS declared wave-uniform (v_readfirstlane): range, code, the tree index and all
 //      branches on them move to the scalar unit (s_cmp / s_cbranch instead of exec-mask regions)
+//   4  form 0 with the cells of TWO levels ahead in flight: the four grandchildren of a node are one aligned 8-byte read
+//      issued as soon as the node is known; the pair of children comes out of the previous such read by a select, the
+//      cell of the next decision out of that pair -- no LDS read is left in the decision chain
 //   2  branch-free and pinned to the vector pipes: every value a VGPR, selects instead of branches, children and the next input
 //      byte prefetched -- the chain is then ~9 dependent VALU instructions per decision
 // Usage: lzma_chain [trees]
@@ -30,7 +33,7 @@ __device__ __forceinline__ unsigned next_byte(const unsigned char* in, State& s)
 
 template <int MODE>
 __global__ __launch_bounds__(64) void chain(unsigned long long* cycles, unsigned* sink, int trees) {
-    __shared__ unsigned short probs[kCells + 8];
+    __shared__ __attribute__((aligned(16))) unsigned short probs[kCells + 8];
     __shared__ unsigned char in[kIn];
     for (int i = threadIdx.x; i < kCells; i += 64) probs[i] = 1024;
     for (int i = threadIdx.x; i < kIn; i += 64) in[i] = (unsigned char)(i * 197 + 13 + blockIdx.x);
@@ -38,7 +41,31 @@ __global__ __launch_bounds__(64) void chain(unsigned long long* cycles, unsigned
     State s{0xFFFFFFFFu, 0x12345678u ^ blockIdx.x, 0};
     unsigned acc = 0;
     const unsigned long long t0 = __builtin_readcyclecounter();
-    if (MODE == 3) {
+    if (MODE == 4) {
+        for (int t = 0; t < trees; t++) {
+            const unsigned base = 1848 + (acc & 7) * 0x300;   // a multiple of four cells: the 8-byte reads are aligned
+            unsigned short* p = probs + base;
+            const uint2* p4 = (const uint2*)p;               // p4[m] = cells 4m .. 4m + 3
+            unsigned m = 1;
+            const uint2 r0 = p4[0];
+            uint2 g = p4[1];                                  // grandchildren of the root: cells 4..7
+            unsigned pr = r0.x >> 16;                         // cell 1
+            unsigned pair = r0.y;                             // cells 2, 3: the root's children
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const unsigned bound = (s.range >> 11) * pr;
+                unsigned b;
+                if (s.code < bound) { p[m] = (unsigned short)(pr + ((2048u - pr) >> 5)); s.range = bound; b = 0; }
+                else { p[m] = (unsigned short)(pr - (pr >> 5)); s.code -= bound; s.range -= bound; b = 1; }
+                if (s.range < (1u << 24)) { s.range <<= 8; s.code = (s.code << 8) | next_byte(in, s); }
+                pr = b ? pair >> 16 : pair & 0xFFFFu;         // the child taken (level i + 1)
+                pair = b ? g.y : g.x;                         // its children (level i + 2), from the read issued one decision ago
+                m = 2 * m + b;
+                if (i + 3 < 8) g = p4[m];                     // its grandchildren (level i + 3): needed at the end of the NEXT decision
+            }
+            acc = acc * 31 + m;
+        }
+    } else if (MODE == 3) {
         unsigned range = __builtin_amdgcn_readfirstlane(s.range), code = __builtin_amdgcn_readfirstlane(s.code), ip = 0;
         for (int t = 0; t < trees; t++) {
             unsigned short* p = probs + 1847 + (acc & 7) * 0x300;
@@ -118,9 +145,9 @@ int main(int argc, char** argv) {
     CK(hipMalloc(&dc, sizeof(unsigned long long) * cus * 16));
     CK(hipMalloc(&ds, sizeof(unsigned) * cus * 16));
     std::vector<unsigned long long> h(cus * 16);
-    const char* names[4] = {"0 library form (uniform C++, cell read in the chain)", "1 + children read before the decision", "2 branch-free, all VGPR, children + input prefetched", "3 form 0 on the scalar unit (readfirstlane per cell)"};
+    const char* names[5] = {"0 library form (uniform C++, cell read in the chain)", "1 + children read before the decision", "2 branch-free, all VGPR, children + input prefetched", "3 form 0 on the scalar unit (readfirstlane per cell)", "4 form 0, cells of two levels ahead in flight"};
     printf("%d trees of 8 decisions per wave; cycles per DECISION (median over waves)\n%-58s %10s %10s %10s\n", trees, "form", "4 waves/CU", "8 waves/CU", "10 waves/CU");
-    for (int mode = 0; mode < 4; mode++) {
+    for (int mode = 0; mode < 5; mode++) {
         printf("%-58s", names[mode]);
         for (int wpc : {4, 8, 10}) {
             const int grid = cus * wpc;
@@ -129,6 +156,7 @@ int main(int argc, char** argv) {
                 if (mode == 1) hipLaunchKernelGGL(chain<1>, dim3(grid), dim3(64), 0, 0, dc, ds, trees);
                 if (mode == 2) hipLaunchKernelGGL(chain<2>, dim3(grid), dim3(64), 0, 0, dc, ds, trees);
                 if (mode == 3) hipLaunchKernelGGL(chain<3>, dim3(grid), dim3(64), 0, 0, dc, ds, trees);
+                if (mode == 4) hipLaunchKernelGGL(chain<4>, dim3(grid), dim3(64), 0, 0, dc, ds, trees);
                 CK(hipDeviceSynchronize());
             }
             CK(hipMemcpy(h.data(), dc, sizeof(unsigned long long) * grid, hipMemcpyDeviceToHost));
