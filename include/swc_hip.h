@@ -243,9 +243,11 @@ void swc_free(void* p);
 /* 1 if a gfx950 device is usable, 0 otherwise (then every decode entry point returns SWC_E_DEVICE) */
 int swc_device_available(void);
 const char* swc_version(void);
-/* Measurement knob (never changes results): "phase_timing" = 0 | 1 (HIP events between the kernels of the batch
- * launches of the CALLING THREAD -- like the launch stream and the staging buffers, measurement state is per thread).
- * Meant for benchmarking. */
+/* Measurement knobs (never change results), meant for benchmarking:
+ *   "phase_timing" = 0 | 1      HIP events between the kernels of the batch launches of the CALLING THREAD (like the launch
+ *                               stream and the staging buffers, measurement state is per thread);
+ *   "lzma_coder_cache" = 1 | 0  process-wide: LZMA / LZMA2 launches with a workspace keep four literal coders in LDS as a
+ *                               cache (16 streams per CU, default) or all coders of lc + lp <= 3 (10 streams per CU). */
 int swc_set_tuning(const char* key, int value);
 /* Profile builds of the library (-DSWC_PROFILE) only: a device buffer of 32 x uint64 per job of the next Deflate
  * launches that the kernels fill with cycle counts per stage (tools/exp_profile.py).  NULL switches it off.  A no-op in

@@ -90,7 +90,23 @@ def p_mix(n, seed):
     return b"".join(parts)[:n]
 
 
-PAYLOADS = {"text": p_text, "rep": p_rep, "zero": p_zero, "rand": p_rand, "mix": p_mix}
+def p_bin(n, seed):
+    """Binary records: 16-byte rows of a little-endian counter, two 16-bit samples of a random walk, a float32 of a slowly
+    varying value and four bytes of a small alphabet with the top bit set -- compressible, and its bytes fall into all eight
+    classes of "top three bits of the previous byte" (the worst case of the LZMA literal-coder cache)."""
+    rng = np.random.Generator(np.random.PCG64(SEED_BASE + seed))
+    rows = n // 16 + 1
+    rec = np.zeros((rows, 16), dtype=np.uint8)
+    rec[:, 0:4] = (np.arange(rows, dtype=np.uint32) * 3 + int(rng.integers(0, 1 << 20))).view(np.uint8).reshape(rows, 4)
+    walk = np.cumsum(rng.integers(-40, 41, size=(rows, 2)), axis=0).astype(np.int16)
+    rec[:, 4:8] = walk.view(np.uint8).reshape(rows, 4)
+    val = (1000.0 + np.cumsum(rng.normal(0, 0.01, rows))).astype(np.float32)
+    rec[:, 8:12] = val.view(np.uint8).reshape(rows, 4)
+    rec[:, 12:16] = rng.choice(np.array([0x80, 0x9C, 0xA5, 0xC3, 0xE2, 0xFF, 0x41, 0x0A], dtype=np.uint8), size=(rows, 4))
+    return rec.reshape(-1)[:n].tobytes()
+
+
+PAYLOADS = {"text": p_text, "rep": p_rep, "zero": p_zero, "rand": p_rand, "mix": p_mix, "bin": p_bin}
 
 
 # ------------------------------------------------------------------------------- Deflate / gzip / zlib

@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <cstddef>
 #include <mutex>
+#include <atomic>
 #include "swc_common.h"
 #include "inflate_lane.h"
 #include "inflate_sync.h"
@@ -189,6 +190,8 @@ hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_
 // SWC_E_NEED_WORKSPACE.  `spill` holds kLzmaSpillBytes per job.
 constexpr size_t kLzmaSpillBytes = (size_t)(0x300u << 12) * 2;
 
+// LDSBITS >= 0: the literal coders of lc + lp <= LDSBITS in LDS (no workspace: 4 -> 28 KB, 5 streams per CU);
+// LDSBITS < 0: LDS as a cache of four literal coders, all of them in the workspace (9,840 B, 16 streams per CU; lzma_wave.h)
 template <bool LZMA2, int LDSBITS>
 __global__ __launch_bounds__(64) void swc_lzma_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* spill, uint64_t* prof) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lzma_lds[];
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(64) void swc_lzma_kernel(Job* __restrict__ jobs, ui
     if (g >= n) return;
     Job job = jobs[g];
     SWC_AS_GLOBAL uint16_t* sp = spill ? (SWC_AS_GLOBAL uint16_t*)(spill + (size_t)g * kLzmaSpillBytes) : nullptr;
-    lzma::lzma_job<kWave>(job, LZMA2, lzma_lds, sp, (int)threadIdx.x, LDSBITS, prof ? prof + 32 * (size_t)g : nullptr);
+    lzma::lzma_job<kWave>(job, LZMA2, lzma_lds, sp, (int)threadIdx.x, LDSBITS < 0 ? 0 : LDSBITS, prof ? prof + 32 * (size_t)g : nullptr, LDSBITS < 0);
     if (threadIdx.x == 0) {
         jobs[g].out_len = job.out_len;
         jobs[g].in_consumed = job.in_consumed;
@@ -206,13 +209,21 @@ __global__ __launch_bounds__(64) void swc_lzma_kernel(Job* __restrict__ jobs, ui
 
 size_t lzma_spill_bytes_per_job() { return kLzmaSpillBytes; }
 
+// "lzma_coder_cache" (swc_set_tuning): 1 = LDS as a cache of four literal coders (default), 0 = round 2's layout (all eight
+// coders of lc + lp <= 3 in LDS, 10 streams per CU) -- kept for A/B measurements; both produce the same bytes.
+static std::atomic<int> g_lzma_cache{1};
+void set_lzma_coder_cache(int on) { g_lzma_cache = on; }
+
 hipError_t launch_lzma(bool lzma2, Job* jobs, size_t n, void* spill, hipStream_t stream) {
     if (n == 0) return hipSuccess;
     dim3 grid((unsigned)n), block(kWave);
     g_pt.begin(stream);
-    if (spill) {
+    if (spill && !g_lzma_cache) {
         if (lzma2) hipLaunchKernelGGL((swc_lzma_kernel<true, 3>), grid, block, lzma::lds_bytes_for(3), stream, jobs, (uint32_t)n, (uint8_t*)spill, g_prof);
         else hipLaunchKernelGGL((swc_lzma_kernel<false, 3>), grid, block, lzma::lds_bytes_for(3), stream, jobs, (uint32_t)n, (uint8_t*)spill, g_prof);
+    } else if (spill) {
+        if (lzma2) hipLaunchKernelGGL((swc_lzma_kernel<true, -1>), grid, block, lzma::lds_bytes_cached(), stream, jobs, (uint32_t)n, (uint8_t*)spill, g_prof);
+        else hipLaunchKernelGGL((swc_lzma_kernel<false, -1>), grid, block, lzma::lds_bytes_cached(), stream, jobs, (uint32_t)n, (uint8_t*)spill, g_prof);
     } else {
         if (lzma2) hipLaunchKernelGGL((swc_lzma_kernel<true, 4>), grid, block, lzma::lds_bytes_for(4), stream, jobs, (uint32_t)n, (uint8_t*)nullptr, g_prof);
         else hipLaunchKernelGGL((swc_lzma_kernel<false, 4>), grid, block, lzma::lds_bytes_for(4), stream, jobs, (uint32_t)n, (uint8_t*)nullptr, g_prof);

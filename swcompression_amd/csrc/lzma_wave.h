@@ -17,6 +17,7 @@
 #define SWC_LZMA_WAVE_H
 
 #include "swc_common.h"
+#include "simt.h"
 
 namespace swc {
 namespace lzma {
@@ -42,6 +43,17 @@ constexpr int kProbCells = P_LITERAL + (0x300 << kMaxLdsLitBits);  // 14,135
 // 3 (what xz writes: lc 3, lp 0) -> 15,984 B = 10 streams per CU; 4 -> 28,272 B = 5 streams per CU
 constexpr int lds_bytes_for(int bits) { return (((P_LITERAL + (0x300 << bits)) * 2 + 15) / 16) * 16; }
 constexpr int kLdsBytesPerWave = lds_bytes_for(kMaxLdsLitBits);
+// LDS as a CACHE of the literal coders (round 3).  The kernel is latency-bound on one serial chain per stream, so its speed
+// is the number of streams a CU holds, and that is set by the model in LDS: 15,984 B with the eight literal coders of
+// lc + lp = 3 -> 10 streams.  A literal coder (0x300 cells) is picked by the top bits of the previous byte; data use few of
+// them at a time (text: four), so LDS keeps kCoderSlots of them and all coders live in the HBM workspace: 9,840 B -> 16
+// streams per CU.  A miss writes the victim back and loads the coder (1.5 KB each way, all lanes; a coder nobody has used
+// since the last model reset is filled with the initial value instead); slots are replaced round-robin.  Any lc + lp works
+// this way (the old path kept lc + lp <= 3 in LDS and decoded larger models cell by cell from HBM).
+constexpr int kCoderSlots = 4;
+constexpr int kSlotBase = (P_LITERAL + 3) & ~3;   // first cell of slot 0: dword-aligned copies
+constexpr int lds_bytes_cached() { return (((kSlotBase + 0x300 * kCoderSlots) * 2 + 15) / 16) * 16; }
+constexpr uint32_t kNoCoder = 0xFFFFFFFFu;
 constexpr int LEN_CHOICE = 0, LEN_CHOICE2 = 1, LEN_LOW = 2, LEN_MID = 2 + 128, LEN_HIGH = 2 + 256;
 
 // cycle accounting of profile builds (-DSWC_PROFILE, tools/exp_profile_lzma.py): a scope adds its cycles to one slot
@@ -74,7 +86,11 @@ struct Decoder {
     // ---- model -----------------------------------------------------------------------------------
     uint16_t* probs;            // LDS (host: heap) -- P_LITERAL + (0x300 << lds_bits) cells
     int lds_bits;               // literal coders with lc + lp <= lds_bits live in LDS, larger ones in lit_spill
-    SWC_AS_GLOBAL uint16_t* lit_spill;  // HBM literal coder when lc+lp > 4, else unused
+    SWC_AS_GLOBAL uint16_t* lit_spill;  // HBM literal coder when lc+lp > 4, else unused; cache mode: the home of all coders
+    bool cached = false;        // LDS holds kCoderSlots literal coders (see kCoderSlots); lit_spill is required
+    uint32_t tag0 = kNoCoder, tag1 = kNoCoder, tag2 = kNoCoder, tag3 = kNoCoder;   // the coder in each slot
+    uint32_t victim = 0;        // the slot the next miss replaces
+    uint64_t fresh = 0;         // bit c: coder c (c < 64) has not been used since the last reset -- its cells are all 1024, nothing to load
     bool have_model;
     int lc, lp, pb;
     uint64_t dict_size;
@@ -199,8 +215,56 @@ struct Decoder {
         return 16 + tree(&p[LEN_HIGH], 8);
     }
 
+    // The LDS copy of literal coder `c` (cache mode): a hit is four compares; see kCoderSlots.
+    SWC_HD uint16_t* literal_coder(uint32_t c) {
+        static_assert(kCoderSlots == 4, "four tags");
+        if (tag0 == c) return probs + kSlotBase;
+        if (tag1 == c) return probs + kSlotBase + 0x300;
+        if (tag2 == c) return probs + kSlotBase + 2 * 0x300;
+        if (tag3 == c) return probs + kSlotBase + 3 * 0x300;
+        const uint32_t v = victim;
+        victim = (victim + 1) & 3u;
+        const uint32_t old = v == 0 ? tag0 : v == 1 ? tag1 : v == 2 ? tag2 : tag3;
+        uint16_t* sp = probs + kSlotBase + v * 0x300;
+        uint32_t* sp32 = (uint32_t*)sp;
+        if (old != kNoCoder) {
+            SWC_AS_GLOBAL uint32_t* home = (SWC_AS_GLOBAL uint32_t*)(lit_spill + (size_t)old * 0x300);
+            for (int j = lane; j < 0x300 / 2; j += WAVE) home[j] = sp32[j];
+        }
+        if (c < 64 && ((fresh >> c) & 1u)) {
+            for (int j = lane; j < 0x300 / 2; j += WAVE) sp32[j] = 0x04000400u;
+            fresh &= ~(1ull << c);
+        } else {
+            // (a coder written back earlier comes back through the same lanes that stored it)
+            const SWC_AS_GLOBAL uint32_t* home = (const SWC_AS_GLOBAL uint32_t*)(lit_spill + (size_t)c * 0x300);
+            for (int j = lane; j < 0x300 / 2; j += WAVE) sp32[j] = home[j];
+        }
+        tag0 = v == 0 ? c : tag0; tag1 = v == 1 ? c : tag1; tag2 = v == 2 ? c : tag2; tag3 = v == 3 ? c : tag3;
+        simt::wave_fence();
+        return sp;
+    }
+
     // LZMADecoder.swift:79-100.  All lanes initialise a slice of the model.
     SWC_HD void reset_state_and_decoders() {
+        if (cached) {
+            state = 0;
+            rep0 = rep1 = rep2 = rep3 = 0;
+            need_ws = lit_spill == nullptr;
+            for (int i = lane; i < P_LITERAL; i += WAVE) probs[i] = 1024;
+            tag0 = tag1 = tag2 = tag3 = kNoCoder;   // (dropped, not written back: the model starts over)
+            victim = 0;
+            const int lit_bits = lc + lp;
+            if (lit_bits <= 6) {
+                fresh = lit_bits == 6 ? ~0ull : (1ull << (1u << lit_bits)) - 1ull;
+            } else {
+                fresh = 0;
+                const uint32_t cells = 0x300u << lit_bits;
+                if (lit_spill) for (uint32_t i = (uint32_t)lane; i < cells; i += WAVE) lit_spill[i] = 1024;
+            }
+            simt::wave_fence();
+            have_model = true;
+            return;
+        }
         state = 0;
         rep0 = rep1 = rep2 = rep3 = 0;
         need_ws = false;
@@ -273,7 +337,7 @@ struct Decoder {
         if (!have_model) return SWC_E_REF_TRAP;  // `probabilities` is still empty: index trap at :119
         if (need_ws) return SWC_E_NEED_WORKSPACE;
         const int lit_bits = lc + lp;
-        const bool spill = lit_bits > lds_bits;
+        const bool spill = !cached && lit_bits > lds_bits;
 
         for (;;) {
             if (trapped()) return SWC_E_REF_TRAP;
@@ -292,7 +356,7 @@ struct Decoder {
                 const uint32_t lit_state = (uint32_t)(((pos & ((1u << lp) - 1)) << lc) + (prev >> (8 - lc)));
                 int symbol = 1;
                 if (!spill) {
-                    uint16_t* lpb = &probs[P_LITERAL + lit_state * 0x300];
+                    uint16_t* lpb = cached ? literal_coder(lit_state) : &probs[P_LITERAL + lit_state * 0x300];
                     if (state >= 7) {
                         SWC_LZMA_PROF(10)
                         SWC_LZMA_COUNT(11, 1);
@@ -466,8 +530,9 @@ struct Decoder {
 // job.aux: LZMA2 = dictionary-size byte; LZMA = lc | lp << 8 | pb << 16.
 // job.dict_len: LZMA = declared uncompressed size (UINT64_MAX = unknown); job.dict (reinterpreted) = dictionary size.
 template <int WAVE>
-SWC_HD void lzma_job(Job& job, bool is_lzma2, uint16_t* probs, SWC_AS_GLOBAL uint16_t* lit_spill, int lane, int lds_bits = kMaxLdsLitBits, uint64_t* prof = nullptr) {
+SWC_HD void lzma_job(Job& job, bool is_lzma2, uint16_t* probs, SWC_AS_GLOBAL uint16_t* lit_spill, int lane, int lds_bits = kMaxLdsLitBits, uint64_t* prof = nullptr, bool cached = false) {
     Decoder<WAVE> d;
+    d.cached = cached;
     d.in = (gcptr)job.in; d.n = job.in_len; d.ip = 0;
     d.out = (gptr)job.out; d.cap = job.out_cap; d.pos = 0;
     d.lane = lane;

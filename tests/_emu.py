@@ -80,15 +80,19 @@ def lz4_block(inputs, caps, dicts=None, misalign=0):
     return run_batch("emu_lz4_block", inputs, caps, dicts=dicts, misalign=misalign)
 
 
-def lzma2(inputs, caps, dict_bytes):
-    return run_batch("emu_lzma", inputs, caps, aux=dict_bytes, fn_args=(C.c_int(1),))
+LZMA_MODE = 0   # 0: literal coders in LDS / cell-by-cell spill (kernel without a workspace); 1: LDS as a cache of four coders
 
 
-def lzma(inputs, caps, props, dict_sizes, sizes):
+def lzma2(inputs, caps, dict_bytes, mode=None):
+    return run_batch("emu_lzma_mode", inputs, caps, aux=dict_bytes, fn_args=(C.c_int(1), C.c_int(LZMA_MODE if mode is None else mode)))
+
+
+def lzma(inputs, caps, props, dict_sizes, sizes, mode=None):
     """props: list of (lc, lp, pb); sizes: declared uncompressed size or -1."""
     aux = [lc | (lp << 8) | (pb << 16) for lc, lp, pb in props]
     extra = [s & 0xFFFFFFFFFFFFFFFF for s in sizes]
-    return run_batch("emu_lzma", inputs, caps, aux=aux, extra=extra, fn_args=(C.c_int(0),), dict_ptr_values=dict_sizes)
+    return run_batch("emu_lzma_mode", inputs, caps, aux=aux, extra=extra, fn_args=(C.c_int(0), C.c_int(LZMA_MODE if mode is None else mode)),
+                     dict_ptr_values=dict_sizes)
 
 
 def bzip2_block(streams, body_bits, crcs, caps, lcap=1000000):

@@ -56,14 +56,18 @@ extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {
 
 // LZMA: the wave-uniform decode chain is run as a single logical lane (WAVE = 1); the literal-coder
 // spill (lc+lp > 4) is always available, as the single-shot C ABI guarantees on the device.
-extern "C" void emu_lzma(swc::Job* jobs, size_t n, int is_lzma2) {
+// mode 0: every literal coder in LDS up to lc + lp = 4, larger models cell by cell from the spill (the kernel without a
+// workspace, and the old spill path); mode 1: LDS as a cache of four literal coders (the kernel with a workspace).
+extern "C" void emu_lzma_mode(swc::Job* jobs, size_t n, int is_lzma2, int mode) {
     std::vector<uint16_t> probs(swc::lzma::kProbCells + 8);
     std::vector<uint16_t> spill((size_t)0x300 << 12);
     for (size_t g = 0; g < n; g++) {
         std::fill(probs.begin(), probs.end(), (uint16_t)0xBEEF);
-        swc::lzma::lzma_job<1>(jobs[g], is_lzma2 != 0, probs.data(), spill.data(), 0);
+        std::fill(spill.begin(), spill.end(), (uint16_t)0xDEAD);
+        swc::lzma::lzma_job<1>(jobs[g], is_lzma2 != 0, probs.data(), spill.data(), 0, swc::lzma::kMaxLdsLitBits, nullptr, mode == 1);
     }
 }
+extern "C" void emu_lzma(swc::Job* jobs, size_t n, int is_lzma2) { emu_lzma_mode(jobs, n, is_lzma2, 0); }
 
 // BZip2: the three stages run back to back for each job, single logical lane (WAVE = 1).
 extern "C" void emu_bzip2_block(swc::Job* jobs, size_t n, size_t lcap) {

@@ -1,8 +1,22 @@
 """CPU tier: the LZMA / LZMA2 wave decoder (swcompression_amd/csrc/lzma_wave.h) built for the host as a
 single logical lane vs the oracle (reference Sources/LZMA/*.swift, Sources/LZMA2/*.swift)."""
+import lzma as _pylzma
+
+import numpy as np
+import pytest
+
 import _emu as E
 import _oracle as O
 import _streams as S
+
+
+@pytest.fixture(autouse=True, params=[0, 1], ids=["coders-in-lds", "coder-cache"])
+def _model_mode(request):
+    """Every test runs in both model layouts of the device kernels (lzma_wave.h: all literal coders in LDS / LDS as a cache of
+    four coders with the workspace behind it)."""
+    E.LZMA_MODE = request.param
+    yield
+    E.LZMA_MODE = 0
 
 
 def test_lzma2_valid():
@@ -58,3 +72,24 @@ def test_capacity_is_reported():
     cases = S.lzma2_valid(sizes=(5000, 70000))[:6]
     res = E.lzma2([z for z, _, _ in cases], [len(x) // 2 for _, _, x in cases], [db for _, db, _ in cases])
     assert all(r[0] == 901 for r in res)
+
+
+def test_every_literal_coder_in_turn():
+    """The coder cache under pressure: a payload whose previous-byte classes cycle through all coders of every model shape the
+    system encoder produces (lc + lp <= 4: up to sixteen coders for four slots), so that slots are written back and come back
+    with their adapted cells.  (Larger models -- legal in .lzma, never written by liblzma -- are reached by the raw fuzz above.)"""
+    rng = np.random.Generator(np.random.PCG64(0x5C0DE + 401))
+    n = 60000
+    base = (np.arange(n) * 37 % 256).astype(np.uint8)
+    noise = rng.integers(0, 256, n, dtype=np.uint8)
+    x = np.where(rng.random(n) < 0.7, base, noise).astype(np.uint8).tobytes()
+    ins, props, dss, szs, exp = [], [], [], [], []
+    for lc, lp, pb in ((3, 0, 2), (4, 0, 0), (0, 4, 2), (2, 2, 0), (0, 0, 0), (1, 3, 4)):
+        f = [{"id": _pylzma.FILTER_LZMA1, "lc": lc, "lp": lp, "pb": pb, "dict_size": 1 << 16}]
+        z = _pylzma.compress(x, format=_pylzma.FORMAT_RAW, filters=f)
+        ins.append(z); props.append((lc, lp, pb)); dss.append(1 << 16); szs.append(len(x))
+        exp.append(O.lzma_raw(z, lc, lp, pb, 1 << 16, len(x)))
+        assert exp[-1][:2] == (0, x)
+    res = E.lzma(ins, [len(x) + 16] * len(ins), props, dss, szs)
+    for r, e, p in zip(res, exp, props):
+        assert r[0] == e[0] and r[1] == e[1] and r[2] == e[2], p
