@@ -78,7 +78,11 @@ struct Decoder {
     // ---- I/O -----------------------------------------------------------------------------------
     gcptr in;
     uint64_t n;        // input bytes
-    uint64_t ip;       // next input byte
+    // the next input byte is in[win_base + wk]: `wk` (32 bits, relative to the window of the input that sits in a register, see
+    // below) is what the decision chain advances and tests; the 64-bit position exists only where a chunk or the job needs it
+    uint32_t wk = 0;   // offset of the next input byte from win_base
+    uint32_t wlim = 0; // n - win_base (saturated): wk > wlim <=> a byte past the end of the input has been read
+    SWC_HD uint64_t ip() const { return win_base + wk; }
     gptr out;
     uint64_t cap;
     uint64_t pos;      // bytes produced == dictEnd == out.count of the reference
@@ -114,25 +118,30 @@ struct Decoder {
     // Bytes past the end of the input read as zero and `ip` keeps counting: trapped() (checked where the old `trap` flag was:
     // before anything of the symbol is written) is the reference's trap of LittleEndianByteReader.byte() (App. A L4).
     static constexpr uint32_t kSymbolBytes = 48;
-    uint64_t win_base;          // input offset of lane 0's dword (a multiple of 4); far away: no window loaded
+    uint64_t win_base;          // input offset of lane 0's dword (a multiple of 4)
     uint32_t win;               // this lane's dword
     uint32_t prev_byte;         // out[pos - 1] (0 when the dictionary is empty): the literal coder's context, kept in a register
     SWC_HD void win_load(uint64_t at) {
+        if (at > n) trap = true;   // (already past the end: stays so)
         win_base = at & ~(uint64_t)3;
-        const uint64_t o = win_base + 4ull * (uint32_t)lane;
-        uint32_t w = 0;
-        if (o + 4 <= n) w = load_u32(in + o);
-        else for (uint32_t k = 0; k < 4; k++) if (o + k < n) w |= (uint32_t)in[o + k] << (8 * k);
-        win = w;
+        wk = (uint32_t)at & 3u;
+        const uint64_t left = n > win_base ? n - win_base : 0;
+        wlim = left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)left;
+        if (WAVE != 1) {
+            const uint64_t o = win_base + 4ull * (uint32_t)lane;
+            uint32_t w = 0;
+            if (o + 4 <= n) w = load_u32(in + o);
+            else for (uint32_t k = 0; k < 4; k++) if (o + k < n) w |= (uint32_t)in[o + k] << (8 * k);
+            win = w;
+        }
     }
     SWC_HD void ensure_window() {
-        if (WAVE != 1 && ip - win_base > 4ull * WAVE - kSymbolBytes) win_load(ip);
+        if (wk > 4u * 64u - kSymbolBytes) win_load(ip());   // (the host build keeps the same rhythm: one code path)
     }
-    SWC_HD bool trapped() const { return trap || ip > n; }
+    SWC_HD bool trapped() const { return trap || wk > wlim; }
     SWC_HD uint8_t next_byte() {
-        if (WAVE == 1) { const uint64_t i = ip++; return i < n ? in[i] : (uint8_t)0; }
-        const uint32_t k = (uint32_t)(ip - win_base);   // < 4 * WAVE: ensure_window() ran within the last kSymbolBytes bytes
-        ip++;
+        const uint32_t k = wk++;   // < 256: ensure_window() ran within the last kSymbolBytes bytes
+        if (WAVE == 1) return k < wlim ? in[win_base + k] : (uint8_t)0;
 #if defined(__HIP_DEVICE_COMPILE__)
         const uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)win, __builtin_amdgcn_readfirstlane((int)(k >> 2)));   // (the index is the same in every lane: said so, or the compiler loops over the lanes)
 #else
@@ -218,10 +227,11 @@ struct Decoder {
     // The LDS copy of literal coder `c` (cache mode): a hit is four compares; see kCoderSlots.
     SWC_HD uint16_t* literal_coder(uint32_t c) {
         static_assert(kCoderSlots == 4, "four tags");
-        if (tag0 == c) return probs + kSlotBase;
-        if (tag1 == c) return probs + kSlotBase + 0x300;
-        if (tag2 == c) return probs + kSlotBase + 2 * 0x300;
-        if (tag3 == c) return probs + kSlotBase + 3 * 0x300;
+        {   // a hit: the slot number by selects, ONE branch (on the device every `if` on these values is an exec-mask region)
+            const uint32_t slot = (tag1 == c ? 1u : 0u) + (tag2 == c ? 2u : 0u) + (tag3 == c ? 3u : 0u);
+            const bool hit = tag0 == c || slot != 0u;
+            if (hit) return probs + kSlotBase + slot * 0x300;
+        }
         const uint32_t v = victim;
         victim = (victim + 1) & 3u;
         const uint32_t old = v == 0 ? tag0 : v == 1 ? tag1 : v == 2 ? tag2 : tag3;
@@ -327,7 +337,7 @@ struct Decoder {
     // LZMADecoder.swift:107-284.  Returns an swc_status.
     SWC_HD int decode() {
         SWC_LZMA_PROF(0)
-        if (n - ip < 5) return SWC_E_LZMA_RANGE_DECODER_INIT_ERROR;  // LZMARangeDecoder.swift:21
+        if (n - ip() < 5) return SWC_E_LZMA_RANGE_DECODER_INIT_ERROR;  // LZMARangeDecoder.swift:21
         ensure_window();
         const uint8_t first = next_byte();
         code = 0;
@@ -488,14 +498,14 @@ struct Decoder {
                 const uint32_t b1 = next_byte(), b2 = next_byte();       // decodeUncompressed :84-89
                 if (trapped()) return SWC_E_REF_TRAP;
                 const uint64_t size = ((uint64_t)b1 << 8) + b2 + 1;
-                if (n - ip < size) return SWC_E_REF_TRAP;                // byte() past the end inside the copy loop
+                if (n - ip() < size) return SWC_E_REF_TRAP;                // byte() past the end inside the copy loop
                 if (pos + size <= cap) {
-                    for (uint64_t i = (uint64_t)lane; i < size; i += WAVE) out[pos + i] = in[ip + i];
-                    prev_byte = in[ip + size - 1];
+                    for (uint64_t i = (uint64_t)lane; i < size; i += WAVE) out[pos + i] = in[ip() + i];
+                    prev_byte = in[ip() + size - 1];
                 } else {
                     overflow = true;
                 }
-                ip += size;
+                wk += (uint32_t)size;   // (<= 65,536; the loop top reloads the window)
                 pos += size;
                 if (pos - dict_start >= dict_size) dict_start = pos - dict_size + 1;
                 if (overflow) return SWC_E_CAPACITY;
@@ -519,10 +529,10 @@ struct Decoder {
                 if (reset == 3) reset_dictionary();
             }
             uncompressed_size = unpack;
-            const uint64_t out_start = pos, in_start = ip;
+            const uint64_t out_start = pos, in_start = ip();
             const int st = decode();
             if (st) return st;
-            if (!(unpack == (int64_t)(pos - out_start) && (int64_t)(ip - in_start) == comp)) return SWC_E_LZMA2_WRONG_SIZES;  // :79-81
+            if (!(unpack == (int64_t)(pos - out_start) && (int64_t)(ip() - in_start) == comp)) return SWC_E_LZMA2_WRONG_SIZES;  // :79-81
         }
     }
 };
@@ -533,7 +543,7 @@ template <int WAVE>
 SWC_HD void lzma_job(Job& job, bool is_lzma2, uint16_t* probs, SWC_AS_GLOBAL uint16_t* lit_spill, int lane, int lds_bits = kMaxLdsLitBits, uint64_t* prof = nullptr, bool cached = false) {
     Decoder<WAVE> d;
     d.cached = cached;
-    d.in = (gcptr)job.in; d.n = job.in_len; d.ip = 0;
+    d.in = (gcptr)job.in; d.n = job.in_len;
     d.out = (gptr)job.out; d.cap = job.out_cap; d.pos = 0;
     d.lane = lane;
     d.probs = probs; d.lit_spill = lit_spill; d.lds_bits = lds_bits;
@@ -546,7 +556,8 @@ SWC_HD void lzma_job(Job& job, bool is_lzma2, uint16_t* probs, SWC_AS_GLOBAL uin
     d.rep0 = d.rep1 = d.rep2 = d.rep3 = 0;
     d.state = 0;
     d.trap = false; d.overflow = false; d.need_ws = false;
-    d.win_base = ~(uint64_t)0 - 4096; d.win = 0; d.prev_byte = 0;
+    d.win = 0; d.prev_byte = 0;
+    d.win_load(0);
     int st;
     if (is_lzma2) {
         st = d.decode_lzma2((uint8_t)job.aux);
@@ -562,7 +573,7 @@ SWC_HD void lzma_job(Job& job, bool is_lzma2, uint16_t* probs, SWC_AS_GLOBAL uin
         }
     }
     job.out_len = d.pos;
-    job.in_consumed = d.ip < d.n ? d.ip : d.n;   // (a read past the end keeps counting, see next_byte())
+    job.in_consumed = d.ip() < d.n ? d.ip() : d.n;   // (a read past the end keeps counting, see next_byte())
     job.status = st;
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     if (prof && lane == 0) for (int k = 0; k < 16; k++) prof[k] = d.pacc[k];
