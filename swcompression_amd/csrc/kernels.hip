@@ -192,8 +192,11 @@ constexpr size_t kLzmaSpillBytes = (size_t)(0x300u << 12) * 2;
 
 // LDSBITS >= 0: the literal coders of lc + lp <= LDSBITS in LDS (no workspace: 4 -> 28 KB, 5 streams per CU);
 // LDSBITS < 0: LDS as a cache of four literal coders, all of them in the workspace (9,840 B, 16 streams per CU; lzma_wave.h)
+#ifndef SWC_LZMA_WAVES
+#define SWC_LZMA_WAVES 4
+#endif
 template <bool LZMA2, int LDSBITS>
-__global__ __launch_bounds__(64) void swc_lzma_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* spill, uint64_t* prof) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_LZMA_WAVES))) void swc_lzma_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* spill, uint64_t* prof) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lzma_lds[];
     uint32_t g = blockIdx.x;
     if (g >= n) return;

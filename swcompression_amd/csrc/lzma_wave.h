@@ -50,7 +50,10 @@ constexpr int kLdsBytesPerWave = lds_bytes_for(kMaxLdsLitBits);
 // streams per CU.  A miss writes the victim back and loads the coder (1.5 KB each way, all lanes; a coder nobody has used
 // since the last model reset is filled with the initial value instead); slots are replaced round-robin.  Any lc + lp works
 // this way (the old path kept lc + lp <= 3 in LDS and decoded larger models cell by cell from HBM).
-constexpr int kCoderSlots = 4;
+#ifndef SWC_LZMA_SLOTS
+#define SWC_LZMA_SLOTS 4
+#endif
+constexpr int kCoderSlots = SWC_LZMA_SLOTS;
 constexpr int kSlotBase = (P_LITERAL + 3) & ~3;   // first cell of slot 0: dword-aligned copies
 constexpr int lds_bytes_cached() { return (((kSlotBase + 0x300 * kCoderSlots) * 2 + 15) / 16) * 16; }
 constexpr uint32_t kNoCoder = 0xFFFFFFFFu;
@@ -226,14 +229,14 @@ struct Decoder {
 
     // The LDS copy of literal coder `c` (cache mode): a hit is four compares; see kCoderSlots.
     SWC_HD uint16_t* literal_coder(uint32_t c) {
-        static_assert(kCoderSlots == 4, "four tags");
+        static_assert(kCoderSlots == 3 || kCoderSlots == 4, "three or four tags");
         {   // a hit: the slot number by selects, ONE branch (on the device every `if` on these values is an exec-mask region)
-            const uint32_t slot = (tag1 == c ? 1u : 0u) + (tag2 == c ? 2u : 0u) + (tag3 == c ? 3u : 0u);
+            const uint32_t slot = (tag1 == c ? 1u : 0u) + (tag2 == c ? 2u : 0u) + (kCoderSlots > 3 && tag3 == c ? 3u : 0u);
             const bool hit = tag0 == c || slot != 0u;
             if (hit) return probs + kSlotBase + slot * 0x300;
         }
         const uint32_t v = victim;
-        victim = (victim + 1) & 3u;
+        victim = victim + 1 == (uint32_t)kCoderSlots ? 0u : victim + 1;
         const uint32_t old = v == 0 ? tag0 : v == 1 ? tag1 : v == 2 ? tag2 : tag3;
         uint16_t* sp = probs + kSlotBase + v * 0x300;
         uint32_t* sp32 = (uint32_t*)sp;
