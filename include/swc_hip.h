@@ -71,9 +71,10 @@ typedef struct swc_batch_opts {
 int swc_batch_decompress(int codec, swc_job* jobs, size_t n, const swc_batch_opts* opts);
 
 /* Scratch bytes the codec needs in HBM (Deflate / LZ4: match records + literal stream of the two-phase path,
- * LZMA: probability model spill, BZip2: tt[]).  LZ4 also runs without it (one block per lane, much slower on
- * large blocks).  Allocated internally by the single-shot calls; batch callers pass it via
- * swc_batch_decompress_ws. */
+ * LZMA: the home of the literal coders, of which LDS caches four -- 16 streams per CU and any lc + lp; without it the model
+ * of lc + lp <= 4 sits in LDS whole, 5 streams per CU, larger models are refused with SWC_E_NEED_WORKSPACE; BZip2: tt[]).
+ * LZ4 also runs without it (one block per lane, much slower on large blocks).  Allocated internally by the single-shot
+ * calls; batch callers pass it via swc_batch_decompress_ws. */
 size_t swc_batch_workspace_bytes(int codec, size_t n_jobs, uint64_t max_out_cap);
 int swc_batch_decompress_ws(int codec, swc_job* jobs, size_t n, void* workspace, size_t workspace_bytes,
                             const swc_batch_opts* opts);
