@@ -149,13 +149,13 @@ __global__ __launch_bounds__(64) void swc_lz4_parse_kernel(Job* __restrict__ job
     }
 }
 
-__global__ __launch_bounds__(lz4w::kResolveThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void swc_lz4_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm) {
+__global__ __launch_bounds__(lz4w::kResolveThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void swc_lz4_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof) {
     __shared__ __attribute__((aligned(16))) lzr::Lds<lz4w::kResolveThreads, lz4w::kRingLog2> lds;
     uint32_t g = blockIdx.x;
     if (g >= n) return;
     Job job = jobs[g];
     if (job.dict != nullptr) return;
-    lzr::resolve_job<lz4w::kResolveThreads, lz4w::kRingLog2, lz4w::kKeep, true>(job, wm.area(g), wm.bytes(g), &lds);
+    lzr::resolve_job<lz4w::kResolveThreads, lz4w::kRingLog2, lz4w::kKeep, true>(job, wm.area(g), wm.bytes(g), &lds, prof ? prof + 32 * (size_t)g + 16 : nullptr);
 }
 
 size_t lz4_ws_bytes_per_job(uint64_t cap) { return lzr::ws_bytes_per_job(cap); }
@@ -177,7 +177,7 @@ hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_
     const WsMap wm{(uint8_t*)ws, stride, ws_off};
     hipLaunchKernelGGL(swc_lz4_parse_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof);
     g_pt.mark(stream);
-    hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(lz4w::kResolveThreads), 0, stream, jobs, (uint32_t)n, wm);
+    hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(lz4w::kResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof);
     g_pt.mark(stream);
     return hipGetLastError();
 }
