@@ -1001,7 +1001,12 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, SyncProf& pf) {
                 return SWC_E_DEFLATE_WRONG_SYMBOL;  // :155 (symbol 16 first)
             }
             prev = val;
+#if defined(__HIP_DEVICE_COMPILE__)
+            // every lane stores (lane i: entry min(i, rep - 1)): no exec-mask region in this serial loop; zeros land on zeros
+            { const int i = ln.wlane < rep - 1 ? ln.wlane : rep - 1; lens[n + i] = (uint8_t)val; }
+#else
             if (val != 0) for (int i = ln.wlane; i < rep; i += ln.wlanes) lens[n + i] = (uint8_t)val;
+#endif
             n += rep;
         }
         if (n != total) return SWC_E_DEFLATE_WRONG_SYMBOL;  // :161
