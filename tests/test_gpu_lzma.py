@@ -184,3 +184,36 @@ def test_config5_shape_many_256k_units():
     for i in range(b.n):
         o = int(b._out_off[i])
         assert blob[o:o + 262144].tobytes() == plains[i % len(units)]
+
+
+def test_literal_coder_cache_against_whole_model():
+    """The two model layouts of the device kernel (lzma_wave.h: LDS as a cache of four literal coders / all coders in LDS) on
+    payloads that use few coders (text), all eight of lc = 3 (binary records) and sixteen (lc = 4; lc = 0, lp = 4): the same
+    bytes, sizes and consumed input, and both equal to the oracle."""
+    from swcompression_amd import _lib
+    lib = _lib.load()
+    plains = [corpus.p_text(150000, 11), corpus.PAYLOADS["bin"](150000, 12), corpus.p_mix(150000, 13), corpus.p_rand(30000, 14)]
+    units, want = [], []
+    for p in plains:
+        for lc, lp in ((3, 0), (4, 0), (0, 4), (2, 2), (0, 0)):
+            f = [{"id": lzma.FILTER_LZMA2, "preset": 6, "lc": lc, "lp": lp, "dict_size": 1 << 20}]
+            units.append(lzma.compress(p, format=lzma.FORMAT_RAW, filters=f))
+            want.append(p)
+    db = corpus.lzma2_dict_byte(1 << 20)
+    assert O.lzma2(units[7], db)[:2] == (0, want[7])
+    outs = {}
+    try:
+        for mode in (1, 0):
+            assert lib.swc_set_tuning(b"lzma_coder_cache", mode) == 0
+            b = DeviceBatch("lzma2", units, [len(p) for p in want], aux=[db] * len(units))
+            b.launch(sync=True)
+            r = b.results()
+            assert (r["status"] == 0).all(), (mode, r["status"])
+            outs[mode] = [b.output(k, len(want[k])) for k in range(len(units))]
+            for k in range(len(units)):
+                assert int(r["out_len"][k]) == len(want[k]) and int(r["in_consumed"][k]) == len(units[k]), (mode, k)
+    finally:
+        lib.swc_set_tuning(b"lzma_coder_cache", 1)
+    for k in range(len(units)):
+        assert outs[1][k] == want[k], ("cache", k)
+        assert outs[0][k] == want[k], ("whole model", k)
