@@ -352,8 +352,11 @@ struct Decoder {
         const int lit_bits = lc + lp;
         const bool spill = !cached && lit_bits > lds_bits;
 
+        // Where the input runs out is noticed lazily (reads past the end return zeros and harm nothing): ONE test per symbol,
+        // in front of the write of its output, and inside every other error return, so that a stream that ends early reports the
+        // reference's trap and not an error computed from the zeros behind it.  (On the device each such test is an exec-mask
+        // region in the serial chain; there were six to eight per symbol.)
         for (;;) {
-            if (trapped()) return SWC_E_REF_TRAP;
             if (overflow) return SWC_E_CAPACITY;
             ensure_window();
             if (uncompressed_size == 0 && code == 0) break;  // :114
@@ -361,8 +364,7 @@ struct Decoder {
             int is_match;
             { SWC_LZMA_PROF(8) is_match = bit(&probs[P_IS_MATCH + (state << 4) + pos_state]); }
             if (is_match == 0) {
-                if (trapped()) return SWC_E_REF_TRAP;
-                if (uncompressed_size == 0) return SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :121
+                if (uncompressed_size == 0) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :121
                 SWC_LZMA_PROF(3)
                 SWC_LZMA_COUNT(6, 1);
                 const uint32_t prev = pos == dict_start ? 0u : prev_byte;
@@ -374,7 +376,6 @@ struct Decoder {
                         SWC_LZMA_PROF(10)
                         SWC_LZMA_COUNT(11, 1);
                         uint32_t match_byte = byte_at(rep0 + 1);
-                        if (trapped()) return SWC_E_REF_TRAP;
                         do {
                             const int match_bit = (match_byte >> 7) & 1;
                             match_byte = (match_byte << 1) & 0xFF;
@@ -388,7 +389,6 @@ struct Decoder {
                     SWC_AS_GLOBAL uint16_t* lpb = lit_spill + (size_t)lit_state * 0x300;
                     if (state >= 7) {
                         uint32_t match_byte = byte_at(rep0 + 1);
-                        if (trapped()) return SWC_E_REF_TRAP;
                         do {
                             const int match_bit = (match_byte >> 7) & 1;
                             match_byte = (match_byte << 1) & 0xFF;
@@ -405,19 +405,16 @@ struct Decoder {
                 state = state < 4 ? 0 : state < 10 ? state - 3 : state - 6;
                 continue;
             }
-            if (trapped()) return SWC_E_REF_TRAP;
 
             uint32_t len;
             {
             SWC_LZMA_PROF(4)
             if (bit(&probs[P_IS_REP + state]) != 0) {
-                if (trapped()) return SWC_E_REF_TRAP;
-                if (uncompressed_size == 0) return SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :178
-                if (pos == dict_start) return SWC_E_LZMA_WINDOW_IS_EMPTY;                  // :181
+                if (uncompressed_size == 0) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :178
+                if (pos == dict_start) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_WINDOW_IS_EMPTY;                  // :181
                 if (bit(&probs[P_IS_REP_G0 + state]) == 0) {
                     if ((state << 4) + pos_state >= 191) return SWC_E_REF_TRAP;            // reference index 241+... == 432
                     if (bit(&probs[P_IS_REP0_LONG + (state << 4) + pos_state]) == 0) {
-                        if (trapped()) return SWC_E_REF_TRAP;
                         state = state < 7 ? 9 : 11;
                         SWC_LZMA_COUNT(7, 1);
                         const uint8_t b = byte_at(rep0 + 1);
@@ -463,13 +460,12 @@ struct Decoder {
                     }
                     rep0 = dist;
                 }
-                if (trapped()) return SWC_E_REF_TRAP;
                 if (rep0 == 0xFFFFFFFFull) {                                               // :260 end marker
-                    if (code != 0) return SWC_E_LZMA_RANGE_DECODER_FINISH_ERROR;           // :261
+                    if (code != 0) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_RANGE_DECODER_FINISH_ERROR;   // :261
                     break;
                 }
-                if (uncompressed_size == 0) return SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :266
-                if (rep0 >= dict_size || (rep0 > pos && pos < dict_size)) return SWC_E_LZMA_NOT_ENOUGH_TO_REPEAT;  // :269
+                if (uncompressed_size == 0) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :266
+                if (rep0 >= dict_size || (rep0 > pos && pos < dict_size)) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_NOT_ENOUGH_TO_REPEAT;  // :269
             }
             }
             if (trapped()) return SWC_E_REF_TRAP;
