@@ -212,14 +212,18 @@ struct Decoder {
     }
     SWC_HD int tree_reverse(uint16_t* p, int limit, int start, int bits) {  // :26-43
         int m = 1, sym = 0;
-        for (int i = 0; i < bits; i++) {
+        bool bad = false;   // an index outside the table: the reference traps there; here the walk goes on over a clamped cell
+        for (int i = 0; i < bits; i++) {   // (no test-and-leave per decision in the chain) and the trap is recorded behind the loop
             int idx = start + m;
-            if (idx < 0 || idx >= limit) { trap = true; return 0; }
+            const bool out_of_range = idx < 0 || idx >= limit;
+            bad = bad || out_of_range;
+            idx = out_of_range ? 0 : idx;
             int b = bit(&p[idx]);
             m = (m << 1) + b;
             sym |= b << i;
         }
-        return sym;
+        trap = trap || bad;
+        return bad ? 0 : sym;
     }
     SWC_HD int len_decode(uint16_t* p, int pos_state) {  // LZMALenDecoder.swift:30-38
         if (bit(&p[LEN_CHOICE]) == 0) return tree(&p[LEN_LOW + pos_state * 8], 3);
@@ -296,11 +300,11 @@ struct Decoder {
     // put(): LZMADecoder.swift:288-294.  One byte, written by lane 0.
     SWC_HD void put(uint8_t b) {
         SWC_LZMA_PROF(9)
-        if (pos < cap) { if (lane == 0) out[pos] = b; }
-        else overflow = true;
+        if (pos < cap) out[pos] = b;   // (every lane stores the same byte to the same address: one write, no second mask region)
+        overflow = overflow || pos >= cap;
         prev_byte = b;
         pos++;
-        if (pos - dict_start == dict_size) dict_start++;
+        dict_start += pos - dict_start == dict_size ? 1u : 0u;
     }
     // byte(at:): LZMADecoder.swift:296-298 -- out[distance <= dictEnd ? dictEnd - distance : dictSize - distance + dictEnd]
     SWC_HD uint8_t byte_at(uint64_t distance) {
@@ -357,9 +361,11 @@ struct Decoder {
         // reference's trap and not an error computed from the zeros behind it.  (On the device each such test is an exec-mask
         // region in the serial chain; there were six to eight per symbol.)
         for (;;) {
-            if (overflow) return SWC_E_CAPACITY;
-            ensure_window();
-            if (uncompressed_size == 0 && code == 0) break;  // :114
+            if (overflow || wk > 4u * 64u - kSymbolBytes || uncompressed_size == 0) {   // (one test in the common case)
+                if (overflow) return SWC_E_CAPACITY;
+                ensure_window();
+                if (uncompressed_size == 0 && code == 0) break;  // :114
+            }
             const int pos_state = (int)(pos & ((1u << pb) - 1));
             int is_match;
             { SWC_LZMA_PROF(8) is_match = bit(&probs[P_IS_MATCH + (state << 4) + pos_state]); }
@@ -384,7 +390,12 @@ struct Decoder {
                             if (match_bit != b) break;
                         } while (symbol < 0x100);
                     }
-                    while (symbol < 0x100) symbol = (symbol << 1) | bit(&lpb[symbol]);
+                    if (symbol == 1) {   // not in matched mode: exactly eight decisions (a constant trip count: no loop test in the chain)
+#pragma unroll
+                        for (int i = 0; i < 8; i++) symbol = (symbol << 1) | bit(&lpb[symbol]);
+                    } else {
+                        while (symbol < 0x100) symbol = (symbol << 1) | bit(&lpb[symbol]);
+                    }
                 } else {
                     SWC_AS_GLOBAL uint16_t* lpb = lit_spill + (size_t)lit_state * 0x300;
                     if (state >= 7) {
