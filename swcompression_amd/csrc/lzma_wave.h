@@ -418,9 +418,11 @@ struct Decoder {
             }
 
             uint32_t len;
+            bool is_rep;
             {
             SWC_LZMA_PROF(4)
-            if (bit(&probs[P_IS_REP + state]) != 0) {
+            is_rep = bit(&probs[P_IS_REP + state]) != 0;
+            if (is_rep) {
                 if (uncompressed_size == 0) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :178
                 if (pos == dict_start) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_WINDOW_IS_EMPTY;                  // :181
                 if (bit(&probs[P_IS_REP_G0 + state]) == 0) {
@@ -471,18 +473,29 @@ struct Decoder {
                     }
                     rep0 = dist;
                 }
-                if (rep0 == 0xFFFFFFFFull) {                                               // :260 end marker
-                    if (code != 0) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_RANGE_DECODER_FINISH_ERROR;   // :261
-                    break;
-                }
-                if (uncompressed_size == 0) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :266
-                if (rep0 >= dict_size || (rep0 > pos && pos < dict_size)) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_NOT_ENOUGH_TO_REPEAT;  // :269
             }
             }
-            if (trapped()) return SWC_E_REF_TRAP;
+            // Everything that can stop a match -- the end marker, the declared size, the window, the end of the input -- in ONE
+            // test (all input of the symbol has been read): the checks of the reference, in its order, sit behind it.
             len += 2;
-            if (uncompressed_size > -1 && uncompressed_size < (int64_t)len) return SWC_E_LZMA_REPEAT_WILL_EXCEED;  // :275
-            if (rep0 + 1 > pos) return SWC_E_REF_TRAP;  // byte(at:) would index past out.count (App. A L2)
+            {
+                const bool end_marker = !is_rep && rep0 == 0xFFFFFFFFull;
+                const bool odd = end_marker | (!is_rep & (uncompressed_size == 0)) | (!is_rep & ((rep0 >= dict_size) | ((rep0 > pos) & (pos < dict_size))))
+                               | trapped() | ((uncompressed_size > -1) & (uncompressed_size < (int64_t)len)) | (rep0 + 1 > pos);
+                if (odd) {
+                    if (end_marker) {                                                          // :260
+                        if (code != 0) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_RANGE_DECODER_FINISH_ERROR;   // :261
+                        break;
+                    }
+                    if (!is_rep) {
+                        if (uncompressed_size == 0) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :266
+                        if (rep0 >= dict_size || (rep0 > pos && pos < dict_size)) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_NOT_ENOUGH_TO_REPEAT;  // :269
+                    }
+                    if (trapped()) return SWC_E_REF_TRAP;
+                    if (uncompressed_size > -1 && uncompressed_size < (int64_t)len) return SWC_E_LZMA_REPEAT_WILL_EXCEED;  // :275
+                    if (rep0 + 1 > pos) return SWC_E_REF_TRAP;  // byte(at:) would index past out.count (App. A L2)
+                }
+            }
             copy_match(rep0 + 1, len);
             uncompressed_size -= len;
         }
