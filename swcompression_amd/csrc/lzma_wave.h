@@ -319,10 +319,14 @@ struct Decoder {
     SWC_HD void copy_match(uint64_t distance, uint32_t len) {
         SWC_LZMA_PROF(1)
         SWC_LZMA_COUNT(5, 1);
-        if (pos + len <= cap) {
+        const bool fits = pos + len <= cap;
+        if (fits) {
             gptr dst = out + pos;
             uint32_t last = 0;   // the byte this lane wrote last: the lane that wrote dst[len - 1] holds the new prev_byte
-            if (distance >= len) {
+            if ((len <= (uint32_t)WAVE) & (distance >= len)) {
+                // the common case in one step: no loop, no overlap
+                if ((uint32_t)lane < len) { last = dst[(int64_t)lane - (int64_t)distance]; dst[lane] = (uint8_t)last; }
+            } else if (distance >= len) {
                 for (uint32_t i = (uint32_t)lane; i < len; i += WAVE) { last = dst[(int64_t)i - (int64_t)distance]; dst[i] = (uint8_t)last; }
             } else {
                 // overlapping: every byte is a copy of one of the `distance` bytes before `pos`
@@ -333,12 +337,11 @@ struct Decoder {
 #else
             prev_byte = last;
 #endif
-        } else {
-            overflow = true;
         }
+        overflow = overflow || !fits;
         pos += len;
-        uint64_t span = pos - dict_start;
-        if (span >= dict_size && dict_size > 0) dict_start = pos - dict_size + 1;  // `len` put()s worth of window sliding
+        const uint64_t span = pos - dict_start;
+        dict_start = ((span >= dict_size) & (dict_size > 0)) ? pos - dict_size + 1 : dict_start;  // `len` put()s worth of window sliding
     }
 
     // LZMADecoder.swift:107-284.  Returns an swc_status.
