@@ -93,3 +93,44 @@ def test_every_literal_coder_in_turn():
     res = E.lzma(ins, [len(x) + 16] * len(ins), props, dss, szs)
     for r, e, p in zip(res, exp, props):
         assert r[0] == e[0] and r[1] == e[1] and r[2] == e[2], p
+
+
+def test_random_payload_mixtures_every_model_shape():
+    """Seeded random mixtures of text-like, binary, repetitive and random pieces under every (lc, lp, pb) with lc + lp <= 4, as
+    LZMA1 and as LZMA2 with small chunks (several model resets per stream): both model layouts against the oracle."""
+    import random
+    rnd = random.Random(0x5C0DE + 402)
+    rng = np.random.Generator(np.random.PCG64(0x5C0DE + 403))
+
+    def piece(kind, n):
+        if kind == 0:
+            return bytes(rnd.choice(b"etaoin shrdlu,.\nETAOIN0123") for _ in range(n))
+        if kind == 1:
+            return rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        if kind == 2:
+            return (bytes(rnd.randrange(256) for _ in range(rnd.randrange(1, 9))) * (n // 2 + 1))[:n]
+        return (np.cumsum(rng.integers(-3, 4, n)) & 0xFF).astype(np.uint8).tobytes()
+
+    shapes = [(lc, lp, pb) for lc in range(5) for lp in range(5 - lc) for pb in (0, 2, 4)]
+    ins1, props, dss, szs, want1 = [], [], [], [], []
+    ins2, want2 = [], []
+    for k, (lc, lp, pb) in enumerate(shapes):
+        x = b"".join(piece(rnd.randrange(4), rnd.randrange(1, 3000)) for _ in range(rnd.randrange(1, 12)))
+        f1 = [{"id": _pylzma.FILTER_LZMA1, "lc": lc, "lp": lp, "pb": pb, "dict_size": 1 << 16}]
+        z1 = _pylzma.compress(x, format=_pylzma.FORMAT_RAW, filters=f1)
+        ins1.append(z1); props.append((lc, lp, pb)); dss.append(1 << 16); szs.append(len(x) if k & 1 else -1); want1.append(x)
+        f2 = [{"id": _pylzma.FILTER_LZMA2, "lc": lc, "lp": lp, "pb": pb, "dict_size": 1 << 16}]
+        ins2.append(_pylzma.compress(x, format=_pylzma.FORMAT_RAW, filters=f2)); want2.append(x)
+    res = E.lzma(ins1, [len(x) + 300 for x in want1], props, dss, szs)
+    for r, z, x, p, ds, sz in zip(res, ins1, want1, props, dss, szs):
+        e = O.lzma_raw(z, p[0], p[1], p[2], ds, sz)
+        if e[0] == 901:
+            continue
+        assert r[0] == e[0] and (e[0] != 0 or (r[1] == e[1] and r[2] == e[2])), p
+    db = 16   # 64 KiB dictionary
+    res = E.lzma2(ins2, [max(len(x), 1) for x in want2], [db] * len(ins2))
+    for r, z, x, p in zip(res, ins2, want2, shapes):
+        e = O.lzma2(z, db)
+        assert r[0] == e[0], p       # (pb = 4: a valid stream can reach the index the reference traps on, SURVEY.md App. A L1)
+        if e[0] == 0:
+            assert r[:3] == (0, x, len(z)) and e[1] == x, p
