@@ -54,4 +54,45 @@ for kind, size in (("text", 300000), ("mix", 200000), ("rep", 100000), ("zero", 
         assert not run(fn, z[:len(z) * 2 // 3], p)[0]
         n += 2
     n += 2
+# LZMA2 in both model layouts (all literal coders in LDS / LDS as a cache of four), whole and truncated
+import lzma as _lzma
+lib.emu_lzma_mode.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_int]
+
+
+def run_lzma2(data, plain, mode, cap=None):
+    cap = len(plain) if cap is None else cap
+    j = (Job * 1)()
+    ib = libc.malloc(max(len(data), 1))
+    C.memmove(ib, data, len(data))
+    ob = libc.malloc(max(cap, 1))
+    j[0].in_, j[0].in_len, j[0].out, j[0].out_cap, j[0].aux = ib, len(data), ob, cap, 16   # 64 KiB dictionary
+    lib.emu_lzma_mode(j, 1, 1, mode)
+    ok = j[0].status == 0 and C.string_at(ob, cap) == plain[:cap]
+    libc.free(ib)
+    libc.free(ob)
+    return ok, j[0].status
+
+
+for kind, size in (("text", 120000), ("bin", 90000), ("mix", 80000), ("rand", 20000)):
+    p = corpus.PAYLOADS[kind](size, 5)
+    for lc, lp in ((3, 0), (0, 4), (4, 0)):
+        z = _lzma.compress(p, format=_lzma.FORMAT_RAW, filters=[{"id": _lzma.FILTER_LZMA2, "lc": lc, "lp": lp, "dict_size": 1 << 16}])
+        for mode in (0, 1):
+            assert run_lzma2(z, p, mode)[0], ("lzma2", kind, lc, lp, mode)
+            assert not run_lzma2(z[:len(z) * 2 // 3], p, mode)[0]
+            assert run_lzma2(z, p, mode, cap=len(p) // 2)[1] == 901
+            n += 3
+
+# the wave-per-stream CRC-32: 16-byte loads at every alignment must stay inside an exact-size buffer
+import zlib
+lib.emu_crc32_wave.argtypes = [C.c_void_p, C.c_size_t]
+lib.emu_crc32_wave.restype = C.c_uint32
+base = corpus.p_mix(70000, 9)
+for length in list(range(0, 70)) + [2044, 2047, 2048, 2049, 4096, 6143, 6145, 65536, 69999]:
+    for mis in (0, 1, 3, 8, 13):
+        buf = libc.malloc(max(length + mis, 1))
+        C.memmove(buf + mis, base[:length], length)          # the data end exactly where the allocation ends
+        assert lib.emu_crc32_wave(buf + mis, length) == zlib.crc32(base[:length]), (length, mis)
+        libc.free(buf)
+        n += 1
 print("asan-clean", n)
