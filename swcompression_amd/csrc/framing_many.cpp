@@ -13,6 +13,8 @@
 #include <condition_variable>
 #include <deque>
 #include <functional>
+#include <chrono>
+#include <cstdlib>
 #include <map>
 #include <vector>
 #include "framing.h"
@@ -195,11 +197,12 @@ int swc_unarchive_many(int kind, const uint8_t* const* archives, const size_t* l
 namespace {
 struct DeviceWorker {
     std::mutex m;
-    std::condition_variable cv;
+    std::condition_variable cv, idle_cv;
     std::deque<std::function<void()>> q;
-    explicit DeviceWorker(int device) {
-        std::thread([this, device] {
-            (void)hipSetDevice(device);
+    bool busy = false;
+    int device;
+    explicit DeviceWorker(int dev) : device(dev) {
+        std::thread([this] {
             for (;;) {
                 std::function<void()> f;
                 {
@@ -207,8 +210,11 @@ struct DeviceWorker {
                     cv.wait(lk, [this] { return !q.empty(); });
                     f = std::move(q.front());
                     q.pop_front();
+                    busy = true;
                 }
                 f();
+                f = nullptr;   // (the task's captures go before the worker reports itself idle)
+                { std::lock_guard<std::mutex> lk(m); busy = false; if (q.empty()) idle_cv.notify_all(); }
             }
         }).detach();   // (ends with the process: a joinable static thread would have to outlive the HIP runtime's own teardown)
     }
@@ -216,13 +222,30 @@ struct DeviceWorker {
         { std::lock_guard<std::mutex> lk(m); q.push_back(std::move(f)); }
         cv.notify_one();
     }
+    // waits (bounded) until nothing is queued or running
+    void drain() {
+        std::unique_lock<std::mutex> lk(m);
+        idle_cv.wait_for(lk, std::chrono::seconds(10), [this] { return q.empty() && !busy; });
+    }
+};
+struct WorkerPool {
+    std::mutex m;
+    std::map<int, DeviceWorker*> pool;   // (never destroyed: the threads are detached)
+    static WorkerPool& get() {
+        static WorkerPool* p = [] {
+            WorkerPool* w = new WorkerPool;
+            // exit() while another thread is still inside a call: let its tasks finish before the HIP runtime and the statics go
+            std::atexit([] { WorkerPool& wp = WorkerPool::get(); std::vector<DeviceWorker*> ws; { std::lock_guard<std::mutex> lk(wp.m); for (auto& kv : wp.pool) ws.push_back(kv.second); } for (DeviceWorker* w2 : ws) w2->drain(); });
+            return w;
+        }();
+        return *p;
+    }
 };
 DeviceWorker& worker_of(int device) {
-    static std::mutex m;
-    static std::map<int, DeviceWorker*> pool;   // (never destroyed: see above)
-    std::lock_guard<std::mutex> lk(m);
-    auto it = pool.find(device);
-    if (it == pool.end()) it = pool.emplace(device, new DeviceWorker(device)).first;
+    WorkerPool& wp = WorkerPool::get();
+    std::lock_guard<std::mutex> lk(wp.m);
+    auto it = wp.pool.find(device);
+    if (it == wp.pool.end()) it = wp.pool.emplace(device, new DeviceWorker(device)).first;
     return *it->second;
 }
 // the uncompressed size the framing declares, 0 if it declares none (or nonsense: a hint for the balance only)
@@ -262,32 +285,54 @@ int swc_unarchive_many_devices(int kind, const uint8_t* const* archives, const s
             while (d < n_devices && acc * n_devices >= total * d) cut[d++] = i + 1;
         }
     }
-    std::vector<Result> res(n);
-    std::vector<int> st(n_devices, SWC_OK);
-    std::mutex done_m;
-    std::condition_variable done_cv;
-    size_t outstanding = 0;
-    for (size_t d = 0; d < n_devices; d++) {
+    // Everything a task touches lives in ONE shared block that the tasks hold by value: the caller waits for all of them, but
+    // a worker may still be inside notify / unlock when the caller wakes up, and must not find the frame gone.
+    struct Shared {
+        std::vector<Result> res;
+        std::vector<int> st;
+        std::mutex m;
+        std::condition_variable cv;
+        size_t outstanding = 0;
+    };
+    auto sh = std::make_shared<Shared>();
+    sh->res.resize(n);
+    sh->st.assign(n_devices, SWC_OK);
+    bool post_failed = false;
+    for (size_t d = 0; d < n_devices && !post_failed; d++) {
         const size_t lo = cut[d], hi = cut[d + 1];
         if (lo >= hi) continue;
-        { std::lock_guard<std::mutex> lk(done_m); outstanding++; }
-        worker_of(devices[d]).post([&, d, lo, hi] {
-            try {
-                std::vector<Result> part(hi - lo);
-                st[d] = many_dispatch(kind, archives + lo, lens + lo, hi - lo, part);
-                if (st[d] == SWC_OK)
-                    for (size_t i = lo; i < hi; i++) res[i] = std::move(part[i - lo]);
-            } catch (...) {
-                st[d] = SWC_E_DEVICE;
-            }
-            { std::lock_guard<std::mutex> lk(done_m); outstanding--; }
-            done_cv.notify_all();
-        });
+        const int dev = devices[d];
+        try {
+            { std::lock_guard<std::mutex> lk(sh->m); sh->outstanding++; }
+            worker_of(dev).post([sh, kind, archives, lens, d, lo, hi, dev] {
+                try {
+                    // (per task, not once per thread: a failed or later reset device must not let the range run elsewhere)
+                    if (hipSetDevice(dev) != hipSuccess) sh->st[d] = SWC_E_DEVICE;
+                    else {
+                        std::vector<Result> part(hi - lo);
+                        sh->st[d] = many_dispatch(kind, archives + lo, lens + lo, hi - lo, part);
+                        if (sh->st[d] == SWC_OK)
+                            for (size_t i = lo; i < hi; i++) sh->res[i] = std::move(part[i - lo]);
+                    }
+                } catch (...) {
+                    sh->st[d] = SWC_E_DEVICE;
+                }
+                std::lock_guard<std::mutex> lk(sh->m);   // (notify under the lock: the waiter cannot leave between the two)
+                sh->outstanding--;
+                sh->cv.notify_all();
+            });
+        } catch (...) {   // worker_of / post could not allocate: this range was never queued
+            { std::lock_guard<std::mutex> lk(sh->m); sh->outstanding--; }
+            sh->st[d] = SWC_E_DEVICE;
+            post_failed = true;
+        }
     }
-    {   // (every posted task is waited for before anything of this frame goes away, whatever happened above)
-        std::unique_lock<std::mutex> lk(done_m);
-        done_cv.wait(lk, [&] { return outstanding == 0; });
+    {   // every task that WAS posted is waited for, whatever happened above: they read the caller's archives
+        std::unique_lock<std::mutex> lk(sh->m);
+        sh->cv.wait(lk, [&] { return sh->outstanding == 0; });
     }
+    std::vector<Result>& res = sh->res;
+    std::vector<int>& st = sh->st;
     for (size_t d = 0; d < n_devices; d++) if (st[d]) return st[d];
     hand_over(res, outs, out_lens, statuses);
     return SWC_OK;

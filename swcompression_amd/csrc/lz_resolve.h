@@ -363,6 +363,10 @@ struct Resolver {
                     // the records and the literal window of what follows (their prefetches were aimed elsewhere)
                     lfill = (lbase & ~(uint64_t)15) + kLitWin;
                     SIMT_BEGIN(t, T)
+                        // FAR: a run of more than KEEP bytes may be followed at once by a match whose source lies inside the run
+                        // but in front of the ring's history -- the next batch would read it from `out` with nothing between
+                        // this batch's stores and that load but an LDS-only barrier.  So: my stores done, THEN the barrier.
+                        if (FAR) simt::vmem_fence();
                         const uint32_t nx = base + kRpt * (uint32_t)t;
                         r_nx0[t] = nx < nrec ? recs[nx] : 0u;
                         r_nx1[t] = nx + 1u < nrec ? recs[nx + 1u] : 0u;

@@ -143,3 +143,58 @@ def test_randomised_blocks_two_phase_batch():
         if i % 13 == 0:
             assert O.lz4_block(blocks[i])[:2] == (0, p)
     O.lib.refcpu_set_max_output(1 << 30)
+
+
+def _lz4_sequence(lits, offset=None, mlen=None):
+    """One LZ4 sequence (LZ4.swift:341-412): token, literal-length extension, literals, offset, match-length extension."""
+    def ext(v):
+        out = bytearray()
+        while v >= 255:
+            out.append(255); v -= 255
+        out.append(v)
+        return bytes(out)
+    ll = len(lits)
+    ml = 0 if mlen is None else mlen - 4
+    tok = (min(ll, 15) << 4) | min(ml, 15)
+    s = bytes([tok]) + (ext(ll - 15) if ll >= 15 else b"") + lits
+    if mlen is not None:
+        s += struct.pack("<H", offset) + (ext(ml - 15) if ml >= 15 else b"")
+    return s
+
+
+def test_far_matches_right_behind_a_long_literal_run():
+    """the resolve kernel keeps 32 KiB of history in LDS and reads older match sources back from the output
+    buffer.  A literal run of more than 32 KiB is stored by the copy path in one step; matches with offsets 32769..65535
+    that follow at once read bytes of that run from HBM -- they must see them (fence + workgroup barrier after the run)."""
+    rnd = random.Random(77)
+    blocks, plains = [], []
+    for L in (32769, 40000, 65535, 70000, 200000, 1 << 20):
+        for rep in range(4):
+            lits = corpus.p_rand(L, 900 + rep)
+            plain = bytearray(lits)
+            blk = bytearray()
+            first = True
+            for _ in range(rnd.choice([1, 3, 40, 400])):
+                off = rnd.randrange(32769, min(65535, len(plain)) + 1)
+                ml = rnd.choice([4, 5, 8, 19, 64, 300, 2000])
+                blk += _lz4_sequence(bytes(lits) if first else b"", off, ml)
+                first = False
+                for _k in range(ml):
+                    plain.append(plain[len(plain) - off])
+            tail = corpus.p_rand(12, 5)
+            blk += _lz4_sequence(tail)
+            plain += tail
+            blocks.append(bytes(blk)); plains.append(bytes(plain))
+    O.lib.refcpu_set_max_output(1 << 23)
+    for z, p in zip(blocks[::5], plains[::5]):
+        assert O.lz4_block(z)[:2] == (0, p)
+    O.lib.refcpu_set_max_output(1 << 30)
+    # many copies at once so that both workgroups of a CU and several rounds of the grid are in flight
+    reps = 8
+    b = DeviceBatch("lz4_block", blocks * reps, [len(p) for p in plains] * reps)
+    b.launch(sync=True)
+    r = b.results()
+    for i in range(len(blocks) * reps):
+        p = plains[i % len(blocks)]
+        assert int(r["status"][i]) == 0 and int(r["out_len"][i]) == len(p), i
+        assert b.output(i, len(p)) == p, "bytes differ on block %d" % i
