@@ -1,37 +1,35 @@
 // inflate_sync.h -- Deflate entropy decode (phase 1), one compressed stream per WAVEFRONT, 64 lanes decoding 64
 // sub-chunks of the stream at once.
 //
-// Replaces the symbol loop of Deflate.decompress(_ bitReader:) (reference Sources/Deflate/Deflate.swift:171-236) and the
-// code-length section of a dynamic header (:86-167).  Huffman decoding is a serial chain -- where a code starts is known
-// only when the previous one has been decoded -- but a decoder started at a WRONG bit offset falls into step with the
-// true symbol sequence after a few symbols (it lands on a new position after every code; about one position in
-// thirteen is a true symbol start).  A wavefront therefore cuts the next kSyncRound bytes of the stream into 64
-// sub-chunks of kSyncChunk bytes, one per lane, and iterates:
+// Replaces the symbol loop of Deflate.decompress(_ bitReader:) (reference Sources/Deflate/Deflate.swift:171-236), the
+// code-length section of a dynamic header (:86-167) and the table construction of Code.huffmanCodes / DecodingTree.init
+// (Sources/Common/CodingTree/Code.swift:15-39, DecodingTree.swift:15-34).  Huffman decoding is a serial chain -- where a
+// code starts is known only when the previous one has been decoded -- but a decoder started at a WRONG bit offset falls
+// into step with the true symbol sequence after a few symbols.  A wavefront therefore cuts the next kSyncRound bytes of the
+// stream into 64 sub-chunks of kSyncChunk bytes, one per lane, and runs a ROUND:
 //
-//   pass 1      lane 0 starts at the true position, every other lane at its sub-chunk boundary; all decode (counting
-//               only) until they cross the end of their sub-chunk and note where they ended;
-//   pass 2..    a lane whose start differs from the end of its left neighbour decodes again from there.  After pass 2
-//               nearly every lane is on the true sequence (its garbage decode had synchronised inside the neighbour's
-//               sub-chunk); the loop runs until the chain of (start == left neighbour's end) reaches the end-of-block
-//               symbol or lane 63 -- each pass makes at least one more lane final, so it terminates;
-//   scan        exclusive prefix sums of the per-lane counts (literals, records, output bytes);
-//   emit        every lane decodes its sub-chunk once more and writes its literals to the dense literal stream and one
-//               record per match to the record list (lz_resolve.h) at exact offsets.  A sub-chunk closes its trailing
-//               literals with a literal-only record, so that no lane needs the literal run of its neighbour.
+//   walk        lane 0 starts at the true position, every other lane at its sub-chunk boundary; all decode -- nothing but
+//               the code lengths -- until they cross the end of their sub-chunk and note where they ended (walk_chunk: ten
+//               vector instructions per code);
+//   provisional every lane decodes ONCE more from where its left neighbour's walk ended, and this pass counts and emits:
+//   decode      records and literal groups go to the wave's row-major scratch in the workspace (decode_chunk_prov: about
+//               thirty vector instructions per code, no conditional region -- both stores of a step are unconditional and
+//               aim at the row that is current, so a row is simply rewritten until it is final);
+//   chain check lane k's decode must end where lane k + 1's began; lanes for which it does not decode again (1.4 passes
+//               per round on text); when the chain holds, three wave scans give every lane its offsets and copy_prov moves
+//               the rows to their final places in the record list and the literal stream (lz_resolve.h);
+//   fallback    anything unusual -- a symbol for the checked step, a literal run too long for one record, the capacity or the
+//               workspace inside the round, a distance beyond the output -- abandons the attempt before anything is committed;
+//               the general passes (count, scan, emit: decode_chunk) or the checked one-symbol step take over.
 //
-// All 64 lanes share ONE set of tables in LDS: direct lookup tables (10 / 8 bits) whose entries carry code length,
-// extra bits, kind and base value; a code longer than the tables finds its length by comparing the bit-reversed window
-// against the canonical limits of the lengths 9..15 and its symbol in the sorted symbol array.  The input of a round is
-// staged in LDS with coalesced loads; a lane walks its sub-chunk through a two-dword register window whose next dword is
-// read from LDS every iteration, needed or not.  Sub-chunks are 17 dwords long: an odd stride keeps the 64 lanes on 64
-// different LDS banks without padding, and everything in LDS together is exactly 10 KB (16 waves per CU).
-//
-// Anything the fast path does not want to decide -- an unassigned or over-subscribed code, symbols 286/287, distance
-// symbols 30/31, a distance beyond the output, the end of the input inside a symbol, the capacity inside a round -- makes
-// it return WITHOUT committing the round; the caller then runs the fully checked one-symbol step of inflate_lane.h,
-// which carries the reference's error taxonomy.  Headers, stored blocks and static tables also stay with inflate_lane.h;
-// the code-length section of a dynamic header is decoded here through a 128-entry table, and its histogram / counting
-// sort run on all lanes.
+// All 64 lanes share ONE set of tables in LDS: direct lookup tables (10 / 8 bits, 32-bit entries that carry everything a
+// step needs, laid out so that the position update, the table switch of a length code and the loop exit are one instruction
+// each -- see the entry layout below) and two-level SUBTABLES for the codes longer than that (184 entries in LDS, which
+// covers text and most binary data; larger sets overflow to the workspace).  The input of a round is staged in LDS shifted
+// left by two bits, so that the funnel shift a lane reads its window with yields the table ADDRESS bits directly.
+// Sub-chunks are 17 dwords long: an odd stride keeps the 64 lanes on different LDS banks, and everything in LDS together is
+// exactly 10 KB (16 waves per CU).  What only the checked step needs -- canonical limits and the sorted symbol arrays with the
+// reference's semantics for incomplete and over-subscribed sets -- lives in the workspace, not in LDS.
 #ifndef SWC_INFLATE_SYNC_H
 #define SWC_INFLATE_SYNC_H
 
@@ -44,29 +42,48 @@ namespace inflate {
 constexpr int kSyncLitBits = 10, kSyncDistBits = 8;
 // Input bytes per lane and round: a whole number of dwords and an ODD number of them (17), so that the lanes, which start
 // a pass at the same offset of their sub-chunks, read 64 different LDS banks without any padding of the staged input.
-// With 68 bytes the wave's LDS is EXACTLY 10,240 bytes = 16 waves per CU: the kernel's speed is proportional to the waves
-// a CU holds (measured by padding the LDS: 12 waves 13.7 ms, 9 waves 17.6 ms, 7 waves 22.1 ms; 16 waves 12.05 ms), and
-// shorter sub-chunks cost more in rounds and lane imbalance than further waves bring (60 bytes: 12.85 ms, 52: 13.75 ms).
+// With 68 bytes the wave's LDS is EXACTLY 10,240 bytes = 16 waves per CU (measured in round 2 by padding the LDS: 12 waves
+// 13.7 ms, 9 waves 17.6 ms, 7 waves 22.1 ms against 12.05 ms; 60-byte sub-chunks 12.85 ms, 52 bytes 13.75 ms).
 constexpr uint32_t kSyncChunk = SWC_SYNC_CHUNK;
 constexpr uint32_t kSyncRound = 64u * kSyncChunk;
-constexpr uint32_t kSyncStage = (kSyncRound + 32u + 15u) & ~15u;    // + what the last lane may read past its sub-chunk (a code of <= 48 bits, then the window's two dwords and the next one: < 28 bytes)
-constexpr uint32_t kSyncStageLds = kSyncStage;
-constexpr uint32_t kEntInvalid = 0x80000000u;        // bit 31 = STOP: the decode loops end at this entry -- the end-of-block symbol (with kEntEob), or a code
-                                                      // of the set that is not a symbol the fast path takes (without; such an entry counts no bits)
+constexpr uint32_t kSyncStage = (kSyncRound + 32u + 15u) & ~15u;    // + what the last lane may read past its sub-chunk (a code of <= 48 bits, then the window's two dwords: < 24 bytes)
 constexpr uint32_t kPosFail = 0xFFFFFFFFu;
 static_assert(kSyncChunk % 4 == 0 && kSyncChunk >= 36, "sub-chunks are whole dwords");
 
-// Table entry, laid out for a decode loop without branches per kind:
-//   [0:4] bits the symbol takes (code + extra)   [5] end of block   [6:9] code length   [10] length symbol: the next code is
-//   a distance (the bit IS the offset of the distance table in `lut`)   [11:14] extra bits   [15] literal
-//   [16:30] base value   [31] stop (end of block, or invalid).   0: no entry (long code).
-constexpr uint32_t kEntEob = 1u << 5, kEntLen = 1u << kSyncLitBits, kEntLit = 1u << 15;
-constexpr uint32_t kEntClenShift = 6, kEntExtShift = 11;
-static_assert(kSyncLitBits == 10, "the entry layout keeps bit 10 for the length flag");
-// kind, lit/len table: 1 literal, 2 length, 3 end of block; distance table: 0 distance.
+// ---- table entry ----------------------------------------------------------------------------------------------------
+//   [0:4]   n2: bits the symbol takes (code + extra) + 2.  0: a LINK to a subtable (below)
+//   [5:9]   c2: code length + 2
+//   [10:11] both set UNLESS this is a length symbol: the two bits by which the index masks of the two tables differ
+//   [12]    length symbol: the next code is a distance (the bit IS the byte offset of the distance table behind the lit/len table)
+//   [13]    literal
+//   [14:28] base value: the literal, the length base, the distance base - 1
+//   [29]    distance symbol
+//   [30]    stop: the end-of-block symbol (n2 > 2) or no symbol the fast path takes (n2 == 2: no bits)
+//   [31]    set in length AND distance entries: added to a position it flips its top bit on at a length code and off again at the
+//           distance code, so that ONE signed compare (position < end of the sub-chunk) is the whole loop condition; a stop
+//           entry adds bit 30 and thereby ends the loop as well.  (Entries of the distance table that stop carry bit 31 too.)
+// LINK (n2 == 0, bits 30 / 31 clear): [5:9] index width k of the subtable, [10:14] bits in front of it + 2 (12 / 10),
+//   [18:29] index of the subtable's first entry.
+// The window a lane looks at, `bits4`, is the stream from the symbol's first bit on, shifted LEFT by two (the stage is stored
+// that way): (bits4 & mask) | table is the LDS byte address of the entry, and the extra bits of the symbol are
+// bfe(bits4, 0, n2) >> c2.
+constexpr uint32_t kEntNotLen = 3u << 10, kEntLen = 1u << 12, kEntLit = 1u << 13, kEntDist = 1u << 29, kEntStop = 1u << 30, kEntTog = 1u << 31;
+constexpr uint32_t kEntBaseShift = 14, kEntPosMask = kEntTog | kEntStop | 31u;
+constexpr uint32_t kLitMask4 = ((1u << kSyncLitBits) - 1u) << 2, kDistMask4 = ((1u << kSyncDistBits) - 1u) << 2;
+static_assert(kEntLen == 4u << kSyncLitBits, "the length flag is the byte offset of the distance table");
+static_assert((kLitMask4 & ~kEntNotLen) == kDistMask4, "the masks differ in the not-length bits");
+constexpr uint32_t kInvLit = 2u | kEntNotLen | kEntStop, kInvDist = kInvLit | kEntTog;
+// kind: 1 literal, 2 length, 3 end of block, 0 distance (value: the distance base itself)
 SWC_HD uint32_t make_entry(uint32_t clen, uint32_t ext, uint32_t kind, uint32_t value) {
-    return (clen + ext) | (kind == 1 ? kEntLit : kind == 2 ? kEntLen : kind == 3 ? kEntEob | kEntInvalid : 0u) | (clen << kEntClenShift) | (ext << kEntExtShift) | (value << 16);
+    const uint32_t c = (clen + ext + 2u) | ((clen + 2u) << 5);
+    return kind == 1 ? c | kEntNotLen | kEntLit | (value << kEntBaseShift)
+         : kind == 2 ? c | kEntLen | kEntTog | (value << kEntBaseShift)
+         : kind == 3 ? c | kEntNotLen | kEntStop
+                     : c | kEntNotLen | kEntDist | kEntTog | ((value - 1u) << kEntBaseShift);
 }
+SWC_HD uint32_t ent_bits(uint32_t e) { return (e & 31u) - 2u; }
+SWC_HD bool ent_is_eob(uint32_t e) { return (e & kEntStop) != 0u && (e & 31u) > 2u; }
+SWC_HD bool ent_is_link(uint32_t e) { return (e & kEntPosMask) == 0u; }
 
 // The entry of lit/len symbol `sym` (0..287) / distance symbol `sym` (0..31) with a code of `d` bits
 // (Deflate+Constants.swift: lengthBase / distanceBase as arithmetic).
@@ -74,59 +91,71 @@ SWC_HD uint32_t entry_of_symbol(bool dist, uint32_t sym, uint32_t d) {
     if (!dist) {
         if (sym < 256) return make_entry(d, 0, 1, sym);
         if (sym == 256) return make_entry(d, 0, 3, 0);
-        if (sym > 285) return kEntInvalid;       // 286, 287: the checked step reports wrongSymbol
+        if (sym > 285) return kInvLit;           // 286, 287: the checked step reports wrongSymbol
         const uint32_t s = sym - 257u;
         const uint32_t e = s < 8 || s == 28 ? 0u : (s >> 2) - 1u;
         const uint32_t base = s < 8 ? 3u + s : s == 28 ? 258u : 3u + ((4u + (s & 3u)) << e);
         return make_entry(d, e, 2, base);
     }
-    if (sym > 29) return kEntInvalid;            // 30, 31: wrongSymbol
+    if (sym > 29) return kInvDist;               // 30, 31: wrongSymbol
     const uint32_t e = sym < 4 ? 0u : (sym >> 1) - 1u;
     const uint32_t base = sym < 4 ? 1u + sym : 1u + ((2u + (sym & 1u)) << e);
     return make_entry(d, e, 0, base);
 }
 
-// The canonical tables of inflate_lane.h (struct Table) kept in LDS: per length d the left-justified code limit, the slot
-// word (sorted index of the first code - first code | index of the first symbol >= 256 << 16) and the sorted index of the
-// first code; the number of codes; the over-subscription flag.  Lit/len alphabet at kAuxLit, distance alphabet at kAuxDist.
+// The canonical tables the checked step decodes with (struct Table of round 1, now in the workspace): per length d the
+// left-justified code limit, the slot word (sorted index of the first code - first code), the sorted index of the first code;
+// the number of codes; the over-subscription flag.  Lit/len alphabet at kAuxLit, distance alphabet at kAuxDist.
 constexpr int kAuxLim = 0, kAuxSlot = 16, kAuxStart = 32, kAuxCount = 48 /* == start[16] */, kAuxOver = 49, kAuxTable = 52;
 constexpr int kAuxLit = 0, kAuxDist = kAuxTable, kAuxWords = 2 * kAuxTable;
+// The spill in the workspace (lz_resolve.h: behind the scratch rows): aux | sorted symbols (16 bit each) | subtable overflow
+constexpr uint32_t kSpillSyms = 512, kSpillSub = 1536, kSubLds = 184, kSubMax = (uint32_t)(lzr::kProvSpillBytes - kSpillSub) / 4u;
+constexpr uint32_t kSymDist = 288;   // the distance symbols follow the lit/len symbols in the sorted array
+static_assert(kAuxWords * 4 <= (int)kSpillSyms && kSpillSyms + 2 * (288 + 32) <= kSpillSub && kSubMax < 4096u, "spill layout");
 
 struct SyncLds {   // 10,240 bytes: see kSyncChunk
-    uint32_t syms[kWordsPerLane];                                   // the sorted symbol arrays of inflate_lane.h (LaneLds{syms, 1})
+    alignas(16) uint8_t stage[kSyncStage];                          // staged input of a round (shifted left by two bits); header build: scratch.  FIRST: the window reads (two dwords at a computed address) then need no base added
     uint32_t lut[(1 << kSyncLitBits) + (1 << kSyncDistBits)];      // direct tables: lit/len, then distance
-    uint32_t aux[kAuxWords];                                        // the canonical tables (see kAux*)
+    uint32_t sub[kSubLds];                                          // subtables of the long codes (if they fit)
 #ifdef SWC_SYNC_LDS_PAD
     uint8_t occupancy_experiment_pad[SWC_SYNC_LDS_PAD];             // (tools/gpu_chunk_sweep.sh: fewer waves per CU, nothing else changed)
 #endif
-    alignas(16) uint8_t stage[kSyncStageLds];                       // staged input of a round; header build: code lengths, counters, code-length table
 };
-#if SWC_SYNC_CHUNK == 68
-static_assert(sizeof(SyncLds) <= 10240, "16 waves per CU: the wave's LDS must stay within 160 KB / 16");
+#if SWC_SYNC_CHUNK == 68 && !defined(SWC_SYNC_LDS_PAD)
+static_assert(sizeof(SyncLds) == 10240, "16 waves per CU: the wave's LDS must stay within 160 KB / 16");
 #endif
 // header scratch inside `stage`
-constexpr uint32_t kHdrLens = 0;       // 320 bytes: code length of symbol s
-constexpr uint32_t kHdrCnt = 320;      // 48 words: codes per length (lit/len, of those symbols < 256, distance)
+constexpr uint32_t kHdrLens = 0;       // 320 bytes: code length of symbol s (lit/len, then distance)
+constexpr uint32_t kHdrRun = 320;      // 32 words: running / final number of codes per length (lit/len, distance)
 constexpr uint32_t kHdrClLut = 512;    // 128 bytes: code-length code, len | symbol << 3 (0xFF: no code)
+constexpr uint32_t kHdrSorted = 640;   // 320 x 16 bit: (symbol | length << 9) in canonical order
+constexpr uint32_t kHdrRank = 1280;    // 320 x 16 bit: rank of symbol s among the codes of its length   (dead before kHdrPt is written)
+constexpr uint32_t kHdrIn = 1280;      // 1,040 bytes: the staged code-length section of the header           (dead before the table build)
+constexpr uint32_t kHdrPt = 1280;      // (1024 + 256) x 16 bit: per first-level prefix of a long code: subtable offset | width << 12
+constexpr uint32_t kHdrTab = 3840;     // 2 x (first code[16] | sorted index of the first code[17]) words
+static_assert(kHdrTab + 2 * 33 * 4 <= kSyncStage && kHdrPt + 2 * 1280 <= kHdrTab, "header scratch fits the stage");
 
 enum { kSyncEob = 0, kSyncBail = 1, kSyncBailCap = 2 };
 #if defined(SWC_HOST_EMULATION)
 // statistics of the emulated decoder (tests, tools/sync_stats.py): rounds committed, bails, lane-passes, symbol iterations
 inline uint64_t g_sync_stats[8];
 #define SWC_SYNC_STAT(i, n) (g_sync_stats[i] += (n))
-// wave-steps: a pass takes as long as its busiest lane.  g_sync_wave[k] adds up, per pass of kind k (0 walk, 1 count,
-// 2 emit), the largest number of code iterations any of the 64 lanes ran (lanes are emulated in ascending order here).
-inline uint64_t g_sync_iters = 0, g_sync_wave[4] = {0, 0, 0, 0}, g_sync_passmax = 0;
+// wave-steps: a pass takes as long as its busiest lane.  g_sync_wave[k] adds up, per pass of kind k (0 walk, 1 provisional /
+// count, 2 emit), the largest number of code iterations any of the 64 lanes ran; [3]: wave-steps in which some lane met a long code.
+inline uint64_t g_sync_iters = 0, g_sync_wave[4] = {0, 0, 0, 0}, g_sync_passmax = 0, g_sync_it0 = 0;
+inline uint8_t g_sync_long[4096];
 #define SWC_SYNC_ITER() (g_sync_iters++)
-#define SWC_SYNC_LANE_BEGIN(t) if ((t) == 0) g_sync_passmax = 0; const uint64_t it0_ = g_sync_iters;
-#define SWC_SYNC_LANE_END(t, n, k) { if (g_sync_iters - it0_ > g_sync_passmax) g_sync_passmax = g_sync_iters - it0_; if ((t) == (n) - 1) g_sync_wave[k] += g_sync_passmax; }
+#define SWC_SYNC_LONG() (g_sync_long[(g_sync_iters - 1 - g_sync_it0) & 4095] = 1)
+#define SWC_SYNC_LANE_BEGIN(first) if (first) { g_sync_passmax = 0; for (auto& h_ : g_sync_long) h_ = 0; } g_sync_it0 = g_sync_iters;
+#define SWC_SYNC_LANE_END(last, k) { if (g_sync_iters - g_sync_it0 > g_sync_passmax) g_sync_passmax = g_sync_iters - g_sync_it0; if (last) { g_sync_wave[k] += g_sync_passmax; for (auto h_ : g_sync_long) g_sync_wave[3] += h_; } }
 #else
 #define SWC_SYNC_STAT(i, n) ((void)0)
 #define SWC_SYNC_ITER() ((void)0)
-#define SWC_SYNC_LANE_BEGIN(t)
-#define SWC_SYNC_LANE_END(t, n, k)
+#define SWC_SYNC_LONG() ((void)0)
+#define SWC_SYNC_LANE_BEGIN(first)
+#define SWC_SYNC_LANE_END(last, k)
 #endif
-enum { kFlagEob = 1u, kFlagFail = 2u, kFlagTrap = 4u };
+enum { kFlagEob = 1u, kFlagFail = 2u, kFlagTrap = 4u, kFlagSlow = 8u };
 // profile builds (-DSWC_PROFILE): cycles per part of one stream -- 0 header, 1 tables, 2 staging, 3 decode passes, 4 chain
 // logic + scans, 5 copy / emit, 6 checked steps / rest; 7 rounds, 8 passes, 9 walk pass
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -142,40 +171,123 @@ struct SyncProf {};
 #define SWC_SPC(pp, k, n)
 #endif
 
-SWC_D void lds_atomic_inc(uint32_t* p) {
+SWC_HD uint32_t funnel32(uint32_t hi, uint32_t lo, uint32_t sh) {  // bits [sh, sh + 32) of hi:lo; only sh % 32 counts
 #if defined(__HIP_DEVICE_COMPILE__)
-    __hip_atomic_fetch_add(p, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    return __builtin_amdgcn_alignbit(hi, lo, sh);
 #else
-    (*p)++;
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (sh & 31u));
+#endif
+}
+SWC_HD uint32_t bfe32(uint32_t v, uint32_t off, uint32_t width) {   // only off % 32 and width % 32 count; width 0 -> 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ubfe(v, off, width);
+#else
+    off &= 31u; width &= 31u;
+    return width == 0 ? 0u : (v >> off) & ((1u << width) - 1u);
+#endif
+}
+SWC_HD uint32_t sbfe1(uint32_t v, uint32_t bit) {   // all ones if the bit is set
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (uint32_t)__builtin_amdgcn_sbfe((int)v, bit, 1u);
+#else
+    return (v >> bit) & 1u ? 0xFFFFFFFFu : 0u;
+#endif
+}
+SWC_HD uint32_t bfi32(uint32_t m, uint32_t a, uint32_t b) {   // (a & m) | (b & ~m) as v_bfi_b32 (the optimiser turns the C form into a compare and a select when m is a sign mask)
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(m), "v"(a), "v"(b));
+    return d;
+#else
+    return (a & m) | (b & ~m);
+#endif
+}
+SWC_HD uint32_t alignbyte32(uint32_t hi, uint32_t lo, uint32_t nbytes) {   // bytes [n, n + 4) of hi:lo, n = nbytes % 4
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, nbytes);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (nbytes & 3u)));
+#endif
+}
+// (a << K) + b as ONE instruction (v_lshl_add_u32): the optimiser otherwise regroups sums of shifted terms into more of them
+template <int K>
+SWC_HD uint32_t lshl_add(uint32_t a, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d;
+    asm("v_lshl_add_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "n"(K), "v"(b));
+    return d;
+#else
+    return (a << K) + b;
+#endif
+}
+// (a & m) | o as ONE instruction (v_and_or_b32) with both constants in registers (a VOP3 instruction of gfx9 takes no literal)
+SWC_HD uint32_t and_or(uint32_t a, uint32_t m, uint32_t o) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d;
+    asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(m), "v"(o));
+    return d;
+#else
+    return (a & m) | o;
+#endif
+}
+// m ? 0 : b for a mask m of all ones or all zeros (v_bfi_b32 with the constant 0: the optimiser turns the C form into a compare and a select)
+SWC_HD uint32_t clear_if(uint32_t m, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d;
+    asm("v_bfi_b32 %0, %1, 0, %2" : "=v"(d) : "v"(m), "v"(b));
+    return d;
+#else
+    return b & ~m;
+#endif
+}
+// a * k + b, a signed 24-bit multiply-add (v_mad_i32_i24)
+SWC_HD uint32_t mad24(uint32_t a, int32_t k, uint32_t b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(k), "v"(b));
+    return d;
+#else
+    return (uint32_t)((int32_t)a * k) + b;
 #endif
 }
 
-// ---- tables ------------------------------------------------------------------------------------------------------
-// Code.swift:23-37 per length, from the per-length counts: cnt[d] codes of length d, of which lo[d] are symbols < 256
-// (lo == nullptr: none).  Every lane computes and stores the same values.
-SWC_D void table_from_counts(const uint32_t* cnt, const uint32_t* lo, uint32_t* tb) {
-    uint32_t v = 0, off = 0, over = 0;
-    tb[kAuxLim] = 0; tb[kAuxSlot] = 0; tb[kAuxStart] = 0;
-#pragma unroll 1
-    for (int d = 1; d <= 15; d++) {
-        const uint32_t c = cnt[d];
-        tb[kAuxLim + d] = (v + c) << (15 - d);
-        if (c != 0 && v + c > (1u << d)) over = 1;
-        tb[kAuxSlot + d] = ((off - v) & 0xFFFFu) | ((off + (lo ? lo[d] : 0u)) << 16);
-        tb[kAuxStart + d] = off;
-        off += c;
-        v = (v + c) << 1;
-    }
-    tb[kAuxCount] = off;
-    tb[kAuxOver] = over;
+// Where the subtables of the stream are: in LDS (g == nullptr) or in the workspace.
+struct SubTab {
+    const SWC_AS_GLOBAL uint32_t* g;
+};
+// The spill of a stream in the workspace
+struct Spill {
+    SWC_AS_GLOBAL uint32_t* aux;
+    SWC_AS_GLOBAL uint16_t* syms;
+    SWC_AS_GLOBAL uint32_t* sub;
+};
+
+// the two dwords of the stage that hold LDS bit `p`, funnelled: LDS bits [p, p + 32)
+SWC_D uint32_t stage_bits(const SyncLds* sl, uint32_t p) {
+    const uint32_t* w = (const uint32_t*)(sl->stage + ((p >> 3) & 0x1FFCu));
+    return funnel32(w[1], w[0], p);
 }
-// One symbol of the lit/len (LIT) or distance alphabet from the LDS form of the tables, with the reference's
-// semantics for every code set (Lane::decode_sym<LIT, true>: DecodingTree.swift:36-50 over the heap Code.swift:15-39
-// builds -- for an over-subscribed set the shallowest occupied node wins, the last writer of a node wins).
-// Returns the symbol or -1 (symbolNotFound: unassigned path, or the code runs past the end of the input).
+// the entry a LINK leads to
+SWC_D uint32_t long_lookup(const SyncLds* sl, const SubTab st, uint32_t bits4, uint32_t link) {
+    const uint32_t idx = bfe32(bits4, link >> 10, link >> 5);
+    const uint32_t at = (link >> 18) + idx;
+    return st.g ? st.g[at] : sl->sub[at < kSubLds ? at : 0u];
+}
+// the entry of the code that starts at stream bit `pos` of the round (general passes: not the hot loops)
+SWC_D uint32_t entry_at(const SyncLds* sl, const SubTab st, uint32_t pos, bool dist, uint32_t& bits4) {
+    bits4 = stage_bits(sl, pos);
+    uint32_t e = *(const uint32_t*)((const uint8_t*)sl->lut + ((bits4 & (dist ? kDistMask4 : kLitMask4)) | (dist ? kEntLen : 0u)));
+    if (ent_is_link(e)) e = long_lookup(sl, st, bits4, e);
+    return e;
+}
+
+// ---- the checked step (canonical tables in the workspace) --------------------------------------------------------------
+// One symbol of the lit/len (LIT) or distance alphabet with the reference's semantics for every code set (DecodingTree.swift:
+// 36-50 over the heap Code.swift:15-39 builds -- for an over-subscribed set the shallowest occupied node wins, the last writer
+// of a node wins).  Returns the symbol or -1 (symbolNotFound: unassigned path, or the code runs past the end of the input).
 template <bool LIT>
-SWC_D int decode_sym_lds(BitReader& br, const SyncLds* sl) {
-    const uint32_t* tb = sl->aux + (LIT ? kAuxLit : kAuxDist);
+SWC_D int decode_sym_canon(BitReader& br, const Spill sp) {
+    const SWC_AS_GLOBAL uint32_t* tb = sp.aux + (LIT ? kAuxLit : kAuxDist);
     const uint32_t c15 = brev32(br.peek32()) >> 17;
     uint32_t len = 16, idx = 0;
     if (tb[kAuxOver] == 0) {
@@ -200,19 +312,16 @@ SWC_D int decode_sym_lds(BitReader& br, const SyncLds* sl) {
     }
     if (len > br.bc) return -1;  // DecodingTree.swift:39 -- ran out of bits before reaching a leaf
     br.consume(len);
-    const LaneLds l{const_cast<uint32_t*>(sl->syms), 1};
-    uint32_t sym = *sym_ptr(l, LIT ? W_LIT_SYM : W_DIST_SYM, idx);
-    if (LIT) sym |= idx >= (tb[kAuxSlot + len] >> 16) ? 256u : 0u;
-    return (int)sym;
+    if (idx >= (LIT ? 288u : 32u)) return -1;   // (cannot happen for a set the header accepted; keeps the read inside the array)
+    return (int)sp.syms[(LIT ? 0u : kSymDist) + idx];
 }
 
-// One symbol with every check of the reference (Deflate.swift:171-236) -- Lane::careful_step over the LDS tables, so
-// that the wave kernel never holds the register form of the tables.  Returns SWC_OK to continue, -1 at the
+// One symbol with every check of the reference (Deflate.swift:171-236).  Returns SWC_OK to continue, -1 at the
 // end-of-block symbol, or the error.
-SWC_D int careful_step_lds(Lane& ln, const SyncLds* sl) {
+SWC_D int careful_step(Lane& ln, const Spill sp) {
     BitReader& br = ln.br;
     br.refill();
-    const int sym = decode_sym_lds<true>(br, sl);
+    const int sym = decode_sym_canon<true>(br, sp);
     if (sym < 0) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :175
     if (sym < 256) {
         ln.put_byte((uint8_t)sym);
@@ -232,7 +341,7 @@ SWC_D int careful_step_lds(Lane& ln, const SyncLds* sl) {
         length = 3 + ((4 + (s & 3)) << e) + br.bits(e);  // Constants.lengthBase
     }
     br.refill();
-    const int dc = decode_sym_lds<false>(br, sl);
+    const int dc = decode_sym_canon<false>(br, sp);
     if (dc < 0) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :199
     if (dc > 29) return SWC_E_DEFLATE_WRONG_SYMBOL;     // :201
     uint32_t distance;
@@ -249,224 +358,211 @@ SWC_D int careful_step_lds(Lane& ln, const SyncLds* sl) {
     return SWC_OK;
 }
 
-// Direct tables from the canonical tables and the sorted symbol arrays in LDS.  All lanes.
-SWC_D void sync_build_luts(SyncLds* sl) {
-    constexpr int N = kWave;
-    const LaneLds l{sl->syms, 1};
-    SIMT_BEGIN(t, N)
-        for (int i = t; i < (1 << kSyncLitBits) + (1 << kSyncDistBits); i += N) sl->lut[i] = 0;
-    SIMT_END_WAVE
-    SIMT_BEGIN(t, N)
+// ---- tables ------------------------------------------------------------------------------------------------------
+// Code.swift:23-37 per length, from the per-length counts cnt[1..15]: into the workspace form (tb: kAux*) and into the two
+// small arrays the table build reads (first code and sorted index of the first code per length).  One lane per table.
+SWC_D void table_from_counts(const uint32_t* cnt, SWC_AS_GLOBAL uint32_t* tb, uint32_t* first, uint32_t* start) {
+    uint32_t v = 0, off = 0, over = 0;
+    tb[kAuxLim] = 0; tb[kAuxSlot] = 0; tb[kAuxStart] = 0;
+    first[0] = 0; start[0] = 0;
 #pragma unroll 1
-        for (int tbl = 0; tbl < 2; tbl++) {
-            const uint32_t* tb = sl->aux + (tbl ? kAuxDist : kAuxLit);
-            const uint32_t n_sym = tb[kAuxCount], n_max = tbl ? 32u : 288u;
-            const uint32_t lut_bits = tbl ? (uint32_t)kSyncDistBits : (uint32_t)kSyncLitBits;
-            uint32_t* lut = sl->lut + (tbl ? (1 << kSyncLitBits) : 0);
-            for (uint32_t j = (uint32_t)t; j < n_sym && j < n_max; j += (uint32_t)N) {
-                uint32_t d = 1;
-#pragma unroll 1
-                for (uint32_t q = 2; q <= 15; q++) if (j >= tb[kAuxStart + q]) d = q;   // the length whose index range holds j
-                const uint32_t fst = d == 1 ? 0u : tb[kAuxLim + d - 1] >> (15 - d);
-                const uint32_t code = fst + (j - tb[kAuxStart + d]);
-                const uint32_t rev = brev32(code) >> (32 - d);
-                uint32_t sym;
-                if (tbl == 0) {
-                    sym = *sym_ptr(l, W_LIT_SYM, j);
-                    if (j >= (tb[kAuxSlot + d] >> 16)) sym |= 256u;
-                } else {
-                    sym = *sym_ptr(l, W_DIST_SYM, j);
-                }
-                const uint32_t entry = entry_of_symbol(tbl != 0, sym, d);
-                if (d <= lut_bits)
-                    for (uint32_t m = rev; m < (1u << lut_bits); m += 1u << d) lut[m] = entry;
-            }
-        }
-    SIMT_END_WAVE
+    for (int d = 1; d <= 15; d++) {
+        const uint32_t c = cnt[d];
+        tb[kAuxLim + d] = (v + c) << (15 - d);
+        if (c != 0 && v + c > (1u << d)) over = 1;
+        tb[kAuxSlot + d] = (off - v) & 0xFFFFu;
+        tb[kAuxStart + d] = off;
+        first[d] = v;
+        start[d] = off;
+        off += c;
+        v = (v + c) << 1;
+    }
+    tb[kAuxCount] = off;
+    tb[kAuxOver] = over;
+    start[16] = off;
 }
 
-// From the code lengths lens[0 .. literals + distances) in the header scratch: histogram, canonical tables, the
-// (length, symbol)-sorted symbol arrays of inflate_lane.h, per-symbol entries and direct tables.  All lanes.
-SWC_D void sync_tables_from_lengths(SyncLds* sl, int literals, int distances) {
+// From the code lengths lens[0 .. literals + distances) in the header scratch: the canonical tables and the (length,
+// symbol)-sorted symbol arrays in the workspace (what the checked step decodes with) and -- unless a set is over-subscribed,
+// which only the checked step decodes -- the direct tables and the subtables of the long codes.  All lanes.  Returns false
+// if the fast path cannot take the block (over-subscribed, or subtables beyond the overflow area).
+//   A  rank of every symbol among the codes of its length, 64 symbols at a time: the lanes with the same length find each
+//      other with four ballots (one per bit of the length), rank = the number of those in front of me + the running count;
+//   B  first code / first sorted index per length (one lane per alphabet), scatter of the symbols into canonical order;
+//   C  in canonical order: codes that fit the direct table fill their slots; a longer code belongs to the subtable of its
+//      first 10 / 8 bits, whose width is set by the LAST (longest) code with that prefix -- prefixes do not decrease in
+//      canonical order, so "last" is a look at the next symbol -- and whose offset is a running sum over those;
+//   D  the long codes fill their subtable slots.
+SWC_D bool sync_tables_from_lengths(SyncLds* sl, const Spill sp, int literals, int distances, SubTab& st) {
     using simt::PT;
     constexpr int N = kWave;
     const uint8_t* lens = sl->stage + kHdrLens;
-    uint32_t* cnt = (uint32_t*)(sl->stage + kHdrCnt);
-    const LaneLds l{sl->syms, 1};
+    uint32_t* run = (uint32_t*)(sl->stage + kHdrRun);
+    uint16_t* sorted = (uint16_t*)(sl->stage + kHdrSorted);
+    uint16_t* rankb = (uint16_t*)(sl->stage + kHdrRank);
+    uint16_t* pt = (uint16_t*)(sl->stage + kHdrPt);
+    uint32_t* tab = (uint32_t*)(sl->stage + kHdrTab);   // per alphabet: first[16] | start[17]
     const int total = literals + distances;
-    // codes per length of the lit/len alphabet, of those symbols < 256, and of the distance alphabet
-    SIMT_BEGIN(t, N)
-        for (int s = t; s < total; s += N) {
-            const uint32_t v = lens[s];
-            if (v) {
-                if (s < literals) { lds_atomic_inc(&cnt[v]); if (s < 256) lds_atomic_inc(&cnt[16 + v]); }
-                else lds_atomic_inc(&cnt[32 + v]);
-            }
-        }
-    SIMT_END_WAVE
-    table_from_counts(cnt, cnt + 16, sl->aux + kAuxLit);
-    table_from_counts(cnt + 32, nullptr, sl->aux + kAuxDist);
-    simt::wave_fence();
-    // counting sort by (length, symbol): 64 symbols at a time, rank within the length by ballot; cnt[d] / cnt[32 + d]
-    // become the running positions
-    SIMT_BEGIN(t, N)
-        if (t < 16) { cnt[t] = sl->aux[kAuxLit + kAuxStart + t]; cnt[32 + t] = sl->aux[kAuxDist + kAuxStart + t]; }
-    SIMT_END_WAVE
-    PT<uint32_t, N> v;
+    st.g = nullptr;
+    // ---- A
+    SIMT_BEGIN(t, N) if (t < 32) run[t] = 0; SIMT_END_WAVE
+    PT<uint32_t, N> v, upd;
+    PT<uint64_t, N> m;
     PT<bool, N> p;
 #pragma unroll 1
     for (int g = 0; g * N < literals + N; g++) {   // the groups of the lit/len alphabet, then the one group of the distance alphabet
         const bool is_dist = g * N >= literals;
         const int s0 = is_dist ? literals : g * N, s_end = is_dist ? total : literals;
-        SIMT_BEGIN(t, N) v[t] = s0 + t < s_end ? (uint32_t)lens[s0 + t] : 0u; SIMT_END
-#pragma unroll 1
-        for (uint32_t d = 1; d <= 15; d++) {
-            SIMT_BEGIN(t, N) p[t] = v[t] == d; SIMT_END
-            const uint64_t m = simt::wave_ballot<N>(p);
-            if (m == 0) continue;
-            uint32_t* rp = &cnt[(is_dist ? 32u : 0u) + d];
-            const uint32_t r0 = *rp;
-            SIMT_BEGIN(t, N)
-                if (p[t]) *sym_ptr(l, is_dist ? W_DIST_SYM : W_LIT_SYM, r0 + (uint32_t)simt::popc64(m & ((1ull << t) - 1ull))) = (uint8_t)(s0 + t - (is_dist ? literals : 0));
-            SIMT_END_WAVE
-            *rp = r0 + (uint32_t)simt::popc64(m);
-            simt::wave_fence();
-        }
-    }
-    sync_build_luts(sl);
-}
-
-// ---- one sub-chunk -----------------------------------------------------------------------------------------------
-struct ChunkOut {
-    uint32_t end;     // bit position (relative to the round base) just past the last symbol taken; kPosFail: no valid decode
-    uint32_t nlit, nrec, nout;
-    uint32_t flags;
-};
-
-SWC_HD uint32_t funnel32(uint32_t hi, uint32_t lo, uint32_t sh) {  // bits [sh, sh + 32) of hi:lo, sh < 32
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_alignbit(hi, lo, sh);
-#else
-    return (uint32_t)((((uint64_t)hi << 32) | lo) >> sh);
-#endif
-}
-SWC_HD uint32_t bfe32(uint32_t v, uint32_t off, uint32_t width) {   // width 0..16, off + width <= 32
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __builtin_amdgcn_ubfe(v, off, width);
-#else
-    return width == 0 ? 0u : (v >> off) & ((1u << width) - 1u);
-#endif
-}
-
-// A code longer than the direct tables (lit/len: more than 10 bits, distance: more than 8): its length from the canonical
-// limits of the lengths 9..15 in LDS (`aux`; reads the compiler pairs up) with compares, its symbol from the sorted symbol
-// array, its entry by arithmetic -- no per-symbol entry table, which would cost the wave 1.3 KB of LDS.  The wave pays for
-// this path whenever ANY lane meets such a code (about one iteration in seven on text), so the alphabet only selects a base
-// address.
-struct LongCodes {
-    SWC_D void load(const SyncLds*) {}
-    // the entry of the code that starts `bits` (state: 0 lit/len, anything else distance); kEntInvalid if there is none
-    SWC_D uint32_t lookup(const SyncLds* sl, uint32_t bits, uint32_t state) const {
-        const uint32_t c15 = brev32(bits) >> 17;
-        const bool st = state != 0;
-        const uint32_t* tb = sl->aux + (st ? kAuxDist : kAuxLit);
-        // the limits do not decrease with the length: count how many the window reaches, keep the slot word of that length
-        uint32_t len = 9u, slw = tb[kAuxSlot + 9];
+        SIMT_BEGIN(t, N) v[t] = s0 + t < s_end ? (uint32_t)lens[s0 + t] : 0u; m[t] = ~0ull; SIMT_END
 #pragma unroll
-        for (int d = 9; d < 15; d++) {
-            const bool g = c15 >= tb[kAuxLim + d];
-            len += g ? 1u : 0u;
-            slw = g ? tb[kAuxSlot + d + 1] : slw;
+        for (int k = 0; k < 4; k++) {
+            SIMT_BEGIN(t, N) p[t] = ((v[t] >> k) & 1u) != 0u; SIMT_END
+            const uint64_t b = simt::wave_ballot<N>(p);
+            SIMT_BEGIN(t, N) m[t] &= p[t] ? b : ~b; SIMT_END
         }
-        len += c15 >= tb[kAuxLim + 15] ? 1u : 0u;
-        const uint32_t lenc = len > 15 ? 15u : len;
-        uint32_t j = (slw + (c15 >> (15 - lenc))) & 0xFFFFu;
-        const uint32_t jmax = st ? 31u : 287u;
-        j = j > jmax ? jmax : j;
-        const LaneLds l{const_cast<uint32_t*>(sl->syms), 1};
-        uint32_t sym = *sym_ptr(l, st ? W_DIST_SYM : W_LIT_SYM, j);
-        if (!st && j >= (slw >> 16)) sym |= 256u;
-        const uint32_t e = entry_of_symbol(st, sym, lenc);
-        return len > 15 ? kEntInvalid : e;
+        SIMT_BEGIN(t, N)
+            upd[t] = 0;
+            if (v[t] != 0u) {
+                const uint32_t rank = (uint32_t)simt::popc64(m[t] & ((1ull << t) - 1ull)), cnt = (uint32_t)simt::popc64(m[t]);
+                const uint32_t base = run[(is_dist ? 16u : 0u) + v[t]];
+                rankb[s0 + t] = (uint16_t)(base + rank);
+                if (rank == cnt - 1u) upd[t] = base + cnt;   // the last lane of the length moves the running count on
+            }
+        SIMT_END_WAVE
+        SIMT_BEGIN(t, N) if (upd[t] != 0u) run[(is_dist ? 16u : 0u) + v[t]] = upd[t]; SIMT_END_WAVE
     }
-};
-
-// MODE 0: count.  MODE 1: emit literals and records.  MODE 2: check distances only (output beyond the capacity).
-// MODE 3: walk (where does the decode end?).  BIG: literal runs of more than lzr::kLitRunMax bytes in front of a match
-// get a record of their own (only possible in a sub-chunk that holds more than that many literals: the caller picks).
-// CHK: symbols may run past the end of the input.
-// Decodes from bit `start` until a lit/len symbol would begin at or beyond `chunk_end`, or the end-of-block symbol.
-template <int MODE, bool BIG, bool CHK>
-SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr lit_dst,
-                        SWC_AS_GLOBAL uint32_t* rec_dst, uint64_t out_pos0, ChunkOut& r) {
-    const uint8_t* stg = sl->stage;
-    uint32_t wa = (start >> 5) << 2, bp = start & 31u;    // the window: dwords at byte offset wa and wa + 4 of the staged input, bit bp of it is next
-    uint32_t d0 = *(const uint32_t*)(stg + wa), d1 = *(const uint32_t*)(stg + wa + 4);
-    uint32_t tsel = 0, tmsk = (1u << kSyncLitBits) - 1u;   // the table of the next code: dword offset into `lut` and index mask
-    uint32_t plen = 0, run = 0, nlit = 0, nrec = 0, nout = 0, flags = 0;
-    uint32_t lb = 0, lbn = 0;                              // literals on their way to the literal stream, four per store
-    const uint32_t room = out_pos0 > 0x40000000ull ? 0x40000000u : (uint32_t)out_pos0;   // output in front of the sub-chunk, as far as a distance can reach
-    // The loop is bound by the number of vector instructions it issues (measured: the SIMDs' VALU pipes are busy 80 % of
-    // the kernel), so the body is one straight line of few selects -- no branch per kind of symbol, the window's next dword
-    // is read whether the window moves on or not, everything rare (long code, end of block, anything invalid) sits behind
-    // ONE test.
-    for (;;) {
-        const uint32_t posb = (wa << 3) + bp;
-        if ((uint32_t)(tsel == 0) & (uint32_t)(posb >= chunk_end)) break;   // (bitwise: one compare pair, no nested mask region)
-        SWC_SYNC_STAT(4 + (MODE == 3 ? 0 : MODE), 1);   // code iterations per mode
-        SWC_SYNC_ITER();
-        const uint32_t bits = funnel32(d1, d0, bp);
-        uint32_t e = sl->lut[(bits & tmsk) | tsel];
-        const uint32_t nx = *(const uint32_t*)(stg + wa + 8);
-        if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, tsel); }   // a code longer than the direct table (or no code at all)
-        const uint32_t n = e & 31u;
-        if ((e & kEntInvalid) || (CHK && posb + n > in_bits)) {
-            // not a symbol the fast path takes / the symbol runs past the end of the input / the end of the block
-            if (!(e & kEntEob) || (CHK && posb + n > in_bits)) flags |= kFlagFail;
-            else { bp += n; flags |= kFlagEob; }
-            break;
+    // ---- B
+    SIMT_BEGIN(t, N)
+        if (t < 2) table_from_counts(run + 16 * t, sp.aux + (t ? kAuxDist : kAuxLit), tab + 33 * t, tab + 33 * t + 16);
+    SIMT_END_WAVE
+    SIMT_BEGIN(t, N)
+        for (int s = t; s < total; s += N) {
+            const uint32_t d = lens[s];
+            if (d) {
+                const bool dd = s >= literals;
+                const uint32_t j = (dd ? kSymDist : 0u) + tab[(dd ? 33 : 0) + 16 + d] + rankb[s];
+                const uint32_t sym = (uint32_t)(s - (dd ? literals : 0));
+                if (j < kSymDist + 32u) { sorted[j] = (uint16_t)(sym | (d << 9)); sp.syms[j] = (uint16_t)sym; }
+            }
         }
-        const bool was_dist = tsel != 0;
-        if (MODE != 3) {
-            const uint32_t is_lit = (e >> 15) & 1u;
-            const uint32_t val = ((e >> 16) & 0x7FFFu) + bfe32(bits, (e >> kEntClenShift) & 15u, (e >> kEntExtShift) & 15u);
-            if (MODE != 0 && was_dist && val > room + nout) { flags |= kFlagTrap; break; }
-            const bool big = BIG && was_dist && run > lzr::kLitRunMax;
-            if (MODE == 1) {
-                if (is_lit) {
-                    lb = funnel32(val, lb, 8);            // the new byte enters at the top: after four the dword is in stream order
-                    if (++lbn == 4) { store_u32(lit_dst, lb); lit_dst += 4; lbn = 0; }
+        // the direct tables start out as "no symbol the fast path takes"
+        for (int i = t; i < (1 << kSyncLitBits) + (1 << kSyncDistBits); i += N) sl->lut[i] = i < (1 << kSyncLitBits) ? kInvLit : kInvDist;
+    SIMT_END_WAVE
+    simt::vmem_fence();   // (the wave reads the spill back -- here and in the checked step: its stores are done first)
+    if (sp.aux[kAuxLit + kAuxOver] != 0u || sp.aux[kAuxDist + kAuxOver] != 0u) return false;
+    // ---- C
+    uint32_t used = 0, used_lit = 0;
+    PT<uint32_t, N> sz, rv, ln2;
+#pragma unroll 1
+    for (int tbl = 0; tbl < 2; tbl++) {
+        const uint32_t root = tbl ? (uint32_t)kSyncDistBits : (uint32_t)kSyncLitBits, rmask = (1u << root) - 1u;
+        const uint32_t* first = tab + 33 * tbl;
+        const uint32_t* start = first + 16;
+        const uint32_t n_sym = start[16] < (tbl ? 32u : 288u) ? start[16] : (tbl ? 32u : 288u);
+        const uint16_t* srt = sorted + (tbl ? kSymDist : 0u);
+        uint32_t* lut = sl->lut + (tbl ? (1 << kSyncLitBits) : 0);
+        uint16_t* ptt = pt + (tbl ? (1 << kSyncLitBits) : 0);
+#pragma unroll 1
+        for (uint32_t j0 = 0; j0 < n_sym; j0 += (uint32_t)N) {
+            SIMT_BEGIN(t, N)
+                const uint32_t j = j0 + (uint32_t)t;
+                sz[t] = 0; ln2[t] = 0; rv[t] = 0;
+                if (j < n_sym) {
+                    const uint32_t w = srt[j], sym = w & 511u, d = w >> 9;
+                    const uint32_t code = first[d] + (j - start[d]);
+                    const uint32_t rev = brev32(code) >> (32u - d);
+                    rv[t] = rev; ln2[t] = d;
+                    if (d <= root) {
+                        const uint32_t entry = entry_of_symbol(tbl != 0, sym, d);
+                        for (uint32_t q = rev; q <= rmask; q += 1u << d) lut[q] = entry;
+                    } else {
+                        bool last = j + 1u == n_sym;
+                        if (!last) {
+                            const uint32_t w2 = srt[j + 1u], d2 = w2 >> 9;
+                            const uint32_t rev2 = brev32(first[d2] + (j + 1u - start[d2])) >> (32u - d2);
+                            last = (rev2 & rmask) != (rev & rmask);
+                        }
+                        if (last) sz[t] = 1u << (d - root);
+                    }
                 }
-                if (was_dist) {
-                    if (big) *rec_dst++ = lzr::make_lits(run);
-                    *rec_dst++ = lzr::make_match(big ? 0u : run, plen, val);
+            SIMT_END
+            PT<uint32_t, N> x = sz;
+            simt::wave_scan_incl<N>(x);
+            SIMT_BEGIN(t, N)
+                if (sz[t] != 0u) {
+                    const uint32_t at = used + x[t] - sz[t], k = ln2[t] - root, pre = rv[t] & rmask;
+                    if (at + sz[t] <= kSubMax) {
+                        ptt[pre] = (uint16_t)(at | (k << 12));
+                        lut[pre] = (k << 5) | ((root + 2u) << 10) | (at << 18);
+                    }
+                }
+            SIMT_END
+            used += simt::wave_read<N>(x, N - 1);
+        }
+        if (tbl == 0) used_lit = used;
+    }
+    if (used > kSubMax) return false;
+    SWC_AS_GLOBAL uint32_t* subg = used > kSubLds ? sp.sub : nullptr;
+    st.g = subg;
+    simt::wave_fence();
+    // ---- D: the subtables start out as "no symbol", then every long code fills its slots
+    SIMT_BEGIN(t, N)
+        for (uint32_t i = (uint32_t)t; i < used; i += (uint32_t)N) {
+            const uint32_t inv = i < used_lit ? kInvLit : kInvDist;
+            if (subg) subg[i] = inv; else sl->sub[i] = inv;
+        }
+    SIMT_END_WAVE
+    if (subg) simt::vmem_fence();
+#pragma unroll 1
+    for (int tbl = 0; tbl < 2; tbl++) {
+        const uint32_t root = tbl ? (uint32_t)kSyncDistBits : (uint32_t)kSyncLitBits, rmask = (1u << root) - 1u;
+        const uint32_t* first = tab + 33 * tbl;
+        const uint32_t* start = first + 16;
+        const uint32_t n_sym = start[16] < (tbl ? 32u : 288u) ? start[16] : (tbl ? 32u : 288u);
+        if (start[root + 1] >= n_sym) continue;    // no code longer than the direct table
+        const uint16_t* srt = sorted + (tbl ? kSymDist : 0u);
+        const uint16_t* ptt = pt + (tbl ? (1 << kSyncLitBits) : 0);
+        SIMT_BEGIN(t, N)
+            for (uint32_t j = start[root + 1] + (uint32_t)t; j < n_sym; j += (uint32_t)N) {
+                const uint32_t w = srt[j], sym = w & 511u, d = w >> 9;
+                const uint32_t rev = brev32(first[d] + (j - start[d])) >> (32u - d);
+                const uint32_t entry = entry_of_symbol(tbl != 0, sym, d);
+                const uint32_t pw = ptt[rev & rmask], at = pw & 0xFFFu, k = pw >> 12;
+                for (uint32_t q = rev >> root; q < (1u << k); q += 1u << (d - root)) {
+                    if (subg) subg[at + q] = entry; else sl->sub[at + q] = entry;
                 }
             }
-            nlit += is_lit;
-            nout += is_lit + (was_dist ? plen : 0u);
-            nrec += was_dist ? (big ? 2u : 1u) : 0u;
-            run = was_dist ? 0u : run + is_lit;
-            plen = (e & kEntLen) ? val : plen;
-        }
-        tsel = e & kEntLen;                                                 // 0, or 1 << kSyncLitBits: the distance table follows the lit/len table
-        tmsk = ((1u << kSyncLitBits) - 1u) >> ((tsel >> kSyncLitBits) * (uint32_t)(kSyncLitBits - kSyncDistBits));   // 10-bit index, or 8-bit
-        bp += n;
-        const bool sh = bp >= 32;
-        wa += sh ? 4u : 0u;
-        bp &= 31u;
-        d0 = sh ? d1 : d0;
-        d1 = sh ? nx : d1;
+        SIMT_END
     }
-    if (MODE != 3 && run > 0) {   // the sub-chunk closes its literal run itself
-        nrec++;
-        if (MODE == 1) *rec_dst++ = lzr::make_lits(run);
-    }
-    if (MODE == 1) {
-        for (uint32_t i = 0; i < lbn; i++) lit_dst[i] = (uint8_t)(lb >> (8 * (4u - lbn + i)));   // the pending bytes sit at the top
-    }
-    r.end = (flags & kFlagFail) ? kPosFail : (wa << 3) + bp;
-    r.nlit = nlit; r.nrec = nrec; r.nout = nout;
-    r.flags = flags;
+    simt::wave_fence();
+    if (subg) simt::vmem_fence();
+    return true;
+}
+
+// ---- one sub-chunk: where does a decode from `start` end?  (The walk pass.) -----------------------------------------------
+// Positions are stream bits relative to the round's base.  Returns the position just past the last symbol taken, or kPosFail.
+// The loop: window address (2 instructions), funnel, table address, [LDS], position mask, link test, position, the two table
+// selectors, compare -- ten vector instructions per code.
+SWC_D uint32_t walk_chunk(const SyncLds* sl, const SubTab st, uint32_t start, uint32_t chunk_end, uint32_t in_bits) {
+    if (chunk_end > in_bits) chunk_end = in_bits;          // (the zero fill behind the input is not worth decoding)
+    if (start >= in_bits) return kPosFail;
+    uint32_t pos = start, tm = kLitMask4, tb = 0, e = 0;
+    uint32_t c_notlen = kEntNotLen, c_dmask = kDistMask4;
+    SWC_OPAQUE(c_notlen); SWC_OPAQUE(c_dmask);
+    if (start < chunk_end) do {   // (tested at the bottom: one mask update and one branch per iteration)
+        SWC_SYNC_STAT(4, 1);
+        SWC_SYNC_ITER();
+        const uint32_t bits4 = stage_bits(sl, pos);
+        e = *(const uint32_t*)((const uint8_t*)sl->lut + and_or(bits4, tm, tb));
+        uint32_t mm = e & kEntPosMask;
+        if (mm == 0u) { SWC_SYNC_STAT(7, 1); SWC_SYNC_LONG(); e = long_lookup(sl, st, bits4, e); mm = e & kEntPosMask; }
+        pos = pos + mm + 0xFFFFFFFEu;
+        tm = and_or(e, c_notlen, c_dmask);
+        tb = e & kEntLen;
+    } while ((int32_t)pos < (int32_t)chunk_end);
+    const uint32_t endb = pos & 0x3FFFFFFFu;
+    const bool fail = ((pos & kEntStop) != 0u && !ent_is_eob(e)) || endb > in_bits;
+    return fail ? kPosFail : endb;
 }
 
 // ---- one sub-chunk, decoded ONCE into the round's scratch ------------------------------------------------------------------
@@ -474,163 +570,100 @@ SWC_D void decode_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, u
 // and records to its column of the stream's scratch area (lz_resolve.h: rows across the lanes, sized for the worst case, so
 // the loop needs no bounds test), counting as it goes; the round then scans the counts and COPIES every lane's piece to its
 // final offset (copy_prov) instead of decoding a third time.  What the lane cannot know yet -- the output position of its
-// sub-chunk -- enters only through `need`: the largest (distance - output bytes of the sub-chunk in front of the match),
-// checked after the scan.  Literals gather in a 64-bit accumulator (the new byte enters at the top) and leave as a group of
-// eight; the group store and the record store share ONE conditional region of the loop, each aimed at row 0 when it is not
-// its turn.  The loop has no variant for the end of the input: it stops at the last bit, and a symbol that ran past it is
-// caught by the final position.  `run0`: literals in front of the sub-chunk that no record covers yet (lane 0 of the first
-// round of a block).  A sub-chunk that ends at the end-of-block symbol leaves its trailing literals uncovered (`tail`), every
-// other one closes them with a literal-only record.
+// sub-chunk -- enters only through `need`: the largest (distance - 1 - output bytes of the sub-chunk in front of the match),
+// checked after the scan (NEED = false: the round starts 32 KiB or more into the output, where no distance can fail).
+// Both stores of a step are UNCONDITIONAL: the literal accumulator (the newest byte at the top, four to a group) goes to the
+// row of the group it belongs to, a record to the row of the next record -- a step that adds nothing rewrites what is there,
+// and a row is final when its last writer has been.  `run0`: literals in front of the sub-chunk that no record covers yet
+// (lane 0 of the first round of a block).  A sub-chunk that ends at the end-of-block symbol leaves its trailing literals
+// uncovered (`tail`), every other one closes them with a literal-only record.
 struct ProvOut {
     uint32_t end, nlit, nrec, nout, flags, tail;
     int32_t need;
 };
-enum { kFlagSlow = 8u };   // the sub-chunk needs the general path (a literal run that no single record can carry)
-constexpr uint32_t kProvRecRow = 64u * 4u, kProvLitRow = 64u * 8u;   // bytes from one row of the scratch to the next
+constexpr uint32_t kProvRow = 64u * 4u;   // bytes from one row of the scratch to the next (records and literal groups alike)
 
-// The two loops below have ONE exit, at the top: the end-of-block symbol and anything the fast path does not take raise their
-// flag and pull the end of the sub-chunk to zero, so that the next test at the top leaves (their side effects are neutral: an
-// end-of-block entry is neither literal nor length, and a lane that raised the fail flag is discarded).  A loop with several
-// exits costs the wavefront a dozen scalar instructions of mask bookkeeping per iteration.
-// `seen`: the OR of all entries a loop took.  Only the entry that stopped it has bit 31, only the end-of-block entry bit 5.
-SWC_HD uint32_t flags_of_seen(uint32_t seen) { return (seen & kEntEob) ? kFlagEob : (seen & kEntInvalid) ? kFlagFail : 0u; }
-SWC_HD uint32_t sext_bit31(uint32_t e) { return (uint32_t)((int32_t)e >> 31); }   // all ones for a stop entry
-
-// Where does a decode from `start` end?  (The walk pass: no counting.)  Returns the bit position just past the last symbol
-// taken, or kPosFail.
-SWC_D uint32_t walk_chunk(const SyncLds* sl, const LongCodes lc, uint32_t start, uint32_t chunk_end, uint32_t in_bits) {
-    const uint8_t* stg = sl->stage;
-    uint32_t wa = (start >> 5) << 2, bp = start & 31u;
-    uint32_t d0 = *(const uint32_t*)(stg + wa), d1 = *(const uint32_t*)(stg + wa + 4);
-    uint32_t tsel = 0, tmsk = (1u << kSyncLitBits) - 1u, seen = 0;
-    if (chunk_end > in_bits) chunk_end = in_bits;          // (the zero fill behind the input is not worth decoding)
-    if (start >= in_bits) { seen = kEntInvalid; chunk_end = 0; }
-    if (start < chunk_end) {   // (tested at the bottom: one mask update and one branch per iteration)
-        bool go;
-        do {
-            SWC_SYNC_STAT(4, 1);
-            SWC_SYNC_ITER();
-            const uint32_t bits = funnel32(d1, d0, bp);
-            uint32_t e = sl->lut[(bits & tmsk) | tsel];
-            const uint32_t nx = *(const uint32_t*)(stg + wa + 8);
-            if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, tsel); }
-            seen |= e;
-            chunk_end &= ~sext_bit31(e);
-            const bool is_len = (e & kEntLen) != 0u;
-            tsel = e & kEntLen;
-            tmsk = is_len ? (1u << kSyncDistBits) - 1u : (1u << kSyncLitBits) - 1u;
-            bp += e & 31u;
-            const bool sh = bp >= 32;
-            wa += sh ? 4u : 0u;
-            bp &= 31u;
-            d0 = sh ? d1 : d0;
-            d1 = sh ? nx : d1;
-            go = is_len || (wa << 3) + bp < chunk_end;
-        } while (go);
-    }
-    const uint32_t endb = (wa << 3) + bp;
-    return flags_of_seen(seen) == kFlagFail || endb > in_bits ? kPosFail : endb;
-}
-
-// prov: the stream's scratch; lane: my column of its rows
-SWC_D void decode_chunk_prov(const SyncLds* sl, const LongCodes lc, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr prov,
+template <bool NEED>
+SWC_D void decode_chunk_prov(const SyncLds* sl, const SubTab st, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr prov,
                              uint32_t lane, uint32_t run0, ProvOut& r) {
     // (one base pointer for the wave and 32-bit offsets per lane: the stores take the base from scalar registers)
-    const uint32_t rdummy = 4u * lane, ldummy = (uint32_t)lzr::kProvRecBytes + 8u * lane;
-    const uint8_t* stg = sl->stage;
-    uint32_t wa = (start >> 5) << 2, bp = start & 31u;
-    uint32_t d0 = *(const uint32_t*)(stg + wa), d1 = *(const uint32_t*)(stg + wa + 4);
-    uint32_t tsel = 0, tmsk = (1u << kSyncLitBits) - 1u, seen = 0;
-    uint32_t plen = 0, run = run0, nlit = 0, nout = 0, pend = 0;   // pend: literals in the accumulator (nlit mod 8)
-    uint32_t roff = rdummy + kProvRecRow, loff = ldummy + kProvLitRow;   // byte offsets of my next record / literal group in the scratch (row 1 is the first)
-    uint32_t lb0 = 0, lb1 = 0;                             // pending literals: the newest at the top of lb1:lb0
+    const uint32_t rbase = 4u * lane, lbase = (uint32_t)lzr::kProvRecBytes + 4u * lane;
+    uint32_t pos = start, tm = kLitMask4, tb = 0, e = 0;
+    uint32_t plen = 0, run = run0, nl3 = 3, nout = 0, lb = 0;
+    uint32_t roff = rbase + kProvRow;                      // byte offset of my next record in the scratch (row 1 is the first)
     int32_t need = -0x40000000;
+    uint32_t c_notlen = kEntNotLen, c_dmask = kDistMask4;
+    int32_t c_m256 = -256;
+    SWC_OPAQUE(c_notlen); SWC_OPAQUE(c_dmask); SWC_OPAQUE(c_m256);
     if (chunk_end > in_bits) chunk_end = in_bits;          // (the zero fill behind the input is not worth decoding)
-    if (start >= in_bits) { seen = kEntInvalid; chunk_end = 0; }   // nothing left for this sub-chunk: the checked step says what that means
-    bool go = false;
-    if (start < chunk_end) do {   // (tested at the bottom: one mask update and one branch per iteration)
+    const bool dead = start >= in_bits;                    // nothing left for this sub-chunk: the checked step says what that means
+    if (!dead && start < chunk_end) do {                   // (tested at the bottom: one mask update and one branch per iteration)
         SWC_SYNC_STAT(5, 1);
         SWC_SYNC_ITER();
-        const uint32_t bits = funnel32(d1, d0, bp);
-        uint32_t e = sl->lut[(bits & tmsk) | tsel];
-        const uint32_t nx = *(const uint32_t*)(stg + wa + 8);
-        if (e == 0) { SWC_SYNC_STAT(7, 1); e = lc.lookup(sl, bits, tsel); }
-        seen |= e;
-        chunk_end &= ~sext_bit31(e);
-        const bool was_dist = tsel != 0;
-        const uint32_t is_lit = (e >> 15) & 1u;
-        const uint32_t val = ((e >> 16) & 0x7FFFu) + bfe32(bits, (e >> kEntClenShift) & 15u, (e >> kEntExtShift) & 15u);
-        // literal: into the accumulator (a shift by 0 leaves it alone)
-        const uint32_t sh8 = is_lit << 3;
-        lb0 = funnel32(lb1, lb0, sh8);
-        lb1 = funnel32(val, lb1, sh8);
-        nlit += is_lit;
-        pend += is_lit;
-        const uint32_t full8 = pend & 8u;                  // the eighth literal of a group has just entered
-        pend &= 7u;
-        const bool full = full8 != 0u;
-        const int32_t nd = (int32_t)val - (int32_t)nout;   // a distance needs this much output in front of the sub-chunk
-        need = was_dist && nd > need ? nd : need;
-        if ((tsel | full8) != 0u) {
-            store_u64(prov + (full ? loff : ldummy), ((uint64_t)lb1 << 32) | lb0);
-            store_u32(prov + (was_dist ? roff : rdummy), lzr::make_match(run, plen, val));
-            loff += full ? kProvLitRow : 0u;
-            roff += was_dist ? kProvRecRow : 0u;
+        const uint32_t bits4 = stage_bits(sl, pos);
+        e = *(const uint32_t*)((const uint8_t*)sl->lut + and_or(bits4, tm, tb));
+        uint32_t mm = e & kEntPosMask;
+        if (mm == 0u) { SWC_SYNC_STAT(7, 1); SWC_SYNC_LONG(); e = long_lookup(sl, st, bits4, e); mm = e & kEntPosMask; }
+        pos = pos + mm + 0xFFFFFFFEu;
+        tm = and_or(e, c_notlen, c_dmask);
+        tb = e & kEntLen;
+        const uint32_t val = (bfe32(bits4, 0, e) >> ((e >> 5) & 31u)) + bfe32(e, kEntBaseShift, 15);
+        // a literal enters the accumulator at the top (a shift by 0 bytes leaves it alone); the group it belongs to is rewritten
+        const uint32_t lit1 = bfe32(e, 13, 1);
+        lb = alignbyte32(val, lb, lit1);
+        nl3 += lit1;
+        store_u32(prov + lshl_add<6>(nl3 & ~3u, lbase), lb);
+        // a distance completes a record; any other step writes a word that the next record of the lane overwrites
+        const uint32_t dm = sbfe1(e, 29);
+        store_u32(prov + roff, lshl_add<7>(plen, lshl_add<16>(val, run)));
+        roff = mad24(dm, c_m256, roff);
+        if (NEED) {
+            const int32_t nd = (int32_t)val - (int32_t)nout;   // this much output must exist in front of the sub-chunk
+            need = (int32_t)bfi32(dm, (uint32_t)(nd > need ? nd : need), (uint32_t)need);
         }
-        nout += is_lit + (was_dist ? plen : 0u);
-        run = was_dist ? 0u : run + is_lit;
-        const bool is_len = (e & kEntLen) != 0u;
-        plen = is_len ? val : plen;
-        tsel = e & kEntLen;
-        tmsk = is_len ? (1u << kSyncDistBits) - 1u : (1u << kSyncLitBits) - 1u;
-        bp += e & 31u;
-        const bool sh = bp >= 32;
-        wa += sh ? 4u : 0u;
-        bp &= 31u;
-        d0 = sh ? d1 : d0;
-        d1 = sh ? nx : d1;
-        go = is_len || (wa << 3) + bp < chunk_end;
-    } while (go);
-    if (nlit & 7u) {   // the last, incomplete group: its bytes sit at the top of the accumulator
-        const uint32_t dn = (8u - (nlit & 7u)) << 3;
-        store_u64(prov + loff, (((uint64_t)lb1 << 32) | lb0) >> dn);
-    }
-    uint32_t flags = flags_of_seen(seen);
+        nout += lit1 + plen;                               // (plen is zero except in the step of the distance)
+        run = clear_if(dm, run + lit1);
+        plen = val & sbfe1(e, 12);
+    } while ((int32_t)pos < (int32_t)chunk_end);
+    const uint32_t nlit = nl3 - 3u;
+    const uint32_t endb = pos & 0x3FFFFFFFu;
+    uint32_t flags = 0;
+    if (dead) flags = kFlagFail;
+    else if (pos & kEntStop) flags = ent_is_eob(e) ? kFlagEob : kFlagFail;
     uint32_t tail = 0;
     if (run > 0) {
         if (flags & kFlagEob) tail = run;
-        else { store_u32(prov + roff, lzr::make_lits(run)); roff += kProvRecRow; }
+        else { store_u32(prov + roff, lzr::make_lits(run)); roff += kProvRow; }
     }
-    const uint32_t endb = (wa << 3) + bp;
     if (endb > in_bits) flags |= kFlagFail;                // a symbol ran past the end of the input
     if (nlit + run0 > lzr::kLitRunMax) flags |= kFlagSlow;  // (conservative: only then can a run exceed what a match record carries)
     r.end = (flags & kFlagFail) ? kPosFail : endb;
-    r.nlit = nlit; r.nrec = (roff - rdummy) / kProvRecRow - 1u; r.nout = nout; r.flags = flags; r.tail = tail; r.need = need;
+    r.nlit = nlit; r.nrec = (roff - rbase) / kProvRow - 1u; r.nout = nout; r.flags = flags; r.tail = tail; r.need = need;
 }
 
 // A lane's piece of the round moves from its column of the scratch to its final place: `nrec` records to `rdst` (dword
-// aligned), `nlit` literal bytes to `ldst` (any alignment).  The loads of a step read one row: coalesced.
+// aligned), `nlit` literal bytes to `ldst` (any alignment).  The loads of a step read one row: coalesced.  The last,
+// incomplete literal group holds its bytes at the top.
 SWC_D void copy_prov(gcptr plit, gcptr prec, uint32_t nlit, uint32_t nrec, gptr ldst, SWC_AS_GLOBAL uint32_t* rdst) {
     // Sixteen records and eight literal groups are loaded per step, all before the first store (the scratch of all resident
     // waves exceeds the L2, so a load takes its several hundred cycles: one load per step would expose that latency forty
     // times per round).  Rows past the lane's count hold something and exist (the scratch is sized for the worst case): they
     // are loaded and not stored.
-    const uint32_t ngrp = (nlit + 7u) >> 3;
+    const uint32_t ngrp = (nlit + 3u) >> 2;
     for (uint32_t i = 0, g = 0; i < nrec || g < ngrp; i += 16, g += 8) {
-        uint32_t v[16];
-        uint64_t w[8];
+        uint32_t v[16], w[8];
 #pragma unroll
         for (uint32_t k = 0; k < 16; k++) {
             const uint32_t row = i + k + 1u < (uint32_t)lzr::kProvRecRows ? i + k + 1u : (uint32_t)lzr::kProvRecRows - 1u;
-            v[k] = load_u32(prec + (size_t)row * kProvRecRow);
+            v[k] = load_u32(prec + (size_t)row * kProvRow);
         }
 #pragma unroll
         for (uint32_t k = 0; k < 8; k++) {
             const uint32_t row = g + k + 1u < (uint32_t)lzr::kProvLitRows ? g + k + 1u : (uint32_t)lzr::kProvLitRows - 1u;
-            w[k] = load_u64(plit + (size_t)row * kProvLitRow);
+            w[k] = load_u32(plit + (size_t)row * kProvRow);
         }
         // (wide stores: the lanes' destinations lie apart, so the memory pipeline takes a store lane by lane -- four records or
-        // two groups per lane and instruction instead of one)
+        // four groups per lane and instruction instead of one)
 #pragma unroll
         for (uint32_t k = 0; k < 16; k += 4) {
             if (i + k + 4u <= nrec) store_u128_a4((gptr)(rdst + i + k), v[k], v[k + 1], v[k + 2], v[k + 3]);
@@ -640,25 +673,92 @@ SWC_D void copy_prov(gcptr plit, gcptr prec, uint32_t nlit, uint32_t nrec, gptr 
             }
         }
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k += 2) {
-            const uint32_t at = 8u * (g + k);
-            if (at + 16u <= nlit) store_u128_a4(ldst + at, (uint32_t)w[k], (uint32_t)(w[k] >> 32), (uint32_t)w[k + 1], (uint32_t)(w[k + 1] >> 32));
+        for (uint32_t k = 0; k < 8; k += 4) {
+            const uint32_t at = 4u * (g + k);
+            if (at + 16u <= nlit) store_u128_a4(ldst + at, w[k], w[k + 1], w[k + 2], w[k + 3]);
             else {
 #pragma unroll
-                for (uint32_t q = 0; q < 2; q++) {
-                    const uint32_t aq = at + 8u * q;
-                    if (aq + 8u <= nlit) store_u64(ldst + aq, w[k + q]);
-                    else if (aq < nlit) { uint64_t x = w[k + q]; for (uint32_t z = aq; z < nlit; z++, x >>= 8) ldst[z] = (uint8_t)x; }
+                for (uint32_t q = 0; q < 4; q++) {
+                    const uint32_t aq = at + 4u * q;
+                    if (aq + 4u <= nlit) store_u32(ldst + aq, w[k + q]);
+                    else if (aq < nlit) { uint32_t x = w[k + q] >> (8u * (4u - (nlit - aq))); for (uint32_t z = aq; z < nlit; z++, x >>= 8) ldst[z] = (uint8_t)x; }
                 }
             }
         }
     }
 }
 
+// ---- one sub-chunk, the general passes ------------------------------------------------------------------------------------
+struct ChunkOut {
+    uint32_t end;     // bit position (relative to the round base) just past the last symbol taken; kPosFail: no valid decode
+    uint32_t nlit, nrec, nout;
+    uint32_t flags;
+};
+// MODE 0: count.  MODE 1: emit literals and records.  MODE 2: check distances only (output beyond the capacity).
+// BIG: literal runs of more than lzr::kLitRunMax bytes in front of a match get a record of their own (only possible in a
+// sub-chunk that holds more than that many literals: the caller picks).  CHK: symbols may run past the end of the input.
+// Decodes from bit `start` until a lit/len symbol would begin at or beyond `chunk_end`, or the end-of-block symbol.
+// (Rounds the provisional decode abandoned, and lanes behind an early end of block: not the hot path.)
+template <int MODE, bool BIG, bool CHK>
+SWC_D void decode_chunk(const SyncLds* sl, const SubTab st, uint32_t start, uint32_t chunk_end, uint32_t in_bits, gptr lit_dst,
+                        SWC_AS_GLOBAL uint32_t* rec_dst, uint64_t out_pos0, ChunkOut& r) {
+    uint32_t pos = start;
+    bool dist_next = false;
+    uint32_t plen = 0, run = 0, nlit = 0, nrec = 0, nout = 0, flags = 0;
+    uint32_t lb = 0, lbn = 0;                              // literals on their way to the literal stream, four per store
+    const uint32_t room = out_pos0 > 0x40000000ull ? 0x40000000u : (uint32_t)out_pos0;   // output in front of the sub-chunk, as far as a distance can reach
+    for (;;) {
+        if (!dist_next && pos >= chunk_end) break;
+        SWC_SYNC_STAT(4 + MODE, 1);
+        SWC_SYNC_ITER();
+        uint32_t bits4;
+        const uint32_t e = entry_at(sl, st, pos, dist_next, bits4);
+        const uint32_t n = ent_bits(e);
+        if ((e & kEntStop) || (CHK && pos + n > in_bits)) {
+            // not a symbol the fast path takes / the symbol runs past the end of the input / the end of the block
+            if (!ent_is_eob(e) || (CHK && pos + n > in_bits)) flags |= kFlagFail;
+            else { pos += n; flags |= kFlagEob; }
+            break;
+        }
+        const bool was_dist = dist_next;
+        const uint32_t is_lit = (e >> 13) & 1u;
+        const uint32_t val = (bfe32(bits4, 0, e) >> ((e >> 5) & 31u)) + bfe32(e, kEntBaseShift, 15) + (was_dist ? 1u : 0u);   // literal, length or distance
+        if (MODE != 0 && was_dist && val > room + nout) { flags |= kFlagTrap; break; }
+        const bool big = BIG && was_dist && run > lzr::kLitRunMax;
+        if (MODE == 1) {
+            if (is_lit) {
+                lb = funnel32(val, lb, 8);            // the new byte enters at the top: after four the dword is in stream order
+                if (++lbn == 4) { store_u32(lit_dst, lb); lit_dst += 4; lbn = 0; }
+            }
+            if (was_dist) {
+                if (big) *rec_dst++ = lzr::make_lits(run);
+                *rec_dst++ = lzr::make_match(big ? 0u : run, plen, val);
+            }
+        }
+        nlit += is_lit;
+        nout += is_lit + (was_dist ? plen : 0u);
+        nrec += was_dist ? (big ? 2u : 1u) : 0u;
+        run = was_dist ? 0u : run + is_lit;
+        plen = (e & kEntLen) ? val : plen;
+        dist_next = (e & kEntLen) != 0u;
+        pos += n;
+    }
+    if (run > 0) {   // the sub-chunk closes its literal run itself
+        nrec++;
+        if (MODE == 1) *rec_dst++ = lzr::make_lits(run);
+    }
+    if (MODE == 1) {
+        for (uint32_t i = 0; i < lbn; i++) lit_dst[i] = (uint8_t)(lb >> (8 * (4u - lbn + i)));   // the pending bytes sit at the top
+    }
+    r.end = (flags & kFlagFail) ? kPosFail : pos;
+    r.nlit = nlit; r.nrec = nrec; r.nout = nout;
+    r.flags = flags;
+}
+
 // ---- the rounds of one block ---------------------------------------------------------------------------------------
 // Decodes from the reader's position until the end-of-block symbol (kSyncEob) or until something the fast path leaves
 // to the checked step (kSyncBail; kSyncBailCap: the capacity lies inside the next round).  Commits whole rounds only.
-SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
+SWC_D int sync_block(Lane& ln, SyncLds* sl, const SubTab st, SyncProf& pf) {
     using simt::PT;
     constexpr int N = kWave;
     // Literals in front of the block that no record covers yet (the tail of the previous block, stored bytes): the first
@@ -667,7 +767,7 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
     {
         const uint64_t kept = ln.pos < ln.cap ? ln.pos : ln.cap;
         const uint64_t open = kept > ln.last_end ? kept - ln.last_end : 0;
-        if (ln.prov != nullptr && open <= 64) pending = (uint32_t)open;
+        if (open <= 64) pending = (uint32_t)open;
         else ln.flush_tail();
     }
     uint64_t P = simt::uniform(ln.br.consumed_bits());
@@ -678,27 +778,30 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
     int result = kSyncBail;
     PT<uint32_t, N> start, endp, pe, c_lit, c_rec, c_out, flg, x_lit, x_rec, x_out, c_tail, c_need;
     PT<bool, N> todo, pb, have;
-    LongCodes lc;
-    lc.load(sl);
     for (;;) {
         const uint32_t B = (uint32_t)(P >> 3) & ~3u;
         const uint32_t q0 = (uint32_t)(P - 8ull * B);
         SWC_SP(pf, 6)
         SWC_SPC(pf, 7, 1);
         const uint64_t left = (uint64_t)(in_len - B) * 8;
-        const uint32_t in_bits = left > 0x7FFFFFFFull ? 0x7FFFFFFFu : (uint32_t)left;
-        // stage [B, B + kSyncStage), zero-filled beyond the input
+        const uint32_t in_bits = left > 0x3FFFFFFFull ? 0x3FFFFFFFu : (uint32_t)left;
+        // stage [B, B + kSyncStage), zero-filled beyond the input, shifted left by two bits: LDS bit p + 2 is stream bit p
         SIMT_BEGIN(t, N)
             for (uint32_t o = 16u * (uint32_t)t; o < kSyncStage; o += 16u * N) {
                 uint64_t a = 0, b = 0;
+                uint32_t prev = 0;
                 const uint64_t at = (uint64_t)B + o;
-                if (at + 16 <= in_len) { a = load_u64(in + at); b = load_u64(in + at + 8); }
-                else {
+                if (at + 16 <= in_len) {
+                    a = load_u64(in + at); b = load_u64(in + at + 8);
+                    if (o != 0) prev = load_u32(in + at - 4);
+                } else {
                     for (uint32_t k = 0; k < 8; k++) if (at + k < in_len) a |= (uint64_t)in[at + k] << (8 * k);
                     for (uint32_t k = 0; k < 8; k++) if (at + 8 + k < in_len) b |= (uint64_t)in[at + 8 + k] << (8 * k);
+                    if (o != 0) for (uint32_t k = 0; k < 4; k++) if (at - 4 + k < in_len) prev |= (uint32_t)in[at - 4 + k] << (8 * k);
                 }
                 uint32_t* st32 = (uint32_t*)(sl->stage + o);
-                st32[0] = (uint32_t)a; st32[1] = (uint32_t)(a >> 32); st32[2] = (uint32_t)b; st32[3] = (uint32_t)(b >> 32);
+                const uint32_t w0 = (uint32_t)a, w1 = (uint32_t)(a >> 32), w2 = (uint32_t)b, w3 = (uint32_t)(b >> 32);
+                st32[0] = funnel32(w0, prev, 30); st32[1] = funnel32(w1, w0, 30); st32[2] = funnel32(w2, w1, 30); st32[3] = funnel32(w3, w2, 30);
             }
             start[t] = t == 0 ? q0 : (uint32_t)t * kSyncChunk * 8u;
         SIMT_END_WAVE
@@ -710,12 +813,11 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
         SWC_SYNC_STAT(2, 1);
         SWC_SPC(pf, 8, 1);
         SIMT_BEGIN(t, N)
-            ChunkOut r;
-            SWC_SYNC_LANE_BEGIN(t)
+            SWC_SYNC_LANE_BEGIN(t_i_ == 0)
             const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
-            r.end = walk_chunk(sl, lc, start[t], ce, in_bits);
-            endp[t] = r.end; flg[t] = 0; have[t] = false;
-            SWC_SYNC_LANE_END(t, N, 0)
+            endp[t] = walk_chunk(sl, st, start[t], ce, in_bits);
+            flg[t] = 0; have[t] = false;
+            SWC_SYNC_LANE_END(t_i_ == N - 1, 0)
         SIMT_END
         SWC_SP(pf, 9)
         // ---- the round in ONE more decode (the common case): every lane decodes its sub-chunk from the end of its left
@@ -723,8 +825,9 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
         // offsets.  Anything unusual -- a symbol for the checked step, a literal run too long for one record, the capacity
         // or the workspace inside the round, a distance beyond the output -- abandons the attempt BEFORE anything is
         // committed; the general passes below then take the round.
-        if (ln.prov != nullptr && pos < ln.cap) {
+        if (pos < ln.cap) {
             bool ok = true;
+            const bool need_check = pos < 32768u;   // (further in, every distance the tables can produce has its source)
             for (;;) {
                 simt::wave_shift_up<N>(pe, endp, q0);
                 SIMT_BEGIN(t, N) pb[t] = !(have[t] && (t == 0 || start[t] == pe[t])); SIMT_END
@@ -743,7 +846,7 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                 SWC_SPC(pf, 8, 1);
                 SIMT_BEGIN(t, N)
                     todo[t] = t == 0 ? !have[t] : pe[t] != kPosFail && (start[t] != pe[t] || !have[t]);
-                    SWC_SYNC_LANE_BEGIN(t)
+                    SWC_SYNC_LANE_BEGIN(t_i_ == 0)
                     if (todo[t]) {
                         SWC_SYNC_STAT(3, 1);
                         if (t != 0) start[t] = pe[t];
@@ -754,13 +857,13 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                             // the checked step.  Nothing of mine belongs to the block (and a decode from there could run through
                             // several sub-chunks: the scratch is sized for one).
                             r.end = kPosFail; r.nlit = r.nrec = r.nout = r.tail = 0; r.flags = kFlagFail; r.need = 0;
-                        } else
-                        decode_chunk_prov(sl, lc, start[t], ce, in_bits, ln.prov, (uint32_t)t, t == 0 ? pending : 0u, r);
+                        } else if (need_check) decode_chunk_prov<true>(sl, st, start[t], ce, in_bits, ln.prov, (uint32_t)t, t == 0 ? pending : 0u, r);
+                        else decode_chunk_prov<false>(sl, st, start[t], ce, in_bits, ln.prov, (uint32_t)t, t == 0 ? pending : 0u, r);
                         endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; flg[t] = r.flags;
                         c_tail[t] = r.tail; c_need[t] = (uint32_t)r.need;
                         have[t] = true;
                     }
-                    SWC_SYNC_LANE_END(t, N, 1)
+                    SWC_SYNC_LANE_END(t_i_ == N - 1, 1)
                 SIMT_END
                 SWC_SP(pf, 3)
             }
@@ -774,18 +877,20 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
                 simt::wave_scan_incl<N>(x_out);
                 const uint32_t tot_lit = simt::wave_read<N>(x_lit, N - 1), tot_rec = simt::wave_read<N>(x_rec, N - 1), tot_out = simt::wave_read<N>(x_out, N - 1);
                 SWC_SP(pf, 4)
-                // every distance must reach back no further than the output in front of its match
-                SIMT_BEGIN(t, N)
-                    const uint64_t p0 = pos + (x_out[t] - c_out[t]);
-                    const int32_t room = p0 > 0x40000000ull ? 0x40000000 : (int32_t)p0;
-                    pb[t] = (uint32_t)t < nv && (int32_t)c_need[t] > room;
-                SIMT_END
-                if (simt::wave_ballot<N>(pb)) ok = false;
+                if (need_check) {
+                    // every distance must reach back no further than the output in front of its match (need = distance - 1 - ...)
+                    SIMT_BEGIN(t, N)
+                        const uint64_t p0 = pos + (x_out[t] - c_out[t]);
+                        const int32_t room = p0 > 0x40000000ull ? 0x40000000 : (int32_t)p0;
+                        pb[t] = (uint32_t)t < nv && (int32_t)c_need[t] >= room;
+                    SIMT_END
+                    if (simt::wave_ballot<N>(pb)) ok = false;
+                }
                 if (pos + tot_out > ln.cap || (uint64_t)nrec + tot_rec > ln.max_rec) ok = false;
                 if (ok) {
                     SIMT_BEGIN(t, N)
                         if ((uint32_t)t < nv) {
-                            copy_prov(ln.prov + lzr::kProvRecBytes + 8u * (uint32_t)t, ln.prov + 4u * (uint32_t)t, c_lit[t], c_rec[t],
+                            copy_prov(ln.prov + lzr::kProvRecBytes + 4u * (uint32_t)t, ln.prov + 4u * (uint32_t)t, c_lit[t], c_rec[t],
                                       ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]));
                         }
                     SIMT_END
@@ -831,23 +936,23 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
             SWC_SPC(pf, 8, 1);
             SIMT_BEGIN(t, N)
                 todo[t] = t == 0 ? !have[t] : pe[t] != kPosFail && (start[t] != pe[t] || !have[t]);
-                SWC_SYNC_LANE_BEGIN(t)
+                SWC_SYNC_LANE_BEGIN(t_i_ == 0)
                 if (todo[t]) {
                     SWC_SYNC_STAT(3, 1);   // lane decodes
                     if (t != 0) start[t] = pe[t];
                     ChunkOut r;
                     const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
                     if (start[t] + kSyncChunk * 8u < ce) { r.end = kPosFail; r.nlit = r.nrec = r.nout = 0; r.flags = kFlagFail; }   // (see the pass above)
-                    else if (chk) decode_chunk<0, false, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
-                    else decode_chunk<0, false, false>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                    else if (chk) decode_chunk<0, false, true>(sl, st, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                    else decode_chunk<0, false, false>(sl, st, start[t], ce, in_bits, nullptr, nullptr, 0, r);
                     if (r.nlit > lzr::kLitRunMax) {   // a literal run may need a record of its own: count those too
-                        if (chk) decode_chunk<0, true, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
-                        else decode_chunk<0, true, false>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                        if (chk) decode_chunk<0, true, true>(sl, st, start[t], ce, in_bits, nullptr, nullptr, 0, r);
+                        else decode_chunk<0, true, false>(sl, st, start[t], ce, in_bits, nullptr, nullptr, 0, r);
                     }
                     endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; flg[t] = r.flags;
                     have[t] = true;
                 }
-                SWC_SYNC_LANE_END(t, N, 1)
+                SWC_SYNC_LANE_END(t_i_ == N - 1, 1)
             SIMT_END
             SWC_SP(pf, 3)
         }
@@ -867,18 +972,18 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
         if (!beyond && pos + tot_out > ln.cap) { result = kSyncBailCap; break; }
         if (!beyond && (uint64_t)nrec + tot_rec > ln.max_rec) break;
         SIMT_BEGIN(t, N)
-            SWC_SYNC_LANE_BEGIN(t)
+            SWC_SYNC_LANE_BEGIN(t_i_ == 0)
             if ((uint32_t)t < nv) {
                 ChunkOut r;
                 const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
                 const uint64_t p0 = pos + (x_out[t] - c_out[t]);
                 const bool bigs = c_lit[t] > lzr::kLitRunMax;
-                if (beyond) decode_chunk<2, false, true>(sl, lc, start[t], ce, in_bits, nullptr, nullptr, p0, r);
-                else if (bigs || chk) decode_chunk<1, true, true>(sl, lc, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
-                else decode_chunk<1, false, false>(sl, lc, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
+                if (beyond) decode_chunk<2, false, true>(sl, st, start[t], ce, in_bits, nullptr, nullptr, p0, r);
+                else if (bigs || chk) decode_chunk<1, true, true>(sl, st, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
+                else decode_chunk<1, false, false>(sl, st, start[t], ce, in_bits, ln.lits + nlit + (x_lit[t] - c_lit[t]), ln.recs + nrec + (x_rec[t] - c_rec[t]), p0, r);
                 flg[t] = r.flags;
             }
-            SWC_SYNC_LANE_END(t, N, 2)
+            SWC_SYNC_LANE_END(t_i_ == N - 1, 2)
         SIMT_END
         SWC_SP(pf, 5)
         SIMT_BEGIN(t, N) pb[t] = (uint32_t)t < nv && (flg[t] & kFlagTrap) != 0; SIMT_END
@@ -896,11 +1001,13 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, SyncProf& pf) {
     return result;
 }
 
-// ---- the code-length section of a dynamic header (Deflate.swift:86-167), wave-parallel where it can be -----------------
-// Same results and errors as Lane::build_dynamic: the code lengths are decoded once, serially (through a 128-entry
-// table of the code-length code), into an LDS array; the per-length histogram and the counting sort that produces the
-// (length, symbol)-sorted arrays run on all lanes.
-SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, SyncProf& pf) {
+// ---- the code-length section of a dynamic header (Deflate.swift:86-167) ---------------------------------------------------
+// Same results and errors as the reference's loop.  The section is staged in LDS once (round 3 read it dword by dword from
+// the stream, one exposed memory latency per eight code lengths); then, 64 bit offsets at a time, every lane decodes the
+// code-length symbol that WOULD start at its offset (table read, extra bits, repeat count), and a scalar chain walks from
+// symbol to symbol over the lanes (one cross-lane read per symbol), checking what the reference checks in its order and
+// storing the lengths.  Histogram, canonical codes and tables then run on all lanes (sync_tables_from_lengths).
+SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, const Spill sp, SubTab& st, bool& fast, SyncProf& pf) {
     using simt::PT;
     constexpr int N = kWave;
     BitReader& br = ln.br;
@@ -949,12 +1056,15 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, SyncProf& pf) {
         }
     }
     uint8_t* lens = sl->stage + kHdrLens;
-    uint32_t* cnt = (uint32_t*)(sl->stage + kHdrCnt);
     uint8_t* cl_lut = sl->stage + kHdrClLut;
+    uint32_t* hin = (uint32_t*)(sl->stage + kHdrIn);
     const int total = literals + distances;
+    const uint64_t end_bits = (uint64_t)br.len * 8;
+    uint64_t W = simt::uniform(br.consumed_bits());      // absolute bit position of the next code-length symbol
+    gcptr in = br.in;
+    const uint32_t in_len = br.len;
     SIMT_BEGIN(t, N)
         for (int i = t; i < 80; i += N) ((uint32_t*)lens)[i] = 0;
-        if (t < 48) cnt[t] = 0;
         for (int x = t; x < 128; x += N) {   // the code the stream bits x (first bit = bit 0) begin with
             uint32_t len;
             const int idx = Lane::cl_lookup(cl, brev32((uint32_t)x) >> 17, len);
@@ -962,40 +1072,58 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, SyncProf& pf) {
             cl_lut[x] = idx < 0 ? (uint8_t)0xFF : (uint8_t)(len | (sym << 3));
         }
     SIMT_END_WAVE
-    {   // Deflate.swift:117-162, every lane the same
-        int n = 0;
-        uint32_t prev = 0;
-#if defined(__HIP_DEVICE_COMPILE__)
-        // the 128-entry table of the code-length code sits in two registers spread over the lanes (lane i: entries i and
-        // 64 + i): the serial loop below looks its entry up with a cross-lane read instead of an LDS round trip per symbol
-        const uint32_t lut_lo = cl_lut[threadIdx.x & 63u], lut_hi = cl_lut[64u + (threadIdx.x & 63u)];
-#endif
-        while (n < total) {
-            br.refill();
-#if defined(__HIP_DEVICE_COMPILE__)
-            const uint32_t x7 = simt::uniform(br.peek32() & 127u);
-            const uint32_t e = x7 < 64u ? (uint32_t)__builtin_amdgcn_readlane((int)lut_lo, (int)x7) : (uint32_t)__builtin_amdgcn_readlane((int)lut_hi, (int)(x7 - 64u));
-#else
-            const uint32_t e = simt::uniform((uint32_t)cl_lut[br.peek32() & 127u]);   // (scalar from here on: see BitReader)
-#endif
-            if (e == 0xFFu || (e & 7u) > br.bc) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :122
-            br.consume(e & 7u);
-            const uint32_t sym = e >> 3;
-            int rep;
+    int n = 0;
+    uint32_t prev = 0;
+    uint64_t HB = ~0ull;                                  // byte offset of the staged part of the header (none yet)
+    PT<uint32_t, N> pk;
+    while (n < total) {   // Deflate.swift:117-162
+        if (HB == ~0ull || W + 64 + 32 > 8 * (HB + 1024)) {
+            HB = (W >> 3) & ~3ull;
+            SIMT_BEGIN(t, N)
+                uint64_t a = 0, b = 0;
+                const uint64_t at = HB + 16u * (uint32_t)t;
+                if (at + 16 <= in_len) { a = load_u64(in + at); b = load_u64(in + at + 8); }
+                else {
+                    for (uint32_t k = 0; k < 8; k++) if (at + k < in_len) a |= (uint64_t)in[at + k] << (8 * k);
+                    for (uint32_t k = 0; k < 8; k++) if (at + 8 + k < in_len) b |= (uint64_t)in[at + 8 + k] << (8 * k);
+                }
+                uint32_t* h4 = hin + 4 * t;
+                h4[0] = (uint32_t)a; h4[1] = (uint32_t)(a >> 32); h4[2] = (uint32_t)b; h4[3] = (uint32_t)(b >> 32);
+                if (t < 4) hin[256 + t] = 0;
+            SIMT_END_WAVE
+        }
+        // every lane: the symbol that would start at bit W + t
+        const uint32_t rel0 = (uint32_t)(W - 8 * HB);
+        SIMT_BEGIN(t, N)
+            const uint32_t rel = rel0 + (uint32_t)t;
+            const uint32_t* w = hin + (rel >> 5);
+            const uint32_t bits = funnel32(w[1], w[0], rel);
+            const uint32_t e = cl_lut[bits & 127u];
+            const uint32_t len = e & 7u, sym = e >> 3;
+            const uint32_t xb = sym == 16u ? 2u : sym == 17u ? 3u : sym == 18u ? 7u : 0u;
+            const uint32_t xv = bfe32(bits, len, xb);
+            const uint32_t rep = sym < 16u ? 1u : sym == 18u ? 11u + xv : 3u + xv;
+            // n[0:4] | len[5:7] | symbol[8:12] | repeat[16:23] | no code[31]
+            pk[t] = e == 0xFFu ? 0x80000000u : (len + xb) | (len << 5) | (sym << 8) | (rep << 16);
+        SIMT_END
+        uint32_t l = 0;
+        while (l < 64u && n < total) {
+            const uint32_t x = simt::uniform(simt::wave_read<N>(pk, (int)l));
+            const uint64_t avail = end_bits - (W + l);
+            const uint32_t nb = x & 31u, len = (x >> 5) & 7u, sym = (x >> 8) & 31u;
+            const int rep = (int)((x >> 16) & 255u);
+            if ((x >> 31) != 0u || (uint64_t)len > avail) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :122
             uint32_t val;
             if (sym <= 15) {
-                rep = 1; val = sym;
+                val = sym;
             } else if (sym == 16 && n > 0) {
-                if (br.bc < 2) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :132
-                rep = (int)br.bits(2) + 3; val = prev;
+                if ((uint64_t)nb > avail) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :132
+                val = prev;
                 if (n + rep > total) return SWC_E_DEFLATE_WRONG_SYMBOL;  // :135
-            } else if (sym == 17) {
-                if (br.bc < 3) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :145
-                n += (int)br.bits(3) + 3; prev = 0;
-                continue;
-            } else if (sym == 18) {
-                if (br.bc < 7) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :152
-                n += (int)br.bits(7) + 11; prev = 0;
+            } else if (sym == 17 || sym == 18) {
+                if ((uint64_t)nb > avail) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :145, :152
+                n += rep; prev = 0;
+                l += nb;
                 continue;
             } else {
                 return SWC_E_DEFLATE_WRONG_SYMBOL;  // :155 (symbol 16 first)
@@ -1008,32 +1136,33 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, SyncProf& pf) {
             if (val != 0) for (int i = ln.wlane; i < rep; i += ln.wlanes) lens[n + i] = (uint8_t)val;
 #endif
             n += rep;
+            l += nb;
         }
-        if (n != total) return SWC_E_DEFLATE_WRONG_SYMBOL;  // :161
+        W += l;
     }
+    if (n != total) return SWC_E_DEFLATE_WRONG_SYMBOL;  // :161
     simt::wave_fence();
+    br.seek(W);
     SWC_SP(pf, 0)
-    sync_tables_from_lengths(sl, literals, distances);
+    fast = sync_tables_from_lengths(sl, sp, literals, distances, st);
     return SWC_OK;
 }
 
 // Deflate.swift:77-81 with the fixed code of Deflate+Constants.swift:11-173: the same table build from the fixed lengths
-SWC_D void build_static_par(SyncLds* sl, SyncProf& pf) {
-    (void)pf;
+SWC_D void build_static_par(SyncLds* sl, const Spill sp, SubTab& st, bool& fast) {
     constexpr int N = kWave;
     uint8_t* lens = sl->stage + kHdrLens;
-    uint32_t* cnt = (uint32_t*)(sl->stage + kHdrCnt);
     SIMT_BEGIN(t, N)
-        if (t < 48) cnt[t] = 0;
         for (int s = t; s < 320; s += N) lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
     SIMT_END_WAVE
-    sync_tables_from_lengths(sl, 288, 32);
+    fast = sync_tables_from_lengths(sl, sp, 288, 32, st);
 }
 
 // ---- the job -------------------------------------------------------------------------------------------------------
 // Deflate.swift:30-249 for one stream on one wavefront.  `ws` / `ws_bytes`: the stream's area in the HBM workspace
-// (lzr::StreamHeader | records | literal stream).  On the device every lane of the wave calls this with its lane number;
-// the host emulation calls it once (lane 0 of 1) and runs the 64 lanes of the parallel parts one after another.
+// (lzr::StreamHeader | records | scratch rows + table spill | literal stream).  On the device every lane of the wave calls
+// this with its lane number; the host emulation calls it once (lane 0 of 1) and runs the 64 lanes of the parallel parts one
+// after another.
 SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes, int lane, int lanes, uint64_t* prof = nullptr) {
     Lane ln;
     SyncProf pf;
@@ -1042,7 +1171,7 @@ SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes,
 #endif
     ln.wlane = lane;
     ln.wlanes = lanes;
-    ln.l = LaneLds{sl->syms, 1};
+    ln.l = LaneLds{nullptr, 1};
     ln.out = (gptr)job.out;
     ln.cap = job.out_cap;
     ln.pos = 0;
@@ -1051,7 +1180,8 @@ SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes,
     ln.last_end = 0;
     const size_t lo = ws ? lzr::lit_offset(ws_bytes, job.out_cap) : 0;
     ln.recs = (SWC_AS_GLOBAL uint32_t*)(ws + sizeof(lzr::StreamHeader));
-    size_t rec_end = lo;   // the lanes' scratch (lzr::kProvBytes) sits between the record list and the literal stream, if the area has room for it
+    // the lanes' scratch and the table spill (lzr::kProvBytes) sit between the record list and the literal stream
+    size_t rec_end = lo;
     ln.prov = nullptr;
     if (lo >= sizeof(lzr::StreamHeader) + 256 + lzr::kProvBytes) {
         rec_end = (lo - lzr::kProvBytes) & ~(size_t)15;
@@ -1059,9 +1189,16 @@ SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes,
     }
     ln.max_rec = rec_end > sizeof(lzr::StreamHeader) ? (uint32_t)((rec_end - sizeof(lzr::StreamHeader)) / 4) : 0u;
     ln.lits = (gptr)(ws + lo);
+    Spill sp{nullptr, nullptr, nullptr};
+    if (ln.prov) {
+        gptr s0 = ln.prov + lzr::kProvRecBytes + lzr::kProvLitBytes;
+        sp.aux = (SWC_AS_GLOBAL uint32_t*)s0;
+        sp.syms = (SWC_AS_GLOBAL uint16_t*)(s0 + kSpillSyms);
+        sp.sub = (SWC_AS_GLOBAL uint32_t*)(s0 + kSpillSub);
+    }
     int st = SWC_OK;
-    if (lo == 0) {
-        st = SWC_E_NEED_WORKSPACE;
+    if (lo == 0 || ln.prov == nullptr) {
+        st = SWC_E_NEED_WORKSPACE;   // (an area smaller than swc_batch_workspace_bytes asks for)
         ln.br.init((gcptr)job.in, 0, 0);
     } else if (job.in_len > 0xFFFFFFF0ull) {
         st = SWC_E_INVALID_ARGUMENT;  // streams are addressed with 32-bit byte offsets on device
@@ -1078,21 +1215,22 @@ SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes,
                 st = ln.run_stored();
             } else if (type == 1 || type == 2) {
                 SWC_SP(pf, 6)
-                if (type == 1) build_static_par(sl, pf);
-                else st = build_dynamic_par(ln, sl, pf);
+                bool fast = false;
+                SubTab stb{nullptr};
+                if (type == 1) build_static_par(sl, sp, stb, fast);
+                else st = build_dynamic_par(ln, sl, sp, stb, fast, pf);
                 SWC_SP(pf, 1)
                 if (st == SWC_OK) {
-                    bool fast = sl->aux[kAuxLit + kAuxOver] == 0 && sl->aux[kAuxDist + kAuxOver] == 0;
                     for (;;) {   // Deflate.swift:171-236
                         if (fast) {
-                            const int r = sync_block(ln, sl, pf);
+                            const int r = sync_block(ln, sl, stb, pf);
                             if (r == kSyncEob) break;
                             if (r == kSyncBail) fast = false;   // the checked step takes the rest of the block
                             // kSyncBailCap: checked steps until the capacity is behind us
                         }
                         const uint64_t until = fast && ln.pos < ln.cap ? ln.cap : ~0ull;
                         int s2 = SWC_OK;
-                        do { s2 = careful_step_lds(ln, sl); } while (s2 == SWC_OK && ln.pos < until && until != ~0ull);
+                        do { s2 = careful_step(ln, sp); } while (s2 == SWC_OK && ln.pos < until && until != ~0ull);
                         if (s2 == -1) break;
                         if (s2) { st = s2; break; }
                     }

@@ -45,7 +45,7 @@ struct WsMap {
 // Phase 1: one stream per WAVEFRONT, 64 sub-chunks of the stream decoded at once (inflate_sync.h).
 // LDS: the shared tables + the staged input of a round, exactly 10 KiB per wave -> 16 waves per CU.
 #ifndef SWC_SYNC_WAVES_PER_SIMD
-#define SWC_SYNC_WAVES_PER_SIMD 3
+#define SWC_SYNC_WAVES_PER_SIMD 4
 #endif
 // Measurement state belongs to the CALLING THREAD, like the launch stream and the staging buffers (api.cpp): two threads
 // that bench at once do not see each other's events.

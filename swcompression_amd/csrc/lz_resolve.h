@@ -61,14 +61,18 @@ SWC_HD size_t max_records(uint64_t cap) { return (size_t)(cap / 3 + cap / 32 + 6
 SWC_HD size_t lit_bytes(uint64_t cap) { return (size_t)((cap + 32 + 15) & ~(uint64_t)15); }   // +32: wide flushes and reads may overshoot
 // Scratch of the wave-parallel Deflate decode (inflate_sync.h): the records and literals of the 64 sub-chunks of the current
 // round before their final offsets are known, as ROWS across the lanes -- row k holds the k-th record (4 bytes) / the k-th
-// group of eight literals of every lane, so that the 64 lanes, which advance at about the same rate, fill whole cache lines
-// together and read them back with coalesced loads.  Sized for the worst case (a sub-chunk of 1-bit codes); row 0 of each
-// part is the target of stores that must not happen.  Sits between the record list and the literal stream.
+// group of FOUR literals of every lane, so that the 64 lanes, which advance at about the same rate, fill whole cache lines
+// together and read them back with coalesced loads.  Sized for the worst case (a sub-chunk of 1-bit codes); row 0 of the
+// literal part is where a lane without literals so far stores.  Behind the rows: the SPILL of the stream's code tables that
+// only the checked one-symbol step needs (canonical limits, sorted symbols) and the overflow of the long-code subtables.
+// Sits between the record list and the literal stream.
 #ifndef SWC_SYNC_CHUNK
 #define SWC_SYNC_CHUNK 68   // input bytes per lane and round of the wave-parallel decode (inflate_sync.h: kSyncChunk)
 #endif
 // a sub-chunk decodes at most 8 * SWC_SYNC_CHUNK + 48 bits: a match takes two bits or more, a literal one
-constexpr size_t kProvRecRows = (8 * SWC_SYNC_CHUNK + 48) / 2 + 5, kProvLitRows = (8 * SWC_SYNC_CHUNK + 48) / 8 + 3, kProvRecBytes = kProvRecRows * 64 * 4, kProvBytes = kProvRecBytes + kProvLitRows * 64 * 8;
+constexpr size_t kProvRecRows = (8 * SWC_SYNC_CHUNK + 48) / 2 + 5, kProvLitRows = (8 * SWC_SYNC_CHUNK + 48) / 4 + 3;
+constexpr size_t kProvRecBytes = kProvRecRows * 64 * 4, kProvLitBytes = kProvLitRows * 64 * 4, kProvSpillBytes = 8192;
+constexpr size_t kProvBytes = kProvRecBytes + kProvLitBytes + kProvSpillBytes;
 SWC_HD size_t ws_bytes_per_job(uint64_t cap) { return ((sizeof(StreamHeader) + max_records(cap) * 4 + 15) & ~(size_t)15) + kProvBytes + lit_bytes(cap); }
 // a job's literal stream inside its area of `stride` bytes (0 if the area is too small for it)
 SWC_HD size_t lit_offset(size_t stride, uint64_t cap) { return stride >= lit_bytes(cap) + sizeof(StreamHeader) ? (stride - lit_bytes(cap)) & ~(size_t)15 : 0; }
