@@ -48,6 +48,13 @@ constexpr uint32_t kSyncChunk = SWC_SYNC_CHUNK;
 constexpr uint32_t kSyncRound = 64u * kSyncChunk;
 constexpr uint32_t kSyncStage = (kSyncRound + 32u + 15u) & ~15u;    // + what the last lane may read past its sub-chunk (a code of <= 48 bits, then the window's two dwords: < 24 bytes)
 constexpr uint32_t kPosFail = 0xFFFFFFFFu;
+#ifndef SWC_SYNC_WALK_BACK
+#define SWC_SYNC_WALK_BACK 128
+#endif
+#ifndef SWC_WALK_WINDOW
+#define SWC_WALK_WINDOW 0
+#endif
+constexpr uint32_t kSyncWalkBack = SWC_SYNC_WALK_BACK;   // bits
 static_assert(kSyncChunk % 4 == 0 && kSyncChunk >= 36, "sub-chunks are whole dwords");
 
 // ---- table entry ----------------------------------------------------------------------------------------------------
@@ -136,6 +143,9 @@ constexpr uint32_t kHdrTab = 3840;     // 2 x (first code[16] | sorted index of 
 static_assert(kHdrTab + 2 * 33 * 4 <= kSyncStage && kHdrPt + 2 * 1280 <= kHdrTab, "header scratch fits the stage");
 
 enum { kSyncEob = 0, kSyncBail = 1, kSyncBailCap = 2 };
+#ifndef SWC_PROV_STORES
+#define SWC_PROV_STORES 2   // the provisional decode's stores: 0 unconditional, 1 masked per lane (a literal came in / a record is complete), 2 literal groups only when full
+#endif
 #if defined(SWC_HOST_EMULATION)
 // statistics of the emulated decoder (tests, tools/sync_stats.py): rounds committed, bails, lane-passes, symbol iterations
 inline uint64_t g_sync_stats[8];
@@ -549,6 +559,30 @@ SWC_D uint32_t walk_chunk(const SyncLds* sl, const SubTab st, uint32_t start, ui
     uint32_t pos = start, tm = kLitMask4, tb = 0, e = 0;
     uint32_t c_notlen = kEntNotLen, c_dmask = kDistMask4;
     SWC_OPAQUE(c_notlen); SWC_OPAQUE(c_dmask);
+#if SWC_WALK_WINDOW
+    // The walk is bound by the latency of its chain, not by its instruction count (four waves per SIMD, two dependent LDS reads
+    // per code in the form below): here the window lives in two registers, the dword behind it is read every step -- needed or
+    // not, off the chain -- and moves in when the position crosses a dword: ONE LDS read in the chain, fourteen instructions.
+    uint32_t d0, d1, bp = pos & 31u;
+    { const uint32_t* w = (const uint32_t*)(sl->stage + ((pos >> 3) & 0x1FFCu)); d0 = w[0]; d1 = w[1]; }
+    if (start < chunk_end) do {
+        SWC_SYNC_STAT(4, 1);
+        SWC_SYNC_ITER();
+        const uint32_t bits4 = funnel32(d1, d0, pos);
+        e = *(const uint32_t*)((const uint8_t*)sl->lut + and_or(bits4, tm, tb));
+        const uint32_t nx = *(const uint32_t*)(sl->stage + ((pos >> 3) & 0x1FFCu) + 8u);
+        uint32_t mm = e & kEntPosMask;
+        if (mm == 0u) { SWC_SYNC_STAT(7, 1); SWC_SYNC_LONG(); e = long_lookup(sl, st, bits4, e); mm = e & kEntPosMask; }
+        pos = pos + mm + 0xFFFFFFFEu;
+        const uint32_t bpn = pos & 31u;
+        const bool crossed = bpn < bp;                      // (a symbol takes fewer than 32 bits)
+        d0 = crossed ? d1 : d0;
+        d1 = crossed ? nx : d1;
+        bp = bpn;
+        tm = and_or(e, c_notlen, c_dmask);
+        tb = e & kEntLen;
+    } while ((int32_t)pos < (int32_t)chunk_end);
+#else
     if (start < chunk_end) do {   // (tested at the bottom: one mask update and one branch per iteration)
         SWC_SYNC_STAT(4, 1);
         SWC_SYNC_ITER();
@@ -560,6 +594,7 @@ SWC_D uint32_t walk_chunk(const SyncLds* sl, const SubTab st, uint32_t start, ui
         tm = and_or(e, c_notlen, c_dmask);
         tb = e & kEntLen;
     } while ((int32_t)pos < (int32_t)chunk_end);
+#endif
     const uint32_t endb = pos & 0x3FFFFFFFu;
     const bool fail = ((pos & kEntStop) != 0u && !ent_is_eob(e)) || endb > in_bits;
     return fail ? kPosFail : endb;
@@ -612,10 +647,19 @@ SWC_D void decode_chunk_prov(const SyncLds* sl, const SubTab st, uint32_t start,
         const uint32_t lit1 = bfe32(e, 13, 1);
         lb = alignbyte32(val, lb, lit1);
         nl3 += lit1;
+        const uint32_t dm = sbfe1(e, 29);
+#if SWC_PROV_STORES == 0
         store_u32(prov + lshl_add<6>(nl3 & ~3u, lbase), lb);
         // a distance completes a record; any other step writes a word that the next record of the lane overwrites
-        const uint32_t dm = sbfe1(e, 29);
         store_u32(prov + roff, lshl_add<7>(plen, lshl_add<16>(val, run)));
+#elif SWC_PROV_STORES == 1
+        // (the stores of the lanes that have nothing new are masked off: the memory pipeline's work is per active lane)
+        if (lit1 != 0u) store_u32(prov + lshl_add<6>(nl3 & ~3u, lbase), lb);
+        if (dm != 0u) store_u32(prov + roff, lshl_add<7>(plen, lshl_add<16>(val, run)));
+#else
+        if (((nl3 & 3u) | (lit1 << 2)) == 7u) store_u32(prov + lshl_add<6>(nl3 & ~3u, lbase), lb);   // a literal came in and completed its group (nl3 % 4 == 3)
+        if (dm != 0u) store_u32(prov + roff, lshl_add<7>(plen, lshl_add<16>(val, run)));
+#endif
         roff = mad24(dm, c_m256, roff);
         if (NEED) {
             const int32_t nd = (int32_t)val - (int32_t)nout;   // this much output must exist in front of the sub-chunk
@@ -626,6 +670,9 @@ SWC_D void decode_chunk_prov(const SyncLds* sl, const SubTab st, uint32_t start,
         plen = val & sbfe1(e, 12);
     } while ((int32_t)pos < (int32_t)chunk_end);
     const uint32_t nlit = nl3 - 3u;
+#if SWC_PROV_STORES == 2
+    if (nlit & 3u) store_u32(prov + lshl_add<6>(nl3 & ~3u, lbase), lb);   // the last, incomplete group
+#endif
     const uint32_t endb = pos & 0x3FFFFFFFu;
     uint32_t flags = 0;
     if (dead) flags = kFlagFail;
@@ -785,26 +832,48 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, const SubTab st, SyncProf& pf) {
         SWC_SPC(pf, 7, 1);
         const uint64_t left = (uint64_t)(in_len - B) * 8;
         const uint32_t in_bits = left > 0x3FFFFFFFull ? 0x3FFFFFFFu : (uint32_t)left;
-        // stage [B, B + kSyncStage), zero-filled beyond the input, shifted left by two bits: LDS bit p + 2 is stream bit p
-        SIMT_BEGIN(t, N)
-            for (uint32_t o = 16u * (uint32_t)t; o < kSyncStage; o += 16u * N) {
-                uint64_t a = 0, b = 0;
-                uint32_t prev = 0;
-                const uint64_t at = (uint64_t)B + o;
-                if (at + 16 <= in_len) {
-                    a = load_u64(in + at); b = load_u64(in + at + 8);
-                    if (o != 0) prev = load_u32(in + at - 4);
-                } else {
-                    for (uint32_t k = 0; k < 8; k++) if (at + k < in_len) a |= (uint64_t)in[at + k] << (8 * k);
-                    for (uint32_t k = 0; k < 8; k++) if (at + 8 + k < in_len) b |= (uint64_t)in[at + 8 + k] << (8 * k);
-                    if (o != 0) for (uint32_t k = 0; k < 4; k++) if (at - 4 + k < in_len) prev |= (uint32_t)in[at - 4 + k] << (8 * k);
+        // stage [B, B + kSyncStage), zero-filled beyond the input, shifted left by two bits: LDS bit p + 2 is stream bit p.
+        // All loads of the round are issued before the first is used: ONE memory latency per round, not one per kilobyte.
+        {
+            constexpr uint32_t kParts = (kSyncStage + 16u * N - 1u) / (16u * N);
+            PT<uint64_t, N> sa[kParts], sb[kParts];
+            PT<uint32_t, N> sp[kParts];
+            SIMT_BEGIN(t, N)
+#pragma unroll
+                for (uint32_t k = 0; k < kParts; k++) {
+                    const uint32_t o = 16u * (uint32_t)t + k * 16u * N;
+                    uint64_t a = 0, b = 0;
+                    uint32_t prev = 0;
+                    const uint64_t at = (uint64_t)B + o;
+                    if (o < kSyncStage) {
+                        if (at + 16 <= in_len) {
+                            a = load_u64(in + at); b = load_u64(in + at + 8);
+                            if (o != 0) prev = load_u32(in + at - 4);
+                        } else {
+                            for (uint32_t q = 0; q < 8; q++) if (at + q < in_len) a |= (uint64_t)in[at + q] << (8 * q);
+                            for (uint32_t q = 0; q < 8; q++) if (at + 8 + q < in_len) b |= (uint64_t)in[at + 8 + q] << (8 * q);
+                            if (o != 0) for (uint32_t q = 0; q < 4; q++) if (at - 4 + q < in_len) prev |= (uint32_t)in[at - 4 + q] << (8 * q);
+                        }
+                    }
+                    sa[k][t] = a; sb[k][t] = b; sp[k][t] = prev;
                 }
-                uint32_t* st32 = (uint32_t*)(sl->stage + o);
-                const uint32_t w0 = (uint32_t)a, w1 = (uint32_t)(a >> 32), w2 = (uint32_t)b, w3 = (uint32_t)(b >> 32);
-                st32[0] = funnel32(w0, prev, 30); st32[1] = funnel32(w1, w0, 30); st32[2] = funnel32(w2, w1, 30); st32[3] = funnel32(w3, w2, 30);
-            }
-            start[t] = t == 0 ? q0 : (uint32_t)t * kSyncChunk * 8u;
-        SIMT_END_WAVE
+            SIMT_END
+            SIMT_BEGIN(t, N)
+#pragma unroll
+                for (uint32_t k = 0; k < kParts; k++) {
+                    const uint32_t o = 16u * (uint32_t)t + k * 16u * N;
+                    if (o < kSyncStage) {
+                        uint32_t* st32 = (uint32_t*)(sl->stage + o);
+                        const uint64_t a = sa[k][t], b = sb[k][t];
+                        const uint32_t w0 = (uint32_t)a, w1 = (uint32_t)(a >> 32), w2 = (uint32_t)b, w3 = (uint32_t)(b >> 32);
+                        st32[0] = funnel32(w0, sp[k][t], 30); st32[1] = funnel32(w1, w0, 30); st32[2] = funnel32(w2, w1, 30); st32[3] = funnel32(w3, w2, 30);
+                    }
+                }
+                // (lanes 1..63 begin their walk kSyncWalkBack bits IN FRONT of their sub-chunk: the further a walk has come when it
+                // crosses into the sub-chunk, the surer its end is the true one, and a wrong end costs the round another pass)
+                start[t] = t == 0 ? q0 : (uint32_t)t * kSyncChunk * 8u - kSyncWalkBack;
+            SIMT_END_WAVE
+        }
         uint32_t nv = 0;
         bool eob = false, bail = false;
         const bool chk = (uint64_t)B + kSyncStage > in_len;   // only the last rounds of a stream can run out of input
@@ -1075,8 +1144,9 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, const Spill sp, SubTab& st, b
     int n = 0;
     uint32_t prev = 0;
     uint64_t HB = ~0ull;                                  // byte offset of the staged part of the header (none yet)
-    PT<uint32_t, N> pk;
-    while (n < total) {   // Deflate.swift:117-162
+    PT<uint32_t, N> nxt, mlo, mhi, jmp, gl, gh, gj, src, symv, repv, errv, cbx, bef, key, kex;
+    PT<bool, N> pb, actv;
+    while (n < total) {   // Deflate.swift:117-162, 64 bit offsets per turn
         if (HB == ~0ull || W + 64 + 32 > 8 * (HB + 1024)) {
             HB = (W >> 3) & ~3ull;
             SIMT_BEGIN(t, N)
@@ -1092,53 +1162,83 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, const Spill sp, SubTab& st, b
                 if (t < 4) hin[256 + t] = 0;
             SIMT_END_WAVE
         }
-        // every lane: the symbol that would start at bit W + t
+        // every lane: the symbol that WOULD start at bit W + t, and the lane the symbol behind it starts at
         const uint32_t rel0 = (uint32_t)(W - 8 * HB);
+        const uint64_t left64 = end_bits - W;
+        const uint32_t left = left64 > 0xFFFFu ? 0xFFFFu : (uint32_t)left64;    // stream bits from W on (as far as it matters)
         SIMT_BEGIN(t, N)
             const uint32_t rel = rel0 + (uint32_t)t;
             const uint32_t* w = hin + (rel >> 5);
             const uint32_t bits = funnel32(w[1], w[0], rel);
             const uint32_t e = cl_lut[bits & 127u];
-            const uint32_t len = e & 7u, sym = e >> 3;
+            const uint32_t len = e & 7u, sym = e == 0xFFu ? 0u : e >> 3;
             const uint32_t xb = sym == 16u ? 2u : sym == 17u ? 3u : sym == 18u ? 7u : 0u;
             const uint32_t xv = bfe32(bits, len, xb);
-            const uint32_t rep = sym < 16u ? 1u : sym == 18u ? 11u + xv : 3u + xv;
-            // n[0:4] | len[5:7] | symbol[8:12] | repeat[16:23] | no code[31]
-            pk[t] = e == 0xFFu ? 0x80000000u : (len + xb) | (len << 5) | (sym << 8) | (rep << 16);
+            const uint32_t avail = left > (uint32_t)t ? left - (uint32_t)t : 0u;
+            symv[t] = sym;
+            repv[t] = sym < 16u ? 1u : sym == 18u ? 11u + xv : 3u + xv;
+            // what the reference would throw HERE, short of what depends on the running count: 1 = no code / the code runs past
+            // the end of the input (:122), 2 = the extra bits do (:132, :145, :152)
+            errv[t] = e == 0xFFu || len > avail ? 1u : len + xb > avail ? 2u : 0u;
+            nxt[t] = (uint32_t)t + (e == 0xFFu ? 1u : len + xb);
+            jmp[t] = nxt[t];
+            mlo[t] = t < 32 ? 1u << t : 0u;
+            mhi[t] = t < 32 ? 0u : 1u << (t - 32);
         SIMT_END
-        uint32_t l = 0;
-        while (l < 64u && n < total) {
-            const uint32_t x = simt::uniform(simt::wave_read<N>(pk, (int)l));
-            const uint64_t avail = end_bits - (W + l);
-            const uint32_t nb = x & 31u, len = (x >> 5) & 7u, sym = (x >> 8) & 31u;
-            const int rep = (int)((x >> 16) & 255u);
-            if ((x >> 31) != 0u || (uint64_t)len > avail) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :122
-            uint32_t val;
-            if (sym <= 15) {
-                val = sym;
-            } else if (sym == 16 && n > 0) {
-                if ((uint64_t)nb > avail) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :132
-                val = prev;
-                if (n + rep > total) return SWC_E_DEFLATE_WRONG_SYMBOL;  // :135
-            } else if (sym == 17 || sym == 18) {
-                if ((uint64_t)nb > avail) return SWC_E_DEFLATE_SYMBOL_NOT_FOUND;  // :145, :152
-                n += rep; prev = 0;
-                l += nb;
-                continue;
-            } else {
-                return SWC_E_DEFLATE_WRONG_SYMBOL;  // :155 (symbol 16 first)
-            }
-            prev = val;
-#if defined(__HIP_DEVICE_COMPILE__)
-            // every lane stores (lane i: entry min(i, rep - 1)): no exec-mask region in this serial loop; zeros land on zeros
-            { const int i = ln.wlane < rep - 1 ? ln.wlane : rep - 1; lens[n + i] = (uint8_t)val; }
-#else
-            if (val != 0) for (int i = ln.wlane; i < rep; i += ln.wlanes) lens[n + i] = (uint8_t)val;
-#endif
-            n += rep;
-            l += nb;
+        // which lanes does the chain from lane 0 visit?  Pointer doubling: after step k a lane knows the lanes within 2^k hops.
+#pragma unroll 1
+        for (int k = 0; k < 6; k++) {
+            if (simt::uniform(simt::wave_read<N>(jmp, 0)) >= 64u) break;   // lane 0 has seen its whole chain (4 bits per symbol: 16 hops)
+            SIMT_BEGIN(t, N) src[t] = jmp[t] < 64u ? jmp[t] : (uint32_t)t; SIMT_END
+            simt::wave_gather<N>(gl, mlo, src);
+            simt::wave_gather<N>(gh, mhi, src);
+            simt::wave_gather<N>(gj, jmp, src);
+            SIMT_BEGIN(t, N) if (jmp[t] < 64u) { mlo[t] |= gl[t]; mhi[t] |= gh[t]; jmp[t] = gj[t]; } SIMT_END
         }
-        W += l;
+        const uint64_t V = ((uint64_t)simt::uniform(simt::wave_read<N>(mhi, 0)) << 32) | simt::uniform(simt::wave_read<N>(mlo, 0));
+        // the running count in front of every visited symbol
+        SIMT_BEGIN(t, N) cbx[t] = (V >> t) & 1ull ? repv[t] : 0u; SIMT_END
+        simt::wave_scan_incl<N>(cbx);
+        // the symbols the reference's loop gets to (count < total), their errors in its order
+        SIMT_BEGIN(t, N)
+            const bool vis = ((V >> t) & 1ull) != 0ull;
+            const uint32_t rep = repv[t], before = (uint32_t)n + cbx[t] - (vis ? rep : 0u), sym = symv[t];
+            const bool act = vis && before < (uint32_t)total;
+            uint32_t err = 0;
+            if (act) {
+                if (errv[t] == 1u) err = (uint32_t)SWC_E_DEFLATE_SYMBOL_NOT_FOUND;                       // :122
+                else if (sym == 16u && before == 0u) err = (uint32_t)SWC_E_DEFLATE_WRONG_SYMBOL;          // :155 (symbol 16 first)
+                else if (sym >= 16u && errv[t] == 2u) err = (uint32_t)SWC_E_DEFLATE_SYMBOL_NOT_FOUND;     // :132, :145, :152
+                else if (sym == 16u && before + rep > (uint32_t)total) err = (uint32_t)SWC_E_DEFLATE_WRONG_SYMBOL;   // :135
+            }
+            errv[t] = err;
+            pb[t] = err != 0u;
+            actv[t] = act;
+            bef[t] = before;
+            // the value a symbol 16 repeats: that of the nearest symbol in front of it that is not a 16 (17 / 18 leave a zero)
+            key[t] = act && sym != 16u ? (((uint32_t)t + 1u) << 8) | (sym < 16u ? sym : 0u) : 0u;
+        SIMT_END
+        {
+            const uint64_t m_err = simt::wave_ballot<N>(pb);
+            if (m_err) return (int)simt::wave_read<N>(errv, simt::ctz64(m_err));   // the first one in the reference's order
+        }
+        kex = key;
+        simt::wave_scan_max_incl<N>(kex);
+        const uint32_t klast = simt::uniform(simt::wave_read<N>(kex, N - 1));
+        simt::wave_shift_up<N>(key, kex, 0u);
+        SIMT_BEGIN(t, N)
+            if (actv[t]) {
+                const uint32_t sym = symv[t];
+                const uint32_t val = sym < 16u ? sym : sym == 16u ? (key[t] ? key[t] & 255u : prev) : 0u;
+                // (a non-zero value repeats at most six times, and -- checked above -- stays inside the table)
+                if (val != 0u) for (uint32_t k = 0; k < repv[t]; k++) lens[bef[t] + k] = (uint8_t)val;
+            }
+        SIMT_END
+        const uint64_t m_act = simt::wave_ballot<N>(actv);
+        const int last = 63 - simt::clz64(m_act);           // (lane 0 is always one of them)
+        n = (int)(simt::uniform(simt::wave_read<N>(bef, last)) + simt::uniform(simt::wave_read<N>(repv, last)));
+        W += simt::uniform(simt::wave_read<N>(nxt, last));
+        if (klast) prev = klast & 255u;
     }
     if (n != total) return SWC_E_DEFLATE_WRONG_SYMBOL;  // :161
     simt::wave_fence();

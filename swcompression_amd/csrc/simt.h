@@ -159,6 +159,44 @@ SWC_D void wave_scan_incl(PT<uint32_t, N>& x) {
     for (int t = 0; t < N; t++) { a += x.v[t]; x.v[t] = a; }
 #endif
 }
+// inclusive prefix MAXIMUM (unsigned) within the 64-lane wave: the DPP scheme of wave_scan_incl_dev with max in place of add
+// (a lane without a source reads the identity 0)
+SWC_D uint32_t wave_scan_max_dev(uint32_t x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    auto mx = [](uint32_t a, uint32_t b) { return a > b ? a : b; };
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false));  // row_shr:1
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false));  // row_shr:2
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false));  // row_shr:4
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false));  // row_shr:8
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false));  // row_bcast:15 -> rows 1, 3
+    x = mx(x, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false));  // row_bcast:31 -> rows 2, 3
+#endif
+    return x;
+}
+template <int N>
+SWC_D void wave_scan_max_incl(PT<uint32_t, N>& x) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    x.v = wave_scan_max_dev(x.v);
+#elif defined(SWC_SIMT_DEVICE_FORM)
+    (void)x;
+#else
+    uint32_t a = 0;
+    for (int t = 0; t < N; t++) { a = x.v[t] > a ? x.v[t] : a; x.v[t] = a; }
+#endif
+}
+// y[t] = x[idx[t] % 64]: every lane reads the value of a lane of its choice
+template <int N>
+SWC_D void wave_gather(PT<uint32_t, N>& y, const PT<uint32_t, N>& x, const PT<uint32_t, N>& idx) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    y.v = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(idx.v << 2), (int)x.v);
+#elif defined(SWC_SIMT_DEVICE_FORM)
+    (void)y; (void)x; (void)idx;
+#else
+    PT<uint32_t, N> r;
+    for (int t = 0; t < N; t++) r.v[t] = x.v[idx.v[t] & (N - 1)];
+    y = r;
+#endif
+}
 // y[t] = x[t - 1] (lane 0: `fill`)
 template <int N>
 SWC_D void wave_shift_up(PT<uint32_t, N>& y, const PT<uint32_t, N>& x, uint32_t fill) {
@@ -208,6 +246,13 @@ SWC_HD int popc32(uint32_t m) {
     return __popc(m);
 #else
     return __builtin_popcount(m);
+#endif
+}
+SWC_HD int clz64(uint64_t m) {   // m != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clzll((long long)m);
+#else
+    return __builtin_clzll(m);
 #endif
 }
 SWC_HD int ctz64(uint64_t m) {   // m != 0
