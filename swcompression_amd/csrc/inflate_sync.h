@@ -51,6 +51,10 @@ constexpr uint32_t kPosFail = 0xFFFFFFFFu;
 #ifndef SWC_SYNC_WALK_BACK
 #define SWC_SYNC_WALK_BACK 128
 #endif
+#ifndef SWC_COPY_REC
+#define SWC_COPY_REC 16   // records / literal groups (both multiples of four) a lane moves per step of copy_prov
+#define SWC_COPY_LIT 8
+#endif
 #ifndef SWC_WALK_WINDOW
 #define SWC_WALK_WINDOW 0
 #endif
@@ -632,14 +636,18 @@ SWC_D void decode_chunk_prov(const SyncLds* sl, const SubTab st, uint32_t start,
     SWC_OPAQUE(c_notlen); SWC_OPAQUE(c_dmask); SWC_OPAQUE(c_m256);
     if (chunk_end > in_bits) chunk_end = in_bits;          // (the zero fill behind the input is not worth decoding)
     const bool dead = start >= in_bits;                    // nothing left for this sub-chunk: the checked step says what that means
+    // (the window of the NEXT step is read as soon as the position is known: its LDS latency runs under the bookkeeping)
+    uint32_t w0 = 0, w1 = 0;
+    if (!dead && start < chunk_end) { const uint32_t* w = (const uint32_t*)(sl->stage + ((pos >> 3) & 0x1FFCu)); w0 = w[0]; w1 = w[1]; }
     if (!dead && start < chunk_end) do {                   // (tested at the bottom: one mask update and one branch per iteration)
         SWC_SYNC_STAT(5, 1);
         SWC_SYNC_ITER();
-        const uint32_t bits4 = stage_bits(sl, pos);
+        const uint32_t bits4 = funnel32(w1, w0, pos);
         e = *(const uint32_t*)((const uint8_t*)sl->lut + and_or(bits4, tm, tb));
         uint32_t mm = e & kEntPosMask;
         if (mm == 0u) { SWC_SYNC_STAT(7, 1); SWC_SYNC_LONG(); e = long_lookup(sl, st, bits4, e); mm = e & kEntPosMask; }
         pos = pos + mm + 0xFFFFFFFEu;
+        { const uint32_t* w = (const uint32_t*)(sl->stage + ((pos >> 3) & 0x1FFCu)); w0 = w[0]; w1 = w[1]; }
         tm = and_or(e, c_notlen, c_dmask);
         tb = e & kEntLen;
         const uint32_t val = (bfe32(bits4, 0, e) >> ((e >> 5) & 31u)) + bfe32(e, kEntBaseShift, 15);
@@ -692,27 +700,29 @@ SWC_D void decode_chunk_prov(const SyncLds* sl, const SubTab st, uint32_t start,
 // aligned), `nlit` literal bytes to `ldst` (any alignment).  The loads of a step read one row: coalesced.  The last,
 // incomplete literal group holds its bytes at the top.
 SWC_D void copy_prov(gcptr plit, gcptr prec, uint32_t nlit, uint32_t nrec, gptr ldst, SWC_AS_GLOBAL uint32_t* rdst) {
-    // Sixteen records and eight literal groups are loaded per step, all before the first store (the scratch of all resident
-    // waves exceeds the L2, so a load takes its several hundred cycles: one load per step would expose that latency forty
-    // times per round).  Rows past the lane's count hold something and exist (the scratch is sized for the worst case): they
-    // are loaded and not stored.
+    // kCopyRec records and kCopyLit literal groups are loaded per step, all before the first store (the scratch of all
+    // resident waves exceeds the L2, so a load takes its several hundred cycles: one load per step would expose that latency
+    // forty times per round; a step lasts as long as the slowest lane's, so the sizes aim at ONE step for a sub-chunk of text --
+    // 23 records and 19 literals on average).  Rows past the lane's count hold something and exist (the scratch is sized for
+    // the worst case): they are loaded and not stored.
+    constexpr uint32_t kCopyRec = SWC_COPY_REC, kCopyLit = SWC_COPY_LIT;
     const uint32_t ngrp = (nlit + 3u) >> 2;
-    for (uint32_t i = 0, g = 0; i < nrec || g < ngrp; i += 16, g += 8) {
-        uint32_t v[16], w[8];
+    for (uint32_t i = 0, g = 0; i < nrec || g < ngrp; i += kCopyRec, g += kCopyLit) {
+        uint32_t v[kCopyRec], w[kCopyLit];
 #pragma unroll
-        for (uint32_t k = 0; k < 16; k++) {
+        for (uint32_t k = 0; k < kCopyRec; k++) {
             const uint32_t row = i + k + 1u < (uint32_t)lzr::kProvRecRows ? i + k + 1u : (uint32_t)lzr::kProvRecRows - 1u;
             v[k] = load_u32(prec + (size_t)row * kProvRow);
         }
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k++) {
+        for (uint32_t k = 0; k < kCopyLit; k++) {
             const uint32_t row = g + k + 1u < (uint32_t)lzr::kProvLitRows ? g + k + 1u : (uint32_t)lzr::kProvLitRows - 1u;
             w[k] = load_u32(plit + (size_t)row * kProvRow);
         }
         // (wide stores: the lanes' destinations lie apart, so the memory pipeline takes a store lane by lane -- four records or
         // four groups per lane and instruction instead of one)
 #pragma unroll
-        for (uint32_t k = 0; k < 16; k += 4) {
+        for (uint32_t k = 0; k < kCopyRec; k += 4) {
             if (i + k + 4u <= nrec) store_u128_a4((gptr)(rdst + i + k), v[k], v[k + 1], v[k + 2], v[k + 3]);
             else {
 #pragma unroll
@@ -720,7 +730,7 @@ SWC_D void copy_prov(gcptr plit, gcptr prec, uint32_t nlit, uint32_t nrec, gptr 
             }
         }
 #pragma unroll
-        for (uint32_t k = 0; k < 8; k += 4) {
+        for (uint32_t k = 0; k < kCopyLit; k += 4) {
             const uint32_t at = 4u * (g + k);
             if (at + 16u <= nlit) store_u128_a4(ldst + at, w[k], w[k + 1], w[k + 2], w[k + 3]);
             else {

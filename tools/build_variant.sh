@@ -9,3 +9,12 @@ OBJS=$(ls $R/swcompression_amd/build/*.o | grep -v kernels.hip.o)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $D/libswc_$N.so $D/kernels_$N.o $OBJS
 rm -f $D/kernels_$N.o
 echo $D/libswc_$N.so
+# registers / scratch of the phase-1 kernel of the variant (scratch > 0 = spills)
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -x hip -S --cuda-device-only $R/swcompression_amd/csrc/kernels.hip -o /tmp/asm/k_$N.s $F 2>/dev/null && python - /tmp/asm/k_$N.s <<'PY'
+import re, sys
+s = open(sys.argv[1]).read()
+for m in re.finditer(r'\.amdhsa_kernel (\S+)(.*?)\.end_amdhsa_kernel', s, re.S):
+    if 'inflate_sync' in m.group(1) or 'lz_resolve' in m.group(1):
+        g = lambda k: re.search(r'\.amdhsa_%s (\S+)' % k, m.group(2)).group(1)
+        print('  ', m.group(1)[9:36], 'vgpr', g('next_free_vgpr'), 'scratch', g('private_segment_fixed_size'))
+PY
