@@ -15,6 +15,7 @@
 #include <cstddef>
 #include <mutex>
 #include <atomic>
+#include <vector>
 #include "swc_common.h"
 #include "inflate_lane.h"
 #include "inflate_sync.h"
@@ -41,6 +42,76 @@ struct WsMap {
     __device__ size_t bytes(uint32_t g) const { return off ? (size_t)(off[g + 1] - off[g]) : stride; }
 };
 
+// Which job does workgroup `b` of an n-job launch take?  The hardware hands consecutive workgroups to the eight XCDs in turn
+// (workgroup b runs on XCD b % 8), so a job list whose cost has a period that divides 8 -- every fourth unit an incompressible
+// one, say -- would put all the expensive jobs on two XCDs and the launch would last as long as if every job were expensive
+// (measured: 192 text + 64 P-mix LZ4 blocks interleaved 3 : 1 took exactly the time of 256 P-mix blocks).  Here XCD x works
+// through the contiguous range [x n/8, (x + 1) n/8) of the list instead, in order: any eighth of the list costs about the same.
+__device__ __forceinline__ uint32_t xcd_job(uint32_t b, uint32_t n) {
+    const uint32_t per = n >> 3;
+    return b < (per << 3) ? (b & 7u) * per + (b >> 3) : b;
+}
+
+// ---- launch order: the longest jobs first ------------------------------------------------------------------------------
+// A job is one workgroup and lasts as long as its unit is big: 8,192 LZ4 blocks of 4 MiB are 1.7 rounds of the parse kernel's
+// resident waves, and when the incompressible blocks of the batch (twice the time of a text block) happen to start in the
+// second round, the launch ends one long block after everybody else has finished (measured: 73 ms for 34 ms of work).  The
+// hardware hands out workgroups in index order, so the jobs are ORDERED by size class -- compressed bytes, in steps of an
+// eighth of an octave -- largest first: a counting sort in three small kernels (histogram, prefix, scatter; the order inside a
+// class is whatever the atomics make it).  perm[b] is the job of workgroup b.  Batches of fewer than kOrderMin jobs keep the
+// plain XCD-aware order.
+constexpr int kOrderClasses = 256;
+constexpr size_t kOrderMin = 2048;
+__device__ __forceinline__ uint32_t order_class(uint64_t len) {
+    const uint32_t v = len > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)len | 8u;
+    const uint32_t e = 31u - (uint32_t)__clz((int)v);
+    return (kOrderClasses - 1) - (e * 8u + ((v >> (e - 3u)) & 7u));   // class 0 = the largest
+}
+__global__ __launch_bounds__(256) void swc_order_hist_kernel(const Job* __restrict__ jobs, uint32_t n, uint32_t* __restrict__ hist) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g < n) atomicAdd(&hist[order_class(jobs[g].in_len)], 1u);
+}
+__global__ __launch_bounds__(kOrderClasses) void swc_order_prefix_kernel(uint32_t* __restrict__ hist) {   // hist[c] -> first slot of class c
+    __shared__ uint32_t s[kOrderClasses];
+    const uint32_t t = threadIdx.x;
+    s[t] = hist[t];
+    __syncthreads();
+    uint32_t a = 0;
+    for (uint32_t i = 0; i < t; i++) a += s[i];
+    hist[t] = a;
+}
+__global__ __launch_bounds__(256) void swc_order_scatter_kernel(const Job* __restrict__ jobs, uint32_t n, uint32_t* __restrict__ cursor, uint32_t* __restrict__ perm) {
+    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
+    if (g < n) perm[atomicAdd(&cursor[order_class(jobs[g].in_len)], 1u)] = g;
+}
+// device buffer of the calling thread for the order of one launch on `stream` (perm[n] | cursors), or nullptr
+static const uint32_t* job_order(const Job* jobs, size_t n, hipStream_t stream) {
+    if (n < kOrderMin) return nullptr;
+    struct Buf { hipStream_t s; int dev; uint32_t* p; size_t cap; };
+    static thread_local std::vector<Buf> bufs;   // (never freed: a few hundred KB per launching thread and stream)
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    Buf* b = nullptr;
+    for (auto& x : bufs) if (x.s == stream && x.dev == dev) b = &x;
+    if (!b) { bufs.push_back(Buf{stream, dev, nullptr, 0}); b = &bufs.back(); }
+    const size_t need = n + kOrderClasses;
+    if (b->cap < need) {
+        if (b->p) (void)hipFree(b->p);
+        b->p = nullptr; b->cap = 0;
+        void* q = nullptr;
+        if (hipMalloc(&q, need * 2 * sizeof(uint32_t)) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+        b->p = (uint32_t*)q; b->cap = need * 2;
+    }
+    uint32_t* cursor = b->p + n;
+    if (hipMemsetAsync(cursor, 0, kOrderClasses * sizeof(uint32_t), stream) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+    const dim3 grid((unsigned)((n + 255) / 256));
+    hipLaunchKernelGGL(swc_order_hist_kernel, grid, dim3(256), 0, stream, jobs, (uint32_t)n, cursor);
+    hipLaunchKernelGGL(swc_order_prefix_kernel, dim3(1), dim3(kOrderClasses), 0, stream, cursor);
+    hipLaunchKernelGGL(swc_order_scatter_kernel, grid, dim3(256), 0, stream, jobs, (uint32_t)n, cursor, b->p);
+    return b->p;
+}
+__device__ __forceinline__ uint32_t job_of(const uint32_t* order, uint32_t b, uint32_t n) { return order ? order[b] : xcd_job(b, n); }
+
 // ---- Deflate: two phases (inflate_sync.h + inflate_lane.h, lz_resolve.h) -------------------------------------------
 // Phase 1: one stream per WAVEFRONT, 64 sub-chunks of the stream decoded at once (inflate_sync.h).
 // LDS: the shared tables + the staged input of a round, exactly 10 KiB per wave -> 16 waves per CU.
@@ -53,7 +124,7 @@ static thread_local uint64_t* g_prof = nullptr;   // profile builds (-DSWC_PROFI
 void set_profile_buffer(void* p) { g_prof = static_cast<uint64_t*>(p); }
 __global__ __launch_bounds__(64, SWC_SYNC_WAVES_PER_SIMD) void swc_inflate_sync_kernel(Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof) {
     __shared__ __attribute__((aligned(16))) inflate::SyncLds sync_lds;
-    uint32_t g = blockIdx.x;
+    uint32_t g = xcd_job(blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];
     inflate::inflate_sync_job(job, &sync_lds, wm.area(g), wm.bytes(g), (int)threadIdx.x, kWave, prof ? prof + 32 * (size_t)g : nullptr);
@@ -69,7 +140,7 @@ constexpr int kInflateResolveThreads = 512, kInflateRingLog2 = 16;
 constexpr uint32_t kInflateKeep = 32768;
 __global__ __launch_bounds__(kInflateResolveThreads) void swc_lz_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof) {
     __shared__ __attribute__((aligned(16))) lzr::Lds<kInflateResolveThreads, kInflateRingLog2> lzr_lds;  // static: > 64 KiB needs no opt-in this way
-    uint32_t g = blockIdx.x;
+    uint32_t g = xcd_job(blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];
     lzr::resolve_job<kInflateResolveThreads, kInflateRingLog2, kInflateKeep>(job, wm.area(g), wm.bytes(g), &lzr_lds, prof ? prof + 32 * (size_t)g + 16 : nullptr);
@@ -135,8 +206,8 @@ __global__ __launch_bounds__(64) void swc_lz4_lane_kernel(Job* __restrict__ jobs
     jobs[g].status = job.status;
 }
 
-__global__ __launch_bounds__(64) void swc_lz4_parse_kernel(Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof) {
-    uint32_t g = blockIdx.x;
+__global__ __launch_bounds__(64) void swc_lz4_parse_kernel(Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof, const uint32_t* __restrict__ order) {
+    uint32_t g = job_of(order, blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];
     if (job.dict != nullptr) return;
@@ -149,9 +220,9 @@ __global__ __launch_bounds__(64) void swc_lz4_parse_kernel(Job* __restrict__ job
     }
 }
 
-__global__ __launch_bounds__(lz4w::kResolveThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void swc_lz4_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof) {
+__global__ __launch_bounds__(lz4w::kResolveThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void swc_lz4_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof, const uint32_t* __restrict__ order) {
     __shared__ __attribute__((aligned(16))) lzr::Lds<lz4w::kResolveThreads, lz4w::kRingLog2> lds;
-    uint32_t g = blockIdx.x;
+    uint32_t g = job_of(order, blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];
     if (job.dict != nullptr) return;
@@ -171,13 +242,14 @@ hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_
     }
     // The parse is latency bound per block (a serial chase), so all blocks are parsed in ONE launch: the more waves
     // in flight, the better the latency hides (8,192 blocks = 8 waves per SIMD).
+    const uint32_t* order = job_order(jobs, n, stream);
     g_pt.begin(stream);
     hipLaunchKernelGGL(swc_lz4_lane_kernel, grid, block, 0, stream, jobs, (uint32_t)n, 1);
     g_pt.mark(stream);
     const WsMap wm{(uint8_t*)ws, stride, ws_off};
-    hipLaunchKernelGGL(swc_lz4_parse_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof);
+    hipLaunchKernelGGL(swc_lz4_parse_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
-    hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(lz4w::kResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof);
+    hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(lz4w::kResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
     return hipGetLastError();
 }
@@ -198,7 +270,7 @@ constexpr size_t kLzmaSpillBytes = (size_t)(0x300u << 12) * 2;
 template <bool LZMA2, int LDSBITS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_LZMA_WAVES))) void swc_lzma_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* spill, uint64_t* prof) {
     extern __shared__ __attribute__((aligned(16))) uint16_t lzma_lds[];
-    uint32_t g = blockIdx.x;
+    uint32_t g = xcd_job(blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];
     SWC_AS_GLOBAL uint16_t* sp = spill ? (SWC_AS_GLOBAL uint16_t*)(spill + (size_t)g * kLzmaSpillBytes) : nullptr;
@@ -245,7 +317,7 @@ constexpr size_t kBzLdsBytes = bzip2::kStage1LdsBytes > sizeof(bzip2::Stage3Lds)
 static_assert(kBzLdsBytes >= 256 * sizeof(uint32_t), "stage 2 counters");
 __global__ __launch_bounds__(64) void swc_bzip2_block_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t lcap) {
     __shared__ __attribute__((aligned(16))) uint8_t bz_lds[kBzLdsBytes];
-    uint32_t g = blockIdx.x;
+    uint32_t g = xcd_job(blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];
     const bzip2::Workspace w = bzip2::carve(ws, g, lcap);
@@ -279,7 +351,7 @@ __global__ __launch_bounds__(64) void swc_bzip2_expand_kernel(Job* __restrict__ 
 // stage 3c: one block per workgroup (block CRC, BZip2.swift:81)
 __global__ __launch_bounds__(256) void swc_bzip2_crc_kernel(Job* __restrict__ jobs, uint32_t n) {
     __shared__ crc::Lds<256, uint32_t> lds;
-    uint32_t g = blockIdx.x;
+    uint32_t g = xcd_job(blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];
     if (job.status != SWC_OK) return;   // decode errors and SWC_E_CAPACITY stand
@@ -395,7 +467,7 @@ hipError_t launch_crc32(const Job* jobs, size_t n, uint32_t* crcs, hipStream_t s
 template <typename W, bool MSB>
 __global__ __launch_bounds__(256) void swc_crc_kernel(const Job* __restrict__ jobs, uint32_t n, uint64_t* __restrict__ sums) {
     __shared__ crc::Lds<256, W> lds;
-    uint32_t g = blockIdx.x;
+    uint32_t g = xcd_job(blockIdx.x, n);
     if (g >= n) return;
     const uint64_t len = jobs[g].out_len < jobs[g].out_cap ? jobs[g].out_len : jobs[g].out_cap;
     W c = crc::crc_group<256, W, MSB>((gcptr)jobs[g].out, len, &lds, (int)threadIdx.x);
@@ -404,7 +476,7 @@ __global__ __launch_bounds__(256) void swc_crc_kernel(const Job* __restrict__ jo
 
 __global__ __launch_bounds__(256) void swc_adler32_kernel(const Job* __restrict__ jobs, uint32_t n, uint64_t* __restrict__ sums) {
     __shared__ sums::AdlerLds<256> lds;
-    uint32_t g = blockIdx.x;
+    uint32_t g = xcd_job(blockIdx.x, n);
     if (g >= n) return;
     const uint64_t len = jobs[g].out_len < jobs[g].out_cap ? jobs[g].out_len : jobs[g].out_cap;
     uint32_t c = sums::adler32_group<256>((gcptr)jobs[g].out, len, &lds, (int)threadIdx.x);
@@ -433,7 +505,7 @@ __global__ __launch_bounds__(64) void swc_xxh32_kernel(const Job* __restrict__ j
 // ---- Delta filter, one stream per 256-thread workgroup ------------------------------------------
 __global__ __launch_bounds__(256) void swc_delta_kernel(Job* __restrict__ jobs, uint32_t n) {
     __shared__ delta::Lds<256> lds;
-    uint32_t g = blockIdx.x;
+    uint32_t g = xcd_job(blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];
     const bool fits = job.in_len <= job.out_cap;

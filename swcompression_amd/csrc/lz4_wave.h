@@ -50,6 +50,10 @@ constexpr uint32_t kInWin = 1024;    // input window of the checked step in LDS
 #define SWC_LZ4_CHUNK 128
 #endif
 constexpr uint32_t kChunk = SWC_LZ4_CHUNK;            // input bytes per lane and round of the sub-chunk-parallel parse (a multiple of 16)
+#ifndef SWC_LZ4_WALK_BACK
+#define SWC_LZ4_WALK_BACK 64
+#endif
+constexpr uint32_t kWalkBack = SWC_LZ4_WALK_BACK;     // bytes in front of its sub-chunk at which a lane's walk begins
 constexpr uint32_t kStageBytes = 64u * kChunk + 64u;  // staged input of a round (+ what the last lane reads past its sub-chunk)
 // The staged input carries ONE pad dword behind every sub-chunk: the lanes of a wave work at similar offsets of their
 // sub-chunks, and with a power-of-two stride they would all hit the same LDS bank.
@@ -165,6 +169,7 @@ struct Parser {
     uint32_t* rbuf;      // kRecBuf records
     uint8_t* lbuf;       // kLitStage + 32 bytes (+ 64 for `wnd`)
     uint32_t rb_n, lb_n; // staged, not yet in HBM (nrec / nlit count them already)
+    gptr prov = nullptr; // the wave's scratch rows in the workspace (lzr::kProvBytes in front of the literal stream), or none
 
     // wave-uniform state
     uint64_t ip, pos, nlit, sequences;
@@ -327,18 +332,25 @@ struct Parser {
     // ---- sub-chunk-parallel parse ----------------------------------------------------------------------------------------
     // Where a sequence starts is known only when the one before it has been parsed, but a parse started at a WRONG byte
     // falls into step with the true sequence chain after a few sequences (it lands on a new byte after every sequence;
-    // about one byte in eleven is a true sequence start).  The wave stages the next 64 sub-chunks of kChunk bytes in
-    // LDS, lane 0 parses from the true position and every other lane from its sub-chunk boundary, all counting only;
-    // a lane whose start differs from where its left neighbour ended parses again from there, until the chain of
-    // (start == left neighbour's end) covers the round.  Exclusive prefix sums of the counts give every lane the place of
-    // its literals and records; one more parse emits them.  A lane stops IN FRONT OF a sequence it does not take: one
-    // that ends in the last kTailKeep bytes of the block (the end-of-block rules are the checked step's), one that needs
-    // bytes beyond the staged window (a long literal run), one with offset 0; the round then ends with that lane.
-    struct ChunkOut {
+    // about one byte in eleven is a true sequence start).  The wave stages the next 64 sub-chunks of kChunk bytes in LDS and
+    // runs the round the way inflate_sync.h runs a Deflate round:
+    //   walk         lane 0 starts at the true position, every other lane kWalkBack bytes IN FRONT of its sub-chunk; all parse
+    //                -- nothing but the lengths -- until they cross the end of their sub-chunk and note where they ended;
+    //   provisional  every lane parses ONCE more from where its left neighbour's walk ended: counts, and ONE record per
+    //   parse        sequence into the wave's row-major scratch (lz_resolve.h: row k = the k-th record of all 64 lanes);
+    //   chain check  lane k must end where lane k + 1 began; lanes for which it does not parse again;
+    //   copy         wave scans give every lane its offsets; the records move to the record list with 16-byte stores, and the
+    //                literals -- found again by walking the lane's OWN records, no token is read a third time -- from the stage
+    //                to the dense literal stream.
+    // A lane stops IN FRONT OF a sequence it does not take: one that ends in the last kTailKeep bytes of the block (the
+    // end-of-block rules are the checked step's), one that needs bytes beyond the staged window or more than one extension byte
+    // per length, more than 127 literals, offset 0; the round then ends with that lane.
+    struct ProvOut {
         uint32_t end;      // byte (relative to the round base) of the first sequence NOT taken
-        uint32_t nlit, nrec, nout, nseq;
+        uint32_t nlit, nrec, nout;
         uint32_t lms;      // output offset (inside the sub-chunk) of the last match start
         uint32_t flags;
+        int32_t need;      // the largest (offset - output bytes of the sub-chunk in front of the match)
     };
     SWC_D static uint32_t rd32(const uint8_t* stage, uint32_t a) {   // the four bytes at `a` (aligned LDS reads + a byte shift)
         const uint32_t* st32 = (const uint32_t*)stage;
@@ -349,56 +361,142 @@ struct Parser {
         return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8 * (a & 3u)));
 #endif
     }
-    // MODE 0: count.  MODE 1: emit literals and records (offsets are checked against the output position).
-    // The loop takes SHORT sequences only -- at most one extension byte for the literal length and one for the match
-    // length (under 270 literals, under 274 match bytes) -- as one straight line of selects: the wave is bound by the
-    // latency of this loop (two dependent LDS reads per sequence).  Anything else stops the lane in front of the
-    // sequence; the round ends there and the checked step (which copies long literal runs with the whole wave) takes it.
-    template <int MODE>
-    SWC_D static void parse_chunk(const uint8_t* stage, uint32_t stage_len, uint32_t start, uint32_t chunk_end, uint32_t tail_limit, gptr lit_dst,
-                                  SWC_AS_GLOBAL uint32_t* rec_dst, uint64_t out_pos0, ChunkOut& r) {
-        uint32_t ip = start, nlit = 0, nrec = 0, nout = 0, nseq = 0, lms = 0, flags = 0;
+    // One sequence at `ip`, SHORT form only (at most one extension byte per length): literal count, match length, offset,
+    // where the literals are and where the next sequence starts; `stop`: the fast path does not take it.
+    struct Seq {
+        uint32_t lit, mlen, offset, lit_at, next;
+        bool stop, tail;
+    };
+    SWC_D static Seq sequence_at(const uint8_t* stage, uint32_t ip, uint32_t safe, uint32_t tail_limit) {
+        Seq q;
+        const uint32_t tok32 = rd32(stage, ip);
+        const uint32_t token = tok32 & 0xFFu, b1 = (tok32 >> 8) & 0xFFu;
+        const uint32_t l0 = token >> 4, m0 = token & 15u;
+        const uint32_t lx = l0 == 15 ? 1u : 0u;
+        q.lit = l0 + (lx ? b1 : 0u);
+        q.lit_at = ip + 1u + lx;
+        const uint32_t p = q.lit_at + q.lit;                   // the offset field (<= ip + 272)
+        const uint32_t pr = p > safe ? safe : p;               // (read something harmless when the lane is about to stop)
+        const uint32_t off32 = rd32(stage, pr);
+        q.offset = off32 & 0xFFFFu;
+        const uint32_t b2 = (off32 >> 16) & 0xFFu;
+        const uint32_t mx = m0 == 15 ? 1u : 0u;
+        q.mlen = 4u + m0 + (mx ? b2 : 0u);
+        q.next = p + 2u + mx;
+        // long lengths, the staged window, the tail of the block: the lane stops in front of it
+        q.stop = ((lx & (uint32_t)(b1 == 255)) | (mx & (uint32_t)(b2 == 255)) | (uint32_t)(p > safe) | (uint32_t)(q.next > tail_limit) | (uint32_t)(q.lit > lzr::kLitRunMax)) != 0u;
+        q.tail = q.next > tail_limit && p <= safe;
+        return q;
+    }
+    // Where does a parse from `start` end?  Returns the first sequence start at or beyond `chunk_end` (or where the lane stopped).
+    SWC_D static uint32_t walk_chunk(const uint8_t* stage, uint32_t stage_len, uint32_t start, uint32_t chunk_end, uint32_t tail_limit) {
+        uint32_t ip = start;
         const uint32_t safe = stage_len >= 8 ? stage_len - 8u : 0u;   // a read of four bytes at or below this stays inside the staged window
         while (ip < chunk_end) {
-            if (ip > safe) { flags |= kLzStop; break; }
-            const uint32_t tok32 = rd32(stage, ip);
-            const uint32_t token = tok32 & 0xFFu, b1 = (tok32 >> 8) & 0xFFu;
-            const uint32_t l0 = token >> 4, m0 = token & 15u;
-            const uint32_t lx = l0 == 15 ? 1u : 0u;
-            const uint32_t lit = l0 + (lx ? b1 : 0u);
-            const uint32_t lit_at = ip + 1u + lx;
-            const uint32_t p = lit_at + lit;                       // the offset field (<= ip + 272)
-            const uint32_t pr = p > safe ? safe : p;               // (read something harmless when the lane is about to stop)
-            const uint32_t off32 = rd32(stage, pr);
-            const uint32_t offset = off32 & 0xFFFFu, b2 = (off32 >> 16) & 0xFFu;
-            const uint32_t mx = m0 == 15 ? 1u : 0u;
-            const uint32_t mlen = 4u + m0 + (mx ? b2 : 0u);
-            const uint32_t pn = p + 2u + mx;                       // the next sequence
-            // long lengths, the staged window, the tail of the block, an invalid offset: the lane stops in front of it
-            const bool stop = (lx & (uint32_t)(b1 == 255)) | (mx & (uint32_t)(b2 == 255)) | (uint32_t)(p > safe) | (uint32_t)(pn > tail_limit);
-            if (stop || offset == 0) {
-                flags |= stop ? (pn > tail_limit && p <= safe ? kLzStop | kLzTail : kLzStop) : kLzFail;   // offset 0: LZ4.swift:382
-                break;
-            }
-            const uint32_t big = lit > lzr::kLitRunMax ? 1u : 0u;
-            if (MODE == 1) {
-                if ((uint64_t)offset > out_pos0 + nout + lit) { flags |= kLzTrap; break; }   // :382 offset <= bytes produced
-                uint32_t i = 0;
-                for (; i + 4 <= lit; i += 4) store_u32(lit_dst + i, rd32(stage, lit_at + i));
-                for (; i < lit; i++) lit_dst[i] = stage[stage_byte(lit_at + i)];
-                lit_dst += lit;
-                if (big) *rec_dst++ = lzr::make_lits(lit);
-                *rec_dst++ = lzr::make_match(big ? 0u : lit, mlen, offset);
-            }
-            nrec += 1u + big;
-            nlit += lit;
-            lms = nout + lit;
-            nout += lit + mlen;
-            nseq++;
-            ip = pn;
+            if (ip > safe) break;
+            const Seq q = sequence_at(stage, ip, safe, tail_limit);
+            // Something the fast path does not take: on the TRUE chain the provisional parse will stop there and end the round,
+            // whatever this walk says; on a wrong chain (the usual case: garbage looks like long lengths one time in thirty) the
+            // walk must not die -- a lane whose walk ends in front of its sub-chunk sends its neighbour off on a wrong start -- so
+            // it steps one byte on and keeps looking for the true chain.
+            ip = (q.stop || q.offset == 0) ? ip + 1u : q.next;
         }
-        r.end = ip; r.nlit = nlit; r.nrec = nrec; r.nout = nout; r.nseq = nseq; r.lms = lms; r.flags = flags;
+        return ip;
     }
+    // The provisional parse: from `start` until a sequence would begin at or beyond `chunk_end`.  Per step either the next
+    // sequence is parsed -- its record goes to the row of the lane's next record, its counts are added -- or (a sequence with
+    // more than four literals) the step only carries literals on; either way up to four literal bytes of the current sequence
+    // are appended to the accumulator (oldest byte lowest), whose low dword is written to the row of the literal group being
+    // filled -- unconditionally, a group is final when its last writer has been.
+    SWC_D static void parse_chunk_prov(const uint8_t* stage, uint32_t stage_len, uint32_t start, uint32_t chunk_end, uint32_t tail_limit, gptr prov,
+                                       uint32_t lane, ProvOut& r) {
+        uint32_t ip = start, nlit = 0, nout = 0, lms = 0, flags = 0;
+        uint32_t roff = 4u * lane + kProvRow;                  // byte offset of my next record in the scratch (row 1 is the first)
+        uint32_t loff = (uint32_t)lzr::kProvRecBytes + 4u * lane + kProvRow;   // ... of the literal group being filled
+        uint32_t acc = 0, nacc = 0;                             // literal bytes of the group being filled
+        uint32_t rem = 0, src = 0;                              // literal bytes of the current sequence not yet taken, where they are
+        int32_t need = -0x40000000;
+        const uint32_t safe = stage_len >= 8 ? stage_len - 8u : 0u;
+        bool go = ip < chunk_end;
+        while (go) {
+            if (rem == 0u) {
+                bool bad = ip > safe;
+                if (bad) flags |= kLzStop;
+                else {
+                    const Seq q = sequence_at(stage, ip, safe, tail_limit);
+                    bad = q.stop || q.offset == 0;
+                    if (bad) flags |= q.stop ? (q.tail ? kLzStop | kLzTail : kLzStop) : kLzFail;   // offset 0: LZ4.swift:382
+                    else {
+                        const int32_t nd = (int32_t)q.offset - (int32_t)(nout + q.lit);          // :382 offset <= bytes produced, checked after the scan
+                        need = nd > need ? nd : need;
+                        store_u32(prov + roff, lzr::make_match(q.lit, q.mlen, q.offset));
+                        roff += kProvRow;
+                        nlit += q.lit;
+                        lms = nout + q.lit;
+                        nout += q.lit + q.mlen;
+                        ip = q.next;
+                        rem = q.lit;
+                        src = q.lit_at;
+                    }
+                }
+                if (bad) go = false;
+            }
+            const uint32_t take = rem < 4u ? rem : 4u;
+            const uint32_t w = rd32(stage, src) & (uint32_t)(((uint64_t)1 << (8u * take)) - 1u);
+            const uint64_t a64 = (uint64_t)acc | ((uint64_t)w << (8u * nacc));
+            store_u32(prov + loff, (uint32_t)a64);
+            const uint32_t tot = nacc + take, full = tot >> 2;
+            acc = full ? (uint32_t)(a64 >> 32) : (uint32_t)a64;
+            nacc = tot & 3u;
+            loff += full * kProvRow;
+            rem -= take;
+            src += take;
+            go = go && (rem > 0u || ip < chunk_end);
+        }
+        if (nacc != 0u) store_u32(prov + loff, acc);   // (the bytes a full group left over in the last step)
+        r.end = ip; r.nlit = nlit; r.nrec = (roff - 4u * lane) / kProvRow - 1u; r.nout = nout; r.lms = lms; r.flags = flags; r.need = need;
+    }
+    // A lane's piece of the round moves from its column of the scratch to its final place: `nrec` records to `rdst` (dword
+    // aligned), `nlit` literal bytes to `ldst` (any alignment).  The loads of a step read one row: coalesced.  The last,
+    // incomplete literal group holds its bytes at the bottom.
+    SWC_D static void copy_prov(gcptr plit, gcptr prec, uint32_t nlit, uint32_t nrec, gptr ldst, SWC_AS_GLOBAL uint32_t* rdst) {
+        const uint32_t ngrp = (nlit + 3u) >> 2;
+        for (uint32_t i = 0, g = 0; i < nrec || g < ngrp; i += 16, g += 8) {
+            uint32_t v[16], w[8];
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint32_t row = i + k + 1u < (uint32_t)lzr::kProvRecRows ? i + k + 1u : (uint32_t)lzr::kProvRecRows - 1u;
+                v[k] = load_u32(prec + (size_t)row * kProvRow);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k++) {
+                const uint32_t row = g + k + 1u < (uint32_t)lzr::kProvLitRows ? g + k + 1u : (uint32_t)lzr::kProvLitRows - 1u;
+                w[k] = load_u32(plit + (size_t)row * kProvRow);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k += 4) {
+                if (i + k + 4u <= nrec) store_u128_a4((gptr)(rdst + i + k), v[k], v[k + 1], v[k + 2], v[k + 3]);
+                else {
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; q++) if (i + k + q < nrec) rdst[i + k + q] = v[k + q];
+                }
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 8; k += 4) {
+                const uint32_t at = 4u * (g + k);
+                if (at + 16u <= nlit) store_u128_a4(ldst + at, w[k], w[k + 1], w[k + 2], w[k + 3]);
+                else {
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; q++) {
+                        const uint32_t aq = at + 4u * q;
+                        if (aq + 4u <= nlit) store_u32(ldst + aq, w[k + q]);
+                        else if (aq < nlit) { uint32_t x = w[k + q]; for (uint32_t z = aq; z < nlit; z++, x >>= 8) ldst[z] = (uint8_t)x; }
+                    }
+                }
+            }
+        }
+    }
+    static constexpr uint32_t kProvRow = 64u * 4u;
 
     // Rounds from `ip` on, as long as whole rounds can be committed.  Returns when the checked step has to take over
     // (the end of the block is near, a sequence that does not fit a round, anything invalid, the capacity).
@@ -408,7 +506,7 @@ struct Parser {
         flush();
         iw_hi = 0;        // the input window of the checked step shares the stage: nothing of it survives a round
         iw_pf = false;
-        PT<uint32_t, N> start, endp, pe, c_lit, c_rec, c_out, c_seq, c_lms, flg, x_lit, x_rec, x_out, x_seq;
+        PT<uint32_t, N> start, endp, pe, c_lit, c_rec, c_out, c_lms, c_need, flg, x_lit, x_rec, x_out;
         PT<bool, N> pb, have;
         for (;;) {
             if (n - ip < 128) return;                              // the last bytes of a block are the checked step's
@@ -418,53 +516,62 @@ struct Parser {
             const uint64_t avail = n - B;
             const uint32_t stage_len = avail < kStageBytes ? (uint32_t)avail : kStageBytes;
             const uint32_t tail_limit = avail - kTailKeep > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)(avail - kTailKeep);
-            SIMT_BEGIN(t, N)
-                for (uint32_t o = 16u * (uint32_t)t; o < kStageBytes; o += 16u * N) {
-                    uint64_t a = 0, b = 0;
-                    if (o + 16 <= stage_len) { a = load_u64(in + B + o); b = load_u64(in + B + o + 8); }
-                    else {
-                        for (uint32_t k = 0; k < 8; k++) if (o + k < stage_len) a |= (uint64_t)in[B + o + k] << (8 * k);
-                        for (uint32_t k = 0; k < 8; k++) if (o + 8 + k < stage_len) b |= (uint64_t)in[B + o + 8 + k] << (8 * k);
+            constexpr uint32_t kPartsAll = (kStageBytes + 16u * N - 1u) / (16u * N), kParts = (kPartsAll + 1u) / 2u;
+#pragma unroll 1
+            for (uint32_t half = 0; half < 2; half++) {   // the loads of HALF a round are issued before the first is used: two memory latencies per round, not nine
+                PT<uint64_t, N> sa[kParts], sb[kParts];
+                SIMT_BEGIN(t, N)
+#pragma unroll
+                    for (uint32_t k = 0; k < kParts; k++) {
+                        const uint32_t o = 16u * (uint32_t)t + (half * kParts + k) * 16u * N;
+                        uint64_t a = 0, b = 0;
+                        if (o < kStageBytes) {
+                            if (o + 16 <= stage_len) { a = load_u64(in + B + o); b = load_u64(in + B + o + 8); }
+                            else {
+                                for (uint32_t q = 0; q < 8; q++) if (o + q < stage_len) a |= (uint64_t)in[B + o + q] << (8 * q);
+                                for (uint32_t q = 0; q < 8; q++) if (o + 8 + q < stage_len) b |= (uint64_t)in[B + o + 8 + q] << (8 * q);
+                            }
+                        }
+                        sa[k][t] = a; sb[k][t] = b;
                     }
-                    uint32_t* st32 = (uint32_t*)stage;   // (a 16-byte piece never straddles a sub-chunk: the pad keeps its dwords together)
-                    const uint32_t d = stage_slot(o >> 2);
-                    st32[d] = (uint32_t)a; st32[d + 1] = (uint32_t)(a >> 32); st32[d + 2] = (uint32_t)b; st32[d + 3] = (uint32_t)(b >> 32);
-                }
-                start[t] = t == 0 ? start0 : (uint32_t)t * kChunk;
+                SIMT_END
+                SIMT_BEGIN(t, N)
+#pragma unroll
+                    for (uint32_t k = 0; k < kParts; k++) {
+                        const uint32_t o = 16u * (uint32_t)t + (half * kParts + k) * 16u * N;
+                        if (o < kStageBytes) {
+                            uint32_t* st32 = (uint32_t*)stage;   // (a 16-byte piece never straddles a sub-chunk: the pad keeps its dwords together)
+                            const uint32_t d = stage_slot(o >> 2);
+                            const uint64_t a = sa[k][t], b = sb[k][t];
+                            st32[d] = (uint32_t)a; st32[d + 1] = (uint32_t)(a >> 32); st32[d + 2] = (uint32_t)b; st32[d + 3] = (uint32_t)(b >> 32);
+                        }
+                    }
+                SIMT_END_WAVE
+            }
+            SIMT_BEGIN(t, N)
+                const uint32_t cs = (uint32_t)t * kChunk;
+                start[t] = t == 0 ? start0 : (cs > kWalkBack + start0 ? cs - kWalkBack : start0);   // (never in front of the true position)
                 have[t] = false;
-                endp[t] = kPosFail;
                 flg[t] = 0;
-            SIMT_END_WAVE
+            SIMT_END
             SWC_LP(0)
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
             pacc[5]++;
+            pacc[6]++;
 #endif
+            SWC_LZ4_STAT(0, 1);
+            SWC_LZ4_STAT(2, 1);
+            // the walk: where does a parse from my guess end?
+            SIMT_BEGIN(t, N)
+                const uint32_t ce = t == N - 1 ? stage_len : ((uint32_t)t + 1u) * kChunk;
+                endp[t] = walk_chunk(stage, stage_len, start[t], ce, tail_limit);
+            SIMT_END
+            SWC_LP(1)
             uint32_t nv = 0;
             int E = 64;
-            SWC_LZ4_STAT(0, 1);
             for (;;) {
-                SWC_LZ4_STAT(2, 1);
-#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-                pacc[6]++;
-#endif
                 simt::wave_shift_up<N>(pe, endp, start0);
-                // parse (again) where the start is not the left neighbour's end, or nothing has been counted yet
-                SIMT_BEGIN(t, N)
-                    const bool pe_ok = t != 0 && pe[t] != kPosFail;
-                    const bool todo = !have[t] || (pe_ok && start[t] != pe[t]);
-                    if (todo) {
-                        if (pe_ok) start[t] = pe[t];
-                        SWC_LZ4_STAT(1, 1);
-                        ChunkOut r;
-                        const uint32_t ce = t == N - 1 ? stage_len : ((uint32_t)t + 1u) * kChunk;
-                        // (a start within 8 bytes of the staged window's end stops there at once: parse_chunk's first test)
-                        parse_chunk<0>(stage, stage_len, start[t], ce, tail_limit, nullptr, nullptr, 0, r);
-                        endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; c_seq[t] = r.nseq; c_lms[t] = r.lms; flg[t] = r.flags;
-                        have[t] = true;
-                    }
-                SIMT_END
-                simt::wave_shift_up<N>(pe, endp, start0);
-                SIMT_BEGIN(t, N) pb[t] = t != 0 && start[t] != pe[t]; SIMT_END
+                SIMT_BEGIN(t, N) pb[t] = !(have[t] && (t == 0 || start[t] == pe[t])); SIMT_END
                 const uint64_t m_bad = simt::wave_ballot<N>(pb);
                 const int b = m_bad ? simt::ctz64(m_bad) : 64;           // lanes [0, b) are on the true chain
                 SIMT_BEGIN(t, N) pb[t] = flg[t] != 0; SIMT_END
@@ -472,45 +579,61 @@ struct Parser {
                 E = m_stop ? simt::ctz64(m_stop) : 64;                   // the lane that stopped in front of a sequence
                 nv = (uint32_t)(E < 64 ? E + 1 : b);
                 if (E < 64 || b == 64) break;
+                SWC_LZ4_STAT(2, 1);
+#if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
+                pacc[6]++;
+#endif
+                SIMT_BEGIN(t, N)
+                    const bool todo = t == 0 ? !have[t] : (start[t] != pe[t] || !have[t]);
+                    if (todo) {
+                        if (t != 0) start[t] = pe[t];
+                        SWC_LZ4_STAT(1, 1);
+                        ProvOut r;
+                        const uint32_t ce = t == N - 1 ? stage_len : ((uint32_t)t + 1u) * kChunk;
+                        parse_chunk_prov(stage, stage_len, start[t], ce, tail_limit, prov, (uint32_t)t, r);
+                        endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; c_lms[t] = r.lms; flg[t] = r.flags;
+                        c_need[t] = (uint32_t)r.need;
+                        have[t] = true;
+                    }
+                SIMT_END
             }
-            SWC_LP(1)
+            SWC_LP(3)
             SIMT_BEGIN(t, N)
                 const bool v = (uint32_t)t < nv;
-                x_lit[t] = v ? c_lit[t] : 0u; x_rec[t] = v ? c_rec[t] : 0u; x_out[t] = v ? c_out[t] : 0u; x_seq[t] = v ? c_seq[t] : 0u;
+                x_lit[t] = v ? c_lit[t] : 0u; x_rec[t] = v ? c_rec[t] : 0u; x_out[t] = v ? c_out[t] : 0u;
             SIMT_END
             simt::wave_scan_incl<N>(x_lit);
             simt::wave_scan_incl<N>(x_rec);
             simt::wave_scan_incl<N>(x_out);
-            simt::wave_scan_incl<N>(x_seq);
             const uint32_t tot_lit = simt::wave_read<N>(x_lit, N - 1), tot_rec = simt::wave_read<N>(x_rec, N - 1);
-            const uint32_t tot_out = simt::wave_read<N>(x_out, N - 1), tot_seq = simt::wave_read<N>(x_seq, N - 1);
+            const uint32_t tot_out = simt::wave_read<N>(x_out, N - 1);
             const uint32_t stop_flags = E < 64 ? simt::wave_read<N>(flg, E) : 0u;
             SWC_LP(2)
-            if (tot_seq == 0) return;                                         // not even one sequence: the checked step
+            if (tot_rec == 0) return;                                         // not even one sequence: the checked step
             if (pos + tot_out > cap || (uint64_t)nrec + tot_rec > max_rec) return;   // the capacity / the workspace: the checked step counts on
+            // :382 every offset must reach back no further than the bytes produced in front of its match
             SIMT_BEGIN(t, N)
-                if ((uint32_t)t < nv && c_seq[t] != 0) {
-                    ChunkOut r;
-                    const uint32_t ce = t == N - 1 ? stage_len : ((uint32_t)t + 1u) * kChunk;
-                    parse_chunk<1>(stage, stage_len, start[t], ce, tail_limit, lits + nlit + (x_lit[t] - c_lit[t]), recs + nrec + (x_rec[t] - c_rec[t]),
-                                   pos + (x_out[t] - c_out[t]), r);
-                    flg[t] = r.flags;
-                } else flg[t] = 0;
+                const uint64_t p0 = pos + (x_out[t] - c_out[t]);
+                const int32_t room = p0 > 0x40000000ull ? 0x40000000 : (int32_t)p0;
+                pb[t] = (uint32_t)t < nv && c_rec[t] != 0 && (int32_t)c_need[t] > room;
             SIMT_END
-            SWC_LP(3)
-            SIMT_BEGIN(t, N) pb[t] = (flg[t] & kLzTrap) != 0; SIMT_END
             if (simt::wave_ballot<N>(pb)) return;                             // an offset beyond the output: the checked step reports it
+            SIMT_BEGIN(t, N)
+                if ((uint32_t)t < nv && c_rec[t] != 0)
+                    copy_prov(prov + lzr::kProvRecBytes + 4u * (uint32_t)t, prov + 4u * (uint32_t)t, c_lit[t], c_rec[t], lits + nlit + (x_lit[t] - c_lit[t]), recs + nrec + (x_rec[t] - c_rec[t]));
+            SIMT_END
+            SWC_LP(7)
             // the last match start of the round: in the last lane that took a sequence
-            SIMT_BEGIN(t, N) pb[t] = (uint32_t)t < nv && c_seq[t] != 0; SIMT_END
+            SIMT_BEGIN(t, N) pb[t] = (uint32_t)t < nv && c_rec[t] != 0; SIMT_END
             const uint64_t m_seq = simt::wave_ballot<N>(pb);
             const int last = 63 - (int)clz64(m_seq);
-            SIMT_BEGIN(t, N) x_seq[t] = (x_out[t] - c_out[t]) + c_lms[t]; SIMT_END
-            last_match_start = (int64_t)(pos + simt::wave_read<N>(x_seq, last));
+            SIMT_BEGIN(t, N) x_lit[t] = (x_out[t] - c_out[t]) + c_lms[t]; SIMT_END
+            last_match_start = (int64_t)(pos + simt::wave_read<N>(x_lit, last));
             pos += tot_out;
             nlit += tot_lit;
             nrec += tot_rec;
-            sequences += tot_seq;
-            SWC_LZ4_STAT(3, tot_seq);
+            sequences += tot_rec;
+            SWC_LZ4_STAT(3, tot_rec);
             ip = B + simt::wave_read<N>(endp, (int)nv - 1);
             if (stop_flags & (kLzFail | kLzTail)) return;                     // anything invalid / the end of the block: the checked step
         }
@@ -518,7 +641,7 @@ struct Parser {
 
     SWC_D int run(uint8_t* stage) {
         // the rounds append records unchecked: the workspace must hold what a block of this capacity can need
-        const bool fast_ok = stage != nullptr && (size_t)max_rec >= lzr::max_records(cap);
+        const bool fast_ok = stage != nullptr && prov != nullptr && (size_t)max_rec >= lzr::max_records(cap);
         int result = SWC_OK;
         for (;;) {
             if (fast_ok && pos < cap) sync_rounds(stage);
@@ -551,7 +674,12 @@ SWC_D void lz4_parse_job(Job& job, uint8_t* ws, size_t ws_bytes, int lane, uint8
     ps.nrec = 0;
     const size_t lo = ws ? lzr::lit_offset(ws_bytes, job.out_cap) : 0;
     ps.recs = (SWC_AS_GLOBAL uint32_t*)(ws + sizeof(lzr::StreamHeader));
-    ps.max_rec = lo > sizeof(lzr::StreamHeader) ? (uint32_t)((lo - sizeof(lzr::StreamHeader)) / 4) : 0u;
+    size_t rec_end = lo;   // the wave's scratch rows sit between the record list and the literal stream, if the area has room for them
+    if (lo >= sizeof(lzr::StreamHeader) + 256 + lzr::kProvBytes) {
+        rec_end = (lo - lzr::kProvBytes) & ~(size_t)15;
+        ps.prov = (gptr)(ws + rec_end);
+    }
+    ps.max_rec = rec_end > sizeof(lzr::StreamHeader) ? (uint32_t)((rec_end - sizeof(lzr::StreamHeader)) / 4) : 0u;
     ps.lits = (gptr)(ws + lo);
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     ps.tlast = __builtin_readcyclecounter();

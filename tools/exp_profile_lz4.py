@@ -13,10 +13,10 @@ lib.swc_set_profile_buffer(prof.data_ptr())
 b.launch(sync=True)
 b.launch(sync=True)
 p = prof.cpu().numpy().reshape(b.n, 32).astype(np.float64)
-names = ["staging", "count passes", "scans", "emit", "checked steps + rest"]
-t = p[:, :5].sum(axis=1).mean()
+names = ["staging", "walk", "scans", "provisional parse", "checked steps + rest"]
+t = p[:, :5].sum(axis=1).mean() + p[:, 7].mean()
 print("lz4 parse: %.0f kcycles per block; rounds %.0f passes %.0f; %%: " % (t / 1e3, p[:, 5].mean(), p[:, 6].mean())
-      + ", ".join("%s %.1f" % (n, 100 * p[:, k].mean() / t) for k, n in enumerate(names)))
+      + ", ".join("%s %.1f" % (n, 100 * p[:, k].mean() / t) for k, n in enumerate(names)) + ", copy %.1f" % (100 * p[:, 7].mean() / t))
 n2 = ["R0+scan", "R1", "R2 expand", "R3 chase+out"]
 t2 = p[:, 16:20].sum(axis=1).mean()
 print("lz4 resolve: %.0f kcycles per block; batches %.0f span/batch %.0f records/batch %.0f; %%: "
