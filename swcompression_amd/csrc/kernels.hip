@@ -206,7 +206,10 @@ __global__ __launch_bounds__(64) void swc_lz4_lane_kernel(Job* __restrict__ jobs
     jobs[g].status = job.status;
 }
 
-__global__ __launch_bounds__(64) void swc_lz4_parse_kernel(Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof, const uint32_t* __restrict__ order) {
+#ifndef SWC_LZ4_PARSE_WAVES
+#define SWC_LZ4_PARSE_WAVES 4
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_LZ4_PARSE_WAVES))) void swc_lz4_parse_kernel(Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof, const uint32_t* __restrict__ order) {
     uint32_t g = job_of(order, blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];

@@ -264,12 +264,14 @@ struct Resolver {
         PT<u128, T> lit_pf;                 // a 16-byte granule of the literal stream on its way into the window
         PT<uint32_t, T> lit_pf_at;          // its stream offset (0xFFFFFFFF: none)
         PT<uint32_t, T> x, y, xb, yb;       // scan values (of the thread's pair of records; xb / yb: the second record alone)
+        PT<uint32_t, T> far_pf;             // FAR: what the prefetch loads of R1 returned (kept so that they are real loads; see the end of run)
         // prologue: first records, first window of literals
         SIMT_BEGIN(t, T)
             r_nx0[t] = 2u * (uint32_t)t < nrec ? recs[2u * (uint32_t)t] : 0u;
             r_nx1[t] = 2u * (uint32_t)t + 1u < nrec ? recs[2u * (uint32_t)t + 1u] : 0u;
             const uint64_t o = 16ull * (uint32_t)t;
             lit_pf_at[t] = 0xFFFFFFFFu;
+            far_pf[t] = 0;
             if (o + 16 <= kLitWin && o + 16 <= lit_cap) *(u128*)(l->litbuf + o) = load_16(lits + o);
             l->slotw[t] = 0;
             if (t == 0) l->slotw[T] = 0;
@@ -383,7 +385,11 @@ struct Resolver {
             }
             // ---- R1: batch geometry, two records per thread, in CELL indices (span-relative position + off)
             const uint32_t lbk = (uint32_t)lbase;
+            gcptr obase_r1 = (gcptr)((const SWC_AS_GLOBAL uint8_t*)out + ((int64_t)rpos - (int64_t)(vcur & 15u)));   // output position of cell 0 (R2 computes the same)
             SIMT_BEGIN(t, T)
+                // FAR: my stores of the batches before are done -- one barrier (B) in front of anybody's loads of old output
+                // (expand_cells; the prefetches below only touch bytes of four batches ago and more)
+                if (FAR) simt::vmem_fence();
 #pragma unroll
                 for (uint32_t k = 0; k < kRpt; k++) {
                     const uint32_t i = kRpt * (uint32_t)t + k;     // my record of the batch
@@ -401,6 +407,19 @@ struct Resolver {
                     uint32_t thr = dist + off > mstart_c ? dist + off : mstart_c;
                     if (len == 0 || thr > 0xFFFFu) thr = 0xFFFFu;
                     const uint32_t lkey = (lbk + (lit_end - lit) - (start + off)) & kLitMask;
+                    if (FAR) {
+                        // a match whose source lies in front of the ring's history is read from the output buffer by the cells of
+                        // R2: the lines are asked for HERE, a barrier and the first steps of R2 earlier, so that those reads find
+                        // them in the cache instead of ending the batch on a round trip to HBM
+                        const int32_t x0 = (int32_t)mstart_c - (int32_t)dist;
+                        uint32_t pv = 0;
+                        if (take && len != 0u && x0 < -(int32_t)KEEP) {
+                            pv = obase_r1[(int64_t)x0];                       // (one byte: the line is what is wanted)
+                            const int32_t x1 = x0 + (int32_t)len - 1;
+                            if ((x1 >> 6) != (x0 >> 6) && x1 < -(int32_t)KEEP) pv ^= (uint32_t)obase_r1[(int64_t)x1] << 8;
+                        }
+                        far_pf[t] ^= pv;
+                    }
                     l->rec8[i] = take ? (uint64_t)mstart_c | ((uint64_t)thr << 16) | ((uint64_t)(dist & 0xFFFFu) << 32) | ((uint64_t)lkey << 48)
                                       : 0xFFFFull;
                     if (take) {
@@ -434,7 +453,6 @@ struct Resolver {
             gptr obase = (gptr)((SWC_AS_GLOBAL uint8_t*)out + base64);
             // ---- R2: prefetch for the next batch, then the cells
             SIMT_BEGIN(t, T)
-                if (FAR) simt::vmem_fence();   // my stores of the batches before are done (see expand_cells); nothing else is in flight here
                 {
                     const uint32_t nx = base + ntake + kRpt * (uint32_t)t;
                     r_nx0[t] = nx < nrec ? recs[nx] : 0u;
@@ -523,6 +541,9 @@ struct Resolver {
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
         if (prof && threadIdx.x == 0) for (int k = 0; k < 8; k++) prof[k] = pacc[k];
 #endif
+        if (FAR) {   // (the prefetched words have a use, so the loads stay)
+            SIMT_BEGIN(t, T) if (far_pf[t] == 0x9E3779B9u) l->wave_sum[0] = far_pf[t]; SIMT_END
+        }
     }
 };
 
