@@ -41,8 +41,11 @@ typedef enum swc_codec {
     SWC_CODEC_LZMA2 = 3,   /* raw LZMA2 chunk stream   -- LZMA2Decoder.decode()    LZMA2Decoder.swift:34-99 */
     SWC_CODEC_LZMA = 4,    /* raw LZMA1 stream         -- LZMADecoder.decode()     LZMADecoder.swift:107-284*/
     SWC_CODEC_BZIP2_BLOCK = 5, /* one bzip2 block body -- BZip2.decode(_:_:)       BZip2.swift:97-270       */
-    SWC_CODEC_DELTA = 6    /* XZ / 7-Zip Delta filter  -- DeltaFilter.decode(_:_:) DeltaFilter.swift:11-33; aux = distance as the
+    SWC_CODEC_DELTA = 6,   /* XZ / 7-Zip Delta filter  -- DeltaFilter.decode(_:_:) DeltaFilter.swift:11-33; aux = distance as the
                               reference passes it (XZBlock.swift:57: property + 1), out may equal in            */
+    SWC_CODEC_LZ4_COMPRESS = 7 /* ENCODE, one LZ4 block -- LZ4.compress(block:_:) LZ4+Compress.swift:157-281: in = prefix ++ block,
+                              dict_len = length of the prefix (dictionary / previous block), out_cap >= n + n / 255 + 16;
+                              A valid block for the same bytes, not the reference's bytes            */
 } swc_codec;
 
 typedef struct swc_job {
@@ -128,6 +131,14 @@ int swc_lzma2_decompress_data(const uint8_t* in, size_t in_len, uint8_t** out, s
  * dict_id < 0 = no id passed; *out valid on SWC_E_DATA_CHECKSUM_MISMATCH */
 int swc_lz4_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len, int64_t dict_id,
                        uint8_t** out, size_t* out_len, size_t* in_consumed);
+/* LZ4.compress(data:independentBlocks:blockChecksums:contentChecksum:contentSize:blockSize:dictionary:dictionaryID:)
+ * LZ4+Compress.swift:47-155 (LZ4.compress(data:) = independent 1, block checksums 0, content checksum 1, content size 0,
+ * 4 MiB blocks, no dictionary).  Frame layout and fields as the reference writes them; the blocks are compressed on the
+ * device, all of them in one launch when they are independent (SWC_CODEC_LZ4_COMPRESS).  dict NULL = none, dict_id < 0 =
+ * none.  block_size 1..4194304 (the reference's precondition), else SWC_E_INVALID_ARGUMENT. */
+int swc_lz4_compress(const uint8_t* data, size_t len, int independent_blocks, int block_checksums, int content_checksum,
+                     int content_size, size_t block_size, const uint8_t* dict, size_t dict_len, int64_t dict_id,
+                     uint8_t** out, size_t* out_len);
 /* LZ4.multiDecompress(data:dictionary:dictionaryID:) LZ4.swift:116-146 */
 int swc_lz4_multi_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len, int64_t dict_id,
                              uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_frames);

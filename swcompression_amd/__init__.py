@@ -235,6 +235,25 @@ class LZ4:
         return _call_simple("swc_lz4_decompress", data, d, dl, did, consumed=True)[0]
 
     @staticmethod
+    def compress(data, independent_blocks=True, block_checksums=False, content_checksum=True, content_size=False,
+                 block_size=4 * 1024 * 1024, dictionary=None, dictionary_id=None):
+        """LZ4.compress(data:independentBlocks:blockChecksums:contentChecksum:contentSize:blockSize:dictionary:dictionaryID:)
+        (LZ4+Compress.swift:47-155; the defaults are those of LZ4.compress(data:), :16-19).  The blocks are compressed on the
+        device; the frame decodes to `data` with the reference's decoder, the block bytes are not the reference encoder's."""
+        lib = _lib.load()
+        data = bytes(data)
+        d = None if dictionary is None else bytes(dictionary)
+        out = C.POINTER(C.c_uint8)()
+        n = C.c_size_t()
+        rc = lib.swc_lz4_compress(data, len(data), int(bool(independent_blocks)), int(bool(block_checksums)), int(bool(content_checksum)),
+                                  int(bool(content_size)), int(block_size), d, 0 if d is None else len(d),
+                                  -1 if dictionary_id is None else int(dictionary_id), C.byref(out), C.byref(n))
+        res = _take(out, n.value)
+        if rc:
+            _raise(rc)
+        return res
+
+    @staticmethod
     def multi_decompress(data, dictionary=None, dictionary_id=None):
         d = None if dictionary is None else bytes(dictionary)
         did = -1 if dictionary_id is None else int(dictionary_id)

@@ -290,6 +290,79 @@ int swc_lz4_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, si
     return SWC_E_DEVICE;
 }
 
+// LZ4.compress(data:independentBlocks:...) LZ4+Compress.swift:47-155: the frame as the reference writes it -- magic, FLG, BD,
+// content size, dictionary ID, header checksum (:55-95), then per block the size word, the block (stored when compression
+// does not shrink it, :119-127), its checksum, the end mark and the content checksum (:142-151).  The blocks are compressed
+// on the device: independent blocks all in ONE launch; dependent blocks one launch too -- what a block may reference
+// (the previous block's last 64 KiB, the dictionary in front of the first, :109-116) is uncompressed INPUT, known up front.
+int swc_lz4_compress(const uint8_t* data, size_t len, int independent_blocks, int block_checksums, int content_checksum,
+                     int content_size, size_t block_size, const uint8_t* dict, size_t dict_len, int64_t dict_id,
+                     uint8_t** out, size_t* out_len) try {
+    if (!out || !out_len || (len && !data) || (dict_len && !dict)) return SWC_E_INVALID_ARGUMENT;
+    if (block_size == 0 || block_size > ((size_t)4 << 20)) { give_empty(out, out_len); return SWC_E_INVALID_ARGUMENT; }   // :50 precondition
+    std::vector<uint8_t> res;
+    const uint8_t magic[4] = {0x04, 0x22, 0x4D, 0x18};
+    res.insert(res.end(), magic, magic + 4);
+    res.push_back((uint8_t)(0x40 | (independent_blocks ? 0x20 : 0) | (block_checksums ? 0x10 : 0) | (content_size ? 0x08 : 0) |
+                            (content_checksum ? 0x04 : 0) | (dict_id >= 0 ? 0x01 : 0)));                                        // :58-63
+    res.push_back(block_size <= (64u << 10) ? 0x40 : block_size <= (256u << 10) ? 0x50 : block_size <= (1u << 20) ? 0x60 : 0x70);   // :66-76
+    if (content_size) for (int i = 0; i < 8; i++) res.push_back((uint8_t)((uint64_t)len >> (8 * i)));                          // :78-83
+    if (dict_id >= 0) for (int i = 0; i < 4; i++) res.push_back((uint8_t)((uint32_t)dict_id >> (8 * i)));                      // :85-89
+    res.push_back((uint8_t)((swc_xxh32(res.data() + 4, res.size() - 4, 0) >> 8) & 0xFF));                                       // :92-93
+    // units: prefix ++ block in one buffer per block (the prefix: at most the last 64 KiB of the dictionary / previous block)
+    const size_t nblk = (len + block_size - 1) / block_size;
+    std::vector<HostUnit> units(nblk);
+    std::vector<std::vector<uint8_t>> joined(nblk);
+    const uint8_t* d0 = dict ? dict + (dict_len > 65536 ? dict_len - 65536 : 0) : nullptr;                                      // :98-99
+    const size_t d0n = dict ? std::min<size_t>(dict_len, 65536) : 0;
+    for (size_t b = 0; b < nblk; b++) {
+        const size_t at = b * block_size, n = std::min(block_size, len - at);
+        const uint8_t* pre = d0;
+        size_t pren = d0n;
+        if (!independent_blocks && b > 0) {   // :112-116 the previous block's data, its last 64 KiB
+            const size_t pn = std::min(block_size, (size_t)65536);
+            pre = data + at - pn; pren = pn;
+        }
+        HostUnit& u = units[b];
+        if (pren == 0) { u.in = data + at; u.in_len = n; }
+        else {
+            joined[b].resize(pren + n);
+            memcpy(joined[b].data(), pre, pren);
+            memcpy(joined[b].data() + pren, data + at, n);
+            u.in = joined[b].data(); u.in_len = pren + n;
+        }
+        u.extra = pren;
+        u.cap_hint = n + n / 255 + 16;
+        u.cap_exact = true;
+    }
+    if (nblk) {
+        const int st = run_units(SWC_CODEC_LZ4_COMPRESS, units);
+        if (st) { give_empty(out, out_len); return st; }
+        for (const HostUnit& u : units) if (u.status != SWC_OK) { give_empty(out, out_len); return SWC_E_DEVICE; }
+    }
+    auto put32 = [&](uint32_t v) { for (int i = 0; i < 4; i++) res.push_back((uint8_t)(v >> (8 * i))); };
+    for (size_t b = 0; b < nblk; b++) {
+        const size_t at = b * block_size, n = std::min(block_size, len - at);
+        const std::vector<uint8_t>& c = units[b].out;
+        if (c.size() > n) {   // :119 not compressible: stored
+            put32(0x80000000u | (uint32_t)n);
+            res.insert(res.end(), data + at, data + at + n);
+            if (block_checksums) put32(swc_xxh32(data + at, n, 0));
+        } else {
+            put32((uint32_t)c.size());
+            res.insert(res.end(), c.begin(), c.end());
+            if (block_checksums) put32(swc_xxh32(c.data(), c.size(), 0));
+        }
+    }
+    put32(0);                                                   // :143 EndMark
+    if (content_checksum) put32(swc_xxh32(data, len, 0));        // :146-151
+    give(res, out, out_len);
+    return SWC_OK;
+} catch (...) {   // std::bad_alloc: never through the C boundary
+    if (out && out_len) give_empty(out, out_len);
+    return SWC_E_DEVICE;
+}
+
 // All frames of a multi-frame buffer in one launch: block sizes are in the block headers, so the frames (standard frames
 // with independent blocks, skippable frames) can be walked without decoding anything.  Used only if every frame then passes
 // its own checks; anything else -- dependent blocks, legacy frames, a dictionary, any error -- goes to the sequential loop

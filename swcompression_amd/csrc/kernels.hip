@@ -22,6 +22,7 @@
 #include "lz_resolve.h"
 #include "lz4_lane.h"
 #include "lz4_wave.h"
+#include "lz4_comp.h"
 #include "lzma_wave.h"
 #include "bzip2_block.h"
 #include "crc32_group.h"
@@ -253,6 +254,28 @@ hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_
     hipLaunchKernelGGL(swc_lz4_parse_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
     hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(lz4w::kResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
+    g_pt.mark(stream);
+    return hipGetLastError();
+}
+
+// ---- LZ4 block compression (lz4_comp.h), one block per wavefront, the hash table in LDS -------------------------------------
+__global__ __launch_bounds__(64) void swc_lz4_compress_kernel(Job* __restrict__ jobs, uint32_t n, const uint32_t* __restrict__ order) {
+    __shared__ uint32_t table[lz4c::kHashSize];
+    uint32_t g = job_of(order, blockIdx.x, n);
+    if (g >= n) return;
+    Job job = jobs[g];
+    lz4c::lz4_compress_job<kWave>(job, table);
+    if (threadIdx.x == 0) {
+        jobs[g].out_len = job.out_len;
+        jobs[g].in_consumed = job.in_consumed;
+        jobs[g].status = job.status;
+    }
+}
+hipError_t launch_lz4_compress(Job* jobs, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint32_t* order = job_order(jobs, n, stream);
+    g_pt.begin(stream);
+    hipLaunchKernelGGL(swc_lz4_compress_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, jobs, (uint32_t)n, order);
     g_pt.mark(stream);
     return hipGetLastError();
 }

@@ -141,3 +141,11 @@ def delta(data, distance, in_place=False):
     out = C.create_string_buffer(max(len(data), 1))
     lib.emu_delta(data, C.cast(out, C.c_void_p), len(data), distance)
     return out.raw[:len(data)]
+
+
+def lz4_compress(blocks, prefixes=None, caps=None):
+    """LZ4 block compression (lz4_comp.h): returns list of (status, compressed bytes, in_consumed, out_len)."""
+    prefixes = prefixes or [b""] * len(blocks)
+    ins = [bytes(p) + bytes(b) for p, b in zip(prefixes, blocks)]
+    caps = caps or [len(b) + len(b) // 255 + 16 for b in blocks]
+    return run_batch("emu_lz4_compress", ins, caps, extra=[len(p) for p in prefixes])

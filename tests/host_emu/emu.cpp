@@ -9,6 +9,7 @@
 #include "../../swcompression_amd/csrc/inflate_sync.h"
 #include "../../swcompression_amd/csrc/lz4_lane.h"
 #include "../../swcompression_amd/csrc/lz4_wave.h"
+#include "../../swcompression_amd/csrc/lz4_comp.h"
 #include "../../swcompression_amd/csrc/lzma_wave.h"
 #include "../../swcompression_amd/csrc/bzip2_block.h"
 #include "../../swcompression_amd/csrc/crc32_group.h"
@@ -51,6 +52,15 @@ extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {
         swc::lz4w::lz4_parse_job<1>(jobs[g], ws.data(), wsb, 0, stage);
         std::memset(&rl, 0xEE, sizeof rl);
         swc::lzr::resolve_job<swc::lz4w::kResolveThreads, swc::lz4w::kRingLog2, swc::lz4w::kKeep, true>(jobs[g], ws.data(), wsb, &rl);
+    }
+}
+
+// LZ4 block compression (lz4_comp.h): job.in = prefix ++ block, job.dict_len = length of the prefix
+extern "C" void emu_lz4_compress(swc::Job* jobs, size_t n) {
+    static uint32_t table[swc::lz4c::kHashSize];
+    for (size_t g = 0; g < n; g++) {
+        std::memset(table, 0xEE, sizeof table);
+        swc::lz4c::lz4_compress_job<64>(jobs[g], table);
     }
 }
 
