@@ -46,6 +46,10 @@ WORKLOADS = {
     "lz4_4m": dict(codec="lz4_block", kind="lz4_block", parts=[("text", 192), ("mix", 64)], n_units=8192, unit=4 << 20,
                    desc="8192 x 4 MiB independent LZ4 blocks (BASELINE configs[2], resident micro-config of SURVEY 8d; 256 distinct: 192 P-text + 64 P-mix)",
                    kernels=["swc_lz4_lane_kernel", "swc_lz4_parse_kernel", "swc_lz4_resolve_kernel"], steps=6),
+    "lz4_compress_4m": dict(codec="lz4_compress", kind="lz4_plain", parts=[("text", 192), ("mix", 64)], n_units=8192, unit=4 << 20,
+                            desc="ENCODE: 8192 x 4 MiB blocks compressed to LZ4 blocks (LZ4.compress(block:), SURVEY 8f row 4; 256 distinct: 192 P-text + 64 P-mix); "
+                                 "value = INPUT GiB/s; every block decoded again on the device and checked",
+                            kernels=["swc_lz4_compress_kernel"], steps=3),
     "bzip2_900k": dict(codec="bzip2_block", kind="bzip2", parts=[("text", 256)], n_units=10240, unit=899000,
                        desc="10240 x 900 kB bzip2 blocks (BASELINE configs[3]; 256 distinct P-text payloads as SURVEY 8d states)",
                        kernels=["swc_bzip2_block_kernel", "swc_bzip2_expand_kernel", "swc_bzip2_crc_kernel"], steps=5),
@@ -88,7 +92,11 @@ def make_batch(name, w, parts, seed, device, select):
     tiled unit list (unit i of the list is distinct unit i % n_distinct at its own device address)."""
     from swcompression_amd import corpus
     from swcompression_amd.batch import DeviceBatch
-    units, plains = corpus.build_units_mixed(w["kind"], parts, w["unit"], seed=seed)
+    if w["kind"] == "lz4_plain":   # the encode workload: the units ARE the plain payloads
+        _, plains = corpus.build_units_mixed("lz4_block", parts, w["unit"], seed=seed)
+        units = plains
+    else:
+        units, plains = corpus.build_units_mixed(w["kind"], parts, w["unit"], seed=seed)
     n_distinct = len(units)
     trailers = None
     kw = {}
@@ -99,6 +107,9 @@ def make_batch(name, w, parts, seed, device, select):
     elif name == "lz4_4m":
         raw = units
         caps = [w["unit"]] * n_distinct
+    elif name == "lz4_compress_4m":
+        raw = units
+        caps = [len(u) + len(u) // 255 + 16 for u in units]
     elif name == "bzip2_900k":
         raw = units  # whole one-block streams: "BZh9" (32 bits) + block magic (48) + block CRC (32) => body at bit 112
         caps = [w["unit"] + 64] * n_distinct
@@ -121,6 +132,8 @@ def cpu_baseline(name, raw, plains, seconds):
     elif name == "lz4_4m":
         O.lib.refcpu_set_max_output(1 << 23)
         fn = lambda u: O.lz4_block(u)[:2]
+    elif name == "lz4_compress_4m":
+        fn = lambda u: (lambda r: (r[0], u))(O.lz4_compress_block(u))   # (oracle/rc_lz4c.c; "output" counted = the input bytes)
     elif name == "bzip2_900k":
         fn = lambda u: O.bzip2(u)[:2]
     else:
@@ -179,6 +192,8 @@ def cpu_context(name, raw, plains, seconds):
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import _oracle as O
     from swcompression_amd import corpus
+    if name == "lz4_compress_4m":
+        return cpu_context_lz4_compress(raw, seconds)
     codec = {"deflate64k": 1, "deflate64k_mix": 1, "lz4_4m": 2, "bzip2_900k": 3, "lzma2_256k": 4}[name]
     aux = corpus.lzma2_dict_byte(1 << 20) if codec == 4 else 0
     fn = O.lib.refcpu_timed_pool
@@ -229,6 +244,56 @@ def cpu_context(name, raw, plains, seconds):
     ctx["system_codec_one_thread"] = {"value": nbytes / dt / 2**30, "unit": "GiB/s decompressed", "cores": 1, "decoder": what,
                                       "compressed_MBps": cbytes / dt / 1e6}
     return ctx
+
+
+def cpu_context_lz4_compress(raw, seconds):
+    """liblz4's own block compressor (LZ4_compress_default) on one thread: a tuned CPU encoder for orientation."""
+    from swcompression_amd import corpus
+    l4 = corpus._liblz4()
+    l4.LZ4_compress_default.restype = C.c_int
+    l4.LZ4_compress_default.argtypes = [C.c_char_p, C.c_char_p, C.c_int, C.c_int]
+    l4.LZ4_versionString.restype = C.c_char_p
+    dst = C.create_string_buffer((4 << 20) + (4 << 20) // 255 + 64)
+    t0 = time.perf_counter()
+    nbytes = i = 0
+    while time.perf_counter() - t0 < min(seconds, 3.0):
+        u = raw[i % len(raw)]
+        assert l4.LZ4_compress_default(u, dst, len(u), len(dst)) > 0
+        nbytes += len(u)
+        i += 1
+    dt = time.perf_counter() - t0
+    return {"system_codec_one_thread": {"value": nbytes / dt / 2**30, "unit": "GiB/s of input", "cores": 1,
+                                        "decoder": "liblz4 %s LZ4_compress_default" % l4.LZ4_versionString().decode()}}
+
+
+def verify_compressed_units(batch, plains, torch):
+    """Every compressed block of the launch is DECODED again on the device (the engine's own LZ4 decoder, reading the
+    compressor's output where it lies) and the XXH32 of what comes out is compared with that of the payload; sizes too."""
+    import numpy as np
+    from swcompression_amd.batch import DeviceBatch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    r = batch.results()
+    if not (r["status"] == 0).all():
+        raise SystemExit("compression failed: statuses %s" % sorted(set(r["status"].tolist())))
+    nd = len(plains)
+    dec = DeviceBatch("lz4_block", [b"\x00"] * nd, [len(p) for p in plains], tile=batch.n // nd, device=str(batch.device))
+    jobs = dec._jobs_host.copy()
+    jobs["in"] = r["out"]
+    jobs["in_len"] = r["out_len"]
+    dec._jobs_host = jobs
+    dec.d_jobs.copy_(torch.from_numpy(jobs.view(np.uint8)).to(dec.device))
+    dec.launch(sync=True)
+    d = dec.results()
+    want_len = np.array([len(p) for p in plains], dtype=np.uint64)
+    ok = bool((d["status"] == 0).all()) and bool((d["out_len"] == want_len[dec.unit_index]).all())
+    want = np.array([O.xxh32(p) for p in plains], dtype=np.uint64)
+    ok = ok and bool((dec.checksum("xxh32") == want[dec.unit_index]).all())
+    if not ok:
+        raise SystemExit("round trip of the compressed blocks failed")
+    ratio = float(want_len[dec.unit_index].sum()) / float(r["out_len"].sum())
+    return {"units_verified": int(batch.n), "method": "every compressed block decoded on the device by swc_lz4_parse/resolve; size and XXH32 == the payload's",
+            "compression_ratio": ratio}
 
 
 def config1_latency(lib, raw, plains, reps=20):
@@ -342,6 +407,8 @@ def run_workload(name, args, lib, torch, dist, world, rank, device, steps, warmu
     r = batch.results()
     if not (r["status"] == 0).all():
         raise SystemExit("decode failed: statuses %s" % sorted(set(r["status"].tolist())))
+    if name == "lz4_compress_4m":   # algorithmic bytes of the encode side: the payload read once, the compressed block written once
+        sum_c = int(r["out_len"].sum())
 
     # The verification after the timed region must see what the LAST timed step wrote, not what the warm-up left behind:
     # before that step the outputs, the result fields of the job records and the CRC buffer are wiped -- between the events
@@ -376,7 +443,7 @@ def run_workload(name, args, lib, torch, dist, world, rank, device, steps, warmu
 
     # every unit of the LAST timed step is checked before anything else launches (the phase-timing launches below rewrite
     # all outputs: checking after them would check them)
-    verify = verify_all_units(name, batch, raw, plains, trailers)
+    verify = verify_compressed_units(batch, plains, torch) if name == "lz4_compress_4m" else verify_all_units(name, batch, raw, plains, trailers)
 
     # outside the timed region: per-kernel durations of more launches (HIP events inside the library, on the launch stream)
     lib.swc_set_tuning(b"phase_timing", 1)
@@ -560,7 +627,7 @@ def main():
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and args.workload == "deflate64k" and not args.no_per_codec and args.scale == 1.0:
         per = {}
-        for name in ("deflate64k_mix", "lz4_4m", "bzip2_900k", "lzma2_256k"):
+        for name in ("deflate64k_mix", "lz4_4m", "bzip2_900k", "lzma2_256k", "lz4_compress_4m"):
             res, b, _, _ = run_workload(name, args, lib, torch, dist, world, rank, device, WORKLOADS[name]["steps"], 1, with_cpu)
             per[name] = res
             del b

@@ -6,7 +6,7 @@
 // length extensions / literals / offset / length extensions (:216-250), a final literals-only sequence (:253-277).
 //
 // The reference's table is an exact dictionary (Swift Dictionary keyed by the four bytes); a GPU wave keeps a HASH table of
-// 2,048 positions in LDS instead, looks 64 consecutive positions up at once, and takes the matches of such a window greedily
+// 8,192 positions in LDS instead, looks 64 consecutive positions up at once, and takes the matches of such a window greedily
 // from the left.  The output therefore is A valid LZ4 block for the same bytes, not the reference's bytes: the contract of
 // this path is decode(compress(x)) == x under the reference decoder's rules (LZ4.swift:332-413, end-of-block rules
 // included), checked against the oracle and liblz4 -- not byte parity of the compressed stream.
@@ -27,7 +27,12 @@
 namespace swc {
 namespace lz4c {
 
-constexpr uint32_t kHashBits = 11, kHashSize = 1u << kHashBits;   // 8 KB of LDS per wave: 19 waves per CU
+#ifndef SWC_LZ4C_HASH_BITS
+#define SWC_LZ4C_HASH_BITS 13
+#endif
+// 8,192 positions = 32 KB of LDS per wave.  The size of the table is the compression ratio: against the reference's exact
+// dictionary (oracle/rc_lz4c.c) on text 2,048 entries lose 22 %, 4,096 12 %, 8,192 5 %, 16,384 1 % (tests/test_lz4_compress.py).
+constexpr uint32_t kHashBits = SWC_LZ4C_HASH_BITS, kHashSize = 1u << kHashBits;
 constexpr uint32_t kLdsBytes = kHashSize * 4;
 
 SWC_HD uint32_t hash4(uint32_t w) { return (w * 2654435761u) >> (32 - kHashBits); }

@@ -170,6 +170,18 @@ def lz4_block(data, dictionary=None):
     return st, _take(out, n.value)
 
 
+def lz4_compress_block(block, prefix=b""):
+    """LZ4.compress(block:_:) (LZ4+Compress.swift:157-281), restated: (status, compressed bytes)."""
+    buf = bytes(prefix) + bytes(block)
+    cap = len(block) + len(block) // 255 + 16
+    out = C.create_string_buffer(max(cap, 1))
+    n = C.c_size_t()
+    lib.refcpu_lz4_compress_block.restype = C.c_int
+    lib.refcpu_lz4_compress_block.argtypes = [C.c_char_p, C.c_size_t, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    st = lib.refcpu_lz4_compress_block(buf, len(buf), len(prefix), out, cap, C.byref(n))
+    return st, out.raw[:min(n.value, cap)]
+
+
 def crc32(data, prev=0):
     return lib.refcpu_crc32(bytes(data), len(data), prev)
 

@@ -76,6 +76,23 @@ def test_prefix_blocks_and_capacity():
     O.lib.refcpu_set_max_output(1 << 30)
 
 
+def test_oracle_restatement_of_the_reference_compressor():
+    """oracle/rc_lz4c.c restates LZ4.compress(block:_:): its blocks must decode under the reference decoder's rules and liblz4
+    (pinning of the restatement), and the engine's hash-table compressor must stay within a few per cent of its ratio."""
+    O.lib.refcpu_set_max_output(1 << 22)
+    for p in [x for x in _payloads() if 0 < len(x) <= 70001]:
+        st, z = O.lz4_compress_block(p)
+        assert st == 0 and O.lz4_block(z)[:2] == (0, p) and _liblz4_decode(z, len(p)) == p
+    pre, blk = corpus.p_text(70000, 5), corpus.p_text(200000, 6)
+    st, z = O.lz4_compress_block(blk, pre[-65536:])
+    assert st == 0 and O.lz4_block(z, pre[-65536:])[:2] == (0, blk)
+    for kind in ("text", "mix"):
+        p = corpus.PAYLOADS[kind](300000, 12)
+        ref, eng = O.lz4_compress_block(p)[1], E.lz4_compress([p])[0][1]
+        assert len(eng) <= len(ref) * 1.15, (kind, len(eng), len(ref))
+    O.lib.refcpu_set_max_output(1 << 30)
+
+
 @pytest.mark.parametrize("order", [1, 2])
 def test_lane_order_does_not_matter(order):
     p = corpus.p_mix(150000, 4)
