@@ -92,7 +92,7 @@ struct Lds {
     alignas(16) uint8_t ring[kRing];                       // byte at virtual position v lives at ring[v % kRing]
     alignas(16) uint8_t litbuf[kLitWin];                   // literal byte at stream offset o lives at litbuf[o % kLitWin]
     alignas(8) uint64_t rec8[kRpt * T + 18];                      // per record, in CELL indices (span-relative + off): mstart | thr << 16 | distance << 32 | litkey << 48 (see R1)
-    uint32_t slotw[T + 1];                                 // per 16-cell slot: record that covers its first in-span cell | record-start flags of its cells << 16
+    uint32_t slotw[T + T / 4 + 2];                         // per 16-cell slot: record that covers its first in-span cell | record-start flags of its cells << 16 (a last batch may span 20 T cells)
     uint32_t wave_sum[2 * (T / 64) + 2];
     uint32_t ntake, span, litspan, overlap, first_rec, nbig, bigbytes;
 };
@@ -104,8 +104,13 @@ struct Resolver {
     static constexpr uint32_t kBigLit = 1024;             // a literal-only record of at least this many bytes opens a run that is copied, not expanded
     static constexpr uint32_t kLitCap = kLitWin - 16u;    // literal bytes one batch may take: what the window holds whatever its granule alignment
     static constexpr uint32_t kSpanMax = 16u * T - 16u;   // output bytes one batch may cover: at most T slots whatever the alignment
-    static constexpr uint32_t kCellOff = 16u * T + 16u;   // cells of the span live in the stale part of the ring, past the span
-    static_assert(48u * T + 16u <= kRing - KEEP, "ring too small for history + span + cells");
+    // The LAST batch of a stream may cover up to 20 T - 16 bytes (a fifth step of R2 / R3): a stream of 64 KiB is eight spans
+    // of 8,176 bytes and 128 bytes over, and a ninth batch for those costs the scan, the geometry and three barriers like any
+    // other (4 % of the kernel on BASELINE configs[1]).  Not with FAR (its expansion is unrolled to four steps; LZ4 blocks are
+    // megabytes long, their last batch does not matter).
+    static constexpr uint32_t kSpanBig = FAR ? kSpanMax : 20u * T - 16u;
+    static constexpr uint32_t kCellOff = kSpanBig + 32u;  // cells of the span live in the stale part of the ring, past the span
+    static_assert(3u * (kSpanBig + 16u) + 16u <= kRing - KEEP, "ring too small for history + span + cells");
     static_assert(kMaxLitOnly + kLitRunMax + kMaxLen <= kSpanMax, "a record must fit a span");
     static_assert(kMaxLitOnly + kLitRunMax <= kLitCap, "a record's literals must fit the literal window");
     static_assert(kRpt * T <= 0x10000u, "record indices are 16 bits");
@@ -274,7 +279,7 @@ struct Resolver {
             far_pf[t] = 0;
             if (o + 16 <= kLitWin && o + 16 <= lit_cap) *(u128*)(l->litbuf + o) = load_16(lits + o);
             l->slotw[t] = 0;
-            if (t == 0) l->slotw[T] = 0;
+            if (t < T / 4 + 2) l->slotw[T + t] = 0;
             if (t < 18) l->rec8[kRpt * T + t] = 0xFFFFull;
         SIMT_END
         lfill = kLitWin;
@@ -334,7 +339,7 @@ struct Resolver {
                     gcptr src = lits + lbase;
                     SIMT_BEGIN(t, T)
                         l->slotw[t] = 0;
-                        if (t == 0) l->slotw[T] = 0;
+                        if (t < T / 4 + 2) l->slotw[T + t] = 0;
                         // (the batch before may have left the bytes of its last, incomplete dword to its successor: they are in the
                         // ring only)
                         if ((uint32_t)t < (V & 3u) && (uint64_t)((V & 3u) - (uint32_t)t) <= rpos) {
@@ -385,6 +390,7 @@ struct Resolver {
             }
             // ---- R1: batch geometry, two records per thread, in CELL indices (span-relative position + off)
             const uint32_t lbk = (uint32_t)lbase;
+            const uint32_t span_max = limit - rpos <= (uint64_t)kSpanBig ? kSpanBig : kSpanMax;   // (everything that is left, if it fits one long batch)
             gcptr obase_r1 = (gcptr)((const SWC_AS_GLOBAL uint8_t*)out + ((int64_t)rpos - (int64_t)(vcur & 15u)));   // output position of cell 0 (R2 computes the same)
             SIMT_BEGIN(t, T)
                 // FAR: my stores of the batches before are done -- one barrier (B) in front of anybody's loads of old output
@@ -399,7 +405,7 @@ struct Resolver {
                     if (len == 0) lit += (r >> 16) << 7;
                     const uint32_t end = k ? x[t] : x[t] - xb[t], lit_end = k ? y[t] : y[t] - yb[t];
                     const uint32_t start = end - (lit + len), mstart = start + lit;
-                    const bool take = r != 0u && end <= kSpanMax && lit_end <= kLitCap;
+                    const bool take = r != 0u && end <= span_max && lit_end <= kLitCap;
                     // mstart: first match cell; thr: first cell that copies from INSIDE the span (a match cell at or past distance +
                     // off; 0xFFFF: none); litkey: (stream offset of the record's first literal) - (its first cell), modulo the window
                     const uint32_t dist = len ? (r >> 16) + 1u : 1u;
@@ -429,7 +435,7 @@ struct Resolver {
                         lds_or(&l->slotw[c0 >> 4], 0x10000u << (c0 & 15u));
                         if (len > dist) l->overlap = 1;      // (every writer stores the same value)
                         if (i == kRpt * T - 1) { l->ntake = kRpt * (uint32_t)T; l->span = end; l->litspan = lit_end; }
-                    } else if (i != 0 && start <= kSpanMax && lit_end - lit <= kLitCap && base + i - 1u < nrec) {
+                    } else if (i != 0 && start <= span_max && lit_end - lit <= kLitCap && base + i - 1u < nrec) {
                         // the first record that is not taken (or the first one past the last record) closes the batch: `start` is
                         // the end of the record before it, which exists and fits span and window, i.e. was taken
                         l->ntake = i; l->span = start; l->litspan = lit_end - lit;
@@ -469,6 +475,7 @@ struct Resolver {
             // ---- R3: one aligned DWORD per thread and step: chase what is unresolved, then the dword leaves for the ring and for HBM
             SIMT_BEGIN(t, T)
                 if ((uint32_t)t * 16u < ncell) l->slotw[t] = 0;   // (read in R2 only; the next batch sets it after its barrier A)
+                if ((uint32_t)t < T / 4 + 2 && ((uint32_t)T + (uint32_t)t) * 16u < ncell + 16u) l->slotw[T + t] = 0;
                 // (a last, incomplete dword -- ncell % 4 != 0 -- is the business of ONE thread after the loop)
                 for (uint32_t q = (uint32_t)t; q < nfull; q += (uint32_t)T) {
                     const uint32_t ca = (cbase + 8u * q) & kMask;
