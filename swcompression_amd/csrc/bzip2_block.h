@@ -11,8 +11,9 @@
 //            per lane, shifted with one cross-lane move), the staged output (a byte per lane) -- and reads them with
 //            ballots and v_readlane: no LDS round trip in the chain.  The tables of all 2-6 codes stay in LDS and are
 //            loaded into the registers at a table switch (every 50 symbols).
-//   stage 2  one block per WAVEFRONT  stable counting-sort scatter  P[base[c]++] = i << 8 | c  (c = L[i]),
-//            each lane owning a contiguous slice of i (per-lane counters in LDS).
+//   stage 2  one block per WAVEFRONT  stable counting-sort scatter  P[base[c]++] = i << 8 | c  (c = L[i]): L is read 64
+//            consecutive bytes at a time (one coalesced load), a lane finds its rank among the equal bytes of the group with
+//            eight ballots (one per bit of the byte), the running counts of the 256 byte values sit in LDS.
 //   stage 3a one block per WAVEFRONT  the n dependent gathers  v = P[end]; end = v >> 8; byte = v & 255  form ONE cycle
 //            through the block, which a single walker can only follow at one HBM round trip per byte (measured: 17 G
 //            gathers/s with a lane per block, 46-59 G/s -- the HBM row-activation limit -- with 64+ walkers per block,

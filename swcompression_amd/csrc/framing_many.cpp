@@ -170,23 +170,6 @@ int many_dispatch(int kind, const uint8_t* const* archives, const size_t* lens, 
 
 using namespace swc;
 
-extern "C" {
-
-int swc_unarchive_many(int kind, const uint8_t* const* archives, const size_t* lens, size_t n,
-                       uint8_t** outs, size_t* out_lens, int32_t* statuses) try {
-    if (kind < 1 || kind > 7 || (n && (!archives || !lens || !outs || !out_lens || !statuses))) return SWC_E_INVALID_ARGUMENT;
-    for (size_t i = 0; i < n; i++) if (lens[i] && !archives[i]) return SWC_E_INVALID_ARGUMENT;
-    if (!device_ready()) return SWC_E_DEVICE;
-    std::vector<Result> res(n);
-    const int st = many_dispatch(kind, archives, lens, n, res);
-    if (st) return st;
-    hand_over(res, outs, out_lens, statuses);
-    return SWC_OK;
-} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
-    for (size_t i = 0; i < n; i++) { outs[i] = host_result(0); out_lens[i] = 0; statuses[i] = SWC_E_DEVICE; }   // (results are handed over last: nothing of theirs is lost)
-    return SWC_E_DEVICE;
-}
-
 // swc_unarchive_many over several GPUs of one node: the archives are independent, so the list is cut into one contiguous
 // range per device, balanced by compressed + declared uncompressed bytes (sum(C + U); U where the framing
 // declares it -- the ISIZE of a gzip member, the content size of an LZ4 frame -- else C stands for both), and every range runs
@@ -259,6 +242,24 @@ uint64_t declared_size(int kind, const uint8_t* p, size_t len) {
     return 0;
 }
 }  // namespace
+
+
+extern "C" {
+
+int swc_unarchive_many(int kind, const uint8_t* const* archives, const size_t* lens, size_t n,
+                       uint8_t** outs, size_t* out_lens, int32_t* statuses) try {
+    if (kind < 1 || kind > 7 || (n && (!archives || !lens || !outs || !out_lens || !statuses))) return SWC_E_INVALID_ARGUMENT;
+    for (size_t i = 0; i < n; i++) if (lens[i] && !archives[i]) return SWC_E_INVALID_ARGUMENT;
+    if (!device_ready()) return SWC_E_DEVICE;
+    std::vector<Result> res(n);
+    const int st = many_dispatch(kind, archives, lens, n, res);
+    if (st) return st;
+    hand_over(res, outs, out_lens, statuses);
+    return SWC_OK;
+} catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
+    for (size_t i = 0; i < n; i++) { outs[i] = host_result(0); out_lens[i] = 0; statuses[i] = SWC_E_DEVICE; }   // (results are handed over last: nothing of theirs is lost)
+    return SWC_E_DEVICE;
+}
 
 int swc_unarchive_many_devices(int kind, const uint8_t* const* archives, const size_t* lens, size_t n,
                                const int* devices, size_t n_devices, uint8_t** outs, size_t* out_lens, int32_t* statuses) try {

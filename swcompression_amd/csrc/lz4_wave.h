@@ -10,19 +10,21 @@
 // been parsed), but a parser started at a WRONG byte falls into step with the true sequence chain after a few sequences
 // (every token it lands on sends it forward to another position; true starts are frequent).  So a wavefront parses the
 // block the way inflate_sync.h decodes a Deflate stream, in rounds of 64 sub-chunks of kChunk input bytes:
-//   walk     lane 0 starts at the true position, every other lane at its sub-chunk boundary; each parses "short"
-//            sequences (fewer than 270 literals, match shorter than 274: at most one extension byte each) until it
-//            crosses the end of its sub-chunk, and notes where it ended;
-//   count    a lane whose start differs from its left neighbour's end parses again from there, counting literals,
-//            records and output bytes; repeated until the chain of (start == left neighbour's end) is consistent up to
-//            the first lane that met something the fast path does not take;
-//   scan     exclusive prefix sums of the counts;
-//   emit     every lane of the consistent chain parses once more, copies its literals to the dense literal stream and
-//            writes its records at exact offsets, validating offsets against the bytes produced so far.
+//   walk         lane 0 starts at the true position, every other lane kWalkBack bytes in front of its sub-chunk; each parses
+//                "short" sequences (at most one extension byte per length), nothing but the lengths, until it crosses the end
+//                of its sub-chunk, and notes where it ended -- a walk that meets something it cannot take (on a wrong chain:
+//                garbage) steps one byte on and keeps looking, it never ends in front of its sub-chunk;
+//   provisional  every lane parses once more from where its left neighbour's walk ended: counts, one record per sequence
+//   parse        into the wave's row-major scratch, the literals appended four at a time to groups in the same scratch;
+//                repeated for the lanes whose start turns out wrong, until the chain of (start == left neighbour's end) holds
+//                up to the first lane that met something the fast path does not take;
+//   copy         wave scans give every lane its offsets; records and literal groups move to the record list and the dense
+//                literal stream with 16-byte stores.
 // The input of a round is staged in LDS with coalesced loads (one pad dword behind every sub-chunk keeps the lanes, which
-// work at similar offsets of their sub-chunks, on different banks).  Longer sequences, an invalid offset, the tail of the
-// block and the last 17 KiB of output capacity are handled by a fully checked one-sequence step (the reference's control
-// flow line by line, executed wave-uniformly, long literal runs copied by all lanes); it also carries the error taxonomy.
+// work at similar offsets of their sub-chunks, on different banks).  Longer sequences (more than 127 literals, more than one
+// extension byte), an invalid offset, the tail of the block and the last 17 KiB of output capacity are handled by a fully
+// checked one-sequence step (the reference's control flow line by line, executed wave-uniformly, long literal runs copied by
+// all lanes); it also carries the error taxonomy.
 //
 // The same source compiles for the host (tests/host_emu): the SIMT regions run their 64 lanes one after another.
 #ifndef SWC_LZ4_WAVE_H

@@ -4,12 +4,17 @@
 // decoder (LZMARangeDecoder.swift:20-80), bit-tree / length decoders (LZMABitTreeDecoder.swift:18-43,
 // LZMALenDecoder.swift:30-38) and the LZMA2 chunk framing (Sources/LZMA2/LZMA2Decoder.swift:34-99).
 //
-// The range coder is a strictly serial chain, so a stream cannot be split; the adaptive probability
-// model (up to 14,135 11-bit cells for lc+lp <= 4) is far too large to keep per LANE, so one wavefront
-// owns one stream: the model lives in the wave's LDS slice as u16 cells (28.3 KiB => 5 streams per CU),
-// all 64 lanes execute the decode chain redundantly (wave-uniform control flow, LDS broadcasts), and
-// the LZ copy of every match is spread over the lanes.  Streams with lc+lp > 4 (legal for .lzma, never
-// produced by xz) spill the literal coder to an HBM workspace.
+// The range coder is a strictly serial chain, so a stream cannot be split; the adaptive probability model (up to 14,135
+// 11-bit cells for lc + lp <= 4) is far too large to keep per LANE, so one wavefront owns one stream and all 64 lanes execute
+// the decode chain redundantly (wave-uniform control flow, LDS broadcasts); the LZ copy of every match is spread over the
+// lanes.  The kernel is bound by the latency of that one chain, so its speed is the number of streams a CU holds -- i.e. the
+// LDS a stream needs.  Two layouts (kernels.hip picks):
+//   coder cache (the default when the launch has a workspace): the 1,847 non-literal cells and FOUR of the literal coders
+//       (0x300 cells each) in LDS, all literal coders in the workspace; a literal whose coder is not cached writes the victim
+//       back and loads its own (coders never used since the last reset are filled, not loaded): 9,840 B => 16 streams per CU;
+//   whole model in LDS (no workspace; round 2's layout): every literal coder of lc + lp <= 4 in LDS, 28,272 B => 5 streams
+//       per CU; lc + lp > 4 (legal for .lzma, never produced by xz) reports SWC_E_NEED_WORKSPACE and is re-run with one.
+// The next 256 input bytes sit in a register spread over the lanes and are refilled at one place per symbol.
 //
 // The same source is compiled for the host with WAVE = 1 (tests/host_emu) to check the serial logic
 // against the oracle without a GPU; the wave-parallel copy is the only part that differs.
