@@ -296,6 +296,46 @@ def verify_compressed_units(batch, plains, torch):
             "compression_ratio": ratio}
 
 
+def archive_paths(lib):
+    """SURVEY 8d-2 / 8d-5 as the ARCHIVE layer sees them (host buffer in, host buffer out, so both PCIe legs, the block
+    discovery and the trailer checks are in the figure): a BGZF file of 4,096 x 64 KiB members through
+    GzipArchive.multiUnarchive (BSIZE locates the members, one launch) and an `xz --block-size=256KiB` stream of 512 blocks
+    through XZArchive.unarchive (the index locates the blocks, one launch)."""
+    import shutil
+    import subprocess
+    import swcompression_amd as swc
+    from swcompression_amd import corpus
+    res = {}
+    parts = [corpus.p_text(65536, 0x5C0DE + 2 + i) for i in range(512)]
+    members = [corpus.gzip_member(p, bgzf=True) for p in parts]
+    data = b"".join(members * 8)
+    swc.GzipArchive.multi_unarchive(data[:len(b"".join(members[:64]))])   # warm-up (pinned staging, pool)
+    l0 = lib.swc_stat(b"launches")
+    t0 = time.perf_counter()
+    out = swc.GzipArchive.multi_unarchive(data)
+    dt = time.perf_counter() - t0
+    assert len(out) == 4096 and out[0] == parts[0] and out[-1] == parts[-1] and sum(len(o) for o in out) == 4096 * 65536
+    res["bgzf_multi_unarchive"] = {"workload": "BGZF file, 4096 members x 64 KiB (512 distinct), GzipArchive.multiUnarchive, host buffers both ways",
+                                   "value": 4096 * 65536 / dt / 2**30, "unit": "GiB/s decompressed (PCIe legs, discovery, CRC-32 / ISIZE checks and the Python list included)",
+                                   "seconds": dt, "launches": int(lib.swc_stat(b"launches") - l0), "compressed_bytes": len(data)}
+    if shutil.which("xz") is None:
+        res["xz_index_unarchive"] = {"error": "no xz command on this box to write a multi-block stream"}
+        return res
+    x = b"".join(corpus.p_text(262144, 0x5C0DE + 5 + i) for i in range(64)) * 8
+    a = subprocess.run(["xz", "-z", "-c", "-T4", "--block-size=262144", "--check=crc64"], input=x, stdout=subprocess.PIPE, check=True).stdout
+    swc.XZArchive.unarchive(subprocess.run(["xz", "-z", "-c"], input=x[:262144], stdout=subprocess.PIPE, check=True).stdout)   # warm-up
+    l0, h0 = lib.swc_stat(b"launches"), lib.swc_stat(b"xz_cache_hits")
+    t0 = time.perf_counter()
+    y = swc.XZArchive.unarchive(a)
+    dt = time.perf_counter() - t0
+    assert y == x
+    res["xz_index_unarchive"] = {"workload": "xz -T4 --block-size=256KiB stream of 512 blocks (64 distinct), XZArchive.unarchive, host buffers both ways",
+                                 "value": len(x) / dt / 2**30, "unit": "GiB/s decompressed (PCIe legs, index walk and CRC-64 checks included)",
+                                 "seconds": dt, "launches": int(lib.swc_stat(b"launches") - l0), "blocks_from_the_batch": int(lib.swc_stat(b"xz_cache_hits") - h0),
+                                 "compressed_bytes": len(a)}
+    return res
+
+
 def config1_latency(lib, raw, plains, reps=20):
     """BASELINE configs[0]: ONE 64 KiB Deflate block through the single-shot C ABI (host buffer in, host buffer out, so
     the figure includes both PCIe copies, the launch and the synchronisation)."""
@@ -495,7 +535,7 @@ def run_workload(name, args, lib, torch, dist, world, rank, device, steps, warmu
                       "parallelism": "%d x independent shards (%s scaling)" % (world, args.scaling)},
            "roofline": roof, "verify": verify}
     if with_cpu and rank == 0:
-        res["cpu_baseline"] = cpu_baseline(name, raw, plains, args.cpu_seconds)
+        res["cpu_baseline"] = cpu_baseline(name, raw, plains, args.cpu_seconds if name == args.workload else min(args.cpu_seconds, 5.0))
         if name != "deflate64k":   # (the headline's context lines are attached by main())
             ctx = cpu_context(name, raw, plains, min(args.cpu_seconds, 4.0))
             if "all_cores" in ctx:
@@ -623,6 +663,11 @@ def main():
         if with_cpu and args.workload == "deflate64k":
             # (skipped together with the CPU legs: profiling commands want nothing but the batch launches in their statistics)
             line["config1_latency"] = config1_latency(lib, raw, plains)
+            if not args.no_per_codec and args.scale == 1.0:
+                try:
+                    line["archive_paths"] = archive_paths(lib)
+                except Exception as e:   # (a line of context, never the reason the headline is lost)
+                    line["archive_paths"] = {"error": str(e)[:200]}
     del batch
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and args.workload == "deflate64k" and not args.no_per_codec and args.scale == 1.0:
