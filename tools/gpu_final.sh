@@ -20,7 +20,7 @@ for k, v in d.get("per_codec", {}).items():
 PY
   ;;
 trace)
-  for W in $WL; do
+  for W in $WL deflate64k_mix lz4_compress_4m; do
     ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_$W -o bench -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-per-codec > $O/trace_$W.log 2>&1 ); echo "trace $W rc=$?"
     python tools/rocpd_summary.py $O/trace_$W/bench_results.db > $O/kernel_stats_$W.txt 2>&1; head -8 $O/kernel_stats_$W.txt
   done ;;
