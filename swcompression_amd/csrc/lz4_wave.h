@@ -409,7 +409,7 @@ struct Parser {
     // sequence is parsed -- its record goes to the row of the lane's next record, its counts are added -- or (a sequence with
     // more than four literals) the step only carries literals on; either way up to four literal bytes of the current sequence
     // are appended to the accumulator (oldest byte lowest), whose low dword is written to the row of the literal group being
-    // filled -- unconditionally, a group is final when its last writer has been.
+    // filled when that group is full (the last, incomplete one behind the loop).
     SWC_D static void parse_chunk_prov(const uint8_t* stage, uint32_t stage_len, uint32_t start, uint32_t chunk_end, uint32_t tail_limit, gptr prov,
                                        uint32_t lane, ProvOut& r) {
         uint32_t ip = start, nlit = 0, nout = 0, lms = 0, flags = 0;
@@ -446,8 +446,8 @@ struct Parser {
             const uint32_t take = rem < 4u ? rem : 4u;
             const uint32_t w = rd32(stage, src) & (uint32_t)(((uint64_t)1 << (8u * take)) - 1u);
             const uint64_t a64 = (uint64_t)acc | ((uint64_t)w << (8u * nacc));
-            store_u32(prov + loff, (uint32_t)a64);
             const uint32_t tot = nacc + take, full = tot >> 2;
+            if (full) store_u32(prov + loff, (uint32_t)a64);   // (masked per lane: the memory pipeline's work is per active lane, and a group rewritten every step reaches HBM every time)
             acc = full ? (uint32_t)(a64 >> 32) : (uint32_t)a64;
             nacc = tot & 3u;
             loff += full * kProvRow;
