@@ -174,7 +174,7 @@ enum { kFlagEob = 1u, kFlagFail = 2u, kFlagTrap = 4u, kFlagSlow = 8u };
 // logic + scans, 5 copy / emit, 6 checked steps / rest; 7 rounds, 8 passes, 9 walk pass
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 struct SyncProf {
-    uint64_t acc[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+    uint64_t acc[16] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     uint64_t tlast = 0;
 };
 #define SWC_SP(pp, k) { const uint64_t t_ = __builtin_readcyclecounter(); (pp).acc[k] += t_ - (pp).tlast; (pp).tlast = t_; }
@@ -407,7 +407,8 @@ SWC_D void table_from_counts(const uint32_t* cnt, SWC_AS_GLOBAL uint32_t* tb, ui
 //      first 10 / 8 bits, whose width is set by the LAST (longest) code with that prefix -- prefixes do not decrease in
 //      canonical order, so "last" is a look at the next symbol -- and whose offset is a running sum over those;
 //   D  the long codes fill their subtable slots.
-SWC_D bool sync_tables_from_lengths(SyncLds* sl, const Spill sp, int literals, int distances, SubTab& st) {
+SWC_D bool sync_tables_from_lengths(SyncLds* sl, const Spill sp, int literals, int distances, SubTab& st, SyncProf& pf) {
+    SWC_SP(pf, 0)
     using simt::PT;
     constexpr int N = kWave;
     const uint8_t* lens = sl->stage + kHdrLens;
@@ -445,6 +446,7 @@ SWC_D bool sync_tables_from_lengths(SyncLds* sl, const Spill sp, int literals, i
         SIMT_END_WAVE
         SIMT_BEGIN(t, N) if (upd[t] != 0u) run[(is_dist ? 16u : 0u) + v[t]] = upd[t]; SIMT_END_WAVE
     }
+    SWC_SP(pf, 10)
     // ---- B
     SIMT_BEGIN(t, N)
         if (t < 2) table_from_counts(run + 16 * t, sp.aux + (t ? kAuxDist : kAuxLit), tab + 33 * t, tab + 33 * t + 16);
@@ -463,6 +465,7 @@ SWC_D bool sync_tables_from_lengths(SyncLds* sl, const Spill sp, int literals, i
         for (int i = t; i < (1 << kSyncLitBits) + (1 << kSyncDistBits); i += N) sl->lut[i] = i < (1 << kSyncLitBits) ? kInvLit : kInvDist;
     SIMT_END_WAVE
     simt::vmem_fence();   // (the wave reads the spill back -- here and in the checked step: its stores are done first)
+    SWC_SP(pf, 11)
     if (sp.aux[kAuxLit + kAuxOver] != 0u || sp.aux[kAuxDist + kAuxOver] != 0u) return false;
     // ---- C
     uint32_t used = 0, used_lit = 0;
@@ -515,6 +518,7 @@ SWC_D bool sync_tables_from_lengths(SyncLds* sl, const Spill sp, int literals, i
         }
         if (tbl == 0) used_lit = used;
     }
+    SWC_SP(pf, 12)
     if (used > kSubMax) return false;
     SWC_AS_GLOBAL uint32_t* subg = used > kSubLds ? sp.sub : nullptr;
     st.g = subg;
@@ -550,6 +554,7 @@ SWC_D bool sync_tables_from_lengths(SyncLds* sl, const Spill sp, int literals, i
     }
     simt::wave_fence();
     if (subg) simt::vmem_fence();
+    SWC_SP(pf, 13)
     return true;
 }
 
@@ -1134,6 +1139,7 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, const Spill sp, SubTab& st, b
             }
         }
     }
+    SWC_SP(pf, 14)
     uint8_t* lens = sl->stage + kHdrLens;
     uint8_t* cl_lut = sl->stage + kHdrClLut;
     uint32_t* hin = (uint32_t*)(sl->stage + kHdrIn);
@@ -1151,6 +1157,7 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, const Spill sp, SubTab& st, b
             cl_lut[x] = idx < 0 ? (uint8_t)0xFF : (uint8_t)(len | (sym << 3));
         }
     SIMT_END_WAVE
+    SWC_SP(pf, 15)
     int n = 0;
     uint32_t prev = 0;
     uint64_t HB = ~0ull;                                  // byte offset of the staged part of the header (none yet)
@@ -1254,18 +1261,18 @@ SWC_D int build_dynamic_par(Lane& ln, SyncLds* sl, const Spill sp, SubTab& st, b
     simt::wave_fence();
     br.seek(W);
     SWC_SP(pf, 0)
-    fast = sync_tables_from_lengths(sl, sp, literals, distances, st);
+    fast = sync_tables_from_lengths(sl, sp, literals, distances, st, pf);
     return SWC_OK;
 }
 
 // Deflate.swift:77-81 with the fixed code of Deflate+Constants.swift:11-173: the same table build from the fixed lengths
-SWC_D void build_static_par(SyncLds* sl, const Spill sp, SubTab& st, bool& fast) {
+SWC_D void build_static_par(SyncLds* sl, const Spill sp, SubTab& st, bool& fast, SyncProf& pf) {
     constexpr int N = kWave;
     uint8_t* lens = sl->stage + kHdrLens;
     SIMT_BEGIN(t, N)
         for (int s = t; s < 320; s += N) lens[s] = (uint8_t)(s < 144 ? 8 : s < 256 ? 9 : s < 280 ? 7 : s < 288 ? 8 : 5);
     SIMT_END_WAVE
-    fast = sync_tables_from_lengths(sl, sp, 288, 32, st);
+    fast = sync_tables_from_lengths(sl, sp, 288, 32, st, pf);
 }
 
 // ---- the job -------------------------------------------------------------------------------------------------------
@@ -1327,7 +1334,7 @@ SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes,
                 SWC_SP(pf, 6)
                 bool fast = false;
                 SubTab stb{nullptr};
-                if (type == 1) build_static_par(sl, sp, stb, fast);
+                if (type == 1) build_static_par(sl, sp, stb, fast, pf);
                 else st = build_dynamic_par(ln, sl, sp, stb, fast, pf);
                 SWC_SP(pf, 1)
                 if (st == SWC_OK) {
@@ -1365,7 +1372,7 @@ SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes,
     }
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     SWC_SP(pf, 6)
-    if (prof && lane == 0) for (int k = 0; k < 10; k++) prof[k] = pf.acc[k];
+    if (prof && lane == 0) for (int k = 0; k < 16; k++) prof[k] = pf.acc[k];
 #else
     (void)prof; (void)pf;
 #endif

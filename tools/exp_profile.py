@@ -14,9 +14,13 @@ b.launch(sync=True)
 b.launch(sync=True)
 p = prof.cpu().numpy().reshape(b.n, 32).astype(np.float64)
 n1 = ["header", "tables", "staging", "decode passes", "chain+scans", "copy/emit", "rest"]
-t1 = p[:, :7].sum(axis=1).mean() + p[:, 9].mean()
+t1 = p[:, :7].sum(axis=1).mean() + p[:, 9:16].sum(axis=1).mean()
 print("phase 1 (inflate_sync): %.0f kcycles per stream; rounds %.2f passes %.2f; %%: " % (t1 / 1e3, p[:, 7].mean(), p[:, 8].mean())
-      + ", ".join("%s %.1f" % (n, 100 * p[:, k].mean() / t1) for k, n in enumerate(n1)) + ", walk %.1f" % (100 * p[:, 9].mean() / t1))
+      + ", ".join("%s %.1f" % (n, 100 * (p[:, k].mean() + (p[:, 14:16].sum(axis=1).mean() if k == 0 else p[:, 10:14].sum(axis=1).mean() if k == 1 else 0)) / t1) for k, n in enumerate(n1))
+      + ", walk %.1f" % (100 * p[:, 9].mean() / t1))
+fine = ["tables A ranks", "tables B codes+scatter", "tables C direct+links", "tables D subtables", "header: reader, 19 lengths, their code", "header: its table"]
+print("   of which (kcycles): " + ", ".join("%s %.1f" % (n, p[:, 10 + k].mean() / 1e3) for k, n in enumerate(fine))
+      + ", header windows + reader seek %.1f, tables rest %.1f" % (p[:, 0].mean() / 1e3, p[:, 1].mean() / 1e3))
 n2 = ["R0+scan", "R1", "R2 expand", "R3 chase+out"]
 t2 = p[:, 16:20].sum(axis=1).mean()
 print("phase 2 (lz_resolve): %.0f kcycles per stream; batches %.2f span/batch %.0f records/batch %.0f; %%: "
