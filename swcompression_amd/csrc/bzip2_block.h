@@ -38,6 +38,7 @@
 
 #include "swc_common.h"
 #include "simt.h"
+#include <type_traits>
 
 namespace swc {
 namespace bzip2 {
@@ -127,7 +128,10 @@ struct MsbReader {
     uint32_t pw;       // the dword at `next`, already loaded (pw_ok)
     bool pw_ok;
     SWC_HD void init(gcptr p, uint64_t nbytes, uint64_t start_bit) {
-        in = p; n = nbytes; next = start_bit >> 3; bb = 0; bc = 0; pw = 0; pw_ok = false;
+        // (the whole state is declared wave-uniform once, here and where bytes come in: the symbol loop branches on it, and a
+        // value the compiler cannot prove uniform turns every one of those branches into an exec-mask region)
+        start_bit = simt::uniform(start_bit);
+        in = p; n = simt::uniform(nbytes); next = start_bit >> 3; bb = 0; bc = 0; pw = 0; pw_ok = false;
         refill();
         uint32_t skip = (uint32_t)(start_bit & 7);
         if (skip > bc) skip = bc;
@@ -143,11 +147,11 @@ struct MsbReader {
                 bc += 32;
                 next += 4;
                 pw_ok = next + 4 <= n;
-                if (pw_ok) pw = load_u32(in + next);
+                if (pw_ok) pw = load_u32(in + next);   // (made uniform where it is used: a readfirstlane here would wait for the load)
             } else {
                 pw_ok = false;
                 while (bc <= 56 && next < n) {
-                    bb |= (uint64_t)in[next++] << (56 - bc);
+                    bb |= (uint64_t)simt::uniform((uint32_t)in[next++]) << (56 - bc);
                     bc += 8;
                 }
             }
@@ -325,119 +329,254 @@ struct Stage1 {
     }
 
     // ---- symbol loop :205-246, state in registers (see the header comment) ---------------------------------------------
-    SWC_HD int symbol_loop(int n_selectors, int used_count, int n_used) {
-        using simt::PT;
-        constexpr int N = 64;
-        if (n_selectors == 0) return SWC_E_REF_TRAP;  // selectors[0] on an empty array (App. A B3)
-        PT<uint32_t, N> my_lim, my_delta, sym_a, sym_b, sym_c, mtf, stg, tmp, prev;
-        PT<bool, N> pb;
+    // The loop is wave-uniform and bound by the NUMBER of instructions a symbol costs (round 3: 33 scalar + 31 vector), so it
+    // is written per GROUP of 50 symbols (one selector): what can be decided once per group is -- enough input for 50 codes
+    // of the maximal length (no end-of-input tests per symbol), room for 50 bytes in L, a prefix-free code (never anything
+    // else from an encoder) -- and the groups that pass run the loop without those tests (phase<true>; the conditions only
+    // get worse along a block, so the first group that fails hands the rest of the block to phase<false>).  Per symbol:
+    //   decode   lane d holds limit, shift and index delta of code length d: ONE compare + ballot gives the length, every lane
+    //            forms the index its length would give, one lane read picks it, one more reads the symbol (the 64 most
+    //            frequent symbols -- the shortest codes -- sit one per lane);
+    //   MTF      the list is kept one POSITION per lane (positions 0-63 in one register, the other 192 in three more): the
+    //            element leaves through a lane read, the positions in front of it move up with one DPP shift of the whole
+    //            wave and one select -- 5 vector instructions, nothing on the scalar unit; positions >= 64 take a general path;
+    //   output   the staging register is a shift register over the lanes (one more DPP shift lets the byte in at lane 0); it is
+    //            flushed at the end of the group (at most 50 bytes are staged: no "is it full" test per symbol) and in front
+    //            of a run.
+    static constexpr int N = 64;
+    struct Loop {
+        simt::PT<uint32_t, N> my_lim, my_delta, my_sh, sym_lo, sym_a, sym_b, sym_c;   // the active table
+        simt::PT<uint32_t, N> l0, l1, l2, l3;    // the list: position 64 i + t in l<i>[t]
+        simt::PT<uint32_t, N> stg;               // L[sbase .. sbase + k) staged: lane j holds byte sbase + k - 1 - j
+        uint32_t sbase, k;
+        uint64_t run_length, repeat_power;       // repeat_power != 1: RUNA / RUNB symbols since the last byte symbol
+        int n_selectors, used_count, n_used, selector_index, table;
+        uint32_t mfast;                          // list positions the short way takes (the end-of-block symbol is n_used + 1)
+        bool over, have_table;
+    };
+    SWC_HD void load_table(Loop& L, int tb) {   // lane d: limit, shift and index delta of code length d; lane t: symbols t, t + 64, ... of the sorted array
         SIMT_BEGIN(t, N)
-            mtf[t] = *(const uint32_t*)(s->mtf + 4 * t);   // lane t: list positions 4t .. 4t + 3, position 4t in the low byte
-            stg[t] = 0;
+            const bool len_lane = t >= 1 && t <= kMaxLen;
+            // lane 0 counts always (the number of limits <= the window IS the length), lane kMaxLen + 1 stands for "no
+            // code": an index no table has
+            L.my_lim[t] = len_lane ? s->lim[tb][t] : t == 0 ? 0u : 0xFFFFFFFFu;
+            L.my_delta[t] = len_lane ? s->delta[tb][t] : 0x80000000u;
+            L.my_sh[t] = len_lane ? (uint32_t)(kMaxLen - t) : 0u;
+            const uint16_t* sy = s->sym[tb];
+            L.sym_lo[t] = (uint32_t)sy[t];
+            L.sym_a[t] = (uint32_t)sy[t] | ((uint32_t)sy[t + 64] << 16);
+            L.sym_b[t] = (uint32_t)sy[t + 128] | ((uint32_t)sy[t + 192] << 16);
+            L.sym_c[t] = t < kMaxSyms + 2 - 256 ? (uint32_t)sy[256 + t] : 0u;
         SIMT_END
-        auto load_table = [&](int tb) {   // lane d: limit and index delta of code length d; lane t: symbols t, t + 64, ... of the sorted array
+    }
+    SWC_HD void flush(Loop& L) {
+        // (a fast group tests the room in L once, at its end: bytes staged beyond it are dropped here, never stored)
+        SIMT_BEGIN(t, N)
+            const uint32_t at = L.sbase + L.k - 1u - (uint32_t)t;   // (the newest byte is in lane 0)
+            if ((uint32_t)t < L.k && at < lcap32) ws.L[at] = (uint8_t)L.stg[t];
+        SIMT_END
+        // (said explicitly: the compiler merges these updates into the per-lane region above and then treats the counters --
+        // and every branch on them -- as different from lane to lane)
+        L.sbase = simt::uniform(L.sbase + L.k);
+        L.k = 0;
+    }
+    // usedSymbols.remove(at: m) + insert(at: 0)  (BZip2.swift:243-244) for any m: positions 0 .. m - 1 move up by one
+    SWC_HD uint32_t mtf_general(Loop& L, uint32_t m) {
+        simt::PT<uint32_t, N> sh0, sh1, sh2, sh3;
+        const uint32_t q = m >> 6, r = m & 63u;
+        // (reads first, then a scalar select: a select between the REGISTERS would become a computed address into the
+        // struct, which then stays in memory with everything in it)
+        const uint32_t e0 = simt::wave_read<N>(L.l0, (int)r), e1 = simt::wave_read<N>(L.l1, (int)r), e2 = simt::wave_read<N>(L.l2, (int)r),
+                       e3 = simt::wave_read<N>(L.l3, (int)r);
+        const uint32_t el = q == 0u ? e0 : q == 1u ? e1 : q == 2u ? e2 : e3;
+        const uint32_t c0 = simt::wave_read<N>(L.l0, 63), c1 = simt::wave_read<N>(L.l1, 63), c2 = simt::wave_read<N>(L.l2, 63);
+        simt::wave_shift_up_dpp<N>(sh0, L.l0, el);
+        simt::wave_shift_up_dpp<N>(sh1, L.l1, c0);
+        simt::wave_shift_up_dpp<N>(sh2, L.l2, c1);
+        simt::wave_shift_up_dpp<N>(sh3, L.l3, c2);
+        SIMT_BEGIN(t, N)
+            const bool in = (uint32_t)t <= r;
+            L.l0[t] = (q > 0u || in) ? sh0[t] : L.l0[t];
+            if (q >= 1u) L.l1[t] = (q > 1u || in) ? sh1[t] : L.l1[t];
+            if (q >= 2u) L.l2[t] = (q > 2u || in) ? sh2[t] : L.l2[t];
+            if (q >= 3u) L.l3[t] = in ? sh3[t] : L.l3[t];
+        SIMT_END
+        return el;
+    }
+    // The symbols of a group that need nothing special, one after the other (FAST groups only): RUNA / RUNB, a run short enough
+    // for the staging register, a byte symbol whose code is among the 64 shortest and whose list position is below 64.
+    // Anything else ends the loop with the symbol (kSymbol) or its table index (kIndex) decoded and counted but not applied.
+    // ONE loop with ONE kind of exit and no stores: with the rare cases inside, the copies the compiler places at their merge
+    // points cost more than the work (a dozen moves per symbol).
+    // Staging: a group starts with an empty register; a byte symbol adds one byte, a run enters only if it leaves a lane for
+    // every symbol the group still has -- so "is the register full" is never asked per symbol.
+    enum { kGroupDone = 0, kSymbol = 1, kIndex = 2 };
+    SWC_HD int hot_symbols(Loop& L, int& i, uint32_t& pending, uint32_t& pending_len) {
+        simt::PT<uint32_t, N> idxv, sh, src;
+        simt::PT<bool, N> pb;
+        // ONE exit test at the bottom and one way round: the backend gives a loop with several exits a guard variable and
+        // a block of moves per exit (UnifyLoopExits), and a `continue` a second latch with its own copies.  `ev` is made opaque
+        // in front of the test so that the exits are not threaded back into the paths that set it.
+        uint32_t ev = kGroupDone;
+        do {
+            br.refill();
+            const uint32_t c = br.peek(kMaxLen);
             SIMT_BEGIN(t, N)
-                const bool len_lane = t >= 1 && t <= kMaxLen;
-                my_lim[t] = len_lane ? s->lim[tb][t] : 0xFFFFFFFFu;
-                my_delta[t] = len_lane ? s->delta[tb][t] : 0u;
-                const uint16_t* sy = s->sym[tb];
-                sym_a[t] = (uint32_t)sy[t] | ((uint32_t)sy[t + 64] << 16);
-                sym_b[t] = (uint32_t)sy[t + 128] | ((uint32_t)sy[t + 192] << 16);
-                sym_c[t] = t < kMaxSyms + 2 - 256 ? (uint32_t)sy[256 + t] : 0u;
+                pb[t] = c >= L.my_lim[t];
+                idxv[t] = (c >> L.my_sh[t]) + L.my_delta[t];
             SIMT_END
-        };
-        uint32_t sbase = 0;   // L[sbase .. n_out) is staged: lane k holds byte sbase + k
-        auto flush = [&]() {
-            const uint32_t cnt = n_out - sbase;
-            SIMT_BEGIN(t, N) if ((uint32_t)t < cnt) ws.L[sbase + (uint32_t)t] = (uint8_t)stg[t]; SIMT_END
-            sbase = n_out;
-        };
-        int decoded = 0;
-        int selector_index = 1;
-        int table = selector_at(0);
-        load_table(table);
-        bool over = s->oversub[table] != 0;
-        uint64_t run_length = 0, repeat_power = 1;
-        bool in_run = false;   // RUNA / RUNB symbols since the last byte symbol (then run_length may be non-zero)
-        for (;;) {
-            if (decoded >= 50) {
-                if (!(selector_index < n_selectors)) return SWC_E_BZIP2_WRONG_SELECTOR;  // :214
-                table = selector_at(selector_index);
-                load_table(table);
-                over = s->oversub[table] != 0;
-                selector_index++;
-                decoded = 0;
-            }
-            int symbol;
-            if (!over) {   // DecodingTree.findNextSymbol for a prefix-free set: length by ballot, index and symbol by readlane
-                br.refill();
-                const uint32_t c = br.peek(kMaxLen);
-                SIMT_BEGIN(t, N) pb[t] = c >= my_lim[t]; SIMT_END
-                const uint32_t len = 1u + (uint32_t)simt::popc64(simt::wave_ballot<N>(pb));
-                if (len > (uint32_t)kMaxLen) return SWC_E_BZIP2_SYMBOL_NOT_FOUND;  // :222
-                const uint32_t idx = (c >> (kMaxLen - len)) + simt::wave_read<N>(my_delta, (int)len);
-                if (len > br.bc && (int64_t)len > br.bits_left()) return SWC_E_BZIP2_SYMBOL_NOT_FOUND;  // DecodingTree.swift:39
-                br.consume(len);
-                SIMT_BEGIN(t, N) tmp[t] = idx < 128u ? sym_a[t] : idx < 256u ? sym_b[t] : sym_c[t]; SIMT_END
-                const uint32_t w = simt::wave_read<N>(tmp, (int)(idx & 63u));
-                symbol = (int)(((idx & 64u) != 0u && idx < 256u) ? w >> 16 : w & 0xFFFFu);
-            } else {       // over-subscribed set (never written by an encoder): the heap semantics, from LDS
-                symbol = decode_symbol(table, 0u, true);
-                if (symbol == -1) return SWC_E_BZIP2_SYMBOL_NOT_FOUND;  // :222
-            }
-            decoded++;
-            if (symbol == 0 || symbol == 1) {  // RUNA / RUNB :226-230 (wrapping, like &+ and smart shifts)
-                run_length += repeat_power << symbol;
-                repeat_power <<= 1;
-                in_run = true;
-                continue;
-            }
-            if (in_run) {   // (without a RUNA / RUNB since the last test run_length is what that test left: not positive)
-                in_run = false;
-                if ((int64_t)run_length > 0) {
-                    if (n_used == 0) return SWC_E_REF_TRAP;  // usedSymbols[0] on an empty array
-                    if ((uint64_t)n_out + run_length > ws.lcap || run_length > 0xFFFFFFFFull) return SWC_E_NEED_WORKSPACE;
-                    flush();
-                    const uint32_t b = simt::wave_read<N>(mtf, 0) & 255u;
-                    const uint32_t run = (uint32_t)run_length;
-                    SIMT_BEGIN(t, N) for (uint32_t i = (uint32_t)t; i < run; i += (uint32_t)N) ws.L[n_out + i] = (uint8_t)b; SIMT_END
-                    n_out += run;
-                    sbase = n_out;
-                    run_length = 0;
-                    repeat_power = 1;
-                }
-            }
-            if (symbol == used_count - 1) break;  // :239 end of block
-            // usedSymbols.remove(at: m) + insert(at: 0)  (BZip2.swift:243-244): positions 0 .. m - 1 move up by one
-            const uint32_t m = (uint32_t)symbol - 1u;
-            const uint32_t q = m >> 2, r = m & 3u;
-            const uint32_t el = (simt::wave_read<N>(mtf, (int)q) >> (8u * r)) & 255u;
-            if (m != 0u) {
-                if (q != 0u) simt::wave_shift_up<N>(prev, mtf, 0u);
-                SIMT_BEGIN(t, N)
-                    const uint32_t cur = mtf[t];
-                    const uint32_t up = (cur << 8) | ((q != 0u && t != 0) ? prev[t] >> 24 : 0u);   // every byte one position up
-                    uint32_t nv = cur;
-                    if ((uint32_t)t < q) nv = up;
-                    else if ((uint32_t)t == q) {
-                        const uint32_t mask = r == 3u ? 0xFFFFFFFFu : (1u << (8u * (r + 1u))) - 1u;   // positions 4q .. m
-                        nv = (up & mask) | (cur & ~mask);
+            const uint32_t len = (uint32_t)simt::popc64(simt::wave_ballot<N>(pb));
+            const uint32_t idx = simt::wave_read<N>(idxv, (int)len);
+            br.consume(len);
+            i++;
+            if (idx < 64u) {
+                const uint32_t symbol = simt::wave_read<N>(L.sym_lo, (int)idx);
+                if (symbol < 2u) {  // RUNA / RUNB :226-230 (wrapping, like &+ and smart shifts)
+                    L.run_length += L.repeat_power << symbol;
+                    L.repeat_power <<= 1;
+                } else {
+                    bool go = true;
+                    if (L.repeat_power != 1ull) {
+                        // k + run + (the 51 - i symbols from this one on) <= 64; a run that is not positive (wrapped) goes the long way too
+                        if (L.run_length - 1ull < (uint64_t)(13u + (uint32_t)i - L.k)) {
+                            const uint32_t run = (uint32_t)L.run_length;
+                            const uint32_t b = simt::wave_read<N>(L.l0, 0) & 255u;
+                            SIMT_BEGIN(t, N) src[t] = (uint32_t)t - run; SIMT_END
+                            simt::wave_gather<N>(sh, L.stg, src);           // lane t takes what lane t - run held
+                            SIMT_BEGIN(t, N) L.stg[t] = (uint32_t)t < run ? b : sh[t]; SIMT_END
+                            L.k += run;
+                            L.run_length = 0;
+                            L.repeat_power = 1;
+                        } else go = false;
                     }
-                    if (t == 0) nv = (nv & ~0xFFu) | el;
-                    mtf[t] = nv;
-                SIMT_END
+                    const uint32_t m = symbol - 1u;
+                    if (go && m < L.mfast) {
+                        const uint32_t el = simt::wave_read<N>(L.l0, (int)m);
+                        simt::wave_shift_up_dpp<N>(sh, L.l0, el);
+                        SIMT_BEGIN(t, N) L.l0[t] = (uint32_t)t <= m ? sh[t] : L.l0[t]; SIMT_END
+                        simt::wave_shift_up_dpp<N>(sh, L.stg, el);
+                        L.stg = sh;
+                        L.k++;
+                    } else { pending = symbol; ev = kSymbol; }
+                }
+            } else { pending = idx; pending_len = len; ev = kIndex; }
+            SWC_OPAQUE_S(ev);
+        } while (ev == kGroupDone && i < 50);
+        return (int)ev;
+    }
+    // Groups until the end-of-block symbol (returns SWC_OK with everything flushed), an error (its status) or -- FAST only --
+    // a group that does not qualify (returns -1 with that group's table loaded).
+    template <bool FAST>
+    SWC_HD int phase(Loop& L) {
+        simt::PT<uint32_t, N> idxv, sh;
+        simt::PT<bool, N> pb;
+        for (;;) {
+            if (!L.have_table) {
+                if (!(L.selector_index < L.n_selectors)) return SWC_E_BZIP2_WRONG_SELECTOR;  // :214
+                L.table = selector_at(L.selector_index++);
+                load_table(L, L.table);
+                L.over = s->oversub[L.table] != 0;
             }
-            // L[n_out] = el, staged a byte per lane
-            if (n_out >= lcap32) return SWC_E_NEED_WORKSPACE;
-            {
-                const uint32_t k = n_out - sbase;
-                SIMT_BEGIN(t, N) if ((uint32_t)t == k) stg[t] = el; SIMT_END
+            L.have_table = false;
+            if (FAST) {
+                // 50 codes of kMaxLen bits are 163 bytes; the reader looks 8 bytes ahead.  (n_used == 0: a run has no byte to repeat.)
+                if (L.over || L.n_used == 0 || br.next + 176 > br.n || (uint64_t)L.sbase + 128 > (uint64_t)lcap32) { L.have_table = true; return -1; }
             }
-            n_out++;
-            if (n_out - sbase == (uint32_t)N) flush();
+            int i = 0;
+            for (;;) {
+                uint32_t symbol;
+                if (FAST) {
+                    uint32_t pend = 0, plen = 0;
+                    if (i >= 50) break;
+                    const int ev = hot_symbols(L, i, pend, plen);
+                    if (ev == kGroupDone) break;
+                    if (ev == kIndex) {
+                        if (plen > (uint32_t)kMaxLen) return SWC_E_BZIP2_SYMBOL_NOT_FOUND;  // :222
+                        const uint32_t wa = simt::wave_read<N>(L.sym_a, (int)(pend & 63u)), wb = simt::wave_read<N>(L.sym_b, (int)(pend & 63u)),
+                                       wc = simt::wave_read<N>(L.sym_c, (int)(pend & 63u));
+                        const uint32_t w = pend < 128u ? wa : pend < 256u ? wb : wc;
+                        symbol = ((pend & 64u) != 0u && pend < 256u) ? w >> 16 : w & 0xFFFFu;
+                    } else symbol = pend;
+                } else {
+                    if (i >= 50) break;
+                    i++;
+                    if (!L.over) {   // DecodingTree.findNextSymbol for a prefix-free set
+                        br.refill();
+                        const uint32_t c = br.peek(kMaxLen);
+                        SIMT_BEGIN(t, N)
+                            pb[t] = c >= L.my_lim[t];
+                            idxv[t] = (c >> L.my_sh[t]) + L.my_delta[t];
+                        SIMT_END
+                        const uint32_t len = (uint32_t)simt::popc64(simt::wave_ballot<N>(pb));
+                        if (len > (uint32_t)kMaxLen) return SWC_E_BZIP2_SYMBOL_NOT_FOUND;  // :222
+                        const uint32_t idx = simt::wave_read<N>(idxv, (int)len);
+                        if (len > br.bc && (int64_t)len > br.bits_left()) return SWC_E_BZIP2_SYMBOL_NOT_FOUND;  // DecodingTree.swift:39
+                        br.consume(len);
+                        const uint32_t wa = simt::wave_read<N>(L.sym_a, (int)(idx & 63u)), wb = simt::wave_read<N>(L.sym_b, (int)(idx & 63u)),
+                                       wc = simt::wave_read<N>(L.sym_c, (int)(idx & 63u));
+                        const uint32_t w = idx < 128u ? wa : idx < 256u ? wb : wc;
+                        symbol = ((idx & 64u) != 0u && idx < 256u) ? w >> 16 : w & 0xFFFFu;
+                    } else {       // over-subscribed set (never written by an encoder): the heap semantics, from LDS
+                        const int sy = decode_symbol(L.table, 0u, true);
+                        if (sy == -1) return SWC_E_BZIP2_SYMBOL_NOT_FOUND;  // :222
+                        symbol = (uint32_t)sy;
+                    }
+                }
+                // ---- one symbol the long way
+                if (symbol < 2u) {  // RUNA / RUNB :226-230 (wrapping, like &+ and smart shifts)
+                    L.run_length += L.repeat_power << symbol;
+                    L.repeat_power <<= 1;
+                    continue;
+                }
+                if (L.repeat_power != 1ull) {   // (a run that wrapped to something not positive is tested again at every byte symbol: same outcome)
+                    if ((int64_t)L.run_length > 0) {
+                        if (L.n_used == 0) return SWC_E_REF_TRAP;  // usedSymbols[0] on an empty array
+                        if ((uint64_t)L.sbase + L.k + L.run_length > ws.lcap || L.run_length > 0xFFFFFFFFull) return SWC_E_NEED_WORKSPACE;
+                        flush(L);
+                        const uint32_t b = simt::wave_read<N>(L.l0, 0) & 255u;
+                        const uint32_t run = (uint32_t)L.run_length;
+                        SIMT_BEGIN(t, N) for (uint32_t j = (uint32_t)t; j < run; j += (uint32_t)N) ws.L[L.sbase + j] = (uint8_t)b; SIMT_END
+                        L.sbase = simt::uniform(L.sbase + run);
+                        L.run_length = 0;
+                        L.repeat_power = 1;
+                    }
+                }
+                if (symbol == (uint32_t)(L.used_count - 1)) {  // :239 end of block
+                    if ((uint64_t)L.sbase + L.k > (uint64_t)lcap32) return SWC_E_NEED_WORKSPACE;
+                    flush(L);
+                    return SWC_OK;
+                }
+                const uint32_t el = mtf_general(L, symbol - 1u);
+                // L[n_out] = el, staged a byte per lane
+                if (!FAST && L.sbase + L.k >= lcap32) return SWC_E_NEED_WORKSPACE;
+                simt::wave_shift_up_dpp<N>(sh, L.stg, el);
+                L.stg = sh;
+                L.k++;
+            }
+            // FAST: runs staged inside the group may have used up the room in L.  (The byte that does not fit is reported here,
+            // not where it was staged: an error in the rest of the group comes first -- only for a column that outgrows its
+            // workspace, which run_units answers with a larger one.)
+            if ((uint64_t)L.sbase + L.k > (uint64_t)lcap32) return SWC_E_NEED_WORKSPACE;
+            flush(L);
         }
-        flush();
-        return SWC_OK;
+    }
+    SWC_HD int symbol_loop(int n_selectors, int used_count, int n_used) {
+        if (n_selectors == 0) return SWC_E_REF_TRAP;  // selectors[0] on an empty array (App. A B3)
+        Loop L;
+        SIMT_BEGIN(t, N)
+            L.l0[t] = s->mtf[t]; L.l1[t] = s->mtf[64 + t]; L.l2[t] = s->mtf[128 + t]; L.l3[t] = s->mtf[192 + t];
+            L.stg[t] = 0;
+        SIMT_END
+        L.sbase = 0; L.k = 0;
+        L.run_length = 0; L.repeat_power = 1;
+        L.n_selectors = n_selectors; L.used_count = used_count; L.n_used = n_used;
+        L.selector_index = 0; L.table = 0;
+        L.mfast = (uint32_t)(n_used < 64 ? n_used : 64);
+        L.over = false; L.have_table = false;
+        int st = phase<true>(L);
+        if (st == -1) st = phase<false>(L);
+        n_out = L.sbase + L.k;
+        return st;
     }
 };
 
@@ -449,7 +588,8 @@ SWC_HD void stage1_job(const Job& job, Stage1Lds* lds, Workspace ws, int lane) {
     d.ws = ws;
     d.lane = lane;
     d.n_out = 0;
-    d.lcap32 = ws.lcap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)ws.lcap;
+    d.ws.lcap = (size_t)simt::uniform((uint64_t)ws.lcap);
+    d.lcap32 = d.ws.lcap > 0xFFFFFFFFull ? 0xFFFFFFFFu : (uint32_t)d.ws.lcap;
     uint32_t orig_ptr = 0;
     int st;
     if (job.dict_len > job.in_len * 8) {

@@ -211,6 +211,19 @@ SWC_D void wave_shift_up(PT<uint32_t, N>& y, const PT<uint32_t, N>& x, uint32_t 
     for (int t = 0; t < N; t++) { const uint32_t cur = x.v[t]; y.v[t] = prev; prev = cur; }
 #endif
 }
+// the same through the data-parallel-primitive path of the vector ALU (v_mov_b32_dpp wave_shr:1, lane 0 keeps `fill`): no
+// LDS instruction and no select -- for serial chains that shift a register once per step
+template <int N>
+SWC_D void wave_shift_up_dpp(PT<uint32_t, N>& y, const PT<uint32_t, N>& x, uint32_t fill) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    y.v = (uint32_t)__builtin_amdgcn_update_dpp((int)fill, (int)x.v, 0x138, 0xf, 0xf, false);   // wave_shr:1
+#elif defined(SWC_SIMT_DEVICE_FORM)
+    (void)y; (void)x; (void)fill;
+#else
+    uint32_t prev = fill;
+    for (int t = 0; t < N; t++) { const uint32_t cur = x.v[t]; y.v[t] = prev; prev = cur; }
+#endif
+}
 // y[t] = x[t + s] (the last s lanes: unspecified on the device, zero in the emulation)
 template <int N>
 SWC_D void wave_shift_down(PT<uint32_t, N>& y, const PT<uint32_t, N>& x, int s) {

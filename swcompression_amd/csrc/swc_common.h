@@ -26,8 +26,10 @@
 // table (and the struct around it) in scratch memory instead of VGPRs.
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SWC_OPAQUE(x) asm("" : "+v"(x))
+#define SWC_OPAQUE_S(x) asm("" : "+s"(x))   // the same for a wave-uniform value (stays in a scalar register)
 #else
 #define SWC_OPAQUE(x) ((void)0)
+#define SWC_OPAQUE_S(x) ((void)0)
 #endif
 
 namespace swc {
