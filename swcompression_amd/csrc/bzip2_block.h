@@ -412,6 +412,147 @@ struct Stage1 {
     // every symbol the group still has -- so "is the register full" is never asked per symbol.
     enum { kGroupDone = 0, kSymbol = 1, kIndex = 2 };
     SWC_HD int hot_symbols(Loop& L, int& i, uint32_t& pending, uint32_t& pending_len) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SWC_BZ_HOT_CXX)
+        return hot_symbols_isa(L, i, pending, pending_len);
+#else
+        return hot_symbols_cxx(L, i, pending, pending_len);
+#endif
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+    // The same loop as hot_symbols_cxx below, written in gfx950 assembly: 33 instructions per byte symbol and 24 per RUNA /
+    // RUNB against the 58 / 41 the compiler makes of the C++ (it keeps the loop-carried values in different registers on
+    // different paths and copies them at every merge point, and it will not shift a register in place).  All scalar state
+    // lives in fixed registers inside the block (s80 - s99: the halves of the 64-bit values are needed on their own, and an
+    // operand has no syntax for that); it is handed over at entry and exit.  What differs from the C++ in form only:
+    //   * `v_mov_b32_dpp x, x wave_shr:1` shifts a register in place, lane 0 is written afterwards with v_writelane (lane
+    //     select 0: no second scalar operand);
+    //   * the window is refilled by the C++ (exit 3 when fewer than 33 bits are left), everything else stays inside.
+    // Wait states the assembler does not insert into inline code: a lane select that was written by v_readlane needs four
+    // (the s_nop in front of the symbol read); DPP sources are written at least two instructions earlier on every path.
+    SWC_D int hot_symbols_isa(Loop& L, int& i, uint32_t& pending, uint32_t& pending_len) {
+        const uint32_t lane = (uint32_t)threadIdx.x;
+        uint32_t ev, pend, plen, t0, t1;
+        // (every scalar operand is said to be wave-uniform once more: a value the compiler holds in a vector register cannot be
+        // bound to an "s" operand)
+        uint32_t ii = simt::uniform((uint32_t)i), bc = simt::uniform(br.bc), k = simt::uniform(L.k);
+        uint64_t bb = simt::uniform(br.bb), rl = simt::uniform(L.run_length), rp = simt::uniform(L.repeat_power);
+        const uint32_t mfast = simt::uniform(L.mfast);
+        for (;;) {
+            asm volatile(
+                "s_mov_b64 s[80:81], %[bb]\n\t"
+                "s_mov_b32 s82, %[bc]\n\t"
+                "s_mov_b32 s83, %[i]\n\t"
+                "s_mov_b32 s84, %[k]\n\t"
+                "s_mov_b64 s[86:87], %[rl]\n\t"
+                "s_mov_b64 s[88:89], %[rp]\n\t"
+                "s_mov_b32 s90, %[mfast]\n\t"
+                "s_mov_b32 s98, 0\n"
+                "Ltop%=:\n\t"
+                "s_cmp_le_u32 s82, 32\n\t"
+                "s_cbranch_scc1 Lrefill%=\n\t"
+                "s_lshr_b32 s91, s81, 6\n\t"
+                "v_cmp_ge_u32_e32 vcc, s91, %[lim]\n\t"
+                "v_lshrrev_b32_e64 %[t0], %[sh], s91\n\t"
+                "v_add_u32_e32 %[t0], %[t0], %[delta]\n\t"
+                "s_bcnt1_i32_b64 s92, vcc\n\t"
+                "s_lshl_b64 s[80:81], s[80:81], s92\n\t"
+                "s_sub_u32 s82, s82, s92\n\t"
+                "s_add_u32 s83, s83, 1\n\t"
+                "v_readlane_b32 s93, %[t0], s92\n\t"
+                "s_cmp_gt_u32 s93, 63\n\t"
+                "s_cbranch_scc1 Lindex%=\n\t"
+                "s_nop 1\n\t"
+                "v_readlane_b32 s94, %[symlo], s93\n\t"
+                "s_cmp_lt_u32 s94, 2\n\t"
+                "s_cbranch_scc1 Lrun%=\n\t"
+                "s_cmp_lg_u64 s[88:89], 1\n\t"
+                "s_cbranch_scc1 Lpend%=\n"
+                "Lbyte%=:\n\t"
+                "s_add_u32 s94, s94, -1\n\t"
+                "s_cmp_ge_u32 s94, s90\n\t"
+                "s_cbranch_scc1 Lsym%=\n\t"
+                "v_readlane_b32 s95, %[l0], s94\n\t"
+                "v_cmp_ge_u32_e32 vcc, s94, %[lane]\n\t"
+                "v_mov_b32_dpp %[t0], %[l0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                "v_cndmask_b32_e32 %[l0], %[l0], %[t0], vcc\n\t"
+                "v_writelane_b32 %[l0], s95, 0\n\t"
+                "v_mov_b32_dpp %[stg], %[stg] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                "v_writelane_b32 %[stg], s95, 0\n\t"
+                "s_add_u32 s84, s84, 1\n"
+                "Lnext%=:\n\t"
+                "s_cmp_lt_u32 s83, 50\n\t"
+                "s_cbranch_scc1 Ltop%=\n\t"
+                "s_branch Ldone%=\n"
+                "Lrun%=:\n\t"
+                "s_lshl_b64 s[96:97], s[88:89], s94\n\t"
+                "s_add_u32 s86, s86, s96\n\t"
+                "s_addc_u32 s87, s87, s97\n\t"
+                "s_lshl_b64 s[88:89], s[88:89], 1\n\t"
+                "s_branch Lnext%=\n"
+                "Lpend%=:\n\t"
+                "s_add_u32 s96, s86, -1\n\t"
+                "s_addc_u32 s97, s87, -1\n\t"
+                "s_sub_u32 s99, s83, s84\n\t"
+                "s_add_u32 s99, s99, 13\n\t"
+                "s_cmp_lg_u32 s97, 0\n\t"
+                "s_cbranch_scc1 Lsym0%=\n\t"
+                "s_cmp_ge_u32 s96, s99\n\t"
+                "s_cbranch_scc1 Lsym0%=\n\t"
+                "v_readlane_b32 s95, %[l0], 0\n\t"
+                "v_subrev_u32_e32 %[t0], s86, %[lane]\n\t"
+                "v_lshlrev_b32_e32 %[t0], 2, %[t0]\n\t"
+                "ds_bpermute_b32 %[t0], %[t0], %[stg]\n\t"
+                "s_and_b32 s95, s95, 0xff\n\t"
+                "v_cmp_gt_u32_e32 vcc, s86, %[lane]\n\t"
+                "v_mov_b32_e32 %[t1], s95\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "v_cndmask_b32_e32 %[stg], %[t0], %[t1], vcc\n\t"
+                "s_add_u32 s84, s84, s86\n\t"
+                "s_mov_b64 s[86:87], 0\n\t"
+                "s_mov_b64 s[88:89], 1\n\t"
+                "s_branch Lbyte%=\n"
+                "Lsym0%=:\n\t"
+                "s_mov_b32 s93, s94\n\t"
+                "s_mov_b32 s98, 1\n\t"
+                "s_branch Ldone%=\n"
+                "Lsym%=:\n\t"
+                "s_add_u32 s93, s94, 1\n\t"
+                "s_mov_b32 s98, 1\n\t"
+                "s_branch Ldone%=\n"
+                "Lindex%=:\n\t"
+                "s_mov_b32 s98, 2\n\t"
+                "s_branch Ldone%=\n"
+                "Lrefill%=:\n\t"
+                "s_mov_b32 s98, 3\n"
+                "Ldone%=:\n\t"
+                "s_mov_b64 %[bb], s[80:81]\n\t"
+                "s_mov_b32 %[bc], s82\n\t"
+                "s_mov_b32 %[i], s83\n\t"
+                "s_mov_b32 %[k], s84\n\t"
+                "s_mov_b64 %[rl], s[86:87]\n\t"
+                "s_mov_b64 %[rp], s[88:89]\n\t"
+                "s_mov_b32 %[ev], s98\n\t"
+                "s_mov_b32 %[pend], s93\n\t"
+                "s_mov_b32 %[plen], s92"
+                : [bb] "+s"(bb), [bc] "+s"(bc), [i] "+s"(ii), [k] "+s"(k), [rl] "+s"(rl), [rp] "+s"(rp),
+                  [ev] "=s"(ev), [pend] "=s"(pend), [plen] "=s"(plen), [l0] "+v"(L.l0.v), [stg] "+v"(L.stg.v), [t0] "=&v"(t0), [t1] "=&v"(t1)
+                : [mfast] "s"(mfast), [lim] "v"(L.my_lim.v), [sh] "v"(L.my_sh.v), [delta] "v"(L.my_delta.v), [symlo] "v"(L.sym_lo.v), [lane] "v"(lane)
+                : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
+                  "s98", "s99", "vcc", "scc");
+            if (ev != 3u) break;
+            br.bb = bb; br.bc = bc;
+            br.refill();
+            bb = simt::uniform(br.bb); bc = simt::uniform(br.bc);
+        }
+        br.bb = bb; br.bc = bc;
+        L.k = k; L.run_length = rl; L.repeat_power = rp;
+        i = (int)ii;
+        pending = pend;
+        pending_len = plen;
+        return (int)ev;
+    }
+#endif
+    SWC_HD int hot_symbols_cxx(Loop& L, int& i, uint32_t& pending, uint32_t& pending_len) {
         simt::PT<uint32_t, N> idxv, sh, src;
         simt::PT<bool, N> pb;
         // ONE exit test at the bottom and one way round: the backend gives a loop with several exits a guard variable and
@@ -435,9 +576,8 @@ struct Stage1 {
                     L.run_length += L.repeat_power << symbol;
                     L.repeat_power <<= 1;
                 } else {
-                    bool go = true;
+                    // k + run + (the 51 - i symbols from this one on) <= 64; a run that is not positive (wrapped) goes the long way
                     if (L.repeat_power != 1ull) {
-                        // k + run + (the 51 - i symbols from this one on) <= 64; a run that is not positive (wrapped) goes the long way too
                         if (L.run_length - 1ull < (uint64_t)(13u + (uint32_t)i - L.k)) {
                             const uint32_t run = (uint32_t)L.run_length;
                             const uint32_t b = simt::wave_read<N>(L.l0, 0) & 255u;
@@ -447,10 +587,10 @@ struct Stage1 {
                             L.k += run;
                             L.run_length = 0;
                             L.repeat_power = 1;
-                        } else go = false;
+                        }
                     }
                     const uint32_t m = symbol - 1u;
-                    if (go && m < L.mfast) {
+                    if (L.repeat_power == 1ull && m < L.mfast) {
                         const uint32_t el = simt::wave_read<N>(L.l0, (int)m);
                         simt::wave_shift_up_dpp<N>(sh, L.l0, el);
                         SIMT_BEGIN(t, N) L.l0[t] = (uint32_t)t <= m ? sh[t] : L.l0[t]; SIMT_END
