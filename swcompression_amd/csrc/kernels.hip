@@ -348,8 +348,16 @@ __global__ __launch_bounds__(64) void swc_bzip2_block_kernel(Job* __restrict__ j
     Job job = jobs[g];
     const bzip2::Workspace w = bzip2::carve(ws, g, lcap);
     bzip2::stage1_job<kWave>(job, reinterpret_cast<bzip2::Stage1Lds*>(bz_lds), w, (int)threadIdx.x);
+#if defined(SWC_BZ_STOP_AFTER) && SWC_BZ_STOP_AFTER == 1   // (timing experiments only, tools/exp_bz_stages.py: wrong results)
+    if (threadIdx.x == 0) { w.hdr->pad = bzip2::kWalkDone; jobs[g].status = SWC_E_DEVICE; }
+    return;
+#endif
     __threadfence_block();   // L and the block header, written by some lanes, are read by all of them from here on
     bzip2::stage2_job(w, reinterpret_cast<uint32_t*>(bz_lds));
+#if defined(SWC_BZ_STOP_AFTER) && SWC_BZ_STOP_AFTER == 2
+    if (threadIdx.x == 0) { w.hdr->pad = bzip2::kWalkDone; jobs[g].status = SWC_E_DEVICE; }
+    return;
+#endif
     __threadfence_block();   // likewise the pointer array P
     bzip2::stage3_walk_job<kWave>(job, w, reinterpret_cast<bzip2::Stage3Lds*>(bz_lds), (int)threadIdx.x);
     if (threadIdx.x == 0 && !bzip2::stage3_expand_needed(w)) {
