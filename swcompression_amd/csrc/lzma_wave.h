@@ -238,7 +238,7 @@ struct Decoder {
 
     // The LDS copy of literal coder `c` (cache mode): a hit is four compares; see kCoderSlots.
     SWC_HD uint16_t* literal_coder(uint32_t c) {
-        static_assert(kCoderSlots == 3 || kCoderSlots == 4, "three or four tags");
+        static_assert(kCoderSlots >= 1 && kCoderSlots <= 4, "one to four tags");
         {   // a hit: the slot number by selects, ONE branch (on the device every `if` on these values is an exec-mask region)
             const uint32_t slot = (tag1 == c ? 1u : 0u) + (tag2 == c ? 2u : 0u) + (kCoderSlots > 3 && tag3 == c ? 3u : 0u);
             const bool hit = tag0 == c || slot != 0u;
