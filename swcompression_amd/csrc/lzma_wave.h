@@ -157,8 +157,12 @@ struct Decoder {
 #endif
         return (uint8_t)(w >> (8 * (k & 3u)));
     }
+#ifndef SWC_LZMA_UNIFORM_BRANCH
+#define SWC_LZMA_UNIFORM_BRANCH 1
+#endif
+    SWC_HD static bool same(bool c) { return SWC_LZMA_UNIFORM_BRANCH ? simt::wave_true(c) : c; }
     SWC_HD void normalize() {     // LZMARangeDecoder.swift:38-43
-        if (range < (1u << 24)) {
+        if (same(range < (1u << 24))) {
             range <<= 8;
             code = (code << 8) | next_byte();
         }
@@ -167,7 +171,7 @@ struct Decoder {
         const uint32_t pr = *p;
         uint32_t bound = (range >> 11) * pr;
         int sym;
-        if (code < bound) {
+        if (same(code < bound)) {
             *p = (uint16_t)(pr + ((2048u - pr) >> 5));
             range = bound;
             sym = 0;
@@ -184,7 +188,7 @@ struct Decoder {
         uint32_t pr = *p;
         uint32_t bound = (range >> 11) * pr;
         int sym;
-        if (code < bound) {
+        if (same(code < bound)) {
             if (lane == 0) *p = (uint16_t)(pr + ((2048u - pr) >> 5));
             range = bound;
             sym = 0;
@@ -242,7 +246,7 @@ struct Decoder {
         {   // a hit: the slot number by selects, ONE branch (on the device every `if` on these values is an exec-mask region)
             const uint32_t slot = (tag1 == c ? 1u : 0u) + (tag2 == c ? 2u : 0u) + (kCoderSlots > 3 && tag3 == c ? 3u : 0u);
             const bool hit = tag0 == c || slot != 0u;
-            if (hit) return probs + kSlotBase + slot * 0x300;
+            if (same(hit)) return probs + kSlotBase + slot * 0x300;
         }
         const uint32_t v = victim;
         victim = victim + 1 == (uint32_t)kCoderSlots ? 0u : victim + 1;
@@ -305,7 +309,7 @@ struct Decoder {
     // put(): LZMADecoder.swift:288-294.  One byte, written by lane 0.
     SWC_HD void put(uint8_t b) {
         SWC_LZMA_PROF(9)
-        if (pos < cap) out[pos] = b;   // (every lane stores the same byte to the same address: one write, no second mask region)
+        if (same(pos < cap)) out[pos] = b;   // (every lane stores the same byte to the same address: one write, no second mask region)
         overflow = overflow || pos >= cap;
         prev_byte = b;
         pos++;
@@ -315,9 +319,9 @@ struct Decoder {
     SWC_HD uint8_t byte_at(uint64_t distance) {
         SWC_LZMA_PROF(2)
         uint64_t idx;
-        if (distance <= pos) idx = pos - distance;
+        if (same(distance <= pos)) idx = pos - distance;
         else { trap = true; return 0; }  // the wrap branch indexes at or past out.count (dictSize >= distance): Swift trap
-        if (idx >= cap) { overflow = true; return 0; }
+        if (same(idx >= cap)) { overflow = true; return 0; }
         return out[idx];
     }
     // `len` bytes from `distance` back, spread over the wave (LZMADecoder.swift:278-282).
@@ -325,13 +329,13 @@ struct Decoder {
         SWC_LZMA_PROF(1)
         SWC_LZMA_COUNT(5, 1);
         const bool fits = pos + len <= cap;
-        if (fits) {
+        if (same(fits)) {
             gptr dst = out + pos;
             uint32_t last = 0;   // the byte this lane wrote last: the lane that wrote dst[len - 1] holds the new prev_byte
-            if ((len <= (uint32_t)WAVE) & (distance >= len)) {
+            if (same((len <= (uint32_t)WAVE) & (distance >= len))) {
                 // the common case in one step: no loop, no overlap
                 if ((uint32_t)lane < len) { last = dst[(int64_t)lane - (int64_t)distance]; dst[lane] = (uint8_t)last; }
-            } else if (distance >= len) {
+            } else if (same(distance >= len)) {
                 for (uint32_t i = (uint32_t)lane; i < len; i += WAVE) { last = dst[(int64_t)i - (int64_t)distance]; dst[i] = (uint8_t)last; }
             } else {
                 // overlapping: every byte is a copy of one of the `distance` bytes before `pos`
@@ -369,7 +373,7 @@ struct Decoder {
         // reference's trap and not an error computed from the zeros behind it.  (On the device each such test is an exec-mask
         // region in the serial chain; there were six to eight per symbol.)
         for (;;) {
-            if (overflow || wk > 4u * 64u - kSymbolBytes || uncompressed_size == 0) {   // (one test in the common case)
+            if (same(overflow || wk > 4u * 64u - kSymbolBytes || uncompressed_size == 0)) {   // (one test in the common case)
                 if (overflow) return SWC_E_CAPACITY;
                 ensure_window();
                 if (uncompressed_size == 0 && code == 0) break;  // :114
@@ -378,7 +382,7 @@ struct Decoder {
             int is_match;
             { SWC_LZMA_PROF(8) is_match = bit(&probs[P_IS_MATCH + (state << 4) + pos_state]); }
             if (is_match == 0) {
-                if (uncompressed_size == 0) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :121
+                if (same(uncompressed_size == 0)) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :121
                 SWC_LZMA_PROF(3)
                 SWC_LZMA_COUNT(6, 1);
                 const uint32_t prev = pos == dict_start ? 0u : prev_byte;
@@ -386,7 +390,7 @@ struct Decoder {
                 int symbol = 1;
                 if (!spill) {
                     uint16_t* lpb = cached ? literal_coder(lit_state) : &probs[P_LITERAL + lit_state * 0x300];
-                    if (state >= 7) {
+                    if (same(state >= 7)) {
                         SWC_LZMA_PROF(10)
                         SWC_LZMA_COUNT(11, 1);
                         uint32_t match_byte = byte_at(rep0 + 1);
@@ -395,7 +399,7 @@ struct Decoder {
                             match_byte = (match_byte << 1) & 0xFF;
                             const int b = bit(&lpb[((1 + match_bit) << 8) + symbol]);
                             symbol = (symbol << 1) | b;
-                            if (match_bit != b) break;
+                            if (same(match_bit != b)) break;
                         } while (symbol < 0x100);
                     }
                     if (symbol == 1) {   // not in matched mode: exactly eight decisions (a constant trip count: no loop test in the chain)
@@ -418,7 +422,7 @@ struct Decoder {
                     }
                     while (symbol < 0x100) symbol = (symbol << 1) | bit_spill(&lpb[symbol]);
                 }
-                if (trapped()) return SWC_E_REF_TRAP;
+                if (same(trapped())) return SWC_E_REF_TRAP;
                 uncompressed_size -= 1;
                 put((uint8_t)(symbol - 0x100));
                 state = state < 4 ? 0 : state < 10 ? state - 3 : state - 6;
@@ -431,15 +435,15 @@ struct Decoder {
             SWC_LZMA_PROF(4)
             is_rep = bit(&probs[P_IS_REP + state]) != 0;
             if (is_rep) {
-                if (uncompressed_size == 0) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :178
-                if (pos == dict_start) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_WINDOW_IS_EMPTY;                  // :181
+                if (same(uncompressed_size == 0)) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :178
+                if (same(pos == dict_start)) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_WINDOW_IS_EMPTY;                  // :181
                 if (bit(&probs[P_IS_REP_G0 + state]) == 0) {
                     if ((state << 4) + pos_state >= 191) return SWC_E_REF_TRAP;            // reference index 241+... == 432
                     if (bit(&probs[P_IS_REP0_LONG + (state << 4) + pos_state]) == 0) {
                         state = state < 7 ? 9 : 11;
                         SWC_LZMA_COUNT(7, 1);
                         const uint8_t b = byte_at(rep0 + 1);
-                        if (trapped()) return SWC_E_REF_TRAP;
+                        if (same(trapped())) return SWC_E_REF_TRAP;
                         put(b);
                         uncompressed_size -= 1;
                         continue;
@@ -490,7 +494,7 @@ struct Decoder {
                 const bool end_marker = !is_rep && rep0 == 0xFFFFFFFFull;
                 const bool odd = end_marker | (!is_rep & (uncompressed_size == 0)) | (!is_rep & ((rep0 >= dict_size) | ((rep0 > pos) & (pos < dict_size))))
                                | trapped() | ((uncompressed_size > -1) & (uncompressed_size < (int64_t)len)) | (rep0 + 1 > pos);
-                if (odd) {
+                if (same(odd)) {
                     if (end_marker) {                                                          // :260
                         if (code != 0) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_RANGE_DECODER_FINISH_ERROR;   // :261
                         break;

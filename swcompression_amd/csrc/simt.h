@@ -275,6 +275,15 @@ SWC_HD int ctz64(uint64_t m) {   // m != 0
     return __builtin_ctzll(m);
 #endif
 }
+// a condition that is the same in every lane, said so: the branch on it becomes a scalar branch (v_cmp, s_cmp_lg_u64 vcc,
+// s_cbranch) instead of an exec-mask region with both sides issued -- for code that runs redundantly on all lanes of a wave
+SWC_D bool wave_true(bool c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(c) != 0ull;
+#else
+    return c;
+#endif
+}
 // make a value that is the same in every lane live in a scalar register
 SWC_D uint32_t uniform(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
