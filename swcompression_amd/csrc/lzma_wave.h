@@ -39,9 +39,10 @@ constexpr int P_IS_REP0_LONG = 240;  // [12 << 4]
 constexpr int P_POS_SLOT = 432;      // [4][64]
 constexpr int P_ALIGN = 688;         // [16]
 constexpr int P_POS_DEC = 704;       // [115]  (reference: 1 + 128 - 14 cells, LZMADecoder.swift:96-97)
-constexpr int P_LEN = 819;           // choice, choice2, low[16][8], mid[16][8], high[256] = 514
-constexpr int P_REP_LEN = 1333;
-constexpr int P_LITERAL = 1847;      // [0x300 << (lc+lp)]
+// (the bit trees start at EVEN cells: tree() reads the two children of a node as one aligned dword)
+constexpr int P_LEN = 820;           // choice, choice2, low[16][8], mid[16][8], high[256] = 514
+constexpr int P_REP_LEN = 1334;
+constexpr int P_LITERAL = 1848;      // [0x300 << (lc+lp)]
 constexpr int kMaxLdsLitBits = 4;    // largest lc + lp any build keeps in LDS (host emulation, tests)
 constexpr int kProbCells = P_LITERAL + (0x300 << kMaxLdsLitBits);  // 14,135
 // LDS of a wave when literal coders up to lc + lp = `bits` stay in LDS (more bits spill to the HBM workspace):
@@ -214,9 +215,44 @@ struct Decoder {
         } while (count > 0);
         return res;
     }
-    SWC_HD int tree(uint16_t* p, int nbits) {  // LZMABitTreeDecoder.swift:18-24
+    // bit() for a cell whose value is already in a register
+    SWC_HD int bit_known(uint16_t* p, uint32_t pr) {
+        uint32_t bound = (range >> 11) * pr;
+        int sym;
+        if (same(code < bound)) {
+            *p = (uint16_t)(pr + ((2048u - pr) >> 5));
+            range = bound;
+            sym = 0;
+        } else {
+            *p = (uint16_t)(pr - (pr >> 5));
+            code -= bound;
+            range -= bound;
+            sym = 1;
+        }
+        normalize();
+        return sym;
+    }
+#ifndef SWC_LZMA_PAIR_READ
+#define SWC_LZMA_PAIR_READ 0
+#endif
+    // LZMABitTreeDecoder.swift:18-24.  SWC_LZMA_PAIR_READ (measured, off: 880 ms against 862, profiles/r04_experiments.txt): the
+    // children of node m are the cells 2m and 2m + 1, ONE aligned dword (`p` starts at an even cell) that can be read while the
+    // decision at m is still being taken, so that the LDS round trip leaves the serial chain -- but the two instructions it
+    // adds per decision cost more than the latency it hides, as the chain microbenchmark of round 3 had said.
+    SWC_HD int tree(uint16_t* p, int nbits) {
         int m = 1;
-        for (int i = 0; i < nbits; i++) m = (m << 1) + bit(&p[m]);
+        if (!SWC_LZMA_PAIR_READ) {
+            for (int i = 0; i < nbits; i++) m = (m << 1) + bit(&p[m]);
+            return m - (1 << nbits);
+        }
+        uint32_t pr = p[1];
+        for (int i = 0; i < nbits; i++) {
+            uint32_t pair = 0;
+            if (i + 1 < nbits) pair = *(const uint32_t*)__builtin_assume_aligned(p + 2 * m, 4);
+            const int b = bit_known(&p[m], pr);
+            pr = b ? pair >> 16 : pair & 0xFFFFu;
+            m = (m << 1) + b;
+        }
         return m - (1 << nbits);
     }
     SWC_HD int tree_reverse(uint16_t* p, int limit, int start, int bits) {  // :26-43
@@ -403,8 +439,11 @@ struct Decoder {
                         } while (symbol < 0x100);
                     }
                     if (symbol == 1) {   // not in matched mode: exactly eight decisions (a constant trip count: no loop test in the chain)
+                        if (SWC_LZMA_PAIR_READ) symbol = 0x100 + tree(lpb, 8);   // (every literal coder starts at an even cell)
+                        else {
 #pragma unroll
-                        for (int i = 0; i < 8; i++) symbol = (symbol << 1) | bit(&lpb[symbol]);
+                            for (int i = 0; i < 8; i++) symbol = (symbol << 1) | bit(&lpb[symbol]);
+                        }
                     } else {
                         while (symbol < 0x100) symbol = (symbol << 1) | bit(&lpb[symbol]);
                     }
