@@ -419,7 +419,7 @@ struct Stage1 {
 #endif
     }
 #if defined(__HIP_DEVICE_COMPILE__)
-    // The same loop as hot_symbols_cxx below, written in gfx950 assembly: 33 instructions per byte symbol and 24 per RUNA /
+    // The same loop as hot_symbols_cxx below, written in gfx950 assembly: 32 instructions per byte symbol and 24 per RUNA /
     // RUNB against the 58 / 41 the compiler makes of the C++ (it keeps the loop-carried values in different registers on
     // different paths and copies them at every merge point, and it will not shift a register in place).  All scalar state
     // lives in fixed registers inside the block (s80 - s99: the halves of the 64-bit values are needed on their own, and an
