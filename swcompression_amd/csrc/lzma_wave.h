@@ -4,14 +4,17 @@
 // decoder (LZMARangeDecoder.swift:20-80), bit-tree / length decoders (LZMABitTreeDecoder.swift:18-43,
 // LZMALenDecoder.swift:30-38) and the LZMA2 chunk framing (Sources/LZMA2/LZMA2Decoder.swift:34-99).
 //
-// The range coder is a strictly serial chain, so a stream cannot be split; the adaptive probability model (up to 14,135
+// The range coder is a strictly serial chain, so a stream cannot be split; the adaptive probability model (up to 14,136
 // 11-bit cells for lc + lp <= 4) is far too large to keep per LANE, so one wavefront owns one stream and all 64 lanes execute
-// the decode chain redundantly (wave-uniform control flow, LDS broadcasts); the LZ copy of every match is spread over the
-// lanes.  The kernel is bound by the latency of that one chain, so its speed is the number of streams a CU holds -- i.e. the
-// LDS a stream needs.  Two layouts (kernels.hip picks):
-//   coder cache (the default when the launch has a workspace): the 1,847 non-literal cells and FOUR of the literal coders
-//       (0x300 cells each) in LDS, all literal coders in the workspace; a literal whose coder is not cached writes the victim
-//       back and loads its own (coders never used since the last reset are filled, not loaded): 9,840 B => 16 streams per CU;
+// the decode chain redundantly; the LZ copy of every match is spread over the lanes.  Every branch on a value that is the same
+// in all lanes is SAID to be so (same() = simt::wave_true: v_cmp + s_cmp_lg_u64 vcc + s_cbranch) -- the compiler cannot know
+// it of a value read from LDS, and made each of them an exec-mask region with both sides issued; the decoded bit then is a
+// constant per side, and tree indices, `state` and the tests on them live on the scalar unit (56 VGPRs).  The kernel is bound
+// by the latency of its one chain, so its speed is the number of streams a CU holds -- i.e. the LDS a stream needs.  Two
+// layouts (kernels.hip picks):
+//   coder cache (the default when the launch has a workspace): the 1,848 non-literal cells and ONE literal coder (0x300
+//       cells) in LDS, all literal coders in the workspace; a literal whose coder is not the cached one writes that back and
+//       loads its own (coders never used since the last reset are filled, not loaded): 5,232 B => 31 streams per CU;
 //   whole model in LDS (no workspace; round 2's layout): every literal coder of lc + lp <= 4 in LDS, 28,272 B => 5 streams
 //       per CU; lc + lp > 4 (legal for .lzma, never produced by xz) reports SWC_E_NEED_WORKSPACE and is re-run with one.
 // The next 256 input bytes sit in a register spread over the lanes and are refilled at one place per symbol.
@@ -52,12 +55,16 @@ constexpr int kLdsBytesPerWave = lds_bytes_for(kMaxLdsLitBits);
 // LDS as a CACHE of the literal coders (round 3).  The kernel is latency-bound on one serial chain per stream, so its speed
 // is the number of streams a CU holds, and that is set by the model in LDS: 15,984 B with the eight literal coders of
 // lc + lp = 3 -> 10 streams.  A literal coder (0x300 cells) is picked by the top bits of the previous byte; data use few of
-// them at a time (text: four), so LDS keeps kCoderSlots of them and all coders live in the HBM workspace: 9,840 B -> 16
-// streams per CU.  A miss writes the victim back and loads the coder (1.5 KB each way, all lanes; a coder nobody has used
+// them at a time (text: four), so LDS keeps kCoderSlots of them and all coders live in the HBM workspace (round 3: four
+// slots, 9,840 B -> 16 streams per CU).  A miss writes the victim back and loads the coder (1.5 KB each way, all lanes; a coder nobody has used
 // since the last model reset is filled with the initial value instead); slots are replaced round-robin.  Any lc + lp works
 // this way (the old path kept lc + lp <= 3 in LDS and decoded larger models cell by cell from HBM).
+// Round 4: with every branch on a wave-identical value a scalar branch (simt::wave_true) the kernel needs 56 VGPRs and is
+// bound by the latency of its chain again, i.e. by the streams per CU: ONE slot (5,232 B -> 31 streams per CU) beats two (24)
+// and four (16) on every payload -- text 751 / 776 / 945 ms, binary records (all eight coders live) 2,462 / 2,612 / 2,818,
+// P-mix 1,732 / 1,799 / 1,941 (profiles/r04_experiments.txt).
 #ifndef SWC_LZMA_SLOTS
-#define SWC_LZMA_SLOTS 4
+#define SWC_LZMA_SLOTS 1
 #endif
 constexpr int kCoderSlots = SWC_LZMA_SLOTS;
 constexpr int kSlotBase = (P_LITERAL + 3) & ~3;   // first cell of slot 0: dword-aligned copies
@@ -392,15 +399,15 @@ struct Decoder {
     // LZMADecoder.swift:107-284.  Returns an swc_status.
     SWC_HD int decode() {
         SWC_LZMA_PROF(0)
-        if (n - ip() < 5) return SWC_E_LZMA_RANGE_DECODER_INIT_ERROR;  // LZMARangeDecoder.swift:21
+        if (same(n - ip() < 5)) return SWC_E_LZMA_RANGE_DECODER_INIT_ERROR;  // LZMARangeDecoder.swift:21
         ensure_window();
         const uint8_t first = next_byte();
         code = 0;
         for (int i = 0; i < 4; i++) code = (code << 8) | next_byte();  // uint32().byteSwapped
         range = 0xFFFFFFFFu;
-        if (first != 0) return SWC_E_LZMA_RANGE_DECODER_INIT_ERROR;
-        if (!have_model) return SWC_E_REF_TRAP;  // `probabilities` is still empty: index trap at :119
-        if (need_ws) return SWC_E_NEED_WORKSPACE;
+        if (same(first != 0)) return SWC_E_LZMA_RANGE_DECODER_INIT_ERROR;
+        if (same(!have_model)) return SWC_E_REF_TRAP;  // `probabilities` is still empty: index trap at :119
+        if (same(need_ws)) return SWC_E_NEED_WORKSPACE;
         const int lit_bits = lc + lp;
         const bool spill = !cached && lit_bits > lds_bits;
 
@@ -410,9 +417,9 @@ struct Decoder {
         // region in the serial chain; there were six to eight per symbol.)
         for (;;) {
             if (same(overflow || wk > 4u * 64u - kSymbolBytes || uncompressed_size == 0)) {   // (one test in the common case)
-                if (overflow) return SWC_E_CAPACITY;
+                if (same(overflow)) return SWC_E_CAPACITY;
                 ensure_window();
-                if (uncompressed_size == 0 && code == 0) break;  // :114
+                if (same(uncompressed_size == 0 && code == 0)) break;  // :114
             }
             const int pos_state = (int)(pos & ((1u << pb) - 1));
             int is_match;
@@ -456,7 +463,7 @@ struct Decoder {
                             match_byte = (match_byte << 1) & 0xFF;
                             const int b = bit_spill(&lpb[((1 + match_bit) << 8) + symbol]);
                             symbol = (symbol << 1) | b;
-                            if (match_bit != b) break;
+                            if (same(match_bit != b)) break;
                         } while (symbol < 0x100);
                     }
                     while (symbol < 0x100) symbol = (symbol << 1) | bit_spill(&lpb[symbol]);
@@ -477,7 +484,7 @@ struct Decoder {
                 if (same(uncompressed_size == 0)) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :178
                 if (same(pos == dict_start)) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_WINDOW_IS_EMPTY;                  // :181
                 if (bit(&probs[P_IS_REP_G0 + state]) == 0) {
-                    if ((state << 4) + pos_state >= 191) return SWC_E_REF_TRAP;            // reference index 241+... == 432
+                    if (same((state << 4) + pos_state >= 191)) return SWC_E_REF_TRAP;            // reference index 241+... == 432
                     if (bit(&probs[P_IS_REP0_LONG + (state << 4) + pos_state]) == 0) {
                         state = state < 7 ? 9 : 11;
                         SWC_LZMA_COUNT(7, 1);
@@ -534,46 +541,46 @@ struct Decoder {
                 const bool odd = end_marker | (!is_rep & (uncompressed_size == 0)) | (!is_rep & ((rep0 >= dict_size) | ((rep0 > pos) & (pos < dict_size))))
                                | trapped() | ((uncompressed_size > -1) & (uncompressed_size < (int64_t)len)) | (rep0 + 1 > pos);
                 if (same(odd)) {
-                    if (end_marker) {                                                          // :260
-                        if (code != 0) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_RANGE_DECODER_FINISH_ERROR;   // :261
+                    if (same(end_marker)) {                                                          // :260
+                        if (same(code != 0)) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_RANGE_DECODER_FINISH_ERROR;   // :261
                         break;
                     }
-                    if (!is_rep) {
-                        if (uncompressed_size == 0) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :266
-                        if (rep0 >= dict_size || (rep0 > pos && pos < dict_size)) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_NOT_ENOUGH_TO_REPEAT;  // :269
+                    if (same(!is_rep)) {
+                        if (same(uncompressed_size == 0)) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_EXCEEDED_UNCOMPRESSED_SIZE;  // :266
+                        if (same(rep0 >= dict_size || (rep0 > pos && pos < dict_size))) return trapped() ? SWC_E_REF_TRAP : SWC_E_LZMA_NOT_ENOUGH_TO_REPEAT;  // :269
                     }
-                    if (trapped()) return SWC_E_REF_TRAP;
-                    if (uncompressed_size > -1 && uncompressed_size < (int64_t)len) return SWC_E_LZMA_REPEAT_WILL_EXCEED;  // :275
-                    if (rep0 + 1 > pos) return SWC_E_REF_TRAP;  // byte(at:) would index past out.count (App. A L2)
+                    if (same(trapped())) return SWC_E_REF_TRAP;
+                    if (same(uncompressed_size > -1 && uncompressed_size < (int64_t)len)) return SWC_E_LZMA_REPEAT_WILL_EXCEED;  // :275
+                    if (same(rep0 + 1 > pos)) return SWC_E_REF_TRAP;  // byte(at:) would index past out.count (App. A L2)
                 }
             }
             copy_match(rep0 + 1, len);
             uncompressed_size -= len;
         }
-        if (trapped()) return SWC_E_REF_TRAP;
-        if (overflow) return SWC_E_CAPACITY;
+        if (same(trapped())) return SWC_E_REF_TRAP;
+        if (same(overflow)) return SWC_E_CAPACITY;
         return SWC_OK;
     }
 
     // LZMA2Decoder.init + decode(): Sources/LZMA2/LZMA2Decoder.swift:17-99
     SWC_HD int decode_lzma2(uint8_t dict_byte) {
-        if (dict_byte & 0xC0) return SWC_E_LZMA2_WRONG_DICTIONARY_SIZE;  // :21
+        if (same(dict_byte & 0xC0)) return SWC_E_LZMA2_WRONG_DICTIONARY_SIZE;  // :21
         const int bits = dict_byte & 0x3F;
-        if (bits >= 40) return SWC_E_LZMA2_WRONG_DICTIONARY_SIZE;        // :24
+        if (same(bits >= 40)) return SWC_E_LZMA2_WRONG_DICTIONARY_SIZE;        // :24
         uint32_t ds = (uint32_t)(2 | (bits & 1)) << (bits / 2 + 11);
         dict_size = ds < 4096 ? 4096 : ds;                               // didSet clamp, LZMAProperties.swift:26-32
         for (;;) {
             ensure_window();
             const uint32_t control = next_byte();                        // :36
-            if (trapped()) return SWC_E_REF_TRAP;
-            if (control == 0) return SWC_OK;
-            if (control == 1 || control == 2) {
-                if (control == 1) reset_dictionary();
+            if (same(trapped())) return SWC_E_REF_TRAP;
+            if (same(control == 0)) return SWC_OK;
+            if (same(control == 1 || control == 2)) {
+                if (same(control == 1)) reset_dictionary();
                 const uint32_t b1 = next_byte(), b2 = next_byte();       // decodeUncompressed :84-89
-                if (trapped()) return SWC_E_REF_TRAP;
+                if (same(trapped())) return SWC_E_REF_TRAP;
                 const uint64_t size = ((uint64_t)b1 << 8) + b2 + 1;
-                if (n - ip() < size) return SWC_E_REF_TRAP;                // byte() past the end inside the copy loop
-                if (pos + size <= cap) {
+                if (same(n - ip() < size)) return SWC_E_REF_TRAP;                // byte() past the end inside the copy loop
+                if (same(pos + size <= cap)) {
                     for (uint64_t i = (uint64_t)lane; i < size; i += WAVE) out[pos + i] = in[ip() + i];
                     prev_byte = in[ip() + size - 1];
                 } else {
@@ -582,31 +589,31 @@ struct Decoder {
                 wk += (uint32_t)size;   // (<= 65,536; the loop top reloads the window)
                 pos += size;
                 if (pos - dict_start >= dict_size) dict_start = pos - dict_size + 1;
-                if (overflow) return SWC_E_CAPACITY;
+                if (same(overflow)) return SWC_E_CAPACITY;
                 continue;
             }
-            if (control <= 0x7F) return SWC_E_LZMA2_WRONG_CONTROL_BYTE;  // :45
+            if (same(control <= 0x7F)) return SWC_E_LZMA2_WRONG_CONTROL_BYTE;  // :45
             const int reset = (control & 0x60) >> 5;                     // dispatch :56-82
             const uint32_t u1 = next_byte(), u2 = next_byte();
             const int64_t unpack = ((int64_t)(control & 0x1F) << 16) + ((int64_t)u1 << 8) + u2 + 1;
             const uint32_t c1 = next_byte(), c2 = next_byte();
             const int64_t comp = ((int64_t)c1 << 8) + c2 + 1;
-            if (trapped()) return SWC_E_REF_TRAP;
-            if (reset == 1) {
+            if (same(trapped())) return SWC_E_REF_TRAP;
+            if (same(reset == 1)) {
                 reset_state_and_decoders();
-            } else if (reset >= 2) {                                     // updateProperties :95-99
+            } else if (same(reset >= 2)) {                                     // updateProperties :95-99
                 const uint32_t pbyte = next_byte();
-                if (trapped()) return SWC_E_REF_TRAP;
-                if (pbyte >= 225) return SWC_E_LZMA_WRONG_PROPERTIES;
+                if (same(trapped())) return SWC_E_REF_TRAP;
+                if (same(pbyte >= 225)) return SWC_E_LZMA_WRONG_PROPERTIES;
                 lc = pbyte % 9; pb = (pbyte / 9) / 5; lp = (pbyte / 9) % 5;
                 reset_state_and_decoders();
-                if (reset == 3) reset_dictionary();
+                if (same(reset == 3)) reset_dictionary();
             }
             uncompressed_size = unpack;
             const uint64_t out_start = pos, in_start = ip();
             const int st = decode();
-            if (st) return st;
-            if (!(unpack == (int64_t)(pos - out_start) && (int64_t)(ip() - in_start) == comp)) return SWC_E_LZMA2_WRONG_SIZES;  // :79-81
+            if (same(st)) return st;
+            if (same(!(unpack == (int64_t)(pos - out_start) && (int64_t)(ip() - in_start) == comp))) return SWC_E_LZMA2_WRONG_SIZES;  // :79-81
         }
     }
 };
