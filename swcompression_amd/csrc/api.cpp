@@ -311,7 +311,7 @@ size_t swc_batch_workspace_bytes(int codec, size_t n_jobs, uint64_t max_out_cap)
     (void)max_out_cap;
     switch (codec) {
         case SWC_CODEC_LZMA:
-        case SWC_CODEC_LZMA2: return n_jobs * lzma_spill_bytes_per_job();  // the literal coders of every stream (LDS caches four of them); optional, see the header
+        case SWC_CODEC_LZMA2: return n_jobs * lzma_spill_bytes_per_job();  // the literal coders of every stream (LDS caches one of them) + the long-length trees; optional, see the header
         case SWC_CODEC_BZIP2_BLOCK: return n_jobs * bzip2_ws_bytes_per_job((size_t)max_out_cap + 64);  // L is never longer than the output
         case SWC_CODEC_DEFLATE: return n_jobs * inflate_ws_bytes_per_job(max_out_cap);  // match records + literal stream of phase 1 (lz_resolve.h)
         case SWC_CODEC_LZ4_BLOCK: return n_jobs * lz4_ws_bytes_per_job(max_out_cap);     // same layout (lz4_wave.h); without it blocks decode one per lane

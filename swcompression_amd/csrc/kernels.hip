@@ -286,7 +286,7 @@ hipError_t launch_lz4_compress(Job* jobs, size_t n, hipStream_t stream) {
 // CU; streams with lc + lp > 3 then run their literal coder out of HBM.  Without a workspace lc + lp = 4 still fits in
 // LDS (28,272 B, 5 streams per CU) and only lc + lp > 4 (legal for .lzma, never produced by xz) reports
 // SWC_E_NEED_WORKSPACE.  `spill` holds kLzmaSpillBytes per job.
-constexpr size_t kLzmaSpillBytes = (size_t)(0x300u << 12) * 2;
+constexpr size_t kLzmaSpillBytes = (size_t)(0x300u << 12) * 2 + 1024;   // every literal coder of lc + lp <= 12, then the two `high` length trees
 
 // LDSBITS >= 0: the literal coders of lc + lp <= LDSBITS in LDS (no workspace: 4 -> 28 KB, 5 streams per CU);
 // LDSBITS < 0: LDS as a cache of kCoderSlots literal coders (one: 5,232 B, 31 streams per CU), all of them in the workspace (lzma_wave.h)

@@ -43,8 +43,10 @@ constexpr int P_POS_SLOT = 432;      // [4][64]
 constexpr int P_ALIGN = 688;         // [16]
 constexpr int P_POS_DEC = 704;       // [115]  (reference: 1 + 128 - 14 cells, LZMADecoder.swift:96-97)
 // (the bit trees start at EVEN cells: tree() reads the two children of a node as one aligned dword)
-constexpr int P_LEN = 820;           // choice, choice2, low[16][8], mid[16][8], high[256] = 514
-constexpr int P_REP_LEN = 1334;
+constexpr int P_LEN = 820;           // choice, choice2, low[16][8], mid[16][8] = 258
+constexpr int P_REP_LEN = 1078;
+constexpr int P_LEN_HIGH = 1336;     // high[256] of the length coder, high[256] of the rep-length coder: lengths >= 18, rare --
+                                     // the LAST non-literal cells, so that the coder cache can leave them out of LDS (kSlotBase)
 constexpr int P_LITERAL = 1848;      // [0x300 << (lc+lp)]
 constexpr int kMaxLdsLitBits = 4;    // largest lc + lp any build keeps in LDS (host emulation, tests)
 constexpr int kProbCells = P_LITERAL + (0x300 << kMaxLdsLitBits);  // 14,135
@@ -67,10 +69,14 @@ constexpr int kLdsBytesPerWave = lds_bytes_for(kMaxLdsLitBits);
 #define SWC_LZMA_SLOTS 1
 #endif
 constexpr int kCoderSlots = SWC_LZMA_SLOTS;
-constexpr int kSlotBase = (P_LITERAL + 3) & ~3;   // first cell of slot 0: dword-aligned copies
+// (Round 4: the slots start where the two `high` length trees would be -- in cache mode those 512 cells live in the workspace
+// behind the literal coders and are decoded through bit_spill(): 1 KB less LDS per stream, 4,208 B with one slot.)
+constexpr int kSlotBase = P_LEN_HIGH;             // first cell of slot 0 (a multiple of four: dword-aligned copies)
+static_assert(kSlotBase % 4 == 0, "slot alignment");
+constexpr size_t kSpillHighCell = (size_t)0x300u << 12;   // workspace: all literal coders of lc + lp <= 12, then the 512 `high` cells
 constexpr int lds_bytes_cached() { return (((kSlotBase + 0x300 * kCoderSlots) * 2 + 15) / 16) * 16; }
 constexpr uint32_t kNoCoder = 0xFFFFFFFFu;
-constexpr int LEN_CHOICE = 0, LEN_CHOICE2 = 1, LEN_LOW = 2, LEN_MID = 2 + 128, LEN_HIGH = 2 + 256;
+constexpr int LEN_CHOICE = 0, LEN_CHOICE2 = 1, LEN_LOW = 2, LEN_MID = 2 + 128;
 
 // cycle accounting of profile builds (-DSWC_PROFILE, tools/exp_profile_lzma.py): a scope adds its cycles to one slot
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -277,10 +283,16 @@ struct Decoder {
         trap = trap || bad;
         return bad ? 0 : sym;
     }
-    SWC_HD int len_decode(uint16_t* p, int pos_state) {  // LZMALenDecoder.swift:30-38
+    SWC_HD int len_decode(uint16_t* p, int pos_state, int which) {  // LZMALenDecoder.swift:30-38; which: 0 length, 1 rep length
         if (bit(&p[LEN_CHOICE]) == 0) return tree(&p[LEN_LOW + pos_state * 8], 3);
         if (bit(&p[LEN_CHOICE2]) == 0) return 8 + tree(&p[LEN_MID + pos_state * 8], 3);
-        return 16 + tree(&p[LEN_HIGH], 8);
+        if (cached) {   // the `high` trees are not in LDS (see kSlotBase)
+            SWC_AS_GLOBAL uint16_t* hp = lit_spill + kSpillHighCell + (size_t)which * 256;
+            int m = 1;
+            for (int i = 0; i < 8; i++) m = (m << 1) + bit_spill(&hp[m]);
+            return 16 + m - 256;
+        }
+        return 16 + tree(&probs[P_LEN_HIGH + which * 256], 8);
     }
 
     // The LDS copy of literal coder `c` (cache mode): a hit is four compares; see kCoderSlots.
@@ -319,7 +331,8 @@ struct Decoder {
             state = 0;
             rep0 = rep1 = rep2 = rep3 = 0;
             need_ws = lit_spill == nullptr;
-            for (int i = lane; i < P_LITERAL; i += WAVE) probs[i] = 1024;
+            for (int i = lane; i < kSlotBase; i += WAVE) probs[i] = 1024;
+            if (lit_spill) for (int i = lane; i < 512; i += WAVE) lit_spill[kSpillHighCell + (size_t)i] = 1024;   // the `high` length trees
             tag0 = tag1 = tag2 = tag3 = kNoCoder;   // (dropped, not written back: the model starts over)
             victim = 0;
             const int lit_bits = lc + lp;
@@ -510,11 +523,11 @@ struct Decoder {
                     rep1 = rep0;
                     rep0 = dist;
                 }
-                len = (uint32_t)len_decode(&probs[P_REP_LEN], pos_state);
+                len = (uint32_t)len_decode(&probs[P_REP_LEN], pos_state, 1);
                 state = state < 7 ? 8 : 11;
             } else {
                 rep3 = rep2; rep2 = rep1; rep1 = rep0;
-                len = (uint32_t)len_decode(&probs[P_LEN], pos_state);
+                len = (uint32_t)len_decode(&probs[P_LEN], pos_state, 0);
                 state = state < 7 ? 7 : 10;
                 const int len_state = len > 3 ? 3 : (int)len;
                 const int pos_slot = tree(&probs[P_POS_SLOT + len_state * 64], 6);

@@ -70,7 +70,7 @@ extern "C" void emu_lz4_compress(swc::Job* jobs, size_t n) {
 // workspace, and the old spill path); mode 1: LDS as a cache of four literal coders (the kernel with a workspace).
 extern "C" void emu_lzma_mode(swc::Job* jobs, size_t n, int is_lzma2, int mode) {
     std::vector<uint16_t> probs(swc::lzma::kProbCells + 8);
-    std::vector<uint16_t> spill((size_t)0x300 << 12);
+    std::vector<uint16_t> spill(((size_t)0x300 << 12) + 512);   // (+ the two `high` length trees of the cache mode)
     for (size_t g = 0; g < n; g++) {
         std::fill(probs.begin(), probs.end(), (uint16_t)0xBEEF);
         std::fill(spill.begin(), spill.end(), (uint16_t)0xDEAD);
