@@ -4,7 +4,7 @@
 # passes.  Usage: gpu_final.sh <tag> [parts...]   parts: tests bench trace pmc sq (default: all)
 # Outputs under gpurun_out/<tag>/; tools/collect_profiles.sh <tag> copies what is to be judged into profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-final}; shift; PARTS=${@:-tests bench trace pmc sq}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
-WL="deflate64k lz4_4m bzip2_900k lzma2_256k"
+WL=${WL:-"deflate64k lz4_4m bzip2_900k lzma2_256k"}; XWL=${XWL-"deflate64k_mix lz4_compress_4m"}
 for P in $PARTS; do case $P in
 tests)
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
@@ -20,7 +20,7 @@ for k, v in d.get("per_codec", {}).items():
 PY
   ;;
 trace)
-  for W in $WL deflate64k_mix lz4_compress_4m; do
+  for W in $WL $XWL; do
     ( cd /tmp && export TMPDIR=/tmp && timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace_$W -o bench -- python $R/bench.py --workload $W --steps 3 --warmup 1 --no-cpu-baseline --no-per-codec > $O/trace_$W.log 2>&1 ); echo "trace $W rc=$?"
     python tools/rocpd_summary.py $O/trace_$W/bench_results.db > $O/kernel_stats_$W.txt 2>&1; head -8 $O/kernel_stats_$W.txt
   done ;;
