@@ -81,3 +81,39 @@ def test_config4_shape_900k_blocks():
     assert (r["status"] == 0).all() and (r["out_len"] == 899000).all()
     for i in range(n):
         assert b.output(i, 899000) == plains[i]
+
+
+def test_symbol_loop_boundaries():
+    """Inputs built to walk the stage-1 symbol loop through its special cases (bzip2_block.h: hot_symbols / phase): alphabets
+    below and above 64 symbols (list positions >= 64, table indices >= 64), zero-run lengths around what the staging register
+    takes (a run enters it only if it leaves a lane for every symbol the group of 50 still has), runs across group boundaries,
+    blocks that end inside a group, exact capacities (the last groups run with the per-symbol tests)."""
+    rnd = random.Random(2024)
+    cases = []
+    for trial in range(120):
+        alpha = rnd.choice([1, 2, 3, 17, 63, 64, 65, 130, 256])
+        syms = bytes(rnd.sample(range(256), alpha))
+        parts = []
+        total = rnd.choice([1, 49, 50, 51, 99, 500, 5000, 40000])
+        while sum(len(p) for p in parts) < total:
+            k = rnd.random()
+            if k < 0.4:
+                parts.append(bytes([rnd.choice(syms)]) * rnd.choice([1, 2, 3, 4, 5, 12, 13, 14, 15, 16, 49, 50, 51, 63, 64, 65, 200, 3000]))
+            elif k < 0.7:
+                w = bytes(rnd.choice(syms) for _ in range(rnd.randrange(1, 9)))
+                parts.append(w * rnd.randrange(1, 60))
+            else:
+                parts.append(bytes(rnd.choice(syms) for _ in range(rnd.randrange(1, 300))))
+        x = b"".join(parts)
+        cases.append((bz2.compress(x, rnd.choice([1, 9])), x))
+    for z, x in cases:
+        assert swc.BZip2.decompress(z) == x
+    # the same blocks as ONE batch at exact capacities (single-block streams only)
+    one = [(z, x) for z, x in cases if z.count(bytes.fromhex("314159265359")) == 1 and len(x) > 0]
+    b = DeviceBatch("bzip2_block", [z for z, _ in one], [len(x) for _, x in one], extra=[112] * len(one),
+                    dict_values=[int.from_bytes(z[10:14], "big") for z, _ in one])
+    b.launch(sync=True)
+    r = b.results()
+    for i, (z, x) in enumerate(one):
+        assert int(r["status"][i]) == 0 and int(r["out_len"][i]) == len(x), (i, int(r["status"][i]))
+        assert b.output(i, len(x)) == x

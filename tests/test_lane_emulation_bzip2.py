@@ -122,3 +122,33 @@ def test_lane_order_does_not_matter():
                 assert r[:2] == (0, x), order
     finally:
         E.set_order(0)
+
+
+def test_symbol_loop_boundaries_emulated():
+    """The CPU twin of tests/test_gpu_bzip2.py::test_symbol_loop_boundaries: the same kinds of input through the host build
+    (hot_symbols_cxx, the C++ form of the assembly loop), at exact capacities."""
+    import bz2, random
+    rnd = random.Random(77)
+    cases = []
+    for trial in range(60):
+        alpha = rnd.choice([1, 2, 3, 17, 63, 64, 65, 130, 256])
+        syms = bytes(rnd.sample(range(256), alpha))
+        parts = []
+        total = rnd.choice([1, 49, 50, 51, 99, 500, 5000])
+        while sum(len(p) for p in parts) < total:
+            k = rnd.random()
+            if k < 0.4:
+                parts.append(bytes([rnd.choice(syms)]) * rnd.choice([1, 2, 3, 4, 5, 12, 13, 14, 15, 16, 49, 50, 51, 63, 64, 65, 200, 3000]))
+            elif k < 0.7:
+                w = bytes(rnd.choice(syms) for _ in range(rnd.randrange(1, 9)))
+                parts.append(w * rnd.randrange(1, 60))
+            else:
+                parts.append(bytes(rnd.choice(syms) for _ in range(rnd.randrange(1, 300))))
+        x = b"".join(parts)
+        z = bz2.compress(x, 9)
+        if z.count(bytes.fromhex("314159265359")) == 1:
+            cases.append((z, x))
+    res = E.bzip2_block([z for z, _ in cases], [112] * len(cases), [int.from_bytes(z[10:14], "big") for z, _ in cases],
+                        [len(x) for _, x in cases])
+    for r, (z, x) in zip(res, cases):
+        assert r[:2] == (0, x)
