@@ -828,8 +828,8 @@ SWC_HD void stage2_job(Workspace ws, uint32_t* cnt) {
 // ---- stage 3a: cut the cycle, walk the pieces, order them, lay the bytes out in L -------------------------------------
 struct Stage3Lds {
     uint32_t len[kSegs + 1];    // bytes of segment s
-    uint32_t next[kSegs + 1];   // segment that starts where s ends
-    uint32_t off[kSegs + 1];    // position of segment s in the block
+    uint32_t nxoff[kSegs + 1];  // first the segment that starts where s ends, then (once the cycle order has passed s) the
+                                // position of s in the block: one array, 2 KB less LDS = 29 instead of 23 waves per CU
     uint32_t ticket;            // next segment to hand out
     uint32_t bad;
     uint32_t part_at[kParts + 1];   // RLE1 undo: part j covers T[part_at[j] .. part_at[j + 1])
@@ -946,7 +946,7 @@ SWC_HD void stage3_walk_job(Job& job, Workspace ws, Stage3Lds* l, int lane) {
         for (uint32_t j = k & ~7u; j < k; j++) if (j < cap) buf[j] = (uint8_t)(acc >> (8 * (j & 7u)));   // pending bytes
         if (k > n) l->bad = 1;                               // cannot happen for a permutation; guards the loops below
         l->len[sg] = k;
-        l->next[sg] = seg_of(cur);
+        l->nxoff[sg] = seg_of(cur);
     }
     // ---- cycle order: from origPtr's segment along `next` until the walk is back; one n-cycle <=> the lengths add up to n
     // exactly when the start comes round again.  (All lanes run this short chain redundantly: <= 513 LDS steps.)
@@ -954,9 +954,10 @@ SWC_HD void stage3_walk_job(Job& job, Workspace ws, Stage3Lds* l, int lane) {
     const uint32_t s0 = seg_of(orig);
     uint32_t sg = s0, off = 0, visited = 0;
     do {
-        l->off[sg] = off;
+        const uint32_t nx = l->nxoff[sg];   // (every lane reads it before any lane's store below: one instruction each)
+        l->nxoff[sg] = off;
         off += l->len[sg];
-        sg = l->next[sg];
+        sg = nx;
         visited++;
     } while (sg != s0 && visited <= segs && off <= n);
     if (!(sg == s0 && off == n && visited == segs)) return;  // several cycles: the reference keeps circling the first one
@@ -964,7 +965,7 @@ SWC_HD void stage3_walk_job(Job& job, Workspace ws, Stage3Lds* l, int lane) {
     for (uint32_t q = 0; q < segs; q++) {
         const uint32_t len = l->len[q], have = len < cap ? len : cap;
         gcptr src = ws.segbuf + (size_t)q * cap;
-        gptr dst = ws.L + l->off[q];
+        gptr dst = ws.L + l->nxoff[q];
         for (uint32_t i = (uint32_t)lane * 8u; i < have; i += (uint32_t)WAVE * 8u) {
             if (have - i >= 8) store_u64(dst + i, load_u64(src + i));
             else for (uint32_t j = i; j < have; j++) dst[j] = src[j];
@@ -976,7 +977,7 @@ SWC_HD void stage3_walk_job(Job& job, Workspace ws, Stage3Lds* l, int lane) {
         if (q >= segs) break;
         const uint32_t len = l->len[q];
         if (len <= cap) continue;
-        gptr dst = ws.L + l->off[q];
+        gptr dst = ws.L + l->nxoff[q];
         uint32_t cur = start_of(q);
         uint64_t acc = 0;
         for (uint32_t k = 0; k < len; k++) {

@@ -339,9 +339,15 @@ hipError_t launch_lzma(bool lzma2, Job* jobs, size_t n, void* spill, hipStream_t
 // random HBM accesses) back to back.  As separate launches the three ran one after the other, each limited by its own
 // resource while the others idled; in one kernel the waves of a CU are at different stages at any time, so the scalar
 // work of some overlaps the memory waits of the others.  LDS: the three stages' areas share one allocation.
-constexpr size_t kBzLdsBytes = bzip2::kStage1LdsBytes > sizeof(bzip2::Stage3Lds) ? (size_t)bzip2::kStage1LdsBytes : sizeof(bzip2::Stage3Lds);
+#ifndef SWC_BZ_LDS_PAD
+#define SWC_BZ_LDS_PAD 0   // (occupancy experiments: more LDS per wave = fewer waves per CU, nothing else changed)
+#endif
+constexpr size_t kBzLdsBytes = (bzip2::kStage1LdsBytes > sizeof(bzip2::Stage3Lds) ? (size_t)bzip2::kStage1LdsBytes : sizeof(bzip2::Stage3Lds)) + SWC_BZ_LDS_PAD;
 static_assert(kBzLdsBytes >= 256 * sizeof(uint32_t), "stage 2 counters");
-__global__ __launch_bounds__(64) void swc_bzip2_block_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t lcap) {
+#ifndef SWC_BZ_WAVES
+#define SWC_BZ_WAVES 6   // (7: 72 VGPRs + 8 bytes of scratch, 28 waves per CU, 495 ms against 479 -- the walk is at the gather rate, more waves do not add to it)
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_BZ_WAVES))) void swc_bzip2_block_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t lcap) {
     __shared__ __attribute__((aligned(16))) uint8_t bz_lds[kBzLdsBytes];
     uint32_t g = xcd_job(blockIdx.x, n);
     if (g >= n) return;
