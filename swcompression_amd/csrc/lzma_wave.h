@@ -181,9 +181,22 @@ struct Decoder {
             code = (code << 8) | next_byte();
         }
     }
+#ifndef SWC_LZMA_BIT_SELECT
+#define SWC_LZMA_BIT_SELECT 0
+#endif
     SWC_HD int bit(uint16_t* p) {  // LZMARangeDecoder.swift:65-80
         const uint32_t pr = *p;
         uint32_t bound = (range >> 11) * pr;
+        if (SWC_LZMA_BIT_SELECT) {   // both sides computed, picked by selects on ONE scalar condition: no branch in the decision
+            const bool zero = same(code < bound);
+            const uint32_t pz = pr + ((2048u - pr) >> 5), po = pr - (pr >> 5);
+            *p = (uint16_t)(zero ? pz : po);
+            const uint32_t r1 = range - bound, c1 = code - bound;
+            range = zero ? bound : r1;
+            code = zero ? code : c1;
+            normalize();
+            return zero ? 0 : 1;
+        }
         int sym;
         if (same(code < bound)) {
             *p = (uint16_t)(pr + ((2048u - pr) >> 5));
