@@ -126,7 +126,7 @@ static int run_units_impl(int codec, std::vector<HostUnit>& units) {
 
     bool want_ws = codec == SWC_CODEC_BZIP2_BLOCK || codec == SWC_CODEC_DEFLATE || codec == SWC_CODEC_LZ4_BLOCK;
     // LZMA / LZMA2: without a workspace every literal coder of a stream sits in LDS (5 streams per CU); with one, LDS caches four
-    // of them (16 streams per CU, lzma_wave.h).  A batch that more than fills the 5-stream layout takes the workspace from the
+    // of them (32 streams per CU, lzma_wave.h).  A batch that more than fills the 5-stream layout takes the workspace from the
     // start -- the container paths (xz, 7z, .lzma, unarchive_many) then run the kernel bench.py measures; a small
     // batch gets one only after a unit reported SWC_E_NEED_WORKSPACE (lc + lp > 4).
     if ((codec == SWC_CODEC_LZMA || codec == SWC_CODEC_LZMA2) && n > 5u * 256u) want_ws = true;

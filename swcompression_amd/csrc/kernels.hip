@@ -310,7 +310,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_LZMA_WAV
 
 size_t lzma_spill_bytes_per_job() { return kLzmaSpillBytes; }
 
-// "lzma_coder_cache" (swc_set_tuning): 1 = LDS as a cache of four literal coders (default), 0 = round 2's layout (all eight
+// "lzma_coder_cache" (swc_set_tuning): 1 = LDS as a cache of the literal coders (kCoderSlots of them; default), 0 = round 2's layout (all eight
 // coders of lc + lp <= 3 in LDS, 10 streams per CU) -- kept for A/B measurements; both produce the same bytes.
 static std::atomic<int> g_lzma_cache{1};
 void set_lzma_coder_cache(int on) { g_lzma_cache = on; }

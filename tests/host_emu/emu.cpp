@@ -67,7 +67,7 @@ extern "C" void emu_lz4_compress(swc::Job* jobs, size_t n) {
 // LZMA: the wave-uniform decode chain is run as a single logical lane (WAVE = 1); the literal-coder
 // spill (lc+lp > 4) is always available, as the single-shot C ABI guarantees on the device.
 // mode 0: every literal coder in LDS up to lc + lp = 4, larger models cell by cell from the spill (the kernel without a
-// workspace, and the old spill path); mode 1: LDS as a cache of four literal coders (the kernel with a workspace).
+// workspace, and the old spill path); mode 1: LDS as a cache of kCoderSlots literal coders, long-length trees in the spill (the kernel with a workspace).
 extern "C" void emu_lzma_mode(swc::Job* jobs, size_t n, int is_lzma2, int mode) {
     std::vector<uint16_t> probs(swc::lzma::kProbCells + 8);
     std::vector<uint16_t> spill(((size_t)0x300 << 12) + 512);   // (+ the two `high` length trees of the cache mode)

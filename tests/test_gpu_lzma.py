@@ -187,7 +187,7 @@ def test_config5_shape_many_256k_units():
 
 
 def test_literal_coder_cache_against_whole_model():
-    """The two model layouts of the device kernel (lzma_wave.h: LDS as a cache of four literal coders / all coders in LDS) on
+    """The two model layouts of the device kernel (lzma_wave.h: LDS as a cache of the literal coders / all coders in LDS) on
     payloads that use few coders (text), all eight of lc = 3 (binary records) and sixteen (lc = 4; lc = 0, lp = 4): the same
     bytes, sizes and consumed input, and both equal to the oracle."""
     from swcompression_amd import _lib
