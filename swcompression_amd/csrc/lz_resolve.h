@@ -101,7 +101,10 @@ template <int T, int RING_LOG2, uint32_t KEEP, bool FAR = false>
 struct Resolver {
     using L = Lds<T, RING_LOG2>;
     static constexpr uint32_t kRing = L::kRing, kMask = kRing - 1u, kLitWin = L::kLitWin, kLitMask = kLitWin - 1u, kRpt = L::kRpt;
-    static constexpr uint32_t kBigLit = 1024;             // a literal-only record of at least this many bytes opens a run that is copied, not expanded
+#ifndef SWC_RESOLVE_BIG_LIT
+#define SWC_RESOLVE_BIG_LIT 1024
+#endif
+    static constexpr uint32_t kBigLit = SWC_RESOLVE_BIG_LIT;   // a literal-only record of at least this many bytes opens a run that is copied, not expanded
     static constexpr uint32_t kLitCap = kLitWin - 16u;    // literal bytes one batch may take: what the window holds whatever its granule alignment
     static constexpr uint32_t kSpanMax = 16u * T - 16u;   // output bytes one batch may cover: at most T slots whatever the alignment
     // The LAST batch of a stream may cover up to 20 T - 16 bytes (a fifth step of R2 / R3): a stream of 64 KiB is eight spans
