@@ -291,7 +291,7 @@ constexpr size_t kLzmaSpillBytes = (size_t)(0x300u << 12) * 2 + 1024;   // every
 // LDSBITS >= 0: the literal coders of lc + lp <= LDSBITS in LDS (no workspace: 4 -> 28 KB, 5 streams per CU);
 // LDSBITS < 0: LDS as a cache of kCoderSlots literal coders (one: 5,232 B, 31 streams per CU), all of them in the workspace (lzma_wave.h)
 #ifndef SWC_LZMA_WAVES
-#define SWC_LZMA_WAVES 7
+#define SWC_LZMA_WAVES 8
 #endif
 template <bool LZMA2, int LDSBITS>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_LZMA_WAVES))) void swc_lzma_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* spill, uint64_t* prof) {

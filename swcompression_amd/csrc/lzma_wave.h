@@ -12,9 +12,11 @@
 // constant per side, and tree indices, `state` and the tests on them live on the scalar unit (56 VGPRs).  The kernel is bound
 // by the latency of its one chain, so its speed is the number of streams a CU holds -- i.e. the LDS a stream needs.  Two
 // layouts (kernels.hip picks):
-//   coder cache (the default when the launch has a workspace): the 1,848 non-literal cells and ONE literal coder (0x300
-//       cells) in LDS, all literal coders in the workspace; a literal whose coder is not the cached one writes that back and
-//       loads its own (coders never used since the last reset are filled, not loaded): 5,232 B => 31 streams per CU;
+//   coder cache (the default when the launch has a workspace): the 1,336 non-literal cells without the two long-length trees
+//       and FOUR LINES of literal coders (a line = 0x100 cells = a third of a coder: its plain tree or one of the two trees of
+//       the matched mode) in LDS, all literal coders and the long-length trees in the workspace; a literal whose line is not
+//       cached writes the oldest line back and loads its own (lines never used since the last reset are filled, not
+//       loaded): 4,720 B => 8 streams per SIMD, the hardware's limit;
 //   whole model in LDS (no workspace; round 2's layout): every literal coder of lc + lp <= 4 in LDS, 28,272 B => 5 streams
 //       per CU; lc + lp > 4 (legal for .lzma, never produced by xz) reports SWC_E_NEED_WORKSPACE and is re-run with one.
 // The next 256 input bytes sit in a register spread over the lanes and are refilled at one place per symbol.
@@ -69,12 +71,21 @@ constexpr int kLdsBytesPerWave = lds_bytes_for(kMaxLdsLitBits);
 #define SWC_LZMA_SLOTS 1
 #endif
 constexpr int kCoderSlots = SWC_LZMA_SLOTS;
+// Round 4, second step: the cache holds LINES of 0x100 cells -- a third of a literal coder: its plain tree, or one of the two
+// trees of the matched mode -- not whole coders.  A plain literal (four of five on text) touches the plain tree only, so a
+// miss moves 512 B each way instead of 1.5 KB, and the same LDS keeps the plain trees of several coders (text alternates
+// between two: after a letter / after a space).  Line L = 3 x coder + third, at home in the workspace at cell L * 0x100.
+#ifndef SWC_LZMA_LINES
+#define SWC_LZMA_LINES 4
+#endif
+constexpr int kLines = SWC_LZMA_LINES;
+static_assert(kLines == 4, "a matched literal can need three lines at once; four tags");
 // (Round 4: the slots start where the two `high` length trees would be -- in cache mode those 512 cells live in the workspace
 // behind the literal coders and are decoded through bit_spill(): 1 KB less LDS per stream, 4,208 B with one slot.)
 constexpr int kSlotBase = P_LEN_HIGH;             // first cell of slot 0 (a multiple of four: dword-aligned copies)
 static_assert(kSlotBase % 4 == 0, "slot alignment");
 constexpr size_t kSpillHighCell = (size_t)0x300u << 12;   // workspace: all literal coders of lc + lp <= 12, then the 512 `high` cells
-constexpr int lds_bytes_cached() { return (((kSlotBase + 0x300 * kCoderSlots) * 2 + 15) / 16) * 16; }
+constexpr int lds_bytes_cached() { return (((kSlotBase + 0x100 * kLines) * 2 + 15) / 16) * 16; }
 constexpr uint32_t kNoCoder = 0xFFFFFFFFu;
 constexpr int LEN_CHOICE = 0, LEN_CHOICE2 = 1, LEN_LOW = 2, LEN_MID = 2 + 128;
 
@@ -117,6 +128,7 @@ struct Decoder {
     uint32_t tag0 = kNoCoder, tag1 = kNoCoder, tag2 = kNoCoder, tag3 = kNoCoder;   // the coder in each slot
     uint32_t victim = 0;        // the slot the next miss replaces
     uint64_t fresh = 0;         // bit c: coder c (c < 64) has not been used since the last reset -- its cells are all 1024, nothing to load
+    uint64_t fresh1 = 0, fresh2 = 0;   // the same for the second and third line of coder c (`fresh`: its first)
     bool have_model;
     int lc, lp, pb;
     uint64_t dict_size;
@@ -308,32 +320,40 @@ struct Decoder {
         return 16 + tree(&probs[P_LEN_HIGH + which * 256], 8);
     }
 
-    // The LDS copy of literal coder `c` (cache mode): a hit is four compares; see kCoderSlots.
-    SWC_HD uint16_t* literal_coder(uint32_t c) {
-        static_assert(kCoderSlots >= 1 && kCoderSlots <= 4, "one to four tags");
-        {   // a hit: the slot number by selects, ONE branch (on the device every `if` on these values is an exec-mask region)
-            const uint32_t slot = (tag1 == c ? 1u : 0u) + (tag2 == c ? 2u : 0u) + (kCoderSlots > 3 && tag3 == c ? 3u : 0u);
-            const bool hit = tag0 == c || slot != 0u;
-            if (same(hit)) return probs + kSlotBase + slot * 0x300;
+    // The LDS copy of line `third` (0 plain tree, 1 / 2 the trees of the matched mode) of literal coder `c` (cache mode): a hit
+    // is four compares and one branch; a miss writes the oldest line back and loads (or, if nobody has touched it since the
+    // last reset, fills) the wanted one -- 512 B each way, two dwords per lane.
+    SWC_HD uint16_t* literal_line(uint32_t c, uint32_t third) {
+        // (Four lines, replaced round-robin.  Two ways for plain trees + two for the matched mode, so that matched literals cannot
+        // evict plain trees, measured slower on every payload: 721 / 1,434 / 2,666 ms against 703 / 1,249 / 2,379.)
+        const uint32_t L = c * 3u + third;
+        {
+            const uint32_t slot = (tag1 == L ? 1u : 0u) + (tag2 == L ? 2u : 0u) + (tag3 == L ? 3u : 0u);
+            const bool hit = tag0 == L || slot != 0u;
+            if (same(hit)) return probs + kSlotBase + slot * 0x100;
         }
         const uint32_t v = victim;
-        victim = victim + 1 == (uint32_t)kCoderSlots ? 0u : victim + 1;
+        victim = victim + 1 == (uint32_t)kLines ? 0u : victim + 1;
         const uint32_t old = v == 0 ? tag0 : v == 1 ? tag1 : v == 2 ? tag2 : tag3;
-        uint16_t* sp = probs + kSlotBase + v * 0x300;
+        uint16_t* sp = probs + kSlotBase + v * 0x100;
         uint32_t* sp32 = (uint32_t*)sp;
-        if (old != kNoCoder) {
-            SWC_AS_GLOBAL uint32_t* home = (SWC_AS_GLOBAL uint32_t*)(lit_spill + (size_t)old * 0x300);
-            for (int j = lane; j < 0x300 / 2; j += WAVE) home[j] = sp32[j];
+        if (same(old != kNoCoder)) {
+            SWC_AS_GLOBAL uint32_t* home = (SWC_AS_GLOBAL uint32_t*)(lit_spill + (size_t)old * 0x100);
+            for (int j = lane; j < 0x100 / 2; j += WAVE) home[j] = sp32[j];
         }
-        if (c < 64 && ((fresh >> c) & 1u)) {
-            for (int j = lane; j < 0x300 / 2; j += WAVE) sp32[j] = 0x04000400u;
-            fresh &= ~(1ull << c);
+        const uint64_t fm = third == 0u ? fresh : third == 1u ? fresh1 : fresh2;
+        if (same(c < 64 && ((fm >> (c & 63u)) & 1u))) {
+            for (int j = lane; j < 0x100 / 2; j += WAVE) sp32[j] = 0x04000400u;
+            const uint64_t bitc = 1ull << (c & 63u);
+            fresh &= ~(third == 0u ? bitc : 0ull);
+            fresh1 &= ~(third == 1u ? bitc : 0ull);
+            fresh2 &= ~(third == 2u ? bitc : 0ull);
         } else {
-            // (a coder written back earlier comes back through the same lanes that stored it)
-            const SWC_AS_GLOBAL uint32_t* home = (const SWC_AS_GLOBAL uint32_t*)(lit_spill + (size_t)c * 0x300);
-            for (int j = lane; j < 0x300 / 2; j += WAVE) sp32[j] = home[j];
+            // (a line written back earlier comes back through the same lanes that stored it)
+            const SWC_AS_GLOBAL uint32_t* home = (const SWC_AS_GLOBAL uint32_t*)(lit_spill + (size_t)L * 0x100);
+            for (int j = lane; j < 0x100 / 2; j += WAVE) sp32[j] = home[j];
         }
-        tag0 = v == 0 ? c : tag0; tag1 = v == 1 ? c : tag1; tag2 = v == 2 ? c : tag2; tag3 = v == 3 ? c : tag3;
+        tag0 = v == 0 ? L : tag0; tag1 = v == 1 ? L : tag1; tag2 = v == 2 ? L : tag2; tag3 = v == 3 ? L : tag3;
         simt::wave_fence();
         return sp;
     }
@@ -351,8 +371,9 @@ struct Decoder {
             const int lit_bits = lc + lp;
             if (lit_bits <= 6) {
                 fresh = lit_bits == 6 ? ~0ull : (1ull << (1u << lit_bits)) - 1ull;
+                fresh1 = fresh2 = fresh;
             } else {
-                fresh = 0;
+                fresh = fresh1 = fresh2 = 0;
                 const uint32_t cells = 0x300u << lit_bits;
                 if (lit_spill) for (uint32_t i = (uint32_t)lane; i < cells; i += WAVE) lit_spill[i] = 1024;
             }
@@ -457,8 +478,31 @@ struct Decoder {
                 const uint32_t prev = pos == dict_start ? 0u : prev_byte;
                 const uint32_t lit_state = (uint32_t)(((pos & ((1u << lp) - 1)) << lc) + (prev >> (8 - lc)));
                 int symbol = 1;
-                if (!spill) {
-                    uint16_t* lpb = cached ? literal_coder(lit_state) : &probs[P_LITERAL + lit_state * 0x300];
+                if (cached) {
+                    if (same(state >= 7)) {
+                        SWC_LZMA_PROF(10)
+                        SWC_LZMA_COUNT(11, 1);
+                        uint32_t match_byte = byte_at(rep0 + 1);
+                        do {
+                            const int match_bit = (match_byte >> 7) & 1;
+                            match_byte = (match_byte << 1) & 0xFF;
+                            uint16_t* lm = literal_line(lit_state, 1u + (uint32_t)match_bit);
+                            const int b = bit(&lm[symbol]);
+                            symbol = (symbol << 1) | b;
+                            if (same(match_bit != b)) break;
+                        } while (symbol < 0x100);
+                    }
+                    if (symbol < 0x100) {
+                        uint16_t* lpb = literal_line(lit_state, 0u);
+                        if (symbol == 1) {   // not in matched mode: exactly eight decisions (a constant trip count: no loop test in the chain)
+#pragma unroll
+                            for (int i = 0; i < 8; i++) symbol = (symbol << 1) | bit(&lpb[symbol]);
+                        } else {
+                            while (symbol < 0x100) symbol = (symbol << 1) | bit(&lpb[symbol]);
+                        }
+                    }
+                } else if (!spill) {
+                    uint16_t* lpb = &probs[P_LITERAL + lit_state * 0x300];
                     if (same(state >= 7)) {
                         SWC_LZMA_PROF(10)
                         SWC_LZMA_COUNT(11, 1);
