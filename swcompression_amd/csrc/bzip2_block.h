@@ -70,7 +70,7 @@ constexpr uint32_t kSegs = 512;        // stage 3a: regular segments per block (
 constexpr uint32_t kSegCapFactor = SWC_BZ_SEGCAP;  // a segment's buffer holds 4 x the mean segment length (2 % are longer, 9 % of the bytes)
 constexpr int kParts = 64;             // stage 3a: the RLE1 undo of a block is cut into this many parts
 
-// workspace per job (HBM): L[lcap] (stage 3: the walked bytes T) | selectors[32768] | P[lcap] (u32) | header | segment buffers
+// workspace per job (HBM): L[lcap] (stage 3: the walked bytes T) | selectors[32768] | P[lcap] (u32) | header | segment info | segment buffers
 struct BlockHeader {   // stage 1 -> stage 2/3
     uint32_t n;        // length of L
     uint32_t orig_ptr;
@@ -93,14 +93,17 @@ SWC_HD size_t segbuf_bytes(size_t lcap) {   // (regular segments + 1) x capacity
     const size_t regs = (lcap + ((size_t)1 << m) - 1) >> m;
     return (regs + 1) * ((size_t)kSegCapFactor << m) + 64;
 }
+constexpr size_t kSegInfoBytes = ((2 * (kSegs + 1) * 4 + 15) / 16) * 16;   // length and successor of every segment (stage 3a)
 SWC_HD size_t ws_bytes_per_job(size_t lcap) {
-    return ((lcap + 15) & ~(size_t)15) + 32768 + lcap * 4 + sizeof(BlockHeader) + 64 + ((segbuf_bytes(lcap) + 15) & ~(size_t)15);
+    return ((lcap + 15) & ~(size_t)15) + 32768 + lcap * 4 + sizeof(BlockHeader) + 64 + kSegInfoBytes + ((segbuf_bytes(lcap) + 15) & ~(size_t)15);
 }
 struct Workspace {
     gptr L;
     gptr selectors;
     SWC_AS_GLOBAL uint32_t* P;
     SWC_AS_GLOBAL BlockHeader* hdr;
+    SWC_AS_GLOBAL uint32_t* seg_len;    // [kSegs + 1] bytes of segment s
+    SWC_AS_GLOBAL uint32_t* seg_next;   // [kSegs + 1] the segment that starts where s ends
     gptr segbuf;
     size_t lcap;
 };
@@ -112,7 +115,10 @@ SWC_HD Workspace carve(uint8_t* base, size_t job, size_t lcap) {
     w.selectors = (gptr)(p + lpad);
     w.P = (SWC_AS_GLOBAL uint32_t*)(p + lpad + 32768);
     w.hdr = (SWC_AS_GLOBAL BlockHeader*)(p + lpad + 32768 + lcap * 4);
-    w.segbuf = (gptr)(p + ((lpad + 32768 + lcap * 4 + sizeof(BlockHeader) + 64 + 15) & ~(size_t)15));
+    const size_t info = (lpad + 32768 + lcap * 4 + sizeof(BlockHeader) + 64 + 15) & ~(size_t)15;
+    w.seg_len = (SWC_AS_GLOBAL uint32_t*)(p + info);
+    w.seg_next = w.seg_len + (kSegs + 1);
+    w.segbuf = (gptr)(p + info + kSegInfoBytes);
     w.lcap = lcap;
     return w;
 }
@@ -172,6 +178,86 @@ struct MsbReader {
 #if defined(__HIP_DEVICE_COMPILE__)
 SWC_D uint32_t wave_count(bool pred) { return (uint32_t)__popcll(__ballot(pred)); }
 #endif
+
+// ---- stage 3a, first part: the walk of the segments, RESUMABLE ------------------------------------------------------------
+// Every lane walks segments (v = P[cur]; byte = v & 255; cur = v >> 8) until none is left.  One call of walk_tick() takes
+// every lane ONE step: it consumes the pointer loaded by the call before, and issues the next load without waiting for it --
+// so whoever calls it can do other work while the gathers are in flight (the pipelined kernel runs the symbol loop of the
+// NEXT block between two ticks; the fused kernel just calls it in a loop).  What the walk leaves per segment -- length and
+// successor -- goes to the workspace, the ticket counter is the only LDS it needs (ctl[0]; ctl[1]: a walk ran away).
+SWC_HD uint32_t take_ticket(uint32_t* t) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return atomicAdd(t, 1u);
+#else
+    return (*t)++;
+#endif
+}
+struct Walk {
+    bool live = false;   // there is a block being walked (false: nothing to do, stage 3b reports the block)
+    Workspace ws;
+    uint32_t n, orig, mbits, mask, regs, segs, cap;
+    bool extra;          // origPtr is a mark of its own
+    uint32_t* ctl;
+    // this lane's segment
+    bool active, pending;
+    uint32_t sg, cur, k, v;
+    uint64_t acc;        // eight bytes per store: a byte per step would be a partial-line write to HBM each time
+    SWC_HD bool is_mark(uint32_t i) const { return (i & mask) == 0 || i == orig; }
+    SWC_HD uint32_t seg_of(uint32_t i) const { return (extra && i == orig) ? regs : i >> mbits; }
+    SWC_HD uint32_t start_of(uint32_t s) const { return s < regs ? s << mbits : orig; }
+};
+SWC_HD void walk_begin(Walk& W, Workspace ws, uint32_t* ctl, int lane) {
+    W.live = false;
+    W.ws = ws;
+    W.ctl = ctl;
+    W.active = W.pending = false;
+    if (lane == 0) ws.hdr->pad = kWalkNone;
+    if (ws.hdr->status != SWC_OK) return;
+    W.n = ws.hdr->n; W.orig = ws.hdr->orig_ptr;
+    if (W.n == 0 || W.orig >= W.n) return;                   // empty block / trap: stage 3b reports it
+    W.mbits = seg_mbits(W.n); W.mask = (1u << W.mbits) - 1u;
+    W.regs = (W.n + W.mask) >> W.mbits;                      // marks 0, M, 2M, ...
+    W.extra = (W.orig & W.mask) != 0;
+    W.segs = W.regs + (W.extra ? 1u : 0u);
+    W.cap = kSegCapFactor << W.mbits;
+    if (lane == 0) { ctl[0] = 0; ctl[1] = 0; }
+    W.live = true;
+}
+// one step of every lane; true when no segment is left and none is being walked
+template <int WAVE>
+SWC_HD bool walk_tick(Walk& W) {
+    if (W.pending) {
+        const uint32_t v = W.v;
+        gptr buf = W.ws.segbuf + (size_t)W.sg * W.cap;       // the first `cap` bytes of a segment go to its buffer
+        W.acc |= (uint64_t)(v & 0xFFu) << (8 * (W.k & 7u));
+        if ((W.k & 7u) == 7u) {
+            const uint32_t g0 = W.k - 7;
+            if (g0 + 8 <= W.cap) store_u64(buf + g0, W.acc);
+            else for (uint32_t j = 0; j < 8; j++) if (g0 + j < W.cap) buf[g0 + j] = (uint8_t)(W.acc >> (8 * j));
+            W.acc = 0;
+        }
+        W.k++;
+        W.cur = v >> 8;
+        if (W.is_mark(W.cur) || W.k > W.n) {
+            for (uint32_t j = W.k & ~7u; j < W.k; j++) if (j < W.cap) buf[j] = (uint8_t)(W.acc >> (8 * (j & 7u)));   // pending bytes
+            if (W.k > W.n) W.ctl[1] = 1;                     // cannot happen for a permutation; guards the loops of walk_finish
+            W.ws.seg_len[W.sg] = W.k;
+            W.ws.seg_next[W.sg] = W.seg_of(W.cur);
+            W.active = false;
+        }
+        W.pending = false;
+    }
+    if (!W.active) {
+        const uint32_t s = take_ticket(&W.ctl[0]);
+        if (s < W.segs) { W.active = true; W.sg = s; W.cur = W.start_of(s); W.k = 0; W.acc = 0; }
+    }
+    if (W.active) { W.v = W.ws.P[W.cur]; W.pending = true; }
+#if defined(__HIP_DEVICE_COMPILE__)
+    return WAVE > 1 ? __ballot(W.active) == 0ull : !W.active;
+#else
+    return !W.active;
+#endif
+}
 
 template <int WAVE>
 struct Stage1 {
@@ -837,14 +923,6 @@ struct Stage3Lds {
 };
 constexpr int kStage3LdsBytes = (sizeof(Stage3Lds) + 15) / 16 * 16;
 
-SWC_HD uint32_t take_ticket(uint32_t* t) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    return atomicAdd(t, 1u);
-#else
-    return (*t)++;
-#endif
-}
-
 // RLE1 undo (BZip2.swift:251-267) as a state machine over the walked bytes T: `run` = equal literals so far (1..4), 0 right
 // after a count byte.  Feed one byte, get the number of output bytes it stands for (1 for a literal, its value for a count).
 struct Rle1 {
@@ -909,49 +987,18 @@ struct OutPack {
     }
 };
 
+// Stage 3a, second part: the segments in cycle order, the bytes laid out in L, RLE1 undone (the walk is complete).
 template <int WAVE>
-SWC_HD void stage3_walk_job(Job& job, Workspace ws, Stage3Lds* l, int lane) {
-    if (lane == 0) ws.hdr->pad = kWalkNone;
-    if (ws.hdr->status != SWC_OK) return;
-    const uint32_t n = ws.hdr->n, orig = ws.hdr->orig_ptr;
-    if (n == 0 || orig >= n) return;                         // empty block / trap: stage 3b reports it
-    const uint32_t mbits = seg_mbits(n), mask = (1u << mbits) - 1u;
-    const uint32_t regs = (n + mask) >> mbits;               // marks 0, M, 2M, ...
-    const bool extra = (orig & mask) != 0;                   // origPtr is a mark of its own
-    const uint32_t segs = regs + (extra ? 1u : 0u);
-    const uint32_t cap = kSegCapFactor << mbits;
-    auto is_mark = [&](uint32_t i) { return (i & mask) == 0 || i == orig; };
-    auto seg_of = [&](uint32_t i) { return (extra && i == orig) ? regs : i >> mbits; };
-    auto start_of = [&](uint32_t sg) { return sg < regs ? sg << mbits : orig; };
-    if (lane == 0) { l->ticket = 0; l->bad = 0; }
-    // ---- every lane walks segments until none is left; the first `cap` bytes of a segment go to its buffer
-    for (;;) {
-        const uint32_t sg = take_ticket(&l->ticket);
-        if (sg >= segs) break;
-        gptr buf = ws.segbuf + (size_t)sg * cap;
-        uint32_t cur = start_of(sg), k = 0;
-        uint64_t acc = 0;                                    // eight bytes per store: a byte per step would be a partial-line
-        do {                                                 // write to HBM each time (655,360 open lines do not stay in L2)
-            const uint32_t v = ws.P[cur];
-            acc |= (uint64_t)(v & 0xFFu) << (8 * (k & 7u));
-            if ((k & 7u) == 7u) {
-                const uint32_t g0 = k - 7;
-                if (g0 + 8 <= cap) store_u64(buf + g0, acc);
-                else for (uint32_t j = 0; j < 8; j++) if (g0 + j < cap) buf[g0 + j] = (uint8_t)(acc >> (8 * j));
-                acc = 0;
-            }
-            k++;
-            cur = v >> 8;
-        } while (!is_mark(cur) && k <= n);
-        for (uint32_t j = k & ~7u; j < k; j++) if (j < cap) buf[j] = (uint8_t)(acc >> (8 * (j & 7u)));   // pending bytes
-        if (k > n) l->bad = 1;                               // cannot happen for a permutation; guards the loops below
-        l->len[sg] = k;
-        l->nxoff[sg] = seg_of(cur);
-    }
+SWC_HD void walk_finish(Job& job, Walk& W, Stage3Lds* l, int lane) {
+    const Workspace ws = W.ws;
+    const uint32_t n = W.n, orig = W.orig, segs = W.segs, cap = W.cap;
+    if (W.ctl[1]) return;
+    for (uint32_t q = (uint32_t)lane; q < segs; q += (uint32_t)WAVE) { l->len[q] = ws.seg_len[q]; l->nxoff[q] = ws.seg_next[q]; }
+    simt::wave_fence();
+    auto start_of = [&](uint32_t sg) { return W.start_of(sg); };
     // ---- cycle order: from origPtr's segment along `next` until the walk is back; one n-cycle <=> the lengths add up to n
     // exactly when the start comes round again.  (All lanes run this short chain redundantly: <= 513 LDS steps.)
-    if (l->bad) return;
-    const uint32_t s0 = seg_of(orig);
+    const uint32_t s0 = W.seg_of(orig);
     uint32_t sg = s0, off = 0, visited = 0;
     do {
         const uint32_t nx = l->nxoff[sg];   // (every lane reads it before any lane's store below: one instruction each)
@@ -1035,6 +1082,16 @@ SWC_HD void stage3_walk_job(Job& job, Workspace ws, Stage3Lds* l, int lane) {
     job.in_consumed = ws.hdr->end_bit;
     job.aux = 0;
     if (lane == 0) ws.hdr->pad = kWalkDone;
+}
+
+// The fused kernel's stage 3a: the whole walk at once.  `l` is the stage's LDS; its ticket / bad words serve as the walk's.
+template <int WAVE>
+SWC_HD void stage3_walk_job(Job& job, Workspace ws, Stage3Lds* l, int lane) {
+    Walk W;
+    walk_begin(W, ws, &l->ticket, lane);
+    if (!W.live) return;
+    while (!walk_tick<WAVE>(W)) {}
+    walk_finish<WAVE>(job, W, l, lane);
 }
 
 // ---- stage 3b: RLE1 undo, one block per lane.  job.dict (as integer) = stored block CRC (checked by stage 3c). ----------
