@@ -512,7 +512,9 @@ struct Stage1 {
     // operand has no syntax for that); it is handed over at entry and exit.  What differs from the C++ in form only:
     //   * `v_mov_b32_dpp x, x wave_shr:1` shifts a register in place, lane 0 is written afterwards with v_writelane (lane
     //     select 0: no second scalar operand);
-    //   * the window is refilled by the C++ (exit 3 when fewer than 33 bits are left), everything else stays inside.
+    //   * the bit window is refilled inside too, by SCALAR loads (s_load_dwordx2 of the aligned pair that holds the next dword,
+    //     asked for one refill ahead; the input is read-only for the kernel, and a FAST group has its 163 bytes): the word
+    //     arrives in scalar registers, and the loop is left only at the end of a group or for a symbol it does not handle.
     // Wait states the assembler does not insert into inline code: a lane select that was written by v_readlane needs four
     // (the s_nop in front of the symbol read); DPP sources are written at least two instructions earlier on every path.
     SWC_D int hot_symbols_isa(Loop& L, int& i, uint32_t& pending, uint32_t& pending_len) {
@@ -523,7 +525,10 @@ struct Stage1 {
         uint32_t ii = simt::uniform((uint32_t)i), bc = simt::uniform(br.bc), k = simt::uniform(L.k);
         uint64_t bb = simt::uniform(br.bb), rl = simt::uniform(L.run_length), rp = simt::uniform(L.repeat_power);
         const uint32_t mfast = simt::uniform(L.mfast);
-        for (;;) {
+        // the window is refilled inside (FAST groups have their input: phase<true>): the address of the next dword to enter it
+        uint64_t addr = simt::uniform((uint64_t)(uintptr_t)br.in + br.next);
+        br.pw_ok = false;
+        {
             asm volatile(
                 "s_mov_b64 s[80:81], %[bb]\n\t"
                 "s_mov_b32 s82, %[bc]\n\t"
@@ -532,10 +537,15 @@ struct Stage1 {
                 "s_mov_b64 s[86:87], %[rl]\n\t"
                 "s_mov_b64 s[88:89], %[rp]\n\t"
                 "s_mov_b32 s90, %[mfast]\n\t"
-                "s_mov_b32 s98, 0\n"
+                "s_mov_b64 s[78:79], %[addr]\n\t"
+                "s_mov_b32 s98, 0\n\t"
+                "s_and_b32 s76, s78, -4\n\t"                 // the aligned pair that holds the dword at the read position, on its way
+                "s_mov_b32 s77, s79\n\t"
+                "s_load_dwordx2 s[74:75], s[76:77], 0x0\n"
                 "Ltop%=:\n\t"
                 "s_cmp_le_u32 s82, 32\n\t"
-                "s_cbranch_scc1 Lrefill%=\n\t"
+                "s_cbranch_scc1 Lrefill%=\n"
+                "Lgo%=:\n\t"
                 "s_lshr_b32 s91, s81, 6\n\t"
                 "v_cmp_ge_u32_e32 vcc, s91, %[lim]\n\t"
                 "v_lshrrev_b32_e64 %[t0], %[sh], s91\n\t"
@@ -608,9 +618,34 @@ struct Stage1 {
                 "Lindex%=:\n\t"
                 "s_mov_b32 s98, 2\n\t"
                 "s_branch Ldone%=\n"
-                "Lrefill%=:\n\t"
-                "s_mov_b32 s98, 3\n"
+                "Lrefill%=:\n\t"                              // 32 more bits into the window; the pair behind them is asked for at once
+                "s_and_b32 s99, s78, 3\n\t"
+                "s_lshl_b32 s99, s99, 3\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"
+                "s_lshr_b64 s[96:97], s[74:75], s99\n\t"
+                "s_add_u32 s78, s78, 4\n\t"
+                "s_addc_u32 s79, s79, 0\n\t"
+                "s_and_b32 s76, s78, -4\n\t"
+                "s_mov_b32 s77, s79\n\t"
+                "s_load_dwordx2 s[74:75], s[76:77], 0x0\n\t"
+                "s_lshr_b32 s97, s96, 24\n\t"                 // the dword's bytes in stream order (no scalar byte swap)
+                "s_lshl_b32 s99, s96, 24\n\t"
+                "s_or_b32 s97, s97, s99\n\t"
+                "s_lshr_b32 s99, s96, 8\n\t"
+                "s_and_b32 s99, s99, 0xff00\n\t"
+                "s_or_b32 s97, s97, s99\n\t"
+                "s_lshl_b32 s99, s96, 8\n\t"
+                "s_and_b32 s99, s99, 0xff0000\n\t"
+                "s_or_b32 s96, s97, s99\n\t"
+                "s_mov_b32 s97, 0\n\t"
+                "s_sub_u32 s99, 32, s82\n\t"
+                "s_lshl_b64 s[96:97], s[96:97], s99\n\t"
+                "s_or_b64 s[80:81], s[80:81], s[96:97]\n\t"
+                "s_add_u32 s82, s82, 32\n\t"
+                "s_branch Lgo%=\n"
                 "Ldone%=:\n\t"
+                "s_waitcnt lgkmcnt(0)\n\t"                    // (the pair on its way must have landed before its registers are anybody else's)
+                "s_mov_b64 %[addr], s[78:79]\n\t"
                 "s_mov_b64 %[bb], s[80:81]\n\t"
                 "s_mov_b32 %[bc], s82\n\t"
                 "s_mov_b32 %[i], s83\n\t"
@@ -620,17 +655,14 @@ struct Stage1 {
                 "s_mov_b32 %[ev], s98\n\t"
                 "s_mov_b32 %[pend], s93\n\t"
                 "s_mov_b32 %[plen], s92"
-                : [bb] "+s"(bb), [bc] "+s"(bc), [i] "+s"(ii), [k] "+s"(k), [rl] "+s"(rl), [rp] "+s"(rp),
+                : [bb] "+s"(bb), [bc] "+s"(bc), [i] "+s"(ii), [k] "+s"(k), [rl] "+s"(rl), [rp] "+s"(rp), [addr] "+s"(addr),
                   [ev] "=s"(ev), [pend] "=s"(pend), [plen] "=s"(plen), [l0] "+v"(L.l0.v), [stg] "+v"(L.stg.v), [t0] "=&v"(t0), [t1] "=&v"(t1)
                 : [mfast] "s"(mfast), [lim] "v"(L.my_lim.v), [sh] "v"(L.my_sh.v), [delta] "v"(L.my_delta.v), [symlo] "v"(L.sym_lo.v), [lane] "v"(lane)
-                : "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
+                : "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
                   "s98", "s99", "vcc", "scc");
-            if (ev != 3u) break;
-            br.bb = bb; br.bc = bc;
-            br.refill();
-            bb = simt::uniform(br.bb); bc = simt::uniform(br.bc);
         }
         br.bb = bb; br.bc = bc;
+        br.next = addr - (uint64_t)(uintptr_t)br.in;
         L.k = k; L.run_length = rl; L.repeat_power = rp;
         i = (int)ii;
         pending = pend;
