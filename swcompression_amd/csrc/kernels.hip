@@ -68,9 +68,16 @@ __device__ __forceinline__ uint32_t order_class(uint64_t len) {
     const uint32_t e = 31u - (uint32_t)__clz((int)v);
     return (kOrderClasses - 1) - (e * 8u + ((v >> (e - 3u)) & 7u));   // class 0 = the largest
 }
+// (one LDS histogram per workgroup and one global atomic per class it holds: 100,000 members of ONE size class otherwise meet at
+// one counter -- 2 ms for the two kernels, a tenth of the launch they were meant to shorten)
 __global__ __launch_bounds__(256) void swc_order_hist_kernel(const Job* __restrict__ jobs, uint32_t n, uint32_t* __restrict__ hist) {
-    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    if (g < n) atomicAdd(&hist[order_class(jobs[g].in_len)], 1u);
+    __shared__ uint32_t cnt[kOrderClasses];
+    const uint32_t t = threadIdx.x, g = blockIdx.x * 256u + t;
+    cnt[t] = 0;
+    __syncthreads();
+    if (g < n) atomicAdd(&cnt[order_class(jobs[g].in_len)], 1u);
+    __syncthreads();
+    if (cnt[t]) atomicAdd(&hist[t], cnt[t]);
 }
 __global__ __launch_bounds__(kOrderClasses) void swc_order_prefix_kernel(uint32_t* __restrict__ hist) {   // hist[c] -> first slot of class c
     __shared__ uint32_t s[kOrderClasses];
@@ -82,8 +89,16 @@ __global__ __launch_bounds__(kOrderClasses) void swc_order_prefix_kernel(uint32_
     hist[t] = a;
 }
 __global__ __launch_bounds__(256) void swc_order_scatter_kernel(const Job* __restrict__ jobs, uint32_t n, uint32_t* __restrict__ cursor, uint32_t* __restrict__ perm) {
-    const uint32_t g = blockIdx.x * 256u + threadIdx.x;
-    if (g < n) perm[atomicAdd(&cursor[order_class(jobs[g].in_len)], 1u)] = g;
+    __shared__ uint32_t cnt[kOrderClasses], base[kOrderClasses];
+    const uint32_t t = threadIdx.x, g = blockIdx.x * 256u + t;
+    cnt[t] = 0;
+    __syncthreads();
+    const uint32_t c = g < n ? order_class(jobs[g].in_len) : 0u;
+    const uint32_t r = g < n ? atomicAdd(&cnt[c], 1u) : 0u;      // my rank among the group's members of the class
+    __syncthreads();
+    if (cnt[t]) base[t] = atomicAdd(&cursor[t], cnt[t]);          // the group's slots of class t
+    __syncthreads();
+    if (g < n) perm[base[c] + r] = g;
 }
 // device buffer of the calling thread for the order of one launch on `stream` (perm[n] | cursors), or nullptr
 static const uint32_t* job_order(const Job* jobs, size_t n, hipStream_t stream) {
@@ -116,6 +131,9 @@ __device__ __forceinline__ uint32_t job_of(const uint32_t* order, uint32_t b, ui
 // ---- Deflate: two phases (inflate_sync.h + inflate_lane.h, lz_resolve.h) -------------------------------------------
 // Phase 1: one stream per WAVEFRONT, 64 sub-chunks of the stream decoded at once (inflate_sync.h).
 // LDS: the shared tables + the staged input of a round, exactly 10 KiB per wave -> 16 waves per CU.
+#ifndef SWC_INFLATE_ORDER
+#define SWC_INFLATE_ORDER 1
+#endif
 #ifndef SWC_SYNC_WAVES_PER_SIMD
 #define SWC_SYNC_WAVES_PER_SIMD 4
 #endif
@@ -123,9 +141,9 @@ __device__ __forceinline__ uint32_t job_of(const uint32_t* order, uint32_t b, ui
 // that bench at once do not see each other's events.
 static thread_local uint64_t* g_prof = nullptr;   // profile builds (-DSWC_PROFILE): 32 counters per job, [0..16) phase 1, [16..32) phase 2
 void set_profile_buffer(void* p) { g_prof = static_cast<uint64_t*>(p); }
-__global__ __launch_bounds__(64, SWC_SYNC_WAVES_PER_SIMD) void swc_inflate_sync_kernel(Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof) {
+__global__ __launch_bounds__(64, SWC_SYNC_WAVES_PER_SIMD) void swc_inflate_sync_kernel(Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof, const uint32_t* __restrict__ order) {
     __shared__ __attribute__((aligned(16))) inflate::SyncLds sync_lds;
-    uint32_t g = xcd_job(blockIdx.x, n);
+    uint32_t g = job_of(order, blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];
     inflate::inflate_sync_job(job, &sync_lds, wm.area(g), wm.bytes(g), (int)threadIdx.x, kWave, prof ? prof + 32 * (size_t)g : nullptr);
@@ -139,9 +157,9 @@ __global__ __launch_bounds__(64, SWC_SYNC_WAVES_PER_SIMD) void swc_inflate_sync_
 // Phase 2: one stream per workgroup of 512 threads, 64 KiB LDS ring (32 KiB of history + span + cells) -> 2 workgroups per CU.
 constexpr int kInflateResolveThreads = 512, kInflateRingLog2 = 16;
 constexpr uint32_t kInflateKeep = 32768;
-__global__ __launch_bounds__(kInflateResolveThreads) void swc_lz_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof) {
+__global__ __launch_bounds__(kInflateResolveThreads) void swc_lz_resolve_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof, const uint32_t* __restrict__ order) {
     __shared__ __attribute__((aligned(16))) lzr::Lds<kInflateResolveThreads, kInflateRingLog2> lzr_lds;  // static: > 64 KiB needs no opt-in this way
-    uint32_t g = xcd_job(blockIdx.x, n);
+    uint32_t g = job_of(order, blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];
     lzr::resolve_job<kInflateResolveThreads, kInflateRingLog2, kInflateKeep>(job, wm.area(g), wm.bytes(g), &lzr_lds, prof ? prof + 32 * (size_t)g + 16 : nullptr);
@@ -182,10 +200,12 @@ hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStr
     if (!ws_off && stride < sizeof(lzr::StreamHeader)) return hipErrorInvalidValue;
     const WsMap wm{(uint8_t*)ws, stride, ws_off};
     const dim3 block(kWave);
+    // (streams of unequal cost -- stored blocks, incompressible stretches -- are launched longest first, like the LZ4 blocks)
+    const uint32_t* order = SWC_INFLATE_ORDER ? job_order(jobs, n, stream) : nullptr;
     g_pt.begin(stream);
-    hipLaunchKernelGGL(swc_inflate_sync_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof);
+    hipLaunchKernelGGL(swc_inflate_sync_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
-    hipLaunchKernelGGL(swc_lz_resolve_kernel, dim3((unsigned)n), dim3(kInflateResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof);
+    hipLaunchKernelGGL(swc_lz_resolve_kernel, dim3((unsigned)n), dim3(kInflateResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
     return hipGetLastError();
 }
