@@ -280,7 +280,7 @@ hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_
 
 // ---- LZ4 block compression (lz4_comp.h), one block per wavefront, the hash table in LDS -------------------------------------
 __global__ __launch_bounds__(64) void swc_lz4_compress_kernel(Job* __restrict__ jobs, uint32_t n, const uint32_t* __restrict__ order) {
-    __shared__ uint32_t table[lz4c::kHashSize];
+    __shared__ __attribute__((aligned(16))) uint16_t table[lz4c::kHashSize];
     uint32_t g = job_of(order, blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];

@@ -6,14 +6,16 @@
 // length extensions / literals / offset / length extensions (:216-250), a final literals-only sequence (:253-277).
 //
 // The reference's table is an exact dictionary (Swift Dictionary keyed by the four bytes); a GPU wave keeps a HASH table of
-// 8,192 positions in LDS instead, looks 64 consecutive positions up at once, and takes the matches of such a window greedily
-// from the left.  The output therefore is A valid LZ4 block for the same bytes, not the reference's bytes: the contract of
+// 8,192 positions in LDS instead (16-bit entries: the low half of the position -- a match reaches 65,535 bytes back, so the
+// half is the distance; 16 KB per wave = two waves per SIMD, which is what hides the latency of this kernel's dependent
+// global reads), looks 64 consecutive positions up at once, and takes the matches of such a window greedily from the left.  The output therefore is A valid LZ4 block for the same bytes, not the reference's bytes: the contract of
 // this path is decode(compress(x)) == x under the reference decoder's rules (LZ4.swift:332-413, end-of-block rules
 // included), checked against the oracle and liblz4 -- not byte parity of the compressed stream.
 //
-//   window   lane i hashes the four bytes at pos + i, reads the table's candidate, then enters its own position (the highest
-//            position of a hash wins: a maximum, so the result does not depend on the order of the lanes); a candidate counts
-//            if it lies at most 65,535 bytes back and its four bytes are equal;
+//   window   lane i hashes the four bytes at pos + i, reads the table's candidate, then enters its own position (of the lanes of
+//            a window that share a hash the HIGHEST enters: found with one ballot per hash bit, so the result does not depend
+//            on the order of the lanes); a candidate counts if it lies 1 .. 65,535 bytes back, not in front of the buffer,
+//            and its four bytes are equal -- an entry that is stale or was never written only yields a candidate that fails;
 //   greedy   the leftmost lane with a candidate: all 64 lanes extend its match together (64 bytes per step), the sequence is
 //            written -- literals copied by all lanes -- and the search goes on behind the match, inside the window or beyond;
 //   prefix   a dictionary / the tail of the previous block (dependent blocks) is handed over as bytes IN FRONT of the block in
@@ -30,22 +32,14 @@ namespace lz4c {
 #ifndef SWC_LZ4C_HASH_BITS
 #define SWC_LZ4C_HASH_BITS 13
 #endif
-// 8,192 positions = 32 KB of LDS per wave.  The size of the table is the compression ratio: against the reference's exact
+// 8,192 positions = 16 KB of LDS per wave.  The size of the table is the compression ratio: against the reference's exact
 // dictionary (oracle/rc_lz4c.c) on text 2,048 entries lose 22 %, 4,096 12 %, 8,192 5 %, 16,384 1 % (tests/test_lz4_compress.py).
 constexpr uint32_t kHashBits = SWC_LZ4C_HASH_BITS, kHashSize = 1u << kHashBits;
-constexpr uint32_t kLdsBytes = kHashSize * 4;
+constexpr uint32_t kLdsBytes = kHashSize * 2;
 
 SWC_HD uint32_t hash4(uint32_t w) { return (w * 2654435761u) >> (32 - kHashBits); }
 // LZ4_compressBound: the largest block `n` bytes can turn into (all literals)
 SWC_HD uint64_t bound(uint64_t n) { return n + n / 255 + 16; }
-
-SWC_D void lds_max(uint32_t* p, uint32_t v) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-#else
-    if (v > *p) *p = v;
-#endif
-}
 
 template <int N>
 struct Compressor {
@@ -54,8 +48,8 @@ struct Compressor {
     uint64_t end;       // one past its last byte
     gptr out;
     uint64_t cap, opos; // output capacity, bytes written (keeps counting past the capacity)
-    uint32_t* table;    // kHashSize positions + 1 (0: none); positions are relative to `tbase`
-    uint64_t tbase;
+    uint16_t* table;    // kHashSize entries: the low 16 bits of the most recent position of the hash
+    uint64_t tbase;     // the buffer's first byte a match may start at
 
     // `cnt` bytes src[from ..] -> out, all lanes
     SWC_D void copy_out(uint64_t from, uint64_t cnt) {
@@ -94,16 +88,36 @@ struct Compressor {
 
     SWC_D void run() {
         using simt::PT;
-        SIMT_BEGIN(t, N) for (uint32_t i = (uint32_t)t; i < kHashSize; i += N) table[i] = 0; SIMT_END_WAVE
-        PT<uint32_t, N> cand, word;
-        PT<bool, N> pb;
+        SIMT_BEGIN(t, N) for (uint32_t i = (uint32_t)t; i < kHashSize / 2; i += N) ((uint32_t*)table)[i] = 0; SIMT_END_WAVE
+        PT<uint32_t, N> cand, word, hsh;
+        PT<bool, N> pb, last;
+        // of the lanes that hold the same hash, the highest: one ballot per bit of the hash narrows the set of equals
+        auto highest_of_equals = [&](uint64_t valid) {
+            PT<uint32_t, N> mlo, mhi;
+            SIMT_BEGIN(t, N) mlo[t] = (uint32_t)valid; mhi[t] = (uint32_t)(valid >> 32); SIMT_END
+            for (uint32_t b = 0; b < kHashBits; b++) {
+                SIMT_BEGIN(t, N) pb[t] = ((hsh[t] >> b) & 1u) != 0u; SIMT_END
+                const uint64_t bal = simt::wave_ballot<N>(pb);
+                SIMT_BEGIN(t, N)
+                    const uint64_t same = ((hsh[t] >> b) & 1u) ? bal : ~bal;
+                    mlo[t] &= (uint32_t)same; mhi[t] &= (uint32_t)(same >> 32);
+                SIMT_END
+            }
+            SIMT_BEGIN(t, N)
+                const uint64_t m = ((uint64_t)mhi[t] << 32) | mlo[t];
+                last[t] = ((valid >> t) & 1ull) != 0ull && (t == N - 1 || (m >> (t + 1)) == 0ull);
+            SIMT_END
+        };
         // the prefix enters the table (its last 65,535 bytes are all a match can reach)
         tbase = start > 65536 ? start - 65536 : 0;
         for (uint64_t p0 = tbase; p0 + 4 <= start; p0 += N) {
             SIMT_BEGIN(t, N)
                 const uint64_t p = p0 + (uint32_t)t;
-                if (p + 4 <= start) lds_max(&table[hash4(load_u32(src + p))], (uint32_t)(p - tbase) + 1u);
-            SIMT_END_WAVE
+                pb[t] = p + 4 <= start;
+                hsh[t] = pb[t] ? hash4(load_u32(src + p)) : 0u;
+            SIMT_END
+            highest_of_equals(simt::wave_ballot<N>(pb));
+            SIMT_BEGIN(t, N) if (last[t]) table[hsh[t]] = (uint16_t)(p0 + (uint32_t)t); SIMT_END_WAVE
         }
         uint64_t pos = start, anchor = start;
         // a match starts at or before end - 12 and ends at or before end - 5 (LZ4+Compress.swift:185, 204-214)
@@ -114,17 +128,21 @@ struct Compressor {
                 const bool ok = p <= mflimit;
                 const uint32_t w = ok ? load_u32(src + p) : 0u;
                 word[t] = w;
-                cand[t] = ok ? table[hash4(w)] : 0u;
+                hsh[t] = ok ? hash4(w) : 0u;
+                cand[t] = ok ? (uint32_t)table[hsh[t]] : 0u;
+                pb[t] = ok;
             SIMT_END_WAVE
+            highest_of_equals(simt::wave_ballot<N>(pb));
             SIMT_BEGIN(t, N)
                 const uint64_t p = pos + (uint32_t)t;
-                if (p <= mflimit) lds_max(&table[hash4(word[t])], (uint32_t)(p - tbase) + 1u);
+                if (last[t]) table[hsh[t]] = (uint16_t)p;
                 bool v = false;
-                if (cand[t] != 0u) {
-                    const uint64_t c = tbase + cand[t] - 1u;
-                    v = c < p && p - c <= 65535 && load_u32(src + c) == word[t];
+                if (p <= mflimit) {
+                    const uint32_t d = ((uint32_t)p - cand[t]) & 0xFFFFu;      // the entry is the low half of a position: this is the distance
+                    v = d != 0u && (uint64_t)d <= p - tbase && load_u32(src + p - d) == word[t];
                 }
                 pb[t] = v;
+                cand[t] = ((uint32_t)p - cand[t]) & 0xFFFFu;                 // from here on: the distance
             SIMT_END_WAVE
             const uint64_t m = simt::wave_ballot<N>(pb);
             uint32_t cur = 0;
@@ -134,7 +152,7 @@ struct Compressor {
                 const uint32_t f = (uint32_t)simt::ctz64(m2);
                 const uint64_t mp = pos + f;
                 if (mp < anchor) { cur = f + 1; continue; }     // (inside the match just written)
-                const uint64_t c = tbase + simt::uniform(simt::wave_read<N>(cand, (int)f)) - 1u;
+                const uint64_t c = mp - simt::uniform(simt::wave_read<N>(cand, (int)f));
                 uint64_t len = 4;
                 for (;;) {   // all lanes extend the match, 64 bytes per step
                     SIMT_BEGIN(t, N)
@@ -158,7 +176,7 @@ struct Compressor {
 // One wavefront = one job: job.in = prefix ++ block, job.dict_len = length of the prefix, job.in_len = both together.
 // job.out_len = bytes of the compressed block (SWC_E_CAPACITY with the size needed if it does not fit out_cap).
 template <int N>
-SWC_D void lz4_compress_job(Job& job, uint32_t* table) {
+SWC_D void lz4_compress_job(Job& job, uint16_t* table) {
     Compressor<N> c;
     c.src = (gcptr)job.in;
     c.start = job.dict_len <= job.in_len ? job.dict_len : job.in_len;

@@ -57,7 +57,7 @@ extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {
 
 // LZ4 block compression (lz4_comp.h): job.in = prefix ++ block, job.dict_len = length of the prefix
 extern "C" void emu_lz4_compress(swc::Job* jobs, size_t n) {
-    static uint32_t table[swc::lz4c::kHashSize];
+    alignas(16) static uint16_t table[swc::lz4c::kHashSize];
     for (size_t g = 0; g < n; g++) {
         std::memset(table, 0xEE, sizeof table);
         swc::lz4c::lz4_compress_job<64>(jobs[g], table);
