@@ -20,6 +20,7 @@
 #include "inflate_lane.h"
 #include "inflate_sync.h"
 #include "lz_resolve.h"
+#include "lz_copy.h"
 #include "lz4_lane.h"
 #include "lz4_wave.h"
 #include "lz4_comp.h"
@@ -165,6 +166,32 @@ __global__ __launch_bounds__(kInflateResolveThreads) void swc_lz_resolve_kernel(
     lzr::resolve_job<kInflateResolveThreads, kInflateRingLog2, kInflateKeep>(job, wm.area(g), wm.bytes(g), &lzr_lds, prof ? prof + 32 * (size_t)g + 16 : nullptr);
 }
 
+// Phase 2, record-granular (lz_copy.h): one stream per WAVEFRONT, the last 6-8 KiB of its output in an LDS window of 8 KiB
+// (9.2 KB of LDS per wave -> 16 waves per CU), older sources read back from the output buffer.  The 16 KiB variant
+// (8 waves per CU, fewer far reads) is kept for comparison runs.
+template <uint32_t WIN, uint32_t SPAN>
+__device__ __forceinline__ void lz_copy_body(const Job* __restrict__ jobs, uint32_t n, const WsMap& wm, const uint32_t* __restrict__ order) {
+    __shared__ __attribute__((aligned(16))) lzc::Lds<WIN> lds;
+    uint32_t g = job_of(order, blockIdx.x, n);
+    if (g >= n) return;
+    Job job = jobs[g];
+    if (job.dict != nullptr) return;   // (LZ4 blocks with a dictionary prefix were decoded by the lane kernel)
+    lzc::copy_job<WIN, SPAN>(job, wm.area(g), wm.bytes(g), &lds);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void swc_lz_copy_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, const uint32_t* __restrict__ order) {
+    lz_copy_body<8192, 2048>(jobs, n, wm, order);
+}
+__global__ __launch_bounds__(64) void swc_lz_copy16_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, const uint32_t* __restrict__ order) {
+    lz_copy_body<16384, 2048>(jobs, n, wm, order);
+}
+// "lz_copier" (swc_set_tuning): 1 = lz_copy.h with an 8 KiB window (default), 2 = with a 16 KiB window, 0 = the byte-cell resolver
+// of lz_resolve.h (rounds 2-4) -- kept for A/B measurements; all produce the same bytes.
+static std::atomic<int> g_lz_copier{1};
+void set_lz_copier(int v) { g_lz_copier = v; }
+static void launch_lz_copy(int mode, const Job* jobs, size_t n, const WsMap& wm, const uint32_t* order, hipStream_t stream) {
+    if (mode == 2) hipLaunchKernelGGL(swc_lz_copy16_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, jobs, (uint32_t)n, wm, order);
+    else hipLaunchKernelGGL(swc_lz_copy_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, jobs, (uint32_t)n, wm, order);
+}
 
 // Optional per-kernel timing of the calling thread's last batch launch (bench.py: roofline per kernel).  HIP events on the
 // launch stream between the kernels; off by default so that the production path issues nothing but the kernels.
@@ -205,7 +232,9 @@ hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStr
     g_pt.begin(stream);
     hipLaunchKernelGGL(swc_inflate_sync_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
-    hipLaunchKernelGGL(swc_lz_resolve_kernel, dim3((unsigned)n), dim3(kInflateResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
+    const int copier = g_lz_copier;
+    if (copier) launch_lz_copy(copier, jobs, n, wm, order, stream);
+    else hipLaunchKernelGGL(swc_lz_resolve_kernel, dim3((unsigned)n), dim3(kInflateResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
     return hipGetLastError();
 }
@@ -273,7 +302,9 @@ hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_
     const WsMap wm{(uint8_t*)ws, stride, ws_off};
     hipLaunchKernelGGL(swc_lz4_parse_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
-    hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(lz4w::kResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
+    const int copier = g_lz_copier;
+    if (copier) launch_lz_copy(copier, jobs, n, wm, order, stream);
+    else hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(lz4w::kResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
     return hipGetLastError();
 }

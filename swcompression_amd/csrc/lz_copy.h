@@ -1,0 +1,647 @@
+// lz_copy.h -- phase 2 of the Deflate and LZ4 paths, record-granular: LZ77 match resolution, one stream per WAVEFRONT,
+// the recent output in an LDS window, older output read back from HBM.
+//
+// The reference executes every back-reference inline, one byte per `out.append`
+// (Sources/Deflate/Deflate.swift:216-232, Sources/LZ4/LZ4.swift:398-410).  Phase 1 (inflate_sync.h, lz4_wave.h) leaves a
+// record list and a dense literal stream per stream in the workspace (formats: lz_resolve.h).  Here the 64 lanes of a wave
+// OWN RECORDS, not bytes:
+//
+//   group      64 consecutive records, one per lane (fewer when they cover more than kSpanMax output bytes or more literals
+//              than the literal buffer holds).  One packed prefix scan over (literals + length, literals) gives every lane
+//              the place of its literals and of its match in the output;
+//   literals   every lane copies its own literal run from the staged literal stream into the window: the first eight bytes
+//              without a branch (two dword reads, four stores whose ADDRESS is the lane's trash slot when the store is not
+//              wanted -- LDS accesses at any byte alignment are single instructions on gfx950), the rest eight bytes a step;
+//   matches    a lane copies its match the same way -- up to 32 bytes as four eight-byte pieces, the last one shifted back to
+//              end on the match's last byte, no loop, no branch -- when its source is final at the start of the group: it
+//              ends in front of the group's first byte (in the window), or it lies in front of the window (FAR: then the bytes
+//              come from the output buffer in HBM and were asked for by front() one group AHEAD, into registers);
+//   the rest   -- matches that reach into their own group (9 % on text), matches longer than 32 bytes or overlapping
+//              themselves (distance < length), far matches nobody asked for -- are copied in record order, one after the other,
+//              by ALL lanes together (a dword per lane, 256 bytes per step; an overlapping match from its first period):
+//              the first record that has not been copied yet finds everything in front of it final.  A group with many of
+//              them (more than kSeqMax) falls back to rounds by watermark: with the head, every lane whose source ends
+//              in front of the head's match copies its own;
+//   window     a LINEAR array, not a ring: when a group does not fit behind the write position any more, the finished bytes
+//              are flushed to HBM (aligned 16-byte stores, the only time the output is written) and the last kKeep bytes
+//              move to the front of the array (16 bytes per lane and step).  No index masks anywhere in the copy code.
+//
+// One iteration = front(next group) + back(this group).  front() issues ALL global loads of the next group -- its far
+// sources, its literals, the records of the group behind it -- and nothing waits for them before the drain at the top of
+// the next iteration (s_waitcnt vmcnt(0)): a full group's copies lie between a load and its use.
+//
+// No workgroup barrier, no cross-wave traffic: a wave is alone with its stream.  Parity: the output is a function of the
+// record list alone; tests/test_lane_emulation_*.py run this source on the host (lane order forward, reverse and shuffled).
+#ifndef SWC_LZ_COPY_H
+#define SWC_LZ_COPY_H
+
+#include "swc_common.h"
+#include "simt.h"
+#include "lz_resolve.h"   // record format, StreamHeader, workspace layout
+
+#ifndef SWC_LZC_CUT
+#define SWC_LZC_CUT 0
+#endif
+
+namespace swc {
+namespace lzc {
+
+using lzr::u128;
+
+template <uint32_t WIN>
+struct Lds {
+    static constexpr uint32_t kWin = WIN;
+    static constexpr uint32_t kLitBuf = 1024;             // bytes of the literal stream staged at a time
+    alignas(16) uint8_t win[WIN + 16];                    // byte at virtual position v lives at win[v - vbase] (+16: reads of short runs overshoot)
+    alignas(16) uint8_t lit[kLitBuf + 16];                // literal at stream offset o lives at lit[o - lv]
+    alignas(8) uint8_t trash[64 * 8];                     // eight bytes per lane: where a store goes that is not wanted
+};
+
+SWC_HD uint32_t ld32(const uint8_t* p) { return *(const u32_unaligned*)p; }
+// LDS READS at any byte alignment are built from ALIGNED dwords and a byte funnel shift (v_alignbyte_b32 takes the shift from
+// the low bits of the address): the LDS serves an unaligned ds_read_b32 at about one LANE per cycle (63 cycles for a full
+// wave, tools/micro/lds_bench.hip), an aligned one in 6; unaligned STORES cost a quarter of a cycle per lane and stay.
+// `a` is the byte offset from the (16-byte aligned) base b; up to 7 (rd32u) / 11 (rd64u) bytes behind the value are touched.
+SWC_HD uint32_t alignbyte(uint32_t hi, uint32_t lo, uint32_t a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_alignbyte(hi, lo, a);
+#else
+    return (uint32_t)((((uint64_t)hi << 32) | lo) >> (8u * (a & 3u)));
+#endif
+}
+SWC_HD uint32_t rd32u(const uint8_t* b, uint32_t a) {
+    const uint32_t* p = (const uint32_t*)(b + (a & ~3u));
+    return alignbyte(p[1], p[0], a);
+}
+SWC_HD uint64_t rd64u(const uint8_t* b, uint32_t a) {
+    const uint32_t* p = (const uint32_t*)(b + (a & ~3u));
+    const uint32_t w0 = p[0], w1 = p[1], w2 = p[2];
+    return (uint64_t)alignbyte(w1, w0, a) | ((uint64_t)alignbyte(w2, w1, a) << 32);
+}
+SWC_HD void st32(uint8_t* p, uint32_t v) { *(u32_unaligned*)p = v; }
+SWC_HD void st64(uint8_t* p, uint64_t v) { *(u64_unaligned*)p = v; }
+SWC_HD void st16(uint8_t* p, uint32_t v) { *(u16_unaligned*)p = (uint16_t)v; }
+// n bytes (1..3) of the little-endian dword w to p
+SWC_HD void st_tail(uint8_t* p, uint32_t w, uint32_t n) {
+    if (n & 1u) p[0] = (uint8_t)w;
+    if (n & 2u) st16(p + (n & 1u), w >> (8u * (n & 1u)));
+}
+// n >= 1 bytes from s to d (both in LDS, any alignment, not overlapping): dwords, the last one shifted back to end on byte n - 1
+SWC_HD void copy_run(uint8_t* d, const uint8_t* s, uint32_t n) {
+    if (n >= 4u) {
+        for (uint32_t k = 0; k < n; k += 4u) {
+            const uint32_t o = k < n - 4u ? k : n - 4u;
+            st32(d + o, ld32(s + o));
+        }
+    } else {
+        st_tail(d, ld32(s), n);
+    }
+}
+
+template <uint32_t WIN, uint32_t SPAN>
+struct Copier {
+    using L = Lds<WIN>;
+    static constexpr int W = 64;
+    static constexpr uint32_t kSpanMax = SPAN;                 // output bytes one group may cover
+    static constexpr uint32_t kKeep = WIN - SPAN - 16u;        // history that survives a slide (a slide leaves kKeep .. kKeep + 15 bytes)
+    static constexpr uint32_t kLitBuf = L::kLitBuf, kLitCap = kLitBuf - 16u;   // literal bytes one group may take (whatever the alignment of its first one)
+    static constexpr uint32_t kBigLit = 256;                   // a literal-only record of at least this many bytes is copied by all lanes together, on its own
+    static constexpr int kPieces = 4;                          // eight-byte pieces of a match a lane copies on its own
+    static constexpr uint32_t kLongLen = 8u * kPieces;         // a longer match is copied by all lanes together
+    static constexpr uint32_t kLongLit = 64;                   // so is a longer literal run in front of a match
+    static constexpr uint32_t kSeqMax = 12;                    // more pending records than this: rounds by watermark
+    static constexpr uint32_t kBack = 65536;                   // the furthest a source lies behind its match (record format)
+    static constexpr uint32_t kLitOff = (uint32_t)offsetof(L, lit), kTrashOff = (uint32_t)offsetof(L, trash);
+    static_assert(lzr::kMaxLitOnly <= kSpanMax, "a literal-only record must fit the room a slide makes");
+    static_assert(lzr::kLitRunMax + lzr::kMaxLen <= kSpanMax && kBigLit - 1u <= kLitCap && lzr::kLitRunMax <= kLitCap, "a record must fit a group");
+    static_assert(64u * (kBigLit - 1u + lzr::kMaxLen + lzr::kLitRunMax) < 0x10000u, "the packed scan keeps 16 bits per sum");
+    // A far source lies in front of the window, i.e. at least kKeep - kMaxLen bytes behind the write position.  Finished bytes
+    // are flushed when a KiB of them has gathered, and what was issued before the last drain() has arrived: `landed`.  front()
+    // asks only for sources that end 128 bytes (a cache line: a line is never read while a part of it is still on its way)
+    // in front of `landed`; anything else waits for its turn in back() and drains first.
+    static_assert(kKeep >= 2u * (WIN - kKeep) + lzr::kMaxLen, "far sources must have left for HBM long before they are read");
+    enum : uint32_t { kFlagCoop = 1u, kFlagFar = 2u };
+
+    L* l;
+    gptr out;
+    gcptr lits;        // the stream's dense literal stream (16-byte aligned base)
+    uint64_t lit_cap;  // bytes that may be READ from it (allocation size, a multiple of 16)
+    uint64_t limit;    // bytes of `out` that exist: min(bytes produced, capacity)
+
+    // wave state (the same in every lane)
+    uint32_t A;        // out & 15: virtual position v = A + output position, so that 16-byte chunks of v are aligned in HBM
+    uint64_t vbase;    // virtual position of win[0] (a multiple of 16)
+    uint64_t fv;       // flush watermark (a multiple of 16): virtual positions below it have LEFT for `out`
+    uint64_t landed;   // ... and below this one they have ARRIVED (the flush watermark at the last full wait)
+
+    SWC_D static uint32_t mod_small(uint32_t m, uint32_t d) {   // m % d for m, d < 2^16, d != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+        uint32_t q = (uint32_t)((float)m * __builtin_amdgcn_rcpf((float)d));   // v_rcp_f32: off by at most one, fixed up below
+        uint32_t r = m - q * d;
+        if ((int32_t)r < 0) r += d;
+        if (r >= d) r -= d;
+        return r;
+#else
+        return m % d;
+#endif
+    }
+    SWC_D static void unpack(uint32_t r, uint32_t& li, uint32_t& le, uint32_t& di) {
+        li = r & 127u;
+        le = (r >> 7) & 511u;
+        if (le == 0u) li += (r >> 16) << 7;
+        di = le ? (r >> 16) + 1u : 0u;
+    }
+    // all of this wave's loads have returned and all of its stores have arrived in memory
+    SWC_D void drain() {
+        simt::vmem_fence();
+        landed = fv;
+    }
+    // The loads of a path that is rarely taken (all lanes on one long run, a far source nobody asked for ahead) are waited for
+    // before the path rejoins the others: behind the join the compiler would otherwise wait -- for EVERYTHING, the loads front()
+    // has just issued for the next group included -- wherever one of that path's destination registers is touched again.
+    SWC_D static void rare_path_done() { simt::vmem_fence(); }
+
+    // ---- flush: virtual positions [fv, vend) rounded down to whole 16-byte chunks go to HBM; `final`: the tail bytes too
+    SWC_D void flush(uint64_t vend, bool final) {
+        const uint64_t v16 = vend & ~(uint64_t)15;
+        const uint64_t vlim = (uint64_t)A + limit;              // virtual end of the output that exists
+        gptr obase = out - A;                                   // HBM address of virtual position 0 (16-byte aligned)
+        if (v16 > fv) {
+            const uint64_t f0 = fv;
+            const uint32_t w0 = (uint32_t)(f0 - vbase);
+            const uint32_t nchunk = (uint32_t)((v16 - f0) >> 4);
+            gptr ob = obase + f0;
+            const bool whole = f0 >= A && v16 <= vlim;          // (all but the first and the last flush of a stream)
+            if (whole) {
+                SIMT_BEGIN(t, W)
+                    for (uint32_t c = (uint32_t)t; c < nchunk; c += (uint32_t)W) lzr::store_16(ob + 16u * c, *(const u128*)(l->win + w0 + 16u * c));
+                SIMT_END_WAVE
+            } else {
+                SIMT_BEGIN(t, W)
+                    for (uint32_t c = (uint32_t)t; c < nchunk; c += (uint32_t)W) {
+                        const uint64_t cv = f0 + 16ull * c;
+                        if (cv >= A && cv + 16u <= vlim) {
+                            lzr::store_16(ob + 16u * c, *(const u128*)(l->win + w0 + 16u * c));
+                        } else {   // the first chunk of an unaligned output, the chunk the limit cuts
+                            for (uint32_t e = 0; e < 16u; e++)
+                                if (cv + e >= A && cv + e < vlim) ob[16u * c + e] = l->win[w0 + 16u * c + e];
+                        }
+                    }
+                SIMT_END_WAVE
+            }
+            fv = v16;
+        }
+        if (final && vend > fv) {
+            const uint32_t ntail = (uint32_t)(vend - fv);   // < 16
+            const uint64_t f0 = fv;
+            const uint32_t w0 = (uint32_t)(f0 - vbase);
+            SIMT_BEGIN(t, W)
+                if ((uint32_t)t < ntail && f0 + (uint32_t)t >= A && f0 + (uint32_t)t < vlim) obase[f0 + (uint32_t)t] = l->win[w0 + (uint32_t)t];
+            SIMT_END_WAVE
+        }
+    }
+
+    // ---- slide: make room behind the window index of output position rpos: flush what is finished, keep the last kKeep
+    // bytes, move them to the front.  Returns the new write index.
+    SWC_D uint32_t slide(uint64_t rpos) {
+        using simt::PT;
+        const uint64_t vcur = (uint64_t)A + rpos;
+        flush(vcur, false);
+        const uint64_t nb = (vcur - kKeep) & ~(uint64_t)15;     // (the caller slides only when vcur - vbase > kKeep + 16)
+        const uint32_t D = (uint32_t)(nb - vbase);
+        const uint32_t nmove = ((uint32_t)(vcur - nb) + 15u) >> 4;   // chunks that stay
+        for (uint32_t c0 = 0; c0 < nmove; c0 += (uint32_t)W) {
+            PT<u128, W> v;
+            SIMT_BEGIN(t, W)
+                v[t] = c0 + (uint32_t)t < nmove ? *(const u128*)(l->win + D + 16u * (c0 + (uint32_t)t)) : u128{0, 0, 0, 0};
+            SIMT_END_WAVE
+            SIMT_BEGIN(t, W)
+                if (c0 + (uint32_t)t < nmove) *(u128*)(l->win + 16u * (c0 + (uint32_t)t)) = v[t];
+            SIMT_END_WAVE
+        }
+        vbase = nb;
+        return (uint32_t)(vcur - nb);
+    }
+
+    // ---- all lanes copy n literal bytes from the literal stream in HBM (offset lo) to window index wd
+    SWC_D void coop_literals(uint32_t wd, uint64_t lo, uint32_t n) {
+        gcptr src = lits + lo;
+        SIMT_BEGIN(t, W)
+            for (uint32_t o = 4u * (uint32_t)t; o < n; o += 4u * (uint32_t)W) {
+                // (whole dwords are read: the literal stream's allocation ends 32 bytes behind its last byte)
+                const uint32_t w = load_u32(src + o);
+                if (o + 4u <= n) st32(l->win + wd + o, w);
+                else st_tail(l->win + wd + o, w, n - o);
+            }
+        SIMT_END_WAVE
+        rare_path_done();
+    }
+
+    // ---- all lanes copy one match of any kind: `wm` window index of its first byte, `n` bytes, `dist` back; `gsrc`: HBM
+    // address of the source's first byte (read where the source lies in front of the window)
+    SWC_D void coop_match(uint32_t wm, uint32_t n, uint32_t dist, gcptr gsrc) {
+        const int32_t ws = (int32_t)wm - (int32_t)dist;
+        if (n < 4u) {
+            // (a piece of a split match, or a far one of three bytes)
+            SIMT_BEGIN(t, W)
+                if ((uint32_t)t < n) l->win[wm + (uint32_t)t] = ws >= 0 ? l->win[ws + (int32_t)mod_small((uint32_t)t, dist)] : gsrc[t];
+            SIMT_END_WAVE
+        } else if (dist >= n || dist >= 4u * (uint32_t)W) {
+            // every step's source was finished by earlier steps or earlier records
+            for (uint32_t o0 = 0; o0 < n; o0 += 4u * (uint32_t)W) {
+                SIMT_BEGIN(t, W)
+                    const uint32_t o = o0 + 4u * (uint32_t)t;
+                    if (o < n) {
+                        const uint32_t oo = o + 4u <= n ? o : n - 4u;          // the last dword ends on the last byte
+                        const int32_t si = ws + (int32_t)oo;
+                        const uint32_t w = si >= 0 ? ld32(l->win + si) : load_u32(gsrc + oo);
+                        st32(l->win + wm + oo, w);
+                    }
+                SIMT_END_WAVE
+            }
+        } else {
+            // distance < length: byte k of the match is byte k % distance of its first period, which is final
+            // (the period is inside the window: distance < 256)
+            const uint32_t step = mod_small((uint32_t)W, dist);
+            simt::PT<uint32_t, W> ph;
+            SIMT_BEGIN(t, W) ph[t] = mod_small((uint32_t)t, dist); SIMT_END
+            for (uint32_t o0 = 0; o0 < n; o0 += (uint32_t)W) {
+                SIMT_BEGIN(t, W)
+                    const uint32_t k = o0 + (uint32_t)t;
+                    if (k < n) l->win[wm + k] = l->win[(uint32_t)ws + ph[t]];
+                    uint32_t p = ph[t] + step;
+                    if (p >= dist) p -= dist;
+                    ph[t] = p;
+                SIMT_END_WAVE
+            }
+        }
+        if (ws < 0) rare_path_done();
+    }
+
+    // ---- a group of records between front() (records -> places, loads asked for) and back() (the copies)
+    struct Group {
+        simt::PT<uint32_t, W> rec;            // the records
+        simt::PT<uint32_t, W> x;              // inclusive sums over the lanes: (literals + length) | literals << 16 (a big run: literal bytes)
+        simt::PT<uint64_t, W> fw[kPieces];    // far sources asked for ahead, eight bytes each
+        simt::PT<u128, W> litpf;              // the 16 bytes of the literal stream this lane stages when the group refills the buffer
+        uint32_t kind;                        // 0: records up to the first big literal-only one; 1: a run of big literal-only records
+        uint32_t ntake, span, litspan;        // records, output bytes, literal bytes of the group
+        uint64_t pf_vbase;                    // window base the far loads assumed (~0: none were wanted)
+        int32_t pf_lim;                       // ... and how far (relative to the group's first byte) a source they asked for may reach
+        uint64_t lv;                          // literal-stream offset of lit[0] while this group is copied
+        bool lit_refill;
+    };
+    // how far -- relative to output position rpos -- a far source may reach that is read now
+    SWC_D int32_t far_limit(uint64_t rpos) const {
+        const int64_t d = (int64_t)landed - (int64_t)((uint64_t)A + rpos) - 128;
+        return d < -(int64_t)0x40000000 ? -(int32_t)0x40000000 : d > 0 ? 0 : (int32_t)d;
+    }
+
+    // ---- front: the records of a group (`left` records remain from it on) that starts at output position `rpos`, literal
+    // offset `lbase`; `vb_pred`: the window base when the group in front of it has been copied (~0: unknown, no far loads
+    // ahead); `lv_prev`: the literal buffer's offset then.
+    // EVERY call issues the same loads, wanted or not (a lane that wants nothing reads a place that certainly exists): a
+    // register that is loaded on one path only reaches the next iteration through a copy, and the compiler waits for the
+    // load in front of the copy -- at once, instead of an iteration later.
+    SWC_D void front(Group& g, const simt::PT<uint32_t, W>& r_in, uint32_t left, uint64_t rpos, uint64_t lbase, uint64_t vb_pred, uint64_t lv_prev) {
+        using simt::PT;
+        PT<bool, W> big;
+        SIMT_BEGIN(t, W)
+            uint32_t li, le, di;
+            g.rec[t] = (uint32_t)t < left ? r_in[t] : 0u;   // (the lanes past the last record loaded it again)
+            unpack(g.rec[t], li, le, di);
+            big[t] = le == 0u && li >= kBigLit;
+        SIMT_END
+        const uint64_t bigmask = simt::wave_ballot<W>(big);
+        const uint32_t nb = bigmask ? (uint32_t)simt::ctz64(bigmask) : 64u;
+        g.lv = lv_prev;
+        g.lit_refill = false;
+        if (nb == 0u) {
+            // the group starts with big literal-only records: the run of them is a group of its own
+            uint32_t nrun = ~bigmask ? (uint32_t)simt::ctz64(~bigmask) : 64u;
+            if (nrun > left) nrun = left;
+            SIMT_BEGIN(t, W)
+                uint32_t li, le, di;
+                unpack(g.rec[t], li, le, di);
+                g.x[t] = (uint32_t)t < nrun ? li : 0u;
+            SIMT_END
+            simt::wave_scan_incl<W>(g.x);
+            g.kind = 1;
+            g.ntake = nrun;
+            g.span = g.litspan = simt::wave_read<W>(g.x, (int)nrun - 1);
+        } else {
+            SIMT_BEGIN(t, W)
+                uint32_t li, le, di;
+                unpack(g.rec[t], li, le, di);
+                g.x[t] = (uint32_t)t < nb ? (li + le) | (li << 16) : 0u;
+            SIMT_END
+            simt::wave_scan_incl<W>(g.x);
+            PT<bool, W> tk;
+            SIMT_BEGIN(t, W)
+                tk[t] = (uint32_t)t < left && (uint32_t)t < nb && (g.x[t] & 0xFFFFu) <= kSpanMax && (g.x[t] >> 16) <= kLitCap;
+            SIMT_END
+            const uint64_t tm = simt::wave_ballot<W>(tk);
+            const uint32_t ntake = ~tm ? (uint32_t)simt::ctz64(~tm) : 64u;     // >= 1: any single record that is not big fits
+            const uint32_t xl = simt::wave_read<W>(g.x, (int)ntake - 1);
+            g.kind = 0;
+            g.ntake = ntake;
+            g.span = xl & 0xFFFFu;
+            g.litspan = xl >> 16;
+            // the literal buffer is refilled when the group's literals reach past what is staged
+            if (g.litspan != 0u && (lv_prev == ~(uint64_t)0 || lbase + g.litspan > lv_prev + kLitBuf)) {
+                g.lv = lbase & ~(uint64_t)15;
+                g.lit_refill = true;
+            }
+        }
+        // ---- the literal stream from lbase (rounded down) on, 16 bytes per lane
+        {
+            const uint64_t lo = lbase & ~(uint64_t)15;
+            gcptr lb = lits + lo;
+            const uint32_t room = lit_cap - lo > 2048u ? 2048u : (uint32_t)(lit_cap - lo);   // (lo + 16 <= lit_cap: the allocation ends 32 bytes behind the last literal)
+            SIMT_BEGIN(t, W)
+                const uint32_t o = 16u * (uint32_t)t;
+                g.litpf[t] = lzr::load_16(lb + (o + 16u <= room ? o : 0u));
+            SIMT_END
+        }
+        // ---- far sources, one group ahead: 32-bit offsets from (the group's first byte - kBack)
+        {
+            const bool known = g.kind == 0u && vb_pred != ~(uint64_t)0;
+            uint64_t vp = known ? vb_pred : 0u;
+            const uint64_t vcur = (uint64_t)A + rpos;
+            if (known && (uint32_t)(vcur - vp) + g.span > WIN) vp = (vcur - kKeep) & ~(uint64_t)15;   // back() will slide (the same arithmetic)
+            const uint32_t wpn = (uint32_t)(vcur - vp);
+            g.pf_vbase = known ? vp : ~(uint64_t)0;
+            g.pf_lim = far_limit(rpos);
+            const int32_t lim = g.pf_lim;
+            const uint32_t ntake = g.ntake;
+            gcptr fb = (gcptr)out + ((int64_t)rpos - (int64_t)kBack);
+            const uint32_t idle = kBack - (rpos < kBack ? (uint32_t)rpos : kBack);      // a place that exists: the output's first bytes, or kBack bytes back
+            SIMT_BEGIN(t, W)
+                uint32_t li, le, di;
+                unpack(g.rec[t], li, le, di);
+                const int32_t srel = (int32_t)((g.x[t] & 0xFFFFu) - le - di);           // my source starts here, relative to the group's first byte
+                const bool ask = known && (uint32_t)t < ntake && le != 0u && (int32_t)wpn + srel < 0 && le <= kLongLen && di >= le && srel + (int32_t)le <= lim;
+                const uint32_t o0 = kBack + (uint32_t)srel;
+                const uint32_t last = (le > 8u ? le : 8u) - 8u;
+#pragma unroll
+                for (int k = 0; k < kPieces; k++) {
+                    const uint32_t ok = 8u * (uint32_t)k < last ? 8u * (uint32_t)k : last;
+                    g.fw[k][t] = load_u64(fb + (ask && 8u * (uint32_t)k < le ? o0 + ok : idle));
+                }
+            SIMT_END
+        }
+    }
+
+    // ---- back: the copies of a group
+    SWC_D void back(Group& g, uint64_t rpos, uint64_t lbase) {
+        using simt::PT;
+        if (g.kind == 1u) {
+            // a run of big literal-only records: all lanes copy them, one record after the other
+            uint64_t rp = rpos, lb = lbase;
+            for (uint32_t i = 0; i < g.ntake; i++) {
+                const uint32_t e1 = simt::wave_read<W>(g.x, (int)i);
+                const uint32_t n = (uint32_t)((uint64_t)rpos + e1 - rp);
+                uint32_t wp = (uint32_t)((uint64_t)A + rp - vbase);
+                if (wp + n > WIN) wp = slide(rp);
+                coop_literals(wp, lb, n);
+                rp += n;
+                lb += n;
+            }
+            return;
+        }
+        const uint32_t ntake = g.ntake;
+        uint32_t wp = (uint32_t)((uint64_t)A + rpos - vbase);
+        if (wp + g.span > WIN) wp = slide(rpos);
+#if SWC_LZC_CUT == 1   // (instruction accounting builds, tools/exp_copier_counts.sh: the output is wrong)
+        return;
+#endif
+        if (g.lit_refill) {   // (g.lv == lbase rounded down: what front() loaded)
+            SIMT_BEGIN(t, W) *(u128*)(l->lit + 16u * (uint32_t)t) = g.litpf[t]; SIMT_END_WAVE
+        }
+        uint8_t* const B = (uint8_t*)l;                                 // window indices are offsets from here
+        const uint32_t lrel = kLitOff + (uint32_t)(lbase - g.lv);
+        const int64_t gdelta = (int64_t)rpos - (int64_t)wp;             // output position = window index + gdelta
+        const bool pfu = g.pf_vbase == vbase;                           // the far loads assumed the window base that came to be
+        const int32_t pf_lim = g.pf_lim;
+        PT<uint32_t, W> lit, len, dist, wm, flags, si;   // si: a signed value
+        PT<bool, W> longlit, pend;
+        // ---- my literals' first eight bytes; my match, if its source was final when the group began
+        SIMT_BEGIN(t, W)
+            const bool mine = (uint32_t)t < ntake;
+            uint32_t li, le, di;
+            unpack(g.rec[t], li, le, di);
+            lit[t] = li; len[t] = le; dist[t] = di;
+            const uint32_t end = g.x[t] & 0xFFFFu, lend = g.x[t] >> 16;
+            const uint32_t wd = wp + end - li - le;                   // window index of my literals
+            const uint32_t m = wd + li;                               // ... of my match
+            const uint32_t s = m - di;                                // ... of its source (negative: in front of the window)
+            wm[t] = m;
+            si[t] = s;
+            // my literals (stores under the exec mask: the LDS takes as long over a store as lanes take part in it, and most
+            // lanes have no literals at all)
+            longlit[t] = mine && li > kLongLit;
+            if (mine && li != 0u && li <= kLongLit) {
+                const uint32_t ls = lrel + lend - li;
+                if (li > 8u) {
+                    for (uint32_t k = 0; k < li; k += 8u) {
+                        const uint32_t o = k < li - 8u ? k : li - 8u;
+                        st64(B + wd + o, rd64u(B, ls + o));
+                    }
+                } else if (li >= 4u) {           // bytes [0, 4) and [li - 4, li)
+                    const uint32_t w0 = rd32u(B, ls), w1 = rd32u(B, ls + li - 4u);
+                    st32(B + wd, w0);
+                    st32(B + wd + li - 4u, w1);
+                } else {
+                    st_tail(B + wd, rd32u(B, ls), li);
+                }
+            }
+            const bool far = (int32_t)s < 0;
+            const bool coop = le > kLongLen || di < le;
+            flags[t] = (coop ? (uint32_t)kFlagCoop : 0u) | (far ? (uint32_t)kFlagFar : 0u);
+            const int32_t srel = (int32_t)(end - le - di);
+            const bool pf = far && pfu && srel + (int32_t)le <= pf_lim;            // front() asked for it
+            const bool old = !far && s + le <= wp;                                  // it ends in front of the group
+            const bool act = mine && le != 0u && !coop && (pf || old);
+            pend[t] = mine && le != 0u && !act;
+            // my match, if its source was final when the group began: eight-byte pieces, the last one shifted back to end on
+            // the last byte; four to seven bytes as two dwords
+            if (act) {
+                if (le >= 8u) {
+                    const uint32_t last = le - 8u;
+                    st64(B + m, far ? g.fw[0][t] : rd64u(B, s));
+                    if (le > 8u) {
+                        const uint32_t o1 = 8u < last ? 8u : last;
+                        st64(B + m + o1, far ? g.fw[1][t] : rd64u(B, s + o1));
+                        if (le > 16u) {
+                            const uint32_t o2 = 16u < last ? 16u : last;
+                            st64(B + m + o2, far ? g.fw[2][t] : rd64u(B, s + o2));
+                            if (le > 24u) st64(B + m + last, far ? g.fw[3][t] : rd64u(B, s + last));
+                        }
+                    }
+                } else {
+                    const uint64_t v0 = far ? g.fw[0][t] : rd64u(B, s);
+                    if (le >= 4u) {
+                        st32(B + m, (uint32_t)v0);
+                        st32(B + m + (le & 3u), (uint32_t)(v0 >> (8u * (le & 3u))));
+                    } else {
+                        st_tail(B + m, (uint32_t)v0, le);
+                    }
+                }
+            }
+        SIMT_END_WAVE
+#if SWC_LZC_CUT == 2
+        return;
+#endif
+        // ---- long literal runs by all lanes
+        for (uint64_t m = simt::wave_ballot<W>(longlit); m; m &= m - 1u) {
+            const int h = simt::ctz64(m);
+            const uint32_t li = simt::wave_read<W>(lit, h);
+            const uint32_t lend = simt::wave_read<W>(g.x, h) >> 16;
+            coop_literals(simt::wave_read<W>(wm, h) - li, lbase + lend - li, li);
+        }
+#if SWC_LZC_CUT == 3
+        return;
+#endif
+        // ---- everything else in record order: the first record that has not been copied finds all bytes in front of it final
+        PT<bool, W> odd;
+        SIMT_BEGIN(t, W) odd[t] = pend[t] && flags[t] != 0u; SIMT_END
+        uint64_t pm = simt::wave_ballot<W>(pend);
+        const uint64_t om = simt::wave_ballot<W>(odd);
+        bool many = (uint32_t)simt::popc64(pm) > kSeqMax;
+        if (om == 0ull && !many) {
+            // the usual case: a few short matches that reach into the group (source in the window, not overlapping): one after
+            // the other, a byte per lane
+            while (pm) {
+                const int h = simt::ctz64(pm);
+                pm &= pm - 1u;
+                const uint32_t hm = simt::wave_read<W>(wm, h), hs = simt::wave_read<W>(si, h), hn = simt::wave_read<W>(len, h);
+                SIMT_BEGIN(t, W)
+                    if ((uint32_t)t < hn) B[hm + (uint32_t)t] = B[hs + (uint32_t)t];
+                SIMT_END_WAVE
+            }
+            return;
+        }
+        while (pm) {
+            const int h = simt::ctz64(pm);
+            const uint32_t hm = simt::wave_read<W>(wm, h);
+            if (!((om >> h) & 1u)) {
+                if (many) {
+                    // many of them: a round by watermark -- with the head, every lane whose source ends in front of the head's
+                    // match copies its own
+                    PT<bool, W> rdy;
+                    const uint64_t pm0 = pm;
+                    SIMT_BEGIN(t, W)
+                        rdy[t] = ((pm0 >> t) & 1u) != 0u && flags[t] == 0u && si[t] + len[t] <= hm;
+                        if (rdy[t]) copy_run(l->win + wm[t], l->win + si[t], len[t]);
+                    SIMT_END_WAVE
+                    pm &= ~simt::wave_ballot<W>(rdy);
+                    many = (uint32_t)simt::popc64(pm) > kSeqMax;
+                    continue;
+                }
+                // a short match that reaches into the group (its source is in the window and does not overlap it): a byte per lane
+                const uint32_t hs = simt::wave_read<W>(si, h), hn = simt::wave_read<W>(len, h);
+                SIMT_BEGIN(t, W)
+                    if ((uint32_t)t < hn) B[hm + (uint32_t)t] = B[hs + (uint32_t)t];
+                SIMT_END_WAVE
+                pm &= pm - 1u;
+                continue;
+            }
+            pm &= pm - 1u;
+            const uint32_t hs = simt::wave_read<W>(si, h), hn = simt::wave_read<W>(len, h);
+            const uint32_t fl = simt::wave_read<W>(flags, h);
+            const int64_t sp = (int64_t)(int32_t)hs + gdelta;      // >= 0: phase 1 rejects a distance beyond the output
+            if ((fl & (uint32_t)kFlagFar) && (int32_t)((int32_t)hs - (int32_t)wp) + (int32_t)hn > far_limit(rpos)) drain();
+            coop_match(hm, hn, simt::wave_read<W>(dist, h), (gcptr)out + (sp >= 0 ? sp : 0));
+        }
+    }
+
+    // a stream of a few bytes: one lane builds it in the window, byte by byte (the prefetches of run() read eight bytes that exist)
+    SWC_D void tiny(const SWC_AS_GLOBAL uint32_t* recs, uint32_t nrec) {
+        const uint32_t lim = (uint32_t)limit;   // < 64
+        SIMT_BEGIN(t, W)
+            if (t == 0) {
+                uint32_t pos = 0;
+                uint64_t lp = 0;
+                for (uint32_t i = 0; i < nrec && pos < lim; i++) {
+                    uint32_t li, le, di;
+                    unpack(recs[i], li, le, di);
+                    for (uint32_t k = 0; k < li && pos < lim; k++, pos++, lp++) l->win[pos] = lits[lp];
+                    for (uint32_t k = 0; k < le && pos < lim; k++, pos++) l->win[pos] = pos >= di ? l->win[pos - di] : (uint8_t)0;
+                }
+            }
+        SIMT_END_WAVE
+        SIMT_BEGIN(t, W)
+            if ((uint32_t)t < lim) out[t] = l->win[t];
+        SIMT_END_WAVE
+    }
+
+    SWC_D void run(const SWC_AS_GLOBAL uint32_t* recs, uint32_t nrec) {
+        using simt::PT;
+        A = (uint32_t)(uintptr_t)out & 15u;
+        vbase = 0;
+        fv = 0;
+        landed = 0;
+        if (nrec == 0) return;
+        if (limit < 64u) { tiny(recs, nrec); return; }
+        uint64_t rpos = 0;               // output bytes finished by earlier groups
+        uint64_t lbase = 0;              // literal bytes consumed by earlier groups
+        uint32_t base = 0;               // first record of the group
+        PT<uint32_t, W> r_nx;            // the records of the group after `nxt`, on their way
+        Group cur, nxt;
+        const uint32_t rlast4 = 4u * (nrec - 1u);
+        gcptr rb = (gcptr)recs;
+        SIMT_BEGIN(t, W) r_nx[t] = load_u32(rb + (4u * (uint32_t)t < rlast4 ? 4u * (uint32_t)t : rlast4)); SIMT_END
+        front(nxt, r_nx, nrec, 0, 0, ~(uint64_t)0, ~(uint64_t)0);
+        {
+            const uint32_t b4 = 4u * nxt.ntake;
+            SIMT_BEGIN(t, W) r_nx[t] = load_u32(rb + (b4 + 4u * (uint32_t)t < rlast4 ? b4 + 4u * (uint32_t)t : rlast4)); SIMT_END
+        }
+        bool more = true;
+        while (more) {
+            // Everything asked for during the last iteration -- the next records, far sources, literals -- is here, and its
+            // stores have arrived (an iteration's loads have the whole of the previous group's copies to come back).
+            drain();
+            cur = nxt;
+            const uint32_t nbase = base + cur.ntake;
+            more = nbase < nrec;
+            if (more) {
+                uint64_t vbp = ~(uint64_t)0;
+                if (cur.kind == 0u) {   // the window base when `cur` has been copied (slide()'s arithmetic)
+                    vbp = vbase;
+                    const uint64_t vcur = (uint64_t)A + rpos;
+                    if ((uint32_t)(vcur - vbp) + cur.span > WIN) vbp = (vcur - kKeep) & ~(uint64_t)15;
+                }
+                front(nxt, r_nx, nrec - nbase, rpos + cur.span, lbase + cur.litspan, vbp, cur.lv);
+                const uint32_t b4 = 4u * (nbase + nxt.ntake);
+                SIMT_BEGIN(t, W) r_nx[t] = load_u32(rb + (b4 + 4u * (uint32_t)t < rlast4 ? b4 + 4u * (uint32_t)t : rlast4)); SIMT_END
+            }
+            back(cur, rpos, lbase);
+            base = nbase;
+            rpos += cur.span;
+            lbase += cur.litspan;
+            // finished bytes leave for HBM a KiB at a time (whole-wave stores), long before they leave the window
+            if ((uint64_t)A + rpos - fv >= 1024u) flush((uint64_t)A + rpos, false);
+        }
+        drain();
+        flush((uint64_t)A + rpos, true);
+    }
+};
+
+// One job: `ws` is the stream's workspace area of `area` bytes written by phase 1.
+template <uint32_t WIN, uint32_t SPAN>
+SWC_D void copy_job(const Job& job, const uint8_t* ws, size_t area, Lds<WIN>* lds) {
+    const SWC_AS_GLOBAL lzr::StreamHeader* h = (const SWC_AS_GLOBAL lzr::StreamHeader*)ws;
+    const size_t lo = lzr::lit_offset(area, job.out_cap);
+    if (lo == 0) return;   // no literal stream: phase 1 reported SWC_E_NEED_WORKSPACE for this job
+    Copier<WIN, SPAN> cp;
+    cp.l = lds;
+    cp.out = (gptr)job.out;
+    cp.lits = (gcptr)ws + lo;
+    cp.lit_cap = lzr::lit_bytes(job.out_cap);
+    cp.limit = job.out_len < job.out_cap ? job.out_len : job.out_cap;
+    cp.run((const SWC_AS_GLOBAL uint32_t*)(ws + sizeof(lzr::StreamHeader)), h->nrec);
+}
+
+}  // namespace lzc
+}  // namespace swc
+#endif

@@ -46,9 +46,13 @@ SWC_D void wave_fence() {
 #endif
 }
 // all of this wave's vector-memory operations (loads and stores) have completed
+// (the builtin, not an asm string: the compiler's own wait insertion then KNOWS that nothing is outstanding behind it and
+// does not wait again -- for everything, loads issued later included -- at the first use of a register loaded before it)
 SWC_D void vmem_fence() {
 #if defined(__HIP_DEVICE_COMPILE__)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    asm volatile("" ::: "memory");
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt and lgkmcnt not waited for (gfx9 encoding)
+    asm volatile("" ::: "memory");
 #endif
 }
 #define SIMT_BEGIN(t, N) { const int t = (int)threadIdx.x; (void)t;

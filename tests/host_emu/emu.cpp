@@ -10,11 +10,16 @@
 #include "../../swcompression_amd/csrc/lz4_lane.h"
 #include "../../swcompression_amd/csrc/lz4_wave.h"
 #include "../../swcompression_amd/csrc/lz4_comp.h"
+#include "../../swcompression_amd/csrc/lz_copy.h"
 #include "../../swcompression_amd/csrc/lzma_wave.h"
 #include "../../swcompression_amd/csrc/bzip2_block.h"
 #include "../../swcompression_amd/csrc/crc32_group.h"
 
 extern "C" void emu_set_order(int o) { swc::simt::g_order = o; }
+// phase 2: 1 = the record-granular copier of lz_copy.h (what the library ships), 0 = the byte-cell resolver of lz_resolve.h
+static int g_copier = 1;
+extern "C" void emu_set_copier(int on) { g_copier = on; }
+constexpr uint32_t kEmuWin = 8192, kEmuSpan = 2048;
 
 // Deflate, one stream per wavefront with 64 sub-chunks decoded at once (inflate_sync.h): the uniform parts run once, the
 // 64 lanes of every parallel region one after another (csrc/simt.h).
@@ -26,6 +31,12 @@ extern "C" void emu_inflate_sync(swc::Job* jobs, size_t n) {
         size_t wsb = swc::lzr::ws_bytes_per_job(jobs[g].out_cap);
         std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
         swc::inflate::inflate_sync_job(jobs[g], &sl, ws.data(), wsb, 0, 1);
+        if (g_copier) {
+            alignas(16) static swc::lzc::Lds<kEmuWin> cl;
+            std::memset(&cl, 0xEE, sizeof cl);
+            swc::lzc::copy_job<kEmuWin, kEmuSpan>(jobs[g], ws.data(), wsb, &cl);
+            continue;
+        }
         std::memset(&rl, 0xEE, sizeof rl);
         swc::lzr::resolve_job<512, 16, 32768>(jobs[g], ws.data(), wsb, &rl);
     }
@@ -50,6 +61,12 @@ extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {
         alignas(16) static uint8_t stage[swc::lz4w::kStageLds];
         std::memset(stage, 0xEE, sizeof stage);
         swc::lz4w::lz4_parse_job<1>(jobs[g], ws.data(), wsb, 0, stage);
+        if (g_copier) {
+            alignas(16) static swc::lzc::Lds<kEmuWin> cl;
+            std::memset(&cl, 0xEE, sizeof cl);
+            swc::lzc::copy_job<kEmuWin, kEmuSpan>(jobs[g], ws.data(), wsb, &cl);
+            continue;
+        }
         std::memset(&rl, 0xEE, sizeof rl);
         swc::lzr::resolve_job<swc::lz4w::kResolveThreads, swc::lz4w::kRingLog2, swc::lz4w::kKeep, true>(jobs[g], ws.data(), wsb, &rl);
     }
@@ -98,6 +115,29 @@ extern "C" void emu_bzip2_block(swc::Job* jobs, size_t n, size_t lcap) {
         if (stage3_expand_needed(w)) stage3_expand_job(jobs[g], w);
         if (jobs[g].status == SWC_OK)
             stage3_check_crc(jobs[g], swc::crc::crc_group<1, uint32_t, true>(jobs[g].out, jobs[g].out_len, &crc_lds, 0));
+    }
+}
+
+// Phase 2 alone (tests/test_lz_copy_records.py): a record list and a literal stream made by the test, laid out as phase 1 lays
+// them out in a workspace area, through lz_copy.h (copier != 0) or lz_resolve.h; `out` may sit at any alignment.
+extern "C" void emu_copy_records(const uint32_t* recs, uint32_t nrec, const uint8_t* lits, size_t nlit, uint8_t* out, size_t cap, size_t out_len, int copier) {
+    const size_t wsb = swc::lzr::ws_bytes_per_job(cap);
+    std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
+    swc::lzr::StreamHeader* h = (swc::lzr::StreamHeader*)ws.data();
+    h->nrec = nrec;
+    h->nlit = nlit;
+    std::memcpy(ws.data() + sizeof(swc::lzr::StreamHeader), recs, 4 * (size_t)nrec);
+    std::memcpy(ws.data() + swc::lzr::lit_offset(wsb, cap), lits, nlit);
+    swc::Job j{};
+    j.out = out; j.out_cap = cap; j.out_len = out_len;
+    if (copier) {
+        alignas(16) static swc::lzc::Lds<kEmuWin> cl;
+        std::memset(&cl, 0xEE, sizeof cl);
+        swc::lzc::copy_job<kEmuWin, kEmuSpan>(j, ws.data(), wsb, &cl);
+    } else {
+        alignas(16) static swc::lzr::Lds<512, 16> rl;
+        std::memset(&rl, 0xEE, sizeof rl);
+        swc::lzr::resolve_job<512, 16, 32768, true>(j, ws.data(), wsb, &rl);
     }
 }
 

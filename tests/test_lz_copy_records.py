@@ -1,0 +1,110 @@
+"""CPU tier: phase 2 of the Deflate / LZ4 paths on its own -- swcompression_amd/csrc/lz_copy.h, the record-granular copier the
+gfx950 kernel swc_lz_copy_kernel is compiled from -- on record lists made HERE, so that every class of record the copier
+treats differently is hit on purpose and in bulk: matches that end in front of their group, matches that reach into it,
+matches in front of the LDS window (read back from the output buffer), overlapping matches (distance < length) down to
+distance 1, matches of 1 / 2 bytes (tails of split matches) and of up to 511, literal runs of every class (0, 1-3, 4-8,
+9-64, 65-127 in front of a match; literal-only records up to 2,048), capacity cuts, every output alignment, every order of
+the emulated lanes.  The expected bytes come from replaying the records one by one in Python (what the reference's
+`out.append` loops do, Deflate.swift:216-232, LZ4.swift:398-410); the byte-cell resolver of rounds 2-4 (lz_resolve.h) runs on the
+same lists as a second witness."""
+import ctypes as C
+import random
+
+import pytest
+
+import _emu as E
+
+lib = E.lib
+lib.emu_copy_records.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+lib.emu_copy_records.restype = None
+
+
+def make_match(lit, length, dist):
+    return lit | (length << 7) | ((dist - 1) << 16)
+
+
+def make_lits(n):
+    return (n & 127) | ((n >> 7) << 16)
+
+
+def build(rnd, nbytes, profile):
+    """A random record list that covers about nbytes of output; returns (records, literal bytes, expected output)."""
+    recs, lits, out = [], bytearray(), bytearray()
+    while len(out) < nbytes:
+        kind = rnd.choices(profile["kinds"], profile["weights"])[0]
+        if kind == "lits" or len(out) == 0:
+            n = rnd.choice(profile["litonly"])
+            b = bytes(rnd.randrange(256) for _ in range(n))
+            recs.append(make_lits(n)); lits += b; out += b
+            continue
+        lit = rnd.choice(profile["lit"])
+        length = rnd.choice(profile["len"])
+        dmax = min(len(out) + lit, 65536)
+        dist = min(dmax, max(1, rnd.choice(profile["dist"])))
+        if kind == "near":
+            dist = min(dmax, rnd.randint(1, 40))
+        elif kind == "far":
+            dist = min(dmax, rnd.randint(9000, 65536))
+        b = bytes(rnd.randrange(256) for _ in range(lit))
+        lits += b; out += b
+        for _ in range(length):
+            out.append(out[-dist])
+        recs.append(make_match(lit, length, dist))
+    return recs, bytes(lits), bytes(out)
+
+
+TEXT = dict(kinds=["match", "near", "far", "lits"], weights=[70, 10, 15, 5], lit=[0] * 14 + [1, 1, 2, 3, 4, 5, 8, 9, 20], len=[3, 3, 4, 5, 6, 7, 8, 9, 10, 12, 15, 16, 17, 24, 25, 32, 33, 40],
+            dist=[50, 300, 700, 2000, 5000, 7000, 12000, 30000], litonly=[1, 2, 3, 5, 17, 100, 255, 256, 300])
+RUNS = dict(kinds=["near", "match", "lits"], weights=[60, 30, 10], lit=[0, 0, 0, 1, 4, 64, 65, 127], len=[1, 2, 3, 4, 30, 64, 65, 100, 258, 300, 511],
+            dist=[1, 2, 3, 4, 7, 255, 256, 257, 1000], litonly=[1, 255, 256, 1023, 1024, 2048])
+DENSE = dict(kinds=["near"], weights=[1], lit=[0, 0, 1], len=[3, 4, 5, 8], dist=[1], litonly=[4])   # (every match reaches into its group)
+STORED = dict(kinds=["lits", "far", "match"], weights=[80, 10, 10], lit=[0, 3], len=[4, 40, 500], dist=[20000, 65536, 100], litonly=[2048, 2048, 2047, 1500, 256, 255])
+
+
+def run_copy(recs, lits, cap, out_len, misalign, copier):
+    buf = C.create_string_buffer(cap + 64 + 32)
+    C.memset(buf, 0xA5, len(buf))
+    o0 = (-C.addressof(buf)) % 16 + 16 + misalign
+    arr = (C.c_uint32 * max(len(recs), 1))(*recs)
+    lib.emu_copy_records(arr, len(recs), lits, len(lits), C.addressof(buf) + o0, cap, out_len, copier)
+    raw = buf.raw
+    assert raw[:o0] == b"\xA5" * o0 and raw[o0 + cap:] == b"\xA5" * (len(raw) - o0 - cap), "bytes outside the output were written"
+    return raw[o0:o0 + min(cap, out_len)]
+
+
+@pytest.mark.parametrize("profile", [TEXT, RUNS, DENSE, STORED], ids=["text", "runs", "dense", "stored"])
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_record_classes(profile, order):
+    rnd = random.Random(hash((profile["len"][0], order)) & 0xFFFF)
+    E.set_order(order)
+    try:
+        for size in (0, 1, 63, 64, 200, 5000, 9000, 40000, 140000):
+            recs, lits, exp = build(rnd, size, profile) if size else ([], b"", b"")
+            for misalign in (0, 5, 15):
+                got = run_copy(recs, lits, max(len(exp), 1), len(exp), misalign, 1)
+                assert got == exp, "copier differs (size %d, misalign %d)" % (size, misalign)
+            if order == 0 and size and profile is not STORED:
+                # (not on STORED: runs of literal-only records of unequal sizes followed by matches 64 KiB back are a stream no
+                # phase 1 writes, and the old resolver's long-literal path -- not shipped any more -- does not take it)
+                assert run_copy(recs, lits, len(exp), len(exp), 3, 0) == exp, "the byte-cell resolver differs"
+    finally:
+        E.set_order(0)
+
+
+def test_capacity_cuts_the_last_records():
+    """Records exist only for output below the capacity: the last one may reach past it (phase 2 clamps at the limit)."""
+    rnd = random.Random(77)
+    for profile in (TEXT, RUNS):
+        recs, lits, exp = build(rnd, 30000, profile)
+        for cut in (1, 2, 17, 300):
+            cap = len(exp) - cut
+            # drop the records that start at or behind the capacity
+            keep, pos = [], 0
+            for r in recs:
+                if pos >= cap:
+                    break
+                keep.append(r)
+                ln = (r >> 7) & 511
+                lit = (r & 127) + (((r >> 16) << 7) if ln == 0 else 0)
+                pos += lit + ln
+            assert run_copy(keep, lits, cap, len(exp), 7, 1) == exp[:cap]
