@@ -74,7 +74,7 @@ typedef struct swc_batch_opts {
 int swc_batch_decompress(int codec, swc_job* jobs, size_t n, const swc_batch_opts* opts);
 
 /* Scratch bytes the codec needs in HBM (Deflate / LZ4: match records + literal stream of the two-phase path,
- * LZMA: the home of the literal coders (LDS caches one) and of the long-length trees -- 32 streams per CU and any lc + lp; without it the model
+ * LZMA: the home of the literal coders (LDS caches four lines of them) and of the long-length trees -- 32 streams per CU and any lc + lp; without it the model
  * of lc + lp <= 4 sits in LDS whole, 5 streams per CU, larger models are refused with SWC_E_NEED_WORKSPACE; BZip2: tt[]).
  * LZ4 also runs without it (one block per lane, much slower on large blocks).  Allocated internally by the single-shot
  * calls; batch callers pass it via swc_batch_decompress_ws. */
@@ -258,8 +258,13 @@ const char* swc_version(void);
 /* Measurement knobs (never change results), meant for benchmarking:
  *   "phase_timing" = 0 | 1      HIP events between the kernels of the batch launches of the CALLING THREAD (like the launch
  *                               stream and the staging buffers, measurement state is per thread);
- *   "lzma_coder_cache" = 1 | 0  process-wide: LZMA / LZMA2 launches with a workspace keep ONE literal coder in LDS as a
- *                               cache (32 streams per CU, default) or all coders of lc + lp <= 3 (10 streams per CU). */
+ *   "lzma_coder_cache" = 1 | 0  process-wide: LZMA / LZMA2 launches with a workspace keep four LINES (a third of a literal
+ *                               coder each) in LDS as a cache of the coders in the workspace (32 streams per CU, default) or
+ *                               all coders of lc + lp <= 3 in LDS (10 streams per CU);
+ *   "lz_copier" = 1 | 0 | 2 | -1 | -2   process-wide: the LZ77 copy phase of Deflate / LZ4 launches -- 1 (default): one stream
+ *                               per wave with an 8 KiB LDS window (csrc/lz_copy.h) for launches of 2,560 streams and more,
+ *                               one stream per 512-thread workgroup (csrc/lz_resolve.h) below; 0: the workgroup kernel always;
+ *                               2: the wave kernel with a 16 KiB window; -1 / -2: the wave kernel whatever the launch size. */
 int swc_set_tuning(const char* key, int value);
 /* Profile builds of the library (-DSWC_PROFILE) only: a device buffer of 32 x uint64 per job of the next Deflate
  * launches that the kernels fill with cycle counts per stage (tools/exp_profile.py).  NULL switches it off.  A no-op in

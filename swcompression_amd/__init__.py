@@ -134,7 +134,21 @@ def _call_simple(name, data, *mid, consumed=False):
     return (blob, cons.value) if consumed else blob
 
 
-def _call_multi(name, data, *mid):
+class _Owner:
+    """Keeps a C result alive for the memoryviews cut from it; swc_free when the last of them is gone."""
+    def __init__(self, ptr):
+        self.ptr = ptr
+
+    def __del__(self):
+        try:
+            _lib.load().swc_free(self.ptr)
+        except Exception:
+            pass
+
+
+def _call_multi(name, data, *mid, views=False):
+    """views=True: the parts are read-only memoryviews INTO the C result instead of bytes objects copied from it -- what a
+    Swift shim does with Data(bytesNoCopy:count:deallocator:); the buffer is released when the last view dies."""
     lib = _lib.load()
     data = bytes(data)
     out = C.POINTER(C.c_uint8)()
@@ -142,7 +156,23 @@ def _call_multi(name, data, *mid):
     sizes = C.POINTER(C.c_size_t)()
     cnt = C.c_size_t()
     st = getattr(lib, name)(data, len(data), *mid, C.byref(out), C.byref(n), C.byref(sizes), C.byref(cnt))
-    parts = _split(_take(out, n.value), _take_sizes(sizes, cnt.value))
+    # every part is copied ONCE, from the C result to its bytes object (a Swift shim wraps the buffer without a copy:
+    # Data(bytesNoCopy:count:deallocator:))
+    szs = _take_sizes(sizes, cnt.value)
+    base = C.cast(out, C.c_void_p).value or 0
+    parts, o = [], 0
+    if views and not st and n.value:
+        arr = (C.c_ubyte * n.value).from_address(base)
+        arr._owner = _Owner(out)
+        mv = memoryview(arr).cast("B").toreadonly()
+        for sz in szs:
+            parts.append(mv[o:o + sz])
+            o += sz
+        return parts
+    for sz in szs:
+        parts.append(C.string_at(base + o, sz) if sz else b"")
+        o += sz
+    lib.swc_free(out)
     if st:
         _raise(st, parts)
     return parts
@@ -165,8 +195,8 @@ class GzipArchive:
         return _call_simple("swc_gzip_unarchive", archive)
 
     @staticmethod
-    def multi_unarchive(archive):
-        return _call_multi("swc_gzip_multi_unarchive", archive)
+    def multi_unarchive(archive, views=False):
+        return _call_multi("swc_gzip_multi_unarchive", archive, views=views)
 
 
 class ZlibArchive:

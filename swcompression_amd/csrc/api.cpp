@@ -5,7 +5,11 @@
 #include <algorithm>
 #include <atomic>
 #include <map>
+#include <chrono>
+#include <functional>
+#include <stdio.h>
 #include <mutex>
+#include <thread>
 #include <vector>
 #include <string.h>
 #include "host_util.h"
@@ -35,7 +39,7 @@ bool device_is_gfx950(int dev) {
         g_dev_state[dev] = strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 2;
         if (g_dev_state[dev] == 1) {   // keep freed staging buffers of the single-shot calls in the pool instead of returning them to the OS
             hipMemPool_t pool;
-            uint64_t keep = 1ull << 30;
+            uint64_t keep = 8ull << 30;   // (a BGZF file of 4,096 members needs a workspace of 1.1 GB per call: kept, not returned to the driver)
             if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
             (void)hipGetLastError();
         }
@@ -76,8 +80,63 @@ static size_t default_cap(int codec, const HostUnit& u) {
     }
 }
 
+// ---- host results: large ones are recycled ---------------------------------------------------------------------------------
+// swc_free() of a result of kResultCacheMin bytes and more parks the buffer (up to kResultCacheMax bytes in all, the largest
+// first to go); the next result of about that size -- at most twice as small -- takes it over with its pages mapped.
+// Everything else is plain malloc / free.
+constexpr size_t kResultCacheMin = (size_t)4 << 20, kResultCacheMax = (size_t)1 << 30;
+static std::mutex g_res_mu;
+static std::map<void*, size_t> g_res_live;                 // large results in the hands of callers: pointer -> capacity
+static std::vector<std::pair<void*, size_t>> g_res_parked;  // freed ones
+uint8_t* host_result(size_t n) {
+    if (n >= kResultCacheMin) {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        size_t best = g_res_parked.size();
+        for (size_t i = 0; i < g_res_parked.size(); i++)
+            if (g_res_parked[i].second >= n && g_res_parked[i].second <= 2 * n && (best == g_res_parked.size() || g_res_parked[i].second < g_res_parked[best].second)) best = i;
+        if (best != g_res_parked.size()) {
+            auto e = g_res_parked[best];
+            g_res_parked.erase(g_res_parked.begin() + (long)best);
+            g_res_live[e.first] = e.second;
+            return static_cast<uint8_t*>(e.first);
+        }
+        void* p = malloc(n);
+        if (p) g_res_live[p] = n;
+        return static_cast<uint8_t*>(p);
+    }
+    return static_cast<uint8_t*>(malloc(n ? n : 1));
+}
+void host_result_free(void* p) {
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        auto it = g_res_live.find(p);
+        if (it != g_res_live.end()) {
+            const size_t cap = it->second;
+            g_res_live.erase(it);
+            size_t held = cap;
+            for (auto& e : g_res_parked) held += e.second;
+            g_res_parked.emplace_back(p, cap);
+            while (held > kResultCacheMax && !g_res_parked.empty()) {   // over the limit: the largest go back to the system
+                size_t big = 0;
+                for (size_t i = 1; i < g_res_parked.size(); i++) if (g_res_parked[i].second > g_res_parked[big].second) big = i;
+                held -= g_res_parked[big].second;
+                free(g_res_parked[big].first);
+                g_res_parked.erase(g_res_parked.begin() + (long)big);
+            }
+            return;
+        }
+    }
+    free(p);
+}
+
 static std::atomic<long long> g_stats[3];
 void stat_add(int which, long long v) { if (which >= 0 && which < 3) g_stats[which] += v; }
+
+// What a thread keeps page-locked between calls, per direction.  Pinning is the expensive part of a large single-shot call
+// (a 268 MB result: tens of milliseconds to lock against 5 ms to copy), so a buffer that served an archive of a gigabyte
+// stays for the next one; only a buffer beyond that is released when its call is over.
+constexpr size_t kPinnedKeep = (size_t)1 << 30;
 
 // Two page-locked staging buffers per calling thread (0: host -> device, 1: device -> host), grown on demand, released
 // when the thread ends.
@@ -90,7 +149,7 @@ uint8_t* pinned_stage(int which, size_t n) {
     static thread_local Buf bufs[2];
     Buf& b = bufs[which & 1];
     if (which & 2) {   // trim request (pinned_trim)
-        if (b.cap > ((size_t)256 << 20)) { (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+        if (b.cap > kPinnedKeep) { (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
         return nullptr;
     }
     if (b.cap < n) {
@@ -102,10 +161,51 @@ uint8_t* pinned_stage(int which, size_t n) {
     return static_cast<uint8_t*>(b.p);
 }
 // A thread that staged a multi-gigabyte container once would hold that much page-locked memory until it ends: buffers above
-// the limit are released when the call that needed them is over (round-2 advisor).
+// kPinnedKeep are released when the call that needed them is over (round-2 advisor; round 4: the limit was 256 MiB, and a
+// 268 MB BGZF file pinned its buffers again on every call).
 static void pinned_trim() {
     for (int w = 0; w < 2; w++) (void)pinned_stage(w | 2, 0);
 }
+
+// The outputs of a launch leave the pinned staging buffer for where they are wanted (HostUnit::dst, else HostUnit::out): by
+// several threads when there is a lot to move (one core copies 10 GB/s; PCIe delivered it at 50).
+struct CopyOut { HostUnit* u; const uint8_t* src; size_t n; };
+static void copy_range(std::vector<CopyOut>& v, size_t lo, size_t hi) {
+    for (size_t i = lo; i < hi; i++) {
+        HostUnit& u = *v[i].u;
+        if (u.in_dst) { if (v[i].n) memcpy(u.dst, v[i].src, v[i].n); u.out.clear(); }
+        else u.out.assign(v[i].src, v[i].src + v[i].n);
+    }
+}
+static void copy_out(std::vector<CopyOut>& v) {
+    size_t total = 0;
+    for (const CopyOut& c : v) total += c.n;
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = std::min<size_t>({(size_t)8, hw ? (size_t)hw : (size_t)1, total >> 24, v.size()});   // a thread per 16 MB, eight at most
+    if (nt < 2) { copy_range(v, 0, v.size()); return; }
+    std::vector<std::thread> th;
+    size_t i = 0, acc = 0;
+    for (size_t t = 0; t < nt; t++) {   // contiguous ranges of about total / nt bytes
+        const size_t lo = i, target = total / nt * (t + 1);
+        while (i < v.size() && (i == lo || acc + v[i].n <= target)) acc += v[i++].n;
+        if (t + 1 == nt) i = v.size();
+        th.emplace_back(copy_range, std::ref(v), lo, i);
+    }
+    for (auto& x : th) x.join();
+}
+
+// SWC_TRACE=1 in the environment: the host-side stages of every run_units call with their wall-clock times, on stderr
+struct Trace {
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    Trace() { static const bool e = getenv("SWC_TRACE") != nullptr; on = e; t0 = last = std::chrono::steady_clock::now(); }
+    void mark(const char* what, size_t bytes = 0) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[swc] %-28s %8.3f ms  (%zu bytes)\n", what, std::chrono::duration<double, std::milli>(now - last).count(), bytes);
+        last = now;
+    }
+};
 
 static int run_units_impl(int codec, std::vector<HostUnit>& units);
 int run_units(int codec, std::vector<HostUnit>& units) {
@@ -118,6 +218,7 @@ static int run_units_impl(int codec, std::vector<HostUnit>& units) {
     const size_t n = units.size();
     if (n == 0) return SWC_OK;
     hipStream_t stream = hipStreamPerThread;   // every calling thread stages, launches and waits on its own stream
+    Trace tr;
     std::vector<size_t> pending(n);
     for (size_t i = 0; i < n; i++) pending[i] = i;
     std::vector<size_t> cap(n);
@@ -126,10 +227,14 @@ static int run_units_impl(int codec, std::vector<HostUnit>& units) {
 
     bool want_ws = codec == SWC_CODEC_BZIP2_BLOCK || codec == SWC_CODEC_DEFLATE || codec == SWC_CODEC_LZ4_BLOCK;
     // LZMA / LZMA2: without a workspace every literal coder of a stream sits in LDS (5 streams per CU); with one, LDS caches four
-    // of them (32 streams per CU, lzma_wave.h).  A batch that more than fills the 5-stream layout takes the workspace from the
+    // LINES (a third of a coder each) and the coders live in the workspace (32 streams per CU, lzma_wave.h).  A batch that more than fills the 5-stream layout takes the workspace from the
     // start -- the container paths (xz, 7z, .lzma, unarchive_many) then run the kernel bench.py measures; a small
     // batch gets one only after a unit reported SWC_E_NEED_WORKSPACE (lc + lp > 4).
-    if ((codec == SWC_CODEC_LZMA || codec == SWC_CODEC_LZMA2) && n > 5u * 256u) want_ws = true;
+    // The up-front workspace is OPPORTUNISTIC: if the device cannot give it -- or only for fewer streams than the
+    // 5-stream layout holds anyway -- the batch runs without one, as it did before, and only units that report
+    // SWC_E_NEED_WORKSPACE come back for it.
+    bool opportunistic_ws = false;
+    if ((codec == SWC_CODEC_LZMA || codec == SWC_CODEC_LZMA2) && n > 5u * 256u) { want_ws = true; opportunistic_ws = true; }
     const bool per_job_ws = codec == SWC_CODEC_DEFLATE || codec == SWC_CODEC_LZ4_BLOCK;   // areas sized from each unit's own capacity
     // rounds: 12 relaunches for growing capacities, plus the extra rounds that splitting by workspace size takes
     for (int round = 0, grow_rounds = 0; grow_rounds < 12 && round < 256 && !pending.empty(); round++) {
@@ -142,9 +247,16 @@ static int run_units_impl(int codec, std::vector<HostUnit>& units) {
             // (what the device has free right now, not a constant: other threads and other entries of a device list launch too)
             size_t free_b = 0, total_b = 0;
             if (hipMemGetInfo(&free_b, &total_b) != hipSuccess) { (void)hipGetLastError(); free_b = (size_t)16 << 30; }
-            const size_t budget = std::min<size_t>((size_t)48 << 30, free_b / 2);
+            size_t io_bytes = 0;   // what the inputs and outputs of the launch take themselves
+            for (size_t i : pending) io_bytes += units[i].in_len + cap[i] + 64;
+            const size_t budget = std::min<size_t>((size_t)48 << 30, (free_b > io_bytes ? free_b - io_bytes : 0) / 2);
             size_t take = 1;
             while (take < pending.size() && swc_batch_workspace_bytes(codec, take + 1, cap[pending[take]]) <= budget) take++;
+            if (opportunistic_ws && take < pending.size() && take < 5u * 256u) {   // not worth it: everybody at once, without
+                want_ws = false;
+                opportunistic_ws = false;
+                take = pending.size();
+            }
             deferred.assign(pending.begin() + take, pending.end());
             pending.resize(take);
         }
@@ -185,49 +297,75 @@ static int run_units_impl(int codec, std::vector<HostUnit>& units) {
             for (size_t k = 0; k < m; k++) mx = std::max(mx, cap[pending[k]]);
             ws_bytes = swc_batch_workspace_bytes(codec, m, mx);
         }
-        const size_t jobs_bytes = (m * sizeof(Job) + 15) & ~(size_t)15, off_bytes = ws_off.size() * sizeof(uint64_t);
-        DevBuf d_in(in_total + 16), d_out(out_total + 16), d_jobs(jobs_bytes + off_bytes), d_ws(ws_bytes);
-        if (!d_in.ok() || !d_out.ok() || !d_jobs.ok() || !d_ws.ok()) return SWC_E_DEVICE;
+        // ONE device buffer [inputs | job records | workspace offsets | checksums | outputs] and one more for the workspace: one
+        // copy up (everything in front of the checksums), one copy down (everything behind the inputs) -- a single-shot call
+        // is a handful of driver calls, and each costs as much as the decode of a 64 KiB block
+        int sum_kind = 0;
+        for (size_t k = 0; k < m && !sum_kind; k++) sum_kind = units[pending[k]].sum_kind;
+        const size_t jobs_bytes = (m * sizeof(Job) + 15) & ~(size_t)15, off_bytes = (ws_off.size() * sizeof(uint64_t) + 15) & ~(size_t)15;
+        const size_t sum_bytes = sum_kind ? (m * sizeof(uint64_t) + 15) & ~(size_t)15 : 0;
+        const size_t in_bytes = in_total + 16;
+        const size_t up_bytes = in_bytes + jobs_bytes + off_bytes;                 // host -> device
+        const size_t down_bytes = jobs_bytes + off_bytes + sum_bytes + out_total;   // device -> host
+        tr.mark("plan");
+        DevBuf d_all(in_bytes + down_bytes + 16), d_ws(ws_bytes);
+        tr.mark("device buffers", in_bytes + down_bytes + ws_bytes);
+        if (d_all.ok() && !d_ws.ok() && opportunistic_ws) {   // no room for the optional workspace: without it
+            want_ws = false;
+            opportunistic_ws = false;
+            pending.insert(pending.end(), deferred.begin(), deferred.end());
+            round--;
+            continue;
+        }
+        if (!d_all.ok() || !d_ws.ok()) return SWC_E_DEVICE;
+        uint8_t* const d_in = d_all.u8();
+        uint8_t* const d_jobs = d_in + in_bytes;
+        uint8_t* const d_sums = d_jobs + jobs_bytes + off_bytes;
+        uint8_t* const d_out = d_sums + sum_bytes;
 
-        // host -> device: inputs, then the job records and the workspace offsets, through the thread's pinned buffer
-        const size_t up_bytes = in_total + 16 + jobs_bytes + off_bytes;
         std::vector<uint8_t> up_fallback;
         uint8_t* up = pinned_stage(0, up_bytes);
         if (!up) { up_fallback.resize(up_bytes); up = up_fallback.data(); }
         for (const Staged& st : staged) if (st.len) memcpy(up + st.off, st.p, st.len);
-        Job* jobs = reinterpret_cast<Job*>(up + in_total + 16);
+        Job* jobs = reinterpret_cast<Job*>(up + in_bytes);
         for (size_t k = 0; k < m; k++) {
             const HostUnit& u = units[pending[k]];
             if (u.dict && u.dict_len) memcpy(up + dict_off[k], u.dict, u.dict_len);
             Job& j = jobs[k];
-            j.in = d_in.u8() + in_off[k];
+            j.in = d_in + in_off[k];
             j.in_len = u.in_len;
-            j.out = d_out.u8() + out_off[k];
+            j.out = d_out + out_off[k];
             j.out_cap = cap[pending[k]];
             j.out_len = 0;
             j.in_consumed = 0;
             j.status = SWC_E_DEVICE;
             j.aux = u.aux;
-            j.dict = u.dict ? d_in.u8() + dict_off[k] : reinterpret_cast<const uint8_t*>((uintptr_t)u.dict_value);
+            j.dict = u.dict ? d_in + dict_off[k] : reinterpret_cast<const uint8_t*>((uintptr_t)u.dict_value);
             j.dict_len = u.dict ? u.dict_len : u.extra;
         }
-        if (off_bytes) memcpy(up + in_total + 16 + jobs_bytes, ws_off.data(), off_bytes);
-        if (hipMemcpyAsync(d_in.ptr(), up, in_total, hipMemcpyHostToDevice, stream) != hipSuccess) return SWC_E_DEVICE;
-        if (hipMemcpyAsync(d_jobs.ptr(), jobs, jobs_bytes + off_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return SWC_E_DEVICE;
-        const uint64_t* d_off = off_bytes ? reinterpret_cast<const uint64_t*>(d_jobs.u8() + jobs_bytes) : nullptr;
-        if (launch_codec(codec, static_cast<Job*>(d_jobs.ptr()), m, d_ws.ptr(), ws_bytes, stream, d_off) != hipSuccess) return SWC_E_DEVICE;
+        if (!ws_off.empty()) memcpy(up + in_bytes + jobs_bytes, ws_off.data(), ws_off.size() * sizeof(uint64_t));
+        tr.mark("stage inputs (pinned)", up_bytes);
+        if (hipMemcpyAsync(d_in, up, up_bytes, hipMemcpyHostToDevice, stream) != hipSuccess) return SWC_E_DEVICE;
+        const uint64_t* d_off = !ws_off.empty() ? reinterpret_cast<const uint64_t*>(d_jobs + jobs_bytes) : nullptr;
+        if (launch_codec(codec, reinterpret_cast<Job*>(d_jobs), m, d_ws.ptr(), ws_bytes, stream, d_off) != hipSuccess) return SWC_E_DEVICE;
+        if (sum_kind && launch_checksum(sum_kind, reinterpret_cast<const Job*>(d_jobs), m, reinterpret_cast<uint64_t*>(d_sums), stream) != hipSuccess) return SWC_E_DEVICE;
         stat_add(0, 1);
         stat_add(1, (long long)m);
-        // device -> host: job records first (they say how much of every output exists), then the outputs
-        std::vector<Job> res(m);
-        if (hipMemcpyAsync(res.data(), d_jobs.ptr(), m * sizeof(Job), hipMemcpyDeviceToHost, stream) != hipSuccess) return SWC_E_DEVICE;
+        // device -> host: the job records (they say how much of every output exists), the checksums, the outputs
         std::vector<uint8_t> down_fallback;
-        uint8_t* down = pinned_stage(1, out_total + 16);
-        if (!down) { down_fallback.resize(out_total + 16); down = down_fallback.data(); }
-        if (hipMemcpyAsync(down, d_out.ptr(), out_total, hipMemcpyDeviceToHost, stream) != hipSuccess) return SWC_E_DEVICE;
+        uint8_t* down = pinned_stage(1, down_bytes);
+        if (!down) { down_fallback.resize(down_bytes); down = down_fallback.data(); }
+        if (hipMemcpyAsync(down, d_jobs, down_bytes, hipMemcpyDeviceToHost, stream) != hipSuccess) return SWC_E_DEVICE;
+        tr.mark("issue launch + copies");
         if (hipStreamSynchronize(stream) != hipSuccess) return SWC_E_DEVICE;
+        tr.mark("H2D + kernels + D2H", down_bytes);
+        const Job* res = reinterpret_cast<const Job*>(down);
+        const uint64_t* sums = reinterpret_cast<const uint64_t*>(down + jobs_bytes + off_bytes);
+        const uint8_t* outs = down + jobs_bytes + off_bytes + sum_bytes;
 
         std::vector<size_t> next;
+        std::vector<CopyOut> done;
+        done.reserve(m);
         for (size_t k = 0; k < m; k++) {
             HostUnit& u = units[pending[k]];
             const Job& j = res[k];
@@ -262,9 +400,14 @@ static int run_units_impl(int codec, std::vector<HostUnit>& units) {
             u.status = (j.status == SWC_E_NEED_WORKSPACE && codec == SWC_CODEC_BZIP2_BLOCK) ? (int)SWC_E_CAPACITY : j.status;
             u.aux_out = j.aux;
             u.in_consumed = (size_t)j.in_consumed;
-            size_t produced = (size_t)std::min<uint64_t>(j.out_len, j.out_cap);
-            u.out.assign(down + out_off[k], down + out_off[k] + produced);
+            const size_t produced = (size_t)std::min<uint64_t>(j.out_len, j.out_cap);
+            u.out_size = produced;
+            u.in_dst = u.dst != nullptr && produced <= u.dst_cap;
+            if (sum_kind && u.sum_kind == sum_kind) { u.sum = sums[k]; u.sum_valid = true; }
+            done.push_back(CopyOut{&u, outs + out_off[k], produced});
         }
+        copy_out(done);
+        tr.mark("copy out", out_total);
         if (!next.empty() && !want_ws)
             for (size_t k = 0; k < m; k++)
                 if (res[k].status == SWC_E_NEED_WORKSPACE) { want_ws = true; break; }
@@ -285,7 +428,7 @@ int swc_set_tuning(const char* key, int value) try {
     if (!key) return SWC_E_INVALID_ARGUMENT;
     if (!strcmp(key, "phase_timing") && (value == 0 || value == 1)) { set_phase_timing(value); return SWC_OK; }
     if (!strcmp(key, "lzma_coder_cache") && (value == 0 || value == 1)) { set_lzma_coder_cache(value); return SWC_OK; }
-    if (!strcmp(key, "lz_copier") && value >= 0 && value <= 2) { set_lz_copier(value); return SWC_OK; }
+    if (!strcmp(key, "lz_copier") && value >= -2 && value <= 2) { set_lz_copier(value); return SWC_OK; }
     return SWC_E_INVALID_ARGUMENT;
 } catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
     return SWC_E_DEVICE;
@@ -306,7 +449,7 @@ int swc_last_phase_ms(float* ms, int cap) { return ms ? last_phase_ms(ms, cap) :
 
 int swc_device_available(void) { return device_ready() ? 1 : 0; }
 const char* swc_version(void) { return "swc-hip 0.1 (gfx950)"; }
-void swc_free(void* p) { free(p); }
+void swc_free(void* p) { host_result_free(p); }
 
 size_t swc_batch_workspace_bytes(int codec, size_t n_jobs, uint64_t max_out_cap) {
     (void)max_out_cap;

@@ -129,8 +129,9 @@ int gzip_member_finish(const uint8_t* d, size_t n, size_t data_pos, const HostUn
     if (n - p < 8) return SWC_E_GZIP_WRONG_MAGIC;                      // :91
     uint32_t crc = (uint32_t)d[p] | (uint32_t)d[p + 1] << 8 | (uint32_t)d[p + 2] << 16 | (uint32_t)d[p + 3] << 24;
     uint32_t isize = (uint32_t)d[p + 4] | (uint32_t)d[p + 5] << 8 | (uint32_t)d[p + 6] << 16 | (uint32_t)d[p + 7] << 24;
-    if ((uint32_t)(u.out.size() & 0xFFFFFFFFu) != isize) return SWC_E_GZIP_WRONG_ISIZE;  // :95
-    crc_error = swc_crc32(u.out.data(), u.out.size(), 0) != crc;       // :99
+    if ((uint32_t)(u.size() & 0xFFFFFFFFu) != isize) return SWC_E_GZIP_WRONG_ISIZE;  // :95
+    // :99 -- the CRC-32 the device computed behind the decode (HostUnit::sum_kind = 1), else here
+    crc_error = (u.sum_valid && u.sum_kind == 1 ? (uint32_t)u.sum : swc_crc32(u.data(), u.size(), 0)) != crc;
     next_pos = p + 8;
     return SWC_OK;
 }
@@ -178,6 +179,7 @@ int swc_gzip_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* 
     int st = gzip_member_prepare(in, in_len, 0, u);
     if (st) { give_empty(out, out_len); return st; }
     const size_t data_pos = (size_t)(u.in - in);
+    u.sum_kind = 1;                                                    // CRC-32 on the device, behind the decode
     st = run_one(SWC_CODEC_DEFLATE, u);
     if (st) { give_empty(out, out_len); return st; }
     size_t next; bool crc_error;
@@ -216,7 +218,9 @@ bool bgzf_index(const uint8_t* in, size_t in_len, std::vector<BlockRef64>& out) 
 }
 }  // namespace swc
 extern "C" {
-static bool bgzf_multi(const uint8_t* in, size_t in_len, std::vector<uint8_t>& all, std::vector<size_t>& sz) {
+// On success *all_out is the malloc()ed concatenation of the members (the caller's result buffer: every member is copied
+// from the staging buffer straight to its place in it, and its CRC-32 comes from the device).
+static bool bgzf_multi(const uint8_t* in, size_t in_len, uint8_t** all_out, size_t* all_len, std::vector<size_t>& sz) {
     struct Member { size_t data_pos, data_len, trailer; };
     std::vector<Member> members;
     {
@@ -226,35 +230,46 @@ static bool bgzf_multi(const uint8_t* in, size_t in_len, std::vector<uint8_t>& a
     }
     if (members.size() < 2) return false;
     std::vector<HostUnit> units(members.size());
+    size_t total = 0;
     for (size_t k = 0; k < members.size(); k++) {
         const uint8_t* t = in + members[k].trailer;
         const uint32_t isize = (uint32_t)t[4] | (uint32_t)t[5] << 8 | (uint32_t)t[6] << 16 | (uint32_t)t[7] << 24;
         units[k].in = in + members[k].data_pos;
         units[k].in_len = members[k].data_len;
-        if ((uint64_t)isize <= (uint64_t)members[k].data_len * 1100 + 4096) units[k].cap_hint = std::max<size_t>(isize, 64);
+        units[k].base = in;                 // one staged copy of the file, every member a sub-range of it
+        units[k].base_len = in_len;
+        units[k].sum_kind = 1;              // CRC-32 on the device
+        if ((uint64_t)isize > (uint64_t)members[k].data_len * 1100 + 4096) return false;   // (not a size this member can have: the walk decides)
+        units[k].cap_hint = std::max<size_t>(isize, 64);
+        units[k].dst_cap = isize;
+        total += isize;
     }
-    if (run_units(SWC_CODEC_DEFLATE, units) != SWC_OK) return false;
-    for (size_t k = 0; k < members.size(); k++) {
+    uint8_t* all = host_result(total);
+    if (!all) return false;
+    {
+        size_t o = 0;
+        for (HostUnit& u : units) { u.dst = all + o; o += u.dst_cap; }
+    }
+    bool ok = run_units(SWC_CODEC_DEFLATE, units) == SWC_OK;
+    for (size_t k = 0; ok && k < members.size(); k++) {
         const HostUnit& u = units[k];
-        if (u.status != SWC_OK || u.in_consumed != members[k].data_len) return false;
         size_t next;
         bool crc_error;
-        if (gzip_member_finish(in, in_len, members[k].data_pos, u, next, crc_error) != SWC_OK || crc_error) return false;
+        ok = u.status == SWC_OK && u.in_consumed == members[k].data_len && u.in_dst && u.out_size == u.dst_cap &&
+             gzip_member_finish(in, in_len, members[k].data_pos, u, next, crc_error) == SWC_OK && !crc_error;
     }
-    for (const HostUnit& u : units) {
-        all.insert(all.end(), u.out.begin(), u.out.end());
-        sz.push_back(u.out.size());
-    }
+    if (!ok) { host_result_free(all); return false; }
+    for (const HostUnit& u : units) sz.push_back(u.out_size);
+    *all_out = all;
+    *all_len = total;
     return true;
 }
 
 int swc_gzip_multi_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_members) try {
     if (!out || !out_len || !sizes || !n_members || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
     {
-        std::vector<uint8_t> fast;
         std::vector<size_t> fsz;
-        if (bgzf_multi(in, in_len, fast, fsz)) {
-            give(fast, out, out_len);
+        if (bgzf_multi(in, in_len, out, out_len, fsz)) {
             *sizes = give_sizes(fsz);
             *n_members = fsz.size();
             return SWC_OK;
@@ -302,6 +317,7 @@ int swc_zlib_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* 
     if (st) { give_empty(out, out_len); return st; }
     HostUnit u;
     u.in = in + p; u.in_len = in_len - p;
+    u.sum_kind = 2;                                                    // Adler-32 on the device, behind the decode
     st = run_one(SWC_CODEC_DEFLATE, u);
     if (st) { give_empty(out, out_len); return st; }
     if (u.status) { give_empty(out, out_len); return u.status; }
@@ -309,7 +325,7 @@ int swc_zlib_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* 
     give(u.out, out, out_len);                                         // wrongAdler32 carries the data (:34,39)
     if (in_len - q < 4) return SWC_E_ZLIB_WRONG_ADLER32;
     uint32_t stored = (uint32_t)in[q] << 24 | (uint32_t)in[q + 1] << 16 | (uint32_t)in[q + 2] << 8 | in[q + 3];
-    return swc_adler32(u.out.data(), u.out.size()) == stored ? SWC_OK : SWC_E_ZLIB_WRONG_ADLER32;
+    return (u.sum_valid ? (uint32_t)u.sum : swc_adler32(u.out.data(), u.out.size())) == stored ? SWC_OK : SWC_E_ZLIB_WRONG_ADLER32;
 } catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
     if (out && out_len) give_empty(out, out_len);
     return SWC_E_DEVICE;

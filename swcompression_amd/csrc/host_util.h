@@ -47,8 +47,11 @@ private:
 // single-shot call).  nullptr if the allocation fails (the caller falls back to its own pageable buffer).
 uint8_t* pinned_stage(int which, size_t n);
 
-// malloc()ed host result handed to the caller (released with swc_free); never NULL.
-inline uint8_t* host_result(size_t n) { return static_cast<uint8_t*>(malloc(n ? n : 1)); }
+// Host result handed to the caller (released with swc_free).  Large results come from -- and go back to -- a small cache
+// of buffers whose pages are already mapped (api.cpp): a fresh 268 MB allocation costs more in page faults (24 ms) than the
+// PCIe transfer that fills it (5 ms).
+uint8_t* host_result(size_t n);
+void host_result_free(void* p);
 
 bool device_is_gfx950(int dev);  // api.cpp: device `dev` exists and is a gfx950 (also prepares its memory pool, once)
 bool device_ready();  // api.cpp: true when a gfx950 device is present and selected
@@ -68,8 +71,21 @@ struct HostUnit {
     size_t dict_len = 0;
     uint64_t extra = 0;          // codec specific (goes to Job::dict_len when dict == nullptr)
     uint64_t dict_value = 0;     // codec specific integer carried in Job::dict when dict == nullptr (LZMA: dictionary size)
+    // Optional: where the output is wanted (a place inside the caller's final buffer, `dst_cap` bytes of room).  If the
+    // unit's output fits it is copied THERE from the pinned staging buffer -- once -- and `out` stays empty (in_dst, out_size).
+    uint8_t* dst = nullptr;
+    size_t dst_cap = 0;
+    // Optional: a checksum of the output computed ON THE DEVICE in the same launch sequence (swc_checksum kinds of
+    // include/swc_hip.h: 1 CRC-32, 2 Adler-32, 3 CRC-64, 4 bzip2 CRC-32, 5 XXH32); one kind per run_units call.
+    int sum_kind = 0;
     // results
     std::vector<uint8_t> out;
+    bool in_dst = false;         // the output is at `dst`, not in `out`
+    size_t out_size = 0;         // bytes of output (wherever they are)
+    uint64_t sum = 0;            // the checksum, if sum_valid
+    bool sum_valid = false;
+    const uint8_t* data() const { return in_dst ? dst : out.data(); }
+    size_t size() const { return in_dst ? out_size : out.size(); }
     size_t in_consumed = 0;
     int32_t status = SWC_OK;
     int32_t aux_out = 0;         // codec specific result (bzip2: computed block CRC)

@@ -188,6 +188,15 @@ __global__ __launch_bounds__(64) void swc_lz_copy16_kernel(const Job* __restrict
 // of lz_resolve.h (rounds 2-4) -- kept for A/B measurements; all produce the same bytes.
 static std::atomic<int> g_lz_copier{1};
 void set_lz_copier(int v) { g_lz_copier = v; }
+// A launch of FEW streams is a matter of latency, not throughput: one wave walks a 64 KiB stream group by group in ~0.3 ms,
+// the 512 threads of the byte-cell resolver in 0.06 ms -- but only 512 of those fit the chip at a time against 4,096 waves.
+// Below kCopierMin streams the launch takes the workgroup kernel (the single-shot calls, small containers), above it the
+// wave kernel (the batches this engine is built for); both write the same bytes (tests/test_lz_copy_records.py).
+constexpr size_t kCopierMin = 2560;
+static int copier_for(size_t n) {
+    const int c = g_lz_copier;
+    return c < 0 ? -c : (c == 1 && n < kCopierMin ? 0 : c);   // (tuning value -1 / -2: the wave kernel whatever the batch size)
+}
 static void launch_lz_copy(int mode, const Job* jobs, size_t n, const WsMap& wm, const uint32_t* order, hipStream_t stream) {
     if (mode == 2) hipLaunchKernelGGL(swc_lz_copy16_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, jobs, (uint32_t)n, wm, order);
     else hipLaunchKernelGGL(swc_lz_copy_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, jobs, (uint32_t)n, wm, order);
@@ -232,7 +241,7 @@ hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStr
     g_pt.begin(stream);
     hipLaunchKernelGGL(swc_inflate_sync_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
-    const int copier = g_lz_copier;
+    const int copier = copier_for(n);
     if (copier) launch_lz_copy(copier, jobs, n, wm, order, stream);
     else hipLaunchKernelGGL(swc_lz_resolve_kernel, dim3((unsigned)n), dim3(kInflateResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
@@ -302,7 +311,7 @@ hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_
     const WsMap wm{(uint8_t*)ws, stride, ws_off};
     hipLaunchKernelGGL(swc_lz4_parse_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
-    const int copier = g_lz_copier;
+    const int copier = copier_for(n);
     if (copier) launch_lz_copy(copier, jobs, n, wm, order, stream);
     else hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(lz4w::kResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);

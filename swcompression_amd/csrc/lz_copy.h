@@ -9,16 +9,19 @@
 //   group      64 consecutive records, one per lane (fewer when they cover more than kSpanMax output bytes or more literals
 //              than the literal buffer holds).  One packed prefix scan over (literals + length, literals) gives every lane
 //              the place of its literals and of its match in the output;
-//   literals   every lane copies its own literal run from the staged literal stream into the window: the first eight bytes
-//              without a branch (two dword reads, four stores whose ADDRESS is the lane's trash slot when the store is not
-//              wanted -- LDS accesses at any byte alignment are single instructions on gfx950), the rest eight bytes a step;
-//   matches    a lane copies its match the same way -- up to 32 bytes as four eight-byte pieces, the last one shifted back to
-//              end on the match's last byte, no loop, no branch -- when its source is final at the start of the group: it
-//              ends in front of the group's first byte (in the window), or it lies in front of the window (FAR: then the bytes
-//              come from the output buffer in HBM and were asked for by front() one group AHEAD, into registers);
+//   literals   every lane copies its own literal run from the staged literal stream into the window, eight bytes a step (one to
+//              three bytes: a word and / or a byte; four to eight: two dwords), the last piece shifted back so that it ends on
+//              the run's last byte -- no byte tails.  READS at any byte alignment are two or three ALIGNED dwords and a byte
+//              funnel shift (v_alignbyte_b32): the LDS serves an unaligned ds_read at one LANE per cycle, an aligned one at
+//              ten lanes (tools/micro/lds_bench.hip); unaligned stores cost a quarter of a cycle per lane and are used as they are;
+//   matches    a lane copies its match the same way -- up to 32 bytes as four eight-byte pieces -- when its source is final at
+//              the start of the group: it ends in front of the group's first byte (in the window), or it lies in front of the
+//              window (FAR: then the bytes come from the output buffer in HBM and were asked for by front() one group AHEAD,
+//              into registers);
 //   the rest   -- matches that reach into their own group (9 % on text), matches longer than 32 bytes or overlapping
 //              themselves (distance < length), far matches nobody asked for -- are copied in record order, one after the other,
-//              by ALL lanes together (a dword per lane, 256 bytes per step; an overlapping match from its first period):
+//              by ALL lanes together (a byte per lane for the short ones; a dword per lane, 256 bytes per step, for the long
+//              ones; an overlapping match from its first period):
 //              the first record that has not been copied yet finds everything in front of it final.  A group with many of
 //              them (more than kSeqMax) falls back to rounds by watermark: with the head, every lane whose source ends
 //              in front of the head's match copies its own;
@@ -54,7 +57,6 @@ struct Lds {
     static constexpr uint32_t kLitBuf = 1024;             // bytes of the literal stream staged at a time
     alignas(16) uint8_t win[WIN + 16];                    // byte at virtual position v lives at win[v - vbase] (+16: reads of short runs overshoot)
     alignas(16) uint8_t lit[kLitBuf + 16];                // literal at stream offset o lives at lit[o - lv]
-    alignas(8) uint8_t trash[64 * 8];                     // eight bytes per lane: where a store goes that is not wanted
 };
 
 SWC_HD uint32_t ld32(const uint8_t* p) { return *(const u32_unaligned*)p; }
@@ -111,7 +113,7 @@ struct Copier {
     static constexpr uint32_t kLongLit = 64;                   // so is a longer literal run in front of a match
     static constexpr uint32_t kSeqMax = 12;                    // more pending records than this: rounds by watermark
     static constexpr uint32_t kBack = 65536;                   // the furthest a source lies behind its match (record format)
-    static constexpr uint32_t kLitOff = (uint32_t)offsetof(L, lit), kTrashOff = (uint32_t)offsetof(L, trash);
+    static constexpr uint32_t kLitOff = (uint32_t)offsetof(L, lit);
     static_assert(lzr::kMaxLitOnly <= kSpanMax, "a literal-only record must fit the room a slide makes");
     static_assert(lzr::kLitRunMax + lzr::kMaxLen <= kSpanMax && kBigLit - 1u <= kLitCap && lzr::kLitRunMax <= kLitCap, "a record must fit a group");
     static_assert(64u * (kBigLit - 1u + lzr::kMaxLen + lzr::kLitRunMax) < 0x10000u, "the packed scan keeps 16 bits per sum");

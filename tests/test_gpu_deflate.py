@@ -23,6 +23,18 @@ from swcompression_amd.batch import DeviceBatch
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["auto", "wave"])
+def lz_copy_kernel(request):
+    """Phase 2 has two kernels that must write the same bytes: launches of fewer than 2,560 streams take the workgroup kernel
+    (lz_resolve.h, latency), larger ones the wave kernel (lz_copy.h, throughput).  Most tests here launch few streams, so every
+    test runs twice: with the library's own choice, and with the wave kernel forced (swc_set_tuning("lz_copier", -1))."""
+    from swcompression_amd import _lib
+    lib = _lib.load()
+    assert lib.swc_set_tuning(b"lz_copier", -1 if request.param == "wave" else 1) == 0
+    yield request.param
+    lib.swc_set_tuning(b"lz_copier", 1)
+
 GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_inline_vectors.json")))
 
 

@@ -14,6 +14,18 @@ from swcompression_amd.batch import DeviceBatch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["auto", "wave"])
+def lz_copy_kernel(request):
+    """Phase 2 has two kernels that must write the same bytes: launches of fewer than 2,560 streams take the workgroup kernel
+    (lz_resolve.h, latency), larger ones the wave kernel (lz_copy.h, throughput).  Most tests here launch few streams, so every
+    test runs twice: with the library's own choice, and with the wave kernel forced (swc_set_tuning("lz_copier", -1))."""
+    from swcompression_amd import _lib
+    lib = _lib.load()
+    assert lib.swc_set_tuning(b"lz_copier", -1 if request.param == "wave" else 1) == 0
+    yield request.param
+    lib.swc_set_tuning(b"lz_copier", 1)
+
+
 def test_batch_blocks_vs_oracle():
     O.lib.refcpu_set_max_output(1 << 22)
     cases = [c for c in S.lz4_blocks_valid() + S.lz4_blocks_fuzz() if c[1] is None]

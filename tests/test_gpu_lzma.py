@@ -28,8 +28,7 @@ def test_lzma2_batch_valid_and_fuzz():
     r = b.results()
     for k, i in enumerate(keep):
         st = int(r["status"][k])
-        if st == 904:                      # lc+lp > 4 without the optional workspace: covered by the single-shot test below
-            continue
+        assert st != 904, "DeviceBatch always supplies the workspace: SWC_E_NEED_WORKSPACE must not come back"
         assert st == exp[i][0], (cases[i][0][:16].hex(), cases[i][1])
         if exp[i][0] == 0:
             assert int(r["out_len"][k]) == len(exp[i][1]) and int(r["in_consumed"][k]) == exp[i][2]
