@@ -50,6 +50,10 @@ WORKLOADS = {
                             desc="ENCODE: 8192 x 4 MiB blocks compressed to LZ4 blocks (LZ4.compress(block:), SURVEY 8f row 4; 256 distinct: 192 P-text + 64 P-mix); "
                                  "value = INPUT GiB/s; every block decoded again on the device and checked",
                             kernels=["swc_lz4_compress_kernel"], steps=10),
+    "deflate_compress_64k": dict(codec="deflate_compress", kind="deflate_plain", parts=[("text", 768), ("mix", 256)], n_units=100000, unit=65536,
+                                 desc="ENCODE: 100000 x 64 KiB buffers compressed to raw Deflate streams (Deflate.compress(data:), SURVEY 8f row 4; 1024 distinct: "
+                                      "768 P-text + 256 P-mix); value = INPUT GiB/s; every stream decoded again on the device and checked",
+                                 kernels=["swc_deflate_compress_kernel"], steps=10),
     "bzip2_900k": dict(codec="bzip2_block", kind="bzip2", parts=[("text", 256)], n_units=10240, unit=899000,
                        desc="10240 x 900 kB bzip2 blocks (BASELINE configs[3]; 256 distinct P-text payloads as SURVEY 8d states)",
                        kernels=["swc_bzip2_block_kernel", "swc_bzip2_expand_kernel", "swc_bzip2_crc_kernel"], steps=10),
@@ -102,8 +106,8 @@ def make_batch(name, w, parts, seed, device, select):
     tiled unit list (unit i of the list is distinct unit i % n_distinct at its own device address)."""
     from swcompression_amd import corpus
     from swcompression_amd.batch import DeviceBatch
-    if w["kind"] == "lz4_plain":   # the encode workload: the units ARE the plain payloads
-        _, plains = corpus.build_units_mixed("lz4_block", parts, w["unit"], seed=seed)
+    if w["kind"] in ("lz4_plain", "deflate_plain"):   # the encode workloads: the units ARE the plain payloads
+        _, plains = corpus.build_units_mixed("lz4_block" if w["kind"] == "lz4_plain" else "gzip", parts, w["unit"], seed=seed)
         units = plains
     else:
         units, plains = corpus.build_units_mixed(w["kind"], parts, w["unit"], seed=seed)
@@ -120,6 +124,9 @@ def make_batch(name, w, parts, seed, device, select):
     elif name == "lz4_compress_4m":
         raw = units
         caps = [len(u) + len(u) // 255 + 16 for u in units]
+    elif name == "deflate_compress_64k":
+        raw = units
+        caps = [len(u) + len(u) // 8 + 16 for u in units]
     elif name == "bzip2_900k":
         raw = units  # whole one-block streams: "BZh9" (32 bits) + block magic (48) + block CRC (32) => body at bit 112
         caps = [w["unit"] + 64] * n_distinct
@@ -144,6 +151,8 @@ def cpu_baseline(name, raw, plains, seconds):
         fn = lambda u: O.lz4_block(u)[:2]
     elif name == "lz4_compress_4m":
         fn = lambda u: (lambda r: (r[0], u))(O.lz4_compress_block(u))   # (oracle/rc_lz4c.c; "output" counted = the input bytes)
+    elif name == "deflate_compress_64k":
+        fn = lambda u: (lambda z: (0, u))(O.deflate_compress(u))        # (oracle/rc_deflatec.c; "output" counted = the input bytes)
     elif name == "bzip2_900k":
         fn = lambda u: O.bzip2(u)[:2]
     else:
@@ -204,6 +213,8 @@ def cpu_context(name, raw, plains, seconds):
     from swcompression_amd import corpus
     if name == "lz4_compress_4m":
         return cpu_context_lz4_compress(raw, seconds)
+    if name == "deflate_compress_64k":
+        return cpu_context_deflate_compress(raw, seconds)
     codec = {"deflate64k": 1, "deflate64k_mix": 1, "lz4_4m": 2, "bzip2_900k": 3, "lzma2_256k": 4}[name]
     aux = corpus.lzma2_dict_byte(1 << 20) if codec == 4 else 0
     fn = O.lib.refcpu_timed_pool
@@ -276,7 +287,21 @@ def cpu_context_lz4_compress(raw, seconds):
                                         "decoder": "liblz4 %s LZ4_compress_default" % l4.LZ4_versionString().decode()}}
 
 
-def verify_compressed_units(batch, plains, torch):
+def cpu_context_deflate_compress(raw, seconds):
+    """zlib at level 1 (its static / dynamic blocks over a fast greedy parse) on one thread, for orientation."""
+    import zlib
+    t0 = time.perf_counter()
+    nbytes = i = 0
+    while time.perf_counter() - t0 < seconds:
+        u = raw[i % len(raw)]
+        zlib.compress(u, 1)
+        nbytes += len(u)
+        i += 1
+    dt = time.perf_counter() - t0
+    return {"system_codec_one_thread": {"value": nbytes / dt / 2**30, "unit": "GiB/s of input", "cores": 1, "decoder": "zlib %s compress level 1" % zlib.ZLIB_VERSION}}
+
+
+def verify_compressed_units(batch, plains, torch, codec="lz4_block"):
     """Every compressed block of the launch is DECODED again on the device (the engine's own LZ4 decoder, reading the
     compressor's output where it lies) and the XXH32 of what comes out is compared with that of the payload; sizes too."""
     import numpy as np
@@ -287,7 +312,7 @@ def verify_compressed_units(batch, plains, torch):
     if not (r["status"] == 0).all():
         raise SystemExit("compression failed: statuses %s" % sorted(set(r["status"].tolist())))
     nd = len(plains)
-    dec = DeviceBatch("lz4_block", [b"\x00"] * nd, [len(p) for p in plains], tile=batch.n // nd, device=str(batch.device))
+    dec = DeviceBatch(codec, [b"\x00"] * nd, [len(p) for p in plains], tile=-(-batch.n // nd), device=str(batch.device), select=(0, batch.n))
     jobs = dec._jobs_host.copy()
     jobs["in"] = r["out"]
     jobs["in_len"] = r["out_len"]
@@ -302,8 +327,16 @@ def verify_compressed_units(batch, plains, torch):
     if not ok:
         raise SystemExit("round trip of the compressed blocks failed")
     ratio = float(want_len[dec.unit_index].sum()) / float(r["out_len"].sum())
-    return {"units_verified": int(batch.n), "method": "every compressed block decoded on the device by swc_lz4_parse/resolve; size and XXH32 == the payload's",
-            "compression_ratio": ratio}
+    # the size of the reference encoder restated (oracle/rc_lz4c.c / rc_deflatec.c) on a sample of the distinct units
+    k = min(nd, 16)
+    sizes = r["out_len"][:nd]
+    if codec == "lz4_block":
+        ref = sum(len(O.lz4_compress_block(plains[i])[1]) for i in range(k))
+    else:
+        ref = sum(len(O.deflate_compress(plains[i])) for i in range(k))
+    ours = int(sum(int(sizes[i]) for i in range(k))) if batch.n // nd >= 1 else 0
+    return {"units_verified": int(batch.n), "method": "every compressed unit decoded on the device by the engine's own decoder; size and XXH32 == the payload's",
+            "compression_ratio": ratio, "size_vs_reference_encoder_restated": {"units": k, "engine_bytes": ours, "oracle_bytes": int(ref), "ratio": ours / ref if ref else None}}
 
 
 def archive_paths(lib):
@@ -478,7 +511,7 @@ def run_workload(name, args, lib, torch, dist, world, rank, device, steps, warmu
     r = batch.results()
     if not (r["status"] == 0).all():
         raise SystemExit("decode failed: statuses %s" % sorted(set(r["status"].tolist())))
-    if name == "lz4_compress_4m":   # algorithmic bytes of the encode side: the payload read once, the compressed block written once
+    if name in ("lz4_compress_4m", "deflate_compress_64k"):   # algorithmic bytes of the encode side: the payload read once, the compressed unit written once
         sum_c = int(r["out_len"].sum())
 
     # The verification after the timed region must see what the LAST timed step wrote, not what the warm-up left behind:
@@ -514,7 +547,12 @@ def run_workload(name, args, lib, torch, dist, world, rank, device, steps, warmu
 
     # every unit of the LAST timed step is checked before anything else launches (the phase-timing launches below rewrite
     # all outputs: checking after them would check them)
-    verify = verify_compressed_units(batch, plains, torch) if name == "lz4_compress_4m" else verify_all_units(name, batch, raw, plains, trailers)
+    if name == "lz4_compress_4m":
+        verify = verify_compressed_units(batch, plains, torch)
+    elif name == "deflate_compress_64k":
+        verify = verify_compressed_units(batch, plains, torch, codec="deflate")
+    else:
+        verify = verify_all_units(name, batch, raw, plains, trailers)
 
     # outside the timed region: per-kernel durations of more launches (HIP events inside the library, on the launch stream)
     lib.swc_set_tuning(b"phase_timing", 1)
@@ -703,7 +741,7 @@ def main():
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and args.workload == "deflate64k" and not args.no_per_codec and args.scale == 1.0:
         per = {}
-        for name in ("deflate64k_mix", "lz4_4m", "bzip2_900k", "lzma2_256k", "lz4_compress_4m"):
+        for name in ("deflate64k_mix", "lz4_4m", "bzip2_900k", "lzma2_256k", "lz4_compress_4m", "deflate_compress_64k"):
             res, b, _, _ = run_workload(name, args, lib, torch, dist, world, rank, device, WORKLOADS[name]["steps"], 1, with_cpu)
             per[name] = res
             del b

@@ -43,9 +43,12 @@ typedef enum swc_codec {
     SWC_CODEC_BZIP2_BLOCK = 5, /* one bzip2 block body -- BZip2.decode(_:_:)       BZip2.swift:97-270       */
     SWC_CODEC_DELTA = 6,   /* XZ / 7-Zip Delta filter  -- DeltaFilter.decode(_:_:) DeltaFilter.swift:11-33; aux = distance as the
                               reference passes it (XZBlock.swift:57: property + 1), out may equal in            */
-    SWC_CODEC_LZ4_COMPRESS = 7 /* ENCODE, one LZ4 block -- LZ4.compress(block:_:) LZ4+Compress.swift:157-281: in = prefix ++ block,
+    SWC_CODEC_LZ4_COMPRESS = 7, /* ENCODE, one LZ4 block -- LZ4.compress(block:_:) LZ4+Compress.swift:157-281: in = prefix ++ block,
                               dict_len = length of the prefix (dictionary / previous block), out_cap >= n + n / 255 + 16;
                               A valid block for the same bytes, not the reference's bytes            */
+    SWC_CODEC_DEFLATE_COMPRESS = 8 /* ENCODE, one raw Deflate stream -- Deflate.compress(data:) Deflate+Compress.swift:22-213: one
+                              stored or static-Huffman block over a greedy LZ77 parse; out_cap >= n + n / 8 + 16, out 4-byte
+                              aligned; A valid stream for the same bytes, not the reference's bytes   */
 } swc_codec;
 
 typedef struct swc_job {
@@ -139,6 +142,11 @@ int swc_lz4_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, si
 int swc_lz4_compress(const uint8_t* data, size_t len, int independent_blocks, int block_checksums, int content_checksum,
                      int content_size, size_t block_size, const uint8_t* dict, size_t dict_len, int64_t dict_id,
                      uint8_t** out, size_t* out_len);
+/* Deflate.compress(data:) Deflate+Compress.swift:22-46: one stored or static-Huffman block, compressed on the device
+ * (SWC_CODEC_DEFLATE_COMPRESS).  ZlibArchive.archive(data:) ZlibArchive.swift:54-70: 0x78 0xDA, that stream, Adler-32 (big
+ * endian; computed on the device in the same launch sequence). */
+int swc_deflate_compress(const uint8_t* data, size_t len, uint8_t** out, size_t* out_len);
+int swc_zlib_archive(const uint8_t* data, size_t len, uint8_t** out, size_t* out_len);
 /* LZ4.multiDecompress(data:dictionary:dictionaryID:) LZ4.swift:116-146 */
 int swc_lz4_multi_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len, int64_t dict_id,
                              uint8_t** out, size_t* out_len, size_t** sizes, size_t* n_frames);

@@ -188,6 +188,12 @@ class Deflate:
         """(output, bytes consumed) -- the reader-taking overload Deflate.swift:30."""
         return _call_simple("swc_deflate_decompress", data, consumed=True)
 
+    @staticmethod
+    def compress(data):
+        """Deflate.compress(data:) (Deflate+Compress.swift:22-46): one stored or static-Huffman block, compressed on the device.
+        The stream decodes to `data` with the reference's decoder; its bytes are not the reference encoder's."""
+        return _call_simple("swc_deflate_compress", data)
+
 
 class GzipArchive:
     @staticmethod
@@ -203,6 +209,11 @@ class ZlibArchive:
     @staticmethod
     def unarchive(archive):
         return _call_simple("swc_zlib_unarchive", archive)
+
+    @staticmethod
+    def archive(data):
+        """ZlibArchive.archive(data:) (ZlibArchive.swift:54-70)."""
+        return _call_simple("swc_zlib_archive", data)
 
 
 class BZip2:

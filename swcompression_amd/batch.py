@@ -10,7 +10,7 @@ import numpy as np
 
 from . import _lib
 
-CODECS = {"deflate": 1, "lz4_block": 2, "lzma2": 3, "lzma": 4, "bzip2_block": 5, "delta": 6, "lz4_compress": 7}
+CODECS = {"deflate": 1, "lz4_block": 2, "lzma2": 3, "lzma": 4, "bzip2_block": 5, "delta": 6, "lz4_compress": 7, "deflate_compress": 8}
 
 JOB_DTYPE = np.dtype([("in", "<u8"), ("in_len", "<u8"), ("out", "<u8"), ("out_cap", "<u8"), ("out_len", "<u8"),
                       ("in_consumed", "<u8"), ("status", "<i4"), ("aux", "<i4"), ("dict", "<u8"), ("dict_len", "<u8")])

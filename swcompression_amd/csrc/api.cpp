@@ -65,6 +65,7 @@ static hipError_t launch_codec(int codec, Job* jobs, size_t n, void* ws, size_t 
         case SWC_CODEC_BZIP2_BLOCK: return launch_bzip2(jobs, n, ws, ws_bytes, stream);
         case SWC_CODEC_DELTA: return launch_delta(jobs, n, stream);
         case SWC_CODEC_LZ4_COMPRESS: return launch_lz4_compress(jobs, n, stream);
+        case SWC_CODEC_DEFLATE_COMPRESS: return launch_deflate_compress(jobs, n, stream);
         default: return hipErrorInvalidValue;
     }
 }

@@ -310,6 +310,48 @@ int swc_gzip_multi_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, si
     return SWC_E_DEVICE;
 }
 
+// Deflate.compress(data:) (Deflate+Compress.swift:22-46): the whole buffer is one unit of SWC_CODEC_DEFLATE_COMPRESS.
+// `sum_kind` != 0: a checksum of the INPUT is wanted as well (ZlibArchive.archive: Adler-32) -- computed here on the host, the
+// input never becomes a job output on the device.
+static int deflate_compress_unit(const uint8_t* data, size_t len, HostUnit& u) {
+    u.in = data; u.in_len = len;
+    u.cap_hint = len + len / 8 + 16;
+    u.cap_exact = true;
+    return run_one(SWC_CODEC_DEFLATE_COMPRESS, u);
+}
+int swc_deflate_compress(const uint8_t* data, size_t len, uint8_t** out, size_t* out_len) try {
+    if (!out || !out_len || (len && !data)) return SWC_E_INVALID_ARGUMENT;
+    HostUnit u;
+    int st = deflate_compress_unit(data, len, u);
+    if (st == SWC_OK) st = u.status;
+    if (st) { give_empty(out, out_len); return st; }
+    give(u.out, out, out_len);
+    return SWC_OK;
+} catch (...) {
+    if (out && out_len) give_empty(out, out_len);
+    return SWC_E_DEVICE;
+}
+// ZlibArchive.archive(data:) (ZlibArchive.swift:54-70)
+int swc_zlib_archive(const uint8_t* data, size_t len, uint8_t** out, size_t* out_len) try {
+    if (!out || !out_len || (len && !data)) return SWC_E_INVALID_ARGUMENT;
+    HostUnit u;
+    int st = deflate_compress_unit(data, len, u);
+    if (st == SWC_OK) st = u.status;
+    if (st) { give_empty(out, out_len); return st; }
+    std::vector<uint8_t> z;
+    z.reserve(u.out.size() + 6);
+    z.push_back(120);                                                  // :56 CM = 8, CINFO = 7
+    z.push_back(218);                                                  // :57 slowest algorithm, no preset dictionary
+    z.insert(z.end(), u.out.begin(), u.out.end());
+    const uint32_t a = swc_adler32(data, len);                         // :62-66 big endian
+    for (int i = 3; i >= 0; i--) z.push_back((uint8_t)(a >> (8 * i)));
+    give(z, out, out_len);
+    return SWC_OK;
+} catch (...) {
+    if (out && out_len) give_empty(out, out_len);
+    return SWC_E_DEVICE;
+}
+
 int swc_zlib_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, size_t* out_len) try {
     if (!out || !out_len || (in_len && !in)) return SWC_E_INVALID_ARGUMENT;
     size_t p = 0;

@@ -24,6 +24,7 @@
 #include "lz4_lane.h"
 #include "lz4_wave.h"
 #include "lz4_comp.h"
+#include "deflate_comp.h"
 #include "lzma_wave.h"
 #include "bzip2_block.h"
 #include "crc32_group.h"
@@ -336,6 +337,28 @@ hipError_t launch_lz4_compress(Job* jobs, size_t n, hipStream_t stream) {
     const uint32_t* order = job_order(jobs, n, stream);
     g_pt.begin(stream);
     hipLaunchKernelGGL(swc_lz4_compress_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, jobs, (uint32_t)n, order);
+    g_pt.mark(stream);
+    return hipGetLastError();
+}
+
+// ---- Deflate compression (deflate_comp.h), one buffer per wavefront: hash table + a staging area of the bit stream in LDS ------
+__global__ __launch_bounds__(64) void swc_deflate_compress_kernel(Job* __restrict__ jobs, uint32_t n, const uint32_t* __restrict__ order) {
+    __shared__ __attribute__((aligned(16))) defc::Lds lds;
+    uint32_t g = job_of(order, blockIdx.x, n);
+    if (g >= n) return;
+    Job job = jobs[g];
+    defc::deflate_compress_job<kWave>(job, &lds);
+    if (threadIdx.x == 0) {
+        jobs[g].out_len = job.out_len;
+        jobs[g].in_consumed = job.in_consumed;
+        jobs[g].status = job.status;
+    }
+}
+hipError_t launch_deflate_compress(Job* jobs, size_t n, hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    const uint32_t* order = job_order(jobs, n, stream);
+    g_pt.begin(stream);
+    hipLaunchKernelGGL(swc_deflate_compress_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, jobs, (uint32_t)n, order);
     g_pt.mark(stream);
     return hipGetLastError();
 }

@@ -18,6 +18,7 @@ int last_phase_ms(float* ms, int cap);
 hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream, const uint64_t* ws_off = nullptr);
 size_t lz4_ws_bytes_per_job(uint64_t cap);
 hipError_t launch_lz4_compress(Job* jobs, size_t n, hipStream_t stream);
+hipError_t launch_deflate_compress(Job* jobs, size_t n, hipStream_t stream);
 hipError_t launch_lzma(bool lzma2, Job* jobs, size_t n, void* spill, hipStream_t stream);
 size_t lzma_spill_bytes_per_job();
 hipError_t launch_bzip2(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream);

@@ -149,3 +149,9 @@ def lz4_compress(blocks, prefixes=None, caps=None):
     ins = [bytes(p) + bytes(b) for p, b in zip(prefixes, blocks)]
     caps = caps or [len(b) + len(b) // 255 + 16 for b in blocks]
     return run_batch("emu_lz4_compress", ins, caps, extra=[len(p) for p in prefixes])
+
+
+def deflate_compress(bufs, caps=None):
+    """Deflate compression (deflate_comp.h): returns list of (status, compressed bytes, in_consumed, out_len)."""
+    caps = caps or [len(b) + len(b) // 8 + 16 for b in bufs]
+    return run_batch("emu_deflate_compress", [bytes(b) for b in bufs], caps)

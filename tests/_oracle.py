@@ -182,6 +182,19 @@ def lz4_compress_block(block, prefix=b""):
     return st, out.raw[:min(n.value, cap)]
 
 
+def deflate_compress(data):
+    """Deflate.compress(data:) (Deflate+Compress.swift:22-213), restated: the compressed bytes."""
+    data = bytes(data)
+    cap = len(data) + len(data) // 8 + 64
+    out = C.create_string_buffer(cap)
+    n = C.c_size_t()
+    lib.refcpu_deflate_compress.restype = C.c_int
+    lib.refcpu_deflate_compress.argtypes = [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    st = lib.refcpu_deflate_compress(data, len(data), out, cap, C.byref(n))
+    assert st == 0, st
+    return out.raw[:n.value]
+
+
 def crc32(data, prev=0):
     return lib.refcpu_crc32(bytes(data), len(data), prev)
 

@@ -10,6 +10,7 @@
 #include "../../swcompression_amd/csrc/lz4_lane.h"
 #include "../../swcompression_amd/csrc/lz4_wave.h"
 #include "../../swcompression_amd/csrc/lz4_comp.h"
+#include "../../swcompression_amd/csrc/deflate_comp.h"
 #include "../../swcompression_amd/csrc/lz_copy.h"
 #include "../../swcompression_amd/csrc/lzma_wave.h"
 #include "../../swcompression_amd/csrc/bzip2_block.h"
@@ -78,6 +79,15 @@ extern "C" void emu_lz4_compress(swc::Job* jobs, size_t n) {
     for (size_t g = 0; g < n; g++) {
         std::memset(table, 0xEE, sizeof table);
         swc::lz4c::lz4_compress_job<64>(jobs[g], table);
+    }
+}
+
+// Deflate compression (deflate_comp.h): job.in = the buffer
+extern "C" void emu_deflate_compress(swc::Job* jobs, size_t n) {
+    alignas(16) static swc::defc::Lds lds;
+    for (size_t g = 0; g < n; g++) {
+        std::memset(&lds, 0xEE, sizeof lds);
+        swc::defc::deflate_compress_job<64>(jobs[g], &lds);
     }
 }
 
