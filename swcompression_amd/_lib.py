@@ -3,7 +3,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-# SWC_LIB: a variant build of the same library (tools/build_variant.sh; A/B runs of compile-time knobs on the GPU box)
+# SWC_LIB (DEVELOPMENT ONLY): a variant build of the same library (tools/build_variant.sh; A/B runs of compile-time knobs on the GPU
+# box).  Whatever the variable names is loaded as it is -- nothing a deployment should set.
 LIB_PATH = os.environ.get("SWC_LIB") or os.path.join(_HERE, "libswc_hip.so")
 
 

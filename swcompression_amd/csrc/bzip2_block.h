@@ -737,8 +737,9 @@ struct Stage1 {
             }
             L.have_table = false;
             if (FAST) {
-                // 50 codes of kMaxLen bits are 163 bytes; the reader looks 8 bytes ahead.  (n_used == 0: a run has no byte to repeat.)
-                if (L.over || L.n_used == 0 || br.next + 176 > br.n || (uint64_t)L.sbase + 128 > (uint64_t)lcap32) { L.have_table = true; return -1; }
+                // 50 codes of kMaxLen bits are 163 bytes; the reader looks 8 bytes ahead and the assembly loop asks for one more aligned
+                // pair beyond that (up to 11 bytes): 184 (it was 176).  (n_used == 0: a run has no byte to repeat.)
+                if (L.over || L.n_used == 0 || br.next + 184 > br.n || (uint64_t)L.sbase + 128 > (uint64_t)lcap32) { L.have_table = true; return -1; }
             }
             int i = 0;
             for (;;) {

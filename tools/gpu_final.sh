@@ -4,7 +4,7 @@
 # passes.  Usage: gpu_final.sh <tag> [parts...]   parts: tests bench trace pmc sq (default: all)
 # Outputs under gpurun_out/<tag>/; tools/collect_profiles.sh <tag> copies what is to be judged into profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-final}; shift; PARTS=${@:-tests bench trace pmc sq}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
-WL=${WL:-"deflate64k lz4_4m bzip2_900k lzma2_256k"}; XWL=${XWL-"deflate64k_mix lz4_compress_4m"}
+WL=${WL:-"deflate64k lz4_4m bzip2_900k lzma2_256k"}; XWL=${XWL-"deflate64k_mix lz4_compress_4m deflate_compress_64k"}
 for P in $PARTS; do case $P in
 tests)
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
