@@ -25,6 +25,8 @@ for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
 # gfx950 half-count correction: only kernels whose reads are wide coalesced streams (16 B per lane).  Calibrated on
 # this path: the resolve kernel stages U + 4*records bytes with 16-byte loads and reports exactly half of that;
 # the lane-per-stream kernels read scattered dwords and report the compressed bytes 1:1.
+# (round 5: phase 2 is swc_lz_copy_kernel for launches of 2,560 streams and more; it reads records as dwords, literals as 16
+# bytes per lane and far sources as scattered 8-byte loads -- its FETCH_SIZE is taken 1:1, the conservative reading)
 WIDE = ("swc_lz_resolve_kernel", "swc_lz4_resolve_kernel")
 # Kernels that verify_all_units launches AFTER the clock has stopped are not part of the step: the XXH32 of the LZ4 outputs and
 # the CRC-32 of the BZip2 / LZMA2 outputs.  For the gzip workloads the CRC-32 IS part of the step.
