@@ -190,6 +190,29 @@ def test_bgzf_members_share_one_launch():
                 assert ei.value.data == exp, k
 
 
+def test_bgzf_views_and_recycled_results():
+    """The members of a BGZF file as VIEWS into the C result (what a Swift shim gets with Data(bytesNoCopy:)): same bytes as the
+    copies, alive as long as one view is; results of 4 MiB and more are parked by swc_free and taken over by the next call of
+    about that size -- a stale byte from the call before must never show."""
+    import gc
+    a = [corpus.p_text(65536, 9100 + i) for i in range(100)]
+    b = [corpus.p_mix(65536, 9300 + i) for i in range(100)]
+    da = b"".join(corpus.gzip_member(p, bgzf=True) for p in a)
+    db = b"".join(corpus.gzip_member(p, bgzf=True) for p in b)
+    for _ in range(3):
+        va = swc.GzipArchive.multi_unarchive(da, views=True)
+        assert [bytes(v) for v in va] == a and all(v.readonly for v in va)
+        keep = va[37]
+        del va
+        gc.collect()
+        assert swc.GzipArchive.multi_unarchive(db) == b            # a different result of the same size in between
+        assert bytes(keep) == a[37]                                  # the kept view still owns its buffer
+        del keep
+        gc.collect()
+        assert swc.GzipArchive.multi_unarchive(db, views=True)[99] == b[99]
+        assert swc.GzipArchive.multi_unarchive(da) == a
+
+
 def test_lz4_multi_frame_one_launch():
     """LZ4.multiDecompress (LZ4.swift:116-146) on a buffer of many frames: block sizes are in the headers, so all frames
     share one launch; anything unusual falls back to the sequential loop and must match the oracle."""
