@@ -45,7 +45,7 @@ WORKLOADS = {
                            kernels=["swc_inflate_sync_kernel", "swc_lz_copy_kernel"], steps=10),
     "lz4_4m": dict(codec="lz4_block", kind="lz4_block", parts=[("text", 192), ("mix", 64)], n_units=8192, unit=4 << 20,
                    desc="8192 x 4 MiB independent LZ4 blocks (BASELINE configs[2], resident micro-config of SURVEY 8d; 256 distinct: 192 P-text + 64 P-mix)",
-                   kernels=["swc_lz4_lane_kernel", "swc_lz4_parse_kernel", "swc_lz_copy_kernel"], steps=10),
+                   kernels=["swc_lz4_lane_kernel", "swc_lz4_parse_kernel", "swc_lz4_copy_kernel"], steps=10),
     "lz4_compress_4m": dict(codec="lz4_compress", kind="lz4_plain", parts=[("text", 192), ("mix", 64)], n_units=8192, unit=4 << 20,
                             desc="ENCODE: 8192 x 4 MiB blocks compressed to LZ4 blocks (LZ4.compress(block:), SURVEY 8f row 4; 256 distinct: 192 P-text + 64 P-mix); "
                                  "value = INPUT GiB/s; every block decoded again on the device and checked",

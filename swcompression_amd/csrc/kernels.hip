@@ -167,9 +167,15 @@ __global__ __launch_bounds__(kInflateResolveThreads) void swc_lz_resolve_kernel(
     lzr::resolve_job<kInflateResolveThreads, kInflateRingLog2, kInflateKeep>(job, wm.area(g), wm.bytes(g), &lzr_lds, prof ? prof + 32 * (size_t)g + 16 : nullptr);
 }
 
-// Phase 2, record-granular (lz_copy.h): one stream per WAVEFRONT, the last 6-8 KiB of its output in an LDS window of 8 KiB
-// (9.2 KB of LDS per wave -> 16 waves per CU), older sources read back from the output buffer.  The 16 KiB variant
-// (8 waves per CU, fewer far reads) is kept for comparison runs.
+// Phase 2, record-granular (lz_copy.h): one stream per WAVEFRONT, the last few KiB of its output in an LDS window, older
+// sources read back from the output buffer.  The window is a trade between the waves a CU holds and the matches that are FAR
+// (profiles/r05_experiments.txt, r05n-p):
+//   Deflate  5 KiB window, groups of up to 1 KiB (6.2 KB of LDS per wave -> 24 waves per CU): 7.4 ms on BASELINE configs[1]
+//            against 8.5 ms with 8 KiB / 2 KiB at 16 waves per CU -- the walk of a stream is serial, and what hides its
+//            LDS and memory latencies is the number of waves; 46 % of the matches of text are far then instead of 35 %;
+//   LZ4      8 KiB window, groups of up to 2 KiB, 16 waves per CU: offsets reach 65,535 bytes back and 4 MiB blocks have long
+//            literal runs -- the smaller window is 1-8 % slower there.
+// The 16 KiB variant (8 waves per CU) is kept for comparison runs.
 template <uint32_t WIN, uint32_t SPAN>
 __device__ __forceinline__ void lz_copy_body(const Job* __restrict__ jobs, uint32_t n, const WsMap& wm, const uint32_t* __restrict__ order) {
     __shared__ __attribute__((aligned(16))) lzc::Lds<WIN> lds;
@@ -179,13 +185,21 @@ __device__ __forceinline__ void lz_copy_body(const Job* __restrict__ jobs, uint3
     if (job.dict != nullptr) return;   // (LZ4 blocks with a dictionary prefix were decoded by the lane kernel)
     lzc::copy_job<WIN, SPAN>(job, wm.area(g), wm.bytes(g), &lds);
 }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void swc_lz_copy_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, const uint32_t* __restrict__ order) {
+#ifndef SWC_LZC_WIN
+#define SWC_LZC_WIN 5120
+#define SWC_LZC_SPAN 1024
+#define SWC_LZC_WAVES 6
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_LZC_WAVES, SWC_LZC_WAVES))) void swc_lz_copy_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, const uint32_t* __restrict__ order) {
+    lz_copy_body<SWC_LZC_WIN, SWC_LZC_SPAN>(jobs, n, wm, order);
+}
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void swc_lz4_copy_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, const uint32_t* __restrict__ order) {
     lz_copy_body<8192, 2048>(jobs, n, wm, order);
 }
 __global__ __launch_bounds__(64) void swc_lz_copy16_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, const uint32_t* __restrict__ order) {
     lz_copy_body<16384, 2048>(jobs, n, wm, order);
 }
-// "lz_copier" (swc_set_tuning): 1 = lz_copy.h with an 8 KiB window (default), 2 = with a 16 KiB window, 0 = the byte-cell resolver
+// "lz_copier" (swc_set_tuning): 1 = lz_copy.h with the windows above (default), 2 = with a 16 KiB window, 0 = the byte-cell resolver
 // of lz_resolve.h (rounds 2-4) -- kept for A/B measurements; all produce the same bytes.
 static std::atomic<int> g_lz_copier{1};
 void set_lz_copier(int v) { g_lz_copier = v; }
@@ -198,8 +212,9 @@ static int copier_for(size_t n) {
     const int c = g_lz_copier;
     return c < 0 ? -c : (c == 1 && n < kCopierMin ? 0 : c);   // (tuning value -1 / -2: the wave kernel whatever the batch size)
 }
-static void launch_lz_copy(int mode, const Job* jobs, size_t n, const WsMap& wm, const uint32_t* order, hipStream_t stream) {
+static void launch_lz_copy(int mode, bool lz4, const Job* jobs, size_t n, const WsMap& wm, const uint32_t* order, hipStream_t stream) {
     if (mode == 2) hipLaunchKernelGGL(swc_lz_copy16_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, jobs, (uint32_t)n, wm, order);
+    else if (lz4) hipLaunchKernelGGL(swc_lz4_copy_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, jobs, (uint32_t)n, wm, order);
     else hipLaunchKernelGGL(swc_lz_copy_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, jobs, (uint32_t)n, wm, order);
 }
 
@@ -243,7 +258,7 @@ hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStr
     hipLaunchKernelGGL(swc_inflate_sync_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
     const int copier = copier_for(n);
-    if (copier) launch_lz_copy(copier, jobs, n, wm, order, stream);
+    if (copier) launch_lz_copy(copier, false, jobs, n, wm, order, stream);
     else hipLaunchKernelGGL(swc_lz_resolve_kernel, dim3((unsigned)n), dim3(kInflateResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
     return hipGetLastError();
@@ -313,7 +328,7 @@ hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_
     hipLaunchKernelGGL(swc_lz4_parse_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
     const int copier = copier_for(n);
-    if (copier) launch_lz_copy(copier, jobs, n, wm, order, stream);
+    if (copier) launch_lz_copy(copier, true, jobs, n, wm, order, stream);
     else hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(lz4w::kResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
     return hipGetLastError();

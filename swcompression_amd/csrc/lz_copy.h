@@ -25,7 +25,8 @@
 //              the first record that has not been copied yet finds everything in front of it final.  A group with many of
 //              them (more than kSeqMax) falls back to rounds by watermark: with the head, every lane whose source ends
 //              in front of the head's match copies its own;
-//   window     a LINEAR array, not a ring: when a group does not fit behind the write position any more, the finished bytes
+//   window     a LINEAR array (WIN bytes: 5 KiB for Deflate, 8 KiB for LZ4 -- kernels.hip), not a ring: when a group does not
+//              fit behind the write position any more, the finished bytes
 //              are flushed to HBM (aligned 16-byte stores, the only time the output is written) and the last kKeep bytes
 //              move to the front of the array (16 bytes per lane and step).  No index masks anywhere in the copy code.
 //
@@ -54,7 +55,10 @@ using lzr::u128;
 template <uint32_t WIN>
 struct Lds {
     static constexpr uint32_t kWin = WIN;
-    static constexpr uint32_t kLitBuf = 1024;             // bytes of the literal stream staged at a time
+#ifndef SWC_LZC_LITBUF
+#define SWC_LZC_LITBUF 1024
+#endif
+    static constexpr uint32_t kLitBuf = SWC_LZC_LITBUF;   // bytes of the literal stream staged at a time (16 bytes per lane: at most 1024)
     alignas(16) uint8_t win[WIN + 16];                    // byte at virtual position v lives at win[v - vbase] (+16: reads of short runs overshoot)
     alignas(16) uint8_t lit[kLitBuf + 16];                // literal at stream offset o lives at lit[o - lv]
 };
@@ -114,7 +118,6 @@ struct Copier {
     static constexpr uint32_t kSeqMax = 12;                    // more pending records than this: rounds by watermark
     static constexpr uint32_t kBack = 65536;                   // the furthest a source lies behind its match (record format)
     static constexpr uint32_t kLitOff = (uint32_t)offsetof(L, lit);
-    static_assert(lzr::kMaxLitOnly <= kSpanMax, "a literal-only record must fit the room a slide makes");
     static_assert(lzr::kLitRunMax + lzr::kMaxLen <= kSpanMax && kBigLit - 1u <= kLitCap && lzr::kLitRunMax <= kLitCap, "a record must fit a group");
     static_assert(64u * (kBigLit - 1u + lzr::kMaxLen + lzr::kLitRunMax) < 0x10000u, "the packed scan keeps 16 bits per sum");
     // A far source lies in front of the window, i.e. at least kKeep - kMaxLen bytes behind the write position.  Finished bytes
@@ -402,12 +405,16 @@ struct Copier {
             uint64_t rp = rpos, lb = lbase;
             for (uint32_t i = 0; i < g.ntake; i++) {
                 const uint32_t e1 = simt::wave_read<W>(g.x, (int)i);
-                const uint32_t n = (uint32_t)((uint64_t)rpos + e1 - rp);
-                uint32_t wp = (uint32_t)((uint64_t)A + rp - vbase);
-                if (wp + n > WIN) wp = slide(rp);
-                coop_literals(wp, lb, n);
-                rp += n;
-                lb += n;
+                uint32_t n = (uint32_t)((uint64_t)rpos + e1 - rp);
+                while (n != 0u) {   // (a record of up to kMaxLitOnly bytes in pieces of what a slide makes room for)
+                    const uint32_t piece = n < kSpanMax ? n : kSpanMax;
+                    uint32_t wp = (uint32_t)((uint64_t)A + rp - vbase);
+                    if (wp + piece > WIN) wp = slide(rp);
+                    coop_literals(wp, lb, piece);
+                    rp += piece;
+                    lb += piece;
+                    n -= piece;
+                }
             }
             return;
         }
@@ -418,7 +425,7 @@ struct Copier {
         return;
 #endif
         if (g.lit_refill) {   // (g.lv == lbase rounded down: what front() loaded)
-            SIMT_BEGIN(t, W) *(u128*)(l->lit + 16u * (uint32_t)t) = g.litpf[t]; SIMT_END_WAVE
+            SIMT_BEGIN(t, W) if (16u * (uint32_t)t < kLitBuf) *(u128*)(l->lit + 16u * (uint32_t)t) = g.litpf[t]; SIMT_END_WAVE
         }
         uint8_t* const B = (uint8_t*)l;                                 // window indices are offsets from here
         const uint32_t lrel = kLitOff + (uint32_t)(lbase - g.lv);

@@ -17,10 +17,21 @@
 #include "../../swcompression_amd/csrc/crc32_group.h"
 
 extern "C" void emu_set_order(int o) { swc::simt::g_order = o; }
-// phase 2: 1 = the record-granular copier of lz_copy.h (what the library ships), 0 = the byte-cell resolver of lz_resolve.h
+// phase 2: 1 = the record-granular copier of lz_copy.h as the library ships it (Deflate: 5 KiB window, LZ4: 8 KiB), 3 = the 5 KiB
+// window for both, 2 = the 8 KiB window for both, 0 = the byte-cell resolver of lz_resolve.h
 static int g_copier = 1;
 extern "C" void emu_set_copier(int on) { g_copier = on; }
-constexpr uint32_t kEmuWin = 8192, kEmuSpan = 2048;
+// (the two window configurations the library ships: kernels.hip)
+template <uint32_t WIN, uint32_t SPAN>
+static void emu_copy(swc::Job& job, const uint8_t* ws, size_t wsb) {
+    alignas(16) static swc::lzc::Lds<WIN> cl;
+    std::memset(&cl, 0xEE, sizeof cl);
+    swc::lzc::copy_job<WIN, SPAN>(job, ws, wsb, &cl);
+}
+static void emu_copy_any(int deflate, swc::Job& job, const uint8_t* ws, size_t wsb) {
+    if (g_copier == 3 || (g_copier == 1 && deflate)) emu_copy<5120, 1024>(job, ws, wsb);
+    else emu_copy<8192, 2048>(job, ws, wsb);
+}
 
 // Deflate, one stream per wavefront with 64 sub-chunks decoded at once (inflate_sync.h): the uniform parts run once, the
 // 64 lanes of every parallel region one after another (csrc/simt.h).
@@ -33,9 +44,7 @@ extern "C" void emu_inflate_sync(swc::Job* jobs, size_t n) {
         std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
         swc::inflate::inflate_sync_job(jobs[g], &sl, ws.data(), wsb, 0, 1);
         if (g_copier) {
-            alignas(16) static swc::lzc::Lds<kEmuWin> cl;
-            std::memset(&cl, 0xEE, sizeof cl);
-            swc::lzc::copy_job<kEmuWin, kEmuSpan>(jobs[g], ws.data(), wsb, &cl);
+            emu_copy_any(1, jobs[g], ws.data(), wsb);
             continue;
         }
         std::memset(&rl, 0xEE, sizeof rl);
@@ -63,9 +72,7 @@ extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {
         std::memset(stage, 0xEE, sizeof stage);
         swc::lz4w::lz4_parse_job<1>(jobs[g], ws.data(), wsb, 0, stage);
         if (g_copier) {
-            alignas(16) static swc::lzc::Lds<kEmuWin> cl;
-            std::memset(&cl, 0xEE, sizeof cl);
-            swc::lzc::copy_job<kEmuWin, kEmuSpan>(jobs[g], ws.data(), wsb, &cl);
+            emu_copy_any(0, jobs[g], ws.data(), wsb);
             continue;
         }
         std::memset(&rl, 0xEE, sizeof rl);
@@ -140,11 +147,9 @@ extern "C" void emu_copy_records(const uint32_t* recs, uint32_t nrec, const uint
     std::memcpy(ws.data() + swc::lzr::lit_offset(wsb, cap), lits, nlit);
     swc::Job j{};
     j.out = out; j.out_cap = cap; j.out_len = out_len;
-    if (copier) {
-        alignas(16) static swc::lzc::Lds<kEmuWin> cl;
-        std::memset(&cl, 0xEE, sizeof cl);
-        swc::lzc::copy_job<kEmuWin, kEmuSpan>(j, ws.data(), wsb, &cl);
-    } else {
+    if (copier == 3) emu_copy<5120, 1024>(j, ws.data(), wsb);
+    else if (copier) emu_copy<8192, 2048>(j, ws.data(), wsb);
+    else {
         alignas(16) static swc::lzr::Lds<512, 16> rl;
         std::memset(&rl, 0xEE, sizeof rl);
         swc::lzr::resolve_job<512, 16, 32768, true>(j, ws.data(), wsb, &rl);

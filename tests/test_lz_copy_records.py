@@ -81,8 +81,9 @@ def test_record_classes(profile, order):
         for size in (0, 1, 63, 64, 200, 5000, 9000, 40000, 140000):
             recs, lits, exp = build(rnd, size, profile) if size else ([], b"", b"")
             for misalign in (0, 5, 15):
-                got = run_copy(recs, lits, max(len(exp), 1), len(exp), misalign, 1)
-                assert got == exp, "copier differs (size %d, misalign %d)" % (size, misalign)
+                for cfg in (1, 3):       # the two window configurations the library ships: 8 KiB / 2 KiB groups, 5 KiB / 1 KiB groups
+                    got = run_copy(recs, lits, max(len(exp), 1), len(exp), misalign, cfg)
+                    assert got == exp, "copier differs (size %d, misalign %d, configuration %d)" % (size, misalign, cfg)
             if order == 0 and size and profile is not STORED:
                 # (not on STORED: runs of literal-only records of unequal sizes followed by matches 64 KiB back are a stream no
                 # phase 1 writes, and the old resolver's long-literal path -- not shipped any more -- does not take it)
@@ -107,4 +108,5 @@ def test_capacity_cuts_the_last_records():
                 ln = (r >> 7) & 511
                 lit = (r & 127) + (((r >> 16) << 7) if ln == 0 else 0)
                 pos += lit + ln
-            assert run_copy(keep, lits, cap, len(exp), 7, 1) == exp[:cap]
+            for cfg in (1, 3):
+                assert run_copy(keep, lits, cap, len(exp), 7, cfg) == exp[:cap]
