@@ -22,9 +22,9 @@
 //              themselves (distance < length), far matches nobody asked for -- are copied in record order, one after the other,
 //              by ALL lanes together (a byte per lane for the short ones; a dword per lane, 256 bytes per step, for the long
 //              ones; an overlapping match from its first period):
-//              the first record that has not been copied yet finds everything in front of it final.  A group with many of
-//              them (more than kSeqMax) falls back to rounds by watermark: with the head, every lane whose source ends
-//              in front of the head's match copies its own;
+//              the first record that has not been copied yet finds everything in front of it final.  When more than kSeqMax
+//              short ones are left (LZ4 text: a quarter of its matches), a bitmap of the group's output first tells which of
+//              them depend on none of the others -- most -- and those are copied by their own lanes, all at once;
 //   window     a LINEAR array (WIN bytes: 5 KiB for Deflate, 8 KiB for LZ4 -- kernels.hip), not a ring: when a group does not
 //              fit behind the write position any more, the finished bytes
 //              are flushed to HBM (aligned 16-byte stores, the only time the output is written) and the last kKeep bytes
@@ -61,6 +61,7 @@ struct Lds {
     static constexpr uint32_t kLitBuf = SWC_LZC_LITBUF;   // bytes of the literal stream staged at a time (16 bytes per lane: at most 1024)
     alignas(16) uint8_t win[WIN + 16];                    // byte at virtual position v lives at win[v - vbase] (+16: reads of short runs overshoot)
     alignas(16) uint8_t lit[kLitBuf + 16];                // literal at stream offset o lives at lit[o - lv]
+    uint32_t pmap[64 + 2];                                // one bit per output byte of the group: it belongs to a match that has not been copied yet
 };
 
 SWC_HD uint32_t ld32(const uint8_t* p) { return *(const u32_unaligned*)p; }
@@ -115,11 +116,15 @@ struct Copier {
     static constexpr int kPieces = 4;                          // eight-byte pieces of a match a lane copies on its own
     static constexpr uint32_t kLongLen = 8u * kPieces;         // a longer match is copied by all lanes together
     static constexpr uint32_t kLongLit = 64;                   // so is a longer literal run in front of a match
-    static constexpr uint32_t kSeqMax = 12;                    // more pending records than this: rounds by watermark
+#ifndef SWC_LZC_SEQMAX
+#define SWC_LZC_SEQMAX 8
+#endif
+    static constexpr uint32_t kSeqMax = SWC_LZC_SEQMAX;        // more short matches left than this: those that do not depend on each other first, all at once
     static constexpr uint32_t kBack = 65536;                   // the furthest a source lies behind its match (record format)
     static constexpr uint32_t kLitOff = (uint32_t)offsetof(L, lit);
     static_assert(lzr::kLitRunMax + lzr::kMaxLen <= kSpanMax && kBigLit - 1u <= kLitCap && lzr::kLitRunMax <= kLitCap, "a record must fit a group");
     static_assert(64u * (kBigLit - 1u + lzr::kMaxLen + lzr::kLitRunMax) < 0x10000u, "the packed scan keeps 16 bits per sum");
+    static_assert(kSpanMax <= 2048u && kLongLen <= 32u, "the bitmap of a group's output has 2,048 bits, a short match 32");
     // A far source lies in front of the window, i.e. at least kKeep - kMaxLen bytes behind the write position.  Finished bytes
     // are flushed when a KiB of them has gathered, and what was issued before the last drain() has arrived: `landed`.  front()
     // asks only for sources that end 128 bytes (a cache line: a line is never read while a part of it is still on its way)
@@ -148,6 +153,13 @@ struct Copier {
         return r;
 #else
         return m % d;
+#endif
+    }
+    SWC_D static void lds_or(uint32_t* p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+        *p |= v;
 #endif
     }
     SWC_D static void unpack(uint32_t r, uint32_t& li, uint32_t& le, uint32_t& di) {
@@ -281,6 +293,32 @@ struct Copier {
             }
         }
         if (ws < 0) rare_path_done();
+    }
+
+    // ---- a lane copies its own match of up to kLongLen bytes from window index s (or, far, from the pieces fw) to m:
+    // eight-byte pieces, the last one shifted back to end on the last byte; four to seven bytes as two dwords
+    SWC_D static void copy_own(uint8_t* B, uint32_t m, uint32_t s, uint32_t le, bool far, uint64_t f0, uint64_t f1, uint64_t f2, uint64_t f3) {
+        if (le >= 8u) {
+            const uint32_t last = le - 8u;
+            st64(B + m, far ? f0 : rd64u(B, s));
+            if (le > 8u) {
+                const uint32_t o1 = 8u < last ? 8u : last;
+                st64(B + m + o1, far ? f1 : rd64u(B, s + o1));
+                if (le > 16u) {
+                    const uint32_t o2 = 16u < last ? 16u : last;
+                    st64(B + m + o2, far ? f2 : rd64u(B, s + o2));
+                    if (le > 24u) st64(B + m + last, far ? f3 : rd64u(B, s + last));
+                }
+            }
+        } else {
+            const uint64_t v0 = far ? f0 : rd64u(B, s);
+            if (le >= 4u) {
+                st32(B + m, (uint32_t)v0);
+                st32(B + m + (le & 3u), (uint32_t)(v0 >> (8u * (le & 3u))));
+            } else {
+                st_tail(B + m, (uint32_t)v0, le);
+            }
+        }
     }
 
     // ---- a group of records between front() (records -> places, loads asked for) and back() (the copies)
@@ -472,31 +510,8 @@ struct Copier {
             const bool old = !far && s + le <= wp;                                  // it ends in front of the group
             const bool act = mine && le != 0u && !coop && (pf || old);
             pend[t] = mine && le != 0u && !act;
-            // my match, if its source was final when the group began: eight-byte pieces, the last one shifted back to end on
-            // the last byte; four to seven bytes as two dwords
-            if (act) {
-                if (le >= 8u) {
-                    const uint32_t last = le - 8u;
-                    st64(B + m, far ? g.fw[0][t] : rd64u(B, s));
-                    if (le > 8u) {
-                        const uint32_t o1 = 8u < last ? 8u : last;
-                        st64(B + m + o1, far ? g.fw[1][t] : rd64u(B, s + o1));
-                        if (le > 16u) {
-                            const uint32_t o2 = 16u < last ? 16u : last;
-                            st64(B + m + o2, far ? g.fw[2][t] : rd64u(B, s + o2));
-                            if (le > 24u) st64(B + m + last, far ? g.fw[3][t] : rd64u(B, s + last));
-                        }
-                    }
-                } else {
-                    const uint64_t v0 = far ? g.fw[0][t] : rd64u(B, s);
-                    if (le >= 4u) {
-                        st32(B + m, (uint32_t)v0);
-                        st32(B + m + (le & 3u), (uint32_t)(v0 >> (8u * (le & 3u))));
-                    } else {
-                        st_tail(B + m, (uint32_t)v0, le);
-                    }
-                }
-            }
+            // my match, if its source was final when the group began
+            if (act) copy_own(B, m, s, le, far, g.fw[0][t], g.fw[1][t], g.fw[2][t], g.fw[3][t]);
         SIMT_END_WAVE
 #if SWC_LZC_CUT == 2
         return;
@@ -511,15 +526,47 @@ struct Copier {
 #if SWC_LZC_CUT == 3
         return;
 #endif
-        // ---- everything else in record order: the first record that has not been copied finds all bytes in front of it final
+        // ---- the matches that are left reach into their own group (or are long, overlapping, far and not asked for: "odd").
         PT<bool, W> odd;
         SIMT_BEGIN(t, W) odd[t] = pend[t] && flags[t] != 0u; SIMT_END
         uint64_t pm = simt::wave_ballot<W>(pend);
         const uint64_t om = simt::wave_ballot<W>(odd);
-        bool many = (uint32_t)simt::popc64(pm) > kSeqMax;
-        if (om == 0ull && !many) {
-            // the usual case: a few short matches that reach into the group (source in the window, not overlapping): one after
-            // the other, a byte per lane
+        if ((uint32_t)simt::popc64(pm & ~om) > kSeqMax) {
+            // Many short ones: most of them do NOT depend on each other -- the source of a match that reaches into its group
+            // usually is made of literals and of matches that are final by now.  A bitmap of the group's output marks the bytes
+            // of the matches still to be copied; a match whose source touches none of them (and lies in front of the first odd
+            // one) is copied by its own lane at once, all of those together.  What is left goes in record order below.
+            const uint32_t odd_m = om ? simt::wave_read<W>(wm, simt::ctz64(om)) : 0xFFFFFFFFu;
+            const uint64_t pm0 = pm;
+            SIMT_BEGIN(t, W) l->pmap[t] = 0u; if (t < 2) l->pmap[64 + t] = 0u; SIMT_END_WAVE
+            SIMT_BEGIN(t, W)
+                if (((pm0 >> t) & 1u) != 0u && flags[t] == 0u) {
+                    const uint32_t a = wm[t] - wp;
+                    const uint64_t mk = ((1ull << len[t]) - 1ull) << (a & 31u);       // (len <= kLongLen = 32)
+                    lds_or(&l->pmap[a >> 5], (uint32_t)mk);
+                    if ((uint32_t)(mk >> 32) != 0u) lds_or(&l->pmap[(a >> 5) + 1u], (uint32_t)(mk >> 32));
+                }
+            SIMT_END_WAVE
+            PT<bool, W> free_;
+            SIMT_BEGIN(t, W)
+                bool f = ((pm0 >> t) & 1u) != 0u && flags[t] == 0u && si[t] + len[t] <= odd_m;
+                if (f && si[t] + len[t] > wp) {                          // the part of my source inside the group
+                    const uint32_t a = (si[t] > wp ? si[t] : wp) - wp, e = si[t] + len[t] - wp;
+                    const uint64_t mk = ((1ull << (e - a)) - 1ull) << (a & 31u);
+                    const uint64_t w = (uint64_t)l->pmap[a >> 5] | ((uint64_t)l->pmap[(a >> 5) + 1u] << 32);
+                    f = (w & mk) == 0ull;
+                }
+                free_[t] = f;
+            SIMT_END
+            const uint64_t fm = simt::wave_ballot<W>(free_);
+            SIMT_BEGIN(t, W)
+                if (free_[t]) copy_own(B, wm[t], si[t], len[t], false, 0, 0, 0, 0);
+            SIMT_END_WAVE
+            pm &= ~fm;
+        }
+        // ---- in record order: the first record that has not been copied finds all bytes in front of it final
+        if (om == 0ull) {
+            // a few short matches (source in the window, not overlapping): one after the other, a byte per lane
             while (pm) {
                 const int h = simt::ctz64(pm);
                 pm &= pm - 1u;
@@ -534,20 +581,6 @@ struct Copier {
             const int h = simt::ctz64(pm);
             const uint32_t hm = simt::wave_read<W>(wm, h);
             if (!((om >> h) & 1u)) {
-                if (many) {
-                    // many of them: a round by watermark -- with the head, every lane whose source ends in front of the head's
-                    // match copies its own
-                    PT<bool, W> rdy;
-                    const uint64_t pm0 = pm;
-                    SIMT_BEGIN(t, W)
-                        rdy[t] = ((pm0 >> t) & 1u) != 0u && flags[t] == 0u && si[t] + len[t] <= hm;
-                        if (rdy[t]) copy_run(l->win + wm[t], l->win + si[t], len[t]);
-                    SIMT_END_WAVE
-                    pm &= ~simt::wave_ballot<W>(rdy);
-                    many = (uint32_t)simt::popc64(pm) > kSeqMax;
-                    continue;
-                }
-                // a short match that reaches into the group (its source is in the window and does not overlap it): a byte per lane
                 const uint32_t hs = simt::wave_read<W>(si, h), hn = simt::wave_read<W>(len, h);
                 SIMT_BEGIN(t, W)
                     if ((uint32_t)t < hn) B[hm + (uint32_t)t] = B[hs + (uint32_t)t];

@@ -170,6 +170,20 @@ extern "C" size_t emu_inflate_records(const uint8_t* in, size_t in_len, uint8_t*
     return n;
 }
 
+// The same for an LZ4 block (tools/analyze_records.py lz4)
+extern "C" size_t emu_lz4_records(const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, uint32_t* recs_out, size_t max_out) {
+    size_t wsb = swc::lzr::ws_bytes_per_job(cap);
+    std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
+    alignas(16) static uint8_t stage[swc::lz4w::kStageLds];
+    swc::Job j{};
+    j.in = in; j.in_len = in_len; j.out = out; j.out_cap = cap;
+    swc::lz4w::lz4_parse_job<1>(j, ws.data(), wsb, 0, stage);
+    uint32_t n = ((swc::lzr::StreamHeader*)ws.data())->nrec;
+    const uint32_t* r = (const uint32_t*)(ws.data() + sizeof(swc::lzr::StreamHeader));
+    for (size_t i = 0; i < n && i < max_out; i++) recs_out[i] = r[i];
+    return n;
+}
+
 // ---- checksums: the group kernels run with T real host threads and a pthread barrier behind swc::group_sync ----------
 #include <thread>
 #include <pthread.h>
