@@ -225,6 +225,15 @@ class BZip2:
     def multi_decompress(data):
         return _call_multi("swc_bzip2_multi_decompress", data)
 
+    @staticmethod
+    def compress(data, block_size=1):
+        """BZip2.compress(data:blockSize:) (BZip2+Compress.swift:40-74; block_size 1..9 = BlockSize.one ... .nine, the default
+        is that of BZip2.compress(data:), :19-21).  All blocks are compressed on the device together.  The stream decodes to
+        `data` with the reference's decoder and libbz2; its bytes are not the reference encoder's."""
+        if not 1 <= int(block_size) <= 9:
+            raise ValueError("block_size must be 1..9")
+        return _call_simple("swc_bzip2_compress", data, int(block_size))
+
 
 class LZMAProperties:
     """LZMAProperties.swift:9-48 (no validation, as in the reference)."""

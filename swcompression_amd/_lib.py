@@ -71,6 +71,7 @@ def load():
     sig("swc_lz4_decompress", I, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int64, u8pp, szp, szp)
     sig("swc_lz4_multi_decompress", I, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int64, u8pp, szp, szpp, szp)
     sig("swc_deflate_compress", I, C.c_char_p, C.c_size_t, u8pp, szp)
+    sig("swc_bzip2_compress", I, C.c_char_p, C.c_size_t, I, u8pp, szp)
     sig("swc_zlib_archive", I, C.c_char_p, C.c_size_t, u8pp, szp)
     sig("swc_lz4_compress", I, C.c_char_p, C.c_size_t, I, I, I, I, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int64, u8pp, szp)
     sig("swc_zip_get_entries_data", I, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t)

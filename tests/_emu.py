@@ -155,3 +155,15 @@ def deflate_compress(bufs, caps=None):
     """Deflate compression (deflate_comp.h): returns list of (status, compressed bytes, in_consumed, out_len)."""
     caps = caps or [len(b) + len(b) // 8 + 16 for b in bufs]
     return run_batch("emu_deflate_compress", [bytes(b) for b in bufs], caps)
+
+
+def bzip2_compress(data, block_size=1):
+    """BZip2 compression (bzip2_comp.h) with the emulation's executor: returns (status, stream bytes)."""
+    data = bytes(data)
+    cap = len(data) + len(data) // 2 + 4096
+    ob = C.create_string_buffer(cap)
+    n = C.c_size_t(0)
+    lib.emu_bzip2_compress.restype = C.c_int
+    st = lib.emu_bzip2_compress(C.c_char_p(data), C.c_size_t(len(data)), C.c_int(block_size), ob, C.c_size_t(cap), C.byref(n))
+    assert n.value <= cap
+    return st, ob.raw[:n.value]

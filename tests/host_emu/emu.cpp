@@ -5,6 +5,8 @@
 // linked into libswc_hip.so.
 #include <vector>
 #include <cstring>
+#include <algorithm>
+#include <memory>
 #include "../../swcompression_amd/csrc/inflate_lane.h"
 #include "../../swcompression_amd/csrc/inflate_sync.h"
 #include "../../swcompression_amd/csrc/lz4_lane.h"
@@ -14,6 +16,7 @@
 #include "../../swcompression_amd/csrc/lz_copy.h"
 #include "../../swcompression_amd/csrc/lzma_wave.h"
 #include "../../swcompression_amd/csrc/bzip2_block.h"
+#include "../../swcompression_amd/csrc/bzip2_comp.h"
 #include "../../swcompression_amd/csrc/crc32_group.h"
 
 extern "C" void emu_set_order(int o) { swc::simt::g_order = o; }
@@ -250,4 +253,59 @@ extern "C" void emu_delta(const uint8_t* in, uint8_t* out, size_t n, unsigned di
     constexpr int T = 256;
     static swc::delta::Lds<T> l;
     run_group<T>([&](int t) { swc::delta::delta_group<T>(in, out, n, distance, &l, t); return (uint64_t)0; });
+}
+
+// BZip2 compression (bzip2_comp.h): the executor of the emulation -- "device memory" is host memory, a kernel is a loop over
+// its elements / blocks, std::sort and two serial scans stand in for the three rocPRIM calls of the device executor.
+namespace {
+struct EmuBz2Exec {
+    std::vector<std::unique_ptr<uint8_t[]>> mem;
+    void begin_chunk() {}
+    void end_chunk() { mem.clear(); }
+    void* alloc(size_t n) { mem.emplace_back(new uint8_t[n + 64]); std::memset(mem.back().get(), 0xEE, n + 64); return mem.back().get(); }
+    void upload(void* d, const void* h, size_t n) { std::memcpy(d, h, n); }
+    void download(void* h, const void* d, size_t n) { std::memcpy(h, d, n); }
+    void zero(void* d, size_t n) { std::memset(d, 0, n); }
+    template <class F> void each(uint32_t m, const F& f) {
+        if (swc::simt::g_order == 1) for (uint32_t i = m; i-- > 0;) f(i);
+        else for (uint32_t i = 0; i < m; i++) f(i);
+    }
+    template <class F> void per_block(uint32_t nb, const F& f) {
+        for (uint32_t b = 0; b < nb; b++) {
+            alignas(16) static typename F::Lds lds;
+            std::memset(&lds, 0xEE, sizeof lds);
+            f.template run<64>(b, &lds);
+        }
+    }
+    int sort_pairs(uint64_t* kin, uint64_t* kout, uint32_t* vin, uint32_t* vout, uint32_t m, int bits) {
+        const uint64_t mask = bits >= 64 ? ~0ull : (1ull << bits) - 1ull;
+        std::vector<uint32_t> idx(m);
+        for (uint32_t i = 0; i < m; i++) { idx[i] = i; if (kin[i] & ~mask) return 1; }   // a key wider than announced: the radix sort would drop bits
+        std::stable_sort(idx.begin(), idx.end(), [&](uint32_t a, uint32_t b) { return kin[a] < kin[b]; });
+        for (uint32_t i = 0; i < m; i++) { kout[i] = kin[idx[i]]; vout[i] = vin[idx[i]]; }
+        return 0;
+    }
+    int scan_max(uint32_t* x, uint32_t m) { uint32_t a = 0; for (uint32_t i = 0; i < m; i++) { a = x[i] > a ? x[i] : a; x[i] = a; } return 0; }
+    int scan_sum(const uint32_t* in, uint32_t* out, uint32_t m) { uint32_t a = 0; for (uint32_t i = 0; i < m; i++) { out[i] = a; a += in[i]; } return 0; }
+    int block_crcs(const uint8_t* raw, const uint32_t* off, uint32_t nb, uint32_t* crcs) {
+        for (uint32_t b = 0; b < nb; b++) {   // CheckSums.bzip2crc32: polynomial 0x04C11DB7, MSB first
+            uint32_t c = 0xFFFFFFFFu;
+            for (uint32_t i = off[b]; i < off[b + 1]; i++) {
+                c ^= (uint32_t)raw[i] << 24;
+                for (int k = 0; k < 8; k++) c = (c & 0x80000000u) ? (c << 1) ^ 0x04C11DB7u : c << 1;
+            }
+            crcs[b] = ~c;
+        }
+        return 0;
+    }
+};
+}  // namespace
+// returns the status; *out_len = bytes needed (the stream is copied only if it fits `cap`)
+extern "C" int emu_bzip2_compress(const uint8_t* data, size_t len, int level, uint8_t* out, size_t cap, size_t* out_len) {
+    EmuBz2Exec x;
+    std::vector<uint8_t> res;
+    const int st = swc::bz2c::compress_stream(x, data, len, level, res);
+    *out_len = res.size();
+    if (st == 0 && res.size() <= cap) std::memcpy(out, res.data(), res.size());
+    return st;
 }

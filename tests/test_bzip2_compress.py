@@ -1,0 +1,172 @@
+"""BZip2.compress (reference Sources/BZip2/BZip2+Compress.swift:19-325, BurrowsWheeler.swift:8-29) on the device.
+
+The contract is that of the other encoders: A valid bzip2 stream for the same bytes with the reference's framing -- "BZh" and the
+level, blocks of level x 80,000 raw bytes (:46), per-block and combined CRC (:54-57, :67-71) -- not the reference encoder's
+bytes (it chooses among up to six Huffman tables per 50 symbols, :95-139; the engine builds one table per block from the block's
+own symbol counts and, as the reference does when it has a single table, writes it twice).  So parity is
+  * decode(compress(x)) == x under the REFERENCE decoder (the oracle's restatement of BZip2.swift:50-95, which must also consume
+    the whole stream), under libbz2 (Python's bz2) and -- GPU tier -- under the engine's own decoder;
+  * the framing: header, block count, the blocks' stored CRCs = CheckSums.bzip2crc32 of the raw blocks;
+  * a size near libbz2's at the same level (a stronger encoder than either: 100,000-byte blocks, up to six tables refined in
+    four passes): within 6 % on text, 12 % on data whose statistics change inside a block.
+CPU tier: the stages of csrc/bzip2_comp.h and their driver on the host emulation (std::sort in place of the device radix sort);
+GPU tier: the C ABI (swc_bzip2_compress)."""
+import bz2
+import os
+import random
+
+import pytest
+
+import _emu as E
+import _oracle as O
+from swcompression_amd import corpus
+
+BLOCK_MAGIC = 0x314159265359
+EOS_MAGIC = 0x177245385090
+
+
+def payloads():
+    rnd = random.Random(7)
+    runs = b"".join(bytes([rnd.randrange(4)]) * rnd.randrange(1, 600) for _ in range(400))
+    ps = [b"", b"a", b"ab", b"aaaa", b"aaaaa", b"a" * 255, b"a" * 256, b"a" * 258, b"a" * 259, b"a" * 260, b"a" * 510, b"a" * 1000 + b"b",
+          b"abc" * 5000, b"ab" * 40000, b"ab" * 40001, bytes(range(256)) * 40, bytes(reversed(range(256))) * 3 + b"xyz", bytes(170000),
+          b"banana", b"abracadabra", b"Hello, World!\n",                                   # BZip2CompressionTests.swift strings
+          corpus.p_rand(100000, 71), corpus.p_text(123457, 72), corpus.p_mix(200001, 73), runs,
+          corpus.p_text(80000, 74), corpus.p_text(80001, 75), corpus.p_text(79999, 76)]
+    for _ in range(10):
+        n = rnd.choice([1, 2, 3, 5, 6, 7, 8, 13, 63, 64, 65, 127, 128, 129, 1000])
+        ps.append(bytes(rnd.choice(b"abcd") for _ in range(n)))
+    return ps
+
+
+def bits_at(z, bit, count):
+    v = 0
+    for i in range(count):
+        p = bit + i
+        v = (v << 1) | ((z[p >> 3] >> (7 - (p & 7))) & 1)
+    return v
+
+
+def check_stream(x, z, level=1):
+    assert bz2.decompress(z) == x
+    st, y, cons = O.bzip2(z)
+    assert (st, y, cons) == (0, x, len(z)), (st, cons, len(z))
+    assert z[:4] == b"BZh" + bytes([0x30 + level])
+    raw = level * 80000
+    blocks = [x[i:i + raw] for i in range(0, len(x), raw)]
+    # the first block starts behind the header, its stored CRC is that of its raw bytes; the trailer carries the combination
+    total = 0
+    for b in blocks:
+        c = O.bzip2crc32(b)
+        total = (((total << 1) | (total >> 31)) & 0xFFFFFFFF) ^ c
+    if blocks:
+        assert bits_at(z, 32, 48) == BLOCK_MAGIC and bits_at(z, 80, 32) == O.bzip2crc32(blocks[0])
+    # the end-of-stream marker and the combined CRC are the last 80 bits before the padding (at most 7 bits)
+    found = False
+    for pad in range(8):
+        end = len(z) * 8 - pad
+        if end >= 112 and bits_at(z, end - 80, 48) == EOS_MAGIC and bits_at(z, end - 32, 32) == total:
+            found = all(bits_at(z, end + k, 1) == 0 for k in range(pad))
+            if found:
+                break
+    assert found
+
+
+@pytest.mark.parametrize("order", [0, 1, 2])
+def test_emulated_stages_round_trip(order):
+    E.set_order(order)
+    try:
+        for x in payloads():
+            st, z = E.bzip2_compress(x)
+            assert st == 0
+            check_stream(x, z)
+    finally:
+        E.set_order(0)
+
+
+def test_emulated_stages_do_not_depend_on_lane_order():
+    ps = [corpus.p_text(50000, 81), corpus.p_mix(30000, 82), b"abcabcabc" * 500, bytes(range(256)) * 9]
+    ref = [E.bzip2_compress(p)[1] for p in ps]
+    for order in (1, 2):
+        E.set_order(order)
+        try:
+            assert [E.bzip2_compress(p)[1] for p in ps] == ref
+        finally:
+            E.set_order(0)
+
+
+@pytest.mark.parametrize("level", [1, 2, 9])
+def test_block_sizes(level):
+    x = corpus.p_text(250000, 83) + corpus.p_mix(60000, 84)
+    st, z = E.bzip2_compress(x, level)
+    assert st == 0
+    check_stream(x, z, level)
+    n_blocks = sum(1 for bit in range(32, len(z) * 8 - 47) if bits_at(z, bit, 48) == BLOCK_MAGIC) if len(z) < 40000 else None
+    if n_blocks is not None:
+        assert n_blocks >= -(-len(x) // (level * 80000))
+
+
+def test_size_against_libbz2():
+    for x, limit in ((corpus.p_text(240000, 85), 1.06), (corpus.p_mix(240000, 86), 1.12), (corpus.p_rand(100000, 87), 1.01)):
+        ours = len(E.bzip2_compress(x)[1])
+        ref = len(bz2.compress(x, 1))
+        assert ours <= ref * limit, (ours, ref, ours / ref)
+
+
+def test_more_blocks_than_one_launch_takes():
+    """The driver cuts the stream into launches of 64 blocks; the bit stream continues across them at any bit offset."""
+    rnd = random.Random(9)
+    x = b"".join(bytes([rnd.randrange(3)]) * rnd.randrange(200, 4000) for _ in range(2600))   # > 64 blocks of 80,000, tiny after rle1
+    assert len(x) > 65 * 80000
+    st, z = E.bzip2_compress(x)
+    assert st == 0
+    check_stream(x, z)
+
+
+# ---------------------------------------------------------------------------------------------------------------------- GPU tier
+@pytest.mark.gpu
+def test_gpu_single_shot_round_trips():
+    import swcompression_amd as swc
+    for x in payloads():
+        z = swc.BZip2.compress(x)
+        check_stream(x, z)
+        assert swc.BZip2.decompress(z) == x
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("level", [1, 5, 9])
+def test_gpu_levels_and_own_decoder(level):
+    import swcompression_amd as swc
+    x = corpus.p_text(1500000, 91) + corpus.p_mix(700000, 92) + bytes(300000) + corpus.p_rand(200000, 93)
+    z = swc.BZip2.compress(x, block_size=level)
+    check_stream(x, z, level)
+    assert swc.BZip2.decompress(z) == x
+    assert len(z) <= len(bz2.compress(x, level)) * 1.10
+
+
+@pytest.mark.gpu
+def test_gpu_many_blocks_two_launches():
+    import swcompression_amd as swc
+    x = b"".join(corpus.p_text(80000, 300 + i) for i in range(70))          # 70 blocks at level 1: two launches (64 + 6)
+    z = swc.BZip2.compress(x)
+    assert bz2.decompress(z) == x
+    assert swc.BZip2.decompress(z) == x
+
+
+@pytest.mark.gpu
+def test_gpu_matches_the_emulated_stages():
+    """The device radix sort and scans against std::sort and the serial scans of the emulation: same stream, byte for byte."""
+    import swcompression_amd as swc
+    for x in (corpus.p_text(200000, 95), b"ab" * 50000, bytes(range(256)) * 100, corpus.p_mix(100000, 96)):
+        assert swc.BZip2.compress(x) == E.bzip2_compress(x)[1]
+
+
+@pytest.mark.gpu
+def test_gpu_rejects_block_sizes_outside_the_enum():
+    import ctypes as C
+    from swcompression_amd import _lib
+    lib = _lib.load()
+    out = C.POINTER(C.c_uint8)()
+    n = C.c_size_t()
+    for bad in (0, 10, -1):
+        assert lib.swc_bzip2_compress(b"abc", 3, bad, C.byref(out), C.byref(n)) == 903
