@@ -61,7 +61,7 @@ struct BlockInfo {
     uint32_t n_used;       // distinct bytes of the column
     uint32_t crc;          // bzip2 CRC-32 of the block's raw bytes
     uint32_t out_bits;     // bits of the block in its output area
-    uint32_t pad;
+    uint32_t head_bits;    // from the host: bits in front of the first symbol
     uint32_t used[8];      // bit b of word w: byte 32 w + b occurs
     uint32_t freq[kMaxSyms + 2];
     uint32_t code[kMaxSyms + 2];   // from the host: canonical code | length << 24
@@ -95,50 +95,129 @@ SWC_D void global_or(SWC_AS_GLOBAL uint32_t* p, uint32_t v) {
 SWC_HD uint32_t bswap32(uint32_t v) { return (v >> 24) | ((v >> 8) & 0xFF00u) | ((v << 8) & 0xFF0000u) | (v << 24); }
 
 // ================================================================================================================ rle1
-// BZip2+Compress.swift:243-262.  Returns the bytes written.
-template <int N>
-SWC_D uint32_t rle1_job(gcptr src, uint32_t n, gptr dst) {
-    using simt::PT;
-    uint32_t opos = 0, carry_q = 0, carry_b = 0x100;   // uncapped run position and value of the byte in front of the chunk
-    for (uint32_t base = 0; base < n; base += (uint32_t)N) {
-        PT<uint32_t, N> b, nb, prev, st, cnt, q, x;
-        SIMT_BEGIN(t, N)
-            const uint32_t i = base + (uint32_t)t;
-            b[t] = i < n ? src[i] : 0x200u;
-            nb[t] = i + 1u < n ? src[i + 1u] : 0x300u;
-        SIMT_END
-        simt::wave_shift_up<N>(prev, b, carry_b);
-        SIMT_BEGIN(t, N) st[t] = b[t] != prev[t] ? (uint32_t)t + 1u : 0u; SIMT_END
-        simt::wave_scan_max_incl<N>(st);
-        SIMT_BEGIN(t, N)
-            const uint32_t i = base + (uint32_t)t;
-            q[t] = st[t] ? (uint32_t)t - (st[t] - 1u) : carry_q + 1u + (uint32_t)t;   // my position in my run
-            const uint32_t p = q[t] % 255u;                                            // ... in its 255-byte sub-run
-            const bool ends = nb[t] != b[t] || p == 254u;
-            cnt[t] = i < n ? (p < 4u ? 1u : 0u) + (ends && p >= 3u ? 1u : 0u) : 0u;
-            x[t] = cnt[t];
-        SIMT_END
-        simt::wave_scan_incl<N>(x);
-        const uint32_t o0 = opos;
-        SIMT_BEGIN(t, N)
-            const uint32_t p = q[t] % 255u;
-            uint32_t o = o0 + x[t] - cnt[t];
-            if (cnt[t] != 0u && p < 4u) dst[o++] = (uint8_t)b[t];
-            if (cnt[t] != 0u && (nb[t] != b[t] || p == 254u) && p >= 3u) dst[o] = (uint8_t)(p - 3u);
-        SIMT_END
-        opos += simt::wave_read<N>(x, N - 1);
-        const uint32_t last = n - base < (uint32_t)N ? n - base - 1u : (uint32_t)N - 1u;
-        carry_q = simt::wave_read<N>(q, (int)last);
-        carry_b = simt::wave_read<N>(b, (int)last);
-    }
-    return opos;
+// BZip2+Compress.swift:243-262 over ALL blocks of a launch, one thread per input byte, three steps around two device scans:
+//   flags    a byte that differs from its predecessor (or is the first of its block) starts a run: start[i] = i + 1, else 0;
+//            (the maximum scan turns that into "first byte of my run + 1" for every byte)
+//   counts   with q = my position in my run and p = q % 255 (runs are cut into pieces of 255): I write the byte itself when
+//            p < 4, and a count behind me when I am the last of a piece of four and more;
+//            (the sum scan turns the counts into places: the blocks end up one behind the other, ready for the sort)
+//   write    ... and the first byte of a block leaves the block's offset.
+struct Rle1 {
+    const SWC_AS_GLOBAL uint8_t* raw;
+    uint32_t n, raw_block, nb;
+    SWC_AS_GLOBAL uint32_t* start;
+    SWC_AS_GLOBAL uint32_t* cnt;
+    SWC_AS_GLOBAL uint32_t* pos;
+    SWC_AS_GLOBAL uint8_t* text;
+    SWC_AS_GLOBAL uint8_t* blk;
+    SWC_AS_GLOBAL uint32_t* off;
+};
+struct Rle1Flags {
+    Rle1 c;
+    SWC_HD void operator()(uint32_t i) const { c.start[i] = i % c.raw_block == 0u || c.raw[i] != c.raw[i - 1u] ? i + 1u : 0u; }
+};
+SWC_HD bool rle1_piece_ends(const Rle1& c, uint32_t i, uint32_t p) {
+    return p == 254u || i + 1u == c.n || (i + 1u) % c.raw_block == 0u || c.raw[i + 1u] != c.raw[i];
 }
+struct Rle1Counts {
+    Rle1 c;
+    SWC_HD void operator()(uint32_t i) const {
+        const uint32_t p = (i + 1u - c.start[i]) % 255u;
+        c.cnt[i] = (p < 4u ? 1u : 0u) + (p >= 3u && rle1_piece_ends(c, i, p) ? 1u : 0u);
+    }
+};
+struct Rle1Write {
+    Rle1 c;
+    SWC_HD void operator()(uint32_t i) const {
+        const uint32_t p = (i + 1u - c.start[i]) % 255u, b = i / c.raw_block;
+        uint32_t o = c.pos[i];
+        if (i % c.raw_block == 0u) c.off[b] = o;
+        if (i + 1u == c.n) c.off[c.nb] = o + c.cnt[i];
+        if (p < 4u) { c.text[o] = c.raw[i]; c.blk[o] = (uint8_t)b; o++; }
+        if (p >= 3u && rle1_piece_ends(c, i, p)) { c.text[o] = (uint8_t)(p - 3u); c.blk[o] = (uint8_t)b; }
+    }
+};
 
 // ================================================================================================================ mtf
+// BZip2+Compress.swift:277-325, a block's column cut into SEGMENTS of kSeg bytes that are coded by a wavefront each:
+//   * the list in front of a segment is known without coding what precedes it: the bytes seen so far in order of their LAST
+//     occurrence, then the bytes not seen yet in ascending order.  seg_last (a wavefront per segment) notes the last position
+//     of every byte value inside the segment, seg_before (a thread per block and byte value) turns that into "last position
+//     before the segment" by a running maximum over the block's segments -- and into the set of bytes the block uses;
+//   * a zero run must not be cut: a segment BEGINS at the first byte at or behind its nominal start that differs from its
+//     predecessor and ends where the next one begins, so runs lie inside segments and a segment's symbols depend on nothing else;
+//   * inside a segment: a byte equal to its predecessor IS a zero, so a ballot per 64 bytes finds the positions that change the
+//     list and only those are walked; the list's first 64 positions live one per lane in a register (finding a byte is a
+//     compare and a ballot, moving it to the front one DPP shift), positions 64..255 in three more registers that are touched only
+//     when the byte is found that deep.
+// Symbols go to the segment's own area (kSegSyms entries), their number to seg_nsym, their frequencies to the block's record.
+constexpr uint32_t kSeg = 4096;
+constexpr uint32_t kSegSyms = kSeg + 64;     // the changes of the segment, the digits of the runs between them, of one long run behind, end of block
+
+struct Segs {
+    const SWC_AS_GLOBAL uint8_t* col;         // the last column, block after block
+    const SWC_AS_GLOBAL uint32_t* off;        // first position of every block
+    const SWC_AS_GLOBAL uint32_t* seg_off;    // first segment of every block, n_blocks + 1
+    const SWC_AS_GLOBAL uint32_t* seg_blk;    // block of every segment
+    SWC_AS_GLOBAL uint32_t* last;             // [segment][256]: last position + 1 of the byte value inside the segment, 0 = none
+    SWC_AS_GLOBAL uint32_t* before;           // [segment][256]: ... anywhere in front of the segment
+    SWC_AS_GLOBAL uint8_t* used;              // [block][256]
+    SWC_AS_GLOBAL uint16_t* syms;             // [segment][kSegSyms]
+    SWC_AS_GLOBAL uint32_t* seg_nsym;
+    SWC_AS_GLOBAL uint32_t* seg_bits;         // bits of the segment's symbols
+    SWC_AS_GLOBAL uint32_t* seg_at;           // ... and where they start in the block's bit stream
+    SWC_AS_GLOBAL uint8_t* stream;            // the bits of all blocks of the launch, one behind the other (zeroed)
+    SWC_AS_GLOBAL uint32_t* blk_at;           // bit every block starts at in it, n_blocks + 1
+    SWC_AS_GLOBAL BlockInfo* infos;
+    uint32_t nb, stream_cap, lead;            // lead: the first block starts at this bit (the stream so far ends inside a dword)
+};
+SWC_D void lds_max(uint32_t* p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_fetch_max(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+#else
+    if (v > *p) *p = v;
+#endif
+}
+SWC_D void global_add(SWC_AS_GLOBAL uint32_t* p, uint32_t v) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+    *p += v;
+#endif
+}
+struct NoLds { uint32_t unused; };
+struct SegLastLds { uint32_t tab[256]; };
+struct SegLast {       // a wavefront per segment
+    Segs c;
+    typedef SegLastLds Lds;
+    template <int N> SWC_D void run(uint32_t s, Lds* lds) const {
+        const uint32_t b = c.seg_blk[s], base = c.off[b], n = c.off[b + 1u] - base;
+        const uint32_t lo = (s - c.seg_off[b]) * kSeg, hi = lo + kSeg < n ? lo + kSeg : n;
+        SIMT_BEGIN(t, N) for (uint32_t i = (uint32_t)t; i < 256u; i += (uint32_t)N) lds->tab[i] = 0u; SIMT_END_WAVE
+        SIMT_BEGIN(t, N)
+            for (uint32_t i = lo + (uint32_t)t; i < hi; i += (uint32_t)N) lds_max(&lds->tab[c.col[base + i]], i + 1u);
+        SIMT_END_WAVE
+        SIMT_BEGIN(t, N) for (uint32_t i = (uint32_t)t; i < 256u; i += (uint32_t)N) c.last[256u * s + i] = lds->tab[i]; SIMT_END
+    }
+};
+struct SegBefore {     // a thread per (block, byte value)
+    Segs c;
+    SWC_HD void operator()(uint32_t i) const {
+        const uint32_t b = i >> 8, v = i & 255u;
+        uint32_t run = 0;
+        for (uint32_t s = c.seg_off[b]; s < c.seg_off[b + 1u]; s++) {
+            const uint32_t l = c.last[256u * s + v];
+            c.before[256u * s + v] = run;
+            run = l > run ? l : run;
+        }
+        c.used[i] = run != 0u ? 1 : 0;
+    }
+};
+
 struct MtfLds {
     uint32_t freq[kMaxSyms + 6];
     uint32_t list[256];
-    uint8_t present[256];
+    uint32_t key[256];
 };
 template <int N>
 struct MtfOut {
@@ -167,125 +246,171 @@ struct MtfOut {
         }
     }
 };
-// L (n >= 1 bytes) -> symbols; fills info.used / n_used / freq / n_sym
+// first position >= from (< n) whose byte differs from the one before it; n if there is none
 template <int N>
-SWC_D void mtf_job(gcptr L, uint32_t n, SWC_AS_GLOBAL uint16_t* syms, MtfLds* lds, SWC_AS_GLOBAL BlockInfo* info) {
-    using simt::PT;
-    static_assert(N == 64, "one list position per lane, four registers");
-    SIMT_BEGIN(t, N)
-        for (uint32_t i = (uint32_t)t; i < kMaxSyms + 6u; i += (uint32_t)N) lds->freq[i] = 0u;
-        for (uint32_t i = (uint32_t)t; i < 256u; i += (uint32_t)N) { lds->present[i] = 0; lds->list[i] = 0x1FFu; }
-    SIMT_END_WAVE
-    SIMT_BEGIN(t, N)
-        for (uint32_t i = (uint32_t)t; i < n; i += (uint32_t)N) lds->present[L[i]] = 1;
-    SIMT_END_WAVE
-    // the bytes that occur, in order, are the list (:279-283)
-    uint32_t used[8];
-    for (uint32_t r = 0; r < 4u; r++) {
-        PT<bool, N> pr;
-        SIMT_BEGIN(t, N) pr[t] = lds->present[64u * r + (uint32_t)t] != 0; SIMT_END
-        const uint64_t m = simt::wave_ballot<N>(pr);
-        used[2u * r] = (uint32_t)m;
-        used[2u * r + 1u] = (uint32_t)(m >> 32);
+SWC_D uint32_t next_change(gcptr L, uint32_t from, uint32_t n) {
+    for (uint32_t base = from; base < n; base += (uint32_t)N) {
+        simt::PT<bool, N> ch;
+        SIMT_BEGIN(t, N)
+            const uint32_t i = base + (uint32_t)t;
+            ch[t] = i < n && i > 0u && L[i] != L[i - 1u];
+        SIMT_END
+        const uint64_t m = simt::wave_ballot<N>(ch);
+        if (m != 0ull) return base + (uint32_t)simt::ctz64(m);
     }
-    uint32_t n_used = 0, below[8];
-    for (uint32_t w = 0; w < 8u; w++) { below[w] = n_used; n_used += (uint32_t)simt::popc32(used[w]); }
-    SIMT_BEGIN(t, N)
+    return n;
+}
+struct MtfSeg {        // a wavefront per segment
+    Segs c;
+    typedef MtfLds Lds;
+    template <int N> SWC_D void run(uint32_t s, Lds* lds) const {
+        using simt::PT;
+        static_assert(N == 64, "one list position per lane, four registers");
+        const uint32_t b = c.seg_blk[s], cbase = c.off[b], n = c.off[b + 1u] - cbase;
+        const uint32_t ls = s - c.seg_off[b], nseg = c.seg_off[b + 1u] - c.seg_off[b];
+        gcptr L = c.col + cbase;
+        SWC_AS_GLOBAL BlockInfo* info = c.infos + b;
+        // ---- the list in front of the segment (:279-283 for the first one)
+        SIMT_BEGIN(t, N)
+            for (uint32_t i = (uint32_t)t; i < kMaxSyms + 6u; i += (uint32_t)N) lds->freq[i] = 0u;
+            for (uint32_t v = (uint32_t)t; v < 256u; v += (uint32_t)N) {
+                lds->list[v] = 0x1FFu;
+                // seen: by last position, descending; then not seen yet: by value, ascending; bytes the block does not use: no place
+                lds->key[v] = c.used[256u * b + v] ? ((c.before[256u * s + v] << 8) | (255u - v)) + 1u : 0u;
+            }
+        SIMT_END_WAVE
+        uint32_t used[8];
         for (uint32_t r = 0; r < 4u; r++) {
-            const uint32_t v = 64u * r + (uint32_t)t, w = v >> 5, bit = v & 31u;
-            uint32_t uw = 0, bw = 0;     // (a select chain, not used[w]: the words live in scalar registers)
-            for (uint32_t k = 0; k < 8u; k++) { uw = w == k ? used[k] : uw; bw = w == k ? below[k] : bw; }
-            if ((uw >> bit) & 1u) lds->list[bw + (uint32_t)simt::popc32(uw & ((1u << bit) - 1u))] = v;
+            PT<bool, N> pr;
+            SIMT_BEGIN(t, N) pr[t] = lds->key[64u * r + (uint32_t)t] != 0u; SIMT_END
+            const uint64_t m = simt::wave_ballot<N>(pr);
+            used[2u * r] = (uint32_t)m;
+            used[2u * r + 1u] = (uint32_t)(m >> 32);
         }
-        if (t < 8) {
-            uint32_t uw = 0;
-            for (uint32_t k = 0; k < 8u; k++) uw = (uint32_t)t == k ? used[k] : uw;
-            info->used[t] = uw;
-        }
-    SIMT_END_WAVE
-    PT<uint32_t, N> l0, l1, l2, l3;
-    SIMT_BEGIN(t, N)
-        l0[t] = lds->list[t]; l1[t] = lds->list[64 + t]; l2[t] = lds->list[128 + t]; l3[t] = lds->list[192 + t];
-    SIMT_END
-    MtfOut<N> m;
-    m.l = lds; m.out = syms; m.nsym = 0; m.nstage = 0;
-    SIMT_BEGIN(t, N) m.stage[t] = 0u; SIMT_END
-    uint32_t run = 0;
-    uint32_t carry_b = simt::wave_read<N>(l0, 0);             // the front of the list: a byte equal to it is a zero (:286-288)
-    for (uint32_t base = 0; base < n; base += (uint32_t)N) {
-        PT<uint32_t, N> chunk, prev;
-        PT<bool, N> ch;
-        SIMT_BEGIN(t, N) chunk[t] = base + (uint32_t)t < n ? L[base + (uint32_t)t] : 0x200u; SIMT_END
-        simt::wave_shift_up<N>(prev, chunk, carry_b);
-        const uint32_t k1 = n - base < (uint32_t)N ? n - base : (uint32_t)N;
-        SIMT_BEGIN(t, N) ch[t] = (uint32_t)t < k1 && chunk[t] != prev[t]; SIMT_END
-        uint64_t cm = simt::wave_ballot<N>(ch);
-        uint32_t pos = 0;
-        while (cm != 0ull) {
-            const uint32_t k = (uint32_t)simt::ctz64(cm);
-            cm &= cm - 1ull;
-            run += k - pos;
-            pos = k + 1u;
-            const uint32_t b = simt::wave_read<N>(chunk, (int)k);
-            m.put_run(run);
-            run = 0;
-            // where is it?  (never at the front: that is the byte before it)
-            PT<bool, N> e;
-            SIMT_BEGIN(t, N) e[t] = l0[t] == b; SIMT_END
-            uint64_t bal = simt::wave_ballot<N>(e);
-            if (bal != 0ull) {
-                const uint32_t li = (uint32_t)simt::ctz64(bal);
-                m.put(li + 1u);                                               // :309-315
-                PT<uint32_t, N> s0;
-                simt::wave_shift_up_dpp<N>(s0, l0, b);
-                SIMT_BEGIN(t, N) l0[t] = (uint32_t)t <= li ? s0[t] : l0[t]; SIMT_END
-                continue;
-            }
-            uint32_t idx;
-            SIMT_BEGIN(t, N) e[t] = l1[t] == b; SIMT_END
-            bal = simt::wave_ballot<N>(e);
-            if (bal != 0ull) idx = 64u + (uint32_t)simt::ctz64(bal);
-            else {
-                SIMT_BEGIN(t, N) e[t] = l2[t] == b; SIMT_END
-                bal = simt::wave_ballot<N>(e);
-                if (bal != 0ull) idx = 128u + (uint32_t)simt::ctz64(bal);
-                else {
-                    SIMT_BEGIN(t, N) e[t] = l3[t] == b; SIMT_END
-                    bal = simt::wave_ballot<N>(e);
-                    idx = 192u + (uint32_t)simt::ctz64(bal | (1ull << 63));
-                }
-            }
-            m.put(idx + 1u);
-            // move to the front: the positions below idx move up by one
-            const uint32_t r = idx >> 6, li = idx & 63u;
-            const uint32_t e0 = simt::wave_read<N>(l0, N - 1), e1 = simt::wave_read<N>(l1, N - 1), e2 = simt::wave_read<N>(l2, N - 1);
-            PT<uint32_t, N> s0, s1, s2, s3;
-            simt::wave_shift_up_dpp<N>(s0, l0, b);
-            simt::wave_shift_up_dpp<N>(s1, l1, e0);
-            simt::wave_shift_up_dpp<N>(s2, l2, e1);
-            simt::wave_shift_up_dpp<N>(s3, l3, e2);
+        uint32_t n_used = 0;
+        for (uint32_t w = 0; w < 8u; w++) n_used += (uint32_t)simt::popc32(used[w]);
+        {
+            PT<uint32_t, N> k0, k1, k2, k3, r0, r1, r2, r3;
             SIMT_BEGIN(t, N)
-                const uint32_t tt = (uint32_t)t;
-                l0[t] = s0[t];
-                l1[t] = r > 1u || tt <= li ? s1[t] : l1[t];
-                l2[t] = r > 2u || (r == 2u && tt <= li) ? s2[t] : l2[t];
-                l3[t] = r == 3u && tt <= li ? s3[t] : l3[t];
+                k0[t] = lds->key[t]; k1[t] = lds->key[64 + t]; k2[t] = lds->key[128 + t]; k3[t] = lds->key[192 + t];
+                r0[t] = 0u; r1[t] = 0u; r2[t] = 0u; r3[t] = 0u;
+            SIMT_END
+            for (uint32_t d = 0; d < 256u; d++) {
+                SIMT_BEGIN(t, N)
+                    const uint32_t kd = lds->key[d];
+                    r0[t] += kd > k0[t] ? 1u : 0u; r1[t] += kd > k1[t] ? 1u : 0u; r2[t] += kd > k2[t] ? 1u : 0u; r3[t] += kd > k3[t] ? 1u : 0u;
+                SIMT_END
+            }
+            SIMT_BEGIN(t, N)
+                if (k0[t]) lds->list[r0[t]] = (uint32_t)t;
+                if (k1[t]) lds->list[r1[t]] = 64u + (uint32_t)t;
+                if (k2[t]) lds->list[r2[t]] = 128u + (uint32_t)t;
+                if (k3[t]) lds->list[r3[t]] = 192u + (uint32_t)t;
+            SIMT_END_WAVE
+        }
+        if (ls == 0u) {
+            SIMT_BEGIN(t, N)
+                if (t < 8) {
+                    uint32_t uw = 0;
+                    for (uint32_t k = 0; k < 8u; k++) uw = (uint32_t)t == k ? used[k] : uw;
+                    info->used[t] = uw;
+                }
+                if (t == 0) info->n_used = n_used;
             SIMT_END
         }
-        run += k1 - pos;
-        carry_b = simt::wave_read<N>(chunk, (int)(k1 - 1u));
+        PT<uint32_t, N> l0, l1, l2, l3;
+        SIMT_BEGIN(t, N)
+            l0[t] = lds->list[t]; l1[t] = lds->list[64 + t]; l2[t] = lds->list[128 + t]; l3[t] = lds->list[192 + t];
+        SIMT_END
+        // ---- my part of the column
+        const uint32_t start = ls == 0u ? 0u : next_change<N>(L, ls * kSeg, n);
+        const uint32_t end = ls + 1u == nseg ? n : next_change<N>(L, (ls + 1u) * kSeg, n);
+        MtfOut<N> m;
+        m.l = lds; m.out = c.syms + (size_t)kSegSyms * s; m.nsym = 0; m.nstage = 0;
+        SIMT_BEGIN(t, N) m.stage[t] = 0u; SIMT_END
+        uint32_t run = 0;
+        uint32_t carry_b = simt::wave_read<N>(l0, 0);             // the front of the list: a byte equal to it is a zero (:286-288)
+        for (uint32_t base = start; base < end; base += (uint32_t)N) {
+            PT<uint32_t, N> chunk, prev;
+            PT<bool, N> ch;
+            SIMT_BEGIN(t, N) chunk[t] = base + (uint32_t)t < end ? L[base + (uint32_t)t] : 0x200u; SIMT_END
+            simt::wave_shift_up<N>(prev, chunk, carry_b);
+            const uint32_t k1 = end - base < (uint32_t)N ? end - base : (uint32_t)N;
+            SIMT_BEGIN(t, N) ch[t] = (uint32_t)t < k1 && chunk[t] != prev[t]; SIMT_END
+            uint64_t cm = simt::wave_ballot<N>(ch);
+            uint32_t pos = 0;
+            while (cm != 0ull) {
+                const uint32_t k = (uint32_t)simt::ctz64(cm);
+                cm &= cm - 1ull;
+                run += k - pos;
+                pos = k + 1u;
+                const uint32_t v = simt::wave_read<N>(chunk, (int)k);
+                m.put_run(run);
+                run = 0;
+                // where is it?  (never at the front: that is the byte before it)
+                PT<bool, N> e;
+                SIMT_BEGIN(t, N) e[t] = l0[t] == v; SIMT_END
+                uint64_t bal = simt::wave_ballot<N>(e);
+                if (bal != 0ull) {
+                    const uint32_t li = (uint32_t)simt::ctz64(bal);
+                    m.put(li + 1u);                                               // :309-315
+                    PT<uint32_t, N> s0;
+                    simt::wave_shift_up_dpp<N>(s0, l0, v);
+                    SIMT_BEGIN(t, N) l0[t] = (uint32_t)t <= li ? s0[t] : l0[t]; SIMT_END
+                    continue;
+                }
+                uint32_t idx;
+                SIMT_BEGIN(t, N) e[t] = l1[t] == v; SIMT_END
+                bal = simt::wave_ballot<N>(e);
+                if (bal != 0ull) idx = 64u + (uint32_t)simt::ctz64(bal);
+                else {
+                    SIMT_BEGIN(t, N) e[t] = l2[t] == v; SIMT_END
+                    bal = simt::wave_ballot<N>(e);
+                    if (bal != 0ull) idx = 128u + (uint32_t)simt::ctz64(bal);
+                    else {
+                        SIMT_BEGIN(t, N) e[t] = l3[t] == v; SIMT_END
+                        bal = simt::wave_ballot<N>(e);
+                        idx = 192u + (uint32_t)simt::ctz64(bal | (1ull << 63));
+                    }
+                }
+                m.put(idx + 1u);
+                // move to the front: the positions below idx move up by one
+                const uint32_t r = idx >> 6, li = idx & 63u;
+                const uint32_t e0 = simt::wave_read<N>(l0, N - 1), e1 = simt::wave_read<N>(l1, N - 1), e2 = simt::wave_read<N>(l2, N - 1);
+                PT<uint32_t, N> s0, s1, s2, s3;
+                simt::wave_shift_up_dpp<N>(s0, l0, v);
+                simt::wave_shift_up_dpp<N>(s1, l1, e0);
+                simt::wave_shift_up_dpp<N>(s2, l2, e1);
+                simt::wave_shift_up_dpp<N>(s3, l3, e2);
+                SIMT_BEGIN(t, N)
+                    const uint32_t tt = (uint32_t)t;
+                    l0[t] = s0[t];
+                    l1[t] = r > 1u || tt <= li ? s1[t] : l1[t];
+                    l2[t] = r > 2u || (r == 2u && tt <= li) ? s2[t] : l2[t];
+                    l3[t] = r == 3u && tt <= li ? s3[t] : l3[t];
+                SIMT_END
+            }
+            run += k1 - pos;
+            carry_b = simt::wave_read<N>(chunk, (int)(k1 - 1u));
+        }
+        m.put_run(run);
+        if (ls + 1u == nseg) m.put(n_used + 1u);                          // the end-of-block symbol (:322-323)
+        if (m.nstage) m.flush();
+        const uint32_t nsym = m.nsym;
+        SIMT_BEGIN(t, N)
+            for (uint32_t i = (uint32_t)t; i < kMaxSyms + 2u; i += (uint32_t)N) if (lds->freq[i]) global_add(&info->freq[i], lds->freq[i]);
+            if (t == 0) { c.seg_nsym[s] = nsym; global_add(&info->n_sym, nsym); }
+        SIMT_END_WAVE
     }
-    m.put_run(run);
-    m.put(n_used + 1u);                                                   // the end-of-block symbol (:322-323)
-    if (m.nstage) m.flush();
-    const uint32_t nsym = m.nsym;
-    SIMT_BEGIN(t, N)
-        for (uint32_t i = (uint32_t)t; i < kMaxSyms + 2u; i += (uint32_t)N) info->freq[i] = lds->freq[i];
-        if (t == 0) { info->n_sym = nsym; info->n_used = n_used; }
-    SIMT_END_WAVE
-}
+};
 
 // ================================================================================================================ emit
+// BZip2+Compress.swift:149-240, a wavefront per SEGMENT again: the host has turned the block's symbol counts into code lengths
+// and knows how long the block's header is; seg_bits (a wavefront per segment) adds up the code lengths of a segment's symbols,
+// seg_scan (a wavefront per block) turns that into the bit every segment starts at, and emit_seg writes a segment's codes --
+// the first segment of a block the header in front of them -- 64 symbols per step: a wave scan of the code lengths for the
+// places, ds_or_b32 into a staging area of the MSB-first bit stream in LDS, byte-swapped dwords to HBM, the dwords a segment
+// shares with its neighbours by atomic OR (the areas are zeroed).
 struct EmitLds {
     uint32_t stage[kStageDw + 4];
     uint32_t code[kMaxSyms + 6];
@@ -295,16 +420,22 @@ struct Emitter {
     EmitLds* l;
     gptr out;          // 16-byte aligned, `cap` a multiple of four
     uint32_t cap;
-    uint32_t obits, odw, fill;
+    uint32_t obits, odw, fill, first_dw;
 
+    SWC_D void begin(EmitLds* lds, gptr o, uint32_t c, uint32_t at) {
+        l = lds; out = o; cap = c; obits = 0; odw = at >> 5; fill = at & 31u; first_dw = at >> 5;
+    }
     SWC_D void flush(bool all) {
         const uint32_t nd = all ? (fill + 31u) >> 5 : fill >> 5;
-        const uint32_t o0 = odw;
+        const uint32_t o0 = odw, f = first_dw;
         simt::PT<uint32_t, N> carry;
         SIMT_BEGIN(t, N)
             for (uint32_t i = (uint32_t)t; i < nd; i += (uint32_t)N) {
                 const uint32_t b = 4u * (o0 + i);
-                if (b + 4u <= cap) *(SWC_AS_GLOBAL uint32_t*)(out + b) = bswap32(l->stage[i]);   // the stream's first bit is the top bit of byte 0
+                const uint32_t v = bswap32(l->stage[i]);        // the stream's first bit is the top bit of byte 0
+                if (b + 4u > cap) continue;
+                if (o0 + i == f || (all && i + 1u == nd)) global_or((SWC_AS_GLOBAL uint32_t*)(out + b), v);   // shared with a neighbour
+                else *(SWC_AS_GLOBAL uint32_t*)(out + b) = v;
             }
             carry[t] = l->stage[nd];
         SIMT_END_WAVE
@@ -349,17 +480,26 @@ struct Emitter {
         }
     }
 };
-// The block from its magic to its last symbol.  info.code[] = canonical code | length << 24 of every symbol 0 .. n_used + 1.
+// bits of the delta form of the code lengths of one table (:196-221)
+SWC_HD uint32_t table_bits(const uint32_t* code, uint32_t alpha) {
+    uint32_t bits = 5;
+    for (uint32_t s = 0; s < alpha; s++) {
+        const uint32_t len = code[s] >> 24, prev = s ? code[s - 1u] >> 24 : len;
+        bits += 2u * (len > prev ? len - prev : prev - len) + 1u;
+    }
+    return bits;
+}
+// bits of a block in front of its first symbol
+SWC_HD uint32_t header_bits(const BlockInfo& info) {
+    uint32_t ranges = 0;
+    for (uint32_t r = 0; r < 16u; r++) if ((info.used[r >> 1] >> (16u * (r & 1u))) & 0xFFFFu) ranges++;
+    return 48u + 32u + 1u + 24u + 16u + 16u * ranges + 3u + 15u + (info.n_sym + 49u) / 50u + 2u * table_bits(info.code, info.n_used + 2u);
+}
+// The block from its magic to the last bit in front of its first symbol.  lds->code[] = canonical code | length << 24 of every symbol.
 template <int N>
-SWC_D void emit_job(const SWC_AS_GLOBAL uint16_t* syms, EmitLds* lds, SWC_AS_GLOBAL BlockInfo* info, gptr out, uint32_t cap) {
+SWC_D void emit_header(Emitter<N>& e, EmitLds* lds, const SWC_AS_GLOBAL BlockInfo* info) {
     using simt::PT;
-    Emitter<N> e;
-    e.l = lds; e.out = out; e.cap = cap; e.obits = 0; e.odw = 0; e.fill = 0;
     const uint32_t alpha = info->n_used + 2u;
-    SIMT_BEGIN(t, N)
-        for (uint32_t i = (uint32_t)t; i < kStageDw + 4u; i += (uint32_t)N) lds->stage[i] = 0u;
-        for (uint32_t i = (uint32_t)t; i < kMaxSyms + 6u; i += (uint32_t)N) lds->code[i] = i < alpha ? info->code[i] : 0u;
-    SIMT_END_WAVE
     PT<uint32_t, N> code, nb;
     // magic (48), block CRC (32), randomised = 0 (1), origin pointer (24), the 16 bits of the used ranges (:149-166)
     uint32_t ranges = 0;
@@ -391,8 +531,7 @@ SWC_D void emit_job(const SWC_AS_GLOBAL uint16_t* syms, EmitLds* lds, SWC_AS_GLO
     SIMT_END
     e.emit(code, nb);
     // two tables, the selectors (:180-194): one per 50 symbols, all of them table 0 = a zero bit each after move-to-front
-    const uint32_t nsym = info->n_sym;
-    const uint32_t nsel = (nsym + 49u) / 50u;
+    const uint32_t nsel = (info->n_sym + 49u) / 50u;
     SIMT_BEGIN(t, N)
         code[t] = t == 0 ? 2u : t == 1 ? nsel : 0u;
         nb[t] = t == 0 ? 3u : t == 1 ? 15u : 0u;
@@ -427,43 +566,94 @@ SWC_D void emit_job(const SWC_AS_GLOBAL uint16_t* syms, EmitLds* lds, SWC_AS_GLO
             e.emit(code, nb);
         }
     }
-    // the symbols (:223-240)
-    for (uint32_t base = 0; base < nsym; base += (uint32_t)N) {
-        SIMT_BEGIN(t, N)
-            uint32_t c = 0, n = 0;
-            if (base + (uint32_t)t < nsym) {
-                const uint32_t w = lds->code[syms[base + (uint32_t)t]];
-                c = w & 0xFFFFFFu; n = w >> 24;
-            }
-            code[t] = c; nb[t] = n;
-        SIMT_END
-        e.emit(code, nb);
-    }
-    const uint32_t bits = e.obits;
-    e.flush(true);
-    SIMT_BEGIN(t, N) if (t == 0) info->out_bits = bits; SIMT_END_WAVE
 }
-
-// ================================================================================================================ join
-// `bits` bits at src (big-endian dwords, 4-byte aligned) to bit offset `at` of dst (zeroed, 4-byte aligned)
 template <int N>
-SWC_D void join_job(gcptr src, uint32_t bits, gptr dst, uint64_t at) {
-    const uint32_t nd = (bits + 31u) >> 5, sh = (uint32_t)(at & 31u);
-    SWC_AS_GLOBAL uint32_t* d32 = (SWC_AS_GLOBAL uint32_t*)dst + (at >> 5);
-    const SWC_AS_GLOBAL uint32_t* s32 = (const SWC_AS_GLOBAL uint32_t*)src;
+SWC_D void load_codes(EmitLds* lds, const SWC_AS_GLOBAL BlockInfo* info) {
+    const uint32_t alpha = info->n_used + 2u;
     SIMT_BEGIN(t, N)
-        for (uint32_t i = (uint32_t)t; i < nd; i += (uint32_t)N) {
-            uint32_t v = bswap32(s32[i]);
-            if (i == nd - 1u && (bits & 31u)) v &= ~(0xFFFFFFFFu >> (bits & 31u));      // nothing behind the last bit
-            if (sh == 0u) global_or(d32 + i, bswap32(v));
-            else {
-                global_or(d32 + i, bswap32(v >> sh));
-                const uint32_t lo = v << (32u - sh);
-                if (lo) global_or(d32 + i + 1u, bswap32(lo));
-            }
-        }
-    SIMT_END
+        for (uint32_t i = (uint32_t)t; i < kStageDw + 4u; i += (uint32_t)N) lds->stage[i] = 0u;
+        for (uint32_t i = (uint32_t)t; i < kMaxSyms + 6u; i += (uint32_t)N) lds->code[i] = i < alpha ? info->code[i] : 0u;
+    SIMT_END_WAVE
 }
+struct SegBits {       // a wavefront per segment
+    Segs c;
+    typedef EmitLds Lds;
+    template <int N> SWC_D void run(uint32_t s, Lds* lds) const {
+        load_codes<N>(lds, c.infos + c.seg_blk[s]);
+        const uint32_t ns = c.seg_nsym[s];
+        const SWC_AS_GLOBAL uint16_t* sy = c.syms + (size_t)kSegSyms * s;
+        simt::PT<uint32_t, N> x;
+        SIMT_BEGIN(t, N)
+            uint32_t a = 0;
+            for (uint32_t i = (uint32_t)t; i < ns; i += (uint32_t)N) a += lds->code[sy[i]] >> 24;
+            x[t] = a;
+        SIMT_END
+        simt::wave_scan_incl<N>(x);
+        const uint32_t total = simt::wave_read<N>(x, N - 1);
+        SIMT_BEGIN(t, N) if (t == 0) c.seg_bits[s] = total; SIMT_END
+    }
+};
+struct SegScan {       // a wavefront per block
+    Segs c;
+    typedef NoLds Lds;
+    template <int N> SWC_D void run(uint32_t b, Lds*) const {
+        uint32_t at = c.infos[b].head_bits;
+        const uint32_t s1 = c.seg_off[b + 1u];
+        for (uint32_t s0 = c.seg_off[b]; s0 < s1; s0 += (uint32_t)N) {
+            simt::PT<uint32_t, N> x, own;
+            SIMT_BEGIN(t, N) own[t] = s0 + (uint32_t)t < s1 ? c.seg_bits[s0 + (uint32_t)t] : 0u; x[t] = own[t]; SIMT_END
+            simt::wave_scan_incl<N>(x);
+            SIMT_BEGIN(t, N) if (s0 + (uint32_t)t < s1) c.seg_at[s0 + (uint32_t)t] = at + x[t] - own[t]; SIMT_END
+            at += simt::wave_read<N>(x, N - 1);
+        }
+        const uint32_t bits = at;
+        SIMT_BEGIN(t, N) if (t == 0) c.infos[b].out_bits = bits; SIMT_END
+    }
+};
+struct BlockScan {     // one wavefront
+    Segs c;
+    typedef NoLds Lds;
+    template <int N> SWC_D void run(uint32_t, Lds*) const {
+        static_assert(kBlocksPerLaunch <= (uint32_t)N, "one lane per block");
+        simt::PT<uint32_t, N> x, own;
+        SIMT_BEGIN(t, N) own[t] = (uint32_t)t < c.nb ? c.infos[t].out_bits : 0u; x[t] = own[t]; SIMT_END
+        simt::wave_scan_incl<N>(x);
+        SIMT_BEGIN(t, N)
+            if ((uint32_t)t < c.nb) c.blk_at[t] = c.lead + x[t] - own[t];
+            if ((uint32_t)t + 1u == c.nb) c.blk_at[c.nb] = c.lead + x[t];
+        SIMT_END
+    }
+};
+struct EmitSeg {       // a wavefront per segment
+    Segs c;
+    typedef EmitLds Lds;
+    template <int N> SWC_D void run(uint32_t s, Lds* lds) const {
+        using simt::PT;
+        const uint32_t b = c.seg_blk[s];
+        const SWC_AS_GLOBAL BlockInfo* info = c.infos + b;
+        load_codes<N>(lds, info);
+        Emitter<N> e;
+        const bool first = s == c.seg_off[b];
+        e.begin(lds, c.stream, c.stream_cap, c.blk_at[b] + (first ? 0u : c.seg_at[s]));
+        if (first) emit_header<N>(e, lds, info);
+        // the symbols (:223-240)
+        const uint32_t ns = c.seg_nsym[s];
+        const SWC_AS_GLOBAL uint16_t* sy = c.syms + (size_t)kSegSyms * s;
+        PT<uint32_t, N> code, nb;
+        for (uint32_t base = 0; base < ns; base += (uint32_t)N) {
+            SIMT_BEGIN(t, N)
+                uint32_t cc = 0, n = 0;
+                if (base + (uint32_t)t < ns) {
+                    const uint32_t w = lds->code[sy[base + (uint32_t)t]];
+                    cc = w & 0xFFFFFFu; n = w >> 24;
+                }
+                code[t] = cc; nb[t] = n;
+            SIMT_END
+            e.emit(code, nb);
+        }
+        e.flush(true);
+    }
+};
 
 // ================================================================================================================ sort
 // Everything the elementwise steps of the sort see (device pointers).
@@ -546,68 +736,6 @@ struct LastColumn {
     }
 };
 
-// ================================================================================================================ per block
-struct BlockPtrs {
-    const SWC_AS_GLOBAL uint8_t* raw;           // the input of the launch
-    const SWC_AS_GLOBAL uint32_t* raw_off;      // n_blocks + 1 offsets
-    SWC_AS_GLOBAL uint8_t* area;                // rle1 results at rle1_bound() strides
-    const SWC_AS_GLOBAL uint32_t* area_off;
-    SWC_AS_GLOBAL uint8_t* text;
-    SWC_AS_GLOBAL uint8_t* blk;
-    const SWC_AS_GLOBAL uint32_t* off;
-    const SWC_AS_GLOBAL uint8_t* col;
-    SWC_AS_GLOBAL uint16_t* syms;               // block b at off[b] + 2 b
-    SWC_AS_GLOBAL uint8_t* outs;                // block bit streams at out_bound() strides
-    const SWC_AS_GLOBAL uint32_t* out_off;
-    SWC_AS_GLOBAL uint8_t* stream;              // the joined result
-    const SWC_AS_GLOBAL uint64_t* stream_at;    // bit offset of every block in it
-    SWC_AS_GLOBAL BlockInfo* infos;
-};
-struct NoLds { uint32_t unused; };
-struct Rle1Block {
-    BlockPtrs p;
-    typedef NoLds Lds;
-    template <int N> SWC_D void run(uint32_t b, Lds*) const {
-        const uint32_t n = p.raw_off[b + 1u] - p.raw_off[b];
-        const uint32_t r = rle1_job<N>(p.raw + p.raw_off[b], n, p.area + p.area_off[b]);
-        SIMT_BEGIN(t, N) if (t == 0) { p.infos[b].n_raw = n; p.infos[b].n_rle = r; } SIMT_END_WAVE
-    }
-};
-struct GatherBlock {   // the rle1 results one behind the other, and the block of every position
-    BlockPtrs p;
-    typedef NoLds Lds;
-    template <int N> SWC_D void run(uint32_t b, Lds*) const {
-        const uint32_t n = p.off[b + 1u] - p.off[b];
-        SIMT_BEGIN(t, N)
-            for (uint32_t i = (uint32_t)t; i < n; i += (uint32_t)N) {
-                p.text[p.off[b] + i] = p.area[p.area_off[b] + i];
-                p.blk[p.off[b] + i] = (uint8_t)b;
-            }
-        SIMT_END
-    }
-};
-struct MtfBlock {
-    BlockPtrs p;
-    typedef MtfLds Lds;
-    template <int N> SWC_D void run(uint32_t b, Lds* lds) const {
-        mtf_job<N>(p.col + p.off[b], p.off[b + 1u] - p.off[b], p.syms + p.off[b] + 2u * b, lds, p.infos + b);
-    }
-};
-struct EmitBlock {
-    BlockPtrs p;
-    typedef EmitLds Lds;
-    template <int N> SWC_D void run(uint32_t b, Lds* lds) const {
-        emit_job<N>(p.syms + p.off[b] + 2u * b, lds, p.infos + b, p.outs + p.out_off[b], p.out_off[b + 1u] - p.out_off[b]);
-    }
-};
-struct JoinBlock {
-    BlockPtrs p;
-    typedef NoLds Lds;
-    template <int N> SWC_D void run(uint32_t b, Lds*) const {
-        join_job<N>(p.outs + p.out_off[b], p.infos[b].out_bits, p.stream, p.stream_at[b]);
-    }
-};
-
 }  // namespace bz2c
 }  // namespace swc
 
@@ -622,31 +750,38 @@ namespace bz2c {
 // canonical code | length << 24: codes are handed out in order of (length, symbol), which is what decoders rebuild.
 inline void huffman_lengths(const uint32_t* freq, uint32_t alpha, uint32_t max_len, uint32_t* code) {
     uint64_t w[kMaxSyms + 2];
-    uint32_t len[kMaxSyms + 2];
+    uint32_t len[kMaxSyms + 2], order[kMaxSyms + 2];
     for (uint32_t i = 0; i < alpha; i++) w[i] = freq[i] ? freq[i] : 1u;
     for (;;) {
-        // repeatedly join the two lightest nodes (alpha <= 258: quadratic is nothing next to a 900 kB block)
-        uint64_t wt[2 * (kMaxSyms + 2)];
-        int parent[2 * (kMaxSyms + 2)];
-        bool live[2 * (kMaxSyms + 2)];
-        uint32_t nn = alpha;
-        for (uint32_t i = 0; i < alpha; i++) { wt[i] = w[i]; parent[i] = -1; live[i] = true; }
-        for (uint32_t joined = 0; joined + 1 < alpha; joined++) {
-            int a = -1, b = -1;
-            for (uint32_t i = 0; i < nn; i++) {
-                if (!live[i]) continue;
-                if (a < 0 || wt[i] < wt[a]) { b = a; a = (int)i; }
-                else if (b < 0 || wt[i] < wt[b]) b = (int)i;
-            }
-            wt[nn] = wt[a] + wt[b]; parent[nn] = -1; live[nn] = true;
-            parent[a] = parent[b] = (int)nn; live[a] = live[b] = false;
-            nn++;
+        // leaves in order of weight, then the two-queue construction: the lightest two of (next leaf, next inner node) are joined,
+        // inner nodes come into being in order of weight
+        for (uint32_t i = 0; i < alpha; i++) order[i] = i;
+        for (uint32_t i = 1; i < alpha; i++) {             // insertion sort: 258 entries, nearly sorted after a flattening
+            const uint32_t o = order[i];
+            uint32_t k = i;
+            while (k > 0 && w[order[k - 1]] > w[o]) { order[k] = order[k - 1]; k--; }
+            order[k] = o;
         }
+        uint64_t wt[kMaxSyms + 2];                           // inner nodes
+        int parent_leaf[kMaxSyms + 2], parent_inner[kMaxSyms + 2];
+        uint32_t nl = 0, ni = 0, made = 0;
+        auto take = [&](int to) -> uint64_t {
+            if (nl < alpha && (ni >= made || w[order[nl]] <= wt[ni])) { parent_leaf[order[nl]] = to; return w[order[nl++]]; }
+            parent_inner[ni] = to;
+            return wt[ni++];
+        };
+        while (alpha - nl + made - ni > 1) {
+            const uint64_t a = take((int)made);
+            const uint64_t b = take((int)made);
+            wt[made] = a + b;
+            parent_inner[made] = -1;
+            made++;
+        }
+        uint32_t depth_inner[kMaxSyms + 2];
+        for (int k = (int)made - 1; k >= 0; k--) depth_inner[k] = parent_inner[k] < 0 ? 0u : depth_inner[parent_inner[k]] + 1u;
         uint32_t longest = 0;
         for (uint32_t i = 0; i < alpha; i++) {
-            uint32_t d = 0;
-            for (int q = parent[i]; q >= 0; q = parent[q]) d++;
-            len[i] = d ? d : 1u;
+            len[i] = made ? depth_inner[parent_leaf[i]] + 1u : 1u;
             if (len[i] > longest) longest = len[i];
         }
         if (longest <= max_len) break;
@@ -659,39 +794,46 @@ inline void huffman_lengths(const uint32_t* freq, uint32_t alpha, uint32_t max_l
     }
 }
 
-// MSB-first bits appended to a byte vector
+// The stream being assembled, MSB first, in memory from the executor's result allocator (the C ABI hands exactly this buffer
+// to the caller: no copy of the finished stream).
+template <class X>
 struct BitSink {
-    std::vector<uint8_t> bytes;
+    X& x;
+    uint8_t* p = nullptr;
+    size_t cap = 0;
     uint64_t bits = 0;
-    void put(uint64_t v, int n) {
+    explicit BitSink(X& ex) : x(ex) {}
+    ~BitSink() { if (p) x.result_free(p); }
+    bool ensure(size_t n) {
+        if (n <= cap) return true;
+        const size_t want = n > 2 * cap ? n : 2 * cap;
+        uint8_t* q = x.result_alloc(want);
+        if (!q) return false;
+        if (p) { memcpy(q, p, (size_t)((bits + 7u) >> 3)); x.result_free(p); }
+        p = q; cap = want;
+        return true;
+    }
+    bool put(uint64_t v, int n) {
+        if (!ensure((size_t)((bits + (uint64_t)n + 7u) >> 3) + 8)) return false;
         for (int i = n - 1; i >= 0; i--) {
-            if ((bits & 7u) == 0) bytes.push_back(0);
-            if ((v >> i) & 1u) bytes.back() |= (uint8_t)(0x80u >> (bits & 7u));
+            if ((bits & 7u) == 0) p[bits >> 3] = 0;
+            if ((v >> i) & 1u) p[bits >> 3] |= (uint8_t)(0x80u >> (bits & 7u));
             bits++;
         }
+        return true;
     }
-    // `nbits` bits of `src` whose first bit sits at bit (bits % 8) of src[0] -- the form the join kernel leaves them in
-    void append_aligned(const uint8_t* src, uint64_t nbits) {
-        if (nbits == 0) return;
-        const uint32_t lead = (uint32_t)(bits & 7u);
-        const uint64_t span = (lead + nbits + 7u) >> 3;
-        const size_t at = bytes.size();
-        if (lead) { bytes.back() |= (uint8_t)(src[0] & (0xFFu >> lead)); src++; }
-        const uint64_t rest = span - (lead ? 1 : 0);
-        bytes.resize(at + rest);
-        if (rest) memcpy(bytes.data() + at, src, rest);
-        bits += nbits;
-    }
+    uint8_t* release(size_t* n) { uint8_t* r = p; *n = (size_t)((bits + 7u) >> 3); p = nullptr; cap = 0; return r; }
 };
 
 // The whole stream.  X is the executor: begin_chunk / end_chunk (device memory of a launch is released there), alloc, upload,
-// download, zero, each(m, f), per_block(nb, f), sort_pairs, scan_max, scan_sum, block_crcs.  Returns SWC_OK or SWC_E_DEVICE
-// (an allocation or a launch failed).
+// download, zero, each(m, f), per_block(nb, f), sort_pairs, scan_max, scan_sum, block_crcs, result_alloc / result_free.  Returns
+// SWC_OK -- *out (from result_alloc, the caller's to free) holds the *out_len bytes of the stream -- or SWC_E_DEVICE (an
+// allocation or a launch failed).
 template <class X>
-int compress_stream(X& x, const uint8_t* data, size_t len, int level, std::vector<uint8_t>& result) {
+int compress_stream(X& x, const uint8_t* data, size_t len, int level, uint8_t** out, size_t* out_len) {
     const size_t raw_block = (size_t)level * 100u * 800u;                         // :46
-    BitSink sink;
-    sink.put(0x425a, 16); sink.put(0x68, 8); sink.put((uint64_t)(0x30 + level), 8);   // :48-50
+    BitSink<X> sink(x);
+    if (!sink.put(0x425a, 16) || !sink.put(0x68, 8) || !sink.put((uint64_t)(0x30 + level), 8)) return SWC_E_DEVICE;   // :48-50
     uint32_t total_crc = 0;
     const size_t n_blocks_all = (len + raw_block - 1) / raw_block;
     for (size_t b0 = 0; b0 < n_blocks_all; b0 += kBlocksPerLaunch) {
@@ -699,71 +841,80 @@ int compress_stream(X& x, const uint8_t* data, size_t len, int level, std::vecto
         const uint8_t* chunk = data + b0 * raw_block;
         const size_t chunk_len = (size_t)(b0 + nb == n_blocks_all ? len - b0 * raw_block : (size_t)nb * raw_block);
         x.begin_chunk();
-        std::vector<uint32_t> raw_off(nb + 1), area_off(nb + 1);
-        for (uint32_t b = 0; b <= nb; b++) raw_off[b] = (uint32_t)(b * raw_block < chunk_len ? b * raw_block : chunk_len);
-        area_off[0] = 0;
-        for (uint32_t b = 0; b < nb; b++) area_off[b + 1] = area_off[b] + rle1_bound(raw_off[b + 1] - raw_off[b]);
-        BlockPtrs p;
-        memset(&p, 0, sizeof(p));
+        const uint32_t n_raw = (uint32_t)chunk_len;
+        const size_t bound = chunk_len + chunk_len / 4 + 16 * (size_t)nb + 16;    // after rle1, at most
+        const size_t t4 = 4 * bound + 16, t8 = 8 * bound + 16;
         uint8_t* d_raw = (uint8_t*)x.alloc(chunk_len + 16);
-        uint32_t* d_offs = (uint32_t*)x.alloc(4 * (size_t)(nb + 1) * 4);            // raw_off | area_off | off | out_off
-        uint8_t* d_area = (uint8_t*)x.alloc(area_off[nb] + 16);
+        uint32_t* d_offs = (uint32_t*)x.alloc(4 * (size_t)(nb + 1) * 4);            // off | blk_at | seg_off | (spare)
         BlockInfo* d_infos = (BlockInfo*)x.alloc(sizeof(BlockInfo) * nb);
-        if (!d_raw || !d_offs || !d_area || !d_infos) return SWC_E_DEVICE;
+        uint8_t* d_text = (uint8_t*)x.alloc(bound + 16);
+        uint8_t* d_blk = (uint8_t*)x.alloc(bound + 16);
+        uint8_t* d_col = (uint8_t*)x.alloc(bound + 16);
+        uint32_t* d_rank = (uint32_t*)x.alloc(t4);
+        uint32_t* d_sa = (uint32_t*)x.alloc(t4);
+        uint64_t* d_k0 = (uint64_t*)x.alloc(t8);
+        uint64_t* d_k1 = (uint64_t*)x.alloc(t8);
+        uint32_t* d_v0 = (uint32_t*)x.alloc(t4);
+        uint32_t* d_v1 = (uint32_t*)x.alloc(t4);
+        uint32_t* d_s0 = (uint32_t*)x.alloc(t4);
+        uint32_t* d_s1 = (uint32_t*)x.alloc(t4);
+        uint32_t* d_head = (uint32_t*)x.alloc(t4);
+        uint32_t* d_keep = (uint32_t*)x.alloc(t4);
+        uint32_t* d_kpos = (uint32_t*)x.alloc(t4);
+        if (!d_raw || !d_offs || !d_infos || !d_text || !d_blk || !d_col || !d_rank || !d_sa || !d_k0 || !d_k1 || !d_v0 || !d_v1 ||
+            !d_s0 || !d_s1 || !d_head || !d_keep || !d_kpos) return SWC_E_DEVICE;
+        x.mark("alloc");
         x.upload(d_raw, chunk, chunk_len);
-        x.upload(d_offs, raw_off.data(), 4 * (nb + 1));
-        x.upload(d_offs + (nb + 1), area_off.data(), 4 * (nb + 1));
+        x.mark("upload");
         x.zero(d_infos, sizeof(BlockInfo) * nb);
-        p.raw = (const SWC_AS_GLOBAL uint8_t*)d_raw;
-        p.raw_off = (const SWC_AS_GLOBAL uint32_t*)d_offs;
-        p.area = (SWC_AS_GLOBAL uint8_t*)d_area;
-        p.area_off = (const SWC_AS_GLOBAL uint32_t*)(d_offs + (nb + 1));
-        p.infos = (SWC_AS_GLOBAL BlockInfo*)d_infos;
-        x.per_block(nb, Rle1Block{p});
+        std::vector<uint32_t> raw_off(nb + 1);
+        for (uint32_t b = 0; b <= nb; b++) raw_off[b] = (uint32_t)(b * raw_block < chunk_len ? b * raw_block : chunk_len);
         std::vector<uint32_t> crcs(nb);
         if (x.block_crcs(d_raw, raw_off.data(), nb, crcs.data())) return SWC_E_DEVICE;
-        std::vector<BlockInfo> infos(nb);
-        x.download(infos.data(), d_infos, sizeof(BlockInfo) * nb);
-        // the blocks one behind the other
-        std::vector<uint32_t> off(nb + 1), out_off(nb + 1);
-        off[0] = 0; out_off[0] = 0;
-        uint32_t longest = 0;
-        for (uint32_t b = 0; b < nb; b++) {
-            off[b + 1] = off[b] + infos[b].n_rle;
-            out_off[b + 1] = out_off[b] + out_bound(infos[b].n_rle);
-            if (infos[b].n_rle > longest) longest = infos[b].n_rle;
+        x.mark("crc");
+        // ---- rle1: the blocks one behind the other (the sort's buffers are free until then)
+        {
+            Rle1 r;
+            memset(&r, 0, sizeof(r));
+            r.raw = (const SWC_AS_GLOBAL uint8_t*)d_raw;
+            r.n = n_raw; r.raw_block = (uint32_t)raw_block; r.nb = nb;
+            r.start = (SWC_AS_GLOBAL uint32_t*)d_head;
+            r.cnt = (SWC_AS_GLOBAL uint32_t*)d_keep;
+            r.pos = (SWC_AS_GLOBAL uint32_t*)d_kpos;
+            r.text = (SWC_AS_GLOBAL uint8_t*)d_text;
+            r.blk = (SWC_AS_GLOBAL uint8_t*)d_blk;
+            r.off = (SWC_AS_GLOBAL uint32_t*)d_offs;
+            x.each(n_raw, Rle1Flags{r});
+            if (x.scan_max(d_head, n_raw)) return SWC_E_DEVICE;
+            x.each(n_raw, Rle1Counts{r});
+            if (x.scan_sum(d_keep, d_kpos, n_raw)) return SWC_E_DEVICE;
+            x.each(n_raw, Rle1Write{r});
         }
-        const uint32_t total = off[nb];
-        x.upload(d_offs + 2 * (nb + 1), off.data(), 4 * (nb + 1));
-        x.upload(d_offs + 3 * (nb + 1), out_off.data(), 4 * (nb + 1));
-        uint8_t* d_text = (uint8_t*)x.alloc((size_t)total + 16);
-        uint8_t* d_blk = (uint8_t*)x.alloc((size_t)total + 16);
-        uint8_t* d_col = (uint8_t*)x.alloc((size_t)total + 16);
-        if (!d_text || !d_blk || !d_col) return SWC_E_DEVICE;
-        p.text = (SWC_AS_GLOBAL uint8_t*)d_text;
-        p.blk = (SWC_AS_GLOBAL uint8_t*)d_blk;
-        p.off = (const SWC_AS_GLOBAL uint32_t*)(d_offs + 2 * (nb + 1));
-        p.col = (const SWC_AS_GLOBAL uint8_t*)d_col;
-        p.out_off = (const SWC_AS_GLOBAL uint32_t*)(d_offs + 3 * (nb + 1));
-        x.per_block(nb, GatherBlock{p});
+        std::vector<uint32_t> off(nb + 1), seg_off(nb + 1);
+        x.download(off.data(), d_offs, 4 * (nb + 1));
+        seg_off[0] = 0;
+        uint32_t longest = 0;
+        size_t stream_cap = 16;
+        for (uint32_t b = 0; b < nb; b++) {
+            const uint32_t n_rle = off[b + 1] - off[b];
+            stream_cap += out_bound(n_rle);
+            seg_off[b + 1] = seg_off[b] + (n_rle + kSeg - 1u) / kSeg;
+            if (n_rle > longest) longest = n_rle;
+        }
+        const uint32_t total = off[nb], n_segs = seg_off[nb];
+        if (total > bound) return SWC_E_DEVICE;
+        std::vector<uint32_t> seg_blk(n_segs);
+        for (uint32_t b = 0; b < nb; b++) for (uint32_t q = seg_off[b]; q < seg_off[b + 1]; q++) seg_blk[q] = b;
+        x.upload(d_offs + 2 * (nb + 1), seg_off.data(), 4 * (nb + 1));
+        x.mark("rle1");
         // ---- the sort
         {
             Bwt c;
             memset(&c, 0, sizeof(c));
-            const size_t t4 = 4 * (size_t)total + 16, t8 = 8 * (size_t)total + 16;
-            uint32_t* d_rank = (uint32_t*)x.alloc(t4);
-            uint32_t* d_sa = (uint32_t*)x.alloc(t4);
-            uint64_t* d_k0 = (uint64_t*)x.alloc(t8);
-            uint64_t* d_k1 = (uint64_t*)x.alloc(t8);
-            uint32_t* d_v0 = (uint32_t*)x.alloc(t4);
-            uint32_t* d_v1 = (uint32_t*)x.alloc(t4);
-            uint32_t* d_s0 = (uint32_t*)x.alloc(t4);
-            uint32_t* d_s1 = (uint32_t*)x.alloc(t4);
-            uint32_t* d_head = (uint32_t*)x.alloc(t4);
-            uint32_t* d_keep = (uint32_t*)x.alloc(t4);
-            uint32_t* d_kpos = (uint32_t*)x.alloc(t4);
-            if (!d_rank || !d_sa || !d_k0 || !d_k1 || !d_v0 || !d_v1 || !d_s0 || !d_s1 || !d_head || !d_keep || !d_kpos) return SWC_E_DEVICE;
-            c.text = p.text; c.blk = p.blk; c.off = p.off; c.infos = p.infos;
+            c.text = (const SWC_AS_GLOBAL uint8_t*)d_text;
+            c.blk = (const SWC_AS_GLOBAL uint8_t*)d_blk;
+            c.off = (const SWC_AS_GLOBAL uint32_t*)d_offs;
+            c.infos = (SWC_AS_GLOBAL BlockInfo*)d_infos;
             c.rank = (SWC_AS_GLOBAL uint32_t*)d_rank;
             c.sa = (SWC_AS_GLOBAL uint32_t*)d_sa;
             c.key_in = (SWC_AS_GLOBAL uint64_t*)d_k0;
@@ -787,6 +938,7 @@ int compress_stream(X& x, const uint8_t* data, size_t len, int level, std::vecto
             x.each(total, FirstKeys{c});
             int key_bits = (int)(8u * kFirstBytes + blk_bits);
             while (c.m != 0u) {
+                x.note("sort round: elements", c.m, (uint32_t)key_bits);
                 if (x.sort_pairs(d_k0, d_k1, d_v0, d_v1, c.m, key_bits)) return SWC_E_DEVICE;
                 x.each(c.m, Heads{c});
                 if (x.scan_max(d_head, c.m)) return SWC_E_DEVICE;
@@ -807,45 +959,79 @@ int compress_stream(X& x, const uint8_t* data, size_t len, int level, std::vecto
             }
             x.each(total, LastColumn{c});
         }
+        x.mark("sort");
         // ---- symbols, lengths, bits
-        uint16_t* d_syms = (uint16_t*)x.alloc(2 * ((size_t)total + 2u * nb) + 16);
-        uint8_t* d_outs = (uint8_t*)x.alloc((size_t)out_off[nb] + 16);
-        if (!d_syms || !d_outs) return SWC_E_DEVICE;
-        p.syms = (SWC_AS_GLOBAL uint16_t*)d_syms;
-        p.outs = (SWC_AS_GLOBAL uint8_t*)d_outs;
-        x.per_block(nb, MtfBlock{p});
+        uint16_t* d_syms = (uint16_t*)x.alloc(2 * (size_t)kSegSyms * n_segs + 16);
+        uint32_t* d_segs = (uint32_t*)x.alloc(4 * (size_t)n_segs * 4 + 16);          // seg_blk | seg_nsym | seg_bits | seg_at
+        uint32_t* d_last = (uint32_t*)x.alloc(4 * 256 * (size_t)n_segs + 16);
+        uint32_t* d_before = (uint32_t*)x.alloc(4 * 256 * (size_t)n_segs + 16);
+        uint8_t* d_used = (uint8_t*)x.alloc(256 * (size_t)nb);
+        uint8_t* d_stream = (uint8_t*)x.alloc(stream_cap);
+        if (!d_syms || !d_segs || !d_last || !d_before || !d_used || !d_stream) return SWC_E_DEVICE;
+        x.upload(d_segs, seg_blk.data(), 4 * (size_t)n_segs);
+        Segs g;
+        {
+            memset(&g, 0, sizeof(g));
+            g.col = (const SWC_AS_GLOBAL uint8_t*)d_col;
+            g.off = (const SWC_AS_GLOBAL uint32_t*)d_offs;
+            g.seg_off = (const SWC_AS_GLOBAL uint32_t*)(d_offs + 2 * (nb + 1));
+            g.seg_blk = (const SWC_AS_GLOBAL uint32_t*)d_segs;
+            g.last = (SWC_AS_GLOBAL uint32_t*)d_last;
+            g.before = (SWC_AS_GLOBAL uint32_t*)d_before;
+            g.used = (SWC_AS_GLOBAL uint8_t*)d_used;
+            g.syms = (SWC_AS_GLOBAL uint16_t*)d_syms;
+            g.seg_nsym = (SWC_AS_GLOBAL uint32_t*)(d_segs + n_segs);
+            g.seg_bits = (SWC_AS_GLOBAL uint32_t*)(d_segs + 2 * (size_t)n_segs);
+            g.seg_at = (SWC_AS_GLOBAL uint32_t*)(d_segs + 3 * (size_t)n_segs);
+            g.stream = (SWC_AS_GLOBAL uint8_t*)d_stream;
+            g.blk_at = (SWC_AS_GLOBAL uint32_t*)(d_offs + (nb + 1));
+            g.infos = (SWC_AS_GLOBAL BlockInfo*)d_infos;
+            g.nb = nb;
+            g.stream_cap = (uint32_t)(stream_cap & ~(size_t)3);
+            g.lead = (uint32_t)(sink.bits & 31u);
+            x.per_block(n_segs, SegLast{g});
+            x.each(256u * nb, SegBefore{g});
+            x.per_block(n_segs, MtfSeg{g});
+        }
+        std::vector<BlockInfo> infos(nb);
         x.download(infos.data(), d_infos, sizeof(BlockInfo) * nb);
+        x.mark("mtf");
         for (uint32_t b = 0; b < nb; b++) {
             infos[b].crc = crcs[b];
             huffman_lengths(infos[b].freq, infos[b].n_used + 2u, 17, infos[b].code);
+            infos[b].head_bits = header_bits(infos[b]);
         }
+        x.mark("lengths");
         x.upload(d_infos, infos.data(), sizeof(BlockInfo) * nb);
-        x.per_block(nb, EmitBlock{p});
-        x.download(infos.data(), d_infos, sizeof(BlockInfo) * nb);
-        std::vector<uint64_t> at(nb + 1);
-        at[0] = sink.bits & 7u;
-        for (uint32_t b = 0; b < nb; b++) at[b + 1] = at[b] + infos[b].out_bits;
-        const size_t stream_bytes = (size_t)((at[nb] + 31u) / 32u * 4u) + 16;
-        uint8_t* d_stream = (uint8_t*)x.alloc(stream_bytes);
-        uint64_t* d_at = (uint64_t*)x.alloc(8 * (size_t)(nb + 1));
-        if (!d_stream || !d_at) return SWC_E_DEVICE;
-        x.zero(d_stream, stream_bytes);
-        x.upload(d_at, at.data(), 8 * (size_t)(nb + 1));
-        p.stream = (SWC_AS_GLOBAL uint8_t*)d_stream;
-        p.stream_at = (const SWC_AS_GLOBAL uint64_t*)d_at;
-        x.per_block(nb, JoinBlock{p});
-        std::vector<uint8_t> joined((size_t)((at[nb] + 7u) >> 3));
-        x.download(joined.data(), d_stream, joined.size());
-        sink.append_aligned(joined.data(), at[nb] - at[0]);
+        x.zero(d_stream, stream_cap);
+        x.per_block(n_segs, SegBits{g});
+        x.per_block(nb, SegScan{g});
+        x.per_block(1, BlockScan{g});
+        x.per_block(n_segs, EmitSeg{g});
+        // the blocks' bits go behind what the stream has: the device has put them from the bit the stream's last dword has
+        // reached, that dword's bytes are kept across the download
+        const uint64_t base = sink.bits & ~31ull;
+        std::vector<uint32_t> at(nb + 1);
+        x.download(at.data(), d_offs + (nb + 1), 4 * (nb + 1));
+        x.mark("emit");
+        const size_t got = (size_t)((at[nb] + 7u) >> 3), at_byte = (size_t)(base >> 3);
+        const size_t launches_left = (n_blocks_all - b0 + kBlocksPerLaunch - 1) / kBlocksPerLaunch;
+        if (!sink.ensure(at_byte + (launches_left > 1 ? got + got / 8 : got) * launches_left + 64)) return SWC_E_DEVICE;
+        uint8_t keep[4] = {0, 0, 0, 0};
+        const size_t kept = (size_t)((at[0] + 7u) >> 3);
+        memcpy(keep, sink.p + at_byte, kept);
+        x.download(sink.p + at_byte, d_stream, got);
+        for (size_t k = 0; k < kept; k++) sink.p[at_byte + k] |= keep[k];
+        sink.bits = base + at[nb];
+        x.mark("download");
         for (uint32_t b = 0; b < nb; b++) {
             total_crc = (total_crc << 1) | (total_crc >> 31);                     // :56-57
             total_crc ^= crcs[b];
         }
         x.end_chunk();
     }
-    sink.put(kEosMagic, 48);                                                      // :67-71
-    sink.put(total_crc, 32);
-    result.swap(sink.bytes);
+    if (!sink.put(kEosMagic, 48) || !sink.put(total_crc, 32)) return SWC_E_DEVICE;    // :67-71
+    *out = sink.release(out_len);
     return SWC_OK;
 }
 

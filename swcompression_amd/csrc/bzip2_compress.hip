@@ -9,7 +9,12 @@
 // rocPRIM is header-only: these are device kernels compiled into this library for gfx950, not a dependency at run time.
 // Memory comes from the stream-ordered pool on the calling thread's stream and goes back at the end of every launch group.
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <thread>
 #include <vector>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -38,13 +43,26 @@ struct DeviceExec {
     size_t temp_bytes = 0;
     bool failed = false;
 
+    // SWC_BZ2C_TRACE=1: wall time of every stage of a launch group on stderr (each mark waits for the stream: a diagnosis aid)
+    bool trace = getenv("SWC_BZ2C_TRACE") != nullptr;
+    std::chrono::steady_clock::time_point t0;
+    void mark(const char* what) {
+        if (!trace) return;
+        (void)hipStreamSynchronize(s);
+        const auto t1 = std::chrono::steady_clock::now();
+        fprintf(stderr, "[bz2c] %-14s %8.3f ms\n", what, std::chrono::duration<double, std::milli>(t1 - t0).count());
+        t0 = t1;
+    }
+    void note(const char* what, uint32_t a, uint32_t b) { if (trace) { mark("..."); fprintf(stderr, "[bz2c] %s %u %u\n", what, a, b); } }
     ~DeviceExec() { end_chunk(); }
-    void begin_chunk() {}
+    void begin_chunk() { t0 = std::chrono::steady_clock::now(); }
     void end_chunk() {
         for (void* p : mem) (void)hipFreeAsync(p, s);
         mem.clear();
         temp = nullptr; temp_bytes = 0;
     }
+    uint8_t* result_alloc(size_t n) { return host_result(n); }
+    void result_free(uint8_t* q) { host_result_free(q); }
     bool ok(hipError_t e) { if (e != hipSuccess) { failed = true; (void)hipGetLastError(); } return e == hipSuccess; }
     void* alloc(size_t n) {
         void* p = nullptr;
@@ -52,15 +70,36 @@ struct DeviceExec {
         mem.push_back(p);
         return p;
     }
+    // Large transfers go through the calling thread's page-locked staging buffers (host_util.h): a pageable source made the
+    // same 32 MiB upload take anything between 1 and 24 ms.  Several threads fill the buffer (one core copies about 10 GB/s).
+    static void copy_threads(uint8_t* dst, const uint8_t* src, size_t n) {
+        const size_t nt = std::min<size_t>(8, n >> 22);
+        if (nt < 2) { memcpy(dst, src, n); return; }
+        std::vector<std::thread> th;
+        const size_t per = (n / nt + 63) & ~(size_t)63;
+        for (size_t t = 0; t < nt; t++) {
+            const size_t lo = std::min(n, t * per), hi = t + 1 == nt ? n : std::min(n, (t + 1) * per);
+            th.emplace_back([=] { if (hi > lo) memcpy(dst + lo, src + lo, hi - lo); });
+        }
+        for (auto& t : th) t.join();
+    }
     void upload(void* d, const void* h, size_t n) {
         if (!n) return;
-        ok(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s));
-        ok(hipStreamSynchronize(s));          // (the source is pageable and the caller's to change)
+        uint8_t* stage = n >= ((size_t)1 << 20) ? pinned_stage(0, n) : nullptr;
+        if (stage) {
+            copy_threads(stage, (const uint8_t*)h, n);
+            ok(hipMemcpyAsync(d, stage, n, hipMemcpyHostToDevice, s));
+        } else {
+            ok(hipMemcpyAsync(d, h, n, hipMemcpyHostToDevice, s));
+        }
+        ok(hipStreamSynchronize(s));          // (the source is the caller's to change, the staging buffer the next upload's)
     }
     void download(void* h, const void* d, size_t n) {
         if (!n) return;
-        ok(hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, s));
+        uint8_t* stage = n >= ((size_t)1 << 20) ? pinned_stage(1, n) : nullptr;
+        ok(hipMemcpyAsync(stage ? (void*)stage : h, d, n, hipMemcpyDeviceToHost, s));
         ok(hipStreamSynchronize(s));
+        if (stage) copy_threads((uint8_t*)h, stage, n);
     }
     void zero(void* d, size_t n) { if (n) ok(hipMemsetAsync(d, 0, n, s)); }
     template <class F> void each(uint32_t m, const F& f) {
@@ -122,11 +161,13 @@ struct DeviceExec {
 
 }  // namespace
 
-int bzip2_compress_device(const uint8_t* data, size_t len, int level, std::vector<uint8_t>& out) {
+// *out: from host_result (swc_free releases it)
+int bzip2_compress_device(const uint8_t* data, size_t len, int level, uint8_t** out, size_t* out_len) {
     DeviceExec x;
-    const int st = bz2c::compress_stream(x, data, len, level, out);
-    if (st != SWC_OK || x.failed) { out.clear(); return SWC_E_DEVICE; }
-    return SWC_OK;
+    *out = nullptr; *out_len = 0;
+    const int st = bz2c::compress_stream(x, data, len, level, out, out_len);
+    if (st == SWC_OK && x.failed) { host_result_free(*out); *out = nullptr; *out_len = 0; }
+    return st != SWC_OK || x.failed ? SWC_E_DEVICE : SWC_OK;
 }
 
 }  // namespace swc

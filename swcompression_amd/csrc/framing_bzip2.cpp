@@ -177,7 +177,7 @@ int decode_candidates(const uint8_t* d, size_t n, std::map<uint64_t, Decoded>& b
 }  // namespace
 }  // namespace swc
 
-namespace swc { int bzip2_compress_device(const uint8_t* data, size_t len, int level, std::vector<uint8_t>& out); }   // bzip2_compress.hip
+namespace swc { int bzip2_compress_device(const uint8_t* data, size_t len, int level, uint8_t** out, size_t* out_len); }   // bzip2_compress.hip
 using namespace swc;
 
 extern "C" {
@@ -230,11 +230,9 @@ int swc_bzip2_multi_decompress(const uint8_t* in, size_t in_len, uint8_t** out, 
 int swc_bzip2_compress(const uint8_t* data, size_t len, int block_size, uint8_t** out, size_t* out_len) try {
     if (!out || !out_len || (len && !data) || block_size < 1 || block_size > 9) return SWC_E_INVALID_ARGUMENT;
     if (!device_ready()) { give_empty(out, out_len); return SWC_E_DEVICE; }
-    std::vector<uint8_t> res;
-    const int st = bzip2_compress_device(data, len, block_size, res);
+    const int st = bzip2_compress_device(data, len, block_size, out, out_len);   // assembled in the caller's buffer
     if (st) { give_empty(out, out_len); return st; }
     stat_add(0, 1);
-    give(res, out, out_len);
     return SWC_OK;
 } catch (...) {
     if (out && out_len) give_empty(out, out_len);

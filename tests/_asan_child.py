@@ -95,4 +95,19 @@ for length in list(range(0, 70)) + [2044, 2047, 2048, 2049, 4096, 6143, 6145, 65
         assert lib.emu_crc32_wave(buf + mis, length) == zlib.crc32(base[:length]), (length, mis)
         libc.free(buf)
         n += 1
+# BZip2 compression: every stage's buffers are allocated at exactly the size the driver asks for
+import bz2
+lib.emu_bzip2_compress.restype = C.c_int
+for x in (b"", b"a", b"ab" * 3000, bytes(range(256)) * 20, corpus.p_text(100000, 3), corpus.p_mix(170000, 4), bytes(90000), corpus.p_rand(30000, 6)):
+    for level in (1, 2):
+        cap = len(x) + len(x) // 2 + 4096
+        ob = libc.malloc(cap)
+        got = C.c_size_t(0)
+        ib = libc.malloc(max(len(x), 1))
+        C.memmove(ib, x, len(x))
+        assert lib.emu_bzip2_compress(C.c_void_p(ib), C.c_size_t(len(x)), C.c_int(level), C.c_void_p(ob), C.c_size_t(cap), C.byref(got)) == 0
+        assert bz2.decompress(C.string_at(ob, got.value)) == x
+        libc.free(ib)
+        libc.free(ob)
+        n += 1
 print("asan-clean", n)

@@ -261,8 +261,12 @@ namespace {
 struct EmuBz2Exec {
     std::vector<std::unique_ptr<uint8_t[]>> mem;
     void begin_chunk() {}
+    void mark(const char*) {}
+    uint8_t* result_alloc(size_t n) { uint8_t* q = (uint8_t*)malloc(n ? n : 1); if (q) std::memset(q, 0xEE, n); return q; }
+    void result_free(uint8_t* q) { free(q); }
+    void note(const char*, uint32_t, uint32_t) {}
     void end_chunk() { mem.clear(); }
-    void* alloc(size_t n) { mem.emplace_back(new uint8_t[n + 64]); std::memset(mem.back().get(), 0xEE, n + 64); return mem.back().get(); }
+    void* alloc(size_t n) { mem.emplace_back(new uint8_t[n ? n : 1]); std::memset(mem.back().get(), 0xEE, n); return mem.back().get(); }   // exact: the ASAN build sees every overrun
     void upload(void* d, const void* h, size_t n) { std::memcpy(d, h, n); }
     void download(void* h, const void* d, size_t n) { std::memcpy(h, d, n); }
     void zero(void* d, size_t n) { std::memset(d, 0, n); }
@@ -303,9 +307,11 @@ struct EmuBz2Exec {
 // returns the status; *out_len = bytes needed (the stream is copied only if it fits `cap`)
 extern "C" int emu_bzip2_compress(const uint8_t* data, size_t len, int level, uint8_t* out, size_t cap, size_t* out_len) {
     EmuBz2Exec x;
-    std::vector<uint8_t> res;
-    const int st = swc::bz2c::compress_stream(x, data, len, level, res);
-    *out_len = res.size();
-    if (st == 0 && res.size() <= cap) std::memcpy(out, res.data(), res.size());
+    uint8_t* res = nullptr;
+    size_t n = 0;
+    const int st = swc::bz2c::compress_stream(x, data, len, level, &res, &n);
+    *out_len = n;
+    if (st == 0 && n <= cap) std::memcpy(out, res, n);
+    free(res);
     return st;
 }
