@@ -377,6 +377,7 @@ def archive_paths(lib):
                                                      "instead of 4096 Python bytes objects copied from it",
                                          "value": 4096 * 65536 / dt / 2**30, "unit": "GiB/s decompressed (PCIe legs, discovery, CRC-32 / ISIZE checks included)",
                                          "seconds": dt, "stats": stats(ts, 1)}
+    res["bzip2_compress"] = bzip2_compress_path(lib)
     if shutil.which("xz") is None:
         res["xz_index_unarchive"] = {"error": "no xz command on this box to write a multi-block stream"}
         return res
@@ -397,6 +398,35 @@ def archive_paths(lib):
                                  "blocks_from_the_batch_per_call": int(lib.swc_stat(b"xz_cache_hits") - h0) // 3, "compressed_bytes": len(a),
                                  "note": "bound by the latency of ONE LZMA2 stream (a 256 KiB block is a serial range-coder chain of about 0.17 s on a wave), not by the host path"}
     return res
+
+
+def bzip2_compress_path(lib):
+    """SURVEY 8f row 4, BZip2.compress(data:blockSize: .nine): 64 blocks of 720,000 bytes (one launch group), host buffer in,
+    host buffer out.  The stream is checked with libbz2 and the engine's own decoder; libbz2 on one core of this box is the
+    CPU figure next to it (a stronger encoder than the reference's, which has no build here)."""
+    import bz2
+    import swcompression_amd as swc
+    from swcompression_amd import corpus
+    x = b"".join((corpus.p_mix if i % 4 == 3 else corpus.p_text)(720000, 0xB2C + i) for i in range(64))
+    swc.BZip2.compress(x, 9)   # one discarded warm-up of the full size
+    l0 = lib.swc_stat(b"launches")
+    ts = []
+    for _ in range(5):
+        t0 = time.perf_counter()
+        z = swc.BZip2.compress(x, 9)
+        ts.append((time.perf_counter() - t0) * 1e3)
+    dt = sum(ts) / len(ts) / 1e3
+    assert bz2.decompress(z) == x and swc.BZip2.decompress(z) == x
+    sample = x[:8 * 720000]
+    t0 = time.perf_counter()
+    ref = bz2.compress(sample, 9)
+    tref = time.perf_counter() - t0
+    ours = len(swc.BZip2.compress(sample, 9))
+    return {"workload": "64 x 720,000 bytes (48 text, 16 mix), BZip2.compress(data:blockSize: .nine), host buffers both ways",
+            "value": len(x) / dt / 2**30, "unit": "GiB/s uncompressed (PCIe legs, the host's code-length step and the assembly of the stream included)",
+            "seconds": dt, "stats": stats(ts, 1), "calls_counted": int(lib.swc_stat(b"launches") - l0), "compressed_bytes": len(z), "ratio": len(z) / len(x),
+            "verified": "libbz2 and the engine's own decoder return the input",
+            "libbz2_one_core": {"GiBps": len(sample) / tref / 2**30, "sample_bytes": len(sample), "size_vs_libbz2": ours / len(ref)}}
 
 
 def config1_latency(lib, raw, plains, reps=20):

@@ -4,29 +4,27 @@
 // their helpers -- initialRle :243-262, BurrowsWheeler.transform (BurrowsWheeler.swift:8-29, SuffixArray.swift), mtfRle
 // :277-325 -- for ALL blocks of a stream at once (blocks are independent until their bits are joined):
 //
-//   rle1      one block per WAVEFRONT.  Runs of 4..255 equal bytes become four bytes and a count (:243-262): 64 bytes per step; a
-//             max-scan of the run starts gives every lane its position in its run, a prefix sum of what the lanes emit (the
-//             byte itself when its position in the 255-byte sub-run is below four, a count behind the last byte of a sub-run of
-//             four and more) gives the places;
+//   rle1      one THREAD per input byte around two device scans.  Runs of 4..255 equal bytes become four bytes and a count
+//             (:243-262): a maximum scan of the run starts gives every byte its position in its run, a sum scan of what the
+//             bytes emit (the byte itself when its position in the 255-byte piece is below four, a count behind the last byte
+//             of a piece of four and more) gives the places -- the blocks come out one behind the other;
 //   sort      the Burrows-Wheeler transform of the result: the rotations of ALL blocks sorted together by prefix doubling.
-//             The first key of a rotation is its block and its first seven bytes (one 64-bit radix sort settles most of a
+//             The first key of a rotation is its block and its first seven bytes (one 62-bit radix sort settles most of a
 //             text), then rounds over the rotations that still share a key with a neighbour ONLY: key = (rank of the
 //             rotation, rank of the rotation h further on), h = 7, 14, 28 ...; a rotation that is alone in its group has
 //             its final row and leaves the working set.  One thread per element, elementwise kernels around a device radix
 //             sort and two device scans (rocPRIM: the only library calls of the engine; bzip2_compress.hip);
-//   mtf       one block per wavefront.  Move-to-front over the bytes that occur, zero runs as RUNA / RUNB digits (bijective base
-//             2), the end-of-block symbol (:277-325).  A byte equal to its predecessor IS a zero, so a ballot per 64 bytes
-//             finds the positions that change the list and only those are walked; the list's first 64 positions live one per
-//             lane in a register (finding a byte is a compare and a ballot, moving it to the front one DPP shift), positions
-//             64..255 in three more registers that are touched only when the byte is found that deep;
-//   lengths   the HOST turns a block's frequencies into code lengths and canonical codes (huffman_lengths: a plain Huffman
-//             tree, weights flattened until no code is longer than 17 bits, as bzip2 itself does) -- 258 numbers per block;
-//   emit      one block per wavefront: magic, CRC, origin pointer, the map of used bytes, TWO identical tables (the format wants
-//             two; the reference duplicates its only one the same way, :142-147) with all selectors zero, the code lengths in
-//             delta form, then the symbols -- 64 per step, a wave scan of the code lengths for the places, ds_or_b32 into a
-//             staging area of the MSB-first bit stream in LDS, byte-swapped dwords to HBM;
-//   join      one block per wavefront: every block's bits are shifted to their place in the stream (blocks start at arbitrary
-//             bit offsets), atomic OR into the zeroed result.
+//   mtf       one WAVEFRONT per segment of 4,096 column bytes.  Move-to-front over the bytes that occur, zero runs as RUNA /
+//             RUNB digits (bijective base 2), the end-of-block symbol (:277-325).  The list in front of a segment follows from
+//             the last positions of the byte values before it; inside, a byte equal to its predecessor IS a zero, so a ballot
+//             per 64 bytes finds the positions that change the list and only those are walked (section "mtf");
+//   lengths   the HOST turns a block's frequencies into code lengths and canonical codes (huffman_lengths: a Huffman tree,
+//             weights flattened until no code is longer than 17 bits, as bzip2 itself does) -- 258 numbers per block;
+//   emit      one wavefront per segment: the bit every segment starts at from two small scans, then 64 codes per step -- a
+//             wave scan of the code lengths for the places, ds_or_b32 into a staging area of the MSB-first bit stream in LDS,
+//             byte-swapped dwords to HBM, straight into the stream.  The first segment of a block writes its header: magic, CRC,
+//             origin pointer, the map of used bytes, TWO identical tables (the format wants two; the reference duplicates its
+//             only one the same way, :142-147) with all selectors zero, the code lengths in delta form.
 //
 // The contract is that of the other two encoders: A valid bzip2 stream for the same bytes with the reference's block
 // cutting (level x 80,000 raw bytes per block, :46), not the reference's bytes (the reference builds up to six tables with a
