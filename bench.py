@@ -422,10 +422,19 @@ def bzip2_compress_path(lib):
     ref = bz2.compress(sample, 9)
     tref = time.perf_counter() - t0
     ours = len(swc.BZip2.compress(sample, 9))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import _oracle as O
+    small = x[:2 * 720000]
+    t0 = time.perf_counter()
+    restated = O.bzip2_compress(small, 9)
+    trest = time.perf_counter() - t0
     return {"workload": "64 x 720,000 bytes (48 text, 16 mix), BZip2.compress(data:blockSize: .nine), host buffers both ways",
             "value": len(x) / dt / 2**30, "unit": "GiB/s uncompressed (PCIe legs, the host's code-length step and the assembly of the stream included)",
             "seconds": dt, "stats": stats(ts, 1), "calls_counted": int(lib.swc_stat(b"launches") - l0), "compressed_bytes": len(z), "ratio": len(z) / len(x),
             "verified": "libbz2 and the engine's own decoder return the input",
+            "cpu_baseline": {"kind": "port", "what": "oracle/rc_bzip2c.c, the reference encoder restated (qsort prefix doubling for its suffix array), one core",
+                             "GiBps": len(small) / trest / 2**30, "sample_bytes": len(small),
+                             "size_vs_reference_encoder_restated": len(swc.BZip2.compress(small, 9)) / len(restated)},
             "libbz2_one_core": {"GiBps": len(sample) / tref / 2**30, "sample_bytes": len(sample), "size_vs_libbz2": ours / len(ref)}}
 
 

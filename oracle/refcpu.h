@@ -89,6 +89,8 @@ int refcpu_lz4_block(const uint8_t* in, size_t in_len, const uint8_t* dict, size
                      uint8_t** out, size_t* out_len);
 /* Deflate.compress(data:) Deflate+Compress.swift:22-213: one stored or static-Huffman block */
 int refcpu_deflate_compress(const uint8_t* data, size_t n, uint8_t* out, size_t cap, size_t* out_len);
+/* BZip2.compress(data:blockSize:) BZip2+Compress.swift:41-325 (level 1..9 = BlockSize.one ... .nine) */
+int refcpu_bzip2_compress(const uint8_t* data, size_t n, int level, uint8_t* out, size_t cap, size_t* out_len);
 /* LZ4.compress(block:_:) LZ4+Compress.swift:157-281: bytes = dict ++ block, the block starts at `start` */
 int refcpu_lz4_compress_block(const uint8_t* bytes, size_t total, size_t start, uint8_t* out, size_t cap, size_t* out_len);
 

@@ -195,6 +195,19 @@ def deflate_compress(data):
     return out.raw[:n.value]
 
 
+def bzip2_compress(data, level=1):
+    """BZip2.compress(data:blockSize:) (BZip2+Compress.swift:41-325), restated: the compressed bytes."""
+    data = bytes(data)
+    cap = len(data) + len(data) // 2 + 4096
+    out = C.create_string_buffer(cap)
+    n = C.c_size_t()
+    lib.refcpu_bzip2_compress.restype = C.c_int
+    lib.refcpu_bzip2_compress.argtypes = [C.c_char_p, C.c_size_t, C.c_int, C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    st = lib.refcpu_bzip2_compress(data, len(data), level, out, cap, C.byref(n))
+    assert st == 0, st
+    return out.raw[:n.value]
+
+
 def crc32(data, prev=0):
     return lib.refcpu_crc32(bytes(data), len(data), prev)
 
