@@ -52,6 +52,31 @@ __global__ void walk_xcd_per_block(const uint32_t* P, size_t n, uint32_t steps, 
     sink[(w * blockDim.x + threadIdx.x) & 0xFFFFF] = acc + end;
 }
 
+// mode 3: what a decoder could do with the L2-resident rate.  The cycle of every block is cut at the indices that are multiples
+// of M (segments of geometrically distributed length, mean M).  The chip is eight TEAMS (one per XCD, told apart by the XCC_ID
+// hardware register); a team takes the blocks x, x + 8, x + 16 ... one after the other, its walkers draw (block, segment) tickets
+// from the team's counter -- no barrier between blocks: the stragglers of a block finish while the others are on the next one.
+__global__ void walk_tickets(const uint32_t* P, size_t n, uint32_t M, uint32_t blocks, uint32_t* counters, uint32_t* sink, uint32_t* xcd_seen) {
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    xcc &= 7u;
+    if (threadIdx.x == 0) atomicAdd(&xcd_seen[xcc], 1u);
+    const uint32_t segs = (uint32_t)((n + M - 1) / M);
+    const uint32_t team_blocks = (blocks + 7u - xcc) / 8u;            // blocks xcc, xcc + 8, ...
+    const uint64_t total = (uint64_t)team_blocks * segs;
+    uint32_t acc = 0;
+    for (;;) {
+        const uint32_t t = atomicAdd(&counters[xcc * 32], 1u);       // (a cache line per team)
+        if (t >= total) break;
+        const uint32_t b = xcc + 8u * (t / segs), sg = t % segs;
+        const uint32_t* p = P + (size_t)b * n;
+        uint32_t end = sg * M, steps = 0;
+        do { const uint32_t v = p[end]; end = v >> 8; acc += v & 255; steps++; } while (end % M != 0);
+        acc += steps;
+    }
+    sink[(blockIdx.x * blockDim.x + threadIdx.x) & 0xFFFFF] = acc;
+}
+
 int main(int argc, char** argv) {
     size_t blocks = argc > 1 ? atol(argv[1]) : 10240, n = argc > 2 ? atol(argv[2]) : 900000;
     int W = argc > 3 ? atoi(argv[3]) : 64, lds_kb = argc > 4 ? atoi(argv[4]) : 0;
@@ -72,7 +97,20 @@ int main(int argc, char** argv) {
     for (int rep = 0; rep < 2; rep++) {
         CK(hipEventRecord(e0));
         uint64_t gathers;
-        if (argc > 5) {   // mode 2: XCD-affine, argv[5] = passes over the block (steps = passes * n / walkers)
+        if (argc > 6) {   // mode 3: tickets, argv[5] = M, argv[6] = workgroups per CU
+            uint32_t M = (uint32_t)atoi(argv[5]);
+            int per_cu = atoi(argv[6]);
+            uint32_t *d_cnt, *d_seen;
+            CK(hipMalloc(&d_cnt, 8 * 32 * 4)); CK(hipMemset(d_cnt, 0, 8 * 32 * 4));
+            CK(hipMalloc(&d_seen, 8 * 4)); CK(hipMemset(d_seen, 0, 8 * 4));
+            CK(hipEventRecord(e0));
+            walk_tickets<<<256 * per_cu, W>>>(d_P, n, M, (uint32_t)blocks, d_cnt, d_sink, d_seen);
+            gathers = (uint64_t)n * blocks;
+            uint32_t seen[8];
+            CK(hipMemcpy(seen, d_seen, 32, hipMemcpyDeviceToHost));
+            if (rep == 0) printf("workgroups per XCD: %u %u %u %u %u %u %u %u\n", seen[0], seen[1], seen[2], seen[3], seen[4], seen[5], seen[6], seen[7]);
+            CK(hipFree(d_cnt)); CK(hipFree(d_seen));
+        } else if (argc > 5) {   // mode 2: XCD-affine, argv[5] = passes over the block (steps = passes * n / walkers)
             int passes = atoi(argv[5]);
             uint32_t walkers = 32 * W;
             uint32_t steps = (uint32_t)((uint64_t)passes * n / walkers);
