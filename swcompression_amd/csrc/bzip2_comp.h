@@ -48,7 +48,10 @@ constexpr uint32_t kStageDw = 256, kFlushDw = 128;
 constexpr uint64_t kBlockMagic = 0x314159265359ull;
 constexpr uint64_t kEosMagic = 0x177245385090ull;
 constexpr uint32_t kBlocksPerLaunch = 64;    // <= 256 (the block index is the top byte of the first sort key)
-constexpr uint32_t kFirstBytes = 7;
+#ifndef SWC_BZ2C_FIRST_BYTES
+#define SWC_BZ2C_FIRST_BYTES 7
+#endif
+constexpr uint32_t kFirstBytes = SWC_BZ2C_FIRST_BYTES;   // 5 / 6 / 7 measured: profiles/r05_experiments.txt
 
 // what a block's stages hand to each other (HBM, one per block)
 struct BlockInfo {
@@ -670,6 +673,7 @@ struct Bwt {
     SWC_AS_GLOBAL uint32_t* head;         // first element of my key group (after the max scan)
     SWC_AS_GLOBAL uint32_t* keep;         // 1: stays in the working set
     SWC_AS_GLOBAL uint32_t* kpos;         // exclusive prefix sum of keep
+    SWC_AS_GLOBAL uint32_t* next_m;       // size of the next working set (one word the host reads each round)
     SWC_AS_GLOBAL uint8_t* col;           // the last column, block after block
     SWC_AS_GLOBAL BlockInfo* infos;
     uint32_t m, h, rank_bits;
@@ -719,6 +723,7 @@ struct Ranks {         // (after the max scan of head)
 struct Compact {       // (after the sum scan of keep)
     Bwt c;
     SWC_HD void operator()(uint32_t p) const {
+        if (p + 1u == c.m) *c.next_m = c.kpos[p] + c.keep[p];
         if (!c.keep[p]) return;
         const uint32_t q = c.kpos[p];
         c.val_in[q] = c.val_out[p];
@@ -843,7 +848,7 @@ int compress_stream(X& x, const uint8_t* data, size_t len, int level, uint8_t** 
         const size_t bound = chunk_len + chunk_len / 4 + 16 * (size_t)nb + 16;    // after rle1, at most
         const size_t t4 = 4 * bound + 16, t8 = 8 * bound + 16;
         uint8_t* d_raw = (uint8_t*)x.alloc(chunk_len + 16);
-        uint32_t* d_offs = (uint32_t*)x.alloc(4 * (size_t)(nb + 1) * 4);            // off | blk_at | seg_off | (spare)
+        uint32_t* d_offs = (uint32_t*)x.alloc(4 * (size_t)(nb + 1) * 4);            // off | blk_at | seg_off | the sort's word
         BlockInfo* d_infos = (BlockInfo*)x.alloc(sizeof(BlockInfo) * nb);
         uint8_t* d_text = (uint8_t*)x.alloc(bound + 16);
         uint8_t* d_blk = (uint8_t*)x.alloc(bound + 16);
@@ -922,6 +927,7 @@ int compress_stream(X& x, const uint8_t* data, size_t len, int level, uint8_t** 
             c.head = (SWC_AS_GLOBAL uint32_t*)d_head;
             c.keep = (SWC_AS_GLOBAL uint32_t*)d_keep;
             c.kpos = (SWC_AS_GLOBAL uint32_t*)d_kpos;
+            c.next_m = (SWC_AS_GLOBAL uint32_t*)(d_offs + 3 * (nb + 1));
             c.col = (SWC_AS_GLOBAL uint8_t*)d_col;
             c.slot = nullptr;
             c.slot_next = (SWC_AS_GLOBAL uint32_t*)d_s0;
@@ -943,10 +949,9 @@ int compress_stream(X& x, const uint8_t* data, size_t len, int level, uint8_t** 
                 x.each(c.m, Ranks{c});
                 if (x.scan_sum(d_keep, d_kpos, c.m)) return SWC_E_DEVICE;
                 x.each(c.m, Compact{c});
-                uint32_t last[2] = {0, 0};
-                x.download(&last[0], d_kpos + (c.m - 1u), 4);
-                x.download(&last[1], d_keep + (c.m - 1u), 4);
-                c.m = last[0] + last[1];
+                uint32_t next_m = 0;
+                x.download(&next_m, d_offs + 3 * (nb + 1), 4);
+                c.m = next_m;
                 c.slot = c.slot_next;
                 which ^= 1;
                 c.slot_next = (SWC_AS_GLOBAL uint32_t*)slot_bufs[which];
