@@ -279,7 +279,10 @@ const char* swc_version(void);
  *   "lz_copier" = 1 | 0 | 2 | -1 | -2   process-wide: the LZ77 copy phase of Deflate / LZ4 launches -- 1 (default): one stream
  *                               per wave with an 8 KiB LDS window (csrc/lz_copy.h) for launches of 2,560 streams and more,
  *                               one stream per 512-thread workgroup (csrc/lz_resolve.h) below; 0: the workgroup kernel always;
- *                               2: the wave kernel with a 16 KiB window; -1 / -2: the wave kernel whatever the launch size. */
+ *                               2: the wave kernel with a 16 KiB window; -1 / -2: the wave kernel whatever the launch size;
+ *   "bzip2_hot_cxx" = 0 | 1     process-wide: BZip2 launches run the instantiation of the block kernel whose plain-symbol loop is
+ *                               compiled from C++ (1) instead of the hand-written assembly (0, default) -- the two are compared
+ *                               by the GPU tests. */
 int swc_set_tuning(const char* key, int value);
 /* Profile builds of the library (-DSWC_PROFILE) only: a device buffer of 32 x uint64 per job of the next Deflate
  * launches that the kernels fill with cycle counts per stage (tools/exp_profile.py).  NULL switches it off.  A no-op in

@@ -259,7 +259,9 @@ SWC_HD bool walk_tick(Walk& W) {
 #endif
 }
 
-template <int WAVE>
+// CXX: the plain-symbol loop from its C++ twin instead of the assembly (the host build always; on the device the tuning value
+// "bzip2_hot_cxx" selects a second instantiation of the kernel, which the GPU tier compares with the default one)
+template <int WAVE, bool CXX = false>
 struct Stage1 {
     Stage1Lds* s;
     MsbReader br;
@@ -499,10 +501,9 @@ struct Stage1 {
     enum { kGroupDone = 0, kSymbol = 1, kIndex = 2 };
     SWC_HD int hot_symbols(Loop& L, int& i, uint32_t& pending, uint32_t& pending_len) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(SWC_BZ_HOT_CXX)
-        return hot_symbols_isa(L, i, pending, pending_len);
-#else
-        return hot_symbols_cxx(L, i, pending, pending_len);
+        if (!CXX) return hot_symbols_isa(L, i, pending, pending_len);
 #endif
+        return hot_symbols_cxx(L, i, pending, pending_len);
     }
 #if defined(__HIP_DEVICE_COMPILE__)
     // The same loop as hot_symbols_cxx below, written in gfx950 assembly: 32 instructions per byte symbol and 24 per RUNA /
@@ -840,9 +841,9 @@ struct Stage1 {
 };
 
 // Stage 1 entry.  job.dict_len = bit offset of the block body (just past the 48-bit magic and the CRC).
-template <int WAVE>
+template <int WAVE, bool CXX = false>
 SWC_HD void stage1_job(const Job& job, Stage1Lds* lds, Workspace ws, int lane) {
-    Stage1<WAVE> d;
+    Stage1<WAVE, CXX> d;
     d.s = lds;
     d.ws = ws;
     d.lane = lane;

@@ -309,41 +309,52 @@ int swc_lz4_compress(const uint8_t* data, size_t len, int independent_blocks, in
     if (content_size) for (int i = 0; i < 8; i++) res.push_back((uint8_t)((uint64_t)len >> (8 * i)));                          // :78-83
     if (dict_id >= 0) for (int i = 0; i < 4; i++) res.push_back((uint8_t)((uint32_t)dict_id >> (8 * i)));                      // :85-89
     res.push_back((uint8_t)((swc_xxh32(res.data() + 4, res.size() - 4, 0) >> 8) & 0xFF));                                       // :92-93
-    // units: prefix ++ block in one buffer per block (the prefix: at most the last 64 KiB of the dictionary / previous block)
+    // units: the kernel wants prefix ++ block in one piece (the prefix: at most the last 64 KiB of the dictionary / previous block).
+    // A dependent block's prefix is the input right in front of it: the unit addresses `data` in place, and the units share
+    // ONE staged copy of it (HostUnit::base).  Only a DICTIONARY prefix has to be joined with its block on the host; those
+    // units go in rounds of at most kJoinBudget bytes (small independent blocks with a dictionary: 64 KiB of prefix each).
     const size_t nblk = (len + block_size - 1) / block_size;
-    std::vector<HostUnit> units(nblk);
-    std::vector<std::vector<uint8_t>> joined(nblk);
+    constexpr size_t kJoinBudget = (size_t)256 << 20;
+    std::vector<std::vector<uint8_t>> comp(nblk);
     const uint8_t* d0 = dict ? dict + (dict_len > 65536 ? dict_len - 65536 : 0) : nullptr;                                      // :98-99
     const size_t d0n = dict ? std::min<size_t>(dict_len, 65536) : 0;
-    for (size_t b = 0; b < nblk; b++) {
-        const size_t at = b * block_size, n = std::min(block_size, len - at);
-        const uint8_t* pre = d0;
-        size_t pren = d0n;
-        if (!independent_blocks && b > 0) {   // :112-116 the previous block's data, its last 64 KiB
-            const size_t pn = std::min(block_size, (size_t)65536);
-            pre = data + at - pn; pren = pn;
+    for (size_t b0 = 0; b0 < nblk;) {
+        std::vector<HostUnit> units;
+        std::vector<std::vector<uint8_t>> joined;
+        size_t b1 = b0, joined_bytes = 0;
+        for (; b1 < nblk; b1++) {
+            const size_t at = b1 * block_size, n = std::min(block_size, len - at);
+            const bool in_place = !independent_blocks && b1 > 0;                   // :112-116 the previous block's data, its last 64 KiB
+            const size_t pren = in_place ? std::min(block_size, (size_t)65536) : d0n;
+            if (!in_place && pren && b1 > b0 && joined_bytes + pren + n > kJoinBudget) break;
+            units.emplace_back();
+            HostUnit& u = units.back();
+            if (in_place) { u.in = data + at - pren; u.in_len = pren + n; u.base = data; u.base_len = len; }
+            else if (pren == 0) { u.in = data + at; u.in_len = n; u.base = data; u.base_len = len; }
+            else {
+                joined.emplace_back(pren + n);
+                memcpy(joined.back().data(), d0, pren);
+                memcpy(joined.back().data() + pren, data + at, n);
+                joined_bytes += pren + n;
+                u.in_len = pren + n;      // (u.in below: the vector of vectors may still grow)
+            }
+            u.extra = pren;
+            u.cap_hint = n + n / 255 + 16;
+            u.cap_exact = true;
         }
-        HostUnit& u = units[b];
-        if (pren == 0) { u.in = data + at; u.in_len = n; }
-        else {
-            joined[b].resize(pren + n);
-            memcpy(joined[b].data(), pre, pren);
-            memcpy(joined[b].data() + pren, data + at, n);
-            u.in = joined[b].data(); u.in_len = pren + n;
-        }
-        u.extra = pren;
-        u.cap_hint = n + n / 255 + 16;
-        u.cap_exact = true;
-    }
-    if (nblk) {
+        for (size_t k = 0, jn = 0; k < units.size(); k++) if (!units[k].in) units[k].in = joined[jn++].data();
         const int st = run_units(SWC_CODEC_LZ4_COMPRESS, units);
         if (st) { give_empty(out, out_len); return st; }
-        for (const HostUnit& u : units) if (u.status != SWC_OK) { give_empty(out, out_len); return SWC_E_DEVICE; }
+        for (size_t k = 0; k < units.size(); k++) {
+            if (units[k].status != SWC_OK) { give_empty(out, out_len); return SWC_E_DEVICE; }
+            comp[b0 + k] = std::move(units[k].out);
+        }
+        b0 = b1;
     }
     auto put32 = [&](uint32_t v) { for (int i = 0; i < 4; i++) res.push_back((uint8_t)(v >> (8 * i))); };
     for (size_t b = 0; b < nblk; b++) {
         const size_t at = b * block_size, n = std::min(block_size, len - at);
-        const std::vector<uint8_t>& c = units[b].out;
+        const std::vector<uint8_t>& c = comp[b];
         if (c.size() > n) {   // :119 not compressible: stored
             put32(0x80000000u | (uint32_t)n);
             res.insert(res.end(), data + at, data + at + n);

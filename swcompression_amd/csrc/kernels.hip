@@ -445,13 +445,16 @@ static_assert(kBzLdsBytes >= 256 * sizeof(uint32_t), "stage 2 counters");
 #ifndef SWC_BZ_WAVES
 #define SWC_BZ_WAVES 6   // (7: 72 VGPRs + 8 bytes of scratch, 28 waves per CU, 495 ms against 479 -- the walk is at the gather rate, more waves do not add to it)
 #endif
+// CXX: the plain-symbol loop of stage 1 compiled from its C++ twin instead of the hand-written assembly ("bzip2_hot_cxx",
+// swc_set_tuning: the differential GPU test of the two, tests/test_gpu_bzip2.py)
+template <bool CXX>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_BZ_WAVES))) void swc_bzip2_block_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t lcap) {
     __shared__ __attribute__((aligned(16))) uint8_t bz_lds[kBzLdsBytes];
     uint32_t g = xcd_job(blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];
     const bzip2::Workspace w = bzip2::carve(ws, g, lcap);
-    bzip2::stage1_job<kWave>(job, reinterpret_cast<bzip2::Stage1Lds*>(bz_lds), w, (int)threadIdx.x);
+    bzip2::stage1_job<kWave, CXX>(job, reinterpret_cast<bzip2::Stage1Lds*>(bz_lds), w, (int)threadIdx.x);
 #if defined(SWC_BZ_STOP_AFTER) && SWC_BZ_STOP_AFTER == 1   // (timing experiments only, tools/exp_bz_stages.py: wrong results)
     if (threadIdx.x == 0) { w.hdr->pad = bzip2::kWalkDone; jobs[g].status = SWC_E_DEVICE; }
     return;
@@ -502,6 +505,8 @@ __global__ __launch_bounds__(256) void swc_bzip2_crc_kernel(Job* __restrict__ jo
 }
 
 size_t bzip2_ws_bytes_per_job(size_t lcap) { return bzip2::ws_bytes_per_job(lcap); }
+static std::atomic<int> g_bzip2_hot_cxx{0};
+void set_bzip2_hot_cxx(int v) { g_bzip2_hot_cxx = v; }
 
 hipError_t launch_bzip2(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {
     if (n == 0) return hipSuccess;
@@ -518,7 +523,8 @@ hipError_t launch_bzip2(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStrea
     const size_t lcap = lo;
     dim3 block(kWave);
     g_pt.begin(stream);
-    hipLaunchKernelGGL(swc_bzip2_block_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
+    if (g_bzip2_hot_cxx) hipLaunchKernelGGL(swc_bzip2_block_kernel<true>, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
+    else hipLaunchKernelGGL(swc_bzip2_block_kernel<false>, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
     g_pt.mark(stream);
     hipLaunchKernelGGL(swc_bzip2_expand_kernel, dim3((unsigned)((n + kWave - 1) / kWave)), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
     g_pt.mark(stream);

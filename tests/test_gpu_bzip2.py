@@ -117,3 +117,50 @@ def test_symbol_loop_boundaries():
     for i, (z, x) in enumerate(one):
         assert int(r["status"][i]) == 0 and int(r["out_len"][i]) == len(x), (i, int(r["status"][i]))
         assert b.output(i, len(x)) == x
+
+
+def _decode_both(z):
+    """(status, data) of BZip2.decompress under the assembly loop and under its C++ twin (tuning "bzip2_hot_cxx")."""
+    from swcompression_amd import _lib
+    lib = _lib.load()
+    res = []
+    for cxx in (0, 1):
+        assert lib.swc_set_tuning(b"bzip2_hot_cxx", cxx) == 0
+        try:
+            res.append((0, swc.BZip2.decompress(z)))
+        except swc.SWCError as e:
+            res.append((e.status, e.data))
+        finally:
+            lib.swc_set_tuning(b"bzip2_hot_cxx", 0)
+    return res
+
+
+def test_assembly_loop_against_its_cxx_twin():
+    """hot_symbols_isa (hand-written gfx950 assembly, the default) and hot_symbols_cxx (what the CPU tier runs) are two
+    instantiations of the block kernel: same status and same bytes on streams of three encoders -- libbz2 (six refined tables),
+    the reference encoder restated (tables from 50 symbols, lengths up to 20 bits for the deep symbols) and the engine's own (one
+    table, up to 17 bits) -- on long zero runs (the staging limit of the run path), and on streams cut short at every byte of
+    the last 200 (a group that ends inside the window the look-ahead loads guard, bzip2_block.h: br.next + 184 > br.n)."""
+    rnd = random.Random(17)
+    skew = bytes(min(255, int(rnd.expovariate(0.05))) for _ in range(200000))            # geometric byte values: long codes
+    runs = b"".join(bytes([rnd.randrange(3)]) * rnd.choice([1, 2, 3, 4, 5, 63, 64, 65, 255, 256, 1000, 70000]) for _ in range(300))
+    plains = [corpus.p_text(300000, 61), corpus.p_mix(200000, 62), corpus.p_rand(50000, 63), skew, runs, bytes(range(256)) * 300,
+              b"ab" * 50000, corpus.p_text(1000, 64), b"a"]
+    streams = []
+    for x in plains:
+        streams.append((bz2.compress(x, 1), x))
+        streams.append((bz2.compress(x, 9), x))
+        streams.append((swc.BZip2.compress(x, 1), x))
+        if len(x) <= 300000:
+            streams.append((O.bzip2_compress(x, 1), x))
+    for z, x in streams:
+        a, b = _decode_both(z)
+        assert a == b == (0, x)
+    O.lib.refcpu_set_max_output(1 << 24)
+    for z, x in streams[:12:3] + streams[-3:]:
+        for cut in list(range(1, 200, 1)):
+            if cut >= len(z):
+                break
+            a, b = _decode_both(z[:-cut])
+            assert a == b, (len(z), cut, a[0], b[0])
+    O.lib.refcpu_set_max_output(1 << 30)

@@ -135,6 +135,25 @@ def test_gpu_frames_decode_with_oracle_liblz4_and_own_decoder():
 
 
 @pytest.mark.gpu
+def test_gpu_prefixes_in_place_and_in_rounds():
+    """Dependent blocks address the input in front of them in place (odd block sizes: the units start anywhere); small
+    independent blocks with a 64 KiB dictionary -- 64 KiB of joined prefix per KiB of data -- go in bounded rounds."""
+    import swcompression_amd as swc
+    O.lib.refcpu_set_max_output(1 << 24)
+    x = corpus.p_text(700000, 31) + corpus.p_mix(300001, 32)
+    d = corpus.p_text(70000, 33)
+    for kw in (dict(independent_blocks=False, block_size=1000), dict(independent_blocks=False, block_size=65537, dictionary=d),
+               dict(independent_blocks=False, block_size=99999), dict(independent_blocks=True, block_size=173)):
+        f = swc.LZ4.compress(x, **kw)
+        assert O.lz4(f, kw.get("dictionary"))[:2] == (0, x), kw
+        assert swc.LZ4.decompress(f, kw.get("dictionary")) == x
+    y = corpus.p_text(6 << 20, 34)                                     # 6,144 blocks of 1 KiB x (64 KiB + 1 KiB) = 400 MB joined: two rounds
+    f = swc.LZ4.compress(y, independent_blocks=True, block_size=1024, dictionary=d)
+    assert O.lz4(f, d)[:2] == (0, y)
+    O.lib.refcpu_set_max_output(1 << 30)
+
+
+@pytest.mark.gpu
 def test_gpu_batch_codec_many_blocks():
     from swcompression_amd.batch import DeviceBatch
     plains = [corpus.PAYLOADS[k](n, 5 + i) for i, (k, n) in enumerate([("text", 65536), ("mix", 65536), ("rand", 4000), ("zero", 65536), ("rep", 30000)] * 40)]
