@@ -8,4 +8,6 @@ for W in deflate64k lz4_4m bzip2_900k lzma2_256k deflate64k_mix lz4_compress_4m 
   cp $O/${W}_traffic.json $P/${TAG}_${W}_traffic.json 2>/dev/null
   cp $O/sq_counters_$W.txt $P/${TAG}_sq_counters_$W.txt 2>/dev/null
 done
+cp $O/kernel_stats_bzip2_compress.txt $P/${TAG}_kernel_stats_bzip2_compress.txt 2>/dev/null
+cp $O/bzip2_compress_timing.txt $P/${TAG}_bzip2_compress_timing.txt 2>/dev/null
 ls $P | grep "^$TAG"

@@ -1,7 +1,7 @@
 #!/bin/bash
 # End-of-round evidence from the shipped build: the GPU test tier, smoke(), the driver's bench command, and for EVERY
 # workload (deflate64k lz4_4m bzip2_900k lzma2_256k) a rocprofv3 kernel trace, the PMC traffic passes and the SQ counter
-# passes.  Usage: gpu_final.sh <tag> [parts...]   parts: tests bench trace pmc sq (default: all)
+# passes.  Usage: gpu_final.sh <tag> [parts...]   parts: tests bench trace pmc sq bzc (default: all but bzc)
 # Outputs under gpurun_out/<tag>/; tools/collect_profiles.sh <tag> copies what is to be judged into profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-final}; shift; PARTS=${@:-tests bench trace pmc sq}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
 WL=${WL:-"deflate64k lz4_4m bzip2_900k lzma2_256k"}; XWL=${XWL-"deflate64k_mix lz4_compress_4m deflate_compress_64k"}
@@ -33,6 +33,10 @@ except Exception as e:
     print("$W traffic: failed", e)
 PY
   done ;;
+bzc)   # BZip2.compress (host to host): timing with the stage trace, and a kernel trace of the same command
+  SWC_BZ2C_TRACE=1 timeout 300 python tools/exp_bzip2_compress.py 32 9 > $O/bzip2_compress_timing.txt 2>&1; grep -v "^\[bz2c\]\|amdgpu" $O/bzip2_compress_timing.txt
+  ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_bzc -o bzc -- python $R/tools/exp_bzip2_compress.py 32 9 > $O/trace_bzc.log 2>&1 ); echo "trace bzc rc=$?"
+  python tools/rocpd_summary.py $O/trace_bzc/bzc_results.db > $O/kernel_stats_bzip2_compress.txt 2>&1; head -8 $O/kernel_stats_bzip2_compress.txt ;;
 sq)
   for W in $WL; do bash tools/pmc_sq.sh $W $TAG > /dev/null 2>&1; cp gpurun_out/pmc_sq_${TAG}_$W/summary.txt $O/sq_counters_$W.txt 2>/dev/null; head -12 $O/sq_counters_$W.txt; done ;;
 esac; done
