@@ -150,9 +150,10 @@ int swc_zlib_archive(const uint8_t* data, size_t len, uint8_t** out, size_t* out
 /* BZip2.compress(data:blockSize:) BZip2+Compress.swift:40-74 (BZip2.compress(data:) :19-21 = block_size 1).  block_size 1..9 =
  * BlockSize.one ... .nine (else SWC_E_INVALID_ARGUMENT); the input is cut into blocks of block_size x 80,000 bytes as the
  * reference cuts it (:46), all blocks are compressed on the device together: initial run-length coding, Burrows-Wheeler
- * transform (prefix doubling over all blocks at once), move-to-front and zero-run coding, Huffman coding with one table per
- * block built from the block's own symbol counts.  The stream decodes to `data` with the reference's decoder and with
- * libbz2; its bytes are not the reference encoder's (which picks among up to six tables per 50 symbols). */
+ * transform (prefix doubling over all blocks at once), move-to-front and zero-run coding, Huffman coding with up to six
+ * tables per block, one per group of 50 symbols, refined in four passes over all groups (bzip2's scheme).  The stream decodes
+ * to `data` with the reference's decoder and with libbz2; its bytes are not the reference encoder's (which builds each of its
+ * tables from a single group of 50 symbols). */
 int swc_bzip2_compress(const uint8_t* data, size_t len, int block_size, uint8_t** out, size_t* out_len);
 /* LZ4.multiDecompress(data:dictionary:dictionaryID:) LZ4.swift:116-146 */
 int swc_lz4_multi_decompress(const uint8_t* in, size_t in_len, const uint8_t* dict, size_t dict_len, int64_t dict_id,

@@ -18,17 +18,17 @@
 //             RUNB digits (bijective base 2), the end-of-block symbol (:277-325).  The list in front of a segment follows from
 //             the last positions of the byte values before it; inside, a byte equal to its predecessor IS a zero, so a ballot
 //             per 64 bytes finds the positions that change the list and only those are walked (section "mtf");
-//   lengths   the HOST turns a block's frequencies into code lengths and canonical codes (huffman_lengths: a Huffman tree,
-//             weights flattened until no code is longer than 17 bits, as bzip2 itself does) -- 258 numbers per block;
+//   tables    up to six Huffman tables per block, a table per group of 50 symbols (:89-147), refined the way bzip2 refines them:
+//             four times -- every group picks its cheapest table (a thread per group), the symbols of a table's groups are
+//             counted, every table gets new code lengths from its counts (a wavefront per table; section "tables");
 //   emit      one wavefront per segment: the bit every segment starts at from two small scans, then 64 codes per step -- a
 //             wave scan of the code lengths for the places, ds_or_b32 into a staging area of the MSB-first bit stream in LDS,
 //             byte-swapped dwords to HBM, straight into the stream.  The first segment of a block writes its header: magic, CRC,
-//             origin pointer, the map of used bytes, TWO identical tables (the format wants two; the reference duplicates its
-//             only one the same way, :142-147) with all selectors zero, the code lengths in delta form.
+//             origin pointer, the map of used bytes, the selectors after move-to-front in unary, the code lengths in delta form.
 //
 // The contract is that of the other two encoders: A valid bzip2 stream for the same bytes with the reference's block
-// cutting (level x 80,000 raw bytes per block, :46), not the reference's bytes (the reference builds up to six tables with a
-// greedy per-50-symbols rule, :95-139; one table built from the block's own frequencies is what this version has).
+// cutting (level x 80,000 raw bytes per block, :46), not the reference's bytes (the reference builds each of its up to six
+// tables from ONE group of 50 symbols and keeps it if it beats the others, :95-139; here the tables are refined over all groups).
 // Parity = decode(compress(x)) == x under the reference's decoder (the oracle), libbz2 and the engine's own decoder.
 //
 // The stages are written once, as functors over an EXECUTOR (compress_stream<X>): the device executor (bzip2_compress.hip)
@@ -51,6 +51,8 @@ constexpr uint32_t kBlocksPerLaunch = 64;    // <= 256 (the block index is the t
 #ifndef SWC_BZ2C_FIRST_BYTES
 #define SWC_BZ2C_FIRST_BYTES 7
 #endif
+constexpr uint32_t kMaxTables = 6, kGroup = 50, kTableIters = 4, kSymStride = kMaxSyms + 2;
+constexpr uint32_t kGroupsPerWave = 1024;    // table choice: groups a wavefront goes through (16 per lane)
 constexpr uint32_t kFirstBytes = SWC_BZ2C_FIRST_BYTES;   // 5 / 6 / 7 measured: profiles/r05_experiments.txt
 
 // what a block's stages hand to each other (HBM, one per block)
@@ -65,7 +67,9 @@ struct BlockInfo {
     uint32_t head_bits;    // from the host: bits in front of the first symbol
     uint32_t used[8];      // bit b of word w: byte 32 w + b occurs
     uint32_t freq[kMaxSyms + 2];
-    uint32_t code[kMaxSyms + 2];   // from the host: canonical code | length << 24
+    uint32_t n_tables;     // from the host: Huffman tables of the block (2..6)
+    uint32_t n_groups;     // ... and groups of 50 symbols (= selectors)
+    uint32_t pad[2];
 };
 SWC_HD uint32_t align16(uint32_t v) { return (v + 15u) & ~15u; }
 SWC_HD uint32_t rle1_bound(uint32_t n) { return align16(n + n / 4u + 16u); }
@@ -165,12 +169,22 @@ struct Segs {
     SWC_AS_GLOBAL uint8_t* used;              // [block][256]
     SWC_AS_GLOBAL uint16_t* syms;             // [segment][kSegSyms]
     SWC_AS_GLOBAL uint32_t* seg_nsym;
+    SWC_AS_GLOBAL uint32_t* seg_sym_at;       // symbols of the block in front of the segment
+    SWC_AS_GLOBAL uint16_t* csyms;            // the blocks' symbols, one behind the other
+    const SWC_AS_GLOBAL uint32_t* sym_off;    // first symbol of every block in csyms, n_blocks + 1
+    const SWC_AS_GLOBAL uint32_t* grp_off;    // first group of every block, n_blocks + 1
+    SWC_AS_GLOBAL uint8_t* sel;               // table of every group of 50 symbols
+    SWC_AS_GLOBAL uint8_t* selmtf;            // ... after move-to-front
+    SWC_AS_GLOBAL uint32_t* rfreq;            // [block][table][kSymStride]: how often a table's groups hold a symbol
+    SWC_AS_GLOBAL uint8_t* len8;              // [block][table][kSymStride]: code lengths
+    SWC_AS_GLOBAL uint32_t* codes;            // [block][table][kSymStride]: canonical code | length << 24
     SWC_AS_GLOBAL uint32_t* seg_bits;         // bits of the segment's symbols
     SWC_AS_GLOBAL uint32_t* seg_at;           // ... and where they start in the block's bit stream
     SWC_AS_GLOBAL uint8_t* stream;            // the bits of all blocks of the launch, one behind the other (zeroed)
     SWC_AS_GLOBAL uint32_t* blk_at;           // bit every block starts at in it, n_blocks + 1
     SWC_AS_GLOBAL BlockInfo* infos;
     uint32_t nb, stream_cap, lead;            // lead: the first block starts at this bit (the stream so far ends inside a dword)
+    uint32_t cost_waves;                      // table choice: wavefronts per block in the grid
 };
 SWC_D void lds_max(uint32_t* p, uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -405,16 +419,201 @@ struct MtfSeg {        // a wavefront per segment
     }
 };
 
+// ================================================================================================================ tables
+// BZip2+Compress.swift:89-147 chooses among up to six Huffman tables per group of 50 symbols.  The reference builds a table from
+// one group and keeps it if it beats the tables so far; here the tables are REFINED the way bzip2 itself does it: start from
+// n tables that each favour a range of the alphabet (equal shares of the symbol counts), then four times -- every group picks
+// the table that codes it in the fewest bits (a thread per group: the six lengths of a symbol sit packed in two LDS words,
+// a group's six costs are two sums), the symbols of a table's groups are counted, and every table gets new code lengths
+// from its counts (a wavefront per table: rank sort, the two-queue Huffman construction by one lane, depths and canonical
+// codes by all).  The symbols of a block must lie one behind the other for that (groups do not respect segments): sym_scan /
+// sym_compact.
+template <int N>
+SWC_D void wave_excl_scan_to(const SWC_AS_GLOBAL uint32_t* in, SWC_AS_GLOBAL uint32_t* out, uint32_t lo, uint32_t hi, uint32_t& carry) {
+    for (uint32_t s0 = lo; s0 < hi; s0 += (uint32_t)N) {
+        simt::PT<uint32_t, N> x, own;
+        SIMT_BEGIN(t, N) own[t] = s0 + (uint32_t)t < hi ? in[s0 + (uint32_t)t] : 0u; x[t] = own[t]; SIMT_END
+        simt::wave_scan_incl<N>(x);
+        const uint32_t at = carry;
+        SIMT_BEGIN(t, N) if (s0 + (uint32_t)t < hi) out[s0 + (uint32_t)t] = at + x[t] - own[t]; SIMT_END
+        carry += simt::wave_read<N>(x, N - 1);
+    }
+}
+struct SymScan {       // a wavefront per block
+    Segs c;
+    typedef NoLds Lds;
+    template <int N> SWC_D void run(uint32_t b, Lds*) const {
+        uint32_t at = 0;
+        wave_excl_scan_to<N>(c.seg_nsym, c.seg_sym_at, c.seg_off[b], c.seg_off[b + 1u], at);
+    }
+};
+struct SymCompact {    // a wavefront per segment
+    Segs c;
+    typedef NoLds Lds;
+    template <int N> SWC_D void run(uint32_t s, Lds*) const {
+        const uint32_t n = c.seg_nsym[s];
+        const SWC_AS_GLOBAL uint16_t* src = c.syms + (size_t)kSegSyms * s;
+        SWC_AS_GLOBAL uint16_t* dst = c.csyms + c.sym_off[c.seg_blk[s]] + c.seg_sym_at[s];
+        SIMT_BEGIN(t, N) for (uint32_t i = (uint32_t)t; i < n; i += (uint32_t)N) dst[i] = src[i]; SIMT_END
+    }
+};
+struct CostLds {
+    uint32_t plen[kSymStride][2];             // lengths of tables 0-2 / 3-5, ten bits each (a group's sums stay below 1,024)
+    uint32_t rfreq[kMaxTables][kSymStride];
+};
+struct GroupCost {     // a wavefront per kGroupsPerWave groups of a block
+    Segs c;
+    typedef CostLds Lds;
+    template <int N> SWC_D void run(uint32_t idx, Lds* lds) const {
+        const uint32_t b = idx / c.cost_waves, w = idx % c.cost_waves;
+        const SWC_AS_GLOBAL BlockInfo* info = c.infos + b;
+        const uint32_t n_groups = info->n_groups, n_tables = info->n_tables, n_sym = info->n_sym, alpha = info->n_used + 2u;
+        const uint32_t g0 = w * kGroupsPerWave;
+        if (g0 >= n_groups) return;
+        const SWC_AS_GLOBAL uint8_t* len8 = c.len8 + (size_t)b * kMaxTables * kSymStride;
+        SIMT_BEGIN(t, N)
+            for (uint32_t sy = (uint32_t)t; sy < kSymStride; sy += (uint32_t)N) {
+                uint32_t p0 = 0, p1 = 0;
+                for (uint32_t k = 0; k < 3u; k++) {
+                    p0 |= (sy < alpha && k < n_tables ? (uint32_t)len8[k * kSymStride + sy] : 20u) << (10u * k);
+                    p1 |= (sy < alpha && k + 3u < n_tables ? (uint32_t)len8[(k + 3u) * kSymStride + sy] : 20u) << (10u * k);
+                }
+                lds->plen[sy][0] = p0; lds->plen[sy][1] = p1;
+            }
+            for (uint32_t i = (uint32_t)t; i < kMaxTables * kSymStride; i += (uint32_t)N) (&lds->rfreq[0][0])[i] = 0u;
+        SIMT_END_WAVE
+        const SWC_AS_GLOBAL uint16_t* sy = c.csyms + c.sym_off[b];
+        SWC_AS_GLOBAL uint8_t* sel = c.sel + c.grp_off[b];
+        SIMT_BEGIN(t, N)
+            for (uint32_t g = g0 + (uint32_t)t; g < n_groups && g < g0 + kGroupsPerWave; g += (uint32_t)N) {
+                const uint32_t lo = g * kGroup, hi = lo + kGroup < n_sym ? lo + kGroup : n_sym;
+                uint32_t c0 = 0, c1 = 0;
+                for (uint32_t i = lo; i < hi; i++) { const uint32_t v = sy[i]; c0 += lds->plen[v][0]; c1 += lds->plen[v][1]; }
+                uint32_t best = 0, cost = c0 & 1023u;
+                for (uint32_t k = 1; k < n_tables; k++) {
+                    const uint32_t ck = ((k < 3u ? c0 : c1) >> (10u * (k % 3u))) & 1023u;
+                    if (ck < cost) { cost = ck; best = k; }
+                }
+                sel[g] = (uint8_t)best;
+                for (uint32_t i = lo; i < hi; i++) lds_inc(&lds->rfreq[best][sy[i]]);
+            }
+        SIMT_END_WAVE
+        SWC_AS_GLOBAL uint32_t* rf = c.rfreq + (size_t)b * kMaxTables * kSymStride;
+        SIMT_BEGIN(t, N)
+            for (uint32_t i = (uint32_t)t; i < kMaxTables * kSymStride; i += (uint32_t)N) {
+                const uint32_t v = (&lds->rfreq[0][0])[i];
+                if (v) global_add(rf + i, v);
+            }
+        SIMT_END
+    }
+};
+struct HuffLds {
+    uint32_t w[kSymStride];          // weights
+    uint32_t order[kSymStride];      // symbols by weight
+    uint32_t wt[kSymStride];         // inner nodes, in order of creation (= of weight)
+    uint32_t parent_leaf[kSymStride];
+    uint32_t parent_inner[kSymStride];
+    uint32_t depth_inner[kSymStride];
+    uint32_t len[kSymStride];
+    uint32_t count[24], base[24];
+};
+// Code lengths (no code longer than max_len: weights halved until that holds, as bzip2's hbMakeCodeLengths does) and canonical
+// codes of one table from the counts of its symbols; a symbol that does not occur counts as one.
+template <int N>
+SWC_D void huffman_wave(HuffLds* l, uint32_t alpha, uint32_t max_len) {
+    using simt::PT;
+    for (;;) {
+        // ---- the symbols in order of weight (ties: by symbol): every lane ranks its symbols against all
+        SIMT_BEGIN(t, N)
+            for (uint32_t s = (uint32_t)t; s < alpha; s += (uint32_t)N) {
+                const uint32_t ws = l->w[s];
+                uint32_t r = 0;
+                for (uint32_t k = 0; k < alpha; k++) { const uint32_t wk = l->w[k]; r += wk < ws || (wk == ws && k < s) ? 1u : 0u; }
+                l->order[r] = s;
+            }
+        SIMT_END_WAVE
+        // ---- two queues: the lightest two of (next leaf, next inner node) are joined; inner nodes come into being in order of weight
+        uint32_t made = 0;
+        SIMT_BEGIN(t, N)
+            if (t == 0) {
+                uint32_t nl = 0, ni = 0, m = 0;
+                while (alpha - nl + m - ni > 1u) {
+                    uint32_t sum = 0;
+                    for (int k = 0; k < 2; k++) {
+                        if (nl < alpha && (ni >= m || l->w[l->order[nl]] <= l->wt[ni])) { const uint32_t s = l->order[nl++]; l->parent_leaf[s] = m; sum += l->w[s]; }
+                        else { l->parent_inner[ni] = m; sum += l->wt[ni++]; }
+                    }
+                    l->wt[m] = sum;
+                    l->parent_inner[m] = 0xFFFFFFFFu;
+                    m++;
+                }
+                for (uint32_t k = m; k-- > 0u;) l->depth_inner[k] = l->parent_inner[k] == 0xFFFFFFFFu ? 0u : l->depth_inner[l->parent_inner[k]] + 1u;
+                l->count[23] = m;
+            }
+        SIMT_END_WAVE
+        made = l->count[23];
+        PT<uint32_t, N> mx;
+        SIMT_BEGIN(t, N)
+            uint32_t m = 0;
+            for (uint32_t s = (uint32_t)t; s < alpha; s += (uint32_t)N) {
+                const uint32_t d = made ? l->depth_inner[l->parent_leaf[s]] + 1u : 1u;
+                l->len[s] = d;
+                m = d > m ? d : m;
+            }
+            mx[t] = m;
+        SIMT_END_WAVE
+        simt::wave_scan_max_incl<N>(mx);
+        if (simt::wave_read<N>(mx, N - 1) <= max_len) break;
+        SIMT_BEGIN(t, N) for (uint32_t s = (uint32_t)t; s < alpha; s += (uint32_t)N) l->w[s] = l->w[s] / 2u + 1u; SIMT_END_WAVE
+    }
+    // ---- canonical codes: in order of (length, symbol)
+    SIMT_BEGIN(t, N) if (t < 24) l->count[t] = 0u; SIMT_END_WAVE
+    SIMT_BEGIN(t, N) for (uint32_t s = (uint32_t)t; s < alpha; s += (uint32_t)N) lds_inc(&l->count[l->len[s]]); SIMT_END_WAVE
+    SIMT_BEGIN(t, N)
+        if (t == 0) {
+            uint32_t next = 0;
+            for (uint32_t k = 1; k <= max_len; k++) { l->base[k] = next; next = (next + l->count[k]) << 1; }
+        }
+    SIMT_END_WAVE
+    SIMT_BEGIN(t, N)
+        for (uint32_t s = (uint32_t)t; s < alpha; s += (uint32_t)N) {
+            const uint32_t ls = l->len[s];
+            uint32_t r = 0;
+            for (uint32_t k = 0; k < s; k++) r += l->len[k] == ls ? 1u : 0u;
+            l->wt[s] = (l->base[ls] + r) | (ls << 24);        // (the inner weights are not needed any more)
+        }
+    SIMT_END_WAVE
+}
+struct Huff {          // a wavefront per (block, table)
+    Segs c;
+    typedef HuffLds Lds;
+    template <int N> SWC_D void run(uint32_t idx, Lds* lds) const {
+        const uint32_t b = idx / kMaxTables, k = idx % kMaxTables;
+        const SWC_AS_GLOBAL BlockInfo* info = c.infos + b;
+        if (k >= info->n_tables) return;
+        const uint32_t alpha = info->n_used + 2u;
+        const size_t at = ((size_t)b * kMaxTables + k) * kSymStride;
+        SIMT_BEGIN(t, N)
+            for (uint32_t s = (uint32_t)t; s < alpha; s += (uint32_t)N) { const uint32_t f = c.rfreq[at + s]; lds->w[s] = f ? f : 1u; }
+        SIMT_END_WAVE
+        huffman_wave<N>(lds, alpha, 17u);
+        SIMT_BEGIN(t, N)
+            for (uint32_t s = (uint32_t)t; s < alpha; s += (uint32_t)N) { c.len8[at + s] = (uint8_t)lds->len[s]; c.codes[at + s] = lds->wt[s]; }
+        SIMT_END
+    }
+};
+
 // ================================================================================================================ emit
-// BZip2+Compress.swift:149-240, a wavefront per SEGMENT again: the host has turned the block's symbol counts into code lengths
-// and knows how long the block's header is; seg_bits (a wavefront per segment) adds up the code lengths of a segment's symbols,
-// seg_scan (a wavefront per block) turns that into the bit every segment starts at, and emit_seg writes a segment's codes --
-// the first segment of a block the header in front of them -- 64 symbols per step: a wave scan of the code lengths for the
-// places, ds_or_b32 into a staging area of the MSB-first bit stream in LDS, byte-swapped dwords to HBM, the dwords a segment
-// shares with its neighbours by atomic OR (the areas are zeroed).
+// BZip2+Compress.swift:149-240, a wavefront per SEGMENT again: block_head (a wavefront per block) moves the selectors to the
+// front -- the position of a selector in the list is the number of tables used more recently than its own, six running
+// maxima -- and adds up the bits in front of the block's first symbol; seg_bits (a wavefront per segment) adds up the code
+// lengths of a segment's symbols, seg_scan / block_scan turn that into the bit every segment and block starts at in the
+// STREAM, and emit_seg writes a segment's codes -- the first segment of a block the header in front of them -- 64 symbols per
+// step: a wave scan of the code lengths for the places, ds_or_b32 into a staging area of the MSB-first bit stream in LDS,
+// byte-swapped dwords to HBM, the dwords a segment shares with its neighbours by atomic OR (the stream is zeroed).
 struct EmitLds {
     uint32_t stage[kStageDw + 4];
-    uint32_t code[kMaxSyms + 6];
+    uint32_t code[kMaxTables][kSymStride];
 };
 template <int N>
 struct Emitter {
@@ -470,123 +669,176 @@ struct Emitter {
         obits += total;
         if (fill >= 32u * kFlushDw) flush(false);
     }
-    // `n` zero bits
-    SWC_D void skip(uint32_t n) {
-        while (n != 0u) {
-            const uint32_t k = n < 2048u ? n : 2048u;
-            fill += k;
-            obits += k;
-            n -= k;
-            if (fill >= 32u * kFlushDw) flush(false);
+};
+// A wavefront per block: the selectors after move-to-front (:187-194, mtf :265-275), and the bits in front of the block's first symbol.
+struct BlockHead {
+    Segs c;
+    typedef NoLds Lds;
+    template <int N> SWC_D void run(uint32_t b, Lds*) const {
+        using simt::PT;
+        SWC_AS_GLOBAL BlockInfo* info = c.infos + b;
+        const uint32_t n_groups = info->n_groups, n_tables = info->n_tables, alpha = info->n_used + 2u;
+        const SWC_AS_GLOBAL uint8_t* sel = c.sel + c.grp_off[b];
+        SWC_AS_GLOBAL uint8_t* out = c.selmtf + c.grp_off[b];
+        // key of table v: where it was used last (+ 8), or -- not used yet -- its place from the back of the list 0 1 2 3 4 5
+        uint32_t key[kMaxTables];
+        for (uint32_t v = 0; v < kMaxTables; v++) key[v] = kMaxTables - v;
+        uint32_t sel_bits = 0;
+        for (uint32_t g0 = 0; g0 < n_groups; g0 += (uint32_t)N) {
+            PT<uint32_t, N> mine, k0, k1, k2, k3, k4, k5, pos;
+            SIMT_BEGIN(t, N) mine[t] = g0 + (uint32_t)t < n_groups ? sel[g0 + (uint32_t)t] : 0xFFu; SIMT_END
+            PT<uint32_t, N>* ks[kMaxTables] = {&k0, &k1, &k2, &k3, &k4, &k5};
+            for (uint32_t v = 0; v < kMaxTables; v++) {
+                PT<uint32_t, N> x, ex;
+                SIMT_BEGIN(t, N) x[t] = mine[t] == v ? g0 + (uint32_t)t + 8u : 0u; SIMT_END
+                simt::wave_scan_max_incl<N>(x);
+                simt::wave_shift_up<N>(ex, x, 0u);                                 // what lies in front of me
+                const uint32_t kv = key[v];
+                SIMT_BEGIN(t, N) (*ks[v])[t] = ex[t] > kv ? ex[t] : kv; SIMT_END
+                const uint32_t last = simt::wave_read<N>(x, N - 1);
+                key[v] = last > kv ? last : kv;
+            }
+            SIMT_BEGIN(t, N)
+                const uint32_t m = mine[t];
+                const uint32_t kk[kMaxTables] = {k0[t], k1[t], k2[t], k3[t], k4[t], k5[t]};
+                uint32_t own = 0, p = 0;
+                for (uint32_t v = 0; v < kMaxTables; v++) own = m == v ? kk[v] : own;
+                for (uint32_t v = 0; v < kMaxTables; v++) p += kk[v] > own ? 1u : 0u;
+                pos[t] = m < kMaxTables ? p : 0u;
+                if (m < kMaxTables) out[g0 + (uint32_t)t] = (uint8_t)p;
+            SIMT_END
+            PT<uint32_t, N> x;
+            SIMT_BEGIN(t, N) x[t] = mine[t] < kMaxTables ? pos[t] + 1u : 0u; SIMT_END
+            simt::wave_scan_incl<N>(x);
+            sel_bits += simt::wave_read<N>(x, N - 1);
         }
+        // the tables in delta form (:196-221): 5 bits, then per symbol two bits per step and a closing zero
+        const SWC_AS_GLOBAL uint8_t* len8 = c.len8 + (size_t)b * kMaxTables * kSymStride;
+        PT<uint32_t, N> tb;
+        SIMT_BEGIN(t, N)
+            uint32_t a = 0;
+            for (uint32_t k = 0; k < n_tables; k++)
+                for (uint32_t s = (uint32_t)t; s < alpha; s += (uint32_t)N) {
+                    const uint32_t len = len8[k * kSymStride + s], prev = s ? len8[k * kSymStride + s - 1u] : len;
+                    a += 2u * (len > prev ? len - prev : prev - len) + 1u;
+                }
+            tb[t] = a;
+        SIMT_END
+        simt::wave_scan_incl<N>(tb);
+        uint32_t ranges = 0;
+        for (uint32_t r = 0; r < 16u; r++) if ((info->used[r >> 1] >> (16u * (r & 1u))) & 0xFFFFu) ranges++;
+        const uint32_t bits = 48u + 32u + 1u + 24u + 16u + 16u * ranges + 3u + 15u + sel_bits + 5u * n_tables + simt::wave_read<N>(tb, N - 1);
+        SIMT_BEGIN(t, N) if (t == 0) info->head_bits = bits; SIMT_END
     }
 };
-// bits of the delta form of the code lengths of one table (:196-221)
-SWC_HD uint32_t table_bits(const uint32_t* code, uint32_t alpha) {
-    uint32_t bits = 5;
-    for (uint32_t s = 0; s < alpha; s++) {
-        const uint32_t len = code[s] >> 24, prev = s ? code[s - 1u] >> 24 : len;
-        bits += 2u * (len > prev ? len - prev : prev - len) + 1u;
-    }
-    return bits;
-}
-// bits of a block in front of its first symbol
-SWC_HD uint32_t header_bits(const BlockInfo& info) {
-    uint32_t ranges = 0;
-    for (uint32_t r = 0; r < 16u; r++) if ((info.used[r >> 1] >> (16u * (r & 1u))) & 0xFFFFu) ranges++;
-    return 48u + 32u + 1u + 24u + 16u + 16u * ranges + 3u + 15u + (info.n_sym + 49u) / 50u + 2u * table_bits(info.code, info.n_used + 2u);
-}
-// The block from its magic to the last bit in front of its first symbol.  lds->code[] = canonical code | length << 24 of every symbol.
+// The block from its magic to the last bit in front of its first symbol.
 template <int N>
-SWC_D void emit_header(Emitter<N>& e, EmitLds* lds, const SWC_AS_GLOBAL BlockInfo* info) {
+SWC_D void emit_header(Emitter<N>& e, const Segs& c, uint32_t b) {
     using simt::PT;
-    const uint32_t alpha = info->n_used + 2u;
+    const SWC_AS_GLOBAL BlockInfo* info = c.infos + b;
+    const uint32_t alpha = info->n_used + 2u, n_tables = info->n_tables, n_groups = info->n_groups;
     PT<uint32_t, N> code, nb;
     // magic (48), block CRC (32), randomised = 0 (1), origin pointer (24), the 16 bits of the used ranges (:149-166)
     uint32_t ranges = 0;
     for (uint32_t r = 0; r < 16u; r++) if ((info->used[r >> 1] >> (16u * (r & 1u))) & 0xFFFFu) ranges |= 1u << (15u - r);
     const uint32_t crc = info->crc, optr = info->orig_ptr;
     SIMT_BEGIN(t, N)
-        uint32_t c = 0, n = 0;
+        uint32_t cc = 0, n = 0;
         switch (t) {
-            case 0: c = (uint32_t)(kBlockMagic >> 24); n = 24; break;
-            case 1: c = (uint32_t)(kBlockMagic & 0xFFFFFFu); n = 24; break;
-            case 2: c = crc; n = 32; break;
-            case 3: c = 0; n = 1; break;
-            case 4: c = optr; n = 24; break;
-            case 5: c = ranges; n = 16; break;
+            case 0: cc = (uint32_t)(kBlockMagic >> 24); n = 24; break;
+            case 1: cc = (uint32_t)(kBlockMagic & 0xFFFFFFu); n = 24; break;
+            case 2: cc = crc; n = 32; break;
+            case 3: cc = 0; n = 1; break;
+            case 4: cc = optr; n = 24; break;
+            case 5: cc = ranges; n = 16; break;
             default: break;
         }
-        code[t] = c; nb[t] = n;
+        code[t] = cc; nb[t] = n;
     SIMT_END
     e.emit(code, nb);
     // the 16 bits of every used range (:168-178)
     SIMT_BEGIN(t, N)
-        uint32_t c = 0, n = 0;
+        uint32_t cc = 0, n = 0;
         if ((uint32_t)t < 16u && ((ranges >> (15u - (uint32_t)t)) & 1u)) {
             const uint32_t w = (info->used[t >> 1] >> (16u * ((uint32_t)t & 1u))) & 0xFFFFu;   // bit b: byte 16 t + b
-            c = brev32(w) >> 16;                                                                // byte 16 t first
+            cc = brev32(w) >> 16;                                                               // byte 16 t first
             n = 16;
         }
-        code[t] = c; nb[t] = n;
+        code[t] = cc; nb[t] = n;
     SIMT_END
     e.emit(code, nb);
-    // two tables, the selectors (:180-194): one per 50 symbols, all of them table 0 = a zero bit each after move-to-front
-    const uint32_t nsel = (info->n_sym + 49u) / 50u;
+    // the number of tables and of selectors, the selectors in unary (:180-194)
     SIMT_BEGIN(t, N)
-        code[t] = t == 0 ? 2u : t == 1 ? nsel : 0u;
+        code[t] = t == 0 ? n_tables : t == 1 ? n_groups : 0u;
         nb[t] = t == 0 ? 3u : t == 1 ? 15u : 0u;
     SIMT_END
     e.emit(code, nb);
-    e.skip(nsel);
-    // the code lengths of both tables in delta form (:196-221): 5 bits of the first length, then per symbol "10" / "11" steps and a 0
-    for (uint32_t tab = 0; tab < 2u; tab++) {
-        const uint32_t first = lds->code[0] >> 24;
+    const SWC_AS_GLOBAL uint8_t* sm = c.selmtf + c.grp_off[b];
+    for (uint32_t g0 = 0; g0 < n_groups; g0 += (uint32_t)N) {
+        SIMT_BEGIN(t, N)
+            const uint32_t p = g0 + (uint32_t)t < n_groups ? sm[g0 + (uint32_t)t] : 0xFFu;
+            code[t] = p < kMaxTables ? (2u << p) - 2u : 0u;        // p ones and a zero
+            nb[t] = p < kMaxTables ? p + 1u : 0u;
+        SIMT_END
+        e.emit(code, nb);
+    }
+    // the code lengths of the tables in delta form (:196-221): 5 bits of the first length, then per symbol "10" / "11" steps and a 0
+    const SWC_AS_GLOBAL uint8_t* len8 = c.len8 + (size_t)b * kMaxTables * kSymStride;
+    for (uint32_t k = 0; k < n_tables; k++) {
+        const SWC_AS_GLOBAL uint8_t* l8 = len8 + k * kSymStride;
+        const uint32_t first = l8[0];
         SIMT_BEGIN(t, N) code[t] = t == 0 ? first : 0u; nb[t] = t == 0 ? 5u : 0u; SIMT_END
         e.emit(code, nb);
         for (uint32_t s0 = 0; s0 < alpha; s0 += 32u) {     // a symbol takes at most 2 * 19 + 1 = 39 bits: two lanes per symbol
             SIMT_BEGIN(t, N)
                 const uint32_t s = s0 + ((uint32_t)t >> 1);
-                uint32_t c = 0, n = 0;
+                uint32_t cc = 0, n = 0;
                 if (s < alpha) {
-                    const uint32_t len = lds->code[s] >> 24, prev = s == 0u ? len : lds->code[s - 1u] >> 24;
+                    const uint32_t len = l8[s], prev = s == 0u ? len : l8[s - 1u];
                     const uint32_t d = len > prev ? len - prev : prev - len;       // <= 19
                     const uint32_t pat = len > prev ? 0xAAAAAAAAu : 0xFFFFFFFFu;   // "10" steps up, "11" steps down
                     if (((uint32_t)t & 1u) == 0u) {        // the first min(d, 16) steps
-                        const uint32_t k = d < 16u ? d : 16u;
-                        n = 2u * k;
-                        c = k ? pat >> (32u - n) : 0u;
+                        const uint32_t q = d < 16u ? d : 16u;
+                        n = 2u * q;
+                        cc = q ? pat >> (32u - n) : 0u;
                     } else {                               // the remaining steps and the closing 0
-                        const uint32_t k = d > 16u ? d - 16u : 0u;
-                        n = 2u * k + 1u;
-                        c = k ? (pat >> (32u - 2u * k)) << 1 : 0u;
+                        const uint32_t q = d > 16u ? d - 16u : 0u;
+                        n = 2u * q + 1u;
+                        cc = q ? (pat >> (32u - 2u * q)) << 1 : 0u;
                     }
                 }
-                code[t] = c; nb[t] = n;
+                code[t] = cc; nb[t] = n;
             SIMT_END
             e.emit(code, nb);
         }
     }
 }
 template <int N>
-SWC_D void load_codes(EmitLds* lds, const SWC_AS_GLOBAL BlockInfo* info) {
-    const uint32_t alpha = info->n_used + 2u;
+SWC_D void load_codes(EmitLds* lds, const Segs& c, uint32_t b) {
+    const SWC_AS_GLOBAL uint32_t* codes = c.codes + (size_t)b * kMaxTables * kSymStride;
+    const uint32_t n = c.infos[b].n_tables * kSymStride;
     SIMT_BEGIN(t, N)
         for (uint32_t i = (uint32_t)t; i < kStageDw + 4u; i += (uint32_t)N) lds->stage[i] = 0u;
-        for (uint32_t i = (uint32_t)t; i < kMaxSyms + 6u; i += (uint32_t)N) lds->code[i] = i < alpha ? info->code[i] : 0u;
+        for (uint32_t i = (uint32_t)t; i < n; i += (uint32_t)N) (&lds->code[0][0])[i] = codes[i];
     SIMT_END_WAVE
+}
+// canonical code | length << 24 of symbol i of segment s (the table: that of the symbol's group of 50 in the block)
+SWC_D uint32_t code_of(const EmitLds* lds, const SWC_AS_GLOBAL uint16_t* sy, const SWC_AS_GLOBAL uint8_t* sel, uint32_t first, uint32_t i) {
+    return lds->code[sel[(first + i) / kGroup]][sy[i]];
 }
 struct SegBits {       // a wavefront per segment
     Segs c;
     typedef EmitLds Lds;
     template <int N> SWC_D void run(uint32_t s, Lds* lds) const {
-        load_codes<N>(lds, c.infos + c.seg_blk[s]);
-        const uint32_t ns = c.seg_nsym[s];
+        const uint32_t b = c.seg_blk[s];
+        load_codes<N>(lds, c, b);
+        const uint32_t ns = c.seg_nsym[s], first = c.seg_sym_at[s];
         const SWC_AS_GLOBAL uint16_t* sy = c.syms + (size_t)kSegSyms * s;
+        const SWC_AS_GLOBAL uint8_t* sel = c.sel + c.grp_off[b];
         simt::PT<uint32_t, N> x;
         SIMT_BEGIN(t, N)
             uint32_t a = 0;
-            for (uint32_t i = (uint32_t)t; i < ns; i += (uint32_t)N) a += lds->code[sy[i]] >> 24;
+            for (uint32_t i = (uint32_t)t; i < ns; i += (uint32_t)N) a += code_of(lds, sy, sel, first, i) >> 24;
             x[t] = a;
         SIMT_END
         simt::wave_scan_incl<N>(x);
@@ -599,14 +851,7 @@ struct SegScan {       // a wavefront per block
     typedef NoLds Lds;
     template <int N> SWC_D void run(uint32_t b, Lds*) const {
         uint32_t at = c.infos[b].head_bits;
-        const uint32_t s1 = c.seg_off[b + 1u];
-        for (uint32_t s0 = c.seg_off[b]; s0 < s1; s0 += (uint32_t)N) {
-            simt::PT<uint32_t, N> x, own;
-            SIMT_BEGIN(t, N) own[t] = s0 + (uint32_t)t < s1 ? c.seg_bits[s0 + (uint32_t)t] : 0u; x[t] = own[t]; SIMT_END
-            simt::wave_scan_incl<N>(x);
-            SIMT_BEGIN(t, N) if (s0 + (uint32_t)t < s1) c.seg_at[s0 + (uint32_t)t] = at + x[t] - own[t]; SIMT_END
-            at += simt::wave_read<N>(x, N - 1);
-        }
+        wave_excl_scan_to<N>(c.seg_bits, c.seg_at, c.seg_off[b], c.seg_off[b + 1u], at);
         const uint32_t bits = at;
         SIMT_BEGIN(t, N) if (t == 0) c.infos[b].out_bits = bits; SIMT_END
     }
@@ -631,21 +876,21 @@ struct EmitSeg {       // a wavefront per segment
     template <int N> SWC_D void run(uint32_t s, Lds* lds) const {
         using simt::PT;
         const uint32_t b = c.seg_blk[s];
-        const SWC_AS_GLOBAL BlockInfo* info = c.infos + b;
-        load_codes<N>(lds, info);
+        load_codes<N>(lds, c, b);
         Emitter<N> e;
-        const bool first = s == c.seg_off[b];
-        e.begin(lds, c.stream, c.stream_cap, c.blk_at[b] + (first ? 0u : c.seg_at[s]));
-        if (first) emit_header<N>(e, lds, info);
+        const bool first_seg = s == c.seg_off[b];
+        e.begin(lds, c.stream, c.stream_cap, c.blk_at[b] + (first_seg ? 0u : c.seg_at[s]));
+        if (first_seg) emit_header<N>(e, c, b);
         // the symbols (:223-240)
-        const uint32_t ns = c.seg_nsym[s];
+        const uint32_t ns = c.seg_nsym[s], first = c.seg_sym_at[s];
         const SWC_AS_GLOBAL uint16_t* sy = c.syms + (size_t)kSegSyms * s;
+        const SWC_AS_GLOBAL uint8_t* sel = c.sel + c.grp_off[b];
         PT<uint32_t, N> code, nb;
         for (uint32_t base = 0; base < ns; base += (uint32_t)N) {
             SIMT_BEGIN(t, N)
                 uint32_t cc = 0, n = 0;
                 if (base + (uint32_t)t < ns) {
-                    const uint32_t w = lds->code[sy[base + (uint32_t)t]];
+                    const uint32_t w = code_of(lds, sy, sel, first, base + (uint32_t)t);
                     cc = w & 0xFFFFFFu; n = w >> 24;
                 }
                 code[t] = cc; nb[t] = n;
@@ -748,52 +993,22 @@ struct LastColumn {
 namespace swc {
 namespace bz2c {
 
-// freq[0 .. alpha): lengths of a Huffman code with no code longer than `max_len` (weights flattened until that holds, as
-// bzip2's own hbMakeCodeLengths does), every symbol of the alphabet coded (a zero frequency counts as one).  code[s] =
-// canonical code | length << 24: codes are handed out in order of (length, symbol), which is what decoders rebuild.
-inline void huffman_lengths(const uint32_t* freq, uint32_t alpha, uint32_t max_len, uint32_t* code) {
-    uint64_t w[kMaxSyms + 2];
-    uint32_t len[kMaxSyms + 2], order[kMaxSyms + 2];
-    for (uint32_t i = 0; i < alpha; i++) w[i] = freq[i] ? freq[i] : 1u;
-    for (;;) {
-        // leaves in order of weight, then the two-queue construction: the lightest two of (next leaf, next inner node) are joined,
-        // inner nodes come into being in order of weight
-        for (uint32_t i = 0; i < alpha; i++) order[i] = i;
-        for (uint32_t i = 1; i < alpha; i++) {             // insertion sort: 258 entries, nearly sorted after a flattening
-            const uint32_t o = order[i];
-            uint32_t k = i;
-            while (k > 0 && w[order[k - 1]] > w[o]) { order[k] = order[k - 1]; k--; }
-            order[k] = o;
-        }
-        uint64_t wt[kMaxSyms + 2];                           // inner nodes
-        int parent_leaf[kMaxSyms + 2], parent_inner[kMaxSyms + 2];
-        uint32_t nl = 0, ni = 0, made = 0;
-        auto take = [&](int to) -> uint64_t {
-            if (nl < alpha && (ni >= made || w[order[nl]] <= wt[ni])) { parent_leaf[order[nl]] = to; return w[order[nl++]]; }
-            parent_inner[ni] = to;
-            return wt[ni++];
-        };
-        while (alpha - nl + made - ni > 1) {
-            const uint64_t a = take((int)made);
-            const uint64_t b = take((int)made);
-            wt[made] = a + b;
-            parent_inner[made] = -1;
-            made++;
-        }
-        uint32_t depth_inner[kMaxSyms + 2];
-        for (int k = (int)made - 1; k >= 0; k--) depth_inner[k] = parent_inner[k] < 0 ? 0u : depth_inner[parent_inner[k]] + 1u;
-        uint32_t longest = 0;
-        for (uint32_t i = 0; i < alpha; i++) {
-            len[i] = made ? depth_inner[parent_leaf[i]] + 1u : 1u;
-            if (len[i] > longest) longest = len[i];
-        }
-        if (longest <= max_len) break;
-        for (uint32_t i = 0; i < alpha; i++) w[i] = w[i] / 2 + 1;
-    }
-    uint32_t next = 0;
-    for (uint32_t l = 1; l <= max_len; l++) {
-        for (uint32_t s = 0; s < alpha; s++) if (len[s] == l) code[s] = next++ | (l << 24);
-        next <<= 1;
+// How many tables a block of n_sym symbols gets, and the lengths the refinement starts from: table k favours (length 0 against
+// 15) a range of the alphabet that holds about an equal share of the symbols -- bzip2's own starting point.
+inline uint32_t tables_for(uint32_t n_sym) { return n_sym < 200u ? 2u : n_sym < 600u ? 3u : n_sym < 1200u ? 4u : n_sym < 2400u ? 5u : 6u; }
+inline void initial_tables(const uint32_t* freq, uint32_t alpha, uint32_t n_sym, uint32_t n_tables, uint8_t* len8 /* [kMaxTables][kSymStride] */) {
+    uint32_t part = n_tables, rem = n_sym;
+    int gs = 0;
+    while (part > 0) {
+        const uint32_t target = rem / part;
+        int ge = gs - 1;
+        uint32_t acc = 0;
+        while (acc < target && ge < (int)alpha - 1) { ge++; acc += freq[ge]; }
+        if (ge > gs && part != n_tables && part != 1 && ((n_tables - part) % 2u) == 1u) { acc -= freq[ge]; ge--; }
+        for (uint32_t v = 0; v < alpha; v++) len8[(part - 1) * kSymStride + v] = ((int)v >= gs && (int)v <= ge) ? 0 : 15;
+        part--;
+        gs = ge + 1;
+        rem -= acc;
     }
 }
 
@@ -963,14 +1178,18 @@ int compress_stream(X& x, const uint8_t* data, size_t len, int level, uint8_t** 
             x.each(total, LastColumn{c});
         }
         x.mark("sort");
-        // ---- symbols, lengths, bits
+        // ---- symbols, tables, bits
         uint16_t* d_syms = (uint16_t*)x.alloc(2 * (size_t)kSegSyms * n_segs + 16);
-        uint32_t* d_segs = (uint32_t*)x.alloc(4 * (size_t)n_segs * 4 + 16);          // seg_blk | seg_nsym | seg_bits | seg_at
+        uint32_t* d_segs = (uint32_t*)x.alloc(4 * (size_t)n_segs * 5 + 16);          // seg_blk | seg_nsym | seg_bits | seg_at | seg_sym_at
         uint32_t* d_last = (uint32_t*)x.alloc(4 * 256 * (size_t)n_segs + 16);
         uint32_t* d_before = (uint32_t*)x.alloc(4 * 256 * (size_t)n_segs + 16);
         uint8_t* d_used = (uint8_t*)x.alloc(256 * (size_t)nb);
         uint8_t* d_stream = (uint8_t*)x.alloc(stream_cap);
-        if (!d_syms || !d_segs || !d_last || !d_before || !d_used || !d_stream) return SWC_E_DEVICE;
+        const size_t tab_cells = (size_t)nb * kMaxTables * kSymStride;
+        uint32_t* d_rfreq = (uint32_t*)x.alloc(4 * tab_cells);
+        uint32_t* d_codes = (uint32_t*)x.alloc(4 * tab_cells);
+        uint8_t* d_len8 = (uint8_t*)x.alloc(tab_cells);
+        if (!d_syms || !d_segs || !d_last || !d_before || !d_used || !d_stream || !d_rfreq || !d_codes || !d_len8) return SWC_E_DEVICE;
         x.upload(d_segs, seg_blk.data(), 4 * (size_t)n_segs);
         Segs g;
         {
@@ -986,6 +1205,10 @@ int compress_stream(X& x, const uint8_t* data, size_t len, int level, uint8_t** 
             g.seg_nsym = (SWC_AS_GLOBAL uint32_t*)(d_segs + n_segs);
             g.seg_bits = (SWC_AS_GLOBAL uint32_t*)(d_segs + 2 * (size_t)n_segs);
             g.seg_at = (SWC_AS_GLOBAL uint32_t*)(d_segs + 3 * (size_t)n_segs);
+            g.seg_sym_at = (SWC_AS_GLOBAL uint32_t*)(d_segs + 4 * (size_t)n_segs);
+            g.rfreq = (SWC_AS_GLOBAL uint32_t*)d_rfreq;
+            g.codes = (SWC_AS_GLOBAL uint32_t*)d_codes;
+            g.len8 = (SWC_AS_GLOBAL uint8_t*)d_len8;
             g.stream = (SWC_AS_GLOBAL uint8_t*)d_stream;
             g.blk_at = (SWC_AS_GLOBAL uint32_t*)(d_offs + (nb + 1));
             g.infos = (SWC_AS_GLOBAL BlockInfo*)d_infos;
@@ -995,18 +1218,49 @@ int compress_stream(X& x, const uint8_t* data, size_t len, int level, uint8_t** 
             x.per_block(n_segs, SegLast{g});
             x.each(256u * nb, SegBefore{g});
             x.per_block(n_segs, MtfSeg{g});
+            x.per_block(nb, SymScan{g});
         }
         std::vector<BlockInfo> infos(nb);
         x.download(infos.data(), d_infos, sizeof(BlockInfo) * nb);
         x.mark("mtf");
+        // the blocks' symbols one behind the other, the groups of 50, the tables the refinement starts from
+        std::vector<uint32_t> sym_off(nb + 1), grp_off(nb + 1);
+        std::vector<uint8_t> len8(tab_cells, 0);
+        sym_off[0] = 0; grp_off[0] = 0;
+        uint32_t most_groups = 0;
         for (uint32_t b = 0; b < nb; b++) {
-            infos[b].crc = crcs[b];
-            huffman_lengths(infos[b].freq, infos[b].n_used + 2u, 17, infos[b].code);
-            infos[b].head_bits = header_bits(infos[b]);
+            BlockInfo& in = infos[b];
+            in.crc = crcs[b];
+            in.n_tables = tables_for(in.n_sym);
+            in.n_groups = (in.n_sym + kGroup - 1u) / kGroup;
+            sym_off[b + 1] = sym_off[b] + ((in.n_sym + 1u) & ~1u);                 // (even: a group's symbols can be read as dwords)
+            grp_off[b + 1] = grp_off[b] + in.n_groups;
+            if (in.n_groups > most_groups) most_groups = in.n_groups;
+            initial_tables(in.freq, in.n_used + 2u, in.n_sym, in.n_tables, len8.data() + (size_t)b * kMaxTables * kSymStride);
         }
-        x.mark("lengths");
+        uint16_t* d_csyms = (uint16_t*)x.alloc(2 * (size_t)sym_off[nb] + 16);
+        uint8_t* d_sel = (uint8_t*)x.alloc(2 * (size_t)grp_off[nb] + 16);             // sel | selmtf
+        uint32_t* d_offs2 = (uint32_t*)x.alloc(4 * (size_t)(nb + 1) * 2);             // sym_off | grp_off
+        if (!d_csyms || !d_sel || !d_offs2) return SWC_E_DEVICE;
         x.upload(d_infos, infos.data(), sizeof(BlockInfo) * nb);
+        x.upload(d_offs2, sym_off.data(), 4 * (nb + 1));
+        x.upload(d_offs2 + (nb + 1), grp_off.data(), 4 * (nb + 1));
+        x.upload(d_len8, len8.data(), tab_cells);
+        g.csyms = (SWC_AS_GLOBAL uint16_t*)d_csyms;
+        g.sym_off = (const SWC_AS_GLOBAL uint32_t*)d_offs2;
+        g.grp_off = (const SWC_AS_GLOBAL uint32_t*)(d_offs2 + (nb + 1));
+        g.sel = (SWC_AS_GLOBAL uint8_t*)d_sel;
+        g.selmtf = (SWC_AS_GLOBAL uint8_t*)(d_sel + grp_off[nb]);
+        g.cost_waves = (most_groups + kGroupsPerWave - 1u) / kGroupsPerWave;
+        x.per_block(n_segs, SymCompact{g});
+        for (uint32_t it = 0; it < kTableIters; it++) {
+            x.zero(d_rfreq, 4 * tab_cells);
+            x.per_block(nb * g.cost_waves, GroupCost{g});
+            x.per_block(nb * kMaxTables, Huff{g});
+        }
+        x.mark("tables");
         x.zero(d_stream, stream_cap);
+        x.per_block(nb, BlockHead{g});
         x.per_block(n_segs, SegBits{g});
         x.per_block(nb, SegScan{g});
         x.per_block(1, BlockScan{g});

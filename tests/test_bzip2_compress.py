@@ -2,15 +2,15 @@
 
 The contract is that of the other encoders: A valid bzip2 stream for the same bytes with the reference's framing -- "BZh" and the
 level, blocks of level x 80,000 raw bytes (:46), per-block and combined CRC (:54-57, :67-71) -- not the reference encoder's
-bytes (it chooses among up to six Huffman tables per 50 symbols, :95-139; the engine builds one table per block from the block's
-own symbol counts and, as the reference does when it has a single table, writes it twice).  So parity is
+bytes (both choose among up to six Huffman tables per group of 50 symbols, :95-139; the reference builds each table from one
+group, the engine refines its tables in four passes over all groups the way bzip2 does).  So parity is
   * decode(compress(x)) == x under the REFERENCE decoder (the oracle's restatement of BZip2.swift:50-95, which must also consume
     the whole stream), under libbz2 (Python's bz2) and -- GPU tier -- under the engine's own decoder;
   * the framing: header, block count, the blocks' stored CRCs = CheckSums.bzip2crc32 of the raw blocks;
   * the size against the reference encoder RESTATED (oracle/rc_bzip2c.c: tables from single groups of 50 symbols, code lengths
     handed out in symbol order -- itself checked here against its own decoder and libbz2): at most four bytes larger (inputs of a few
-    symbols), 3-7 % smaller on text and mixed data; and against libbz2 at the same level (a stronger encoder than either:
-    100,000-byte blocks, up to six tables refined in four passes): within 6 % on text, 12 % on mixed data.
+    symbols), 7-15 % smaller on text and mixed data; and against libbz2 at the same level (the same refinement, but
+    100,000-byte blocks): within 2 %.
 CPU tier: the stages of csrc/bzip2_comp.h and their driver on the host emulation (std::sort in place of the device radix sort);
 GPU tier: the C ABI (swc_bzip2_compress)."""
 import bz2
@@ -122,12 +122,13 @@ def test_size_against_the_reference_encoder_restated():
         ours = len(E.bzip2_compress(x)[1])
         ref = len(O.bzip2_compress(x))
         assert ours <= ref, (ours, ref)
+    assert len(E.bzip2_compress(corpus.p_text(240000, 85))[1]) <= 0.94 * len(O.bzip2_compress(corpus.p_text(240000, 85)))
     for x in payloads():                      # a few symbols only: the reference's two tables of 50-symbol groups fit them exactly
         assert len(E.bzip2_compress(x)[1]) <= len(O.bzip2_compress(x)) + (4 if len(x) < 4096 else 2)
 
 
 def test_size_against_libbz2():
-    for x, limit in ((corpus.p_text(240000, 85), 1.06), (corpus.p_mix(240000, 86), 1.12), (corpus.p_rand(100000, 87), 1.01)):
+    for x, limit in ((corpus.p_text(240000, 85), 1.02), (corpus.p_mix(240000, 86), 1.02), (corpus.p_rand(100000, 87), 1.01)):
         ours = len(E.bzip2_compress(x)[1])
         ref = len(bz2.compress(x, 1))
         assert ours <= ref * limit, (ours, ref, ours / ref)
@@ -161,7 +162,7 @@ def test_gpu_levels_and_own_decoder(level):
     z = swc.BZip2.compress(x, block_size=level)
     check_stream(x, z, level)
     assert swc.BZip2.decompress(z) == x
-    assert len(z) <= len(bz2.compress(x, level)) * 1.10
+    assert len(z) <= len(bz2.compress(x, level)) * 1.03
     if level == 1:
         assert len(z) <= len(O.bzip2_compress(x, level))
 
