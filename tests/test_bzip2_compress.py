@@ -134,6 +134,32 @@ def test_size_against_libbz2():
         assert ours <= ref * limit, (ours, ref, ours / ref)
 
 
+def test_random_structures_round_trip():
+    """Seeded random inputs built from runs, repeats and alphabets of every size: each must come back from libbz2 and the oracle's decoder."""
+    rnd = random.Random(2024)
+    for case in range(120):
+        parts = []
+        alphabet = bytes(rnd.sample(range(256), rnd.choice([1, 2, 3, 5, 17, 64, 200, 256])))
+        for _ in range(rnd.randrange(1, 30)):
+            kind = rnd.randrange(5)
+            if kind == 0:
+                parts.append(bytes([rnd.choice(alphabet)]) * rnd.choice([1, 3, 4, 5, 254, 255, 256, 259, 1000, 5000]))
+            elif kind == 1:
+                parts.append(bytes(rnd.choice(alphabet) for _ in range(rnd.randrange(1, 400))))
+            elif kind == 2 and parts:
+                parts.append(rnd.choice(parts) * rnd.randrange(1, 6))
+            elif kind == 3:
+                unit = bytes(rnd.choice(alphabet) for _ in range(rnd.randrange(1, 9)))
+                parts.append(unit * rnd.randrange(1, 800))
+            else:
+                parts.append(corpus.p_text(rnd.randrange(1, 3000), case))
+        x = b"".join(parts)[:rnd.choice([1, 50, 51, 4095, 4096, 4097, 80000, 80001, 200000])]
+        st, z = E.bzip2_compress(x, rnd.choice([1, 1, 1, 2]))
+        assert st == 0 and bz2.decompress(z) == x, (case, len(x))
+        if case % 8 == 0:
+            assert O.bzip2(z)[:2] == (0, x)
+
+
 def test_more_blocks_than_one_launch_takes():
     """The driver cuts the stream into launches of 64 blocks; the bit stream continues across them at any bit offset."""
     rnd = random.Random(9)

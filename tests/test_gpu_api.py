@@ -90,6 +90,32 @@ def test_sixteen_threads_every_codec():
     assert not errors, errors[:3]
 
 
+def test_eight_threads_compress():
+    """The encoders are entry points like the others: eight threads compress different inputs at once with all three of them
+    (each call has its own stream, staging buffers and -- BZip2 -- its own device memory from the pool) and every result decodes."""
+    import bz2
+    import zlib
+    payloads = [corpus.p_mix(30000 + 50021 * i, 900 + i) + corpus.p_text(100000, 950 + i) for i in range(8)]
+    errors = []
+
+    def worker(i):
+        try:
+            for rep in range(4):
+                x = payloads[(i + rep) % 8]
+                assert bz2.decompress(swc.BZip2.compress(x, 1 + (i + rep) % 3)) == x
+                assert zlib.decompress(swc.Deflate.compress(x), -15) == x
+                assert swc.LZ4.decompress(swc.LZ4.compress(x, block_size=65536)) == x
+        except BaseException as e:   # noqa: BLE001 -- reported by the main thread
+            errors.append((i, repr(e)))
+
+    ts = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    assert not errors, errors[:3]
+
+
 def test_one_large_unit_among_many_small_ones():
     """Workspace areas are sized per unit (prefix sums), not n x the largest capacity: 4,000 small streams and one of
     64 MiB decode in one call (n x 2.35 x 64 MiB would be more than half a terabyte)."""
