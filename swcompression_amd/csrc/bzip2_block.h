@@ -88,12 +88,22 @@ SWC_HD uint32_t seg_mbits(uint32_t n) {
     while (((n + (1u << m) - 1) >> m) > kSegs) m++;
     return m;
 }
-SWC_HD size_t segbuf_bytes(size_t lcap) {   // (regular segments + 1) x capacity, for the largest n = lcap
-    const uint32_t m = seg_mbits((uint32_t)lcap);
-    const size_t regs = (lcap + ((size_t)1 << m) - 1) >> m;
-    return (regs + 1) * ((size_t)kSegCapFactor << m) + 64;
+constexpr uint32_t kSegs2 = 16384, kTeamWords = 512;   // the team walk (bzip2_team.h): segments per block, words of its own per block
+SWC_HD uint32_t seg_mbits2(uint32_t n) {
+    uint32_t m = 5;
+    while (((n + (1u << m) - 1) >> m) > kSegs2) m++;
+    return m;
 }
-constexpr size_t kSegInfoBytes = ((2 * (kSegs + 1) * 4 + 15) / 16) * 16;   // length and successor of every segment (stage 3a)
+SWC_HD size_t segbuf_bytes(size_t lcap) {   // (regular segments + 1) x capacity, for the largest n = lcap; the larger of the two walks' needs
+    const uint32_t m = seg_mbits((uint32_t)lcap), m2 = seg_mbits2((uint32_t)lcap);
+    const size_t regs = (lcap + ((size_t)1 << m) - 1) >> m, regs2 = (lcap + ((size_t)1 << m2) - 1) >> m2;
+    const size_t a = (regs + 1) * ((size_t)kSegCapFactor << m), b = (regs2 + 1) * ((size_t)kSegCapFactor << m2);
+    return (a > b ? a : b) + 64;
+}
+// The team walk (bzip2_team.h) cuts a block into up to kSegs2 segments and keeps their lengths and successors -- and 512 words of
+// its own (ticket counters, prefix of the segment counts) -- in the same area, and the segments' offsets behind them; the fused
+// kernel uses the first 2 x (kSegs + 1) words.
+constexpr size_t kSegInfoBytes = (((4 * (size_t)(kSegs2 + 1) + kTeamWords) * 4 + 15) / 16) * 16;   // length and successor of every segment (stage 3a)
 SWC_HD size_t ws_bytes_per_job(size_t lcap) {
     return ((lcap + 15) & ~(size_t)15) + 32768 + lcap * 4 + sizeof(BlockHeader) + 64 + kSegInfoBytes + ((segbuf_bytes(lcap) + 15) & ~(size_t)15);
 }
@@ -983,6 +993,19 @@ template <typename F>
 SWC_HD void for_bytes(gcptr T, uint32_t lo, uint32_t hi, F f) {
     uint32_t i = lo;
     for (; i < hi && (i & 7u); i++) f((uint32_t)T[i]);
+    // 32 bytes per round trip: the four loads are in flight together (every lane streams through its own part of T, so a step
+    // is a memory latency; with one load per step the RLE1 undo of a launch was 43 ms of nothing but waiting)
+    for (; i + 32 <= hi; i += 32) {
+        const uint64_t w0 = load_u64(T + i), w1 = load_u64(T + i + 8), w2 = load_u64(T + i + 16), w3 = load_u64(T + i + 24);
+#pragma unroll
+        for (int k = 0; k < 8; k++) f((uint32_t)(w0 >> (8 * k)) & 0xFFu);
+#pragma unroll
+        for (int k = 0; k < 8; k++) f((uint32_t)(w1 >> (8 * k)) & 0xFFu);
+#pragma unroll
+        for (int k = 0; k < 8; k++) f((uint32_t)(w2 >> (8 * k)) & 0xFFu);
+#pragma unroll
+        for (int k = 0; k < 8; k++) f((uint32_t)(w3 >> (8 * k)) & 0xFFu);
+    }
     for (; i + 8 <= hi; i += 8) {
         const uint64_t w = load_u64(T + i);
 #pragma unroll
@@ -1020,6 +1043,53 @@ struct OutPack {
         for (; j < done; j++) out[j] = (uint8_t)(buf >> (8 * (j & 7u)));
     }
 };
+
+// RLE1 undo (BZip2.swift:251-267) of the walked bytes L[0 .. n) by the whole wave: kParts independent parts (see first_safe_start),
+// sizes first, then the bytes; the job's result fields.  (L was written by lanes of this wave: stores and loads of one wave
+// are performed in order.)  `part_at` / `part_out`: kParts + 1 words each in LDS.
+template <int WAVE>
+SWC_HD void rle1_undo_to_output(Job& job, const Workspace& ws, uint32_t n, uint32_t* part_at, uint64_t* part_out, int lane) {
+    gcptr T = ws.L;
+    for (int part = lane; part <= kParts; part += WAVE) {
+        uint32_t at;
+        if (part == 0) at = 0;
+        else if (part == kParts) at = n;
+        else at = first_safe_start(T, n, (uint32_t)(((uint64_t)n * (uint32_t)part) / kParts));
+        part_at[part] = at;
+    }
+    for (int part = lane; part < kParts; part += WAVE) {
+        const uint32_t lo = part_at[part], hi = part_at[part + 1];
+        Rle1 f{part == 0 ? 0u : 1u, part == 0 ? 0u : (lo ? (uint32_t)T[lo - 1] : 0u)};
+        uint64_t bytes = 0;
+        for_bytes(T, lo, hi, [&](uint32_t b) { bool c; bytes += f.feed(b, c); });
+        part_out[part + 1] = bytes;
+    }
+    if (lane == 0) {
+        part_out[0] = 0;
+        for (int j = 1; j <= kParts; j++) part_out[j] += part_out[j - 1];
+    }
+    gptr out = (gptr)job.out;
+    const uint64_t ocap = job.out_cap;
+    for (int part = lane; part < kParts; part += WAVE) {
+        const uint32_t lo = part_at[part], hi = part_at[part + 1];
+        Rle1 f{part == 0 ? 0u : 1u, part == 0 ? 0u : (lo ? (uint32_t)T[lo - 1] : 0u)};
+        OutPack o;
+        o.begin(out, ocap, part_out[part]);
+        for_bytes(T, lo, hi, [&](uint32_t b) {
+            bool c;
+            const uint32_t prev = f.prev;
+            const uint32_t cnt = f.feed(b, c);
+            const uint32_t v = c ? prev : b;
+            for (uint32_t k = 0; k < cnt; k++) o.put(v);
+        });
+        o.finish();
+    }
+    const uint64_t total = part_out[kParts];
+    job.out_len = total;
+    job.status = total > ocap ? SWC_E_CAPACITY : SWC_OK;
+    job.in_consumed = ws.hdr->end_bit;
+    job.aux = 0;
+}
 
 // Stage 3a, second part: the segments in cycle order, the bytes laid out in L, RLE1 undone (the walk is complete).
 template <int WAVE>
@@ -1073,48 +1143,7 @@ SWC_HD void walk_finish(Job& job, Walk& W, Stage3Lds* l, int lane) {
         }
         for (uint32_t j = len & ~7u; j < len; j++) if (j >= cap) dst[j] = (uint8_t)(acc >> (8 * (j & 7u)));
     }
-    // ---- RLE1 undo by the whole wave: kParts independent parts (see first_safe_start), sizes first, then the bytes.
-    // (L was written by other lanes of this wave just above: stores and loads of one wave are performed in order.)
-    gcptr T = ws.L;
-    for (int part = lane; part <= kParts; part += WAVE) {
-        uint32_t at;
-        if (part == 0) at = 0;
-        else if (part == kParts) at = n;
-        else at = first_safe_start(T, n, (uint32_t)(((uint64_t)n * (uint32_t)part) / kParts));
-        l->part_at[part] = at;
-    }
-    for (int part = lane; part < kParts; part += WAVE) {
-        const uint32_t lo = l->part_at[part], hi = l->part_at[part + 1];
-        Rle1 f{part == 0 ? 0u : 1u, part == 0 ? 0u : (lo ? (uint32_t)T[lo - 1] : 0u)};
-        uint64_t bytes = 0;
-        for_bytes(T, lo, hi, [&](uint32_t b) { bool c; bytes += f.feed(b, c); });
-        l->part_out[part + 1] = bytes;
-    }
-    if (lane == 0) {
-        l->part_out[0] = 0;
-        for (int j = 1; j <= kParts; j++) l->part_out[j] += l->part_out[j - 1];
-    }
-    gptr out = (gptr)job.out;
-    const uint64_t ocap = job.out_cap;
-    for (int part = lane; part < kParts; part += WAVE) {
-        const uint32_t lo = l->part_at[part], hi = l->part_at[part + 1];
-        Rle1 f{part == 0 ? 0u : 1u, part == 0 ? 0u : (lo ? (uint32_t)T[lo - 1] : 0u)};
-        OutPack o;
-        o.begin(out, ocap, l->part_out[part]);
-        for_bytes(T, lo, hi, [&](uint32_t b) {
-            bool c;
-            const uint32_t prev = f.prev;
-            const uint32_t cnt = f.feed(b, c);
-            const uint32_t v = c ? prev : b;
-            for (uint32_t k = 0; k < cnt; k++) o.put(v);
-        });
-        o.finish();
-    }
-    const uint64_t total = l->part_out[kParts];
-    job.out_len = total;
-    job.status = total > ocap ? SWC_E_CAPACITY : SWC_OK;
-    job.in_consumed = ws.hdr->end_bit;
-    job.aux = 0;
+    rle1_undo_to_output<WAVE>(job, ws, n, l->part_at, l->part_out, lane);
     if (lane == 0) ws.hdr->pad = kWalkDone;
 }
 

@@ -27,6 +27,7 @@
 #include "deflate_comp.h"
 #include "lzma_wave.h"
 #include "bzip2_block.h"
+#include "bzip2_team.h"
 #include "crc32_group.h"
 #include "crc32_wave.h"
 #include "checksum_group.h"
@@ -447,8 +448,9 @@ static_assert(kBzLdsBytes >= 256 * sizeof(uint32_t), "stage 2 counters");
 #endif
 // CXX: the plain-symbol loop of stage 1 compiled from its C++ twin instead of the hand-written assembly ("bzip2_hot_cxx",
 // swc_set_tuning: the differential GPU test of the two, tests/test_gpu_bzip2.py)
+// team != 0: stage 1 and 2 only -- the walk, the lay-out and the RLE1 undo follow as kernels of their own (bzip2_team.h)
 template <bool CXX>
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_BZ_WAVES))) void swc_bzip2_block_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t lcap) {
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_BZ_WAVES))) void swc_bzip2_block_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t lcap, int team) {
     __shared__ __attribute__((aligned(16))) uint8_t bz_lds[kBzLdsBytes];
     uint32_t g = xcd_job(blockIdx.x, n);
     if (g >= n) return;
@@ -465,8 +467,36 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_BZ_WAVES
     if (threadIdx.x == 0) { w.hdr->pad = bzip2::kWalkDone; jobs[g].status = SWC_E_DEVICE; }
     return;
 #endif
+    if (team) return;
     __threadfence_block();   // likewise the pointer array P
     bzip2::stage3_walk_job<kWave>(job, w, reinterpret_cast<bzip2::Stage3Lds*>(bz_lds), (int)threadIdx.x);
+    if (threadIdx.x == 0 && !bzip2::stage3_expand_needed(w)) {
+        jobs[g].out_len = job.out_len;
+        jobs[g].in_consumed = job.in_consumed;
+        jobs[g].status = job.status;
+        jobs[g].aux = job.aux;
+    }
+}
+
+// ---- stage 3a as kernels of its own (bzip2_team.h) ------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void swc_bzip2_team_prep_kernel(uint8_t* ws, size_t lcap, uint32_t n) {
+    bzip2::team_prep<kWave>(ws, lcap, n, blockIdx.x, (int)threadIdx.x);
+}
+#ifndef SWC_BZ_TEAM_THREADS
+#define SWC_BZ_TEAM_THREADS 1024
+#endif
+__global__ __launch_bounds__(SWC_BZ_TEAM_THREADS) void swc_bzip2_team_walk_kernel(uint8_t* ws, size_t lcap, uint32_t n) {
+    uint32_t xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    bzip2::team_walk(ws, lcap, n, xcc & (bzip2::kTeams - 1u));
+}
+__global__ __launch_bounds__(64) void swc_bzip2_team_finish_kernel(Job* __restrict__ jobs, uint32_t n, uint8_t* ws, size_t lcap) {
+    __shared__ bzip2::FinishLds lds;
+    uint32_t g = xcd_job(blockIdx.x, n);
+    if (g >= n) return;
+    Job job = jobs[g];
+    const bzip2::Workspace w = bzip2::carve(ws, g, lcap);
+    bzip2::team_finish<kWave>(job, w, &lds, (int)threadIdx.x);
     if (threadIdx.x == 0 && !bzip2::stage3_expand_needed(w)) {
         jobs[g].out_len = job.out_len;
         jobs[g].in_consumed = job.in_consumed;
@@ -507,6 +537,10 @@ __global__ __launch_bounds__(256) void swc_bzip2_crc_kernel(Job* __restrict__ jo
 size_t bzip2_ws_bytes_per_job(size_t lcap) { return bzip2::ws_bytes_per_job(lcap); }
 static std::atomic<int> g_bzip2_hot_cxx{0};
 void set_bzip2_hot_cxx(int v) { g_bzip2_hot_cxx = v; }
+static std::atomic<int> g_bzip2_team_walk{1}, g_bzip2_team_per_cu{1};
+constexpr size_t kTeamMin = 1024;
+void set_bzip2_team_walk(int v) { g_bzip2_team_walk = v; }
+void set_bzip2_team_per_cu(int v) { g_bzip2_team_per_cu = v; }
 
 hipError_t launch_bzip2(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream) {
     if (n == 0) return hipSuccess;
@@ -523,8 +557,17 @@ hipError_t launch_bzip2(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStrea
     const size_t lcap = lo;
     dim3 block(kWave);
     g_pt.begin(stream);
-    if (g_bzip2_hot_cxx) hipLaunchKernelGGL(swc_bzip2_block_kernel<true>, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
-    else hipLaunchKernelGGL(swc_bzip2_block_kernel<false>, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
+    // "bzip2_team_walk" (swc_set_tuning): 1 = launches of kTeamMin blocks and more walk out of the XCDs' L2 (bzip2_team.h), 0 = never,
+    // 2 = always
+    const int tw = g_bzip2_team_walk;
+    const int team = tw == 2 || (tw == 1 && n >= kTeamMin) ? 1 : 0;
+    if (g_bzip2_hot_cxx) hipLaunchKernelGGL(swc_bzip2_block_kernel<true>, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap, team);
+    else hipLaunchKernelGGL(swc_bzip2_block_kernel<false>, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap, team);
+    if (team) {
+        hipLaunchKernelGGL(swc_bzip2_team_prep_kernel, dim3(bzip2::kTeams), block, 0, stream, (uint8_t*)ws, lcap, (uint32_t)n);
+        hipLaunchKernelGGL(swc_bzip2_team_walk_kernel, dim3(256 * g_bzip2_team_per_cu), dim3(SWC_BZ_TEAM_THREADS), 0, stream, (uint8_t*)ws, lcap, (uint32_t)n);
+        hipLaunchKernelGGL(swc_bzip2_team_finish_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
+    }
     g_pt.mark(stream);
     hipLaunchKernelGGL(swc_bzip2_expand_kernel, dim3((unsigned)((n + kWave - 1) / kWave)), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
     g_pt.mark(stream);

@@ -15,6 +15,8 @@ void set_phase_timing(int on);
 void set_lzma_coder_cache(int on);
 void set_lz_copier(int v);
 void set_bzip2_hot_cxx(int v);
+void set_bzip2_team_walk(int v);
+void set_bzip2_team_per_cu(int v);
 int last_phase_ms(float* ms, int cap);
 hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream, const uint64_t* ws_off = nullptr);
 size_t lz4_ws_bytes_per_job(uint64_t cap);

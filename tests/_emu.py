@@ -95,8 +95,21 @@ def lzma(inputs, caps, props, dict_sizes, sizes, mode=None):
                      dict_ptr_values=dict_sizes)
 
 
+_bzip2_team = None
+
+
+def set_bzip2_team(mode):
+    """None: stage 3a inside the block's own wavefront (bzip2_block.h); (start_team, one_thread): stage 3a as kernels of its own
+    (bzip2_team.h) -- the team whose thread goes first, and whether that thread alone draws all teams' tickets."""
+    global _bzip2_team
+    _bzip2_team = mode
+
+
 def bzip2_block(streams, body_bits, crcs, caps, lcap=1000000):
     """One bzip2 block per job: `streams[i]` is the whole stream, body_bits[i] the bit offset of the block body."""
+    if _bzip2_team is not None:
+        return run_batch("emu_bzip2_block_team", streams, caps, extra=body_bits, dict_ptr_values=crcs,
+                         fn_args=(C.c_size_t(lcap), C.c_int(_bzip2_team[0]), C.c_int(_bzip2_team[1])))
     return run_batch("emu_bzip2_block", streams, caps, extra=body_bits, dict_ptr_values=crcs, fn_args=(C.c_size_t(lcap),))
 
 

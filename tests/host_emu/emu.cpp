@@ -16,6 +16,7 @@
 #include "../../swcompression_amd/csrc/lz_copy.h"
 #include "../../swcompression_amd/csrc/lzma_wave.h"
 #include "../../swcompression_amd/csrc/bzip2_block.h"
+#include "../../swcompression_amd/csrc/bzip2_team.h"
 #include "../../swcompression_amd/csrc/bzip2_comp.h"
 #include "../../swcompression_amd/csrc/crc32_group.h"
 
@@ -135,6 +136,43 @@ extern "C" void emu_bzip2_block(swc::Job* jobs, size_t n, size_t lcap) {
         if (stage3_expand_needed(w)) stage3_expand_job(jobs[g], w);
         if (jobs[g].status == SWC_OK)
             stage3_check_crc(jobs[g], swc::crc::crc_group<1, uint32_t, true>(jobs[g].out, jobs[g].out_len, &crc_lds, 0));
+    }
+}
+
+// BZip2 with stage 3a as kernels of its own (bzip2_team.h): stage 1 + 2 of ALL jobs, then the segment counts and their prefixes
+// per team, the walk (every team's tickets drawn by one thread; `start_team`: the team whose thread goes first and, with the
+// work stealing, through the others' tickets too when `one_thread` is set), the finish per job, the serial fallback, the CRC.
+static uint64_t g_team_finished = 0;   // blocks whose output came from team_finish, not from the serial fallback
+extern "C" uint64_t emu_bzip2_team_finished(int reset) { const uint64_t v = g_team_finished; if (reset) g_team_finished = 0; return v; }
+extern "C" void emu_bzip2_block_team(swc::Job* all_jobs, size_t n_all, size_t lcap, int start_team, int one_thread) {
+    using namespace swc::bzip2;
+    const size_t per = ws_bytes_per_job(lcap), kAtOnce = 24;          // (the workspaces of a launch exist side by side: 24 jobs at a time)
+    std::vector<uint8_t> ws(per * std::min(n_all, kAtOnce) + 64);
+    std::vector<uint32_t> cnt(256 + 256);
+    Stage1Lds lds;
+    static FinishLds fl;
+    static swc::crc::Lds<1, uint32_t> crc_lds;
+    for (size_t j0 = 0; j0 < n_all; j0 += kAtOnce) {
+        swc::Job* jobs = all_jobs + j0;
+        const size_t n = std::min(kAtOnce, n_all - j0);
+        std::fill(ws.begin(), ws.end(), (uint8_t)0xCD);
+        for (size_t g = 0; g < n; g++) {
+            std::memset(&lds, 0xEE, sizeof lds);
+            Workspace w = carve(ws.data(), g, lcap);
+            stage1_job<1>(jobs[g], &lds, w, 0);
+            stage2_job(w, cnt.data());
+        }
+        for (uint32_t t = 0; t < kTeams; t++) team_prep<1>(ws.data(), lcap, (uint32_t)n, t, 0);
+        for (uint32_t d = 0; d < (one_thread ? 1u : kTeams); d++) team_walk(ws.data(), lcap, (uint32_t)n, ((uint32_t)start_team + d) % kTeams);
+        for (size_t g = 0; g < n; g++) {
+            Workspace w = carve(ws.data(), g, lcap);
+            std::memset(&fl, 0xEE, sizeof fl);
+            team_finish<1>(jobs[g], w, &fl, 0);
+            if (stage3_expand_needed(w)) stage3_expand_job(jobs[g], w);
+            else g_team_finished++;
+            if (jobs[g].status == SWC_OK)
+                stage3_check_crc(jobs[g], swc::crc::crc_group<1, uint32_t, true>(jobs[g].out, jobs[g].out_len, &crc_lds, 0));
+        }
     }
 }
 

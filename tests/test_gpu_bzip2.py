@@ -14,6 +14,17 @@ from swcompression_amd.batch import DeviceBatch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["fused", "team"])
+def stage3(request):
+    """Every test with stage 3a inside the block's wavefront and with stage 3a as kernels of its own (bzip2_team.h), whatever
+    the number of blocks of the launch."""
+    from swcompression_amd import _lib
+    lib = _lib.load()
+    assert lib.swc_set_tuning(b"bzip2_team_walk", 2 if request.param == "team" else 0) == 0
+    yield
+    lib.swc_set_tuning(b"bzip2_team_walk", 1)
+
+
 def _same(data):
     st, out, cons = O.bzip2(data)
     if st == 0:

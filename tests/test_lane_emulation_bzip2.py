@@ -4,11 +4,22 @@ walking lives in the C++ host framing and is covered by the GPU tier through the
 streams are used and only block-level outcomes are compared."""
 import random
 
+import pytest
+
 import _emu as E
 import _oracle as O
 import _streams as S
 
 BLOCK_LEVEL = {205, 206, 207, 208, 209, 900}
+
+
+@pytest.fixture(autouse=True, params=["fused", "team", "team-stealing"])
+def stage3(request):
+    """Every test with stage 3a inside the block's wavefront (bzip2_block.h), as kernels of its own (bzip2_team.h: every team's
+    tickets drawn by that team's thread), and with ONE thread that starts at team 5 and goes through all teams' tickets."""
+    E.set_bzip2_team({"fused": None, "team": (0, 0), "team-stealing": (5, 1)}[request.param])
+    yield
+    E.set_bzip2_team(None)
 
 
 def _single_block(stream):
@@ -23,6 +34,20 @@ def test_valid_single_block_streams():
     for r, (z, x) in zip(res, cases):
         assert r[:2] == (0, x)
         assert O.bzip2(z)[:2] == (0, x)
+
+
+def test_the_team_path_finishes_valid_blocks_itself():
+    """(Otherwise the serial fallback of stage 3b would hide a team path that never completes.)"""
+    import ctypes as C
+    if E._bzip2_team is None:
+        return
+    E.lib.emu_bzip2_team_finished.restype = C.c_uint64
+    E.lib.emu_bzip2_team_finished(1)
+    cases = [(z, x) for z, x in S.bzip2_valid() if _single_block(z) and z.count(bytes.fromhex("314159265359")) == 1 and 0 < len(x) <= 100000][:40]
+    res = E.bzip2_block([z for z, _ in cases], [112] * len(cases), [int.from_bytes(z[10:14], "big") for z, _ in cases],
+                        [max(len(x), 1) for _, x in cases])
+    assert all(r[:2] == (0, x) for r, (_, x) in zip(res, cases))
+    assert E.lib.emu_bzip2_team_finished(1) >= len(cases) - 2     # (a periodic payload's permutation has several cycles: the serial walk's, in both forms)
 
 
 def test_body_fuzz_block_level_outcomes():

@@ -56,7 +56,7 @@ __global__ void walk_xcd_per_block(const uint32_t* P, size_t n, uint32_t steps, 
 // of M (segments of geometrically distributed length, mean M).  The chip is eight TEAMS (one per XCD, told apart by the XCC_ID
 // hardware register); a team takes the blocks x, x + 8, x + 16 ... one after the other, its walkers draw (block, segment) tickets
 // from the team's counter -- no barrier between blocks: the stragglers of a block finish while the others are on the next one.
-__global__ void walk_tickets(const uint32_t* P, size_t n, uint32_t M, uint32_t blocks, uint32_t* counters, uint32_t* sink, uint32_t* xcd_seen) {
+__global__ void walk_tickets(const uint32_t* P, size_t n, uint32_t M, uint32_t blocks, uint32_t* counters, uint32_t* sink, uint32_t* xcd_seen, uint8_t* segbuf, uint32_t* seginfo) {
     uint32_t xcc;
     asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
     xcc &= 7u;
@@ -71,7 +71,21 @@ __global__ void walk_tickets(const uint32_t* P, size_t n, uint32_t M, uint32_t b
         const uint32_t b = xcc + 8u * (t / segs), sg = t % segs;
         const uint32_t* p = P + (size_t)b * n;
         uint32_t end = sg * M, steps = 0;
-        do { const uint32_t v = p[end]; end = v >> 8; acc += v & 255; steps++; } while (end % M != 0);
+        if (segbuf) {   // as the decoder would: the bytes of a segment into its buffer (4 M bytes each), eight per store; length and successor
+            uint8_t* buf = segbuf + ((size_t)b * segs + sg) * (4u * M);
+            uint64_t w = 0;
+            do {
+                const uint32_t v = p[end]; end = v >> 8;
+                w |= (uint64_t)(v & 255u) << (8u * (steps & 7u));
+                if ((steps & 7u) == 7u) { if (steps < 4u * M) __builtin_nontemporal_store(w, (uint64_t*)(buf + (steps - 7u))); w = 0; }
+                steps++;
+            } while (end % M != 0);
+            if ((steps & 7u) && steps < 4u * M) __builtin_nontemporal_store(w, (uint64_t*)(buf + (steps & ~7u)));
+            seginfo[((size_t)b * segs + sg) * 2] = steps;
+            seginfo[((size_t)b * segs + sg) * 2 + 1] = end / M;
+        } else {
+            do { const uint32_t v = p[end]; end = v >> 8; acc += v & 255; steps++; } while (end % M != 0);
+        }
         acc += steps;
     }
     sink[(blockIdx.x * blockDim.x + threadIdx.x) & 0xFFFFF] = acc;
@@ -104,7 +118,9 @@ int main(int argc, char** argv) {
             CK(hipMalloc(&d_cnt, 8 * 32 * 4)); CK(hipMemset(d_cnt, 0, 8 * 32 * 4));
             CK(hipMalloc(&d_seen, 8 * 4)); CK(hipMemset(d_seen, 0, 8 * 4));
             CK(hipEventRecord(e0));
-            walk_tickets<<<256 * per_cu, W>>>(d_P, n, M, (uint32_t)blocks, d_cnt, d_sink, d_seen);
+            static uint8_t* d_segbuf = nullptr; static uint32_t* d_seginfo = nullptr;
+            if (argc > 7 && !d_segbuf) { CK(hipMalloc(&d_segbuf, blocks * (n + M) * 4 + 4096)); CK(hipMalloc(&d_seginfo, blocks * ((n + M - 1) / M) * 8 + 64)); }
+            walk_tickets<<<256 * per_cu, W>>>(d_P, n, M, (uint32_t)blocks, d_cnt, d_sink, d_seen, d_segbuf, d_seginfo);
             gathers = (uint64_t)n * blocks;
             uint32_t seen[8];
             CK(hipMemcpy(seen, d_seen, 32, hipMemcpyDeviceToHost));
