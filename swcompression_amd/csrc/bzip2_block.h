@@ -1014,7 +1014,9 @@ SWC_HD void for_bytes(gcptr T, uint32_t lo, uint32_t hi, F f) {
     for (; i < hi; i++) f((uint32_t)T[i]);
 }
 // Output bytes out[pos ..) of ONE writer, eight per store once `pos` reaches a multiple of eight (the bytes below it in
-// that group may belong to another writer); nothing is stored at or beyond `cap`, `pos` keeps counting.
+// that group may belong to another writer); nothing is stored at or beyond `cap`, `pos` keeps counting.  (Sixteen per store
+// -- half the partial-line writes -- was measured slower: the second 64-bit accumulator and its selects cost more than the
+// stores save, profiles/r05_experiments.txt.)
 struct OutPack {
     gptr out;
     uint64_t cap, pos, buf, gstart;   // gstart: first position this writer handles in groups

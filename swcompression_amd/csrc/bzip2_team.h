@@ -39,8 +39,7 @@ constexpr uint32_t kTwSegs = 0, kTwBefore = 1, kTwBad = 2, kTwTeam = 16;
 static_assert(kTwTeam + 32 * kTeams <= kTeamWords, "the team counters fit block 0's words");
 
 struct TeamSegs {
-    SWC_AS_GLOBAL uint32_t* len;     // [kSegs2 + 1]
-    SWC_AS_GLOBAL uint32_t* next;    // [kSegs2 + 1]
+    SWC_AS_GLOBAL uint64_t* ln;      // [kSegs2 + 1] length of the segment | the segment that begins where it ends << 32 (one load per step of the ordering)
     SWC_AS_GLOBAL uint32_t* off;     // [kSegs2 + 1] team_finish: the segment's offset in the block (an array of its own: written by
                                      // some lanes and read by others, it must not sit in lines the wave has read before)
     SWC_AS_GLOBAL uint32_t* resume;  // [kSegs2 + 1] a segment longer than its buffer: the index its walk had reached when the buffer was full
@@ -48,8 +47,7 @@ struct TeamSegs {
 };
 SWC_HD TeamSegs team_segs(const Workspace& w) {
     TeamSegs t;
-    t.len = w.seg_len;
-    t.next = w.seg_len + (kSegs2 + 1);
+    t.ln = (SWC_AS_GLOBAL uint64_t*)w.seg_len;    // (the area is 16-byte aligned)
     t.off = w.seg_len + 2 * (kSegs2 + 1);
     t.resume = w.seg_len + 3 * (kSegs2 + 1);
     t.words = w.seg_len + 4 * (kSegs2 + 1);
@@ -174,8 +172,7 @@ SWC_HD void team_walk(uint8_t* ws_base, size_t lcap, uint32_t n_blocks, uint32_t
             } while (!c.is_mark(cur) && steps <= c.n);
             if ((steps & 7u) != 0u && (steps & ~7u) < c.cap) store_u64_stream(buf + (steps & ~7u), acc);
             if (steps > c.n) ts.words[kTwBad] = 1;      // cannot happen for a permutation
-            ts.len[sg] = steps;
-            ts.next[sg] = c.seg_of(cur);
+            ts.ln[sg] = (uint64_t)steps | ((uint64_t)c.seg_of(cur) << 32);
         }
     }
 }
@@ -220,8 +217,9 @@ SWC_HD void team_finish(Job& job, Workspace ws, FinishLds* l, int lane) {
     for (uint32_t j = (uint32_t)lane; j < pieces; j += (uint32_t)WAVE) {
         uint32_t sg = piece_start(j), bytes = 0, count = 0;
         do {
-            bytes += ts.len[sg];
-            sg = ts.next[sg];
+            const uint64_t v = ts.ln[sg];
+            bytes += (uint32_t)v;
+            sg = (uint32_t)(v >> 32);
             count++;
         } while (sg < segs && !is_start(sg) && count <= segs);
         if (sg >= segs || count > segs) { l->bad = 1; sg = 0; }
@@ -252,9 +250,10 @@ SWC_HD void team_finish(Job& job, Workspace ws, FinishLds* l, int lane) {
     for (uint32_t j = (uint32_t)lane; j < pieces; j += (uint32_t)WAVE) {
         uint32_t sg = piece_start(j), off = l->o.nx[j];
         for (uint32_t q = 0; q < l->o.cnt[j]; q++) {
+            const uint64_t v = ts.ln[sg];
             ts.off[sg] = off;
-            off += ts.len[sg];
-            sg = ts.next[sg];
+            off += (uint32_t)v;
+            sg = (uint32_t)(v >> 32);
         }
     }
     simt::vmem_fence();
@@ -270,7 +269,7 @@ SWC_HD void team_finish(Job& job, Workspace ws, FinishLds* l, int lane) {
     for (uint32_t q0 = 0; q0 < segs; q0 += (uint32_t)(WAVE / kLps)) {
         const uint32_t q = q0 + grp;
         if (q >= segs) continue;
-        const uint32_t len = ts.len[q], have = len < c.cap ? len : c.cap;
+        const uint32_t len = (uint32_t)ts.ln[q], have = len < c.cap ? len : c.cap;
         gcptr src = ws.segbuf + (size_t)q * c.cap;
         gptr dst = ws.L + ts.off[q];
         for (uint32_t i0 = 8u * sub; i0 < have; i0 += 32u * kLps) {          // four pieces per lane in flight together
@@ -304,7 +303,7 @@ SWC_HD void team_finish(Job& job, Workspace ws, FinishLds* l, int lane) {
 #endif
     // ... and what lies behind the buffers: a lane per such segment goes on from where the segment's walk had filled its buffer
     for (uint32_t e = (uint32_t)lane; e < n_over; e += (uint32_t)WAVE) {
-        const uint32_t q = l->a.over[e], len = ts.len[q];
+        const uint32_t q = l->a.over[e], len = (uint32_t)ts.ln[q];
         gptr dst = ws.L + ts.off[q];
         uint32_t cur = ts.resume[q];
         for (uint32_t k = c.cap; k < len; k++) {
