@@ -1,6 +1,20 @@
 #!/bin/bash
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/bzteam; mkdir -p $O; cd $R
-for N in op8; do
-( cd /tmp && export TMPDIR=/tmp && SWC_LIB=$R/swcompression_amd/variants/libswc_$N.so timeout 900 rocprofv3 --kernel-trace --stats -d $O/trace$N -o bench -- python $R/tools/exp_bzteam.py > $O/trace$N.log 2>&1 ); echo "variant $N rc=$?"
-python tools/rocpd_summary.py $O/trace$N/bench_results.db 2>&1 | grep "team_finish" | cut -c1-140
-done
+run() { timeout 600 python bench.py --workload bzip2_900k --steps 4 --warmup 1 --no-cpu-baseline --no-per-codec $@ > $O/b.json 2> $O/b.err
+  python - <<PY
+import json
+try:
+    d = json.loads(open("$O/b.json").read().strip().splitlines()[-1])
+    print("$*:", round(d["ms_per_step"], 1), "ms", round(d["value"], 2), "GiB/s")
+except Exception as e:
+    print("$*: failed", e, open("$O/b.err").read()[-300:])
+PY
+}
+run --tuning bzip2_pipeline=1
+run --tuning bzip2_pipeline=2
+run --tuning bzip2_pipeline=4
+run --tuning bzip2_pipeline=8
+run --tuning bzip2_pipeline=4 --tuning bzip2_team_threads=512
+run --tuning bzip2_pipeline=4 --tuning bzip2_team_threads=512 --tuning bzip2_team_per_cu=2
+run --tuning bzip2_pipeline=8 --tuning bzip2_team_threads=512
+run --tuning bzip2_pipeline=4 --tuning bzip2_team_threads=256 --tuning bzip2_team_per_cu=2
