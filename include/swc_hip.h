@@ -284,10 +284,10 @@ const char* swc_version(void);
  *   "bzip2_hot_cxx" = 0 | 1     process-wide: BZip2 launches run the instantiation of the block kernel whose plain-symbol loop is
  *                               compiled from C++ (1) instead of the hand-written assembly (0, default) -- the two are compared
  *                               by the GPU tests;
- *   "bzip2_team_walk" = 1 | 0 | 2   process-wide: BZip2 launches of 1,024 blocks and more run stage 3 -- the inverse
- *                               Burrows-Wheeler walk, the lay-out, the RLE1 undo -- as kernels of their own that walk out of the
- *                               XCDs' L2 (csrc/bzip2_team.h; 1, default), never (0: one wavefront takes a block through all
- *                               stages), or whatever the number of blocks (2). */
+ *   "bzip2_team_walk" = 1 | 0 | 2   process-wide: BZip2 launches run stage 3 -- the inverse Burrows-Wheeler walk, the lay-out,
+ *                               the RLE1 undo -- as kernels of their own that walk out of the XCDs' L2 (csrc/bzip2_team.h)
+ *                               unless the launch is tiny (1, default), never (0: one wavefront takes a block through all
+ *                               stages), or always (2). */
 int swc_set_tuning(const char* key, int value);
 /* Profile builds of the library (-DSWC_PROFILE) only: a device buffer of 32 x uint64 per job of the next Deflate
  * launches that the kernels fill with cycle counts per stage (tools/exp_profile.py).  NULL switches it off.  A no-op in

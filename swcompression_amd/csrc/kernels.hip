@@ -538,7 +538,7 @@ size_t bzip2_ws_bytes_per_job(size_t lcap) { return bzip2::ws_bytes_per_job(lcap
 static std::atomic<int> g_bzip2_hot_cxx{0};
 void set_bzip2_hot_cxx(int v) { g_bzip2_hot_cxx = v; }
 static std::atomic<int> g_bzip2_team_walk{1}, g_bzip2_team_per_cu{1};
-constexpr size_t kTeamMin = 1024;
+constexpr size_t kTeamMinBytes = 65536;
 void set_bzip2_team_walk(int v) { g_bzip2_team_walk = v; }
 void set_bzip2_team_per_cu(int v) { g_bzip2_team_per_cu = v; }
 
@@ -557,10 +557,11 @@ hipError_t launch_bzip2(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStrea
     const size_t lcap = lo;
     dim3 block(kWave);
     g_pt.begin(stream);
-    // "bzip2_team_walk" (swc_set_tuning): 1 = launches of kTeamMin blocks and more walk out of the XCDs' L2 (bzip2_team.h), 0 = never,
-    // 2 = always
+    // "bzip2_team_walk" (swc_set_tuning): 1 = launches with kTeamMinBytes of column and more walk out of the XCDs' L2 (bzip2_team.h:
+    // faster from ONE block of 100 kB on -- 900 kB: 71 against 85 ms -- its four extra launches cost a 500-byte stream 0.3 ms),
+    // 0 = never, 2 = always
     const int tw = g_bzip2_team_walk;
-    const int team = tw == 2 || (tw == 1 && n >= kTeamMin) ? 1 : 0;
+    const int team = tw == 2 || (tw == 1 && n * lcap >= kTeamMinBytes) ? 1 : 0;
     if (g_bzip2_hot_cxx) hipLaunchKernelGGL(swc_bzip2_block_kernel<true>, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap, team);
     else hipLaunchKernelGGL(swc_bzip2_block_kernel<false>, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap, team);
     if (team) {
