@@ -14,6 +14,8 @@
 //   stage 2  one block per WAVEFRONT  stable counting-sort scatter  P[base[c]++] = i << 8 | c  (c = L[i]): L is read 64
 //            consecutive bytes at a time (one coalesced load), a lane finds its rank among the equal bytes of the group with
 //            eight ballots (one per bit of the byte), the running counts of the 256 byte values sit in LDS.
+//   (stage 3 of every launch but the tiny ones runs as kernels of its own, bzip2_team.h: the same cut of the cycle into segments,
+//   16,384 of them, walked by ticket queues per XCD out of the L2; what follows describes the form inside this kernel)
 //   stage 3a one block per WAVEFRONT  the n dependent gathers  v = P[end]; end = v >> 8; byte = v & 255  form ONE cycle
 //            through the block, which a single walker can only follow at one HBM round trip per byte (measured: 17 G
 //            gathers/s with a lane per block, 46-59 G/s -- the HBM row-activation limit -- with 64+ walkers per block,
