@@ -71,7 +71,7 @@ constexpr uint32_t kScratchWin = 0, kScratchRec = kInWin + 16, kScratchLit = kSc
 static_assert(kScratchEnd <= kStageLds && kScratchRec % 16 == 0 && kScratchLit % 16 == 0, "the checked step's buffers must fit the stage");
 constexpr uint32_t kTailKeep = 16;                    // the sequences that end in the last bytes of a block stay with the checked step
 constexpr uint32_t kPosFail = 0xFFFFFFFFu;
-enum { kLzStop = 1u, kLzFail = 2u, kLzTrap = 4u, kLzTail = 8u };
+enum { kLzStop = 1u, kLzFail = 2u, kLzTrap = 4u, kLzTail = 8u, kLzLong = 16u };
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 #define SWC_LP(k) { const uint64_t t_ = __builtin_readcyclecounter(); pacc[k] += t_ - tlast; tlast = t_; }
 #else
@@ -367,7 +367,7 @@ struct Parser {
     // where the literals are and where the next sequence starts; `stop`: the fast path does not take it.
     struct Seq {
         uint32_t lit, mlen, offset, lit_at, next;
-        bool stop, tail;
+        bool stop, tail, longer;   // longer: stopped for its lengths (more than one extension byte, more than kLitRunMax literals): no round takes it
     };
     SWC_D static Seq sequence_at(const uint8_t* stage, uint32_t ip, uint32_t safe, uint32_t tail_limit) {
         Seq q;
@@ -388,6 +388,7 @@ struct Parser {
         // long lengths, the staged window, the tail of the block: the lane stops in front of it
         q.stop = ((lx & (uint32_t)(b1 == 255)) | (mx & (uint32_t)(b2 == 255)) | (uint32_t)(p > safe) | (uint32_t)(q.next > tail_limit) | (uint32_t)(q.lit > lzr::kLitRunMax)) != 0u;
         q.tail = q.next > tail_limit && p <= safe;
+        q.longer = ((lx & (uint32_t)(b1 == 255)) | (mx & (uint32_t)(b2 == 255)) | (uint32_t)(q.lit > lzr::kLitRunMax)) != 0u && p <= safe;
         return q;
     }
     // Where does a parse from `start` end?  Returns the first sequence start at or beyond `chunk_end` (or where the lane stopped).
@@ -427,7 +428,7 @@ struct Parser {
                 else {
                     const Seq q = sequence_at(stage, ip, safe, tail_limit);
                     bad = q.stop || q.offset == 0;
-                    if (bad) flags |= q.stop ? (q.tail ? kLzStop | kLzTail : kLzStop) : kLzFail;   // offset 0: LZ4.swift:382
+                    if (bad) flags |= q.stop ? (q.tail ? kLzStop | kLzTail : q.longer ? kLzStop | kLzLong : kLzStop) : kLzFail;   // offset 0: LZ4.swift:382
                     else {
                         const int32_t nd = (int32_t)q.offset - (int32_t)(nout + q.lit);          // :382 offset <= bytes produced, checked after the scan
                         need = nd > need ? nd : need;
@@ -637,7 +638,9 @@ struct Parser {
             sequences += tot_rec;
             SWC_LZ4_STAT(3, tot_rec);
             ip = B + simt::wave_read<N>(endp, (int)nv - 1);
-            if (stop_flags & (kLzFail | kLzTail)) return;                     // anything invalid / the end of the block: the checked step
+            // anything invalid / the end of the block / a sequence no round takes (a long literal run: the next round would stage
+            // 8 KiB to find out in its first lane): the checked step
+            if (stop_flags & (kLzFail | kLzTail | kLzLong)) return;
         }
     }
 
