@@ -102,12 +102,19 @@ SWC_HD size_t segbuf_bytes(size_t lcap) {   // (regular segments + 1) x capacity
     const size_t a = (regs + 1) * ((size_t)kSegCapFactor << m), b = (regs2 + 1) * ((size_t)kSegCapFactor << m2);
     return (a > b ? a : b) + 64;
 }
-// The team walk (bzip2_team.h) cuts a block into up to kSegs2 segments and keeps their lengths and successors -- and 512 words of
-// its own (ticket counters, prefix of the segment counts) -- in the same area, and the segments' offsets behind them; the fused
-// kernel uses the first 2 x (kSegs + 1) words.
-constexpr size_t kSegInfoBytes = (((4 * (size_t)(kSegs2 + 1) + kTeamWords) * 4 + 15) / 16) * 16;   // length and successor of every segment (stage 3a)
+// The team walk (bzip2_team.h) cuts a block into up to kSegs2 segments (of 32 bytes and more: a small block has few) and keeps
+// four words per segment -- length and successor, offset, the index where a long segment's buffer was full -- and kTeamWords
+// of its own (ticket counters, prefix of the segment counts) in the same area; the fused kernel uses the first 2 x (kSegs + 1) words.
+SWC_HD uint32_t team_seg_slots(size_t lcap) {     // segments a block of at most lcap bytes can have (+ origPtr's, + one), a multiple of four
+    const size_t by_size = (lcap + 31) / 32;
+    return (uint32_t)((by_size < kSegs2 ? by_size : kSegs2) + 2 + 3) & ~3u;
+}
+SWC_HD size_t seg_info_bytes(size_t lcap) {        // length and successor of every segment (stage 3a)
+    const size_t team = 4 * (size_t)team_seg_slots(lcap), fused = 2 * (size_t)(kSegs + 1);
+    return ((((team > fused ? team : fused) + kTeamWords) * 4 + 15) / 16) * 16;
+}
 SWC_HD size_t ws_bytes_per_job(size_t lcap) {
-    return ((lcap + 15) & ~(size_t)15) + 32768 + lcap * 4 + sizeof(BlockHeader) + 64 + kSegInfoBytes + ((segbuf_bytes(lcap) + 15) & ~(size_t)15);
+    return ((lcap + 15) & ~(size_t)15) + 32768 + lcap * 4 + sizeof(BlockHeader) + 64 + seg_info_bytes(lcap) + ((segbuf_bytes(lcap) + 15) & ~(size_t)15);
 }
 struct Workspace {
     gptr L;
@@ -130,7 +137,7 @@ SWC_HD Workspace carve(uint8_t* base, size_t job, size_t lcap) {
     const size_t info = (lpad + 32768 + lcap * 4 + sizeof(BlockHeader) + 64 + 15) & ~(size_t)15;
     w.seg_len = (SWC_AS_GLOBAL uint32_t*)(p + info);
     w.seg_next = w.seg_len + (kSegs + 1);
-    w.segbuf = (gptr)(p + info + kSegInfoBytes);
+    w.segbuf = (gptr)(p + info + seg_info_bytes(lcap));
     w.lcap = lcap;
     return w;
 }

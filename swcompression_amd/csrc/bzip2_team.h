@@ -39,18 +39,19 @@ constexpr uint32_t kTwSegs = 0, kTwBefore = 1, kTwBad = 2, kTwTeam = 16;
 static_assert(kTwTeam + 32 * kTeams <= kTeamWords, "the team counters fit block 0's words");
 
 struct TeamSegs {
-    SWC_AS_GLOBAL uint64_t* ln;      // [kSegs2 + 1] length of the segment | the segment that begins where it ends << 32 (one load per step of the ordering)
-    SWC_AS_GLOBAL uint32_t* off;     // [kSegs2 + 1] team_finish: the segment's offset in the block (an array of its own: written by
+    SWC_AS_GLOBAL uint64_t* ln;      // [team_seg_slots(lcap)] length of the segment | the segment that begins where it ends << 32 (one load per step of the ordering)
+    SWC_AS_GLOBAL uint32_t* off;     // [slots] team_finish: the segment's offset in the block (an array of its own: written by
                                      // some lanes and read by others, it must not sit in lines the wave has read before)
-    SWC_AS_GLOBAL uint32_t* resume;  // [kSegs2 + 1] a segment longer than its buffer: the index its walk had reached when the buffer was full
+    SWC_AS_GLOBAL uint32_t* resume;  // [slots] a segment longer than its buffer: the index its walk had reached when the buffer was full
     SWC_AS_GLOBAL uint32_t* words;   // [kTeamWords]
 };
 SWC_HD TeamSegs team_segs(const Workspace& w) {
     TeamSegs t;
-    t.ln = (SWC_AS_GLOBAL uint64_t*)w.seg_len;    // (the area is 16-byte aligned)
-    t.off = w.seg_len + 2 * (kSegs2 + 1);
-    t.resume = w.seg_len + 3 * (kSegs2 + 1);
-    t.words = w.seg_len + 4 * (kSegs2 + 1);
+    const uint32_t slots = team_seg_slots(w.lcap);
+    t.ln = (SWC_AS_GLOBAL uint64_t*)w.seg_len;    // (the area is 16-byte aligned, the slots a multiple of four)
+    t.off = w.seg_len + 2 * slots;
+    t.resume = w.seg_len + 3 * slots;
+    t.words = w.seg_len + 4 * slots;
     return t;
 }
 // how a block of n bytes with origin pointer `orig` is cut
