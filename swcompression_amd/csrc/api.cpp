@@ -195,19 +195,6 @@ static void copy_out(std::vector<CopyOut>& v) {
     for (auto& x : th) x.join();
 }
 
-// SWC_TRACE=1 in the environment: the host-side stages of every run_units call with their wall-clock times, on stderr
-struct Trace {
-    bool on;
-    std::chrono::steady_clock::time_point t0, last;
-    Trace() { static const bool e = getenv("SWC_TRACE") != nullptr; on = e; t0 = last = std::chrono::steady_clock::now(); }
-    void mark(const char* what, size_t bytes = 0) {
-        if (!on) return;
-        const auto now = std::chrono::steady_clock::now();
-        fprintf(stderr, "[swc] %-28s %8.3f ms  (%zu bytes)\n", what, std::chrono::duration<double, std::milli>(now - last).count(), bytes);
-        last = now;
-    }
-};
-
 static int run_units_impl(int codec, std::vector<HostUnit>& units);
 int run_units(int codec, std::vector<HostUnit>& units) {
     const int st = run_units_impl(codec, units);

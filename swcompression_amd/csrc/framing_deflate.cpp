@@ -5,6 +5,8 @@
 //   GzipHeader.init(_:)                  reference Sources/GZip/GzipHeader.swift:68-199
 //   ZlibArchive.unarchive                reference Sources/Zlib/ZlibArchive.swift:25-42
 //   ZlibHeader.init(_:)                  reference Sources/Zlib/ZlibHeader.swift:47-92
+#include <thread>
+#include <algorithm>
 #include <vector>
 #include "host_util.h"
 #include "framing.h"
@@ -35,7 +37,16 @@ int run_one_bounded(int codec, HostUnit& u, size_t bound) {
 
 void give(const std::vector<uint8_t>& src, uint8_t** out, size_t* out_len) {
     uint8_t* p = host_result(src.size());
-    if (!src.empty()) memcpy(p, src.data(), src.size());
+    const size_t n = src.size(), nt = std::min<size_t>(8, n >> 24);         // a thread per 16 MB: one core copies 10 GB/s
+    if (nt >= 2) {
+        std::vector<std::thread> th;
+        const size_t per = (n / nt + 63) & ~(size_t)63;
+        for (size_t t = 0; t < nt; t++) {
+            const size_t lo = std::min(n, t * per), hi = t + 1 == nt ? n : std::min(n, (t + 1) * per);
+            th.emplace_back([=, &src] { if (hi > lo) memcpy(p + lo, src.data() + lo, hi - lo); });
+        }
+        for (auto& t : th) t.join();
+    } else if (n) memcpy(p, src.data(), n);
     *out = p;
     *out_len = src.size();
 }

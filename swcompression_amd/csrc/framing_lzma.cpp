@@ -111,12 +111,17 @@ struct Predecoded {
     int prop;
     std::vector<uint8_t> out;
     size_t in_consumed;
+    int sum_kind = 0;        // swc_checksum kind of `sum` (1 CRC-32, 3 CRC-64), 0 = none: computed on the device behind the decode
+    uint64_t sum = 0;
 };
+// what xz_block knows about the data it appended beyond the bytes: a checksum the device computed (a block whose only filter
+// is LZMA2 and whose data were decoded ahead)
+struct BlockSum { int kind = 0; uint64_t sum = 0; };
 typedef std::map<int64_t, Predecoded> BlockCache;
 
 // XZBlock.init (XZBlock.swift:18-97).  Appends the block's data to `out`.
 int xz_block(uint32_t header_size_byte, Reader& r, int check_size, std::vector<uint8_t>& out, int64_t& unpadded_size,
-             int64_t& uncomp_size, BlockCache* cache) {
+             int64_t& uncomp_size, BlockCache* cache, BlockSum* bsum = nullptr) {
     int st;
     const int64_t header_start = r.off - 1;
     const int64_t real_header_size = ((int64_t)header_size_byte + 1) * 4;
@@ -167,6 +172,7 @@ int xz_block(uint32_t header_size_byte, Reader& r, int check_size, std::vector<u
             // decoded ahead from exactly these bytes, cleanly: the same result the launch below would produce
             r.off += (int64_t)hit->second.in_consumed;
             next = std::move(hit->second.out);
+            if (bsum && filters_count == 1) { bsum->kind = hit->second.sum_kind; bsum->sum = hit->second.sum; }
             cache->erase(hit);
             stat_add(2, 1);
         } else if (filters[i].id == 0x21) {
@@ -261,17 +267,18 @@ int xz_stream(Reader& r, std::vector<uint8_t>& out, bool& check_error, BlockCach
         }
         int64_t unpadded, uncomp;
         const size_t bstart = out.size();
-        if ((st = xz_block(hs, r, check_size, out, unpadded, uncomp, cache))) return st;
+        BlockSum bsum;
+        if ((st = xz_block(hs, r, check_size, out, unpadded, uncomp, cache, &bsum))) return st;
         const uint8_t* bd = out.data() + bstart;
         const size_t bl = out.size() - bstart;
         if (check_type == 0x01) {
             const uint32_t c = (uint32_t)r.le(4);
             if (r.trap) return SWC_E_REF_TRAP;
-            if (swc_crc32(bd, bl, 0) != c) { check_error = true; return SWC_OK; }
+            if ((bsum.kind == 1 ? (uint32_t)bsum.sum : swc_crc32(bd, bl, 0)) != c) { check_error = true; return SWC_OK; }
         } else if (check_type == 0x04) {
             const uint64_t c = r.le(8);
             if (r.trap) return SWC_E_REF_TRAP;
-            if (swc_crc64(bd, bl) != c) { check_error = true; return SWC_OK; }
+            if ((bsum.kind == 3 ? bsum.sum : swc_crc64(bd, bl)) != c) { check_error = true; return SWC_OK; }
         } else if (check_type == 0x0A) {
             if (r.left() < 32) return SWC_E_REF_TRAP;
             uint8_t dg[32];
@@ -323,7 +330,7 @@ int xz_padding(Reader& r) {                                                     
 // depend on the bytes behind the block), and the sequential walk below -- which alone decides what the archive means --
 // picks it up when it arrives at the same offset with the same dictionary byte.  Anything inconsistent simply yields
 // no cache entry.
-struct Cand { int64_t data_off; size_t len; int prop; int64_t uncomp; };
+struct Cand { int64_t data_off; size_t len; int prop; int64_t uncomp; int check_type; };
 static void xz_candidates(const uint8_t* d, size_t n, std::vector<Cand>& cands) {
     int64_t end = (int64_t)n;
     for (int streams = 0; streams < 4096 && end >= 32; streams++) {
@@ -360,7 +367,7 @@ static void xz_candidates(const uint8_t* d, size_t n, std::vector<Cand>& cands) 
                 if (d[pos + 1] & 0x80) good = good && !multibyte(h, tmp);
                 good = good && !multibyte(h, id) && id == 0x21 && !multibyte(h, ps) && ps == 1;
                 const int prop = h.u8();
-                if (good && !h.trap) cands.push_back({pos + hsize, (size_t)comp, prop, rc.second});
+                if (good && !h.trap) cands.push_back({pos + hsize, (size_t)comp, prop, rc.second, check_type});
             }
             pos += (rc.first + 3) & ~(int64_t)3;
         }
@@ -372,25 +379,39 @@ void xz_predecode(const uint8_t* d, size_t n, BlockCache& cache) {
     std::vector<Cand> cands;
     xz_candidates(d, n, cands);
     if (cands.size() < 2) return;            // a single block gains nothing from being decoded ahead
+    // the blocks' check, if the streams of the archive agree on CRC-32 or CRC-64: on the device, behind the decode (a launch
+    // computes one kind; XZArchive.swift:106-121 on one host thread was as long as the launch itself)
+    int kind = cands[0].check_type == 0x01 ? 1 : cands[0].check_type == 0x04 ? 3 : 0;
+    for (const Cand& c : cands) if (c.check_type != cands[0].check_type) kind = 0;
     std::vector<HostUnit> units(cands.size());
     for (size_t k = 0; k < cands.size(); k++) {
         HostUnit& u = units[k];
         u.in = d + cands[k].data_off;
         u.in_len = cands[k].len;
+        u.base = d;
+        u.base_len = n;
         u.aux = cands[k].prop;
         u.cap_hint = std::max<size_t>(lzma2_announced_size(u.in, u.in_len), 16);
+        u.sum_kind = kind;
     }
     if (run_units(SWC_CODEC_LZMA2, units) != SWC_OK) return;
     for (size_t k = 0; k < cands.size(); k++) {
         if (units[k].status != SWC_OK) continue;
-        cache[cands[k].data_off] = Predecoded{cands[k].prop, std::move(units[k].out), units[k].in_consumed};
+        Predecoded p{cands[k].prop, std::move(units[k].out), units[k].in_consumed};
+        if (units[k].sum_valid) { p.sum_kind = kind; p.sum = units[k].sum; }
+        cache[cands[k].data_off] = std::move(p);
     }
 }
 
 int xz_run(const uint8_t* in, size_t in_len, std::vector<uint8_t>& all, std::vector<size_t>& sizes) {
+    Trace tr;
     BlockCache cache_store;
     xz_predecode(in, in_len, cache_store);
+    tr.mark("xz: blocks decoded ahead", in_len);
     BlockCache* cache = &cache_store;
+    size_t ahead = 0;
+    for (const auto& kv : cache_store) ahead += kv.second.out.size();
+    all.reserve(ahead + 64);                 // (the result grows block by block: without this, by doubling and copying)
     Reader r{in, in_len, 0, false};
     while (!r.finished()) {
         if (r.left() < 32) { all.clear(); sizes.clear(); return SWC_E_XZ_WRONG_MAGIC; }  // :37
@@ -403,6 +424,7 @@ int xz_run(const uint8_t* in, size_t in_len, std::vector<uint8_t>& all, std::vec
         st = xz_padding(r);
         if (st) { all.clear(); sizes.clear(); return st; }
     }
+    tr.mark("xz: the walk of the streams", all.size());
     return SWC_OK;
 }
 

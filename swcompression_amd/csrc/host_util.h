@@ -3,6 +3,8 @@
 #define SWC_HOST_UTIL_H
 
 #include <hip/hip_runtime.h>
+#include <chrono>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -94,6 +96,19 @@ struct HostUnit {
 // Stage units to HBM, run ONE batched launch of `codec` (re-launching only the units that reported
 // SWC_E_CAPACITY with a larger buffer), fetch the results.  Returns SWC_OK or SWC_E_DEVICE.
 int run_units(int codec, std::vector<HostUnit>& units);
+
+// SWC_TRACE=1 in the environment: the host-side stages of a call with their wall-clock times, on stderr
+struct Trace {
+    bool on;
+    std::chrono::steady_clock::time_point t0, last;
+    Trace() { static const bool e = getenv("SWC_TRACE") != nullptr; on = e; t0 = last = std::chrono::steady_clock::now(); }
+    void mark(const char* what, size_t bytes = 0) {
+        if (!on) return;
+        const auto now = std::chrono::steady_clock::now();
+        fprintf(stderr, "[swc] %-28s %8.3f ms  (%zu bytes)\n", what, std::chrono::duration<double, std::milli>(now - last).count(), bytes);
+        last = now;
+    }
+};
 
 // swc_stat counters (api.cpp)
 void stat_add(int which, long long v);   // 0 launches, 1 units, 2 xz_cache_hits
