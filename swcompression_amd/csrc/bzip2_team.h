@@ -12,14 +12,17 @@
 //     those of the next: no barrier between blocks, the stragglers of a block finish while the others are on the next one,
 //     and the team's L2 holds the one or two blocks its walkers are on;
 //   * a walker keeps the bytes it meets in the segment's buffer (non-temporal stores: they must not push P out of the L2)
-//     and leaves the segment's length and successor, exactly as the fused kernel's walk does.
+//     and leaves the segment's length and successor as the fused kernel's walk does -- and, for the one segment in 55 that is
+//     longer than its buffer, the index at which the buffer was full.
 // Then a wavefront per block (team_finish) puts the segments in cycle order -- 14,000 segments are themselves a chain too long
-// to follow, so it is cut the same way once more: at the segments whose number is a multiple of 64 -- lays the bytes out in L,
-// and undoes RLE1 with the code of the fused kernel (rle1_undo_to_output).  Whatever does not check out (a permutation that is
+// to follow, so it is cut the same way once more: at the segments whose number is a multiple of 64 -- lays the bytes out in L
+// (buffered prefixes by eight lanes per segment, the long segments finished together from where their buffers ended), and
+// undoes RLE1 with the code of the fused kernel (rle1_undo_to_output).  Whatever does not check out (a permutation that is
 // not one cycle, a damaged block) is left to the serial fallback of stage 3b, as before.
 //
 // Kernels: team_prep (segment counts of the blocks, their prefix per team, the counters), team_walk, team_finish; the fused
-// kernel runs with its walk switched off in front of them.  Selected by launch_bzip2 for launches of many blocks.
+// kernel runs with its walk switched off in front of them.  launch_bzip2 takes this path for every launch but the tiny ones
+// (one block of 100 kB is already faster this way: DESIGN.md 5.2).
 #ifndef SWC_BZIP2_TEAM_H
 #define SWC_BZIP2_TEAM_H
 
@@ -32,7 +35,7 @@ constexpr uint32_t kTeams = 8;
 constexpr uint32_t kSuper = 64;                       // team_finish: the chain of segments is cut at every 64th segment
 constexpr uint32_t kSupers = kSegs2 / kSuper + 2;     // ... into at most this many pieces (+ origPtr's segment)
 constexpr uint32_t kOver = 1024;                      // team_finish: segments longer than their buffers it can take (e^-4 of them are: 260 of 14,000)
-// words of a block's own (behind the two segment arrays): [0] segments of the block, [1] segments of the team's blocks in front
+// words of a block's own (behind the per-segment arrays): [0] segments of the block, [1] segments of the team's blocks in front
 // of it, [2] the walk ran away (not a permutation); block 0 also holds, for team x, at [16 + 32 x]: the ticket counter, at
 // [16 + 32 x + 1]: the segments of all of the team's blocks
 constexpr uint32_t kTwSegs = 0, kTwBefore = 1, kTwBad = 2, kTwTeam = 16;
