@@ -118,7 +118,9 @@ def _split(blob, sizes):
     return out
 
 
-def _call_simple(name, data, *mid, consumed=False):
+def _call_simple(name, data, *mid, consumed=False, view=False):
+    """view=True: the result is a read-only memoryview OF the C result instead of a bytes object copied from it (what a Swift
+    shim does with Data(bytesNoCopy:count:deallocator:)); the buffer is released when the view dies."""
     lib = _lib.load()
     data = bytes(data)
     out = C.POINTER(C.c_uint8)()
@@ -128,6 +130,11 @@ def _call_simple(name, data, *mid, consumed=False):
     if consumed:
         args.append(C.byref(cons))
     st = getattr(lib, name)(*args)
+    if view and not st and n.value:
+        arr = (C.c_ubyte * n.value).from_address(C.cast(out, C.c_void_p).value)
+        arr._owner = _Owner(out)
+        mv = memoryview(arr).cast("B").toreadonly()
+        return (mv, cons.value) if consumed else mv
     blob = _take(out, n.value)
     if st:
         _raise(st, blob)
@@ -264,8 +271,8 @@ class LZMA2:
 
 class XZArchive:
     @staticmethod
-    def unarchive(archive):
-        return _call_simple("swc_xz_unarchive", archive)
+    def unarchive(archive, view=False):
+        return _call_simple("swc_xz_unarchive", archive, view=view)
 
     @staticmethod
     def split_unarchive(archive):

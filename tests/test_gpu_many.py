@@ -190,6 +190,18 @@ def test_bgzf_members_share_one_launch():
                 assert ei.value.data == exp, k
 
 
+def test_single_result_as_a_view():
+    import lzma as pylzma
+    x = corpus.p_text(3 << 20, 77)
+    a = pylzma.compress(x, format=pylzma.FORMAT_XZ, check=pylzma.CHECK_CRC64, preset=1)
+    v = swc.XZArchive.unarchive(a, view=True)
+    assert isinstance(v, memoryview) and v.readonly and v == x
+    w = swc.XZArchive.unarchive(a, view=True)                   # the first result is still alive and untouched
+    assert v == x and w == x
+    del v, w
+    assert swc.XZArchive.unarchive(a) == x
+
+
 def test_bgzf_views_and_recycled_results():
     """The members of a BGZF file as VIEWS into the C result (what a Swift shim gets with Data(bytesNoCopy:)): same bytes as the
     copies, alive as long as one view is; results of 4 MiB and more are parked by swc_free and taken over by the next call of
