@@ -266,7 +266,10 @@ SWC_HD void team_finish(Job& job, Workspace ws, FinishLds* l, int lane) {
 #endif
     // lay out.  The buffered prefixes: eight lanes per segment, eight bytes each per step (a lane per segment would read a line
     // per eight bytes and wait for the longest of 64 segments)
-    constexpr int kLps = WAVE >= 8 ? 8 : 1;
+#ifndef SWC_TF_LPS
+#define SWC_TF_LPS 8   // lanes per segment of the prefix copy (the finish with 2 / 4 / 8 / 16: 49.2 / 48.0 / 48.8 / 60.2 ms)
+#endif
+    constexpr int kLps = WAVE >= 8 ? SWC_TF_LPS : 1;
     const uint32_t sub = (uint32_t)lane % kLps, grp = (uint32_t)lane / kLps;
     if (lane == 0) l->n_over = 0;
     simt::wave_fence();
