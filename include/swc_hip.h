@@ -147,6 +147,21 @@ int swc_lz4_compress(const uint8_t* data, size_t len, int independent_blocks, in
  * endian; computed on the device in the same launch sequence). */
 int swc_deflate_compress(const uint8_t* data, size_t len, uint8_t** out, size_t* out_len);
 int swc_zlib_archive(const uint8_t* data, size_t len, uint8_t** out, size_t* out_len);
+/* GzipArchive.archive(data:comment:fileName:writeHeaderCRC:isTextFile:osType:modificationTime:extraFields:)
+ * GzipArchive.swift:126-240: the header as the reference writes it (magic, CM 8, flags, MTIME, XFL 2, OS, FEXTRA, FNAME,
+ * FCOMMENT, FHCRC), Deflate.compress(data) on the device, CRC-32 and ISIZE.  comment / file_name: ISO Latin-1 bytes (NULL =
+ * none; the terminating zero is added unless the last byte is one, :134-136 / :147-149 -- the String conversion and its
+ * cannotEncodeISOLatin1 are the shim's); os_type: the header byte (FileSystemType+Gzip.swift:23-36, 255 = unknown);
+ * has_mtime 0 = four zero bytes, else the low four bytes of `mtime` seconds (:172-178).  Extra fields that sum up (4 + length
+ * each) to more than 65,535 bytes: SWC_E_GZIP_CANNOT_ENCODE_ISO_LATIN1, as the reference throws (:190-191). */
+typedef struct swc_gzip_extra_field {
+    uint8_t si1, si2;
+    const uint8_t* bytes;
+    size_t len;
+} swc_gzip_extra_field;
+int swc_gzip_archive(const uint8_t* data, size_t len, const uint8_t* comment, size_t comment_len, const uint8_t* file_name,
+                     size_t file_name_len, int write_header_crc, int is_text_file, int os_type, int has_mtime, int64_t mtime,
+                     const swc_gzip_extra_field* extra, size_t n_extra, uint8_t** out, size_t* out_len);
 /* BZip2.compress(data:blockSize:) BZip2+Compress.swift:40-74 (BZip2.compress(data:) :19-21 = block_size 1).  block_size 1..9 =
  * BlockSize.one ... .nine (else SWC_E_INVALID_ARGUMENT); the input is cut into blocks of block_size x 80,000 bytes as the
  * reference cuts it (:46), all blocks are compressed on the device together: initial run-length coding, Burrows-Wheeler

@@ -69,6 +69,7 @@ typedef enum swc_status {
     SWC_E_GZIP_WRONG_HEADER_CRC = 604,         /* :21 */
     SWC_E_GZIP_WRONG_CRC = 605,                /* :30 carries members decoded so far */
     SWC_E_GZIP_WRONG_ISIZE = 606,              /* :32 */
+    SWC_E_GZIP_CANNOT_ENCODE_ISO_LATIN1 = 607, /* :34 (GzipArchive.archive: a name or comment outside ISO Latin-1, extra fields beyond 65,535 bytes) */
 
     /* ZlibError -- Sources/Zlib/ZlibError.swift:12-26 */
     SWC_E_ZLIB_WRONG_COMPRESSION_METHOD = 701, /* :14 */

@@ -42,7 +42,7 @@ STATUS = {
     501: ("DataError", "truncated"), 502: ("DataError", "corrupted"), 503: ("DataError", "checksumMismatch"),
     504: ("DataError", "unsupportedFeature"),
     601: ("GzipError", "wrongMagic"), 602: ("GzipError", "wrongCompressionMethod"), 603: ("GzipError", "wrongFlags"),
-    604: ("GzipError", "wrongHeaderCRC"), 605: ("GzipError", "wrongCRC"), 606: ("GzipError", "wrongISize"),
+    604: ("GzipError", "wrongHeaderCRC"), 605: ("GzipError", "wrongCRC"), 606: ("GzipError", "wrongISize"), 607: ("GzipError", "cannotEncodeISOLatin1"),
     701: ("ZlibError", "wrongCompressionMethod"), 702: ("ZlibError", "wrongCompressionInfo"), 703: ("ZlibError", "wrongFcheck"),
     704: ("ZlibError", "wrongCompressionLevel"), 705: ("ZlibError", "wrongAdler32"),
     801: ("XZError", "wrongMagic"), 802: ("XZError", "wrongField"), 803: ("XZError", "wrongInfoCRC"), 804: ("XZError", "wrongFilterID"),
@@ -210,6 +210,46 @@ class GzipArchive:
     @staticmethod
     def multi_unarchive(archive, views=False):
         return _call_multi("swc_gzip_multi_unarchive", archive, views=views)
+
+    @staticmethod
+    def archive(data, comment=None, file_name=None, write_header_crc=False, is_text_file=False, os_type=None,
+                modification_time=None, extra_fields=()):
+        """GzipArchive.archive(data:comment:fileName:writeHeaderCRC:isTextFile:osType:modificationTime:extraFields:)
+        (GzipArchive.swift:126-240).  os_type: the header byte (0 FAT, 3 Unix, 7 Macintosh, 11 NTFS, None = 255 unknown:
+        FileSystemType+Gzip.swift:23-36); modification_time: seconds since 1970; extra_fields: (si1, si2, bytes) triples.
+        The body is Deflate.compress(data) on the device."""
+        def latin1(text):
+            if text is None:
+                return None, 0
+            try:
+                b = text.encode("latin-1") if isinstance(text, str) else bytes(text)
+            except UnicodeEncodeError:
+                _raise(607)                                             # GzipError.cannotEncodeISOLatin1 (:137-141, :150-154)
+            return b, len(b)
+        lib = _lib.load()
+        data = bytes(data)
+        cb, cn = latin1(comment)
+        fb, fn = latin1(file_name)
+        keep = [bytes(e[2]) for e in extra_fields]
+        arr = (_lib.SwcGzipExtraField * max(len(keep), 1))()
+        for k, e in enumerate(extra_fields):
+            arr[k].si1, arr[k].si2 = int(e[0]), int(e[1])
+            arr[k].bytes = C.cast(C.c_char_p(keep[k]), C.c_void_p)
+            arr[k].len = len(keep[k])
+        out = C.POINTER(C.c_uint8)()
+        n = C.c_size_t()
+        if cb is not None and cn == 0:
+            cb = C.create_string_buffer(1).raw                          # a non-NULL pointer: an empty comment is a comment
+        if fb is not None and fn == 0:
+            fb = C.create_string_buffer(1).raw
+        st = lib.swc_gzip_archive(data, len(data), cb, cn, fb, fn, int(bool(write_header_crc)), int(bool(is_text_file)),
+                                  255 if os_type is None else int(os_type), 0 if modification_time is None else 1,
+                                  0 if modification_time is None else int(modification_time), C.cast(arr, C.c_void_p) if keep else None,
+                                  len(keep), C.byref(out), C.byref(n))
+        res = _take(out, n.value)
+        if st:
+            _raise(st, res)
+        return res
 
 
 class ZlibArchive:

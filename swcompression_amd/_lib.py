@@ -15,6 +15,10 @@ class SwcJob(C.Structure):
                 ("dict", C.c_void_p), ("dict_len", C.c_uint64)]
 
 
+class SwcGzipExtraField(C.Structure):
+    _fields_ = [("si1", C.c_uint8), ("si2", C.c_uint8), ("bytes", C.c_void_p), ("len", C.c_size_t)]
+
+
 class SwcBatchOpts(C.Structure):
     _fields_ = [("device", C.c_int32), ("stream", C.c_void_p), ("synchronize", C.c_int32), ("reserved", C.c_int32)]
 
@@ -73,6 +77,8 @@ def load():
     sig("swc_deflate_compress", I, C.c_char_p, C.c_size_t, u8pp, szp)
     sig("swc_bzip2_compress", I, C.c_char_p, C.c_size_t, I, u8pp, szp)
     sig("swc_zlib_archive", I, C.c_char_p, C.c_size_t, u8pp, szp)
+    sig("swc_gzip_archive", I, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, I, I, I, I, C.c_int64,
+        C.c_void_p, C.c_size_t, u8pp, szp)
     sig("swc_lz4_compress", I, C.c_char_p, C.c_size_t, I, I, I, I, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int64, u8pp, szp)
     sig("swc_zip_get_entries_data", I, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t)
     sig("swc_stat", C.c_longlong, C.c_char_p)

@@ -342,6 +342,65 @@ int swc_deflate_compress(const uint8_t* data, size_t len, uint8_t** out, size_t*
     if (out && out_len) give_empty(out, out_len);
     return SWC_E_DEVICE;
 }
+// GzipArchive.archive(data:comment:fileName:writeHeaderCRC:isTextFile:osType:modificationTime:extraFields:) (GzipArchive.swift:126-240)
+int swc_gzip_archive(const uint8_t* data, size_t len, const uint8_t* comment, size_t comment_len, const uint8_t* file_name,
+                     size_t file_name_len, int write_header_crc, int is_text_file, int os_type, int has_mtime, int64_t mtime,
+                     const swc_gzip_extra_field* extra, size_t n_extra, uint8_t** out, size_t* out_len) try {
+    if (!out || !out_len || (len && !data) || (comment_len && !comment) || (file_name_len && !file_name) || (n_extra && !extra))
+        return SWC_E_INVALID_ARGUMENT;
+    uint8_t flags = 0;
+    if (comment) flags |= 1 << 4;                                      // :131-132
+    if (file_name) flags |= 1 << 3;                                    // :144-145
+    if (n_extra) flags |= 1 << 2;                                      // :157-159
+    if (write_header_crc) flags |= 1 << 1;                             // :161-163
+    if (is_text_file) flags |= 1 << 0;                                 // :165-167
+    std::vector<uint8_t> z = {0x1f, 0x8b, 8, flags};                   // :180-184
+    for (int i = 0; i < 4; i++) z.push_back(has_mtime ? (uint8_t)((uint64_t)mtime >> (8 * i)) : 0);   // :171-178, :185-187
+    z.push_back(2);                                                    // :188 XFL: the slowest algorithm
+    z.push_back((uint8_t)os_type);                                     // :169, :189
+    if (n_extra) {                                                     // :191-209
+        size_t xlen = 0;
+        for (size_t k = 0; k < n_extra; k++) {
+            if (extra[k].len && !extra[k].bytes) { give_empty(out, out_len); return SWC_E_INVALID_ARGUMENT; }
+            xlen += 4 + extra[k].len;
+        }
+        if (xlen > 65535) { give_empty(out, out_len); return SWC_E_GZIP_CANNOT_ENCODE_ISO_LATIN1; }
+        z.push_back((uint8_t)(xlen & 0xFF));
+        z.push_back((uint8_t)(xlen >> 8));
+        for (size_t k = 0; k < n_extra; k++) {
+            z.push_back(extra[k].si1);
+            z.push_back(extra[k].si2);
+            z.push_back((uint8_t)(extra[k].len & 0xFF));
+            z.push_back((uint8_t)((extra[k].len >> 8) & 0xFF));
+            z.insert(z.end(), extra[k].bytes, extra[k].bytes + extra[k].len);
+        }
+    }
+    auto terminated = [&](const uint8_t* p, size_t n) {                // :134-136, :147-149: a zero behind it unless it ends in one
+        z.insert(z.end(), p, p + n);
+        if (n == 0 || p[n - 1] != 0) z.push_back(0);
+    };
+    if (file_name) terminated(file_name, file_name_len);               // :213
+    if (comment) terminated(comment, comment_len);                     // :214
+    if (write_header_crc) {                                            // :216-221
+        const uint32_t h = swc_crc32(z.data(), z.size(), 0);
+        z.push_back((uint8_t)h);
+        z.push_back((uint8_t)(h >> 8));
+    }
+    HostUnit u;
+    int st = deflate_compress_unit(data, len, u);                      // :223
+    if (st == SWC_OK) st = u.status;
+    if (st) { give_empty(out, out_len); return st; }
+    z.insert(z.end(), u.out.begin(), u.out.end());
+    const uint32_t c = swc_crc32(data, len, 0);                        // :225-230
+    for (int i = 0; i < 4; i++) z.push_back((uint8_t)(c >> (8 * i)));
+    const uint64_t isize = (uint64_t)len % ((uint64_t)1 << 32);       // :232-237
+    for (int i = 0; i < 4; i++) z.push_back((uint8_t)(isize >> (8 * i)));
+    give(z, out, out_len);
+    return SWC_OK;
+} catch (...) {
+    if (out && out_len) give_empty(out, out_len);
+    return SWC_E_DEVICE;
+}
 // ZlibArchive.archive(data:) (ZlibArchive.swift:54-70)
 int swc_zlib_archive(const uint8_t* data, size_t len, uint8_t** out, size_t* out_len) try {
     if (!out || !out_len || (len && !data)) return SWC_E_INVALID_ARGUMENT;

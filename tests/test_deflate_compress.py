@@ -109,6 +109,34 @@ def test_gpu_single_shot_and_zlib_archive():
 
 
 @pytest.mark.gpu
+def test_gpu_gzip_archive_header_and_trailer():
+    """GzipArchive.archive (GzipArchive.swift:126-240): the header fields as the reference writes them, the body a Deflate stream
+    of the device, CRC-32 and ISIZE; read back by Python's gzip, the oracle's GzipArchive.unarchive and the engine's."""
+    import gzip
+    import struct
+    import swcompression_amd as swc
+    x = corpus.p_text(100000, 51)
+    a = swc.GzipArchive.archive(x)
+    assert a[:10] == bytes([0x1f, 0x8b, 8, 0, 0, 0, 0, 0, 2, 255])                       # no flags, no MTIME, XFL 2, OS unknown
+    assert a[-8:] == struct.pack("<II", zlib.crc32(x) & 0xFFFFFFFF, len(x))
+    assert gzip.decompress(a) == x and O.gzip_unarchive(a) == (0, x) and swc.GzipArchive.unarchive(a) == x
+    b = swc.GzipArchive.archive(x, comment="a comment \xe9", file_name="name.txt", write_header_crc=True, is_text_file=True, os_type=3,
+                                modification_time=1700000000.9, extra_fields=[(ord("B"), ord("C"), b"\x34\x12"), (1, 2, b"")])
+    assert b[3] == 0x1F and b[4:8] == struct.pack("<I", 1700000000) and b[8] == 2 and b[9] == 3
+    assert b[10:12] == struct.pack("<H", 10) and b[12:18] == b"BC\x02\x00\x34\x12" and b[18:22] == bytes([1, 2, 0, 0])
+    assert b[22:31] == b"name.txt\0" and b[31:43] == "a comment \xe9".encode("latin-1") + b"\0"
+    assert b[43:45] == struct.pack("<H", zlib.crc32(b[:43]) & 0xFFFF)                     # FHCRC: the low half of the header's CRC-32
+    assert gzip.decompress(b) == x and O.gzip_unarchive(b) == (0, x) and swc.GzipArchive.unarchive(b) == x
+    e = swc.GzipArchive.archive(b"", comment="", file_name="x\0")
+    assert e[3] == 0x18 and e[10:13] == b"x\0\0" and gzip.decompress(e) == b""          # a name that ends in zero keeps its one; an empty comment is a zero
+    with pytest.raises(swc.GzipError) as ei:
+        swc.GzipArchive.archive(x, comment="\u20ac")
+    assert ei.value.case == "cannotEncodeISOLatin1"
+    with pytest.raises(swc.GzipError):
+        swc.GzipArchive.archive(x, extra_fields=[(1, 1, bytes(65532))])                    # 4 + 65,532 > 65,535 (:190-191)
+
+
+@pytest.mark.gpu
 def test_gpu_batch_decodes_on_the_device():
     """4,096 distinct 64 KiB buffers compressed in one launch, decoded again by the engine's own decoder in one launch."""
     import numpy as np
