@@ -6,7 +6,7 @@
 // (:30-45, with the reference's own size formula :48-83 applied to THIS parse).
 //
 // The reference finds matches through an exact dictionary of the most recent position of every three-byte group it has looked
-// up (a Swift Dictionary); a GPU wave keeps a HASH table of 8,192 positions in LDS (16-bit entries: a match reaches 32,768
+// up (a Swift Dictionary); a GPU wave keeps a HASH table of 4,096 positions in LDS (16-bit entries: a match reaches 32,768
 // bytes back, so the low half of a position is enough to find the distance), looks 64 consecutive positions up at once --
 // of the lanes of a window that share a hash the HIGHEST enters its position, found with one ballot per hash bit, so the
 // result does not depend on the order of the lanes -- and takes the matches of the window greedily from the left; all 64
@@ -28,8 +28,10 @@
 namespace swc {
 namespace defc {
 
+// Positions in the hash table: 13 / 12 / 11 bits = 17 / 9 / 5 KB of LDS per wave = 9 / 17 / 30 waves per CU.  100,000 x 64 KiB:
+// 443 / 312 / 256 ms, 0.999 / 1.015 / 1.050 x the size of the reference encoder restated (profiles/r05_experiments.txt): 12.
 #ifndef SWC_DEFC_HASH_BITS
-#define SWC_DEFC_HASH_BITS 13
+#define SWC_DEFC_HASH_BITS 12
 #endif
 constexpr uint32_t kHashBits = SWC_DEFC_HASH_BITS, kHashSize = 1u << kHashBits;
 constexpr uint32_t kStageDw = 256;                 // dwords of the bit stream staged in LDS (an emission adds at most 64)
