@@ -14,6 +14,7 @@ group, the engine refines its tables in four passes over all groups the way bzip
 CPU tier: the stages of csrc/bzip2_comp.h and their driver on the host emulation (std::sort in place of the device radix sort);
 GPU tier: the C ABI (swc_bzip2_compress)."""
 import bz2
+import json
 import os
 import random
 
@@ -23,6 +24,7 @@ import _emu as E
 import _oracle as O
 from swcompression_amd import corpus
 
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_inline_vectors.json")))
 BLOCK_MAGIC = 0x314159265359
 EOS_MAGIC = 0x177245385090
 
@@ -38,6 +40,8 @@ def payloads():
     for _ in range(10):
         n = rnd.choice([1, 2, 3, 5, 6, 7, 8, 13, 63, 64, 65, 127, 128, 129, 1000])
         ps.append(bytes(rnd.choice(b"abcd") for _ in range(n)))
+    # the inputs of the reference's own compression tests (tests/golden: the strings and byte vectors written inline in its XCTest sources)
+    ps += [s.encode("latin1") for s in GOLD["roundtrip_strings"]] + [bytes.fromhex(h) for h in GOLD["roundtrip_bytes"]]
     return ps
 
 

@@ -52,16 +52,15 @@ def test_oracle_compressor_round_trips_and_block_rule():
         kind = check_stream(x, z)
         if len(x) > 65530:
             assert kind == 1                      # "if data size is greater than 65535 ... static Huffman" (:18-20)
-    for s in GOLD.get("round_trip_strings", []):
-        x = s.encode("latin1") if isinstance(s, str) else bytes(s)
-        check_stream(x, O.deflate_compress(x))
+    for x in [s.encode("latin1") for s in GOLD["roundtrip_strings"]] + [bytes.fromhex(h) for h in GOLD["roundtrip_bytes"]]:
+        check_stream(x, O.deflate_compress(x))            # the inputs of the reference's own compression tests (tests/golden)
 
 
 @pytest.mark.parametrize("order", [0, 1, 2])
 def test_emulated_kernel_round_trips(order):
     E.set_order(order)
     try:
-        ps = payloads()
+        ps = payloads() + [s.encode("latin1") for s in GOLD["roundtrip_strings"]] + [bytes.fromhex(h) for h in GOLD["roundtrip_bytes"]]
         for x, (st, z, cons, n) in zip(ps, E.deflate_compress(ps)):
             assert st == 0 and n == len(z) and cons == len(x)
             check_stream(x, z)
