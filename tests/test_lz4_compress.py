@@ -3,6 +3,8 @@ the reference encoder's bytes (a hash table in LDS instead of an exact dictionar
 decodes to the input under the REFERENCE DECODER's rules -- the oracle's restatement of LZ4.process(block:_:), end-of-block
 rules included -- and under liblz4.  CPU tier: the kernel source built for the host; GPU tier: the C ABI."""
 import ctypes as C
+import json
+import os
 import random
 import struct
 
@@ -13,9 +15,14 @@ import _oracle as O
 from swcompression_amd import corpus
 
 
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "ref_inline_vectors.json")))
+
+
 def _payloads():
     rnd = random.Random(11)
     out = [b"", b"a", b"abcd" * 3, b"x" * 12, b"x" * 13, b"x" * 14, b"abcdefgh" * 40, bytes(range(256)) * 3]
+    # the inputs of the reference's own compression tests (tests/golden: written inline in its XCTest sources)
+    out += [s.encode("latin1") for s in GOLD["roundtrip_strings"]] + [bytes.fromhex(h) for h in GOLD["roundtrip_bytes"]]
     for kind in ("text", "mix", "rep", "zero", "rand"):
         for n in (1, 5, 12, 13, 64, 65, 300, 4096, 65536, 70001, 300000):
             out.append(corpus.PAYLOADS[kind](n, rnd.randrange(1000)))
