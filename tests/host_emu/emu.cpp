@@ -142,6 +142,22 @@ extern "C" void emu_bzip2_block(swc::Job* jobs, size_t n, size_t lcap) {
 // BZip2 with stage 3a as kernels of its own (bzip2_team.h): stage 1 + 2 of ALL jobs, then the segment counts and their prefixes
 // per team, the walk (every team's tickets drawn by one thread; `start_team`: the team whose thread goes first and, with the
 // work stealing, through the others' tickets too when `one_thread` is set), the finish per job, the serial fallback, the CRC.
+// The workspace geometry of stage 3 for a block of n bytes inside a workspace cut for lcap: what the two walks need against what
+// the layout gives them (tests/test_lane_emulation_bzip2.py walks through many (lcap, n) pairs).
+extern "C" void emu_bzip2_layout(size_t lcap, uint32_t n, uint64_t* out) {
+    using namespace swc::bzip2;
+    Cut c;
+    c.set(n, n / 3u + 1u < n ? n / 3u + 1u : 0u);                       // an origin pointer off the marks where there is room
+    const uint32_t m = seg_mbits(n), regs = (n + (1u << m) - 1u) >> m;
+    out[0] = team_seg_slots(lcap);                                      // slots of the per-segment arrays
+    out[1] = c.segs;                                                    // segments the team walk cuts the block into
+    out[2] = segbuf_bytes(lcap);                                        // bytes of segment buffers
+    out[3] = (uint64_t)(c.regs + 1u) * c.cap;                           // ... the team walk needs
+    out[4] = (uint64_t)(regs + 1u) * ((uint64_t)kSegCapFactor << m);    // ... the walk inside the block's wavefront needs
+    out[5] = seg_info_bytes(lcap);
+    out[6] = (2ull * (kSegs + 1) > 4ull * out[0] ? 2ull * (kSegs + 1) : 4ull * out[0]) * 4 + kTeamWords * 4;   // ... and what must fit in it
+    out[7] = ws_bytes_per_job(lcap);
+}
 static uint64_t g_team_finished = 0;   // blocks whose output came from team_finish, not from the serial fallback
 extern "C" uint64_t emu_bzip2_team_finished(int reset) { const uint64_t v = g_team_finished; if (reset) g_team_finished = 0; return v; }
 extern "C" void emu_bzip2_block_team(swc::Job* all_jobs, size_t n_all, size_t lcap, int start_team, int one_thread) {

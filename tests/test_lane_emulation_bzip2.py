@@ -177,3 +177,24 @@ def test_symbol_loop_boundaries_emulated():
                         [len(x) for _, x in cases])
     for r, (z, x) in zip(res, cases):
         assert r[:2] == (0, x)
+
+
+def test_workspace_geometry_holds_for_every_block_size():
+    """A workspace is cut for a capacity; the blocks decoded into it are of any size up to that.  The segment arrays and buffers
+    of both forms of stage 3 must fit whatever the block's own cut is (the number of segments is not monotonic in the size)."""
+    import ctypes as C
+    E.lib.emu_bzip2_layout.argtypes = [C.c_size_t, C.c_uint32, C.POINTER(C.c_uint64)]
+    rnd = random.Random(3)
+    caps = [16, 17, 31, 32, 33, 100, 511, 512, 513, 4096, 16384, 16385, 65535, 65536, 524288, 524289, 900000, 1 << 20, (1 << 20) + 1, 16000000]
+    caps += [rnd.randrange(16, 16000000) for _ in range(200)]
+    prev = 0
+    for lcap in sorted(caps):
+        out = (C.c_uint64 * 8)()
+        for n in {k for k in (1, 2, 31, 32, 33) if k <= lcap} | {max(lcap // 2, 1), max(lcap - 1, 1), lcap} | {rnd.randrange(1, lcap + 1) for _ in range(40)}:
+            E.lib.emu_bzip2_layout(lcap, n, out)
+            slots, segs, bufs, need_team, need_fused, info, info_need, ws = list(out)
+            assert segs + 1 <= slots, (lcap, n, segs, slots)
+            assert need_team + 64 <= bufs and need_fused + 64 <= bufs, (lcap, n, need_team, need_fused, bufs)
+            assert info_need <= info
+        assert ws >= prev                      # launch_bzip2 searches the capacity a workspace holds by bisection
+        prev = ws
