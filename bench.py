@@ -13,7 +13,7 @@ batch of its own; `--scaling strong`: ONE unit list is cut into contiguous range
 (swcompression_amd/shard.py) and every rank decodes its range.  RCCL carries only the barrier, the max-over-ranks time
 and the byte totals.
 
-Prints ONE JSON line: decompressed GiB/s (sum of U over all ranks / max time), plus
+Prints ONE compact JSON line (< 4 KB, `compact_line`; the whole object goes to bench_full.json): decompressed GiB/s (sum of U over all ranks / max time), plus
   roofline     -- HBM roofline of the headline: algorithmic bytes (C + U per unit) / mean duration of a
                   launch, measured with HIP events on the launch stream (per kernel for the Deflate kernels), vs 8 TB/s;
                   `traffic` / `l2_hit_rate` = HBM bytes per launch and TCC_HIT / (TCC_HIT + TCC_MISS) per kernel from the
@@ -56,7 +56,7 @@ WORKLOADS = {
                                  kernels=["swc_deflate_compress_kernel"], steps=10),
     "bzip2_900k": dict(codec="bzip2_block", kind="bzip2", parts=[("text", 256)], n_units=10240, unit=899000,
                        desc="10240 x 900 kB bzip2 blocks (BASELINE configs[3]; 256 distinct P-text payloads as SURVEY 8d states)",
-                       kernels=["swc_bzip2_block_kernel", "swc_bzip2_expand_kernel", "swc_bzip2_crc_kernel"], steps=10),
+                       kernels=["swc_bzip2_block_kernel", "swc_bzip2_team_prep+walk_kernel", "swc_bzip2_team_finish_kernel", "swc_bzip2_expand_kernel", "swc_bzip2_crc_kernel"], steps=10),
     "lzma2_256k": dict(codec="lzma2", kind="lzma2", parts=[("text", 256)], n_units=32768, unit=262144,
                        desc="32768 x 256 KiB raw-LZMA2 units (BASELINE configs[4]; 256 distinct P-text payloads as SURVEY 8d states)",
                        kernels=["swc_lzma_kernel"], steps=10),
@@ -73,6 +73,68 @@ def stats(samples_ms, warmup):
     var = sum((x - mean) ** 2 for x in samples_ms) / n
     return {"iterations": n, "warmup_discarded": warmup, "mean_ms": mean, "sigma_ms": var ** 0.5, "min_ms": min(samples_ms), "max_ms": max(samples_ms),
             "method": "mean +- population sigma over the timed iterations, per-iteration HIP events / wall clock (RunBenchmarkCommand.swift:66-101)"}
+
+
+def _r(x, nd=4):
+    """Round floats for the compact line (the full precision is in bench_full.json)."""
+    return round(x, nd) if isinstance(x, float) else x
+
+
+def compact_line(line):
+    """The LAST line of stdout: the headline object the driver parses, kept well under 4 KB (round 5's full object had grown
+    to 24.7 KB on one line and the driver's record came back `parsed: null`).  Like the reference's harness, which prints one
+    short line per benchmark (RunBenchmarkCommand.swift:66-101).  Everything else goes to bench_full.json."""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: _r(line[k]) for k in keep if k in line}
+    for k in ("rehearsal", "ranks"):
+        if k in line:
+            out[k] = line[k]
+    cfg = line.get("config", {})
+    out["config"] = {k: cfg[k] for k in ("workload", "codec", "units_per_gpu", "unit_bytes", "compressed_bytes_per_gpu", "decompressed_bytes_per_gpu", "parallelism")
+                     if k in cfg}
+    roof = line.get("roofline", {})
+    r = {k: _r(roof[k], 5) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "kernel", "kernel_ms",
+                                      "algorithmic_bytes_per_launch", "dominant_kernel", "dominant_kernel_frac") if k in roof}
+    if roof.get("per_kernel_ms"):
+        r["per_kernel_ms"] = {k[:-3] if k.endswith("_ms") else k: _r(v, 3) for k, v in roof["per_kernel_ms"].items()}
+    out["roofline"] = r
+    cb = line.get("cpu_baseline")
+    if cb:
+        out["cpu_baseline"] = {k: _r(cb[k]) for k in ("value", "unit", "cores", "kind", "sample") if k in cb}
+    ca = line.get("cpu_baseline_all_cores")
+    if ca:
+        out["cpu_baseline_all_cores"] = {k: _r(ca[k]) for k in ("value", "unit", "cores", "kind") if k in ca}
+    st = line.get("stats")
+    if st:
+        out["sigma_ms"] = _r(st.get("sigma_ms"))
+    if "verify" in line:
+        out["units_verified"] = line["verify"].get("units_verified")
+    per = line.get("per_codec")
+    if per:   # {name: [ms_per_step, GiB/s, roofline frac]}
+        out["per_codec_summary"] = {n: [_r(v["ms_per_step"], 2), _r(v["value"], 1), _r(v["roofline"]["frac"], 5)] for n, v in per.items()}
+    c1 = line.get("config1_latency")
+    if c1:
+        out["config1_latency_ms"] = _r(c1.get("median_ms"))
+    if "full" in line:
+        out["full"] = line["full"]
+    return json.dumps(out, separators=(",", ":"))
+
+
+def write_full(line):
+    """The whole object (per_codec, archive_paths, cpu_context, lz4_streamed, L2 hit rates ...) next to the script -- and under
+    gpurun_out/ when that exists, so that it comes back from the GPU box."""
+    names = [os.path.join(ROOT, "bench_full.json")]
+    if os.path.isdir(os.path.join(ROOT, "gpurun_out")):
+        names.append(os.path.join(ROOT, "gpurun_out", "bench_full.json"))
+    wrote = None
+    for n in names:
+        try:
+            with open(n, "w") as f:
+                json.dump(line, f, indent=1)
+            wrote = wrote or os.path.relpath(n, ROOT)
+        except OSError:
+            continue
+    return wrote
 
 
 def parse_args():
@@ -170,10 +232,11 @@ def cpu_baseline(name, raw, plains, seconds):
         cbytes += len(raw[i])
         done += 1
     dt = time.perf_counter() - t0
-    return {"value": nbytes / dt / 2**30, "unit": "GiB/s decompressed", "cores": 1, "kind": "port",
-            "sample": "%d unit decodes (cycling over the %d distinct units of the workload), %.1f s, oracle/librefcpu.so, one thread"
-                      % (done, len(raw), dt),
-            "compressed_MBps": cbytes / dt / 1e6}
+    enc = name in ("lz4_compress_4m", "deflate_compress_64k")   # (the ENCODE workloads time the oracle's ENCODER over the plain payloads)
+    return {"value": nbytes / dt / 2**30, "unit": "GiB/s of input" if enc else "GiB/s decompressed", "cores": 1, "kind": "port",
+            "sample": "%d unit %s (cycling over the %d distinct units of the workload), %.1f s, oracle/librefcpu.so, one thread"
+                      % (done, "encodes" if enc else "decodes", len(raw), dt),
+            "compressed_MBps": None if enc else cbytes / dt / 1e6}
 
 
 def host_cpus():
@@ -806,7 +869,9 @@ def main():
         except Exception as e:   # e.g. not enough pinned host memory on the box: say so instead of dropping the headline
             line["lz4_streamed"] = {"error": str(e)[:200]}
     if rank == 0:
-        print(json.dumps(line))
+        line["full"] = write_full(line)
+        sys.stdout.flush()
+        print(compact_line(line), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -221,7 +221,7 @@ static void launch_lz_copy(int mode, bool lz4, const Job* jobs, size_t n, const 
 
 // Optional per-kernel timing of the calling thread's last batch launch (bench.py: roofline per kernel).  HIP events on the
 // launch stream between the kernels; off by default so that the production path issues nothing but the kernels.
-constexpr int kMaxPhases = 4;
+constexpr int kMaxPhases = 8;
 struct PhaseTimer {
     int on = 0, n = 0;
     bool ok = false, valid = false;
@@ -457,7 +457,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_BZ_WAVES
     Job job = jobs[g];
     const bzip2::Workspace w = bzip2::carve(ws, g, lcap);
     bzip2::stage1_job<kWave, CXX>(job, reinterpret_cast<bzip2::Stage1Lds*>(bz_lds), w, (int)threadIdx.x);
-#if defined(SWC_BZ_STOP_AFTER) && SWC_BZ_STOP_AFTER == 1   // (timing experiments only, tools/exp_bz_stages.py: wrong results)
+#if defined(SWC_BZ_STOP_AFTER) && SWC_BZ_STOP_AFTER == 1   // (timing experiments only, tools/attic/exp_bz_stages.py: wrong results)
     if (threadIdx.x == 0) { w.hdr->pad = bzip2::kWalkDone; jobs[g].status = SWC_E_DEVICE; }
     return;
 #endif
@@ -564,12 +564,14 @@ hipError_t launch_bzip2(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStrea
     const int team = tw == 2 || (tw == 1 && n * lcap >= kTeamMinBytes) ? 1 : 0;
     if (g_bzip2_hot_cxx) hipLaunchKernelGGL(swc_bzip2_block_kernel<true>, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap, team);
     else hipLaunchKernelGGL(swc_bzip2_block_kernel<false>, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap, team);
-    if (team) {
+    g_pt.mark(stream);
+    if (team) {   // (phase timing: block | team prep + walk | team finish | expand | crc -- five figures with the team walk, three without)
         hipLaunchKernelGGL(swc_bzip2_team_prep_kernel, dim3(bzip2::kTeams), block, 0, stream, (uint8_t*)ws, lcap, (uint32_t)n);
         hipLaunchKernelGGL(swc_bzip2_team_walk_kernel, dim3(256 * g_bzip2_team_per_cu), dim3(SWC_BZ_TEAM_THREADS), 0, stream, (uint8_t*)ws, lcap, (uint32_t)n);
+        g_pt.mark(stream);
         hipLaunchKernelGGL(swc_bzip2_team_finish_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
+        g_pt.mark(stream);
     }
-    g_pt.mark(stream);
     hipLaunchKernelGGL(swc_bzip2_expand_kernel, dim3((unsigned)((n + kWave - 1) / kWave)), block, 0, stream, jobs, (uint32_t)n, (uint8_t*)ws, lcap);
     g_pt.mark(stream);
     hipLaunchKernelGGL(swc_bzip2_crc_kernel, dim3((unsigned)n), dim3(256), 0, stream, jobs, (uint32_t)n);

@@ -459,7 +459,7 @@ struct Copier {
         const uint32_t ntake = g.ntake;
         uint32_t wp = (uint32_t)((uint64_t)A + rpos - vbase);
         if (wp + g.span > WIN) wp = slide(rpos);
-#if SWC_LZC_CUT == 1   // (instruction accounting builds, tools/exp_copier_counts.sh: the output is wrong)
+#if SWC_LZC_CUT == 1   // (instruction accounting builds, tools/attic/exp_copier_counts.sh: the output is wrong)
         return;
 #endif
         if (g.lit_refill) {   // (g.lv == lbase rounded down: what front() loaded)

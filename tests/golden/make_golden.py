@@ -107,7 +107,11 @@ def main():
         # BZip2CompressionTests.swift:31-49,87-95; LZ4CompressionTests.swift:29-47)
         "roundtrip_strings": ["ban", "banana", "abaaba", "abracadabra", "cabbage", "baabaabac", "AAAAAAABBBBCCCD", "AAAAAAA",
                               "qwertyuiopasdfghjklzxcvbnm1234567890"],
-        "roundtrip_bytes": ["2e202e202e2020", "000100010000010001"],
+        # ... and LZ4CompressionTests.swift:162-172 (testTrickySequence: "match index was wrongly used as cyclical index"; the
+        # last ten bytes only allow a sequence with a match)
+        "roundtrip_bytes": ["2e202e202e2020", "000100010000010001", "616c202d43202d43202d2d01020304050607080900"],
+        "lz4_tricky_sequence": {"ref": "Tests/LZ4CompressionTests.swift:162-172", "input": "616c202d43202d43202d2d01020304050607080900",
+                                "options": {"independent_blocks": False, "block_checksums": True, "content_checksum": True, "content_size": True}},
         "magic": {"gzip": "1f8b", "bzip2_block": "314159265359", "bzip2_eos": "177245385090", "xz_header": "fd377a585a00",
                   "xz_footer": "595a", "lz4_frame": "04224d18", "lz4_legacy": "02214c18", "lz4_skippable_first": "502a4d18"},
     }

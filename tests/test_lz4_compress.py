@@ -141,6 +141,33 @@ def test_gpu_frames_decode_with_oracle_liblz4_and_own_decoder():
     O.lib.refcpu_set_max_output(1 << 30)
 
 
+def test_tricky_sequence_block_on_the_host_build():
+    """Tests/LZ4CompressionTests.swift:162-172 (a match index once used as a cyclical index): the 21 bytes through the block
+    compressor built for the host, decoded by the oracle's restatement of the reference decoder and by liblz4; and through the
+    oracle's restatement of the reference ENCODER."""
+    t = GOLD["lz4_tricky_sequence"]
+    p = bytes.fromhex(t["input"])
+    assert len(p) == 21
+    st, z, _, zl = E.lz4_compress([p])[0]
+    assert st == 0 and O.lz4_block(z)[:2] == (0, p) and _liblz4_decode(z, len(p)) == p
+    zr = O.lz4_compress_block(p)[1]
+    assert O.lz4_block(zr)[:2] == (0, p) and _liblz4_decode(zr, len(p)) == p
+
+
+@pytest.mark.gpu
+def test_gpu_tricky_sequence_frame():
+    """The same vector through LZ4.compress with the options the reference's test passes (dependent blocks, block checksums,
+    content checksum, content size), then the oracle's frame walk and the engine's own decoder."""
+    import swcompression_amd as swc
+    t = GOLD["lz4_tricky_sequence"]
+    p = bytes.fromhex(t["input"])
+    f = swc.LZ4.compress(p, **t["options"])
+    assert f[:4] == b"\x04\x22\x4d\x18" and f[4] == 0x40 | 0x10 | 0x08 | 0x04     # version 01, block checksums, content size, content checksum
+    assert struct.unpack("<Q", f[6:14])[0] == len(p)
+    assert O.lz4(f)[:2] == (0, p)
+    assert swc.LZ4.decompress(f) == p
+
+
 @pytest.mark.gpu
 def test_gpu_prefixes_in_place_and_in_rounds():
     """Dependent blocks address the input in front of them in place (odd block sizes: the units start anywhere); small

@@ -1,7 +1,7 @@
 """Time of the fused bzip2 kernel cut short after stage 1 / stage 2 (libraries built with -DSWC_BZ_STOP_AFTER=1 | 2:
 tools/build_variant.sh; results are wrong by construction, only the clock is read).  Usage: SWC_LIB=... exp_bz_stages.py"""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 w = bench.WORKLOADS["bzip2_900k"]

@@ -5,7 +5,7 @@ import sys
 import time
 
 import os
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import swcompression_amd as swc
 from swcompression_amd import corpus
 

@@ -1,7 +1,7 @@
 """bzip2_900k launches with the team walk forced, no verification (variant builds cut short produce wrong results).  For kernel traces."""
 import os
 import sys
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 
 import bench

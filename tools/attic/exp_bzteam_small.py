@@ -1,5 +1,5 @@
 import bz2, os, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import swcompression_amd as swc
 from swcompression_amd import _lib, corpus
 lib = _lib.load()

@@ -3,7 +3,7 @@ of its own (= 2).  python tools/exp_bzteam_sweep.py"""
 import os
 import sys
 import time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 
 import bench

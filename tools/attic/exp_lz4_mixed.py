@@ -1,7 +1,7 @@
 """Per-block cycles of the LZ4 kernels in the MIXED bench workload (profile build): text vs P-mix blocks, and the start / end
 times a block's wave reports -- is the launch as long as its slowest blocks, or as its busiest CUs?"""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from swcompression_amd import corpus, _lib
 from swcompression_amd.batch import DeviceBatch

@@ -1,6 +1,6 @@
 """Throughput of the device checksum kernels on decoded batches (100,000 x 64 KiB members; 2,048 x 4 MiB blocks)."""
 import sys, os, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 import bench
 

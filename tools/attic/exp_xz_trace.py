@@ -1,6 +1,6 @@
 """The xz line of bench.py's archive_paths alone; with SWC_TRACE=1 the library prints the host-side stages of every call."""
 import os, shutil, subprocess, sys, time
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import swcompression_amd as swc
 from swcompression_amd import corpus
 x = b"".join(corpus.p_text(262144, 0x5C0DE + 5 + i) for i in range(64)) * 8

@@ -2,7 +2,7 @@
 that are literals followed by another literal whose two code lengths fit the 10-bit direct table, i.e. the loop trips a packed
 entry would remove (CPU only: a plain bit-serial inflate of the corpus's dynamic blocks)."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from swcompression_amd import corpus
 
 LBASE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]

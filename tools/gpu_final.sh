@@ -10,10 +10,12 @@ tests)
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
   python __graft_entry__.py smoke 2>&1 | tail -1 | tee $O/smoke.log ;;
 bench)
-  S=$(date +%s); python bench.py > $O/bench_full.json 2> $O/bench_full.err; echo "bench rc=$? wall=$(( $(date +%s) - S ))s" | tee $O/bench_full.wall
+  # (stdout's last line is the compact headline object the driver parses; the whole object is written to gpurun_out/bench_full.json by bench.py itself)
+  S=$(date +%s); python bench.py > $O/bench_line.json 2> $O/bench_full.err; echo "bench rc=$? wall=$(( $(date +%s) - S ))s" | tee $O/bench_full.wall
+  tail -1 $O/bench_line.json | wc -c; cp gpurun_out/bench_full.json $O/bench_full.json
   python - <<PY
 import json
-d = json.loads(open("$O/bench_full.json").read().strip().splitlines()[-1])
+d = json.load(open("$O/bench_full.json"))
 print("headline", round(d["value"], 1), "GiB/s", round(d["ms_per_step"], 2), "ms", d["roofline"]["per_kernel_ms"])
 for k, v in d.get("per_codec", {}).items():
     print(k, round(v["value"], 1), "GiB/s", round(v["ms_per_step"], 1), "ms", {a: round(b, 1) for a, b in (v["roofline"].get("per_kernel_ms") or {}).items()})
@@ -34,8 +36,8 @@ except Exception as e:
 PY
   done ;;
 bzc)   # BZip2.compress (host to host): timing with the stage trace, and a kernel trace of the same command
-  SWC_BZ2C_TRACE=1 timeout 300 python tools/exp_bzip2_compress.py 32 9 > $O/bzip2_compress_timing.txt 2>&1; grep -v "^\[bz2c\]\|amdgpu" $O/bzip2_compress_timing.txt
-  ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_bzc -o bzc -- python $R/tools/exp_bzip2_compress.py 32 9 > $O/trace_bzc.log 2>&1 ); echo "trace bzc rc=$?"
+  SWC_BZ2C_TRACE=1 timeout 300 python tools/attic/exp_bzip2_compress.py 32 9 > $O/bzip2_compress_timing.txt 2>&1; grep -v "^\[bz2c\]\|amdgpu" $O/bzip2_compress_timing.txt
+  ( cd /tmp && export TMPDIR=/tmp && timeout 300 rocprofv3 --kernel-trace --stats -d $O/trace_bzc -o bzc -- python $R/tools/attic/exp_bzip2_compress.py 32 9 > $O/trace_bzc.log 2>&1 ); echo "trace bzc rc=$?"
   python tools/rocpd_summary.py $O/trace_bzc/bzc_results.db > $O/kernel_stats_bzip2_compress.txt 2>&1; head -8 $O/kernel_stats_bzip2_compress.txt ;;
 sq)
   for W in $WL; do bash tools/pmc_sq.sh $W $TAG > /dev/null 2>&1; cp gpurun_out/pmc_sq_${TAG}_$W/summary.txt $O/sq_counters_$W.txt 2>/dev/null; head -12 $O/sq_counters_$W.txt; done ;;
