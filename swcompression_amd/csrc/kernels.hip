@@ -177,28 +177,29 @@ __global__ __launch_bounds__(kInflateResolveThreads) void swc_lz_resolve_kernel(
 //   LZ4      8 KiB window, groups of up to 2 KiB, 16 waves per CU: offsets reach 65,535 bytes back and 4 MiB blocks have long
 //            literal runs -- the smaller window is 1-8 % slower there.
 // The 16 KiB variant (8 waves per CU) is kept for comparison runs.
-template <uint32_t WIN, uint32_t SPAN>
+template <typename CFG>
 __device__ __forceinline__ void lz_copy_body(const Job* __restrict__ jobs, uint32_t n, const WsMap& wm, const uint32_t* __restrict__ order) {
-    __shared__ __attribute__((aligned(16))) lzc::Lds<WIN> lds;
+    __shared__ __attribute__((aligned(16))) lzc::Lds<CFG::kWin> lds;
     uint32_t g = job_of(order, blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];
     if (job.dict != nullptr) return;   // (LZ4 blocks with a dictionary prefix were decoded by the lane kernel)
-    lzc::copy_job<WIN, SPAN>(job, wm.area(g), wm.bytes(g), &lds);
+    lzc::copy_job<CFG>(job, wm.area(g), wm.bytes(g), &lds);
 }
-#ifndef SWC_LZC_WIN
-#define SWC_LZC_WIN 5120
-#define SWC_LZC_SPAN 1024
+#ifndef SWC_LZC_WAVES
 #define SWC_LZC_WAVES 6
 #endif
+#ifndef SWC_LZC4_WAVES
+#define SWC_LZC4_WAVES 4
+#endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_LZC_WAVES, SWC_LZC_WAVES))) void swc_lz_copy_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, const uint32_t* __restrict__ order) {
-    lz_copy_body<SWC_LZC_WIN, SWC_LZC_SPAN>(jobs, n, wm, order);
+    lz_copy_body<lzc::CfgDeflate>(jobs, n, wm, order);
 }
-__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 4))) void swc_lz4_copy_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, const uint32_t* __restrict__ order) {
-    lz_copy_body<8192, 2048>(jobs, n, wm, order);
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_LZC4_WAVES, SWC_LZC4_WAVES))) void swc_lz4_copy_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, const uint32_t* __restrict__ order) {
+    lz_copy_body<lzc::CfgLz4>(jobs, n, wm, order);
 }
 __global__ __launch_bounds__(64) void swc_lz_copy16_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, const uint32_t* __restrict__ order) {
-    lz_copy_body<16384, 2048>(jobs, n, wm, order);
+    lz_copy_body<lzc::CfgWide>(jobs, n, wm, order);
 }
 // "lz_copier" (swc_set_tuning): 1 = lz_copy.h with the windows above (default), 2 = with a 16 KiB window, 0 = the byte-cell resolver
 // of lz_resolve.h (rounds 2-4) -- kept for A/B measurements; all produce the same bytes.

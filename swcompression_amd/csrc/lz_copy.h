@@ -39,6 +39,7 @@
 #ifndef SWC_LZ_COPY_H
 #define SWC_LZ_COPY_H
 
+#include <type_traits>
 #include "swc_common.h"
 #include "simt.h"
 #include "lz_resolve.h"   // record format, StreamHeader, workspace layout
@@ -55,12 +56,7 @@ using lzr::u128;
 template <uint32_t WIN>
 struct Lds {
     static constexpr uint32_t kWin = WIN;
-#ifndef SWC_LZC_LITBUF
-#define SWC_LZC_LITBUF 1024
-#endif
-    static constexpr uint32_t kLitBuf = SWC_LZC_LITBUF;   // bytes of the literal stream staged at a time (16 bytes per lane: at most 1024)
     alignas(16) uint8_t win[WIN + 16];                    // byte at virtual position v lives at win[v - vbase] (+16: reads of short runs overshoot)
-    alignas(16) uint8_t lit[kLitBuf + 16];                // literal at stream offset o lives at lit[o - lv]
     uint32_t pmap[64 + 2];                                // one bit per output byte of the group: it belongs to a match that has not been copied yet
 };
 
@@ -105,44 +101,55 @@ SWC_HD void copy_run(uint8_t* d, const uint8_t* s, uint32_t n) {
     }
 }
 
-template <uint32_t WIN, uint32_t SPAN>
+// CFG: kWin (bytes of the LDS window), kSpan (output bytes one group may cover), kKeep (history that survives a slide),
+// kLitPieces (eight-byte pieces of a literal run a lane copies on its own).  P: the type of a position in the output or in the
+// literal stream -- uint32_t for streams of less than 4 GiB (every position, watermark and difference is ONE scalar register and
+// one scalar instruction: the copier is bound as much by the CU's scalar unit as by its vector ALU), uint64_t for the rest.
+template <typename CFG, typename P>
 struct Copier {
+    static constexpr uint32_t WIN = CFG::kWin, SPAN = CFG::kSpan;
     using L = Lds<WIN>;
+    using SP = typename std::conditional<sizeof(P) == 4, int32_t, int64_t>::type;
     static constexpr int W = 64;
     static constexpr uint32_t kSpanMax = SPAN;                 // output bytes one group may cover
-    static constexpr uint32_t kKeep = WIN - SPAN - 16u;        // history that survives a slide (a slide leaves kKeep .. kKeep + 15 bytes)
-    static constexpr uint32_t kLitBuf = L::kLitBuf, kLitCap = kLitBuf - 16u;   // literal bytes one group may take (whatever the alignment of its first one)
+    static constexpr uint32_t kKeep = CFG::kKeep;              // history that survives a slide (a slide leaves kKeep .. kKeep + 15 bytes)
     static constexpr uint32_t kBigLit = 256;                   // a literal-only record of at least this many bytes is copied by all lanes together, on its own
-    static constexpr int kPieces = 4;                          // eight-byte pieces of a match a lane copies on its own
+#ifndef SWC_LZC_PIECES
+#define SWC_LZC_PIECES 4
+#endif
+    static constexpr int kPieces = SWC_LZC_PIECES;             // eight-byte pieces of a match a lane copies on its own (copy_own is written for up to four)
     static constexpr uint32_t kLongLen = 8u * kPieces;         // a longer match is copied by all lanes together
-    static constexpr uint32_t kLongLit = 64;                   // so is a longer literal run in front of a match
+    static constexpr int kLitPieces = CFG::kLitPieces;         // eight-byte pieces of a literal run a lane copies on its own
+    static constexpr uint32_t kLongLit = 8u * kLitPieces;      // a longer literal run in front of a match is copied by all lanes together
 #ifndef SWC_LZC_SEQMAX
 #define SWC_LZC_SEQMAX 8
 #endif
     static constexpr uint32_t kSeqMax = SWC_LZC_SEQMAX;        // more short matches left than this: those that do not depend on each other first, all at once
     static constexpr uint32_t kBack = 65536;                   // the furthest a source lies behind its match (record format)
-    static constexpr uint32_t kLitOff = (uint32_t)offsetof(L, lit);
-    static_assert(lzr::kLitRunMax + lzr::kMaxLen <= kSpanMax && kBigLit - 1u <= kLitCap && lzr::kLitRunMax <= kLitCap, "a record must fit a group");
+    static_assert(kKeep % 16u == 0u && kKeep + kSpanMax + 16u <= WIN, "a group fits behind what a slide keeps");
+    static_assert(lzr::kLitRunMax + lzr::kMaxLen <= kSpanMax && kBigLit - 1u + lzr::kMaxLen <= kSpanMax, "a record must fit a group");
     static_assert(64u * (kBigLit - 1u + lzr::kMaxLen + lzr::kLitRunMax) < 0x10000u, "the packed scan keeps 16 bits per sum");
     static_assert(kSpanMax <= 2048u && kLongLen <= 32u, "the bitmap of a group's output has 2,048 bits, a short match 32");
     // A far source lies in front of the window, i.e. at least kKeep - kMaxLen bytes behind the write position.  Finished bytes
     // are flushed when a KiB of them has gathered, and what was issued before the last drain() has arrived: `landed`.  front()
     // asks only for sources that end 128 bytes (a cache line: a line is never read while a part of it is still on its way)
-    // in front of `landed`; anything else waits for its turn in back() and drains first.
-    static_assert(kKeep >= 2u * (WIN - kKeep) + lzr::kMaxLen, "far sources must have left for HBM long before they are read");
+    // in front of `landed`; anything else waits for its turn in back() and drains first.  With the figures below a far source
+    // has as good as always landed when the group AHEAD of its match is being copied.
+    // (The flush watermark lies less than 1,040 bytes behind the position after every group, `landed` one group behind that:
+    // a source that is asked for -- kLongLen bytes at most, kKeep and more behind its match -- has always landed.)
+    static_assert(kKeep >= kLongLen + 1040u + kSpanMax + 128u, "far sources that are asked for ahead must have landed");
     enum : uint32_t { kFlagCoop = 1u, kFlagFar = 2u };
 
     L* l;
     gptr out;
     gcptr lits;        // the stream's dense literal stream (16-byte aligned base)
-    uint64_t lit_cap;  // bytes that may be READ from it (allocation size, a multiple of 16)
-    uint64_t limit;    // bytes of `out` that exist: min(bytes produced, capacity)
+    P limit;           // bytes of `out` that exist: min(bytes produced, capacity)
 
     // wave state (the same in every lane)
     uint32_t A;        // out & 15: virtual position v = A + output position, so that 16-byte chunks of v are aligned in HBM
-    uint64_t vbase;    // virtual position of win[0] (a multiple of 16)
-    uint64_t fv;       // flush watermark (a multiple of 16): virtual positions below it have LEFT for `out`
-    uint64_t landed;   // ... and below this one they have ARRIVED (the flush watermark at the last full wait)
+    P vbase;           // virtual position of win[0] (a multiple of 16)
+    P fv;              // flush watermark (a multiple of 16): virtual positions below it have LEFT for `out`
+    P landed;          // ... and below this one they have ARRIVED (the flush watermark at the last full wait)
 
     SWC_D static uint32_t mod_small(uint32_t m, uint32_t d) {   // m % d for m, d < 2^16, d != 0
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -179,24 +186,26 @@ struct Copier {
     SWC_D static void rare_path_done() { simt::vmem_fence(); }
 
     // ---- flush: virtual positions [fv, vend) rounded down to whole 16-byte chunks go to HBM; `final`: the tail bytes too
-    SWC_D void flush(uint64_t vend, bool final) {
-        const uint64_t v16 = vend & ~(uint64_t)15;
-        const uint64_t vlim = (uint64_t)A + limit;              // virtual end of the output that exists
+    SWC_D void flush(P vend, bool final) {
+        const P v16 = vend & ~(P)15;
+        const P vlim = (P)A + limit;                            // virtual end of the output that exists
         gptr obase = out - A;                                   // HBM address of virtual position 0 (16-byte aligned)
         if (v16 > fv) {
-            const uint64_t f0 = fv;
+            const P f0 = fv;
             const uint32_t w0 = (uint32_t)(f0 - vbase);
             const uint32_t nchunk = (uint32_t)((v16 - f0) >> 4);
             gptr ob = obase + f0;
             const bool whole = f0 >= A && v16 <= vlim;          // (all but the first and the last flush of a stream)
             if (whole) {
                 SIMT_BEGIN(t, W)
+#pragma unroll 1
                     for (uint32_t c = (uint32_t)t; c < nchunk; c += (uint32_t)W) lzr::store_16(ob + 16u * c, *(const u128*)(l->win + w0 + 16u * c));
                 SIMT_END_WAVE
             } else {
                 SIMT_BEGIN(t, W)
+#pragma unroll 1
                     for (uint32_t c = (uint32_t)t; c < nchunk; c += (uint32_t)W) {
-                        const uint64_t cv = f0 + 16ull * c;
+                        const P cv = f0 + (P)(16u * c);
                         if (cv >= A && cv + 16u <= vlim) {
                             lzr::store_16(ob + 16u * c, *(const u128*)(l->win + w0 + 16u * c));
                         } else {   // the first chunk of an unaligned output, the chunk the limit cuts
@@ -210,7 +219,7 @@ struct Copier {
         }
         if (final && vend > fv) {
             const uint32_t ntail = (uint32_t)(vend - fv);   // < 16
-            const uint64_t f0 = fv;
+            const P f0 = fv;
             const uint32_t w0 = (uint32_t)(f0 - vbase);
             SIMT_BEGIN(t, W)
                 if ((uint32_t)t < ntail && f0 + (uint32_t)t >= A && f0 + (uint32_t)t < vlim) obase[f0 + (uint32_t)t] = l->win[w0 + (uint32_t)t];
@@ -220,13 +229,14 @@ struct Copier {
 
     // ---- slide: make room behind the window index of output position rpos: flush what is finished, keep the last kKeep
     // bytes, move them to the front.  Returns the new write index.
-    SWC_D uint32_t slide(uint64_t rpos) {
+    SWC_D uint32_t slide(P rpos) {
         using simt::PT;
-        const uint64_t vcur = (uint64_t)A + rpos;
+        const P vcur = (P)A + rpos;
         flush(vcur, false);
-        const uint64_t nb = (vcur - kKeep) & ~(uint64_t)15;     // (the caller slides only when vcur - vbase > kKeep + 16)
+        const P nb = (vcur - kKeep) & ~(P)15;                   // (the caller slides only when vcur - vbase > kKeep + 16)
         const uint32_t D = (uint32_t)(nb - vbase);
         const uint32_t nmove = ((uint32_t)(vcur - nb) + 15u) >> 4;   // chunks that stay
+#pragma unroll 1
         for (uint32_t c0 = 0; c0 < nmove; c0 += (uint32_t)W) {
             PT<u128, W> v;
             SIMT_BEGIN(t, W)
@@ -241,7 +251,7 @@ struct Copier {
     }
 
     // ---- all lanes copy n literal bytes from the literal stream in HBM (offset lo) to window index wd
-    SWC_D void coop_literals(uint32_t wd, uint64_t lo, uint32_t n) {
+    SWC_D void coop_literals(uint32_t wd, P lo, uint32_t n) {
         gcptr src = lits + lo;
         SIMT_BEGIN(t, W)
             for (uint32_t o = 4u * (uint32_t)t; o < n; o += 4u * (uint32_t)W) {
@@ -320,33 +330,48 @@ struct Copier {
             }
         }
     }
+    // ---- a lane copies its own literal run of up to kLongLit bytes from the pieces front() loaded (piece k: bytes
+    // [min(8 k, n - 8), + 8) of the run; a run of fewer than eight bytes: its bytes at the bottom of piece 0) to window index d
+    SWC_D static void copy_own_lits(uint8_t* B, uint32_t d, uint32_t n, const uint64_t* pc) {
+        if (n >= 8u) {
+            const uint32_t last = n - 8u;
+            st64(B + d, pc[0]);
+#pragma unroll
+            for (int k = 1; k < kLitPieces; k++) {
+                if (n > 8u * (uint32_t)k) st64(B + d + (8u * (uint32_t)k < last ? 8u * (uint32_t)k : last), pc[k]);
+            }
+        } else if (n >= 4u) {
+            st32(B + d, (uint32_t)pc[0]);
+            st32(B + d + (n & 3u), (uint32_t)(pc[0] >> (8u * (n & 3u))));
+        } else {
+            st_tail(B + d, (uint32_t)pc[0], n);
+        }
+    }
 
     // ---- a group of records between front() (records -> places, loads asked for) and back() (the copies)
     struct Group {
         simt::PT<uint32_t, W> rec;            // the records
         simt::PT<uint32_t, W> x;              // inclusive sums over the lanes: (literals + length) | literals << 16 (a big run: literal bytes)
         simt::PT<uint64_t, W> fw[kPieces];    // far sources asked for ahead, eight bytes each
-        simt::PT<u128, W> litpf;              // the 16 bytes of the literal stream this lane stages when the group refills the buffer
+        simt::PT<uint64_t, W> lw[kLitPieces]; // my literal run (up to kLongLit bytes) from the literal stream, eight bytes each
         uint32_t kind;                        // 0: records up to the first big literal-only one; 1: a run of big literal-only records
         uint32_t ntake, span, litspan;        // records, output bytes, literal bytes of the group
-        uint64_t pf_vbase;                    // window base the far loads assumed (~0: none were wanted)
+        P pf_vbase;                           // window base the far loads assumed (~0: none were wanted)
         int32_t pf_lim;                       // ... and how far (relative to the group's first byte) a source they asked for may reach
-        uint64_t lv;                          // literal-stream offset of lit[0] while this group is copied
-        bool lit_refill;
     };
     // how far -- relative to output position rpos -- a far source may reach that is read now
-    SWC_D int32_t far_limit(uint64_t rpos) const {
-        const int64_t d = (int64_t)landed - (int64_t)((uint64_t)A + rpos) - 128;
-        return d < -(int64_t)0x40000000 ? -(int32_t)0x40000000 : d > 0 ? 0 : (int32_t)d;
+    SWC_D int32_t far_limit(P rpos) const {
+        const SP d = (SP)(landed - ((P)A + rpos)) - 128;       // (landed never lies behind the position: d < 0)
+        return d < -(SP)0x40000000 ? -(int32_t)0x40000000 : d > 0 ? 0 : (int32_t)d;
     }
 
     // ---- front: the records of a group (`left` records remain from it on) that starts at output position `rpos`, literal
     // offset `lbase`; `vb_pred`: the window base when the group in front of it has been copied (~0: unknown, no far loads
-    // ahead); `lv_prev`: the literal buffer's offset then.
+    // ahead).
     // EVERY call issues the same loads, wanted or not (a lane that wants nothing reads a place that certainly exists): a
     // register that is loaded on one path only reaches the next iteration through a copy, and the compiler waits for the
     // load in front of the copy -- at once, instead of an iteration later.
-    SWC_D void front(Group& g, const simt::PT<uint32_t, W>& r_in, uint32_t left, uint64_t rpos, uint64_t lbase, uint64_t vb_pred, uint64_t lv_prev) {
+    SWC_D void front(Group& g, const simt::PT<uint32_t, W>& r_in, uint32_t left, P rpos, P lbase, P vb_pred) {
         using simt::PT;
         PT<bool, W> big;
         SIMT_BEGIN(t, W)
@@ -357,8 +382,6 @@ struct Copier {
         SIMT_END
         const uint64_t bigmask = simt::wave_ballot<W>(big);
         const uint32_t nb = bigmask ? (uint32_t)simt::ctz64(bigmask) : 64u;
-        g.lv = lv_prev;
-        g.lit_refill = false;
         if (nb == 0u) {
             // the group starts with big literal-only records: the run of them is a group of its own
             uint32_t nrun = ~bigmask ? (uint32_t)simt::ctz64(~bigmask) : 64u;
@@ -381,7 +404,7 @@ struct Copier {
             simt::wave_scan_incl<W>(g.x);
             PT<bool, W> tk;
             SIMT_BEGIN(t, W)
-                tk[t] = (uint32_t)t < left && (uint32_t)t < nb && (g.x[t] & 0xFFFFu) <= kSpanMax && (g.x[t] >> 16) <= kLitCap;
+                tk[t] = (uint32_t)t < left && (uint32_t)t < nb && (g.x[t] & 0xFFFFu) <= kSpanMax;
             SIMT_END
             const uint64_t tm = simt::wave_ballot<W>(tk);
             const uint32_t ntake = ~tm ? (uint32_t)simt::ctz64(~tm) : 64u;     // >= 1: any single record that is not big fits
@@ -390,30 +413,33 @@ struct Copier {
             g.ntake = ntake;
             g.span = xl & 0xFFFFu;
             g.litspan = xl >> 16;
-            // the literal buffer is refilled when the group's literals reach past what is staged
-            if (g.litspan != 0u && (lv_prev == ~(uint64_t)0 || lbase + g.litspan > lv_prev + kLitBuf)) {
-                g.lv = lbase & ~(uint64_t)15;
-                g.lit_refill = true;
-            }
         }
-        // ---- the literal stream from lbase (rounded down) on, 16 bytes per lane
+        // ---- my literal run, straight from the literal stream in HBM into registers: 32-bit offsets from the group's first literal
         {
-            const uint64_t lo = lbase & ~(uint64_t)15;
-            gcptr lb = lits + lo;
-            const uint32_t room = lit_cap - lo > 2048u ? 2048u : (uint32_t)(lit_cap - lo);   // (lo + 16 <= lit_cap: the allocation ends 32 bytes behind the last literal)
+            gcptr lb = lits + lbase;
+            const bool runs = g.kind == 0u;
+            const uint32_t ntake = g.ntake;
             SIMT_BEGIN(t, W)
-                const uint32_t o = 16u * (uint32_t)t;
-                g.litpf[t] = lzr::load_16(lb + (o + 16u <= room ? o : 0u));
+                uint32_t li, le, di;
+                unpack(g.rec[t], li, le, di);
+                const bool ask = runs && (uint32_t)t < ntake && li != 0u && li <= kLongLit;
+                const uint32_t o0 = ask ? (g.x[t] >> 16) - li : 0u;             // (nothing wanted: the group's first literal, or the byte behind the last: it exists)
+                const uint32_t last = (li > 8u ? li : 8u) - 8u;
+#pragma unroll
+                for (int k = 0; k < kLitPieces; k++) {
+                    const uint32_t ok = 8u * (uint32_t)k < last ? 8u * (uint32_t)k : last;
+                    g.lw[k][t] = load_u64(lb + (ask && 8u * (uint32_t)k < li ? o0 + ok : 0u));
+                }
             SIMT_END
         }
         // ---- far sources, one group ahead: 32-bit offsets from (the group's first byte - kBack)
         {
-            const bool known = g.kind == 0u && vb_pred != ~(uint64_t)0;
-            uint64_t vp = known ? vb_pred : 0u;
-            const uint64_t vcur = (uint64_t)A + rpos;
-            if (known && (uint32_t)(vcur - vp) + g.span > WIN) vp = (vcur - kKeep) & ~(uint64_t)15;   // back() will slide (the same arithmetic)
+            const bool known = g.kind == 0u && vb_pred != ~(P)0;
+            P vp = known ? vb_pred : 0u;
+            const P vcur = (P)A + rpos;
+            if (known && (uint32_t)(vcur - vp) + g.span > WIN) vp = (vcur - kKeep) & ~(P)15;   // back() will slide (the same arithmetic)
             const uint32_t wpn = (uint32_t)(vcur - vp);
-            g.pf_vbase = known ? vp : ~(uint64_t)0;
+            g.pf_vbase = known ? vp : ~(P)0;
             g.pf_lim = far_limit(rpos);
             const int32_t lim = g.pf_lim;
             const uint32_t ntake = g.ntake;
@@ -436,17 +462,17 @@ struct Copier {
     }
 
     // ---- back: the copies of a group
-    SWC_D void back(Group& g, uint64_t rpos, uint64_t lbase) {
+    SWC_D void back(Group& g, P rpos, P lbase) {
         using simt::PT;
         if (g.kind == 1u) {
             // a run of big literal-only records: all lanes copy them, one record after the other
-            uint64_t rp = rpos, lb = lbase;
+            P rp = rpos, lb = lbase;
             for (uint32_t i = 0; i < g.ntake; i++) {
                 const uint32_t e1 = simt::wave_read<W>(g.x, (int)i);
-                uint32_t n = (uint32_t)((uint64_t)rpos + e1 - rp);
+                uint32_t n = (uint32_t)(rpos + e1 - rp);
                 while (n != 0u) {   // (a record of up to kMaxLitOnly bytes in pieces of what a slide makes room for)
                     const uint32_t piece = n < kSpanMax ? n : kSpanMax;
-                    uint32_t wp = (uint32_t)((uint64_t)A + rp - vbase);
+                    uint32_t wp = (uint32_t)((P)A + rp - vbase);
                     if (wp + piece > WIN) wp = slide(rp);
                     coop_literals(wp, lb, piece);
                     rp += piece;
@@ -457,28 +483,23 @@ struct Copier {
             return;
         }
         const uint32_t ntake = g.ntake;
-        uint32_t wp = (uint32_t)((uint64_t)A + rpos - vbase);
+        uint32_t wp = (uint32_t)((P)A + rpos - vbase);
         if (wp + g.span > WIN) wp = slide(rpos);
 #if SWC_LZC_CUT == 1   // (instruction accounting builds, tools/attic/exp_copier_counts.sh: the output is wrong)
         return;
 #endif
-        if (g.lit_refill) {   // (g.lv == lbase rounded down: what front() loaded)
-            SIMT_BEGIN(t, W) if (16u * (uint32_t)t < kLitBuf) *(u128*)(l->lit + 16u * (uint32_t)t) = g.litpf[t]; SIMT_END_WAVE
-        }
         uint8_t* const B = (uint8_t*)l;                                 // window indices are offsets from here
-        const uint32_t lrel = kLitOff + (uint32_t)(lbase - g.lv);
-        const int64_t gdelta = (int64_t)rpos - (int64_t)wp;             // output position = window index + gdelta
         const bool pfu = g.pf_vbase == vbase;                           // the far loads assumed the window base that came to be
         const int32_t pf_lim = g.pf_lim;
         PT<uint32_t, W> lit, len, dist, wm, flags, si;   // si: a signed value
         PT<bool, W> longlit, pend;
-        // ---- my literals' first eight bytes; my match, if its source was final when the group began
+        // ---- my literals; my match, if its source was final when the group began
         SIMT_BEGIN(t, W)
             const bool mine = (uint32_t)t < ntake;
             uint32_t li, le, di;
             unpack(g.rec[t], li, le, di);
             lit[t] = li; len[t] = le; dist[t] = di;
-            const uint32_t end = g.x[t] & 0xFFFFu, lend = g.x[t] >> 16;
+            const uint32_t end = g.x[t] & 0xFFFFu;
             const uint32_t wd = wp + end - li - le;                   // window index of my literals
             const uint32_t m = wd + li;                               // ... of my match
             const uint32_t s = m - di;                                // ... of its source (negative: in front of the window)
@@ -488,19 +509,10 @@ struct Copier {
             // lanes have no literals at all)
             longlit[t] = mine && li > kLongLit;
             if (mine && li != 0u && li <= kLongLit) {
-                const uint32_t ls = lrel + lend - li;
-                if (li > 8u) {
-                    for (uint32_t k = 0; k < li; k += 8u) {
-                        const uint32_t o = k < li - 8u ? k : li - 8u;
-                        st64(B + wd + o, rd64u(B, ls + o));
-                    }
-                } else if (li >= 4u) {           // bytes [0, 4) and [li - 4, li)
-                    const uint32_t w0 = rd32u(B, ls), w1 = rd32u(B, ls + li - 4u);
-                    st32(B + wd, w0);
-                    st32(B + wd + li - 4u, w1);
-                } else {
-                    st_tail(B + wd, rd32u(B, ls), li);
-                }
+                uint64_t pc[kLitPieces];
+#pragma unroll
+                for (int k = 0; k < kLitPieces; k++) pc[k] = g.lw[k][t];
+                copy_own_lits(B, wd, li, pc);
             }
             const bool far = (int32_t)s < 0;
             const bool coop = le > kLongLen || di < le;
@@ -511,7 +523,7 @@ struct Copier {
             const bool act = mine && le != 0u && !coop && (pf || old);
             pend[t] = mine && le != 0u && !act;
             // my match, if its source was final when the group began
-            if (act) copy_own(B, m, s, le, far, g.fw[0][t], g.fw[1][t], g.fw[2][t], g.fw[3][t]);
+            if (act) copy_own(B, m, s, le, far, g.fw[0][t], g.fw[kPieces > 1 ? 1 : 0][t], g.fw[kPieces > 2 ? 2 : 0][t], g.fw[kPieces > 3 ? 3 : 0][t]);
         SIMT_END_WAVE
 #if SWC_LZC_CUT == 2
         return;
@@ -521,7 +533,7 @@ struct Copier {
             const int h = simt::ctz64(m);
             const uint32_t li = simt::wave_read<W>(lit, h);
             const uint32_t lend = simt::wave_read<W>(g.x, h) >> 16;
-            coop_literals(simt::wave_read<W>(wm, h) - li, lbase + lend - li, li);
+            coop_literals(simt::wave_read<W>(wm, h) - li, lbase + (lend - li), li);
         }
 #if SWC_LZC_CUT == 3
         return;
@@ -591,7 +603,7 @@ struct Copier {
             pm &= pm - 1u;
             const uint32_t hs = simt::wave_read<W>(si, h), hn = simt::wave_read<W>(len, h);
             const uint32_t fl = simt::wave_read<W>(flags, h);
-            const int64_t sp = (int64_t)(int32_t)hs + gdelta;      // >= 0: phase 1 rejects a distance beyond the output
+            const int64_t sp = (int64_t)rpos + ((int64_t)(int32_t)hs - (int64_t)wp);      // output position of the source: >= 0, phase 1 rejects a distance beyond the output
             if ((fl & (uint32_t)kFlagFar) && (int32_t)((int32_t)hs - (int32_t)wp) + (int32_t)hn > far_limit(rpos)) drain();
             coop_match(hm, hn, simt::wave_read<W>(dist, h), (gcptr)out + (sp >= 0 ? sp : 0));
         }
@@ -625,15 +637,15 @@ struct Copier {
         landed = 0;
         if (nrec == 0) return;
         if (limit < 64u) { tiny(recs, nrec); return; }
-        uint64_t rpos = 0;               // output bytes finished by earlier groups
-        uint64_t lbase = 0;              // literal bytes consumed by earlier groups
+        P rpos = 0;                      // output bytes finished by earlier groups
+        P lbase = 0;                     // literal bytes consumed by earlier groups
         uint32_t base = 0;               // first record of the group
         PT<uint32_t, W> r_nx;            // the records of the group after `nxt`, on their way
         Group cur, nxt;
         const uint32_t rlast4 = 4u * (nrec - 1u);
         gcptr rb = (gcptr)recs;
         SIMT_BEGIN(t, W) r_nx[t] = load_u32(rb + (4u * (uint32_t)t < rlast4 ? 4u * (uint32_t)t : rlast4)); SIMT_END
-        front(nxt, r_nx, nrec, 0, 0, ~(uint64_t)0, ~(uint64_t)0);
+        front(nxt, r_nx, nrec, 0, 0, ~(P)0);
         {
             const uint32_t b4 = 4u * nxt.ntake;
             SIMT_BEGIN(t, W) r_nx[t] = load_u32(rb + (b4 + 4u * (uint32_t)t < rlast4 ? b4 + 4u * (uint32_t)t : rlast4)); SIMT_END
@@ -647,13 +659,13 @@ struct Copier {
             const uint32_t nbase = base + cur.ntake;
             more = nbase < nrec;
             if (more) {
-                uint64_t vbp = ~(uint64_t)0;
+                P vbp = ~(P)0;
                 if (cur.kind == 0u) {   // the window base when `cur` has been copied (slide()'s arithmetic)
                     vbp = vbase;
-                    const uint64_t vcur = (uint64_t)A + rpos;
-                    if ((uint32_t)(vcur - vbp) + cur.span > WIN) vbp = (vcur - kKeep) & ~(uint64_t)15;
+                    const P vcur = (P)A + rpos;
+                    if ((uint32_t)(vcur - vbp) + cur.span > WIN) vbp = (vcur - kKeep) & ~(P)15;
                 }
-                front(nxt, r_nx, nrec - nbase, rpos + cur.span, lbase + cur.litspan, vbp, cur.lv);
+                front(nxt, r_nx, nrec - nbase, rpos + cur.span, lbase + cur.litspan, vbp);
                 const uint32_t b4 = 4u * (nbase + nxt.ntake);
                 SIMT_BEGIN(t, W) r_nx[t] = load_u32(rb + (b4 + 4u * (uint32_t)t < rlast4 ? b4 + 4u * (uint32_t)t : rlast4)); SIMT_END
             }
@@ -662,26 +674,66 @@ struct Copier {
             rpos += cur.span;
             lbase += cur.litspan;
             // finished bytes leave for HBM a KiB at a time (whole-wave stores), long before they leave the window
-            if ((uint64_t)A + rpos - fv >= 1024u) flush((uint64_t)A + rpos, false);
+            if ((P)A + rpos - fv >= 1024u) flush((P)A + rpos, false);
         }
         drain();
-        flush((uint64_t)A + rpos, true);
+        flush((P)A + rpos, true);
     }
 };
 
+// The window is a trade between the waves a CU holds and the matches that are FAR; the history a slide keeps, between far
+// matches and the LDS traffic of the slides (kernels.hip has the measurements).
+template <uint32_t WINB, uint32_t SPANB, uint32_t KEEPB, int LITP>
+struct Cfg {
+    static constexpr uint32_t kWin = WINB, kSpan = SPANB, kKeep = KEEPB;
+    static constexpr int kLitPieces = LITP;
+};
+
+// The configurations the library ships (kernels.hip: the waves per CU each is launched with; profiles/r05_experiments.txt and
+// r06_experiments.txt: the sweeps).  Deflate: 6 KiB window of which a slide keeps 2.5 KiB (a slide costs more than the far
+// matches it avoids: a far source is four loads that are issued anyway), groups of up to 1 KiB, literal runs of up to 16 bytes
+// per lane -- 6,424 bytes of LDS per wave, 24 waves per CU.  LZ4 (offsets up to 65,535, 4 MiB blocks, longer
+// literal runs): 9 KiB / 6 KiB kept / 2 KiB groups / runs of up to 32 bytes -- 9,496 bytes, 16 waves per CU.
+#ifndef SWC_LZC_WIN
+#define SWC_LZC_WIN 6144
+#define SWC_LZC_SPAN 1024
+#define SWC_LZC_KEEP 2560
+#endif
+#ifndef SWC_LZC_LITP
+#define SWC_LZC_LITP 2
+#endif
+using CfgDeflate = Cfg<SWC_LZC_WIN, SWC_LZC_SPAN, SWC_LZC_KEEP, SWC_LZC_LITP>;
+#ifndef SWC_LZC4_WIN
+#define SWC_LZC4_WIN 9216
+#define SWC_LZC4_SPAN 2048
+#define SWC_LZC4_KEEP 6144
+#endif
+using CfgLz4 = Cfg<SWC_LZC4_WIN, SWC_LZC4_SPAN, SWC_LZC4_KEEP, 4>;
+using CfgWide = Cfg<16384, 2048, 14320, 4>;   // (comparison runs: 8 waves per CU)
+
 // One job: `ws` is the stream's workspace area of `area` bytes written by phase 1.
-template <uint32_t WIN, uint32_t SPAN>
-SWC_D void copy_job(const Job& job, const uint8_t* ws, size_t area, Lds<WIN>* lds) {
+template <typename CFG>
+SWC_D void copy_job(const Job& job, const uint8_t* ws, size_t area, Lds<CFG::kWin>* lds) {
     const SWC_AS_GLOBAL lzr::StreamHeader* h = (const SWC_AS_GLOBAL lzr::StreamHeader*)ws;
     const size_t lo = lzr::lit_offset(area, job.out_cap);
     if (lo == 0) return;   // no literal stream: phase 1 reported SWC_E_NEED_WORKSPACE for this job
-    Copier<WIN, SPAN> cp;
-    cp.l = lds;
-    cp.out = (gptr)job.out;
-    cp.lits = (gcptr)ws + lo;
-    cp.lit_cap = lzr::lit_bytes(job.out_cap);
-    cp.limit = job.out_len < job.out_cap ? job.out_len : job.out_cap;
-    cp.run((const SWC_AS_GLOBAL uint32_t*)(ws + sizeof(lzr::StreamHeader)), h->nrec);
+    const uint64_t limit = job.out_len < job.out_cap ? job.out_len : job.out_cap;
+    const SWC_AS_GLOBAL uint32_t* recs = (const SWC_AS_GLOBAL uint32_t*)(ws + sizeof(lzr::StreamHeader));
+    if (limit < 0xFFF00000ull) {   // (positions, watermarks and their differences in 32 bits)
+        Copier<CFG, uint32_t> cp;
+        cp.l = lds;
+        cp.out = (gptr)job.out;
+        cp.lits = (gcptr)ws + lo;
+        cp.limit = (uint32_t)limit;
+        cp.run(recs, h->nrec);
+    } else {
+        Copier<CFG, uint64_t> cp;
+        cp.l = lds;
+        cp.out = (gptr)job.out;
+        cp.lits = (gcptr)ws + lo;
+        cp.limit = limit;
+        cp.run(recs, h->nrec);
+    }
 }
 
 }  // namespace lzc

@@ -26,15 +26,15 @@ extern "C" void emu_set_order(int o) { swc::simt::g_order = o; }
 static int g_copier = 1;
 extern "C" void emu_set_copier(int on) { g_copier = on; }
 // (the two window configurations the library ships: kernels.hip)
-template <uint32_t WIN, uint32_t SPAN>
+template <typename CFG>
 static void emu_copy(swc::Job& job, const uint8_t* ws, size_t wsb) {
-    alignas(16) static swc::lzc::Lds<WIN> cl;
+    alignas(16) static swc::lzc::Lds<CFG::kWin> cl;
     std::memset(&cl, 0xEE, sizeof cl);
-    swc::lzc::copy_job<WIN, SPAN>(job, ws, wsb, &cl);
+    swc::lzc::copy_job<CFG>(job, ws, wsb, &cl);
 }
 static void emu_copy_any(int deflate, swc::Job& job, const uint8_t* ws, size_t wsb) {
-    if (g_copier == 3 || (g_copier == 1 && deflate)) emu_copy<5120, 1024>(job, ws, wsb);
-    else emu_copy<8192, 2048>(job, ws, wsb);
+    if (g_copier == 3 || (g_copier == 1 && deflate)) emu_copy<swc::lzc::CfgDeflate>(job, ws, wsb);
+    else emu_copy<swc::lzc::CfgLz4>(job, ws, wsb);
 }
 
 // Deflate, one stream per wavefront with 64 sub-chunks decoded at once (inflate_sync.h): the uniform parts run once, the
@@ -204,8 +204,8 @@ extern "C" void emu_copy_records(const uint32_t* recs, uint32_t nrec, const uint
     std::memcpy(ws.data() + swc::lzr::lit_offset(wsb, cap), lits, nlit);
     swc::Job j{};
     j.out = out; j.out_cap = cap; j.out_len = out_len;
-    if (copier == 3) emu_copy<5120, 1024>(j, ws.data(), wsb);
-    else if (copier) emu_copy<8192, 2048>(j, ws.data(), wsb);
+    if (copier == 3) emu_copy<swc::lzc::CfgDeflate>(j, ws.data(), wsb);
+    else if (copier) emu_copy<swc::lzc::CfgLz4>(j, ws.data(), wsb);
     else {
         alignas(16) static swc::lzr::Lds<512, 16> rl;
         std::memset(&rl, 0xEE, sizeof rl);

@@ -3,7 +3,7 @@ gfx950 kernel swc_lz_copy_kernel is compiled from -- on record lists made HERE, 
 treats differently is hit on purpose and in bulk: matches that end in front of their group, matches that reach into it,
 matches in front of the LDS window (read back from the output buffer), overlapping matches (distance < length) down to
 distance 1, matches of 1 / 2 bytes (tails of split matches) and of up to 511, literal runs of every class (0, 1-3, 4-8,
-9-64, 65-127 in front of a match; literal-only records up to 2,048), capacity cuts, every output alignment, every order of
+9-16, 17-32, 33-127 in front of a match -- the classes of both shipped configurations; literal-only records up to 2,048), capacity cuts, every output alignment, every order of
 the emulated lanes.  The expected bytes come from replaying the records one by one in Python (what the reference's
 `out.append` loops do, Deflate.swift:216-232, LZ4.swift:398-410); the byte-cell resolver of rounds 2-4 (lz_resolve.h) runs on the
 same lists as a second witness."""
@@ -58,6 +58,9 @@ TEXT = dict(kinds=["match", "near", "far", "lits"], weights=[70, 10, 15, 5], lit
 RUNS = dict(kinds=["near", "match", "lits"], weights=[60, 30, 10], lit=[0, 0, 0, 1, 4, 64, 65, 127], len=[1, 2, 3, 4, 30, 64, 65, 100, 258, 300, 511],
             dist=[1, 2, 3, 4, 7, 255, 256, 257, 1000], litonly=[1, 255, 256, 1023, 1024, 2048])
 DENSE = dict(kinds=["near"], weights=[1], lit=[0, 0, 1], len=[3, 4, 5, 8], dist=[1], litonly=[4])   # (every match reaches into its group)
+# literal runs around every boundary of the eight-byte pieces a lane copies on its own (Deflate: two pieces, LZ4: four), and beyond
+LITRUNS = dict(kinds=["match", "near", "far", "lits"], weights=[60, 15, 15, 10], lit=[0, 1, 2, 3, 4, 5, 7, 8, 9, 12, 15, 16, 17, 24, 25, 31, 32, 33, 40, 63, 64, 65, 100, 127],
+               len=[3, 4, 5, 8, 9, 16, 31, 32, 33], dist=[1, 5, 50, 700, 5000, 7000, 12000, 30000], litonly=[1, 7, 8, 9, 15, 16, 17, 31, 32, 33, 100, 255, 256])
 STORED = dict(kinds=["lits", "far", "match"], weights=[80, 10, 10], lit=[0, 3], len=[4, 40, 500], dist=[20000, 65536, 100], litonly=[2048, 2048, 2047, 1500, 256, 255])
 
 
@@ -72,7 +75,7 @@ def run_copy(recs, lits, cap, out_len, misalign, copier):
     return raw[o0:o0 + min(cap, out_len)]
 
 
-@pytest.mark.parametrize("profile", [TEXT, RUNS, DENSE, STORED], ids=["text", "runs", "dense", "stored"])
+@pytest.mark.parametrize("profile", [TEXT, RUNS, DENSE, STORED, LITRUNS], ids=["text", "runs", "dense", "stored", "litruns"])
 @pytest.mark.parametrize("order", [0, 1, 2])
 def test_record_classes(profile, order):
     rnd = random.Random(hash((profile["len"][0], order)) & 0xFFFF)
@@ -81,7 +84,7 @@ def test_record_classes(profile, order):
         for size in (0, 1, 63, 64, 200, 5000, 9000, 40000, 140000):
             recs, lits, exp = build(rnd, size, profile) if size else ([], b"", b"")
             for misalign in (0, 5, 15):
-                for cfg in (1, 3):       # the two window configurations the library ships: 8 KiB / 2 KiB groups, 5 KiB / 1 KiB groups
+                for cfg in (1, 3):       # the two configurations the library ships (lz_copy.h: CfgLz4, CfgDeflate)
                     got = run_copy(recs, lits, max(len(exp), 1), len(exp), misalign, cfg)
                     assert got == exp, "copier differs (size %d, misalign %d, configuration %d)" % (size, misalign, cfg)
             if order == 0 and size and profile is not STORED:
