@@ -177,14 +177,14 @@ __global__ __launch_bounds__(kInflateResolveThreads) void swc_lz_resolve_kernel(
 //   LZ4      8 KiB window, groups of up to 2 KiB, 16 waves per CU: offsets reach 65,535 bytes back and 4 MiB blocks have long
 //            literal runs -- the smaller window is 1-8 % slower there.
 // The 16 KiB variant (8 waves per CU) is kept for comparison runs.
-template <typename CFG>
+template <typename CFG, bool R8 = false>
 __device__ __forceinline__ void lz_copy_body(const Job* __restrict__ jobs, uint32_t n, const WsMap& wm, const uint32_t* __restrict__ order) {
     __shared__ __attribute__((aligned(16))) lzc::Lds<CFG::kWin> lds;
     uint32_t g = job_of(order, blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];
     if (job.dict != nullptr) return;   // (LZ4 blocks with a dictionary prefix were decoded by the lane kernel)
-    lzc::copy_job<CFG>(job, wm.area(g), wm.bytes(g), &lds);
+    lzc::copy_job<CFG, R8>(job, wm.area(g), wm.bytes(g), &lds);
 }
 #ifndef SWC_LZC_WAVES
 #define SWC_LZC_WAVES 6
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_LZC_WAVE
     lz_copy_body<lzc::CfgDeflate>(jobs, n, wm, order);
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_LZC4_WAVES, SWC_LZC4_WAVES))) void swc_lz4_copy_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, const uint32_t* __restrict__ order) {
-    lz_copy_body<lzc::CfgLz4>(jobs, n, wm, order);
+    lz_copy_body<lzc::CfgLz4, true>(jobs, n, wm, order);   // (eight-byte records: the literals come from the block itself)
 }
 __global__ __launch_bounds__(64) void swc_lz_copy16_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, const uint32_t* __restrict__ order) {
     lz_copy_body<lzc::CfgWide>(jobs, n, wm, order);
@@ -215,7 +215,7 @@ static int copier_for(size_t n) {
     return c < 0 ? -c : (c == 1 && n < kCopierMin ? 0 : c);   // (tuning value -1 / -2: the wave kernel whatever the batch size)
 }
 static void launch_lz_copy(int mode, bool lz4, const Job* jobs, size_t n, const WsMap& wm, const uint32_t* order, hipStream_t stream) {
-    if (mode == 2) hipLaunchKernelGGL(swc_lz_copy16_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, jobs, (uint32_t)n, wm, order);
+    if (mode == 2 && !lz4) hipLaunchKernelGGL(swc_lz_copy16_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, jobs, (uint32_t)n, wm, order);
     else if (lz4) hipLaunchKernelGGL(swc_lz4_copy_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, jobs, (uint32_t)n, wm, order);
     else hipLaunchKernelGGL(swc_lz_copy_kernel, dim3((unsigned)n), dim3(kWave), 0, stream, jobs, (uint32_t)n, wm, order);
 }
@@ -286,13 +286,16 @@ __global__ __launch_bounds__(64) void swc_lz4_lane_kernel(Job* __restrict__ jobs
 #ifndef SWC_LZ4_PARSE_WAVES
 #define SWC_LZ4_PARSE_WAVES 4
 #endif
+// R8: eight-byte records that say where their literals lie in the block, no literal stream (for the wave copy kernel);
+// otherwise the records and the dense literal stream swc_lz4_resolve_kernel reads
+template <bool R8>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_LZ4_PARSE_WAVES))) void swc_lz4_parse_kernel(Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof, const uint32_t* __restrict__ order) {
     uint32_t g = job_of(order, blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];
     if (job.dict != nullptr) return;
     __shared__ __attribute__((aligned(16))) uint8_t stage[lz4w::kStageLds];
-    lz4w::lz4_parse_job<kWave>(job, wm.area(g), wm.bytes(g), (int)threadIdx.x, stage, prof ? prof + 32 * (size_t)g : nullptr);
+    lz4w::lz4_parse_job<kWave, R8>(job, wm.area(g), wm.bytes(g), (int)threadIdx.x, stage, prof ? prof + 32 * (size_t)g : nullptr);
     if (threadIdx.x == 0) {
         jobs[g].out_len = job.out_len;
         jobs[g].in_consumed = job.in_consumed;
@@ -327,9 +330,10 @@ hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_
     hipLaunchKernelGGL(swc_lz4_lane_kernel, grid, block, 0, stream, jobs, (uint32_t)n, 1);
     g_pt.mark(stream);
     const WsMap wm{(uint8_t*)ws, stride, ws_off};
-    hipLaunchKernelGGL(swc_lz4_parse_kernel, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
-    g_pt.mark(stream);
     const int copier = copier_for(n);
+    if (copier) hipLaunchKernelGGL(swc_lz4_parse_kernel<true>, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
+    else hipLaunchKernelGGL(swc_lz4_parse_kernel<false>, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
+    g_pt.mark(stream);
     if (copier) launch_lz_copy(copier, true, jobs, n, wm, order, stream);
     else hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(lz4w::kResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);

@@ -152,7 +152,10 @@ SWC_HD int top64(uint64_t m) {   // index of the highest set bit, m != 0
 #endif
 }
 
-template <int W>
+// R8: records of EIGHT bytes -- the 32-bit record of lz_resolve.h and, in the upper dword, the offset of its literal run in the
+// block (LZ4 literals are byte-aligned in the input, LZ4.swift:364-366): no literal is copied anywhere by the parse, the copy
+// kernel (lz_copy.h) fetches a run from the block itself.  The area then holds header | records | scratch rows.
+template <int W, bool R8 = false>
 struct Parser {
     Wave<W> w;
     gcptr in;
@@ -215,8 +218,9 @@ struct Parser {
     // staged records / literals -> HBM, all lanes
     SWC_D void flush() {
         if (rb_n) {
-            SWC_AS_GLOBAL uint32_t* dst = recs + (nrec - rb_n);
-            for (uint32_t i = (uint32_t)w.lane; i < rb_n; i += (uint32_t)W) dst[i] = rbuf[i];
+            constexpr uint32_t kD = R8 ? 2u : 1u;   // dwords per record
+            SWC_AS_GLOBAL uint32_t* dst = recs + kD * (nrec - rb_n);
+            for (uint32_t i = (uint32_t)w.lane; i < kD * rb_n; i += (uint32_t)W) dst[i] = rbuf[i];
             rb_n = 0;
         }
         if (lb_n) {
@@ -229,10 +233,13 @@ struct Parser {
         }
     }
 
-    SWC_D void push(uint32_t v) {
+    SWC_D void push(uint32_t v, uint64_t from) {   // `from`: where the record's literals lie in the block (R8)
         if (nrec < max_rec) {   // (beyond the workspace: counted only, the job ends with SWC_E_NEED_WORKSPACE)
             if (rb_n >= kRecBuf) flush();
-            if (w.lane == 0) rbuf[rb_n] = v;
+            if (w.lane == 0) {
+                if (R8) { rbuf[2u * rb_n] = v; rbuf[2u * rb_n + 1u] = (uint32_t)from; }
+                else rbuf[rb_n] = v;
+            }
             rb_n++;
         }
         nrec++;
@@ -242,6 +249,7 @@ struct Parser {
     SWC_D void copy_literals(uint64_t from, uint64_t cnt) {
         uint64_t keep = pos >= cap ? 0 : (cap - pos < cnt ? cap - pos : cnt);
         if (keep == 0) return;
+        if (R8) { nlit += keep; return; }   // (they stay where they are: the record says where)
         if (keep + lb_n <= kLitStage && from + keep <= iw_hi && from + kInWin >= iw_hi) {
             for (uint32_t i = (uint32_t)w.lane; i < (uint32_t)keep; i += (uint32_t)W) lbuf[lb_n + i] = iw[(uint32_t)(from + i) & (kInWin - 1)];
             lb_n += (uint32_t)keep;
@@ -255,24 +263,25 @@ struct Parser {
         }
         nlit += keep;
     }
-    SWC_D void push_lits(uint64_t n) {
+    SWC_D void push_lits(uint64_t n, uint64_t from) {
         while (n > 0) {
             const uint32_t s = n > lzr::kMaxLitOnly ? lzr::kMaxLitOnly : (uint32_t)n;
-            push(lzr::make_lits(s));
+            push(lzr::make_lits(s), from);
+            from += s;
             n -= s;
         }
     }
     // records of one sequence: `lit` literal bytes (already in the literal stream as far as they lie below the
     // capacity), then a match of `mlen` bytes (0: none).  pos = position BEFORE the literals.
-    SWC_D void emit(uint64_t lit, uint64_t mlen, uint32_t offset) {
+    SWC_D void emit(uint64_t lit, uint64_t mlen, uint32_t offset, uint64_t from) {
         uint64_t run = pos >= cap ? 0 : (cap - pos < lit ? cap - pos : lit);   // literal bytes that were kept
         uint64_t p = pos + lit;                                                // match start
-        if (mlen == 0 || p >= cap) { push_lits(run); return; }
-        if (run > lzr::kLitRunMax) { push_lits(run); run = 0; }
+        if (mlen == 0 || p >= cap) { push_lits(run, from); return; }
+        if (run > lzr::kLitRunMax) { push_lits(run, from); run = 0; }
         uint64_t rem = mlen;
         while (rem > 0) {
             const uint32_t piece = rem > lzr::kMaxLen ? lzr::kMaxLen : (uint32_t)rem;
-            if (p < cap) push(lzr::make_match((uint32_t)run, piece, offset));
+            if (p < cap) push(lzr::make_match((uint32_t)run, piece, offset), from);
             run = 0;
             p += piece;
             rem -= piece;
@@ -302,31 +311,32 @@ struct Parser {
             }
         }
         if (n - ip < lit) return SWC_E_DATA_TRUNCATED;                             // :363
+        const uint64_t lit_at = ip;
         copy_literals(ip, lit);
         ip += lit;
         const uint64_t produced = pos + lit;                                       // out.endIndex of the reference (no dictionary on this path)
         if (ip >= n) {                                                             // :368 last sequence: literals only
-            emit(lit, 0, 0);
+            emit(lit, 0, 0, lit_at);
             pos += lit;
             if (!(lit >= 5 || sequences == 1)) return SWC_E_DATA_CORRUPTED;        // :370
             if (!((int64_t)produced - last_match_start >= 12 || last_match_start == -1)) return SWC_E_DATA_CORRUPTED;  // :372
             return -1;
         }
-        if (n - ip < 2) { emit(lit, 0, 0); pos += lit; return SWC_E_DATA_TRUNCATED; }   // :378
+        if (n - ip < 2) { emit(lit, 0, 0, lit_at); pos += lit; return SWC_E_DATA_TRUNCATED; }   // :378
         const uint32_t offset = rd(ip) | (rd(ip + 1) << 8);
         ip += 2;
-        if (!(offset > 0 && offset <= produced)) { emit(lit, 0, 0); pos += lit; return SWC_E_DATA_CORRUPTED; }  // :382
+        if (!(offset > 0 && offset <= produced)) { emit(lit, 0, 0, lit_at); pos += lit; return SWC_E_DATA_CORRUPTED; }  // :382
         uint64_t mlen = 4 + (token & 0xF);
         if (mlen == 19) {
             for (;;) {
-                if (n - ip < 1) { emit(lit, 0, 0); pos += lit; return SWC_E_DATA_TRUNCATED; }  // :388
+                if (n - ip < 1) { emit(lit, 0, 0, lit_at); pos += lit; return SWC_E_DATA_TRUNCATED; }  // :388
                 const uint32_t b = rd(ip++);
                 mlen += b;
                 if (b != 255) break;
             }
         }
         last_match_start = (int64_t)produced;
-        emit(lit, mlen, offset);
+        emit(lit, mlen, offset, lit_at);
         pos += lit + mlen;
         return SWC_OK;
     }
@@ -501,6 +511,52 @@ struct Parser {
     }
     static constexpr uint32_t kProvRow = 64u * 4u;
 
+    // ---- R8: the same two steps without literals -- one sequence and one eight-byte record (record | literal offset << 32) per
+    // step, rows of 512 bytes in the record part of the scratch (a sub-chunk holds at most (kChunk + 2) / 3 sequences)
+    static constexpr uint32_t kProvRow8 = 64u * 8u;
+    static_assert(((kChunk + 2u) / 3u + 3u) * kProvRow8 <= lzr::kProvRecBytes, "the scratch rows hold a sub-chunk's records");
+    SWC_D static void parse_chunk_prov8(const uint8_t* stage, uint32_t stage_len, uint32_t start, uint32_t chunk_end, uint32_t tail_limit, gptr prov,
+                                        uint32_t lane, uint32_t base32, ProvOut& r) {
+        uint32_t ip = start, nlit = 0, nout = 0, lms = 0, flags = 0;
+        uint32_t roff = 8u * lane + kProvRow8;                 // byte offset of my next record in the scratch (row 1 is the first)
+        int32_t need = -0x40000000;
+        const uint32_t safe = stage_len >= 8 ? stage_len - 8u : 0u;
+        while (ip < chunk_end) {
+            if (ip > safe) { flags |= kLzStop; break; }
+            const Seq q = sequence_at(stage, ip, safe, tail_limit);
+            if (q.stop || q.offset == 0) {
+                flags |= q.stop ? (q.tail ? kLzStop | kLzTail : q.longer ? kLzStop | kLzLong : kLzStop) : kLzFail;   // offset 0: LZ4.swift:382
+                break;
+            }
+            const int32_t nd = (int32_t)q.offset - (int32_t)(nout + q.lit);          // :382 offset <= bytes produced, checked after the scan
+            need = nd > need ? nd : need;
+            store_u64(prov + roff, (uint64_t)lzr::make_match(q.lit, q.mlen, q.offset) | ((uint64_t)(base32 + q.lit_at) << 32));
+            roff += kProvRow8;
+            nlit += q.lit;
+            lms = nout + q.lit;
+            nout += q.lit + q.mlen;
+            ip = q.next;
+        }
+        r.end = ip; r.nlit = nlit; r.nrec = (roff - 8u * lane) / kProvRow8 - 1u; r.nout = nout; r.lms = lms; r.flags = flags; r.need = need;
+    }
+    // `nrec` eight-byte records from the lane's column of the scratch to `rdst` (8-byte aligned)
+    SWC_D static void copy_prov8(gcptr prec, uint32_t nrec, SWC_AS_GLOBAL uint32_t* rdst) {
+        constexpr uint32_t kRows = (uint32_t)(lzr::kProvRecBytes / kProvRow8);
+        for (uint32_t i = 0; i < nrec; i += 16) {
+            uint64_t v[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint32_t row = i + k + 1u < kRows ? i + k + 1u : kRows - 1u;
+                v[k] = load_u64(prec + (size_t)row * kProvRow8);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k += 2) {
+                if (i + k + 2u <= nrec) store_u128_a4((gptr)(rdst + 2u * (i + k)), (uint32_t)v[k], (uint32_t)(v[k] >> 32), (uint32_t)v[k + 1], (uint32_t)(v[k + 1] >> 32));
+                else if (i + k < nrec) store_u64((gptr)(rdst + 2u * (i + k)), v[k]);
+            }
+        }
+    }
+
     // Rounds from `ip` on, as long as whole rounds can be committed.  Returns when the checked step has to take over
     // (the end of the block is near, a sequence that does not fit a round, anything invalid, the capacity).
     SWC_D void sync_rounds(uint8_t* stage) {
@@ -593,7 +649,8 @@ struct Parser {
                         SWC_LZ4_STAT(1, 1);
                         ProvOut r;
                         const uint32_t ce = t == N - 1 ? stage_len : ((uint32_t)t + 1u) * kChunk;
-                        parse_chunk_prov(stage, stage_len, start[t], ce, tail_limit, prov, (uint32_t)t, r);
+                        if (R8) parse_chunk_prov8(stage, stage_len, start[t], ce, tail_limit, prov, (uint32_t)t, (uint32_t)B, r);
+                        else parse_chunk_prov(stage, stage_len, start[t], ce, tail_limit, prov, (uint32_t)t, r);
                         endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; c_lms[t] = r.lms; flg[t] = r.flags;
                         c_need[t] = (uint32_t)r.need;
                         have[t] = true;
@@ -622,8 +679,10 @@ struct Parser {
             SIMT_END
             if (simt::wave_ballot<N>(pb)) return;                             // an offset beyond the output: the checked step reports it
             SIMT_BEGIN(t, N)
-                if ((uint32_t)t < nv && c_rec[t] != 0)
-                    copy_prov(prov + lzr::kProvRecBytes + 4u * (uint32_t)t, prov + 4u * (uint32_t)t, c_lit[t], c_rec[t], lits + nlit + (x_lit[t] - c_lit[t]), recs + nrec + (x_rec[t] - c_rec[t]));
+                if ((uint32_t)t < nv && c_rec[t] != 0) {
+                    if (R8) copy_prov8(prov + 8u * (uint32_t)t, c_rec[t], recs + 2u * (nrec + (x_rec[t] - c_rec[t])));
+                    else copy_prov(prov + lzr::kProvRecBytes + 4u * (uint32_t)t, prov + 4u * (uint32_t)t, c_lit[t], c_rec[t], lits + nlit + (x_lit[t] - c_lit[t]), recs + nrec + (x_rec[t] - c_rec[t]));
+                }
             SIMT_END
             SWC_LP(7)
             // the last match start of the round: in the last lane that took a sequence
@@ -646,7 +705,7 @@ struct Parser {
 
     SWC_D int run(uint8_t* stage) {
         // the rounds append records unchecked: the workspace must hold what a block of this capacity can need
-        const bool fast_ok = stage != nullptr && prov != nullptr && (size_t)max_rec >= lzr::max_records(cap);
+        const bool fast_ok = stage != nullptr && prov != nullptr && (size_t)max_rec >= (R8 ? lzr::max_records8(cap) : lzr::max_records(cap));
         int result = SWC_OK;
         for (;;) {
             if (fast_ok && pos < cap) sync_rounds(stage);
@@ -659,9 +718,9 @@ struct Parser {
 };
 
 // One wavefront = one job (blocks WITHOUT a dictionary prefix; those with one stay on lz4_lane.h).
-template <int W>
+template <int W, bool R8 = false>
 SWC_D void lz4_parse_job(Job& job, uint8_t* ws, size_t ws_bytes, int lane, uint8_t* stage, uint64_t* prof = nullptr) {
-    Parser<W> ps;
+    Parser<W, R8> ps;
     ps.w.lane = lane;
     ps.iw = stage + kScratchWin;
     ps.iw_hi = 0;
@@ -680,16 +739,23 @@ SWC_D void lz4_parse_job(Job& job, uint8_t* ws, size_t ws_bytes, int lane, uint8
     const size_t lo = ws ? lzr::lit_offset(ws_bytes, job.out_cap) : 0;
     ps.recs = (SWC_AS_GLOBAL uint32_t*)(ws + sizeof(lzr::StreamHeader));
     size_t rec_end = lo;   // the wave's scratch rows sit between the record list and the literal stream, if the area has room for them
-    if (lo >= sizeof(lzr::StreamHeader) + 256 + lzr::kProvBytes) {
+    if (R8) {
+        // no literal stream: header | eight-byte records | scratch rows at the END of the area (the records take what the literal
+        // stream would have taken: a block needs up to cap / 4 of them)
+        if (lo != 0 && ws_bytes >= sizeof(lzr::StreamHeader) + 256 + lzr::kProvBytes) {
+            rec_end = (ws_bytes - lzr::kProvBytes) & ~(size_t)15;
+            ps.prov = (gptr)(ws + rec_end);
+        }
+    } else if (lo >= sizeof(lzr::StreamHeader) + 256 + lzr::kProvBytes) {
         rec_end = (lo - lzr::kProvBytes) & ~(size_t)15;
         ps.prov = (gptr)(ws + rec_end);
     }
-    ps.max_rec = rec_end > sizeof(lzr::StreamHeader) ? (uint32_t)((rec_end - sizeof(lzr::StreamHeader)) / 4) : 0u;
+    ps.max_rec = rec_end > sizeof(lzr::StreamHeader) ? (uint32_t)((rec_end - sizeof(lzr::StreamHeader)) / (R8 ? 8 : 4)) : 0u;
     ps.lits = (gptr)(ws + lo);
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     ps.tlast = __builtin_readcyclecounter();
 #endif
-    int st = lo == 0 ? SWC_E_NEED_WORKSPACE : ps.run(stage);
+    int st = lo == 0 ? SWC_E_NEED_WORKSPACE : (R8 && job.in_len > 0xFFFFFFF0ull) ? SWC_E_INVALID_ARGUMENT /* literal offsets are 32 bits */ : ps.run(stage);
     ps.flush();
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     { const uint64_t t_ = __builtin_readcyclecounter(); ps.pacc[4] += t_ - ps.tlast; }

@@ -105,7 +105,10 @@ SWC_HD void copy_run(uint8_t* d, const uint8_t* s, uint32_t n) {
 // kLitPieces (eight-byte pieces of a literal run a lane copies on its own).  P: the type of a position in the output or in the
 // literal stream -- uint32_t for streams of less than 4 GiB (every position, watermark and difference is ONE scalar register and
 // one scalar instruction: the copier is bound as much by the CU's scalar unit as by its vector ALU), uint64_t for the rest.
-template <typename CFG, typename P>
+// R8: records of EIGHT bytes -- the 32-bit record and, in the upper dword, the offset of its literal run from `lits`, which then
+// is not a dense literal stream but the compressed input itself: LZ4 keeps its literals byte-aligned in the block (LZ4.swift:
+// 364-366), so the parse kernel writes no literal stream at all and the copier fetches a run where the encoder left it.
+template <typename CFG, typename P, bool R8 = false>
 struct Copier {
     static constexpr uint32_t WIN = CFG::kWin, SPAN = CFG::kSpan;
     using L = Lds<WIN>;
@@ -142,8 +145,9 @@ struct Copier {
 
     L* l;
     gptr out;
-    gcptr lits;        // the stream's dense literal stream (16-byte aligned base)
+    gcptr lits;        // the stream's dense literal stream (16-byte aligned base); R8: the compressed block
     P limit;           // bytes of `out` that exist: min(bytes produced, capacity)
+    uint32_t nin;      // R8: bytes of `lits` that exist (the block's compressed size: nothing is read beyond it)
 
     // wave state (the same in every lane)
     uint32_t A;        // out & 15: virtual position v = A + output position, so that 16-byte chunks of v are aligned in HBM
@@ -253,10 +257,13 @@ struct Copier {
     // ---- all lanes copy n literal bytes from the literal stream in HBM (offset lo) to window index wd
     SWC_D void coop_literals(uint32_t wd, P lo, uint32_t n) {
         gcptr src = lits + lo;
+        const uint32_t room = R8 ? nin - (uint32_t)lo : 0xFFFFFFFFu;   // (R8: a run may end with the block)
         SIMT_BEGIN(t, W)
             for (uint32_t o = 4u * (uint32_t)t; o < n; o += 4u * (uint32_t)W) {
                 // (whole dwords are read: the literal stream's allocation ends 32 bytes behind its last byte)
-                const uint32_t w = load_u32(src + o);
+                uint32_t w;
+                if (!R8 || o + 4u <= room) w = load_u32(src + o);
+                else { w = 0; for (uint32_t q = 0; o + q < room && q < 4u; q++) w |= (uint32_t)src[o + q] << (8u * q); }
                 if (o + 4u <= n) st32(l->win + wd + o, w);
                 else st_tail(l->win + wd + o, w, n - o);
             }
@@ -354,6 +361,7 @@ struct Copier {
         simt::PT<uint32_t, W> x;              // inclusive sums over the lanes: (literals + length) | literals << 16 (a big run: literal bytes)
         simt::PT<uint64_t, W> fw[kPieces];    // far sources asked for ahead, eight bytes each
         simt::PT<uint64_t, W> lw[kLitPieces]; // my literal run (up to kLongLit bytes) from the literal stream, eight bytes each
+        simt::PT<uint32_t, W> loff;           // R8: where my literal run starts (offset from `lits`)
         uint32_t kind;                        // 0: records up to the first big literal-only one; 1: a run of big literal-only records
         uint32_t ntake, span, litspan;        // records, output bytes, literal bytes of the group
         P pf_vbase;                           // window base the far loads assumed (~0: none were wanted)
@@ -371,12 +379,13 @@ struct Copier {
     // EVERY call issues the same loads, wanted or not (a lane that wants nothing reads a place that certainly exists): a
     // register that is loaded on one path only reaches the next iteration through a copy, and the compiler waits for the
     // load in front of the copy -- at once, instead of an iteration later.
-    SWC_D void front(Group& g, const simt::PT<uint32_t, W>& r_in, uint32_t left, P rpos, P lbase, P vb_pred) {
+    SWC_D void front(Group& g, const simt::PT<uint32_t, W>& r_in, const simt::PT<uint32_t, W>& o_in, uint32_t left, P rpos, P lbase, P vb_pred) {
         using simt::PT;
         PT<bool, W> big;
         SIMT_BEGIN(t, W)
             uint32_t li, le, di;
             g.rec[t] = (uint32_t)t < left ? r_in[t] : 0u;   // (the lanes past the last record loaded it again)
+            g.loff[t] = R8 ? o_in[t] : 0u;
             unpack(g.rec[t], li, le, di);
             big[t] = le == 0u && li >= kBigLit;
         SIMT_END
@@ -416,14 +425,40 @@ struct Copier {
         }
         // ---- my literal run, straight from the literal stream in HBM into registers: 32-bit offsets from the group's first literal
         {
-            gcptr lb = lits + lbase;
+            gcptr lb = R8 ? lits : lits + lbase;
             const bool runs = g.kind == 0u;
             const uint32_t ntake = g.ntake;
+            // R8: the last runs of a block end with the block -- an eight-byte piece that would reach past it is read further in
+            // front and shifted down (the block's last groups only: the offsets grow with the records)
+            const bool guard = R8 && runs && nin >= 8u && simt::wave_read<W>(g.loff, (int)ntake - 1) + (lzr::kLitRunMax + 8u) > nin;
+            if (R8 && nin < 8u) {   // (a block of a few bytes that still claims output, i.e. one that ends in an error: back() copies its runs byte by byte)
+                SIMT_BEGIN(t, W)
+#pragma unroll
+                    for (int k = 0; k < kLitPieces; k++) g.lw[k][t] = 0;
+                SIMT_END
+            } else if (guard) {
+                const uint32_t top = nin - 8u;
+                SIMT_BEGIN(t, W)
+                    uint32_t li, le, di;
+                    unpack(g.rec[t], li, le, di);
+                    const bool ask = (uint32_t)t < ntake && li != 0u && li <= kLongLit;
+                    const uint32_t o0 = ask ? g.loff[t] : 0u;
+                    const uint32_t last = (li > 8u ? li : 8u) - 8u;
+#pragma unroll
+                    for (int k = 0; k < kLitPieces; k++) {
+                        const uint32_t ok = 8u * (uint32_t)k < last ? 8u * (uint32_t)k : last;
+                        const uint32_t a = ask && 8u * (uint32_t)k < li ? o0 + ok : 0u;
+                        const uint32_t a1 = a < top ? a : top;
+                        g.lw[k][t] = load_u64(lb + a1) >> (8u * (a - a1));   // (a - a1 < 8: a literal byte lies inside the block)
+                    }
+                SIMT_END
+            } else {
             SIMT_BEGIN(t, W)
                 uint32_t li, le, di;
                 unpack(g.rec[t], li, le, di);
                 const bool ask = runs && (uint32_t)t < ntake && li != 0u && li <= kLongLit;
-                const uint32_t o0 = ask ? (g.x[t] >> 16) - li : 0u;             // (nothing wanted: the group's first literal, or the byte behind the last: it exists)
+                // (nothing wanted: the group's first literal, or the byte behind the last: it exists; R8: the block's first bytes)
+                const uint32_t o0 = ask ? (R8 ? g.loff[t] : (g.x[t] >> 16) - li) : 0u;
                 const uint32_t last = (li > 8u ? li : 8u) - 8u;
 #pragma unroll
                 for (int k = 0; k < kLitPieces; k++) {
@@ -431,6 +466,7 @@ struct Copier {
                     g.lw[k][t] = load_u64(lb + (ask && 8u * (uint32_t)k < li ? o0 + ok : 0u));
                 }
             SIMT_END
+            }
         }
         // ---- far sources, one group ahead: 32-bit offsets from (the group's first byte - kBack)
         {
@@ -469,6 +505,7 @@ struct Copier {
             P rp = rpos, lb = lbase;
             for (uint32_t i = 0; i < g.ntake; i++) {
                 const uint32_t e1 = simt::wave_read<W>(g.x, (int)i);
+                if (R8) lb = (P)simt::wave_read<W>(g.loff, (int)i);
                 uint32_t n = (uint32_t)(rpos + e1 - rp);
                 while (n != 0u) {   // (a record of up to kMaxLitOnly bytes in pieces of what a slide makes room for)
                     const uint32_t piece = n < kSpanMax ? n : kSpanMax;
@@ -507,8 +544,9 @@ struct Copier {
             si[t] = s;
             // my literals (stores under the exec mask: the LDS takes as long over a store as lanes take part in it, and most
             // lanes have no literals at all)
-            longlit[t] = mine && li > kLongLit;
-            if (mine && li != 0u && li <= kLongLit) {
+            const bool own_lits = li <= kLongLit && !(R8 && nin < 8u);
+            longlit[t] = mine && li != 0u && !own_lits;
+            if (mine && li != 0u && own_lits) {
                 uint64_t pc[kLitPieces];
 #pragma unroll
                 for (int k = 0; k < kLitPieces; k++) pc[k] = g.lw[k][t];
@@ -533,7 +571,7 @@ struct Copier {
             const int h = simt::ctz64(m);
             const uint32_t li = simt::wave_read<W>(lit, h);
             const uint32_t lend = simt::wave_read<W>(g.x, h) >> 16;
-            coop_literals(simt::wave_read<W>(wm, h) - li, lbase + (lend - li), li);
+            coop_literals(simt::wave_read<W>(wm, h) - li, R8 ? (P)simt::wave_read<W>(g.loff, h) : lbase + (lend - li), li);
         }
 #if SWC_LZC_CUT == 3
         return;
@@ -618,7 +656,8 @@ struct Copier {
                 uint64_t lp = 0;
                 for (uint32_t i = 0; i < nrec && pos < lim; i++) {
                     uint32_t li, le, di;
-                    unpack(recs[i], li, le, di);
+                    unpack(recs[R8 ? 2u * i : i], li, le, di);
+                    if (R8) lp = recs[2u * i + 1u];
                     for (uint32_t k = 0; k < li && pos < lim; k++, pos++, lp++) l->win[pos] = lits[lp];
                     for (uint32_t k = 0; k < le && pos < lim; k++, pos++) l->win[pos] = pos >= di ? l->win[pos - di] : (uint8_t)0;
                 }
@@ -640,16 +679,23 @@ struct Copier {
         P rpos = 0;                      // output bytes finished by earlier groups
         P lbase = 0;                     // literal bytes consumed by earlier groups
         uint32_t base = 0;               // first record of the group
-        PT<uint32_t, W> r_nx;            // the records of the group after `nxt`, on their way
+        PT<uint32_t, W> r_nx, o_nx;      // the records of the group after `nxt` (R8: and their literal offsets), on their way
         Group cur, nxt;
-        const uint32_t rlast4 = 4u * (nrec - 1u);
+        constexpr uint32_t kRecBytes = R8 ? 8u : 4u;
+        const uint32_t rlast4 = kRecBytes * (nrec - 1u);
         gcptr rb = (gcptr)recs;
-        SIMT_BEGIN(t, W) r_nx[t] = load_u32(rb + (4u * (uint32_t)t < rlast4 ? 4u * (uint32_t)t : rlast4)); SIMT_END
-        front(nxt, r_nx, nrec, 0, 0, ~(P)0);
-        {
-            const uint32_t b4 = 4u * nxt.ntake;
-            SIMT_BEGIN(t, W) r_nx[t] = load_u32(rb + (b4 + 4u * (uint32_t)t < rlast4 ? b4 + 4u * (uint32_t)t : rlast4)); SIMT_END
-        }
+        // the 64 records from record `first` on (the lanes past the last record load it again)
+        auto load_records = [&](uint32_t first) {
+            const uint32_t b4 = kRecBytes * first;
+            SIMT_BEGIN(t, W)
+                const uint32_t o = b4 + kRecBytes * (uint32_t)t < rlast4 ? b4 + kRecBytes * (uint32_t)t : rlast4;
+                if (R8) { const uint64_t v = load_u64(rb + o); r_nx[t] = (uint32_t)v; o_nx[t] = (uint32_t)(v >> 32); }
+                else { r_nx[t] = load_u32(rb + o); o_nx[t] = 0u; }
+            SIMT_END
+        };
+        load_records(0);
+        front(nxt, r_nx, o_nx, nrec, 0, 0, ~(P)0);
+        load_records(nxt.ntake);
         bool more = true;
         while (more) {
             // Everything asked for during the last iteration -- the next records, far sources, literals -- is here, and its
@@ -665,9 +711,8 @@ struct Copier {
                     const P vcur = (P)A + rpos;
                     if ((uint32_t)(vcur - vbp) + cur.span > WIN) vbp = (vcur - kKeep) & ~(P)15;
                 }
-                front(nxt, r_nx, nrec - nbase, rpos + cur.span, lbase + cur.litspan, vbp);
-                const uint32_t b4 = 4u * (nbase + nxt.ntake);
-                SIMT_BEGIN(t, W) r_nx[t] = load_u32(rb + (b4 + 4u * (uint32_t)t < rlast4 ? b4 + 4u * (uint32_t)t : rlast4)); SIMT_END
+                front(nxt, r_nx, o_nx, nrec - nbase, rpos + cur.span, lbase + cur.litspan, vbp);
+                load_records(nbase + nxt.ntake);
             }
             back(cur, rpos, lbase);
             base = nbase;
@@ -711,26 +756,30 @@ using CfgDeflate = Cfg<SWC_LZC_WIN, SWC_LZC_SPAN, SWC_LZC_KEEP, SWC_LZC_LITP>;
 using CfgLz4 = Cfg<SWC_LZC4_WIN, SWC_LZC4_SPAN, SWC_LZC4_KEEP, 4>;
 using CfgWide = Cfg<16384, 2048, 14320, 4>;   // (comparison runs: 8 waves per CU)
 
-// One job: `ws` is the stream's workspace area of `area` bytes written by phase 1.
-template <typename CFG>
+// One job: `ws` is the stream's workspace area of `area` bytes written by phase 1.  R8 (LZ4): the area holds the header and
+// eight-byte records only, the literals are fetched from the job's input.
+template <typename CFG, bool R8 = false>
 SWC_D void copy_job(const Job& job, const uint8_t* ws, size_t area, Lds<CFG::kWin>* lds) {
     const SWC_AS_GLOBAL lzr::StreamHeader* h = (const SWC_AS_GLOBAL lzr::StreamHeader*)ws;
     const size_t lo = lzr::lit_offset(area, job.out_cap);
     if (lo == 0) return;   // no literal stream: phase 1 reported SWC_E_NEED_WORKSPACE for this job
     const uint64_t limit = job.out_len < job.out_cap ? job.out_len : job.out_cap;
     const SWC_AS_GLOBAL uint32_t* recs = (const SWC_AS_GLOBAL uint32_t*)(ws + sizeof(lzr::StreamHeader));
+    gcptr lits = R8 ? (gcptr)job.in : (gcptr)ws + lo;
     if (limit < 0xFFF00000ull) {   // (positions, watermarks and their differences in 32 bits)
-        Copier<CFG, uint32_t> cp;
+        Copier<CFG, uint32_t, R8> cp;
         cp.l = lds;
         cp.out = (gptr)job.out;
-        cp.lits = (gcptr)ws + lo;
+        cp.lits = lits;
+        cp.nin = R8 ? (uint32_t)job.in_len : 0xFFFFFFFFu;   // (blocks are addressed with 32-bit offsets: launch_lz4 rejects larger ones)
         cp.limit = (uint32_t)limit;
         cp.run(recs, h->nrec);
     } else {
-        Copier<CFG, uint64_t> cp;
+        Copier<CFG, uint64_t, R8> cp;
         cp.l = lds;
         cp.out = (gptr)job.out;
-        cp.lits = (gcptr)ws + lo;
+        cp.lits = lits;
+        cp.nin = R8 ? (uint32_t)job.in_len : 0xFFFFFFFFu;
         cp.limit = limit;
         cp.run(recs, h->nrec);
     }

@@ -58,6 +58,9 @@ struct StreamHeader {
 // plus the literal-only records (one per kLitRunMax + 1 literals in front of a match, one per sub-chunk tail of the
 // wave-parallel Deflate decode: a tail record closes >= 50 bits of input) plus slack.
 SWC_HD size_t max_records(uint64_t cap) { return (size_t)(cap / 3 + cap / 32 + 64); }
+// ... and an LZ4 block whose records carry the offset of their literals (lz4_wave.h: R8): a sequence with a match yields four
+// output bytes or more, a literal-only record stands for up to kMaxLitOnly bytes
+SWC_HD size_t max_records8(uint64_t cap) { return (size_t)(cap / 4 + cap / 1024 + 64); }
 SWC_HD size_t lit_bytes(uint64_t cap) { return (size_t)((cap + 32 + 15) & ~(uint64_t)15); }   // +32: wide flushes and reads may overshoot
 // Scratch of the wave-parallel Deflate decode (inflate_sync.h): the records and literals of the 64 sub-chunks of the current
 // round before their final offsets are known, as ROWS across the lanes -- row k holds the k-th record (4 bytes) / the k-th

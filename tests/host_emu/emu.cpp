@@ -26,15 +26,21 @@ extern "C" void emu_set_order(int o) { swc::simt::g_order = o; }
 static int g_copier = 1;
 extern "C" void emu_set_copier(int on) { g_copier = on; }
 // (the two window configurations the library ships: kernels.hip)
-template <typename CFG>
+template <typename CFG, bool R8 = false>
 static void emu_copy(swc::Job& job, const uint8_t* ws, size_t wsb) {
     alignas(16) static swc::lzc::Lds<CFG::kWin> cl;
     std::memset(&cl, 0xEE, sizeof cl);
-    swc::lzc::copy_job<CFG>(job, ws, wsb, &cl);
+    swc::lzc::copy_job<CFG, R8>(job, ws, wsb, &cl);
 }
+// (Deflate: four-byte records + the dense literal stream; LZ4: eight-byte records whose literals stay in the block -- R8)
 static void emu_copy_any(int deflate, swc::Job& job, const uint8_t* ws, size_t wsb) {
-    if (g_copier == 3 || (g_copier == 1 && deflate)) emu_copy<swc::lzc::CfgDeflate>(job, ws, wsb);
-    else emu_copy<swc::lzc::CfgLz4>(job, ws, wsb);
+    if (deflate) {
+        if (g_copier == 2) emu_copy<swc::lzc::CfgLz4>(job, ws, wsb);
+        else emu_copy<swc::lzc::CfgDeflate>(job, ws, wsb);
+    } else {
+        if (g_copier == 3) emu_copy<swc::lzc::CfgDeflate, true>(job, ws, wsb);
+        else emu_copy<swc::lzc::CfgLz4, true>(job, ws, wsb);
+    }
 }
 
 // Deflate, one stream per wavefront with 64 sub-chunks decoded at once (inflate_sync.h): the uniform parts run once, the
@@ -74,11 +80,12 @@ extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {
         std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
         alignas(16) static uint8_t stage[swc::lz4w::kStageLds];
         std::memset(stage, 0xEE, sizeof stage);
-        swc::lz4w::lz4_parse_job<1>(jobs[g], ws.data(), wsb, 0, stage);
         if (g_copier) {
+            swc::lz4w::lz4_parse_job<1, true>(jobs[g], ws.data(), wsb, 0, stage);
             emu_copy_any(0, jobs[g], ws.data(), wsb);
             continue;
         }
+        swc::lz4w::lz4_parse_job<1>(jobs[g], ws.data(), wsb, 0, stage);
         std::memset(&rl, 0xEE, sizeof rl);
         swc::lzr::resolve_job<swc::lz4w::kResolveThreads, swc::lz4w::kRingLog2, swc::lz4w::kKeep, true>(jobs[g], ws.data(), wsb, &rl);
     }
@@ -211,6 +218,24 @@ extern "C" void emu_copy_records(const uint32_t* recs, uint32_t nrec, const uint
         std::memset(&rl, 0xEE, sizeof rl);
         swc::lzr::resolve_job<512, 16, 32768, true>(j, ws.data(), wsb, &rl);
     }
+}
+
+// The same with EIGHT-byte records (record | literal offset << 32) whose literals lie in `in` (the LZ4 path): `in` is copied
+// into a buffer of exactly in_len bytes, so that a read past the block shows under AddressSanitizer.
+extern "C" void emu_copy_records8(const uint32_t* recs2, uint32_t nrec, const uint8_t* in, size_t in_len, uint8_t* out, size_t cap, size_t out_len, int copier) {
+    const size_t wsb = swc::lzr::ws_bytes_per_job(cap);
+    std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
+    swc::lzr::StreamHeader* h = (swc::lzr::StreamHeader*)ws.data();
+    h->nrec = nrec;
+    h->nlit = 0;
+    std::memcpy(ws.data() + sizeof(swc::lzr::StreamHeader), recs2, 8 * (size_t)nrec);
+    std::unique_ptr<uint8_t[]> exact(new uint8_t[in_len ? in_len : 1]);
+    std::memcpy(exact.get(), in, in_len);
+    swc::Job j{};
+    j.in = exact.get(); j.in_len = in_len;
+    j.out = out; j.out_cap = cap; j.out_len = out_len;
+    if (copier == 3) emu_copy<swc::lzc::CfgDeflate, true>(j, ws.data(), wsb);
+    else emu_copy<swc::lzc::CfgLz4, true>(j, ws.data(), wsb);
 }
 
 // Debug/analysis helper (tools/analyze_records.py): phase 1 only, returns the record list of one stream.

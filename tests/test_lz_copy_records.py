@@ -95,6 +95,56 @@ def test_record_classes(profile, order):
         E.set_order(0)
 
 
+lib.emu_copy_records8.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+lib.emu_copy_records8.restype = None
+
+
+def run_copy8(recs, offs, block, cap, out_len, misalign, copier):
+    buf = C.create_string_buffer(cap + 64 + 32)
+    C.memset(buf, 0xA5, len(buf))
+    o0 = (-C.addressof(buf)) % 16 + 16 + misalign
+    flat = [x for r, o in zip(recs, offs) for x in (r, o)]
+    arr = (C.c_uint32 * max(len(flat), 1))(*flat)
+    lib.emu_copy_records8(arr, len(recs), block, len(block), C.addressof(buf) + o0, cap, out_len, copier)
+    raw = buf.raw
+    assert raw[:o0] == b"\xA5" * o0 and raw[o0 + cap:] == b"\xA5" * (len(raw) - o0 - cap), "bytes outside the output were written"
+    return raw[o0:o0 + min(cap, out_len)]
+
+
+@pytest.mark.parametrize("profile", [TEXT, LITRUNS, STORED], ids=["text", "litruns", "stored"])
+@pytest.mark.parametrize("order", [0, 2])
+def test_records_that_point_at_their_literals(profile, order):
+    """The LZ4 form of the records (lz4_wave.h R8, LZ4.swift:364-366: literals are byte-aligned in the block): eight bytes, the
+    upper dword the offset of the literal run in the BLOCK, no dense literal stream.  The block here is the literal runs with one
+    to four other bytes between them (tokens, offsets, length bytes), and the last run ends with the block: nothing may be read
+    past it (the emulation copies the block into a buffer of exactly its size; tests/test_emulation_asan.py runs the LZ4 path
+    of it under AddressSanitizer)."""
+    rnd = random.Random(hash((profile["len"][-1], order)) & 0xFFFF)
+    E.set_order(order)
+    try:
+        for size in (1, 63, 64, 200, 5000, 40000, 140000):
+            recs, lits, exp = build(rnd, size, profile)
+            block, offs, lp = bytearray(), [], 0
+            for r in recs:
+                ln = (r >> 7) & 511
+                li = (r & 127) + (((r >> 16) << 7) if ln == 0 else 0)
+                block += bytes(rnd.randrange(256) for _ in range(rnd.randint(1, 4)))
+                offs.append(len(block))
+                block += lits[lp:lp + li]
+                lp += li
+            # (the last record's literals end the block when it has any; cut what was appended behind a record without literals)
+            block = bytes(block[:max(o + ((r & 127) + (((r >> 16) << 7) if (r >> 7) & 511 == 0 else 0)) for r, o in zip(recs, offs))])
+            for misalign in (0, 7):
+                for cfg in (1, 3):
+                    got = run_copy8(recs, offs, block, len(exp), len(exp), misalign, cfg)
+                    assert got == exp, "copier differs (size %d, misalign %d, configuration %d)" % (size, misalign, cfg)
+        # a block of fewer than eight bytes that still claims output (a stream that ends in an error): byte by byte
+        recs = [make_match(3, 100, 2)]
+        assert run_copy8(recs, [1], b"\x00abc", 103, 103, 0, 1) == b"abc" + b"bc" * 50
+    finally:
+        E.set_order(0)
+
+
 def test_capacity_cuts_the_last_records():
     """Records exist only for output below the capacity: the last one may reach past it (phase 2 clamps at the limit)."""
     rnd = random.Random(77)
