@@ -738,7 +738,7 @@ struct Cfg {
 // r06_experiments.txt: the sweeps).  Deflate: 6 KiB window of which a slide keeps 2.5 KiB (a slide costs more than the far
 // matches it avoids: a far source is four loads that are issued anyway), groups of up to 1 KiB, literal runs of up to 16 bytes
 // per lane -- 6,424 bytes of LDS per wave, 24 waves per CU.  LZ4 (offsets up to 65,535, 4 MiB blocks, longer
-// literal runs): 9 KiB / 6 KiB kept / 2 KiB groups / runs of up to 32 bytes -- 9,496 bytes, 16 waves per CU.
+// literal runs): 9 KiB / 3.25 KiB kept / 2 KiB groups / runs of up to 32 bytes -- 9,496 bytes, 16 waves per CU.
 #ifndef SWC_LZC_WIN
 #define SWC_LZC_WIN 6144
 #define SWC_LZC_SPAN 1024
@@ -751,9 +751,12 @@ using CfgDeflate = Cfg<SWC_LZC_WIN, SWC_LZC_SPAN, SWC_LZC_KEEP, SWC_LZC_LITP>;
 #ifndef SWC_LZC4_WIN
 #define SWC_LZC4_WIN 9216
 #define SWC_LZC4_SPAN 2048
-#define SWC_LZC4_KEEP 6144
+#define SWC_LZC4_KEEP 3328
 #endif
-using CfgLz4 = Cfg<SWC_LZC4_WIN, SWC_LZC4_SPAN, SWC_LZC4_KEEP, 4>;
+#ifndef SWC_LZC4_LITP
+#define SWC_LZC4_LITP 4
+#endif
+using CfgLz4 = Cfg<SWC_LZC4_WIN, SWC_LZC4_SPAN, SWC_LZC4_KEEP, SWC_LZC4_LITP>;
 using CfgWide = Cfg<16384, 2048, 14320, 4>;   // (comparison runs: 8 waves per CU)
 
 // One job: `ws` is the stream's workspace area of `area` bytes written by phase 1.  R8 (LZ4): the area holds the header and

@@ -196,7 +196,47 @@ struct Decoder {
 #ifndef SWC_LZMA_BIT_SELECT
 #define SWC_LZMA_BIT_SELECT 0
 #endif
+#ifndef SWC_LZMA_BIT_ASM
+#define SWC_LZMA_BIT_ASM 1
+#endif
     SWC_HD int bit(uint16_t* p) {  // LZMARangeDecoder.swift:65-80
+#if defined(__HIP_DEVICE_COMPILE__) && SWC_LZMA_BIT_ASM
+        // The decision as ONE block of gfx950 instructions: read, split the range, compare, ONE scalar branch, the side taken
+        // (probability update, range / code), the store -- 13 instructions on the zero side, 12 on the one side.  From the C++
+        // form below the compiler makes two conditional regions joined by a flag register (a move, a branch, an and-not and a
+        // second branch more per decision), because it structures the if / else for lanes that might disagree; they cannot:
+        // every value here is the same in all 64 lanes (vcc is all ones or zero).  The cell is in LDS: the low half of its
+        // generic address is its LDS address.
+        const uint32_t a = (uint32_t)(uintptr_t)p;
+        uint32_t pr, bound;   // (bound doubles as the scratch register of the probability update once the range has taken it)
+        int sym;
+        asm volatile(
+            "ds_read_u16 %[pr], %[a]\n\t"
+            "v_lshrrev_b32 %[bound], 11, %[range]\n\t"
+            "s_waitcnt lgkmcnt(0)\n\t"
+            "v_mul_u32_u24 %[bound], %[bound], %[pr]\n\t"
+            "v_cmp_lt_u32 vcc, %[code], %[bound]\n\t"
+            "s_cbranch_vccz 1f\n\t"
+            "v_mov_b32 %[range], %[bound]\n\t"
+            "v_sub_u32 %[bound], 0x800, %[pr]\n\t"
+            "v_lshrrev_b32 %[bound], 5, %[bound]\n\t"
+            "v_add_u32 %[pr], %[pr], %[bound]\n\t"
+            "s_mov_b32 %[sym], 0\n\t"
+            "s_branch 2f\n"
+            "1:\n\t"
+            "v_sub_u32 %[code], %[code], %[bound]\n\t"
+            "v_sub_u32 %[range], %[range], %[bound]\n\t"
+            "v_lshrrev_b32 %[bound], 5, %[pr]\n\t"
+            "v_sub_u32 %[pr], %[pr], %[bound]\n\t"
+            "s_mov_b32 %[sym], 1\n"
+            "2:\n\t"
+            "ds_write_b16 %[a], %[pr]"
+            : [pr] "=&v"(pr), [bound] "=&v"(bound), [sym] "=&s"(sym), [range] "+v"(range), [code] "+v"(code)
+            : [a] "v"(a)
+            : "vcc", "memory");
+        normalize();
+        return sym;
+#else
         const uint32_t pr = *p;
         uint32_t bound = (range >> 11) * pr;
         if (SWC_LZMA_BIT_SELECT) {   // both sides computed, picked by selects on ONE scalar condition: no branch in the decision
@@ -222,6 +262,7 @@ struct Decoder {
         }
         normalize();
         return sym;
+#endif
     }
     SWC_HD int bit_spill(SWC_AS_GLOBAL uint16_t* p) {
         uint32_t pr = *p;
