@@ -143,8 +143,9 @@ int swc_lz4_compress(const uint8_t* data, size_t len, int independent_blocks, in
                      int content_size, size_t block_size, const uint8_t* dict, size_t dict_len, int64_t dict_id,
                      uint8_t** out, size_t* out_len);
 /* Deflate.compress(data:) Deflate+Compress.swift:22-46: one stored or static-Huffman block, compressed on the device
- * (SWC_CODEC_DEFLATE_COMPRESS).  ZlibArchive.archive(data:) ZlibArchive.swift:54-70: 0x78 0xDA, that stream, Adler-32 (big
- * endian; computed on the device in the same launch sequence). */
+ * (SWC_CODEC_DEFLATE_COMPRESS; one wavefront per buffer -- the throughput is in batches of buffers, a single large one
+ * runs at a wavefront's pace).  ZlibArchive.archive(data:) ZlibArchive.swift:54-70: 0x78 0xDA, that stream, Adler-32 of the
+ * input (big endian; computed on the host). */
 int swc_deflate_compress(const uint8_t* data, size_t len, uint8_t** out, size_t* out_len);
 int swc_zlib_archive(const uint8_t* data, size_t len, uint8_t** out, size_t* out_len);
 /* GzipArchive.archive(data:comment:fileName:writeHeaderCRC:isTextFile:osType:modificationTime:extraFields:)
@@ -283,26 +284,35 @@ uint32_t swc_xxh32(const uint8_t* p, size_t n, uint32_t seed);
 void swc_sha256(const uint8_t* p, size_t n, uint8_t digest[32]);
 
 void swc_free(void* p);
+/* What the library keeps between calls -- freed device memory in the device's pool (2 GiB), the calling thread's two page-locked
+ * staging buffers (512 MiB each), large host results handed back through swc_free() (512 MiB in all) -- goes back to the
+ * driver / the system: the parked results, the CALLING thread's staging buffers, the current device's pool.  The limits:
+ * swc_set_tuning "pool_keep_mib" / "pinned_keep_mib" / "result_cache_mib" (or the environment variables SWC_POOL_KEEP_MIB /
+ * SWC_PINNED_KEEP_MIB / SWC_RESULT_CACHE_MIB, read when the library is loaded).  Returns SWC_OK. */
+int swc_trim(void);
 /* 1 if a gfx950 device is usable, 0 otherwise (then every decode entry point returns SWC_E_DEVICE) */
 int swc_device_available(void);
 const char* swc_version(void);
-/* Measurement knobs (never change results), meant for benchmarking:
+/* Knobs that never change results.  Memory kept between calls (see swc_trim): "pool_keep_mib", "pinned_keep_mib",
+ * "result_cache_mib" = MiB (>= 0).  Measurement knobs, meant for benchmarking:
  *   "phase_timing" = 0 | 1      HIP events between the kernels of the batch launches of the CALLING THREAD (like the launch
  *                               stream and the staging buffers, measurement state is per thread);
  *   "lzma_coder_cache" = 1 | 0  process-wide: LZMA / LZMA2 launches with a workspace keep four LINES (a third of a literal
  *                               coder each) in LDS as a cache of the coders in the workspace (32 streams per CU, default) or
  *                               all coders of lc + lp <= 3 in LDS (10 streams per CU);
  *   "lz_copier" = 1 | 0 | 2 | -1 | -2   process-wide: the LZ77 copy phase of Deflate / LZ4 launches -- 1 (default): one stream
- *                               per wave with an 8 KiB LDS window (csrc/lz_copy.h) for launches of 2,560 streams and more,
- *                               one stream per 512-thread workgroup (csrc/lz_resolve.h) below; 0: the workgroup kernel always;
- *                               2: the wave kernel with a 16 KiB window; -1 / -2: the wave kernel whatever the launch size;
+ *                               per wave (csrc/lz_copy.h: Deflate a 6 KiB LDS window in groups of up to 1 KiB, LZ4 9 KiB / 2 KiB)
+ *                               for launches of 2,560 streams and more, one stream per 512-thread workgroup
+ *                               (csrc/lz_resolve.h) below; 0: the workgroup kernel always; 2: Deflate launches take the wave
+ *                               kernel with a 16 KiB window; -1 / -2: the wave kernel whatever the launch size;
  *   "bzip2_hot_cxx" = 0 | 1     process-wide: BZip2 launches run the instantiation of the block kernel whose plain-symbol loop is
  *                               compiled from C++ (1) instead of the hand-written assembly (0, default) -- the two are compared
  *                               by the GPU tests;
  *   "bzip2_team_walk" = 1 | 0 | 2   process-wide: BZip2 launches run stage 3 -- the inverse Burrows-Wheeler walk, the lay-out,
  *                               the RLE1 undo -- as kernels of their own that walk out of the XCDs' L2 (csrc/bzip2_team.h)
  *                               unless the launch is tiny (1, default), never (0: one wavefront takes a block through all
- *                               stages), or always (2). */
+ *                               stages), or always (2);
+ *   "bzip2_team_per_cu" = 1 | 2 process-wide: workgroups of the team walk per CU (1, default; 2 for comparison runs). */
 int swc_set_tuning(const char* key, int value);
 /* Profile builds of the library (-DSWC_PROFILE) only: a device buffer of 32 x uint64 per job of the next Deflate
  * launches that the kernels fill with cycle counts per stage (tools/exp_profile.py).  NULL switches it off.  A no-op in

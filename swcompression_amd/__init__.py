@@ -96,6 +96,12 @@ def device_available():
     return bool(_lib.load().swc_device_available())
 
 
+def trim():
+    """swc_trim(): what the library keeps between calls (freed device memory in the pool, this thread's page-locked staging
+    buffers, parked host results) goes back to the driver / the system."""
+    return _lib.load().swc_trim()
+
+
 def _take(ptr, n):
     lib = _lib.load()
     data = C.string_at(ptr, n) if n else b""

@@ -55,6 +55,7 @@ def load():
         f.argtypes = list(args)
 
     sig("swc_free", None, C.c_void_p)
+    sig("swc_trim", I)
     sig("swc_device_available", I)
     sig("swc_version", C.c_char_p)
     sig("swc_set_tuning", I, C.c_char_p, I)

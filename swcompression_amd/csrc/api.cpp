@@ -8,8 +8,10 @@
 #include <chrono>
 #include <functional>
 #include <stdio.h>
+#include <stdlib.h>
 #include <mutex>
 #include <thread>
+#include <system_error>
 #include <vector>
 #include <string.h>
 #include "host_util.h"
@@ -20,6 +22,22 @@ static_assert(offsetof(swc_job, status) == offsetof(swc::Job, status), "layout")
 static_assert(offsetof(swc_job, dict_len) == offsetof(swc::Job, dict_len), "layout");
 
 namespace swc {
+
+// What the library keeps between calls so that the next call need not ask the driver / the kernel for it again: freed device
+// memory in the device's pool, the calling thread's page-locked staging buffers, the large host results handed back through
+// swc_free().  All three are bounded, the bounds can be set (swc_set_tuning "pool_keep_mib" / "pinned_keep_mib" /
+// "result_cache_mib", or the environment variables SWC_POOL_KEEP_MIB / SWC_PINNED_KEEP_MIB / SWC_RESULT_CACHE_MIB read once),
+// and swc_trim() gives everything back (a process with N threads held 2 N GiB of pinned memory and 8 GiB of HBM).
+static size_t env_mib(const char* name, size_t dflt) {
+    const char* v = getenv(name);
+    if (!v || !*v) return dflt;
+    char* end = nullptr;
+    const unsigned long long x = strtoull(v, &end, 10);
+    return end && *end == 0 && x <= (1ull << 20) ? (size_t)x : dflt;
+}
+static std::atomic<size_t> g_pool_keep{env_mib("SWC_POOL_KEEP_MIB", 2048) << 20};       // a BGZF file of 4,096 members needs a workspace of 1.1 GB per call
+static std::atomic<size_t> g_pinned_keep{env_mib("SWC_PINNED_KEEP_MIB", 512) << 20};    // per thread and direction
+static std::atomic<size_t> g_result_cache{env_mib("SWC_RESULT_CACHE_MIB", 512) << 20};  // process-wide
 
 static std::once_flag g_dev_once;
 static bool g_dev_ok = false;
@@ -39,7 +57,7 @@ bool device_is_gfx950(int dev) {
         g_dev_state[dev] = strncmp(prop.gcnArchName, "gfx950", 6) == 0 ? 1 : 2;
         if (g_dev_state[dev] == 1) {   // keep freed staging buffers of the single-shot calls in the pool instead of returning them to the OS
             hipMemPool_t pool;
-            uint64_t keep = 8ull << 30;   // (a BGZF file of 4,096 members needs a workspace of 1.1 GB per call: kept, not returned to the driver)
+            uint64_t keep = g_pool_keep.load();
             if (hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
             (void)hipGetLastError();
         }
@@ -85,7 +103,7 @@ static size_t default_cap(int codec, const HostUnit& u) {
 // swc_free() of a result of kResultCacheMin bytes and more parks the buffer (up to kResultCacheMax bytes in all, the largest
 // first to go); the next result of about that size -- at most twice as small -- takes it over with its pages mapped.
 // Everything else is plain malloc / free.
-constexpr size_t kResultCacheMin = (size_t)4 << 20, kResultCacheMax = (size_t)1 << 30;
+constexpr size_t kResultCacheMin = (size_t)4 << 20;
 static std::mutex g_res_mu;
 static std::map<void*, size_t> g_res_live;                 // large results in the hands of callers: pointer -> capacity
 static std::vector<std::pair<void*, size_t>> g_res_parked;  // freed ones
@@ -118,7 +136,7 @@ void host_result_free(void* p) {
             size_t held = cap;
             for (auto& e : g_res_parked) held += e.second;
             g_res_parked.emplace_back(p, cap);
-            while (held > kResultCacheMax && !g_res_parked.empty()) {   // over the limit: the largest go back to the system
+            while (held > g_result_cache.load() && !g_res_parked.empty()) {   // over the limit: the largest go back to the system
                 size_t big = 0;
                 for (size_t i = 1; i < g_res_parked.size(); i++) if (g_res_parked[i].second > g_res_parked[big].second) big = i;
                 held -= g_res_parked[big].second;
@@ -137,7 +155,6 @@ void stat_add(int which, long long v) { if (which >= 0 && which < 3) g_stats[whi
 // What a thread keeps page-locked between calls, per direction.  Pinning is the expensive part of a large single-shot call
 // (a 268 MB result: tens of milliseconds to lock against 5 ms to copy), so a buffer that served an archive of a gigabyte
 // stays for the next one; only a buffer beyond that is released when its call is over.
-constexpr size_t kPinnedKeep = (size_t)1 << 30;
 
 // Two page-locked staging buffers per calling thread (0: host -> device, 1: device -> host), grown on demand, released
 // when the thread ends.
@@ -149,8 +166,8 @@ uint8_t* pinned_stage(int which, size_t n) {
     };
     static thread_local Buf bufs[2];
     Buf& b = bufs[which & 1];
-    if (which & 2) {   // trim request (pinned_trim)
-        if (b.cap > kPinnedKeep) { (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
+    if (which & 6) {   // trim request (2: pinned_trim after a call -- what is over the limit; 4: swc_trim -- everything)
+        if (b.p && ((which & 4) || b.cap > g_pinned_keep.load())) { (void)hipHostFree(b.p); b.p = nullptr; b.cap = 0; }
         return nullptr;
     }
     if (b.cap < n) {
@@ -162,7 +179,7 @@ uint8_t* pinned_stage(int which, size_t n) {
     return static_cast<uint8_t*>(b.p);
 }
 // A thread that staged a multi-gigabyte container once would hold that much page-locked memory until it ends: buffers above
-// kPinnedKeep are released when the call that needed them is over (round-2 advisor; round 4: the limit was 256 MiB, and a
+// the limit ("pinned_keep_mib") are released when the call that needed them is over (round-2 advisor; round 4: the limit was 256 MiB, and a
 // 268 MB BGZF file pinned its buffers again on every call).
 static void pinned_trim() {
     for (int w = 0; w < 2; w++) (void)pinned_stage(w | 2, 0);
@@ -185,13 +202,17 @@ static void copy_out(std::vector<CopyOut>& v) {
     size_t nt = std::min<size_t>({(size_t)8, hw ? (size_t)hw : (size_t)1, total >> 24, v.size()});   // a thread per 16 MB, eight at most
     if (nt < 2) { copy_range(v, 0, v.size()); return; }
     std::vector<std::thread> th;
-    size_t i = 0, acc = 0;
-    for (size_t t = 0; t < nt; t++) {   // contiguous ranges of about total / nt bytes
-        const size_t lo = i, target = total / nt * (t + 1);
-        while (i < v.size() && (i == lo || acc + v[i].n <= target)) acc += v[i++].n;
-        if (t + 1 == nt) i = v.size();
-        th.emplace_back(copy_range, std::ref(v), lo, i);
-    }
+    size_t i = 0, acc = 0, done = 0;   // done: entries a thread has taken
+    try {
+        for (size_t t = 0; t < nt; t++) {   // contiguous ranges of about total / nt bytes
+            const size_t lo = i, target = total / nt * (t + 1);
+            while (i < v.size() && (i == lo || acc + v[i].n <= target)) acc += v[i++].n;
+            if (t + 1 == nt) i = v.size();
+            th.emplace_back(copy_range, std::ref(v), lo, i);
+            done = i;
+        }
+    } catch (const std::system_error&) {}   // no more threads to be had: this one copies what nobody took (never std::terminate)
+    if (done < v.size()) copy_range(v, done, v.size());
     for (auto& x : th) x.join();
 }
 
@@ -420,6 +441,17 @@ int swc_set_tuning(const char* key, int value) try {
     if (!strcmp(key, "bzip2_hot_cxx") && (value == 0 || value == 1)) { set_bzip2_hot_cxx(value); return SWC_OK; }
     if (!strcmp(key, "bzip2_team_walk") && value >= 0 && value <= 2) { set_bzip2_team_walk(value); return SWC_OK; }
     if (!strcmp(key, "bzip2_team_per_cu") && value >= 1 && value <= 2) { set_bzip2_team_per_cu(value); return SWC_OK; }
+    if (!strcmp(key, "pinned_keep_mib") && value >= 0) { g_pinned_keep = (size_t)value << 20; return SWC_OK; }
+    if (!strcmp(key, "result_cache_mib") && value >= 0) { g_result_cache = (size_t)value << 20; return SWC_OK; }
+    if (!strcmp(key, "pool_keep_mib") && value >= 0) {   // applies to the current device at once, to the others when they are first used
+        g_pool_keep = (size_t)value << 20;
+        int dev = 0;
+        hipMemPool_t pool;
+        uint64_t keep = g_pool_keep.load();
+        if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) (void)hipMemPoolSetAttribute(pool, hipMemPoolAttrReleaseThreshold, &keep);
+        (void)hipGetLastError();
+        return SWC_OK;
+    }
     return SWC_E_INVALID_ARGUMENT;
 } catch (...) {   // std::bad_alloc / length_error from a size taken from the input: never through the C boundary
     return SWC_E_DEVICE;
@@ -437,6 +469,28 @@ long long swc_stat(const char* key) {
 }
 
 int swc_last_phase_ms(float* ms, int cap) { return ms ? last_phase_ms(ms, cap) : 0; }
+
+// Everything the library holds for the next call goes back: the parked host results, the CALLING thread's page-locked staging
+// buffers (they are thread-local: other threads release theirs by calling this themselves, or when they end), and -- after a
+// synchronisation of the calling thread's stream -- the freed device memory in the current device's pool.
+int swc_trim(void) try {
+    {
+        std::lock_guard<std::mutex> lk(g_res_mu);
+        for (auto& e : g_res_parked) free(e.first);
+        g_res_parked.clear();
+    }
+    for (int w = 0; w < 2; w++) (void)pinned_stage(w | 4, 0);
+    int dev = 0;
+    hipMemPool_t pool;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetDefaultMemPool(&pool, dev) == hipSuccess) {
+        (void)hipStreamSynchronize(hipStreamPerThread);
+        (void)hipMemPoolTrimTo(pool, 0);
+    }
+    (void)hipGetLastError();
+    return SWC_OK;
+} catch (...) {
+    return SWC_E_DEVICE;
+}
 
 int swc_device_available(void) { return device_ready() ? 1 : 0; }
 const char* swc_version(void) { return "swc-hip 0.1 (gfx950)"; }

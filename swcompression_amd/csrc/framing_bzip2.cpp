@@ -11,6 +11,7 @@
 #include <algorithm>
 #include <map>
 #include <thread>
+#include <system_error>
 #include <vector>
 #include "framing.h"
 
@@ -58,8 +59,14 @@ void scan_block_magics(const uint8_t* d, size_t n, uint64_t from_bit, std::vecto
     std::vector<std::vector<uint64_t>> found(threads);
     std::vector<std::thread> pool;
     const size_t per = (n + threads - 1) / threads;
-    for (size_t t = 0; t < threads; t++)
-        pool.emplace_back([&, t] { scan_range(d, n, t * per, std::min(n, (t + 1) * per), from_bit, found[t]); });
+    size_t started = 0;
+    try {
+        for (size_t t = 0; t < threads; t++) {
+            pool.emplace_back([&, t] { scan_range(d, n, t * per, std::min(n, (t + 1) * per), from_bit, found[t]); });
+            started = t + 1;
+        }
+    } catch (const std::system_error&) {}   // no more threads to be had: this one scans the ranges nobody took
+    for (size_t t = started; t < threads; t++) scan_range(d, n, t * per, std::min(n, (t + 1) * per), from_bit, found[t]);
     for (auto& th : pool) th.join();
     for (auto& f : found) out.insert(out.end(), f.begin(), f.end());
 }

@@ -6,6 +6,8 @@
 //   ZlibArchive.unarchive                reference Sources/Zlib/ZlibArchive.swift:25-42
 //   ZlibHeader.init(_:)                  reference Sources/Zlib/ZlibHeader.swift:47-92
 #include <thread>
+#include <system_error>
+#include <new>
 #include <algorithm>
 #include <vector>
 #include "host_util.h"
@@ -37,14 +39,20 @@ int run_one_bounded(int codec, HostUnit& u, size_t bound) {
 
 void give(const std::vector<uint8_t>& src, uint8_t** out, size_t* out_len) {
     uint8_t* p = host_result(src.size());
+    if (!p) throw std::bad_alloc();   // (host_result is malloc: the entry points' function-try-blocks turn this into SWC_E_DEVICE)
     const size_t n = src.size(), nt = std::min<size_t>(8, n >> 24);         // a thread per 16 MB: one core copies 10 GB/s
     if (nt >= 2) {
         std::vector<std::thread> th;
         const size_t per = (n / nt + 63) & ~(size_t)63;
-        for (size_t t = 0; t < nt; t++) {
-            const size_t lo = std::min(n, t * per), hi = t + 1 == nt ? n : std::min(n, (t + 1) * per);
-            th.emplace_back([=, &src] { if (hi > lo) memcpy(p + lo, src.data() + lo, hi - lo); });
-        }
+        size_t done = 0;   // bytes whose copy a thread has taken
+        try {
+            for (size_t t = 0; t < nt; t++) {
+                const size_t lo = std::min(n, t * per), hi = t + 1 == nt ? n : std::min(n, (t + 1) * per);
+                th.emplace_back([=, &src] { if (hi > lo) memcpy(p + lo, src.data() + lo, hi - lo); });
+                done = hi;
+            }
+        } catch (const std::system_error&) {}   // no more threads to be had: this one copies the rest
+        if (done < n) memcpy(p + done, src.data() + done, n - done);
         for (auto& t : th) t.join();
     } else if (n) memcpy(p, src.data(), n);
     *out = p;
@@ -255,6 +263,9 @@ static bool bgzf_multi(const uint8_t* in, size_t in_len, uint8_t** all_out, size
         units[k].dst_cap = isize;
         total += isize;
     }
+    // (ISIZE is a field of the file: the sum of them sizes ONE host buffer before a byte is decoded.  A file whose trailers claim
+    // more than 64 x its own size -- or 64 MiB -- goes the sequential walk, which grows its result with the bytes it decodes.)
+    if (total > std::max<size_t>((size_t)64 << 20, in_len * 64)) return false;
     uint8_t* all = host_result(total);
     if (!all) return false;
     {
@@ -321,9 +332,10 @@ int swc_gzip_multi_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, si
     return SWC_E_DEVICE;
 }
 
-// Deflate.compress(data:) (Deflate+Compress.swift:22-46): the whole buffer is one unit of SWC_CODEC_DEFLATE_COMPRESS.
-// `sum_kind` != 0: a checksum of the INPUT is wanted as well (ZlibArchive.archive: Adler-32) -- computed here on the host, the
-// input never becomes a job output on the device.
+// Deflate.compress(data:) (Deflate+Compress.swift:22-46): the whole buffer is one unit of SWC_CODEC_DEFLATE_COMPRESS -- one
+// wavefront parses it, as the reference's one loop does: the engine's throughput is in the batch (swc_decode_batch with
+// SWC_CODEC_DEFLATE_COMPRESS, bench.py deflate_compress_64k), a single large buffer runs at a wavefront's pace (about 5 MB/s).
+// The checksums of the archive writers (Adler-32, CRC-32 of the INPUT) are computed on the host by their callers.
 static int deflate_compress_unit(const uint8_t* data, size_t len, HostUnit& u) {
     u.in = data; u.in_len = len;
     u.cap_hint = len + len / 8 + 16;

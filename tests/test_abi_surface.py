@@ -30,6 +30,18 @@ def test_exports_every_declared_symbol():
         assert hasattr(lib, n), "libswc_hip.so does not export %s" % n
 
 
+def test_memory_knobs_without_a_device():
+    """swc_trim() and the three limits of what the library keeps between calls work -- and do nothing harmful -- on a
+    box without a GPU: nothing is parked, nothing pinned, no pool to trim."""
+    lib = _lib.load()
+    assert lib.swc_trim() == 0
+    for key in (b"pool_keep_mib", b"pinned_keep_mib", b"result_cache_mib"):
+        assert lib.swc_set_tuning(key, 256) == 0 and lib.swc_set_tuning(key, -1) != 0
+    assert lib.swc_set_tuning(b"pool_keep_mib", 2048) == 0 and lib.swc_set_tuning(b"pinned_keep_mib", 512) == 0
+    assert lib.swc_set_tuning(b"result_cache_mib", 512) == 0
+    assert swc.trim() == 0
+
+
 def test_status_table_matches_header():
     hdr = open(os.path.join(ROOT, "include", "swc_status.h")).read()
     codes = {int(v) for v in re.findall(r"=\s*(\d+)", hdr)} - {0}

@@ -161,3 +161,21 @@ def test_zip_with_many_entries_stages_the_container_once():
     assert [n for n, _ in entries] == names
     assert all(d == p for (_, d), p in zip(entries, plains))
     assert dt < 60, "took %.1f s" % dt
+
+
+@pytest.mark.gpu
+def test_trim_gives_back_and_the_next_call_still_works():
+    """swc_trim(): after a call that left a parked result, pinned staging buffers and pooled device memory behind,
+    the trim returns SWC_OK, and the same call afterwards produces the same bytes (everything is simply acquired again)."""
+    import swcompression_amd as swc
+    from swcompression_amd import corpus
+    parts = [corpus.p_text(65536, 4242 + i) for i in range(96)]
+    data = b"".join(corpus.gzip_member(p, bgzf=True) for p in parts)     # 6 MiB of output: above the 4 MiB the result cache starts at
+    assert swc.GzipArchive.multi_unarchive(data) == parts
+    lib = swc._lib.load()
+    assert lib.swc_set_tuning(b"result_cache_mib", 0) == 0 and lib.swc_set_tuning(b"pinned_keep_mib", 0) == 0
+    assert swc.GzipArchive.multi_unarchive(data) == parts
+    assert swc.trim() == 0
+    assert swc.GzipArchive.multi_unarchive(data) == parts
+    assert lib.swc_set_tuning(b"result_cache_mib", 512) == 0 and lib.swc_set_tuning(b"pinned_keep_mib", 512) == 0
+    assert swc.trim() == 0
