@@ -60,6 +60,10 @@ WORKLOADS = {
     "lzma2_256k": dict(codec="lzma2", kind="lzma2", parts=[("text", 256)], n_units=32768, unit=262144,
                        desc="32768 x 256 KiB raw-LZMA2 units (BASELINE configs[4]; 256 distinct P-text payloads as SURVEY 8d states)",
                        kernels=["swc_lzma_kernel"], steps=10),
+    "lzma2_256k_bin": dict(codec="lzma2", kind="lzma2", parts=[("bin", 128)], n_units=8192, unit=262144,
+                           desc="8192 x 256 KiB raw-LZMA2 units of BINARY RECORDS (corpus.p_bin: all eight classes of the literal coder's context in use -- the worst "
+                                "case of the coder cache in LDS; a per_codec line next to the text of BASELINE configs[4]; 128 distinct)",
+                           kernels=["swc_lzma_kernel"], steps=3),
 }
 PAYLOAD_NOTE = ("P-text = Zipf pseudo-words, P-mix = 4 KiB pieces of text / repeated phrase / uniform random bytes (the random pieces come out as "
                 "stored blocks, literal-only sequences and incompressible chunks); system encoders (zlib 6 / liblz4 / bz2 9 / xz 6)")
@@ -217,6 +221,9 @@ def cpu_baseline(name, raw, plains, seconds):
         fn = lambda u: (lambda z: (0, u))(O.deflate_compress(u))        # (oracle/rc_deflatec.c; "output" counted = the input bytes)
     elif name == "bzip2_900k":
         fn = lambda u: O.bzip2(u)[:2]
+    elif name.startswith("lzma2_256k"):
+        db = corpus.lzma2_dict_byte(1 << 20)
+        fn = lambda u: O.lzma2(u, db)[:2]
     else:
         db = corpus.lzma2_dict_byte(1 << 20)
         fn = lambda u: O.lzma2(u, db)[:2]
@@ -278,7 +285,7 @@ def cpu_context(name, raw, plains, seconds):
         return cpu_context_lz4_compress(raw, seconds)
     if name == "deflate_compress_64k":
         return cpu_context_deflate_compress(raw, seconds)
-    codec = {"deflate64k": 1, "deflate64k_mix": 1, "lz4_4m": 2, "bzip2_900k": 3, "lzma2_256k": 4}[name]
+    codec = {"deflate64k": 1, "deflate64k_mix": 1, "lz4_4m": 2, "bzip2_900k": 3, "lzma2_256k": 4, "lzma2_256k_bin": 4}[name]
     aux = corpus.lzma2_dict_byte(1 << 20) if codec == 4 else 0
     fn = O.lib.refcpu_timed_pool
     fn.restype = C.c_double
@@ -854,7 +861,7 @@ def main():
     torch.cuda.empty_cache()
     if rank == 0 and world == 1 and args.workload == "deflate64k" and not args.no_per_codec and args.scale == 1.0:
         per = {}
-        for name in ("deflate64k_mix", "lz4_4m", "bzip2_900k", "lzma2_256k", "lz4_compress_4m", "deflate_compress_64k"):
+        for name in ("deflate64k_mix", "lz4_4m", "bzip2_900k", "lzma2_256k", "lzma2_256k_bin", "lz4_compress_4m", "deflate_compress_64k"):
             res, b, _, _ = run_workload(name, args, lib, torch, dist, world, rank, device, WORKLOADS[name]["steps"], 1, with_cpu)
             per[name] = res
             del b

@@ -127,6 +127,7 @@ struct Decoder {
     bool cached = false;        // LDS holds kCoderSlots literal coders (see kCoderSlots); lit_spill is required
     uint32_t tag0 = kNoCoder, tag1 = kNoCoder, tag2 = kNoCoder, tag3 = kNoCoder;   // the coder in each slot
     uint32_t victim = 0;        // the slot the next miss replaces
+    uint32_t mru = 0;           // the slot that was used last
     uint64_t fresh = 0;         // bit c: coder c (c < 64) has not been used since the last reset -- its cells are all 1024, nothing to load
     uint64_t fresh1 = 0, fresh2 = 0;   // the same for the second and third line of coder c (`fresh`: its first)
     bool have_model;
@@ -371,10 +372,17 @@ struct Decoder {
         {
             const uint32_t slot = (tag1 == L ? 1u : 0u) + (tag2 == L ? 2u : 0u) + (tag3 == L ? 3u : 0u);
             const bool hit = tag0 == L || slot != 0u;
-            if (same(hit)) return probs + kSlotBase + slot * 0x100;
+#ifndef SWC_LZMA_KEEP_MRU
+#define SWC_LZMA_KEEP_MRU 0   // (measured: text 612 against 621 ms, binary records 635 against 621, P-mix the same -- off)
+#endif
+            if (same(hit)) { if (SWC_LZMA_KEEP_MRU) mru = slot; return probs + kSlotBase + slot * 0x100; }
         }
-        const uint32_t v = victim;
-        victim = victim + 1 == (uint32_t)kLines ? 0u : victim + 1;
+        // (round-robin, but never the line that was used last: one scalar move on the hit path keeps the hot line -- on text the
+        // plain tree of the lower-case coder -- out of the rotation)
+        uint32_t v = victim;
+        if (SWC_LZMA_KEEP_MRU && v == mru) v = v + 1 == (uint32_t)kLines ? 0u : v + 1;
+        victim = v + 1 == (uint32_t)kLines ? 0u : v + 1;
+        if (SWC_LZMA_KEEP_MRU) mru = v;
         const uint32_t old = v == 0 ? tag0 : v == 1 ? tag1 : v == 2 ? tag2 : tag3;
         uint16_t* sp = probs + kSlotBase + v * 0x100;
         uint32_t* sp32 = (uint32_t*)sp;
