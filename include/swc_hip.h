@@ -284,7 +284,7 @@ uint32_t swc_xxh32(const uint8_t* p, size_t n, uint32_t seed);
 void swc_sha256(const uint8_t* p, size_t n, uint8_t digest[32]);
 
 void swc_free(void* p);
-/* What the library keeps between calls -- freed device memory in the device's pool (2 GiB), the calling thread's two page-locked
+/* What the library keeps between calls -- freed device memory in the device's pool (4 GiB), the calling thread's two page-locked
  * staging buffers (512 MiB each), large host results handed back through swc_free() (512 MiB in all) -- goes back to the
  * driver / the system: the parked results, the CALLING thread's staging buffers, the current device's pool.  The limits:
  * swc_set_tuning "pool_keep_mib" / "pinned_keep_mib" / "result_cache_mib" (or the environment variables SWC_POOL_KEEP_MIB /

@@ -35,7 +35,7 @@ static size_t env_mib(const char* name, size_t dflt) {
     const unsigned long long x = strtoull(v, &end, 10);
     return end && *end == 0 && x <= (1ull << 20) ? (size_t)x : dflt;
 }
-static std::atomic<size_t> g_pool_keep{env_mib("SWC_POOL_KEEP_MIB", 2048) << 20};       // a BGZF file of 4,096 members needs a workspace of 1.1 GB per call
+static std::atomic<size_t> g_pool_keep{env_mib("SWC_POOL_KEEP_MIB", 4096) << 20};       // a BGZF file of 4,096 members needs a workspace of 1.1 GB per call, an xz file of 512 blocks one of 3 GB
 static std::atomic<size_t> g_pinned_keep{env_mib("SWC_PINNED_KEEP_MIB", 512) << 20};    // per thread and direction
 static std::atomic<size_t> g_result_cache{env_mib("SWC_RESULT_CACHE_MIB", 512) << 20};  // process-wide
 
