@@ -581,6 +581,59 @@ struct Copier {
         SIMT_BEGIN(t, W) odd[t] = pend[t] && flags[t] != 0u; SIMT_END
         uint64_t pm = simt::wave_ballot<W>(pend);
         const uint64_t om = simt::wave_ballot<W>(odd);
+#ifndef SWC_LZC_BYTELANES
+#define SWC_LZC_BYTELANES 256
+#endif
+        if (SWC_LZC_BYTELANES != 0 && om == 0ull && pm != 0ull) {
+            // ---- Nothing odd among them (nine groups in ten on text): the BYTES of the matches that are left, one per lane.  A
+            // running sum of their lengths numbers the bytes; a lane finds the match its byte belongs to through a marker at
+            // the match's first byte (LDS) and a running maximum over the lanes, fetches window index and source with two
+            // cross-lane reads, and then all lanes copy their byte TOGETHER, again and again, until a round reads what the round
+            // before it read: sources lie strictly in front of their bytes and everything else in the window is final, so that
+            // state is the one and only fixed point -- the sequence the reference's append loop would have produced
+            // (Deflate.swift:216-232).  A round is a byte read, a byte write and a ballot; a match that does not depend on another
+            // one of them (five of six) is right after the first, the loop ends one round after the deepest chain.  64 bytes a pass.
+            PT<uint32_t, W> incl, offs, pk;
+            SIMT_BEGIN(t, W) incl[t] = pend[t] ? len[t] : 0u; SIMT_END
+            simt::wave_scan_incl<W>(incl);
+            const uint32_t nbytes = simt::wave_read<W>(incl, W - 1);
+            if (nbytes <= (uint32_t)SWC_LZC_BYTELANES) {
+                SIMT_BEGIN(t, W)
+                    offs[t] = incl[t] - (pend[t] ? len[t] : 0u);
+                    pk[t] = wm[t] | (si[t] << 16);          // (both are window indices below 64 KiB: nothing here is far)
+                SIMT_END
+                for (uint32_t c0 = 0; c0 < nbytes; c0 += (uint32_t)W) {
+                    PT<uint32_t, W> mk, ga, gb, dsti, srci, prev, val;
+                    PT<bool, W> act, chg;
+                    SIMT_BEGIN(t, W) l->pmap[t] = 0u; SIMT_END_WAVE
+                    SIMT_BEGIN(t, W)
+                        if (pend[t] && offs[t] < c0 + (uint32_t)W && offs[t] + len[t] > c0) l->pmap[(offs[t] > c0 ? offs[t] : c0) - c0] = (uint32_t)t + 1u;
+                    SIMT_END_WAVE
+                    SIMT_BEGIN(t, W) mk[t] = l->pmap[t]; SIMT_END
+                    simt::wave_scan_max_incl<W>(mk);
+                    SIMT_BEGIN(t, W) mk[t] = mk[t] ? mk[t] - 1u : 0u; SIMT_END
+                    simt::wave_gather<W>(ga, pk, mk);
+                    simt::wave_gather<W>(gb, offs, mk);
+                    SIMT_BEGIN(t, W)
+                        const uint32_t j = c0 + (uint32_t)t, k = j - gb[t];
+                        act[t] = j < nbytes;
+                        dsti[t] = (ga[t] & 0xFFFFu) + k;
+                        srci[t] = (ga[t] >> 16) + k;
+                        prev[t] = 0x100u;
+                    SIMT_END
+                    for (;;) {
+                        SIMT_BEGIN(t, W) val[t] = act[t] ? (uint32_t)B[srci[t]] : 0x100u; SIMT_END_WAVE
+                        SIMT_BEGIN(t, W)
+                            if (act[t]) B[dsti[t]] = (uint8_t)val[t];
+                            chg[t] = val[t] != prev[t];
+                            prev[t] = val[t];
+                        SIMT_END_WAVE
+                        if (simt::wave_ballot<W>(chg) == 0ull) break;
+                    }
+                }
+                return;
+            }
+        }
         if ((uint32_t)simt::popc64(pm & ~om) > kSeqMax) {
             // Many short ones: most of them do NOT depend on each other -- the source of a match that reaches into its group
             // usually is made of literals and of matches that are final by now.  A bitmap of the group's output marks the bytes
