@@ -108,6 +108,12 @@ SWC_HD void copy_run(uint8_t* d, const uint8_t* s, uint32_t n) {
 // R8: records of EIGHT bytes -- the 32-bit record and, in the upper dword, the offset of its literal run from `lits`, which then
 // is not a dense literal stream but the compressed input itself: LZ4 keeps its literals byte-aligned in the block (LZ4.swift:
 // 364-366), so the parse kernel writes no literal stream at all and the copier fetches a run where the encoder left it.
+#ifndef SWC_LZC_FAKE
+#define SWC_LZC_FAKE 0   // (timing experiments only, wrong output: 1 = the literal loads, 2 = the far loads, 3 = both read one hot place)
+#endif
+#ifndef SWC_LZC_FLUSH_EARLY
+#define SWC_LZC_FLUSH_EARLY 1
+#endif
 template <typename CFG, typename P, bool R8 = false>
 struct Copier {
     static constexpr uint32_t WIN = CFG::kWin, SPAN = CFG::kSpan;
@@ -140,7 +146,7 @@ struct Copier {
     // has as good as always landed when the group AHEAD of its match is being copied.
     // (The flush watermark lies less than 1,040 bytes behind the position after every group, `landed` one group behind that:
     // a source that is asked for -- kLongLen bytes at most, kKeep and more behind its match -- has always landed.)
-    static_assert(kKeep >= kLongLen + 1040u + kSpanMax + 128u, "far sources that are asked for ahead must have landed");
+    static_assert(kKeep >= kLongLen + 1040u + (SWC_LZC_FLUSH_EARLY ? 2u : 1u) * kSpanMax + 128u, "far sources that are asked for ahead must have landed");
     enum : uint32_t { kFlagCoop = 1u, kFlagFar = 2u };
 
     L* l;
@@ -181,7 +187,9 @@ struct Copier {
     }
     // all of this wave's loads have returned and all of its stores have arrived in memory
     SWC_D void drain() {
+#if !defined(SWC_LZC_NODRAIN)   // (timing experiments only: the output may be wrong)
         simt::vmem_fence();
+#endif
         landed = fv;
     }
     // The loads of a path that is rarely taken (all lanes on one long run, a far source nobody asked for ahead) are waited for
@@ -456,7 +464,7 @@ struct Copier {
             SIMT_BEGIN(t, W)
                 uint32_t li, le, di;
                 unpack(g.rec[t], li, le, di);
-                const bool ask = runs && (uint32_t)t < ntake && li != 0u && li <= kLongLit;
+                const bool ask = !SWC_LZC_FAKE && runs && (uint32_t)t < ntake && li != 0u && li <= kLongLit;
                 // (nothing wanted: the group's first literal, or the byte behind the last: it exists; R8: the block's first bytes)
                 const uint32_t o0 = ask ? (R8 ? g.loff[t] : (g.x[t] >> 16) - li) : 0u;
                 const uint32_t last = (li > 8u ? li : 8u) - 8u;
@@ -485,7 +493,7 @@ struct Copier {
                 uint32_t li, le, di;
                 unpack(g.rec[t], li, le, di);
                 const int32_t srel = (int32_t)((g.x[t] & 0xFFFFu) - le - di);           // my source starts here, relative to the group's first byte
-                const bool ask = known && (uint32_t)t < ntake && le != 0u && (int32_t)wpn + srel < 0 && le <= kLongLen && di >= le && srel + (int32_t)le <= lim;
+                const bool ask = !(SWC_LZC_FAKE & 2) && known && (uint32_t)t < ntake && le != 0u && (int32_t)wpn + srel < 0 && le <= kLongLen && di >= le && srel + (int32_t)le <= lim;
                 const uint32_t o0 = kBack + (uint32_t)srel;
                 const uint32_t last = (le > 8u ? le : 8u) - 8u;
 #pragma unroll
@@ -754,6 +762,12 @@ struct Copier {
             // Everything asked for during the last iteration -- the next records, far sources, literals -- is here, and its
             // stores have arrived (an iteration's loads have the whole of the previous group's copies to come back).
             drain();
+#if SWC_LZC_FLUSH_EARLY
+            // finished bytes leave for HBM a KiB at a time (whole-wave stores), long before they leave the window -- and at the TOP of
+            // the iteration: the drain of the next one then finds stores that have had a whole group's copies to arrive, not stores
+            // issued a moment ago (a wave spent two fifths of its time waiting, most of it there)
+            if ((P)A + rpos - fv >= 1024u) flush((P)A + rpos, false);
+#endif
             cur = nxt;
             const uint32_t nbase = base + cur.ntake;
             more = nbase < nrec;
@@ -771,8 +785,10 @@ struct Copier {
             base = nbase;
             rpos += cur.span;
             lbase += cur.litspan;
+#if !SWC_LZC_FLUSH_EARLY
             // finished bytes leave for HBM a KiB at a time (whole-wave stores), long before they leave the window
             if ((P)A + rpos - fv >= 1024u) flush((P)A + rpos, false);
+#endif
         }
         drain();
         flush((P)A + rpos, true);
@@ -795,7 +811,7 @@ struct Cfg {
 #ifndef SWC_LZC_WIN
 #define SWC_LZC_WIN 6144
 #define SWC_LZC_SPAN 1024
-#define SWC_LZC_KEEP 2560
+#define SWC_LZC_KEEP 3328
 #endif
 #ifndef SWC_LZC_LITP
 #define SWC_LZC_LITP 2
@@ -804,7 +820,7 @@ using CfgDeflate = Cfg<SWC_LZC_WIN, SWC_LZC_SPAN, SWC_LZC_KEEP, SWC_LZC_LITP>;
 #ifndef SWC_LZC4_WIN
 #define SWC_LZC4_WIN 9216
 #define SWC_LZC4_SPAN 2048
-#define SWC_LZC4_KEEP 3328
+#define SWC_LZC4_KEEP 5376
 #endif
 #ifndef SWC_LZC4_LITP
 #define SWC_LZC4_LITP 4

@@ -9,7 +9,7 @@ fi
 cp $O/bench_full.json $P/${TAG}_bench_full.json 2>/dev/null
 cp $O/bench_line.json $P/${TAG}_bench_line.json 2>/dev/null
 cp $O/pytest_gpu.log $P/${TAG}_pytest_gpu.log 2>/dev/null
-for W in deflate64k lz4_4m bzip2_900k lzma2_256k deflate64k_mix lz4_compress_4m deflate_compress_64k; do
+for W in deflate64k lz4_4m bzip2_900k lzma2_256k deflate64k_mix lzma2_256k_bin lz4_compress_4m deflate_compress_64k; do
   cp $O/kernel_stats_$W.txt $P/${TAG}_kernel_stats_$W.txt 2>/dev/null
   cp $O/${W}_traffic.json $P/${TAG}_${W}_traffic.json 2>/dev/null
   cp $O/sq_counters_$W.txt $P/${TAG}_sq_counters_$W.txt 2>/dev/null

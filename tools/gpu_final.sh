@@ -4,7 +4,8 @@
 # passes.  Usage: gpu_final.sh <tag> [parts...]   parts: tests bench trace pmc sq bzc (default: all but bzc)
 # Outputs under gpurun_out/<tag>/; tools/collect_profiles.sh <tag> copies what is to be judged into profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}; TAG=${1:-final}; shift; PARTS=${@:-tests bench trace pmc sq}; O=$R/gpurun_out/$TAG; mkdir -p $O; cd $R
-WL=${WL:-"deflate64k lz4_4m bzip2_900k lzma2_256k"}; XWL=${XWL-"deflate64k_mix lz4_compress_4m deflate_compress_64k"}
+WL=${WL:-"deflate64k lz4_4m bzip2_900k lzma2_256k"}; XWL=${XWL-"deflate64k_mix lzma2_256k_bin lz4_compress_4m deflate_compress_64k"}
+PWL=${PWL-"deflate64k_mix lz4_compress_4m deflate_compress_64k"}   # PMC traffic for these too (the encode workloads: VERDICT r5)
 for P in $PARTS; do case $P in
 tests)
   timeout 1500 python -m pytest tests -m gpu -x -q > $O/pytest_gpu.log 2>&1; echo "pytest rc=$?"; tail -3 $O/pytest_gpu.log
@@ -27,7 +28,7 @@ trace)
     python tools/rocpd_summary.py $O/trace_$W/bench_results.db > $O/kernel_stats_$W.txt 2>&1; head -8 $O/kernel_stats_$W.txt
   done ;;
 pmc)
-  for W in $WL; do bash tools/pmc_bench.sh $W $TAG > $O/pmc_$W.log 2>&1; cp gpurun_out/pmc_bench_${TAG}_$W/traffic.json $O/${W}_traffic.json 2>/dev/null; python - <<PY
+  for W in $WL $PWL; do bash tools/pmc_bench.sh $W $TAG > $O/pmc_$W.log 2>&1; cp gpurun_out/pmc_bench_${TAG}_$W/traffic.json $O/${W}_traffic.json 2>/dev/null; python - <<PY
 import json
 try:
     d = json.load(open("$O/${W}_traffic.json")); print("$W traffic GB", round(d["hbm_bytes_per_launch"] / 1e9, 1), "fetch", round(d["fetch_bytes_corrected"] / 1e9, 1), "write", round(d["write_bytes"] / 1e9, 1))
