@@ -47,8 +47,10 @@ typedef enum swc_codec {
                               dict_len = length of the prefix (dictionary / previous block), out_cap >= n + n / 255 + 16;
                               A valid block for the same bytes, not the reference's bytes            */
     SWC_CODEC_DEFLATE_COMPRESS = 8 /* ENCODE, one raw Deflate stream -- Deflate.compress(data:) Deflate+Compress.swift:22-213: one
-                              stored or static-Huffman block over a greedy LZ77 parse; out_cap >= n + n / 8 + 16, out 4-byte
-                              aligned; A valid stream for the same bytes, not the reference's bytes   */
+                              stored or static-Huffman block over a greedy LZ77 parse; out_cap >= n + n / 8 + 32, out 4-byte
+                              aligned; A valid stream for the same bytes, not the reference's bytes.  aux bit 0:
+                              the unit is a SEGMENT of a longer stream -- BFINAL clear, an empty stored block behind the block, so
+                              that the outputs of consecutive segments, the last one with aux = 0, are one stream           */
 } swc_codec;
 
 typedef struct swc_job {
@@ -143,8 +145,8 @@ int swc_lz4_compress(const uint8_t* data, size_t len, int independent_blocks, in
                      int content_size, size_t block_size, const uint8_t* dict, size_t dict_len, int64_t dict_id,
                      uint8_t** out, size_t* out_len);
 /* Deflate.compress(data:) Deflate+Compress.swift:22-46: one stored or static-Huffman block, compressed on the device
- * (SWC_CODEC_DEFLATE_COMPRESS; one wavefront per buffer -- the throughput is in batches of buffers, a single large one
- * runs at a wavefront's pace).  ZlibArchive.archive(data:) ZlibArchive.swift:54-70: 0x78 0xDA, that stream, Adler-32 of the
+ * (SWC_CODEC_DEFLATE_COMPRESS; one wavefront per buffer of up to 1 MiB; a larger one is cut into segments of 256 KiB that
+ * are compressed in one launch and come out as non-final static blocks joined by empty stored blocks -- one Deflate stream).  ZlibArchive.archive(data:) ZlibArchive.swift:54-70: 0x78 0xDA, that stream, Adler-32 of the
  * input (big endian; computed on the host). */
 int swc_deflate_compress(const uint8_t* data, size_t len, uint8_t** out, size_t* out_len);
 int swc_zlib_archive(const uint8_t* data, size_t len, uint8_t** out, size_t* out_len);

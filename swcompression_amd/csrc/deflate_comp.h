@@ -95,6 +95,7 @@ struct Compressor {
     uint64_t obits;      // bits of the stream so far (keeps counting past the capacity)
     uint64_t odw;        // dwords that have left the stage for `out`
     uint32_t fill;       // bits in the stage
+    bool nonfinal = false;   // a segment of a larger buffer: BFINAL clear, an empty stored block behind the block (job.aux bit 0)
 
     SWC_D static void lds_or(uint32_t* p, uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -189,8 +190,9 @@ struct Compressor {
                 last[t] = ((valid >> t) & 1ull) != 0ull && (t == N - 1 || (m >> (t + 1)) == 0ull);
             SIMT_END
         };
-        // block header: BFINAL = 1, BTYPE = 01 (Deflate+Compress.swift:103-104)
-        SIMT_BEGIN(t, N) code[t] = t == 0 ? 3u : 0u; nb[t] = t == 0 ? 3u : 0u; SIMT_END
+        // block header: BFINAL = 1, BTYPE = 01 (Deflate+Compress.swift:103-104); a SEGMENT of a larger buffer (`nonfinal`,
+        // framing_deflate.cpp) leaves BFINAL clear
+        SIMT_BEGIN(t, N) code[t] = t == 0 ? (nonfinal ? 2u : 3u) : 0u; nb[t] = t == 0 ? 3u : 0u; SIMT_END
         emit(code, nb);
         uint64_t pos = 0, anchor = 0;
         const uint64_t plimit = n >= 3 ? n - 3 : 0;     // the last position a match may start at (:155: i < endIndex - 2)
@@ -243,6 +245,16 @@ struct Compressor {
             pos = anchor > pos + N ? anchor : pos + N;
         }
         sequence(anchor, n - anchor, 0, 0, true);   // the rest as literals, the end-of-block code (:198-207, :135)
+        if (nonfinal) {
+            // an empty stored block behind it (000, the padding to the byte, LEN = 0, NLEN = 0xFFFF): the segment ends on a byte,
+            // and the segments of a buffer are one Deflate stream when they are put one behind the other
+            const uint32_t pad = (8u - (uint32_t)((obits + 3u) & 7u)) & 7u;
+            SIMT_BEGIN(t, N)
+                code[t] = t == 3 ? 0xFFFFu : 0u;
+                nb[t] = t == 0 ? 3u : t == 1 ? pad : t == 2 || t == 3 ? 16u : 0u;
+            SIMT_END
+            emit(code, nb);
+        }
         flush(true);
     }
 };
@@ -257,6 +269,7 @@ SWC_D void deflate_compress_job(Job& job, Lds* lds) {
     c.out = (gptr)job.out;
     c.cap = job.out_cap;
     c.l = lds;
+    c.nonfinal = (job.aux & 1) != 0;
     c.run();
     uint64_t size = (c.obits + 7) >> 3;
     // Deflate+Compress.swift:30-45: stored if not larger than the static block and the length fits 16 bits
@@ -268,7 +281,7 @@ SWC_D void deflate_compress_job(Job& job, Lds* lds) {
         const uint64_t cap = c.cap;
         SIMT_BEGIN(t, N)
             if (t == 0) {
-                const uint8_t h[5] = {1, (uint8_t)(nn & 0xFFu), (uint8_t)(nn >> 8), (uint8_t)(nl & 0xFFu), (uint8_t)(nl >> 8)};
+                const uint8_t h[5] = {(uint8_t)(c.nonfinal ? 0 : 1), (uint8_t)(nn & 0xFFu), (uint8_t)(nn >> 8), (uint8_t)(nl & 0xFFu), (uint8_t)(nl >> 8)};
                 for (uint32_t k = 0; k < 5u; k++) if (k < cap) o[k] = h[k];
             }
             for (uint32_t i = (uint32_t)t; i < nn; i += (uint32_t)N) if (5ull + i < cap) o[5u + i] = s[i];

@@ -332,11 +332,42 @@ int swc_gzip_multi_unarchive(const uint8_t* in, size_t in_len, uint8_t** out, si
     return SWC_E_DEVICE;
 }
 
-// Deflate.compress(data:) (Deflate+Compress.swift:22-46): the whole buffer is one unit of SWC_CODEC_DEFLATE_COMPRESS -- one
-// wavefront parses it, as the reference's one loop does: the engine's throughput is in the batch (swc_decode_batch with
-// SWC_CODEC_DEFLATE_COMPRESS, bench.py deflate_compress_64k), a single large buffer runs at a wavefront's pace (about 5 MB/s).
-// The checksums of the archive writers (Adler-32, CRC-32 of the INPUT) are computed on the host by their callers.
+// Deflate.compress(data:) (Deflate+Compress.swift:22-46): a buffer of up to 1 MiB is one unit of SWC_CODEC_DEFLATE_COMPRESS -- one
+// wavefront parses it, as the reference's one loop does (a wavefront's pace is about 5 MB/s: the engine's throughput is in the
+// number of units of a launch).  The checksums of the archive writers (Adler-32, CRC-32 of the INPUT) are computed on the host by
+// their callers.
+// A LARGE buffer is cut into segments of kCompressSegment bytes, one wavefront each, all in one launch: every segment but the
+// last comes back as a non-final static block followed by an empty stored block (so that it ends on a byte: job.aux bit 0,
+// deflate_comp.h), and the segments one behind the other are one Deflate stream that the reference's decoder reads block by
+// block (Deflate.swift:30-249).  What is given up: matches across a segment's start (under 0.1 % of the size at 256 KiB), and
+// the reference's "one block" shape -- which SURVEY 8f-4 does not ask to keep.  Buffers of up to kCompressWhole bytes stay ONE
+// block, as the reference writes them.
+constexpr size_t kCompressWhole = (size_t)1 << 20, kCompressSegment = (size_t)256 << 10;
 static int deflate_compress_unit(const uint8_t* data, size_t len, HostUnit& u) {
+    if (len > kCompressWhole) {
+        const size_t nseg = (len + kCompressSegment - 1) / kCompressSegment;
+        std::vector<HostUnit> segs(nseg);
+        for (size_t k = 0; k < nseg; k++) {
+            HostUnit& s = segs[k];
+            const size_t lo = k * kCompressSegment, n = std::min(kCompressSegment, len - lo);
+            s.in = data + lo; s.in_len = n;
+            s.base = data; s.base_len = len;            // one staged copy of the buffer, every segment a sub-range of it
+            s.cap_hint = n + n / 8 + 32;
+            s.cap_exact = true;
+            s.aux = k + 1 < nseg ? 1 : 0;
+        }
+        const int st = run_units(SWC_CODEC_DEFLATE_COMPRESS, segs);
+        if (st != SWC_OK) return st;
+        size_t total = 0;
+        for (const HostUnit& s : segs) { if (s.status != SWC_OK) { u.status = s.status; return SWC_OK; } total += s.size(); }
+        u.out.clear();
+        u.out.reserve(total);
+        for (const HostUnit& s : segs) u.out.insert(u.out.end(), s.data(), s.data() + s.size());
+        u.out_size = u.out.size();
+        u.in_consumed = len;
+        u.status = SWC_OK;
+        return SWC_OK;
+    }
     u.in = data; u.in_len = len;
     u.cap_hint = len + len / 8 + 16;
     u.cap_exact = true;

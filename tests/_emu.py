@@ -164,10 +164,11 @@ def lz4_compress(blocks, prefixes=None, caps=None):
     return run_batch("emu_lz4_compress", ins, caps, extra=[len(p) for p in prefixes])
 
 
-def deflate_compress(bufs, caps=None):
-    """Deflate compression (deflate_comp.h): returns list of (status, compressed bytes, in_consumed, out_len)."""
-    caps = caps or [len(b) + len(b) // 8 + 16 for b in bufs]
-    return run_batch("emu_deflate_compress", [bytes(b) for b in bufs], caps)
+def deflate_compress(bufs, caps=None, aux=None):
+    """Deflate compression (deflate_comp.h): returns list of (status, compressed bytes, in_consumed, out_len).  aux[i] & 1: unit i
+    is a segment of a longer stream (BFINAL clear, an empty stored block behind its block)."""
+    caps = caps or [len(b) + len(b) // 8 + 32 for b in bufs]
+    return run_batch("emu_deflate_compress", [bytes(b) for b in bufs], caps, aux=aux)
 
 
 def bzip2_compress(data, block_size=1):

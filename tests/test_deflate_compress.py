@@ -94,6 +94,31 @@ def test_capacity_reports_required_size():
     assert st == 901 and n == len(full[1])
 
 
+def test_segments_of_a_longer_stream_join_into_one():
+    """job.aux bit 0 (what swc_deflate_compress does with a buffer of more than 1 MiB): every segment but the last is a NON-FINAL
+    block followed by an empty stored block, so it ends on a byte, and the segments one behind the other are one Deflate stream --
+    for the reference's decoder restated (Deflate.swift:30-249: block after block until BFINAL) and for zlib.  Segments of every
+    kind: text, incompressible (a stored block when short enough), empty, a few bytes (every padding 0 .. 7 comes up)."""
+    rnd = random.Random(3)
+    segs = [corpus.p_text(70000, 1), corpus.p_rand(3000, 2), b"", b"a", b"ab", corpus.p_text(333, 3), corpus.p_rep(5000, 4), corpus.p_rand(70000, 5)]
+    segs += [corpus.p_text(rnd.randint(1, 400), 10 + i) for i in range(24)] + [corpus.p_text(4097, 6)]
+    res = E.deflate_compress(segs, aux=[1] * (len(segs) - 1) + [0])
+    stream = b""
+    for (st, z, _, zl), s in zip(res[:-1], segs[:-1]):
+        assert st == 0 and zl == len(z) and z[0] & 1 == 0                                        # non-final
+        if (z[0] >> 1) & 3 == 1:
+            assert z[-4:] == b"\x00\x00\xff\xff"                                                 # static: the empty stored block behind it (LEN = 0, NLEN = 0xFFFF)
+        else:
+            assert (z[0] >> 1) & 3 == 0 and len(z) == 5 + len(s)                                   # stored: ends on a byte as it is
+        stream += z
+    assert res[-1][0] == 0 and res[-1][1][0] & 1 == 1
+    stream += res[-1][1]
+    plain = b"".join(segs)
+    assert zlib.decompress(stream, -15) == plain
+    st, out, used = O.deflate(stream)
+    assert (st, out) == (0, plain) and used == len(stream)
+
+
 # ---------------------------------------------------------------------------------------------------------------------- GPU tier
 @pytest.mark.gpu
 def test_gpu_single_shot_and_zlib_archive():
@@ -105,6 +130,26 @@ def test_gpu_single_shot_and_zlib_archive():
         a = swc.ZlibArchive.archive(x)
         assert a[:2] == bytes([120, 218]) and zlib.decompress(a) == x and swc.ZlibArchive.unarchive(a) == x
         assert O.zlib_unarchive(a)[:2] == (0, x)
+
+
+@pytest.mark.gpu
+def test_gpu_large_buffer_in_segments():
+    """swc_deflate_compress on more than 1 MiB: segments of 256 KiB in one launch, one stream out (one wavefront took a
+    100 MB buffer tens of seconds)."""
+    import time
+    import swcompression_amd as swc
+    x = corpus.p_text(5 * (1 << 20) + 12345, 77) + corpus.p_rand(300000, 78) + corpus.p_text(1 << 20, 79)
+    t0 = time.perf_counter()
+    z = swc.Deflate.compress(x)
+    dt = time.perf_counter() - t0
+    assert z[0] & 1 == 0 and len(z) < len(x) * 0.62                      # several blocks; text still halves
+    assert zlib.decompress(z, -15) == x
+    st, out, used = O.deflate(z)
+    assert (st, out) == (0, x) and used == len(z)
+    assert swc.Deflate.decompress(z) == x
+    assert dt < 1.0, dt                                                   # (one wavefront over 6.5 MB would take more than a second)
+    a = swc.ZlibArchive.archive(x)
+    assert zlib.decompress(a) == x
 
 
 @pytest.mark.gpu
