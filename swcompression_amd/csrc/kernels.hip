@@ -190,7 +190,7 @@ __device__ __forceinline__ void lz_copy_body(const Job* __restrict__ jobs, uint3
 #define SWC_LZC_WAVES 6
 #endif
 #ifndef SWC_LZC4_WAVES
-#define SWC_LZC4_WAVES 4
+#define SWC_LZC4_WAVES 5
 #endif
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_LZC_WAVES, SWC_LZC_WAVES))) void swc_lz_copy_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, const uint32_t* __restrict__ order) {
     lz_copy_body<lzc::CfgDeflate>(jobs, n, wm, order);

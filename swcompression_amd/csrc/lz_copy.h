@@ -804,10 +804,10 @@ struct Cfg {
 };
 
 // The configurations the library ships (kernels.hip: the waves per CU each is launched with; profiles/r05_experiments.txt and
-// r06_experiments.txt: the sweeps).  Deflate: 6 KiB window of which a slide keeps 2.5 KiB (a slide costs more than the far
+// r06_experiments.txt: the sweeps).  Deflate: 6 KiB window of which a slide keeps 3.25 KiB (a slide costs more than the far
 // matches it avoids: a far source is four loads that are issued anyway), groups of up to 1 KiB, literal runs of up to 16 bytes
 // per lane -- 6,424 bytes of LDS per wave, 24 waves per CU.  LZ4 (offsets up to 65,535, 4 MiB blocks, longer
-// literal runs): 9 KiB / 3.25 KiB kept / 2 KiB groups / runs of up to 32 bytes -- 9,496 bytes, 16 waves per CU.
+// literal runs): 7 KiB / 3.25 KiB kept / 1 KiB groups / runs of up to 32 bytes -- 7,448 bytes and 81 VGPRs, 20 waves per CU.
 #ifndef SWC_LZC_WIN
 #define SWC_LZC_WIN 6144
 #define SWC_LZC_SPAN 1024
@@ -818,9 +818,9 @@ struct Cfg {
 #endif
 using CfgDeflate = Cfg<SWC_LZC_WIN, SWC_LZC_SPAN, SWC_LZC_KEEP, SWC_LZC_LITP>;
 #ifndef SWC_LZC4_WIN
-#define SWC_LZC4_WIN 9216
-#define SWC_LZC4_SPAN 2048
-#define SWC_LZC4_KEEP 5376
+#define SWC_LZC4_WIN 7168
+#define SWC_LZC4_SPAN 1024
+#define SWC_LZC4_KEEP 3328
 #endif
 #ifndef SWC_LZC4_LITP
 #define SWC_LZC4_LITP 4
