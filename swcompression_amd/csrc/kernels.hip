@@ -177,17 +177,22 @@ __global__ __launch_bounds__(kInflateResolveThreads) void swc_lz_resolve_kernel(
 //   LZ4      8 KiB window, groups of up to 2 KiB, 16 waves per CU: offsets reach 65,535 bytes back and 4 MiB blocks have long
 //            literal runs -- the smaller window is 1-8 % slower there.
 // The 16 KiB variant (8 waves per CU) is kept for comparison runs.
-template <typename CFG, bool R8 = false>
+template <typename CFG, int RM = 0>
 __device__ __forceinline__ void lz_copy_body(const Job* __restrict__ jobs, uint32_t n, const WsMap& wm, const uint32_t* __restrict__ order) {
     __shared__ __attribute__((aligned(16))) lzc::Lds<CFG::kWin> lds;
     uint32_t g = job_of(order, blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];
     if (job.dict != nullptr) return;   // (LZ4 blocks with a dictionary prefix were decoded by the lane kernel)
-    lzc::copy_job<CFG, R8>(job, wm.area(g), wm.bytes(g), &lds);
+    lzc::copy_job<CFG, RM>(job, wm.area(g), wm.bytes(g), &lds);
 }
 #ifndef SWC_LZC_WAVES
 #define SWC_LZC_WAVES 6
+#endif
+// how the LZ4 parse tells the copy kernel where a record's literals lie in the block (lz4_wave.h): 1 = eight-byte records with the
+// offset in the upper dword, 2 = four-byte records, the offset derived by a running sum, anchors where the rule breaks
+#ifndef SWC_LZ4_RECORD_MODE
+#define SWC_LZ4_RECORD_MODE 2
 #endif
 #ifndef SWC_LZC4_WAVES
 #define SWC_LZC4_WAVES 5
@@ -196,7 +201,7 @@ __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_LZC_WAVE
     lz_copy_body<lzc::CfgDeflate>(jobs, n, wm, order);
 }
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_LZC4_WAVES, SWC_LZC4_WAVES))) void swc_lz4_copy_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, const uint32_t* __restrict__ order) {
-    lz_copy_body<lzc::CfgLz4, true>(jobs, n, wm, order);   // (eight-byte records: the literals come from the block itself)
+    lz_copy_body<lzc::CfgLz4, SWC_LZ4_RECORD_MODE>(jobs, n, wm, order);   // (the literals come from the block itself)
 }
 __global__ __launch_bounds__(64) void swc_lz_copy16_kernel(const Job* __restrict__ jobs, uint32_t n, WsMap wm, const uint32_t* __restrict__ order) {
     lz_copy_body<lzc::CfgWide>(jobs, n, wm, order);
@@ -288,14 +293,14 @@ __global__ __launch_bounds__(64) void swc_lz4_lane_kernel(Job* __restrict__ jobs
 #endif
 // R8: eight-byte records that say where their literals lie in the block, no literal stream (for the wave copy kernel);
 // otherwise the records and the dense literal stream swc_lz4_resolve_kernel reads
-template <bool R8>
+template <int RM>
 __global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(SWC_LZ4_PARSE_WAVES))) void swc_lz4_parse_kernel(Job* __restrict__ jobs, uint32_t n, WsMap wm, uint64_t* prof, const uint32_t* __restrict__ order) {
     uint32_t g = job_of(order, blockIdx.x, n);
     if (g >= n) return;
     Job job = jobs[g];
     if (job.dict != nullptr) return;
     __shared__ __attribute__((aligned(16))) uint8_t stage[lz4w::kStageLds];
-    lz4w::lz4_parse_job<kWave, R8>(job, wm.area(g), wm.bytes(g), (int)threadIdx.x, stage, prof ? prof + 32 * (size_t)g : nullptr);
+    lz4w::lz4_parse_job<kWave, RM>(job, wm.area(g), wm.bytes(g), (int)threadIdx.x, stage, prof ? prof + 32 * (size_t)g : nullptr);
     if (threadIdx.x == 0) {
         jobs[g].out_len = job.out_len;
         jobs[g].in_consumed = job.in_consumed;
@@ -331,8 +336,8 @@ hipError_t launch_lz4(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_
     g_pt.mark(stream);
     const WsMap wm{(uint8_t*)ws, stride, ws_off};
     const int copier = copier_for(n);
-    if (copier) hipLaunchKernelGGL(swc_lz4_parse_kernel<true>, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
-    else hipLaunchKernelGGL(swc_lz4_parse_kernel<false>, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
+    if (copier) hipLaunchKernelGGL(swc_lz4_parse_kernel<SWC_LZ4_RECORD_MODE>, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
+    else hipLaunchKernelGGL(swc_lz4_parse_kernel<0>, dim3((unsigned)n), block, 0, stream, jobs, (uint32_t)n, wm, g_prof, order);
     g_pt.mark(stream);
     if (copier) launch_lz_copy(copier, true, jobs, n, wm, order, stream);
     else hipLaunchKernelGGL(swc_lz4_resolve_kernel, dim3((unsigned)n), dim3(lz4w::kResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof, order);

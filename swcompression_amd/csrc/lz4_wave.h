@@ -155,9 +155,29 @@ SWC_HD int top64(uint64_t m) {   // index of the highest set bit, m != 0
 // R8: records of EIGHT bytes -- the 32-bit record of lz_resolve.h and, in the upper dword, the offset of its literal run in the
 // block (LZ4 literals are byte-aligned in the input, LZ4.swift:364-366): no literal is copied anywhere by the parse, the copy
 // kernel (lz_copy.h) fetches a run from the block itself.  The area then holds header | records | scratch rows.
-template <int W, bool R8 = false>
+// RM (record mode): 0 = four-byte records + the dense literal stream (swc_lz4_resolve_kernel); 1 = R8; 2 = four-byte records whose
+// literal offsets the copier DERIVES: in the short form the rounds take (at most one extension byte per length) a sequence is
+// 3 + [lit >= 15] + [mlen >= 19] bytes and its literals, so the start S of every sequence is a running sum over the records and
+// its literals lie at S + 1 + [lit >= 15] -- no second dword per record (3.1 G records for 34 GB of text: 12.5 GB written twice by
+// the parse and read once by the copy).  Where the rule does not hold -- the records of a sequence in long form, a literal run cut
+// into literal-only records (those continue at S, S += lit), what follows them -- the parse, which SIMULATES the copier's sum as it
+// pushes records, writes an ANCHOR (record index, S) into the area the literal stream would have had; the copier starts a new
+// group at an anchor.  An anchor stands for 128 bytes of output or more, so cap / 8 entries are room enough.
+template <int W, int RM = 0>
 struct Parser {
+    static constexpr bool R8 = RM == 1, R4 = RM == 2;
     Wave<W> w;
+    SWC_AS_GLOBAL uint32_t* anc = nullptr;   // R4: anchors (record index, S) in the order of the records
+    uint32_t nanc = 0, max_anc = 0;
+    uint64_t s_pred = 0;                     // R4: where the copier's running sum stands (the start of the next sequence by its rule)
+    SWC_D void anchor(uint32_t rec, uint64_t S) {
+        if (nanc < max_anc && w.lane == 0) { anc[2u * nanc] = rec; anc[2u * nanc + 1u] = (uint32_t)S; }
+        nanc++;
+        s_pred = S;
+    }
+    // the copier's rule (lz_copy.h: Copier::seq_bytes): bytes from the start of a record's sequence to the start of the next
+    SWC_HD static uint32_t seq_bytes(uint32_t li, uint32_t le) { return le ? 3u + li + (li >= 15u ? 1u : 0u) + (le >= 19u ? 1u : 0u) : li; }
+    SWC_HD static uint32_t lit_skip(uint32_t li, uint32_t le) { return le ? 1u + (li >= 15u ? 1u : 0u) : 0u; }
     gcptr in;
     uint64_t n;          // compressed bytes
     uint64_t cap;
@@ -241,6 +261,13 @@ struct Parser {
                 else rbuf[rb_n] = v;
             }
             rb_n++;
+            if (R4) {   // where would the copier look for this record's literals?  An anchor if not where they are.
+                const uint32_t le = (v >> 7) & 511u;
+                const uint32_t li = (v & 127u) + (le ? 0u : (v >> 16) << 7);
+                const uint32_t skip = lit_skip(li, le);
+                if (li != 0u && s_pred + skip != from) anchor(nrec, from - skip);
+                s_pred += seq_bytes(li, le);
+            }
         }
         nrec++;
     }
@@ -249,7 +276,7 @@ struct Parser {
     SWC_D void copy_literals(uint64_t from, uint64_t cnt) {
         uint64_t keep = pos >= cap ? 0 : (cap - pos < cnt ? cap - pos : cnt);
         if (keep == 0) return;
-        if (R8) { nlit += keep; return; }   // (they stay where they are: the record says where)
+        if (RM != 0) { nlit += keep; return; }   // (they stay where they are: the record says where, or the copier's sum does)
         if (keep + lb_n <= kLitStage && from + keep <= iw_hi && from + kInWin >= iw_hi) {
             for (uint32_t i = (uint32_t)w.lane; i < (uint32_t)keep; i += (uint32_t)W) lbuf[lb_n + i] = iw[(uint32_t)(from + i) & (kInWin - 1)];
             lb_n += (uint32_t)keep;
@@ -515,10 +542,12 @@ struct Parser {
     // step, rows of 512 bytes in the record part of the scratch (a sub-chunk holds at most (kChunk + 2) / 3 sequences)
     static constexpr uint32_t kProvRow8 = 64u * 8u;
     static_assert(((kChunk + 2u) / 3u + 3u) * kProvRow8 <= lzr::kProvRecBytes, "the scratch rows hold a sub-chunk's records");
+    // (R4: the same with four-byte records in rows of 256 bytes)
     SWC_D static void parse_chunk_prov8(const uint8_t* stage, uint32_t stage_len, uint32_t start, uint32_t chunk_end, uint32_t tail_limit, gptr prov,
                                         uint32_t lane, uint32_t base32, ProvOut& r) {
+        constexpr uint32_t kRecB = R4 ? 4u : 8u, kRow = 64u * kRecB;
         uint32_t ip = start, nlit = 0, nout = 0, lms = 0, flags = 0;
-        uint32_t roff = 8u * lane + kProvRow8;                 // byte offset of my next record in the scratch (row 1 is the first)
+        uint32_t roff = kRecB * lane + kRow;                   // byte offset of my next record in the scratch (row 1 is the first)
         int32_t need = -0x40000000;
         const uint32_t safe = stage_len >= 8 ? stage_len - 8u : 0u;
         while (ip < chunk_end) {
@@ -530,14 +559,34 @@ struct Parser {
             }
             const int32_t nd = (int32_t)q.offset - (int32_t)(nout + q.lit);          // :382 offset <= bytes produced, checked after the scan
             need = nd > need ? nd : need;
-            store_u64(prov + roff, (uint64_t)lzr::make_match(q.lit, q.mlen, q.offset) | ((uint64_t)(base32 + q.lit_at) << 32));
-            roff += kProvRow8;
+            if (R4) store_u32(prov + roff, lzr::make_match(q.lit, q.mlen, q.offset));
+            else store_u64(prov + roff, (uint64_t)lzr::make_match(q.lit, q.mlen, q.offset) | ((uint64_t)(base32 + q.lit_at) << 32));
+            roff += kRow;
             nlit += q.lit;
             lms = nout + q.lit;
             nout += q.lit + q.mlen;
             ip = q.next;
         }
-        r.end = ip; r.nlit = nlit; r.nrec = (roff - 8u * lane) / kProvRow8 - 1u; r.nout = nout; r.lms = lms; r.flags = flags; r.need = need;
+        r.end = ip; r.nlit = nlit; r.nrec = (roff - kRecB * lane) / kRow - 1u; r.nout = nout; r.lms = lms; r.flags = flags; r.need = need;
+    }
+    // `nrec` four-byte records from the lane's column of the scratch to `rdst` (R4)
+    SWC_D static void copy_prov4(gcptr prec, uint32_t nrec, SWC_AS_GLOBAL uint32_t* rdst) {
+        for (uint32_t i = 0; i < nrec; i += 16) {
+            uint32_t v[16];
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k++) {
+                const uint32_t row = i + k + 1u < (uint32_t)lzr::kProvRecRows ? i + k + 1u : (uint32_t)lzr::kProvRecRows - 1u;
+                v[k] = load_u32(prec + (size_t)row * kProvRow);
+            }
+#pragma unroll
+            for (uint32_t k = 0; k < 16; k += 4) {
+                if (i + k + 4u <= nrec) store_u128_a4((gptr)(rdst + i + k), v[k], v[k + 1], v[k + 2], v[k + 3]);
+                else {
+#pragma unroll
+                    for (uint32_t q = 0; q < 4; q++) if (i + k + q < nrec) rdst[i + k + q] = v[k + q];
+                }
+            }
+        }
     }
     // `nrec` eight-byte records from the lane's column of the scratch to `rdst` (8-byte aligned)
     SWC_D static void copy_prov8(gcptr prec, uint32_t nrec, SWC_AS_GLOBAL uint32_t* rdst) {
@@ -649,7 +698,7 @@ struct Parser {
                         SWC_LZ4_STAT(1, 1);
                         ProvOut r;
                         const uint32_t ce = t == N - 1 ? stage_len : ((uint32_t)t + 1u) * kChunk;
-                        if (R8) parse_chunk_prov8(stage, stage_len, start[t], ce, tail_limit, prov, (uint32_t)t, (uint32_t)B, r);
+                        if (RM != 0) parse_chunk_prov8(stage, stage_len, start[t], ce, tail_limit, prov, (uint32_t)t, (uint32_t)B, r);
                         else parse_chunk_prov(stage, stage_len, start[t], ce, tail_limit, prov, (uint32_t)t, r);
                         endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; c_lms[t] = r.lms; flg[t] = r.flags;
                         c_need[t] = (uint32_t)r.need;
@@ -678,9 +727,13 @@ struct Parser {
                 pb[t] = (uint32_t)t < nv && c_rec[t] != 0 && (int32_t)c_need[t] > room;
             SIMT_END
             if (simt::wave_ballot<N>(pb)) return;                             // an offset beyond the output: the checked step reports it
+            if (R4) {   // the sequences of a round follow the copier's rule among themselves: an anchor only if its running sum does not stand at the round's first sequence
+                if (s_pred != ip) anchor(nrec, ip);
+            }
             SIMT_BEGIN(t, N)
                 if ((uint32_t)t < nv && c_rec[t] != 0) {
-                    if (R8) copy_prov8(prov + 8u * (uint32_t)t, c_rec[t], recs + 2u * (nrec + (x_rec[t] - c_rec[t])));
+                    if (R4) copy_prov4(prov + 4u * (uint32_t)t, c_rec[t], recs + nrec + (x_rec[t] - c_rec[t]));
+                    else if (R8) copy_prov8(prov + 8u * (uint32_t)t, c_rec[t], recs + 2u * (nrec + (x_rec[t] - c_rec[t])));
                     else copy_prov(prov + lzr::kProvRecBytes + 4u * (uint32_t)t, prov + 4u * (uint32_t)t, c_lit[t], c_rec[t], lits + nlit + (x_lit[t] - c_lit[t]), recs + nrec + (x_rec[t] - c_rec[t]));
                 }
             SIMT_END
@@ -697,6 +750,7 @@ struct Parser {
             sequences += tot_rec;
             SWC_LZ4_STAT(3, tot_rec);
             ip = B + simt::wave_read<N>(endp, (int)nv - 1);
+            if (R4) s_pred = ip;
             // anything invalid / the end of the block / a sequence no round takes (a long literal run: the next round would stage
             // 8 KiB to find out in its first lane): the checked step
             if (stop_flags & (kLzFail | kLzTail | kLzLong)) return;
@@ -718,9 +772,10 @@ struct Parser {
 };
 
 // One wavefront = one job (blocks WITHOUT a dictionary prefix; those with one stay on lz4_lane.h).
-template <int W, bool R8 = false>
+template <int W, int RM = 0>
 SWC_D void lz4_parse_job(Job& job, uint8_t* ws, size_t ws_bytes, int lane, uint8_t* stage, uint64_t* prof = nullptr) {
-    Parser<W, R8> ps;
+    constexpr bool R8 = RM == 1, R4 = RM == 2;
+    Parser<W, RM> ps;
     ps.w.lane = lane;
     ps.iw = stage + kScratchWin;
     ps.iw_hi = 0;
@@ -752,10 +807,14 @@ SWC_D void lz4_parse_job(Job& job, uint8_t* ws, size_t ws_bytes, int lane, uint8
     }
     ps.max_rec = rec_end > sizeof(lzr::StreamHeader) ? (uint32_t)((rec_end - sizeof(lzr::StreamHeader)) / (R8 ? 8 : 4)) : 0u;
     ps.lits = (gptr)(ws + lo);
+    if (R4 && lo != 0) {   // the anchors take the place of the literal stream
+        ps.anc = (SWC_AS_GLOBAL uint32_t*)(ws + lo);
+        ps.max_anc = (uint32_t)(lzr::lit_bytes(job.out_cap) / 8);
+    }
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     ps.tlast = __builtin_readcyclecounter();
 #endif
-    int st = lo == 0 ? SWC_E_NEED_WORKSPACE : (R8 && job.in_len > 0xFFFFFFF0ull) ? SWC_E_INVALID_ARGUMENT /* literal offsets are 32 bits */ : ps.run(stage);
+    int st = lo == 0 ? SWC_E_NEED_WORKSPACE : (RM != 0 && job.in_len > 0xFFFFFFF0ull) ? SWC_E_INVALID_ARGUMENT /* literal offsets are 32 bits */ : ps.run(stage);
     ps.flush();
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     { const uint64_t t_ = __builtin_readcyclecounter(); ps.pacc[4] += t_ - ps.tlast; }
@@ -767,12 +826,16 @@ SWC_D void lz4_parse_job(Job& job, uint8_t* ws, size_t ws_bytes, int lane, uint8
         st = SWC_E_NEED_WORKSPACE;
         ps.nrec = ps.max_rec;
     }
+    if (R4 && ps.nanc > ps.max_anc) {   // (cannot happen for an area sized by swc_batch_workspace_bytes: an anchor stands for 128 bytes of output)
+        st = SWC_E_NEED_WORKSPACE;
+        ps.nanc = ps.max_anc;
+    }
     if (st == SWC_OK && ps.pos > ps.cap) st = SWC_E_CAPACITY;
     if (lane == 0) {
         if (ws && ws_bytes >= sizeof(lzr::StreamHeader)) {
             SWC_AS_GLOBAL lzr::StreamHeader* h = (SWC_AS_GLOBAL lzr::StreamHeader*)ws;
             h->nrec = ps.nrec;
-            h->pad0 = 0;
+            h->pad0 = R4 ? ps.nanc : 0u;   // (R4: the number of anchors)
             h->nlit = ps.nlit;
         }
     }

@@ -114,8 +114,24 @@ SWC_HD void copy_run(uint8_t* d, const uint8_t* s, uint32_t n) {
 #ifndef SWC_LZC_FLUSH_EARLY
 #define SWC_LZC_FLUSH_EARLY 1
 #endif
-template <typename CFG, typename P, bool R8 = false>
+// RM == 2 ("R4"): four-byte records again, `lits` the compressed block, and the place of a record's literals DERIVED: the start S
+// of a sequence is a running sum over the records of seq_bytes(literals, length) -- what a sequence in LZ4's short form takes --
+// and its literals lie lit_skip() behind S.  The parse (lz4_wave.h), which simulates this sum, leaves an ANCHOR (record index, S)
+// wherever the rule would go wrong; a group never reaches across an anchor, and one that starts at an anchor takes its S from it.
+template <typename CFG, typename P, int RM = 0>
 struct Copier {
+    static constexpr bool R8 = RM == 1, R4 = RM == 2, INP = RM != 0;   // INP: the literals lie in the compressed block (`lits`), a run at g.loff
+    SWC_HD static uint32_t seq_bytes(uint32_t li, uint32_t le) { return le ? 3u + li + (li >= 15u ? 1u : 0u) + (le >= 19u ? 1u : 0u) : li; }
+    SWC_HD static uint32_t lit_skip(uint32_t li, uint32_t le) { return le ? 1u + (li >= 15u ? 1u : 0u) : 0u; }
+    // the second field of the packed scan: literal bytes (the offset into the dense literal stream), R4: bytes of the sequence
+    SWC_HD static uint32_t lit_step(uint32_t li, uint32_t le) { return R4 ? seq_bytes(li, le) : li; }
+    const SWC_AS_GLOBAL uint32_t* anc = nullptr;   // R4: the anchors, (record index, S) pairs
+    uint32_t nanc = 0, anc_i = 0;                  // ... how many, the next one to load
+    uint32_t anc_rec = 0xFFFFFFFFu, anc_S = 0;     // ... the next anchor (0xFFFFFFFF: none left)
+    SWC_D void next_anchor() {
+        if (anc_i < nanc) { anc_rec = simt::uniform(anc[2u * anc_i]); anc_S = simt::uniform(anc[2u * anc_i + 1u]); anc_i++; }
+        else anc_rec = 0xFFFFFFFFu;
+    }
     static constexpr uint32_t WIN = CFG::kWin, SPAN = CFG::kSpan;
     using L = Lds<WIN>;
     using SP = typename std::conditional<sizeof(P) == 4, int32_t, int64_t>::type;
@@ -265,12 +281,12 @@ struct Copier {
     // ---- all lanes copy n literal bytes from the literal stream in HBM (offset lo) to window index wd
     SWC_D void coop_literals(uint32_t wd, P lo, uint32_t n) {
         gcptr src = lits + lo;
-        const uint32_t room = R8 ? nin - (uint32_t)lo : 0xFFFFFFFFu;   // (R8: a run may end with the block)
+        const uint32_t room = INP ? nin - (uint32_t)lo : 0xFFFFFFFFu;   // (INP: a run may end with the block)
         SIMT_BEGIN(t, W)
             for (uint32_t o = 4u * (uint32_t)t; o < n; o += 4u * (uint32_t)W) {
                 // (whole dwords are read: the literal stream's allocation ends 32 bytes behind its last byte)
                 uint32_t w;
-                if (!R8 || o + 4u <= room) w = load_u32(src + o);
+                if (!INP || o + 4u <= room) w = load_u32(src + o);
                 else { w = 0; for (uint32_t q = 0; o + q < room && q < 4u; q++) w |= (uint32_t)src[o + q] << (8u * q); }
                 if (o + 4u <= n) st32(l->win + wd + o, w);
                 else st_tail(l->win + wd + o, w, n - o);
@@ -371,7 +387,8 @@ struct Copier {
         simt::PT<uint64_t, W> lw[kLitPieces]; // my literal run (up to kLongLit bytes) from the literal stream, eight bytes each
         simt::PT<uint32_t, W> loff;           // R8: where my literal run starts (offset from `lits`)
         uint32_t kind;                        // 0: records up to the first big literal-only one; 1: a run of big literal-only records
-        uint32_t ntake, span, litspan;        // records, output bytes, literal bytes of the group
+        uint32_t ntake, span, litspan;        // records, output bytes, literal bytes (R4: sequence bytes) of the group
+        P S0;                                 // offset of the group's first literal from `lits` (R4: the start of its first sequence)
         P pf_vbase;                           // window base the far loads assumed (~0: none were wanted)
         int32_t pf_lim;                       // ... and how far (relative to the group's first byte) a source they asked for may reach
     };
@@ -387,9 +404,15 @@ struct Copier {
     // EVERY call issues the same loads, wanted or not (a lane that wants nothing reads a place that certainly exists): a
     // register that is loaded on one path only reaches the next iteration through a copy, and the compiler waits for the
     // load in front of the copy -- at once, instead of an iteration later.
-    SWC_D void front(Group& g, const simt::PT<uint32_t, W>& r_in, const simt::PT<uint32_t, W>& o_in, uint32_t left, P rpos, P lbase, P vb_pred) {
+    SWC_D void front(Group& g, const simt::PT<uint32_t, W>& r_in, const simt::PT<uint32_t, W>& o_in, uint32_t left, P rpos, P lbase, P vb_pred, uint32_t base_rec) {
         using simt::PT;
         PT<bool, W> big;
+        if (R4) {   // a group that starts at an anchor takes its S from it; no group reaches across the next one
+            if (anc_rec == base_rec) { lbase = (P)anc_S; next_anchor(); }
+            const uint32_t room = anc_rec - base_rec;     // (>= 1: the anchors' record indices grow)
+            if (room < left) left = room;
+        }
+        g.S0 = lbase;
         SIMT_BEGIN(t, W)
             uint32_t li, le, di;
             g.rec[t] = (uint32_t)t < left ? r_in[t] : 0u;   // (the lanes past the last record loaded it again)
@@ -416,7 +439,7 @@ struct Copier {
             SIMT_BEGIN(t, W)
                 uint32_t li, le, di;
                 unpack(g.rec[t], li, le, di);
-                g.x[t] = (uint32_t)t < nb ? (li + le) | (li << 16) : 0u;
+                g.x[t] = (uint32_t)t < nb ? (li + le) | (lit_step(li, le) << 16) : 0u;
             SIMT_END
             simt::wave_scan_incl<W>(g.x);
             PT<bool, W> tk;
@@ -431,15 +454,23 @@ struct Copier {
             g.span = xl & 0xFFFFu;
             g.litspan = xl >> 16;
         }
+        if (R4) {   // where my literals lie in the block: the start of my sequence by the running sum, the token and the length byte behind it
+            const bool runs = g.kind == 0u;
+            SIMT_BEGIN(t, W)
+                uint32_t li, le, di;
+                unpack(g.rec[t], li, le, di);
+                g.loff[t] = (uint32_t)lbase + (runs ? (g.x[t] >> 16) - seq_bytes(li, le) + lit_skip(li, le) : g.x[t] - li);
+            SIMT_END
+        }
         // ---- my literal run, straight from the literal stream in HBM into registers: 32-bit offsets from the group's first literal
         {
-            gcptr lb = R8 ? lits : lits + lbase;
+            gcptr lb = INP ? lits : lits + lbase;
             const bool runs = g.kind == 0u;
             const uint32_t ntake = g.ntake;
             // R8: the last runs of a block end with the block -- an eight-byte piece that would reach past it is read further in
             // front and shifted down (the block's last groups only: the offsets grow with the records)
-            const bool guard = R8 && runs && nin >= 8u && simt::wave_read<W>(g.loff, (int)ntake - 1) + (lzr::kLitRunMax + 8u) > nin;
-            if (R8 && nin < 8u) {   // (a block of a few bytes that still claims output, i.e. one that ends in an error: back() copies its runs byte by byte)
+            const bool guard = INP && runs && nin >= 8u && simt::wave_read<W>(g.loff, (int)ntake - 1) + (lzr::kLitRunMax + 8u) > nin;
+            if (INP && nin < 8u) {   // (a block of a few bytes that still claims output, i.e. one that ends in an error: back() copies its runs byte by byte)
                 SIMT_BEGIN(t, W)
 #pragma unroll
                     for (int k = 0; k < kLitPieces; k++) g.lw[k][t] = 0;
@@ -466,7 +497,7 @@ struct Copier {
                 unpack(g.rec[t], li, le, di);
                 const bool ask = !SWC_LZC_FAKE && runs && (uint32_t)t < ntake && li != 0u && li <= kLongLit;
                 // (nothing wanted: the group's first literal, or the byte behind the last: it exists; R8: the block's first bytes)
-                const uint32_t o0 = ask ? (R8 ? g.loff[t] : (g.x[t] >> 16) - li) : 0u;
+                const uint32_t o0 = ask ? (INP ? g.loff[t] : (g.x[t] >> 16) - li) : 0u;
                 const uint32_t last = (li > 8u ? li : 8u) - 8u;
 #pragma unroll
                 for (int k = 0; k < kLitPieces; k++) {
@@ -513,7 +544,7 @@ struct Copier {
             P rp = rpos, lb = lbase;
             for (uint32_t i = 0; i < g.ntake; i++) {
                 const uint32_t e1 = simt::wave_read<W>(g.x, (int)i);
-                if (R8) lb = (P)simt::wave_read<W>(g.loff, (int)i);
+                if (INP) lb = (P)simt::wave_read<W>(g.loff, (int)i);
                 uint32_t n = (uint32_t)(rpos + e1 - rp);
                 while (n != 0u) {   // (a record of up to kMaxLitOnly bytes in pieces of what a slide makes room for)
                     const uint32_t piece = n < kSpanMax ? n : kSpanMax;
@@ -552,7 +583,7 @@ struct Copier {
             si[t] = s;
             // my literals (stores under the exec mask: the LDS takes as long over a store as lanes take part in it, and most
             // lanes have no literals at all)
-            const bool own_lits = li <= kLongLit && !(R8 && nin < 8u);
+            const bool own_lits = li <= kLongLit && !(INP && nin < 8u);
             longlit[t] = mine && li != 0u && !own_lits;
             if (mine && li != 0u && own_lits) {
                 uint64_t pc[kLitPieces];
@@ -579,7 +610,7 @@ struct Copier {
             const int h = simt::ctz64(m);
             const uint32_t li = simt::wave_read<W>(lit, h);
             const uint32_t lend = simt::wave_read<W>(g.x, h) >> 16;
-            coop_literals(simt::wave_read<W>(wm, h) - li, R8 ? (P)simt::wave_read<W>(g.loff, h) : lbase + (lend - li), li);
+            coop_literals(simt::wave_read<W>(wm, h) - li, INP ? (P)simt::wave_read<W>(g.loff, h) : lbase + (lend - li), li);
         }
 #if SWC_LZC_CUT == 3
         return;
@@ -713,12 +744,17 @@ struct Copier {
         const uint32_t lim = (uint32_t)limit;   // < 64
         SIMT_BEGIN(t, W)
             if (t == 0) {
-                uint32_t pos = 0;
-                uint64_t lp = 0;
+                uint32_t pos = 0, ai = 0;
+                uint64_t lp = 0, S = 0;
                 for (uint32_t i = 0; i < nrec && pos < lim; i++) {
                     uint32_t li, le, di;
                     unpack(recs[R8 ? 2u * i : i], li, le, di);
                     if (R8) lp = recs[2u * i + 1u];
+                    if (R4) {   // (the rule of front(), one record at a time)
+                        if (ai < nanc && anc[2u * ai] == i) { S = anc[2u * ai + 1u]; ai++; }
+                        lp = S + lit_skip(li, le);
+                        S += seq_bytes(li, le);
+                    }
                     for (uint32_t k = 0; k < li && pos < lim; k++, pos++, lp++) l->win[pos] = lits[lp];
                     for (uint32_t k = 0; k < le && pos < lim; k++, pos++) l->win[pos] = pos >= di ? l->win[pos - di] : (uint8_t)0;
                 }
@@ -738,7 +774,6 @@ struct Copier {
         if (nrec == 0) return;
         if (limit < 64u) { tiny(recs, nrec); return; }
         P rpos = 0;                      // output bytes finished by earlier groups
-        P lbase = 0;                     // literal bytes consumed by earlier groups
         uint32_t base = 0;               // first record of the group
         PT<uint32_t, W> r_nx, o_nx;      // the records of the group after `nxt` (R8: and their literal offsets), on their way
         Group cur, nxt;
@@ -755,7 +790,8 @@ struct Copier {
             SIMT_END
         };
         load_records(0);
-        front(nxt, r_nx, o_nx, nrec, 0, 0, ~(P)0);
+        if (R4) { anc_i = 0; next_anchor(); }
+        front(nxt, r_nx, o_nx, nrec, 0, 0, ~(P)0, 0u);
         load_records(nxt.ntake);
         bool more = true;
         while (more) {
@@ -778,13 +814,13 @@ struct Copier {
                     const P vcur = (P)A + rpos;
                     if ((uint32_t)(vcur - vbp) + cur.span > WIN) vbp = (vcur - kKeep) & ~(P)15;
                 }
-                front(nxt, r_nx, o_nx, nrec - nbase, rpos + cur.span, lbase + cur.litspan, vbp);
+                // (the literal offset of the next group: the literal bytes consumed so far; R4: where the running sum stands)
+                front(nxt, r_nx, o_nx, nrec - nbase, rpos + cur.span, cur.S0 + cur.litspan, vbp, nbase);
                 load_records(nbase + nxt.ntake);
             }
-            back(cur, rpos, lbase);
+            back(cur, rpos, cur.S0);
             base = nbase;
             rpos += cur.span;
-            lbase += cur.litspan;
 #if !SWC_LZC_FLUSH_EARLY
             // finished bytes leave for HBM a KiB at a time (whole-wave stores), long before they leave the window
             if ((P)A + rpos - fv >= 1024u) flush((P)A + rpos, false);
@@ -828,30 +864,33 @@ using CfgDeflate = Cfg<SWC_LZC_WIN, SWC_LZC_SPAN, SWC_LZC_KEEP, SWC_LZC_LITP>;
 using CfgLz4 = Cfg<SWC_LZC4_WIN, SWC_LZC4_SPAN, SWC_LZC4_KEEP, SWC_LZC4_LITP>;
 using CfgWide = Cfg<16384, 2048, 14320, 4>;   // (comparison runs: 8 waves per CU)
 
-// One job: `ws` is the stream's workspace area of `area` bytes written by phase 1.  R8 (LZ4): the area holds the header and
-// eight-byte records only, the literals are fetched from the job's input.
-template <typename CFG, bool R8 = false>
+// One job: `ws` is the stream's workspace area of `area` bytes written by phase 1.  RM 1 (R8) / 2 (R4), LZ4: the literals are
+// fetched from the job's input; R8: the area holds the header and eight-byte records; R4: four-byte records, and the anchors where
+// the literal stream would be (their number in the header's pad0).
+template <typename CFG, int RM = 0>
 SWC_D void copy_job(const Job& job, const uint8_t* ws, size_t area, Lds<CFG::kWin>* lds) {
     const SWC_AS_GLOBAL lzr::StreamHeader* h = (const SWC_AS_GLOBAL lzr::StreamHeader*)ws;
     const size_t lo = lzr::lit_offset(area, job.out_cap);
     if (lo == 0) return;   // no literal stream: phase 1 reported SWC_E_NEED_WORKSPACE for this job
     const uint64_t limit = job.out_len < job.out_cap ? job.out_len : job.out_cap;
     const SWC_AS_GLOBAL uint32_t* recs = (const SWC_AS_GLOBAL uint32_t*)(ws + sizeof(lzr::StreamHeader));
-    gcptr lits = R8 ? (gcptr)job.in : (gcptr)ws + lo;
+    gcptr lits = RM != 0 ? (gcptr)job.in : (gcptr)ws + lo;
     if (limit < 0xFFF00000ull) {   // (positions, watermarks and their differences in 32 bits)
-        Copier<CFG, uint32_t, R8> cp;
+        Copier<CFG, uint32_t, RM> cp;
         cp.l = lds;
         cp.out = (gptr)job.out;
         cp.lits = lits;
-        cp.nin = R8 ? (uint32_t)job.in_len : 0xFFFFFFFFu;   // (blocks are addressed with 32-bit offsets: launch_lz4 rejects larger ones)
+        cp.nin = RM != 0 ? (uint32_t)job.in_len : 0xFFFFFFFFu;   // (blocks are addressed with 32-bit offsets: the parse rejects larger ones)
+        if (RM == 2) { cp.anc = (const SWC_AS_GLOBAL uint32_t*)(ws + lo); cp.nanc = h->pad0; }
         cp.limit = (uint32_t)limit;
         cp.run(recs, h->nrec);
     } else {
-        Copier<CFG, uint64_t, R8> cp;
+        Copier<CFG, uint64_t, RM> cp;
         cp.l = lds;
         cp.out = (gptr)job.out;
         cp.lits = lits;
-        cp.nin = R8 ? (uint32_t)job.in_len : 0xFFFFFFFFu;
+        cp.nin = RM != 0 ? (uint32_t)job.in_len : 0xFFFFFFFFu;
+        if (RM == 2) { cp.anc = (const SWC_AS_GLOBAL uint32_t*)(ws + lo); cp.nanc = h->pad0; }
         cp.limit = limit;
         cp.run(recs, h->nrec);
     }

@@ -39,10 +39,20 @@ def run(fn, data, plain, cap=None):
 
 n = 0
 units, plains = corpus.build_units("lz4_block", 2048, 65536, payload="mix")
-for i in list(range(0, 2048, 97)) + [1137]:   # 1137: a true sequence chain that reaches the staged window's last bytes
-    ok, st = run("emu_lz4_block", units[i], plains[i])
-    assert ok, ("lz4 mix", i, st)
-    n += 1
+for mode in (1, 2):   # both forms of the LZ4 records (eight-byte / derived offsets + anchors): the copier reads literals out of the INPUT
+    lib.emu_set_lz4_record_mode(mode)
+    for i in list(range(0, 2048, 97)) + [1137]:   # 1137: a true sequence chain that reaches the staged window's last bytes
+        ok, st = run("emu_lz4_block", units[i], plains[i])
+        assert ok, ("lz4 mix", i, st, mode)
+        n += 1
+    for kind, size in (("text", 200000), ("mix", 150000), ("bin", 100000)):
+        p = corpus.PAYLOADS[kind](size, 5)
+        z = corpus.lz4_block(p)
+        assert run("emu_lz4_block", z, p)[0], ("lz4", kind, mode)
+        for cut in (1, 2, 5, 9, len(z) // 3):
+            assert not run("emu_lz4_block", z[:len(z) - cut], p)[0]
+        n += 6
+lib.emu_set_lz4_record_mode(2)
 for kind, size in (("text", 300000), ("mix", 200000), ("rep", 100000), ("zero", 70000), ("rand", 50000)):
     p = corpus.PAYLOADS[kind](size, 3)
     z = corpus.lz4_block(p)

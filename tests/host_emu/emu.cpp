@@ -26,20 +26,28 @@ extern "C" void emu_set_order(int o) { swc::simt::g_order = o; }
 static int g_copier = 1;
 extern "C" void emu_set_copier(int on) { g_copier = on; }
 // (the two window configurations the library ships: kernels.hip)
-template <typename CFG, bool R8 = false>
+template <typename CFG, int RM = 0>
 static void emu_copy(swc::Job& job, const uint8_t* ws, size_t wsb) {
     alignas(16) static swc::lzc::Lds<CFG::kWin> cl;
     std::memset(&cl, 0xEE, sizeof cl);
-    swc::lzc::copy_job<CFG, R8>(job, ws, wsb, &cl);
+    swc::lzc::copy_job<CFG, RM>(job, ws, wsb, &cl);
 }
+// how the LZ4 parse tells the copier where the literals lie (kernels.hip: SWC_LZ4_RECORD_MODE): 1 = eight-byte records, 2 = derived + anchors
+static int g_lz4_mode = 2;
+extern "C" void emu_set_lz4_record_mode(int m) { g_lz4_mode = m; }
 // (Deflate: four-byte records + the dense literal stream; LZ4: eight-byte records whose literals stay in the block -- R8)
 static void emu_copy_any(int deflate, swc::Job& job, const uint8_t* ws, size_t wsb) {
     if (deflate) {
         if (g_copier == 2) emu_copy<swc::lzc::CfgLz4>(job, ws, wsb);
         else emu_copy<swc::lzc::CfgDeflate>(job, ws, wsb);
     } else {
-        if (g_copier == 3) emu_copy<swc::lzc::CfgDeflate, true>(job, ws, wsb);
-        else emu_copy<swc::lzc::CfgLz4, true>(job, ws, wsb);
+        if (g_lz4_mode == 1) {
+            if (g_copier == 3) emu_copy<swc::lzc::CfgDeflate, 1>(job, ws, wsb);
+            else emu_copy<swc::lzc::CfgLz4, 1>(job, ws, wsb);
+        } else {
+            if (g_copier == 3) emu_copy<swc::lzc::CfgDeflate, 2>(job, ws, wsb);
+            else emu_copy<swc::lzc::CfgLz4, 2>(job, ws, wsb);
+        }
     }
 }
 
@@ -81,7 +89,8 @@ extern "C" void emu_lz4_block(swc::Job* jobs, size_t n) {
         alignas(16) static uint8_t stage[swc::lz4w::kStageLds];
         std::memset(stage, 0xEE, sizeof stage);
         if (g_copier) {
-            swc::lz4w::lz4_parse_job<1, true>(jobs[g], ws.data(), wsb, 0, stage);
+            if (g_lz4_mode == 1) swc::lz4w::lz4_parse_job<1, 1>(jobs[g], ws.data(), wsb, 0, stage);
+            else swc::lz4w::lz4_parse_job<1, 2>(jobs[g], ws.data(), wsb, 0, stage);
             emu_copy_any(0, jobs[g], ws.data(), wsb);
             continue;
         }
@@ -234,8 +243,40 @@ extern "C" void emu_copy_records8(const uint32_t* recs2, uint32_t nrec, const ui
     swc::Job j{};
     j.in = exact.get(); j.in_len = in_len;
     j.out = out; j.out_cap = cap; j.out_len = out_len;
-    if (copier == 3) emu_copy<swc::lzc::CfgDeflate, true>(j, ws.data(), wsb);
-    else emu_copy<swc::lzc::CfgLz4, true>(j, ws.data(), wsb);
+    if (copier == 3) emu_copy<swc::lzc::CfgDeflate, 1>(j, ws.data(), wsb);
+    else emu_copy<swc::lzc::CfgLz4, 1>(j, ws.data(), wsb);
+}
+// ... and with FOUR-byte records whose literal offsets are derived (lz_copy.h RM == 2): `anchors` = nanc (record index, S) pairs
+extern "C" void emu_copy_records4(const uint32_t* recs, uint32_t nrec, const uint32_t* anchors, uint32_t nanc, const uint8_t* in, size_t in_len,
+                                  uint8_t* out, size_t cap, size_t out_len, int copier) {
+    const size_t wsb = swc::lzr::ws_bytes_per_job(cap);
+    std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
+    swc::lzr::StreamHeader* h = (swc::lzr::StreamHeader*)ws.data();
+    h->nrec = nrec;
+    h->pad0 = nanc;
+    h->nlit = 0;
+    std::memcpy(ws.data() + sizeof(swc::lzr::StreamHeader), recs, 4 * (size_t)nrec);
+    std::memcpy(ws.data() + swc::lzr::lit_offset(wsb, cap), anchors, 8 * (size_t)nanc);
+    std::unique_ptr<uint8_t[]> exact(new uint8_t[in_len ? in_len : 1]);
+    std::memcpy(exact.get(), in, in_len);
+    swc::Job j{};
+    j.in = exact.get(); j.in_len = in_len;
+    j.out = out; j.out_cap = cap; j.out_len = out_len;
+    if (copier == 3) emu_copy<swc::lzc::CfgDeflate, 2>(j, ws.data(), wsb);
+    else emu_copy<swc::lzc::CfgLz4, 2>(j, ws.data(), wsb);
+}
+
+// The LZ4 parse alone in the derived-offset form (record mode 2): how many records and how many anchors a block needs
+extern "C" void emu_lz4_parse_counts(const uint8_t* in, size_t in_len, size_t cap, uint32_t* nrec, uint32_t* nanc) {
+    size_t wsb = swc::lzr::ws_bytes_per_job(cap);
+    std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD), out(cap + 16);
+    alignas(16) static uint8_t stage[swc::lz4w::kStageLds];
+    swc::Job j{};
+    j.in = in; j.in_len = in_len; j.out = out.data(); j.out_cap = cap;
+    swc::lz4w::lz4_parse_job<1, 2>(j, ws.data(), wsb, 0, stage);
+    const swc::lzr::StreamHeader* h = (const swc::lzr::StreamHeader*)ws.data();
+    *nrec = h->nrec;
+    *nanc = h->pad0;
 }
 
 // Debug/analysis helper (tools/analyze_records.py): phase 1 only, returns the record list of one stream.

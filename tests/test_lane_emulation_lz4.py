@@ -2,9 +2,21 @@
 the oracle's restatement of LZ4.process(block:_:) (reference Sources/LZ4/LZ4.swift:332-413)."""
 import random
 
+import pytest
+
 import _emu as E
 import _oracle as O
 import _streams as S
+
+
+@pytest.fixture(autouse=True, params=[2, 1], ids=["derived-offsets", "eight-byte-records"])
+def record_mode(request):
+    """Every test runs with both forms in which the parse tells the copier where a record's literals lie in the block
+    (kernels.hip SWC_LZ4_RECORD_MODE: 2 ships -- four-byte records, offsets derived by a running sum, anchors where the rule
+    breaks; 1 -- eight-byte records with the offset in the upper dword)."""
+    E.lib.emu_set_lz4_record_mode(request.param)
+    yield request.param
+    E.lib.emu_set_lz4_record_mode(2)
 
 
 def test_valid_blocks_and_dictionaries():

@@ -145,6 +145,68 @@ def test_records_that_point_at_their_literals(profile, order):
         E.set_order(0)
 
 
+lib.emu_copy_records4.argtypes = [C.POINTER(C.c_uint32), C.c_uint32, C.POINTER(C.c_uint32), C.c_uint32, C.c_char_p, C.c_size_t, C.c_void_p, C.c_size_t, C.c_size_t, C.c_int]
+lib.emu_copy_records4.restype = None
+
+
+def _seq_bytes(li, le):
+    return 3 + li + (1 if li >= 15 else 0) + (1 if le >= 19 else 0) if le else li
+
+
+def _lit_skip(li, le):
+    return 1 + (1 if li >= 15 else 0) if le else 0
+
+
+@pytest.mark.parametrize("profile", [TEXT, LITRUNS, STORED, RUNS], ids=["text", "litruns", "stored", "runs"])
+@pytest.mark.parametrize("order", [0, 2])
+def test_records_whose_literal_offsets_are_derived(profile, order):
+    """The shipped LZ4 form (lz4_wave.h / lz_copy.h record mode 2): four-byte records, the place of a record's literals in the
+    block DERIVED -- the start S of its sequence is a running sum of seq_bytes(literals, length) over the records, the literals
+    lie lit_skip() behind S -- and an ANCHOR (record index, S) wherever the rule would miss.  The block here is laid out by the
+    rule for most records and OFF the rule (extra bytes in front) for a random tenth of them, which get anchors -- computed by
+    the simulation the parse runs -- so groups are cut at anchors in the middle, at their first record, back to back; the last run
+    ends with the block (nothing may be read past it: the emulation copies the block into a buffer of exactly its size)."""
+    rnd = random.Random(hash((profile["len"][0], order, 4)) & 0xFFFF)
+    E.set_order(order)
+    try:
+        for size in (1, 63, 64, 200, 5000, 40000, 140000):
+            recs, lits, exp = build(rnd, size, profile)
+            block, anchors, lp, S = bytearray(), [], 0, 0
+            for i, r in enumerate(recs):
+                le = (r >> 7) & 511
+                li = (r & 127) + (((r >> 16) << 7) if le == 0 else 0)
+                start = len(block)                                   # where this record's sequence begins in the block
+                if rnd.random() < 0.1 or start > S:                  # off the rule (forced when the block has run ahead of the rule's sum)
+                    block += bytes(rnd.randrange(256) for _ in range(rnd.randint(1, 5) + max(0, S - start)))
+                    start = len(block)
+                else:
+                    block += bytes(rnd.randrange(256) for _ in range(S - start))
+                    start = S
+                block += bytes(rnd.randrange(256) for _ in range(_lit_skip(li, le)))
+                if li and S != start:
+                    anchors += [i, start]
+                    S = start
+                block += lits[lp:lp + li]
+                lp += li
+                if le:                                               # the rest of the sequence: offset field, a length byte
+                    block += bytes(rnd.randrange(256) for _ in range(2 + (1 if le >= 19 else 0)))
+                S += _seq_bytes(li, le)
+            # (a stream whose last record is literal-only ends with its literals, as an LZ4 block does)
+            arr = (C.c_uint32 * len(recs))(*recs)
+            anc = (C.c_uint32 * max(len(anchors), 1))(*anchors)
+            for misalign in (0, 7):
+                for cfg in (1, 3):
+                    buf = C.create_string_buffer(len(exp) + 64 + 32)
+                    C.memset(buf, 0xA5, len(buf))
+                    o0 = (-C.addressof(buf)) % 16 + 16 + misalign
+                    lib.emu_copy_records4(arr, len(recs), anc, len(anchors) // 2, bytes(block), len(block), C.addressof(buf) + o0, len(exp), len(exp), cfg)
+                    raw = buf.raw
+                    assert raw[:o0] == b"\xA5" * o0 and raw[o0 + len(exp):] == b"\xA5" * (len(raw) - o0 - len(exp))
+                    assert raw[o0:o0 + len(exp)] == exp, "copier differs (size %d, misalign %d, configuration %d, %d anchors)" % (size, misalign, cfg, len(anchors) // 2)
+    finally:
+        E.set_order(0)
+
+
 def test_capacity_cuts_the_last_records():
     """Records exist only for output below the capacity: the last one may reach past it (phase 2 clamps at the limit)."""
     rnd = random.Random(77)
