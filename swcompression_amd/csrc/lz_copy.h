@@ -281,7 +281,7 @@ struct Copier {
     // ---- all lanes copy n literal bytes from the literal stream in HBM (offset lo) to window index wd
     SWC_D void coop_literals(uint32_t wd, P lo, uint32_t n) {
         gcptr src = lits + lo;
-        const uint32_t room = INP ? nin - (uint32_t)lo : 0xFFFFFFFFu;   // (INP: a run may end with the block)
+        const uint32_t room = INP ? ((uint32_t)lo < nin ? nin - (uint32_t)lo : 0u) : 0xFFFFFFFFu;   // (INP: a run may end with the block)
         SIMT_BEGIN(t, W)
             for (uint32_t o = 4u * (uint32_t)t; o < n; o += 4u * (uint32_t)W) {
                 // (whole dwords are read: the literal stream's allocation ends 32 bytes behind its last byte)
@@ -459,7 +459,8 @@ struct Copier {
             SIMT_BEGIN(t, W)
                 uint32_t li, le, di;
                 unpack(g.rec[t], li, le, di);
-                g.loff[t] = (uint32_t)lbase + (runs ? (g.x[t] >> 16) - seq_bytes(li, le) + lit_skip(li, le) : g.x[t] - li);
+                const uint32_t o = (uint32_t)lbase + (runs ? (g.x[t] >> 16) - seq_bytes(li, le) + lit_skip(li, le) : g.x[t] - li);
+                g.loff[t] = o < nin ? o : nin;   // (never beyond the block, whatever the records say: the guarded loads below then stay inside it)
             SIMT_END
         }
         // ---- my literal run, straight from the literal stream in HBM into registers: 32-bit offsets from the group's first literal
