@@ -7,5 +7,5 @@ for MODE in weak strong; do
   timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
     bench.py --gpus 2 --steps 3 --warmup 1 --scale 0.2 --scaling $MODE --rehearse-on-one-gpu 2>&1 | grep '^{' | python -c "
 import sys, json
-d = json.loads(sys.stdin.read()); print('$MODE', d['n_gpus'], round(d['value'], 1), round(d['ms_per_step'], 2), d['config']['units_per_gpu'], d['config']['parallelism'], d['verify'])"
+d = json.loads(sys.stdin.read()); print('$MODE', d['n_gpus'], round(d['value'], 1), round(d['ms_per_step'], 2), d['config']['units_per_gpu'], d['config']['parallelism'], d.get('units_verified'), d.get('rehearsal'), d.get('ranks'))"
 done
