@@ -39,7 +39,14 @@
 namespace swc {
 namespace inflate {
 
-constexpr int kSyncLitBits = 10, kSyncDistBits = 8;
+// Index bits of the first-level literal/length table.  9 bits make the wave's LDS exactly 8 KB -- 20 waves per CU instead of 16, and
+// the kernel gains with its waves (12 / 14 / 16 per CU: 7.72 / 7.09 / 6.64 ms) -- but five waves per SIMD leave 96 VGPRs for a body that
+// needs 127: 108 bytes of scratch, 6.55 ms against 6.50-6.59 (and 6.70 at four waves: the second-level lookups of the ten-bit codes).
+// profiles/r06_experiments.txt, r07h-i.
+#ifndef SWC_SYNC_LIT_BITS
+#define SWC_SYNC_LIT_BITS 10
+#endif
+constexpr int kSyncLitBits = SWC_SYNC_LIT_BITS, kSyncDistBits = 8;
 // Input bytes per lane and round: a whole number of dwords and an ODD number of them (17), so that the lanes, which start
 // a pass at the same offset of their sub-chunks, read 64 different LDS banks without any padding of the staged input.
 // With 68 bytes the wave's LDS is EXACTLY 10,240 bytes = 16 waves per CU (measured in round 2 by padding the LDS: 12 waves
@@ -78,7 +85,9 @@ static_assert(kSyncChunk % 4 == 0 && kSyncChunk >= 36, "sub-chunks are whole dwo
 // The window a lane looks at, `bits4`, is the stream from the symbol's first bit on, shifted LEFT by two (the stage is stored
 // that way): (bits4 & mask) | table is the LDS byte address of the entry, and the extra bits of the symbol are
 // bfe(bits4, 0, n2) >> c2.
-constexpr uint32_t kEntNotLen = 3u << 10, kEntLen = 1u << 12, kEntLit = 1u << 13, kEntDist = 1u << 29, kEntStop = 1u << 30, kEntTog = 1u << 31;
+constexpr uint32_t kEntLenBit = (uint32_t)kSyncLitBits + 2u;
+constexpr uint32_t kEntNotLen = ((1u << (kSyncLitBits - kSyncDistBits)) - 1u) << (kSyncDistBits + 2), kEntLen = 1u << kEntLenBit, kEntLit = 1u << 13, kEntDist = 1u << 29, kEntStop = 1u << 30, kEntTog = 1u << 31;
+static_assert(kSyncLitBits > kSyncDistBits && kEntLenBit <= 12u, "the entry keeps bits 10 .. 12 for the table switch");
 constexpr uint32_t kEntBaseShift = 14, kEntPosMask = kEntTog | kEntStop | 31u;
 constexpr uint32_t kLitMask4 = ((1u << kSyncLitBits) - 1u) << 2, kDistMask4 = ((1u << kSyncDistBits) - 1u) << 2;
 static_assert(kEntLen == 4u << kSyncLitBits, "the length flag is the byte offset of the distance table");
@@ -132,7 +141,7 @@ struct SyncLds {   // 10,240 bytes: see kSyncChunk
     uint8_t occupancy_experiment_pad[SWC_SYNC_LDS_PAD];             // (tools/gpu_chunk_sweep.sh: fewer waves per CU, nothing else changed)
 #endif
 };
-#if SWC_SYNC_CHUNK == 68 && !defined(SWC_SYNC_LDS_PAD)
+#if SWC_SYNC_CHUNK == 68 && !defined(SWC_SYNC_LDS_PAD) && SWC_SYNC_LIT_BITS == 10
 static_assert(sizeof(SyncLds) == 10240, "16 waves per CU: the wave's LDS must stay within 160 KB / 16");
 #endif
 // header scratch inside `stage`
@@ -680,7 +689,7 @@ SWC_D void decode_chunk_prov(const SyncLds* sl, const SubTab st, uint32_t start,
         }
         nout += lit1 + plen;                               // (plen is zero except in the step of the distance)
         run = clear_if(dm, run + lit1);
-        plen = val & sbfe1(e, 12);
+        plen = val & sbfe1(e, kEntLenBit);
     } while ((int32_t)pos < (int32_t)chunk_end);
     const uint32_t nlit = nl3 - 3u;
 #if SWC_PROV_STORES == 2
