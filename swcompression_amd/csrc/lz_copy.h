@@ -3,32 +3,40 @@
 //
 // The reference executes every back-reference inline, one byte per `out.append`
 // (Sources/Deflate/Deflate.swift:216-232, Sources/LZ4/LZ4.swift:398-410).  Phase 1 (inflate_sync.h, lz4_wave.h) leaves a
-// record list and a dense literal stream per stream in the workspace (formats: lz_resolve.h).  Here the 64 lanes of a wave
-// OWN RECORDS, not bytes:
+// record list per stream in the workspace (format: lz_resolve.h) and -- Deflate -- a dense literal stream; LZ4's literals stay
+// where they are in the block.  Here the 64 lanes of a wave OWN RECORDS, not bytes:
 //
-//   group      64 consecutive records, one per lane (fewer when they cover more than kSpanMax output bytes or more literals
-//              than the literal buffer holds).  One packed prefix scan over (literals + length, literals) gives every lane
-//              the place of its literals and of its match in the output;
-//   literals   every lane copies its own literal run from the staged literal stream into the window, eight bytes a step (one to
-//              three bytes: a word and / or a byte; four to eight: two dwords), the last piece shifted back so that it ends on
-//              the run's last byte -- no byte tails.  READS at any byte alignment are two or three ALIGNED dwords and a byte
-//              funnel shift (v_alignbyte_b32): the LDS serves an unaligned ds_read at one LANE per cycle, an aligned one at
-//              ten lanes (tools/micro/lds_bench.hip); unaligned stores cost a quarter of a cycle per lane and are used as they are;
-//   matches    a lane copies its match the same way -- up to 32 bytes as four eight-byte pieces -- when its source is final at
-//              the start of the group: it ends in front of the group's first byte (in the window), or it lies in front of the
-//              window (FAR: then the bytes come from the output buffer in HBM and were asked for by front() one group AHEAD,
-//              into registers);
-//   the rest   -- matches that reach into their own group (9 % on text), matches longer than 32 bytes or overlapping
-//              themselves (distance < length), far matches nobody asked for -- are copied in record order, one after the other,
-//              by ALL lanes together (a byte per lane for the short ones; a dword per lane, 256 bytes per step, for the long
-//              ones; an overlapping match from its first period):
-//              the first record that has not been copied yet finds everything in front of it final.  When more than kSeqMax
-//              short ones are left (LZ4 text: a quarter of its matches), a bitmap of the group's output first tells which of
-//              them depend on none of the others -- most -- and those are copied by their own lanes, all at once;
-//   window     a LINEAR array (WIN bytes: 5 KiB for Deflate, 8 KiB for LZ4 -- kernels.hip), not a ring: when a group does not
-//              fit behind the write position any more, the finished bytes
-//              are flushed to HBM (aligned 16-byte stores, the only time the output is written) and the last kKeep bytes
-//              move to the front of the array (16 bytes per lane and step).  No index masks anywhere in the copy code.
+//   group      64 consecutive records, one per lane (fewer when they cover more than kSpanMax output bytes).  One packed prefix
+//              scan over (literals + length, literals) gives every lane the place of its literals and of its match in the output
+//              (LZ4: the second field is the bytes of the record's SEQUENCE in the block -- the running sum says where its
+//              literals lie, see Copier);
+//   literals   a lane's literal run -- up to 16 bytes (Deflate) / 32 (LZ4) -- is loaded by front() from the literal stream (LZ4:
+//              from the compressed block itself) in HBM straight into registers, one group AHEAD, as eight-byte pieces, the last
+//              one shifted back so that it ends on the run's last byte; back() stores it into the window: one to three bytes as
+//              a byte and / or a word, four to eight as two dwords, more as eight-byte pieces -- no byte tails.  (Round 5 staged
+//              the literal stream in an LDS buffer; the buffer's KiB is window now, and its reads are gone);
+//   matches    a lane copies its match -- up to 32 bytes as four eight-byte pieces -- when its source is final at the start of
+//              the group: it ends in front of the group's first byte (in the window), or it lies in front of the window (FAR:
+//              then the bytes come from the output buffer in HBM and were asked for by front() one group ahead, into
+//              registers).  READS from the window at any byte alignment are two or three ALIGNED dwords and a byte funnel shift
+//              (v_alignbyte_b32): the LDS serves an unaligned ds_read at one LANE per cycle, an aligned one at ten lanes
+//              (tools/micro/lds_bench.hip); unaligned stores cost a quarter of a cycle per lane and are used as they are;
+//   the rest   -- matches that reach into their own group (9 % on Deflate text, 28 % on LZ4 text), matches longer than 32 bytes
+//              or overlapping themselves (distance < length), far matches nobody asked for.  Nothing long, overlapping or far
+//              among them and at most 256 bytes in all (nine groups in ten): a BYTE PER LANE -- a running sum of the lengths
+//              numbers the bytes, a marker per match in LDS and a running maximum tell a lane which match its byte belongs to
+//              -- and all lanes copy their byte together, round after round, until a round reads what the round before it read
+//              (sources lie strictly in front of their bytes: that state is the reference's sequence).  Otherwise in record
+//              order, one after the other, by ALL lanes together (a byte per lane for the short ones; a dword per lane, 256
+//              bytes per step, for the long ones; an overlapping match from its first period), after a bitmap of the group's
+//              output has let those that depend on none of the others go at once, each by its own lane;
+//   window     a LINEAR array (6 KiB for Deflate, 7 KiB for LZ4 -- CfgDeflate / CfgLz4 below), not a ring: when a group does
+//              not fit behind the write position any more, the last kKeep bytes (3.25 KiB) move to the front of the array (16
+//              bytes per lane and step).  The slide is the expensive thing, not the far matches a short history makes (a far
+//              source is four loads that are issued anyway): kKeep is what asking ahead needs, no more.  Finished bytes are
+//              flushed to HBM a KiB at a time (aligned 16-byte stores, the only time the output is written) at the TOP of an
+//              iteration, so that the next full wait finds stores that have had a whole group's copies to arrive.  No index
+//              masks anywhere in the copy code; every position, watermark and difference is 32 bits (streams under 4 GiB).
 //
 // One iteration = front(next group) + back(this group).  front() issues ALL global loads of the next group -- its far
 // sources, its literals, the records of the group behind it -- and nothing waits for them before the drain at the top of
