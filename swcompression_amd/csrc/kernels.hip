@@ -169,13 +169,15 @@ __global__ __launch_bounds__(kInflateResolveThreads) void swc_lz_resolve_kernel(
 }
 
 // Phase 2, record-granular (lz_copy.h): one stream per WAVEFRONT, the last few KiB of its output in an LDS window, older
-// sources read back from the output buffer.  The window is a trade between the waves a CU holds and the matches that are FAR
-// (profiles/r05_experiments.txt, r05n-p):
-//   Deflate  5 KiB window, groups of up to 1 KiB (6.2 KB of LDS per wave -> 24 waves per CU): 7.4 ms on BASELINE configs[1]
-//            against 8.5 ms with 8 KiB / 2 KiB at 16 waves per CU -- the walk of a stream is serial, and what hides its
-//            LDS and memory latencies is the number of waves; 46 % of the matches of text are far then instead of 35 %;
-//   LZ4      8 KiB window, groups of up to 2 KiB, 16 waves per CU: offsets reach 65,535 bytes back and 4 MiB blocks have long
-//            literal runs -- the smaller window is 1-8 % slower there.
+// sources read back from the output buffer.  The configurations (lz_copy.h: CfgDeflate, CfgLz4; profiles/r05_experiments.txt r05n-p,
+// profiles/r06_experiments.txt r06b-c, r06t, r07a):
+//   Deflate  6 KiB window of which a slide keeps 3.25 KiB, groups of up to 1 KiB, 6.4 KB of LDS per wave -> 24 waves per CU: 6.2 ms on
+//            BASELINE configs[1] (round 5: 5 KiB window, 4,080 B kept, the literal stream staged in LDS: 7.65).  What a slide keeps is
+//            what asking for far sources one group ahead needs, no more: the slide -- two LDS passes over everything kept -- costs
+//            more than the far matches a short history makes (6 KiB / 5,104 kept: 7.30; / 4,096: 6.58; / 2,560: 6.41 before the
+//            flush moved to the top of the iteration, which needs 3,328);
+//   LZ4      7 KiB window, 3.25 KiB kept, groups of up to 1 KiB, runs of up to 32 literal bytes per lane, 81 VGPRs -> 20 waves per CU
+//            (9 KiB / 2 KiB groups / 16 waves: 57.9 against 56.6 ms).
 // The 16 KiB variant (8 waves per CU) is kept for comparison runs.
 template <typename CFG, int RM = 0>
 __device__ __forceinline__ void lz_copy_body(const Job* __restrict__ jobs, uint32_t n, const WsMap& wm, const uint32_t* __restrict__ order) {
