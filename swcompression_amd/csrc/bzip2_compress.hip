@@ -15,6 +15,7 @@
 #include <cstring>
 #include <algorithm>
 #include <thread>
+#include <system_error>
 #include <vector>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -77,10 +78,15 @@ struct DeviceExec {
         if (nt < 2) { memcpy(dst, src, n); return; }
         std::vector<std::thread> th;
         const size_t per = (n / nt + 63) & ~(size_t)63;
-        for (size_t t = 0; t < nt; t++) {
-            const size_t lo = std::min(n, t * per), hi = t + 1 == nt ? n : std::min(n, (t + 1) * per);
-            th.emplace_back([=] { if (hi > lo) memcpy(dst + lo, src + lo, hi - lo); });
-        }
+        size_t done = 0;   // bytes whose copy a thread has taken
+        try {
+            for (size_t t = 0; t < nt; t++) {
+                const size_t lo = std::min(n, t * per), hi = t + 1 == nt ? n : std::min(n, (t + 1) * per);
+                th.emplace_back([=] { if (hi > lo) memcpy(dst + lo, src + lo, hi - lo); });
+                done = hi;
+            }
+        } catch (const std::system_error&) {}   // no more threads to be had: this one copies the rest (never std::terminate)
+        if (done < n) memcpy(dst + done, src + done, n - done);
         for (auto& t : th) t.join();
     }
     void upload(void* d, const void* h, size_t n) {
