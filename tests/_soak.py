@@ -113,3 +113,19 @@ def random_deflate_stream(rnd, n, seed):
     co = zlib.compressobj(rnd.choice([0, 1, 2, 3, 4, 6, 9]), zlib.DEFLATED, -rnd.choice([9, 10, 12, 15]), rnd.choice([1, 4, 8, 9]), rnd.choice(STRATEGIES))
     cut = rnd.randrange(len(p) + 1)
     return co.compress(p[:cut]) + co.flush(rnd.choice([zlib.Z_NO_FLUSH, zlib.Z_SYNC_FLUSH, zlib.Z_FULL_FLUSH])) + co.compress(p[cut:]) + co.flush()
+
+
+def random_lzma2_unit(rnd, n, seed):
+    """(raw LZMA2 stream, dictionary byte): liblzma with random lc / lp / pb, dictionary size, mode, match finder and nice length over
+    spliced text -- small dictionaries make the encoder restart its state and dictionary between chunks."""
+    import lzma
+    p = spliced_plain(rnd, n, seed)
+    lc = rnd.randrange(0, 5)
+    lp = rnd.randrange(0, 5 - lc)
+    dict_size = rnd.choice([4096, 4096, 65536, 1 << 20, 1 << 23])
+    f = {"id": lzma.FILTER_LZMA2, "lc": lc, "lp": lp, "pb": rnd.randrange(0, 5), "dict_size": dict_size,
+         "mode": rnd.choice([lzma.MODE_FAST, lzma.MODE_NORMAL]), "nice_len": rnd.choice([5, 8, 32, 64, 273]),
+         "mf": rnd.choice([lzma.MF_HC3, lzma.MF_HC4, lzma.MF_BT2, lzma.MF_BT4]), "depth": rnd.choice([0, 1, 4])}
+    if f["mode"] == lzma.MODE_FAST and f["mf"] in (lzma.MF_BT2, lzma.MF_BT4) and f["nice_len"] < 8:
+        f["nice_len"] = 8
+    return lzma.compress(p, format=lzma.FORMAT_RAW, filters=[f]), corpus.lzma2_dict_byte(dict_size)

@@ -1,4 +1,4 @@
-"""GPU tier: a soak of the two LZ77 decode paths (Deflate, LZ4 block) on randomly BUILT streams, against the oracle.
+"""GPU tier: a soak of the two LZ77 decode paths (Deflate, LZ4 block) and of LZMA2 / BZip2 on randomly BUILT streams, against the oracle.
 
 The other GPU tests take their streams from encoders, which never produce most of what the formats allow.  Here the LZ4
 blocks are assembled sequence by sequence (LZ4.swift:341-412) from random literal-run lengths, match lengths and offsets
@@ -37,8 +37,8 @@ def _both_kernels(fn):
         lib.swc_set_tuning(b"lz_copier", 1)
 
 
-def _check(codec, streams, exp, caps, label):
-    b = DeviceBatch(codec, streams, caps)
+def _check(codec, streams, exp, caps, label, aux=None):
+    b = DeviceBatch(codec, streams, caps, aux=aux)
     b.launch(sync=True)
     r = b.results()
     for i, e in enumerate(exp):
@@ -83,5 +83,60 @@ def test_deflate_streams_over_spliced_text(seed):
         keep = [i for i, e in enumerate(exp) if e[0] != 901]
         caps = [max(len(exp[i][1]), 1) + rnd.choice([0, 0, 0, 5]) for i in keep]
         _both_kernels(lambda label: _check("deflate", [streams[i] for i in keep], [exp[i] for i in keep], caps, "seed %d, %s" % (seed, label)))
+    finally:
+        O.lib.refcpu_set_max_output(1 << 30)
+
+
+@pytest.mark.parametrize("seed", range(ROUNDS))
+def test_lzma2_units_of_random_encoder_settings(seed):
+    """The range decoder's decision is one block of gfx950 instructions (lzma_wave.h: SWC_LZMA_BIT_ASM): every lc / lp / pb,
+    dictionaries from 4 KiB, both layouts of the literal coders."""
+    from swcompression_amd import _lib
+    lib = _lib.load()
+    rnd = random.Random(0x7A4C + seed)
+    O.lib.refcpu_set_max_output(1 << 24)
+    try:
+        units = [K.random_lzma2_unit(rnd, rnd.choice([0, 1, 9, 300, 4000, 70000, 300000]), 5000 * seed + i) for i in range(96)]
+        units += [(K.damage(rnd, z), db) for z, db in (units[rnd.randrange(len(units))] for _ in range(64))]
+        exp = [O.lzma2(z, db) for z, db in units]
+        keep = [i for i, e in enumerate(exp) if e[0] != 901]
+        caps = [max(len(exp[i][1]), 1) + rnd.choice([0, 0, 64]) for i in keep]
+        try:
+            for mode in (1, 0):
+                assert lib.swc_set_tuning(b"lzma_coder_cache", mode) == 0
+                _check("lzma2", [units[i][0] for i in keep], [exp[i] for i in keep], caps, "seed %d, coder cache %d" % (seed, mode), aux=[units[i][1] for i in keep])
+        finally:
+            lib.swc_set_tuning(b"lzma_coder_cache", 1)
+    finally:
+        O.lib.refcpu_set_max_output(1 << 30)
+
+
+@pytest.mark.parametrize("seed", range(ROUNDS))
+def test_bzip2_streams_over_spliced_text(seed):
+    """libbz2 at every block size over spliced text (zero runs and distance-1 copies: runs of every length for the RLE1 undo, the
+    ones of 4 .. 259 bytes and the megabyte ones), damaged copies; all archives of a round in one launch, the inverse BWT once as
+    the team kernels and once inside the block's wavefront."""
+    import bz2
+    import swcompression_amd as swc
+    from swcompression_amd import _lib
+    lib = _lib.load()
+    rnd = random.Random(0xB2 + 977 * seed)
+    O.lib.refcpu_set_max_output(1 << 24)
+    try:
+        streams = [bz2.compress(K.spliced_plain(rnd, rnd.choice([0, 1, 9, 300, 4000, 70000, 250000, 1200000]), 3000 * seed + i), rnd.randrange(1, 10)) for i in range(48)]
+        streams += [K.damage(rnd, streams[rnd.randrange(len(streams))]) for _ in range(48)]
+        exp = [O.bzip2(z) for z in streams]
+        keep = [i for i, e in enumerate(exp) if e[0] != 901]
+        try:
+            for mode in (2, 0):
+                assert lib.swc_set_tuning(b"bzip2_team_walk", mode) == 0
+                got = swc.unarchive_many("bzip2", [streams[i] for i in keep])
+                for k, i in enumerate(keep):
+                    what = "seed %d, team walk %d, stream %d (%d bytes in)" % (seed, mode, i, len(streams[i]))
+                    assert got[k][0] == exp[i][0], "status %d, oracle %d: %s" % (got[k][0], exp[i][0], what)
+                    if exp[i][0] == 0:
+                        assert got[k][1] == exp[i][1], "bytes differ: " + what
+        finally:
+            lib.swc_set_tuning(b"bzip2_team_walk", 1)
     finally:
         O.lib.refcpu_set_max_output(1 << 30)

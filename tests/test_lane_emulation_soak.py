@@ -64,3 +64,17 @@ def test_deflate_streams_over_spliced_text(seed, bounded_oracle):
     for copier in (1, 2, 0):    # the Deflate window, the LZ4 window, the workgroup resolver
         E.lib.emu_set_copier(copier)
         _compare(E.inflate(ins, caps, misalign=seed % 16), want, ins, "seed %d, copier %d" % (seed, copier))
+
+
+@pytest.mark.parametrize("seed", range(4))
+def test_lzma2_units_of_random_encoder_settings(seed, bounded_oracle):
+    rnd = random.Random(0xE7A4C + seed)
+    units = [K.random_lzma2_unit(rnd, rnd.choice([0, 1, 9, 300, 4000, 70000, 200000]), 5000 * seed + i) for i in range(64)]
+    units += [(K.damage(rnd, z), db) for z, db in (units[rnd.randrange(len(units))] for _ in range(48))]
+    exp = [O.lzma2(z, db) for z, db in units]
+    keep = [i for i, e in enumerate(exp) if e[0] != 901]
+    ins, want = [units[i][0] for i in keep], [exp[i] for i in keep]
+    caps = [max(len(e[1]), 1) + rnd.choice([0, 0, 64]) for e in want]
+    E.set_order(seed % 3)
+    for mode in (1, 0):         # LDS as a cache of the literal coders / all coders in LDS
+        _compare(E.lzma2(ins, caps, [units[i][1] for i in keep], mode=mode), want, ins, "seed %d, model layout %d" % (seed, mode))
