@@ -1,4 +1,4 @@
-"""GPU tier: a soak of the two LZ77 decode paths (Deflate, LZ4 block) and of LZMA2 / BZip2 on randomly BUILT streams, against the oracle.
+"""GPU tier: a soak of the two LZ77 decode paths (Deflate, LZ4 block) and of LZMA2 / BZip2 on randomly BUILT streams, against the oracle; the three encoders on the same kind of text.
 
 The other GPU tests take their streams from encoders, which never produce most of what the formats allow.  Here the LZ4
 blocks are assembled sequence by sequence (LZ4.swift:341-412) from random literal-run lengths, match lengths and offsets
@@ -138,5 +138,37 @@ def test_bzip2_streams_over_spliced_text(seed):
                         assert got[k][1] == exp[i][1], "bytes differ: " + what
         finally:
             lib.swc_set_tuning(b"bzip2_team_walk", 1)
+    finally:
+        O.lib.refcpu_set_max_output(1 << 30)
+
+
+@pytest.mark.parametrize("seed", range(ROUNDS))
+def test_encoders_on_spliced_text(seed):
+    """The three encoders on spliced text of random sizes (Deflate.compress beyond the megabyte above which it works in segments,
+    LZ4 frames of every block size with and without linked blocks, BZip2 at every block size): the ORACLE's decoder, which must
+    consume the whole stream, and the system's codec return the input."""
+    import bz2
+    import zlib
+    import swcompression_amd as swc
+    rnd = random.Random(0xE2C + 31 * seed)
+    O.lib.refcpu_set_max_output(1 << 24)
+    try:
+        for i in range(10):
+            p = K.spliced_plain(rnd, rnd.choice([0, 1, 2, 3, 9, 300, 4000, 65536, 300000, 1048576, 1048577, 2500000]), 800 * seed + i)
+            z = swc.Deflate.compress(p)
+            assert O.deflate(z) == (0, p, len(z)), "Deflate.compress, seed %d, buffer %d (%d bytes)" % (seed, i, len(p))
+            assert zlib.decompress(z, -15) == p
+        for i in range(10):
+            p = K.spliced_plain(rnd, rnd.choice([0, 1, 12, 13, 300, 4000, 65536, 65537, 300000, 2500000]), 900 * seed + i)
+            kw = dict(independent_blocks=rnd.random() < 0.5, block_checksums=rnd.random() < 0.5, content_checksum=rnd.random() < 0.5,
+                      content_size=rnd.random() < 0.5, block_size=rnd.choice([173, 1024, 65536, 65537, 200000, 1 << 20, 4 << 20]))
+            z = swc.LZ4.compress(p, **kw)
+            assert O.lz4(z) == (0, p, len(z)), "LZ4.compress, seed %d, buffer %d (%d bytes, %r)" % (seed, i, len(p), kw)
+        for i in range(6):
+            p = K.spliced_plain(rnd, rnd.choice([0, 1, 9, 300, 4000, 99999, 100000, 100001, 250000, 1000000]), 700 * seed + i)
+            bs = rnd.randrange(1, 10)
+            z = swc.BZip2.compress(p, bs)
+            assert O.bzip2(z) == (0, p, len(z)), "BZip2.compress, seed %d, buffer %d (%d bytes, block size %d)" % (seed, i, len(p), bs)
+            assert bz2.decompress(z) == p
     finally:
         O.lib.refcpu_set_max_output(1 << 30)
