@@ -10,7 +10,7 @@ the oracle; the engine must return the oracle's status and -- for status 0 -- it
 copies (bit flips, truncations, garbage tails) must return the oracle's status.  Each round runs once with the library's
 choice of phase-2 kernel and once with the wave kernel forced.
 
-SWC_SOAK_ROUNDS (default 2) sets the number of seeded rounds; profiles/r06z_soak_gpu.log is a run of 400 (800 tests, 19 minutes).
+SWC_SOAK_ROUNDS (default 2) sets the number of seeded rounds; profiles/r06z_soak_gpu.log holds runs of 300 - 1,500 rounds per test.
 """
 import os
 import random
