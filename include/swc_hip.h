@@ -307,6 +307,10 @@ const char* swc_version(void);
  *                               for launches of 2,560 streams and more, one stream per 512-thread workgroup
  *                               (csrc/lz_resolve.h) below; 0: the workgroup kernel always; 2: Deflate launches take the wave
  *                               kernel with a 16 KiB window; -1 / -2: the wave kernel whatever the launch size;
+ *   "deflate_team" = 1 | 0 | -1 process-wide: Deflate launches of up to 256 streams give every stream a workgroup of six wavefronts
+ *                               (csrc/inflate_sync.h: the master on the job, the helpers on the rounds behind the master's --
+ *                               the latency of ONE stream is a wave's, and a team cuts it by three) (1, default), one wavefront
+ *                               per stream whatever the launch (0), or a team up to 4,096 streams (-1: tests);
  *   "bzip2_hot_cxx" = 0 | 1     process-wide: BZip2 launches run the instantiation of the block kernel whose plain-symbol loop is
  *                               compiled from C++ (1) instead of the hand-written assembly (0, default) -- the two are compared
  *                               by the GPU tests;

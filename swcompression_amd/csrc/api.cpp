@@ -438,6 +438,7 @@ int swc_set_tuning(const char* key, int value) try {
     if (!strcmp(key, "phase_timing") && (value == 0 || value == 1)) { set_phase_timing(value); return SWC_OK; }
     if (!strcmp(key, "lzma_coder_cache") && (value == 0 || value == 1)) { set_lzma_coder_cache(value); return SWC_OK; }
     if (!strcmp(key, "lz_copier") && value >= -2 && value <= 2) { set_lz_copier(value); return SWC_OK; }
+    if (!strcmp(key, "deflate_team") && value >= -1 && value <= 1) { set_deflate_team(value); return SWC_OK; }
     if (!strcmp(key, "bzip2_hot_cxx") && (value == 0 || value == 1)) { set_bzip2_hot_cxx(value); return SWC_OK; }
     if (!strcmp(key, "bzip2_team_walk") && value >= 0 && value <= 2) { set_bzip2_team_walk(value); return SWC_OK; }
     if (!strcmp(key, "bzip2_team_per_cu") && value >= 1 && value <= 2) { set_bzip2_team_per_cu(value); return SWC_OK; }

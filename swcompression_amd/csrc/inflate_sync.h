@@ -826,10 +826,276 @@ SWC_D void decode_chunk(const SyncLds* sl, const SubTab st, uint32_t start, uint
     r.flags = flags;
 }
 
+// ---- a TEAM of wavefronts on one stream -----------------------------------------------------------------------------
+// A launch of few streams is a matter of latency: one wave takes a round of a 64 KiB stream in 50 us whatever else the chip
+// does, and the stream has five.  A team is a workgroup of kTeamWaves wavefronts on ONE stream: wave 0, the MASTER, runs the
+// job as above; while it works on the round at byte B of the block, HELPER h stages the round at B + h * kTeamStride -- its
+// sub-chunk 0 is the sub-chunk 63 of the round in front of it -- with the master's tables (copied into its own LDS once per
+// block), walks all 64 sub-chunks, lane 0 from the first bit of its sub-chunk, and decodes sub-chunks 1 .. 63 into its own
+// scratch rows exactly as the master's fast path does.  The helper cannot know whether its lane 0 was in step at the end of its
+// sub-chunk (after 544 bits: 99.3 %), and it need not: the master, having committed the round in front, ADOPTS the helper's
+// round if and only if the helper's lane 1 began at the bit where the committed round ended -- a chain of decodes that starts
+// at the true position IS the true sequence -- and otherwise simply decodes on from there itself.  What the master needs for that is a
+// dozen numbers per helper (the totals, the largest distance shortfall, where the round ended): the adoption is serial but scalar,
+// and the helpers then copy their own rows to the offsets the master names, all at once.  Three workgroup barriers per super-round
+// (rounds open / rounds done / copy); the helpers wait in the first while the master parses a header or takes checked steps.
+#ifndef SWC_TEAM_WAVES
+#define SWC_TEAM_WAVES 6
+#endif
+#if defined(SWC_HOST_EMULATION)
+inline uint64_t g_team_adopted = 0;
+#define SWC_TEAM_STAT() (g_team_adopted++)
+#else
+#define SWC_TEAM_STAT() ((void)0)
+#endif
+constexpr int kTeamWaves = SWC_TEAM_WAVES;
+constexpr uint32_t kTeamStride = 63u * kSyncChunk;
+constexpr size_t kTeamProvBytes = lzr::kProvRecBytes + lzr::kProvLitBytes;   // a helper's scratch rows (no table spill of its own)
+struct TeamRound {   // what a helper hands back; lanes [1, nv) are its chain
+    uint32_t c_lit[kWave], c_rec[kWave];   // per lane: literal bytes, records (the helper copies them itself when it is adopted)
+    uint32_t nv, eob, ok;
+    uint32_t start1;                       // where its lane 1 began (bits from its round's base)
+    uint32_t end_last, tail_last;          // where lane nv - 1 ended; the literals behind its last record (a round that ends the block)
+    uint32_t tot_lit, tot_rec, tot_out;
+    uint32_t mneed;                        // the largest (distance - 1 - output in front of the match inside the round), biased by 2^31
+    // the master's answer
+    uint32_t adopt, nrec_base;
+    uint64_t nlit_base;
+};
+struct TeamShared {
+    uint32_t cmd;                    // 1: a round for the helpers, 0: the job is over
+    uint32_t gen;                    // changes with every set of tables the master builds
+    uint32_t B, in_len;              // the master's round; the stream
+    uint64_t in, subg;               // the stream; the subtable overflow in the workspace (SubTab::g)
+    uint64_t lits, recs;             // the stream's literal stream and record list (the helpers copy into them)
+    uint32_t hgen[kTeamWaves];       // the tables helper h holds
+    TeamRound r[kTeamWaves - 1];
+};
+struct Team {
+    TeamShared* sh = nullptr;        // nullptr: the wave works alone
+    SyncLds* lds = nullptr;          // kTeamWaves of them, [0] the master's
+    gptr scratch = nullptr;          // helper h's rows at (h - 1) * kTeamProvBytes
+    int helpers = 0;
+    uint32_t gen = 0;
+};
+
+// one round of helper h (h = 1 .. helpers): see above
+SWC_D void team_helper_round(const Team& tm, int h) {
+    using simt::PT;
+    constexpr int N = kWave;
+    TeamShared* sh = tm.sh;
+    SyncLds* sl = tm.lds + h;
+    TeamRound& R = sh->r[h - 1];
+    const uint32_t in_len = simt::uniform(sh->in_len);
+    const uint64_t B64 = (uint64_t)simt::uniform(sh->B) + (uint64_t)h * kTeamStride;
+    gcptr in = (gcptr)(uintptr_t)simt::uniform(sh->in);
+    const SubTab st{(const SWC_AS_GLOBAL uint32_t*)(uintptr_t)simt::uniform(sh->subg)};
+    gptr prov = tm.scratch + (size_t)(h - 1) * kTeamProvBytes;
+    if (B64 + 2u * kSyncChunk >= (uint64_t)in_len) {   // nothing behind its sub-chunk 0
+        SIMT_BEGIN(t, N) if (t == 0) { R.ok = 0; R.nv = 0; R.eob = 0; R.adopt = 0; } SIMT_END_WAVE
+        return;
+    }
+    const uint32_t B = (uint32_t)B64;
+    if (simt::uniform(sh->hgen[h]) != simt::uniform(sh->gen)) {   // the master's tables, once per block
+        const SyncLds* msl = tm.lds;
+        constexpr int kLutWords = (int)(sizeof(sl->lut) / 4), kSubWords = (int)(sizeof(sl->sub) / 4);
+        SIMT_BEGIN(t, N)
+            for (int i = t; i < kLutWords; i += N) sl->lut[i] = msl->lut[i];
+            for (int i = t; i < kSubWords; i += N) sl->sub[i] = msl->sub[i];
+            if (t == 0) sh->hgen[h] = sh->gen;
+        SIMT_END_WAVE
+    }
+    const uint64_t left = (uint64_t)(in_len - B) * 8;
+    const uint32_t in_bits = left > 0x3FFFFFFFull ? 0x3FFFFFFFu : (uint32_t)left;
+    PT<uint32_t, N> start, endp, pe, c_lit, c_rec, c_out, flg, c_tail, c_need;
+    PT<bool, N> todo, pb, have;
+    {   // stage [B, B + kSyncStage) shifted left by two bits, zero-filled beyond the input (as sync_block does)
+        constexpr uint32_t kParts = (kSyncStage + 16u * N - 1u) / (16u * N);
+        PT<uint64_t, N> sa[kParts], sb[kParts];
+        PT<uint32_t, N> spv[kParts];
+        SIMT_BEGIN(t, N)
+#pragma unroll
+            for (uint32_t k = 0; k < kParts; k++) {
+                const uint32_t o = 16u * (uint32_t)t + k * 16u * N;
+                uint64_t a = 0, b = 0;
+                uint32_t prev = 0;
+                const uint64_t at = (uint64_t)B + o;
+                if (o < kSyncStage) {
+                    if (at + 16 <= in_len) {
+                        a = load_u64(in + at); b = load_u64(in + at + 8);
+                        if (o != 0) prev = load_u32(in + at - 4);
+                    } else {
+                        for (uint32_t q = 0; q < 8; q++) if (at + q < in_len) a |= (uint64_t)in[at + q] << (8 * q);
+                        for (uint32_t q = 0; q < 8; q++) if (at + 8 + q < in_len) b |= (uint64_t)in[at + 8 + q] << (8 * q);
+                        if (o != 0) for (uint32_t q = 0; q < 4; q++) if (at - 4 + q < in_len) prev |= (uint32_t)in[at - 4 + q] << (8 * q);
+                    }
+                }
+                sa[k][t] = a; sb[k][t] = b; spv[k][t] = prev;
+            }
+        SIMT_END
+        SIMT_BEGIN(t, N)
+#pragma unroll
+            for (uint32_t k = 0; k < kParts; k++) {
+                const uint32_t o = 16u * (uint32_t)t + k * 16u * N;
+                if (o < kSyncStage) {
+                    uint32_t* st32 = (uint32_t*)(sl->stage + o);
+                    const uint64_t a = sa[k][t], b = sb[k][t];
+                    const uint32_t w0 = (uint32_t)a, w1 = (uint32_t)(a >> 32), w2 = (uint32_t)b, w3 = (uint32_t)(b >> 32);
+                    st32[0] = funnel32(w0, spv[k][t], 30); st32[1] = funnel32(w1, w0, 30); st32[2] = funnel32(w2, w1, 30); st32[3] = funnel32(w3, w2, 30);
+                }
+            }
+            start[t] = t == 0 ? 0u : (uint32_t)t * kSyncChunk * 8u - kSyncWalkBack;
+        SIMT_END_WAVE
+    }
+    SIMT_BEGIN(t, N)
+        const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
+        endp[t] = walk_chunk(sl, st, start[t], ce, in_bits);
+        flg[t] = 0; have[t] = t == 0;          // lane 0 only walks: its sub-chunk belongs to the round in front
+        c_lit[t] = c_rec[t] = c_out[t] = c_tail[t] = 0; c_need[t] = 0;
+    SIMT_END
+    uint32_t nv = 0;
+    bool ok = true, eob = false;
+    for (;;) {
+        simt::wave_shift_up<N>(pe, endp, 0u);
+        SIMT_BEGIN(t, N) pb[t] = !(have[t] && (t == 0 || start[t] == pe[t])); SIMT_END
+        const uint64_t m_bad = simt::wave_ballot<N>(pb);
+        const int b = m_bad ? simt::ctz64(m_bad) : 64;
+        const uint64_t chain = b == 64 ? ~0ull : (1ull << b) - 1ull;
+        SIMT_BEGIN(t, N) pb[t] = (flg[t] & kFlagEob) != 0; SIMT_END
+        const uint64_t m_eob = simt::wave_ballot<N>(pb) & chain;
+        const int E = m_eob ? simt::ctz64(m_eob) : 64;
+        nv = (uint32_t)(E < 64 ? E + 1 : b);
+        SIMT_BEGIN(t, N) pb[t] = (flg[t] & (kFlagFail | kFlagSlow)) != 0 || (t == 0 && endp[t] == kPosFail); SIMT_END
+        if (simt::wave_ballot<N>(pb) & (nv == 64 ? ~0ull : (1ull << nv) - 1ull)) { ok = false; break; }
+        if (E < 64) { eob = true; break; }
+        if (b == 64) break;
+        SIMT_BEGIN(t, N)
+            todo[t] = t != 0 && pe[t] != kPosFail && (start[t] != pe[t] || !have[t]);
+            if (todo[t]) {
+                start[t] = pe[t];
+                ProvOut r;
+                const uint32_t ce = ((uint32_t)t + 1u) * kSyncChunk * 8u;
+                if (start[t] + kSyncChunk * 8u < ce) { r.end = kPosFail; r.nlit = r.nrec = r.nout = r.tail = 0; r.flags = kFlagFail; r.need = 0; }
+                else decode_chunk_prov<true>(sl, st, start[t], ce, in_bits, prov, (uint32_t)t, 0u, r);
+                endp[t] = r.end; c_lit[t] = r.nlit; c_rec[t] = r.nrec; c_out[t] = r.nout; flg[t] = r.flags;
+                c_tail[t] = r.tail; c_need[t] = (uint32_t)r.need;
+                have[t] = true;
+            }
+        SIMT_END
+    }
+    // totals over the chain, and the largest shortfall of a distance against the output in front of its match INSIDE the round:
+    // lane t's matches need  need[t] <= (output in front of the round) + (output of lanes 1 .. t - 1)
+    PT<uint32_t, N> x_out, xs;
+    SIMT_BEGIN(t, N)
+        const bool v = t >= 1 && (uint32_t)t < nv;
+        c_lit[t] = v ? c_lit[t] : 0u; c_rec[t] = v ? c_rec[t] : 0u; c_out[t] = v ? c_out[t] : 0u;
+        x_out[t] = c_out[t];
+        pe[t] = c_lit[t]; xs[t] = c_rec[t];
+    SIMT_END
+    simt::wave_scan_incl<N>(x_out);
+    simt::wave_scan_incl<N>(pe);
+    simt::wave_scan_incl<N>(xs);
+    const uint32_t tot_out = simt::wave_read<N>(x_out, N - 1), tot_lit = simt::wave_read<N>(pe, N - 1), tot_rec = simt::wave_read<N>(xs, N - 1);
+    SIMT_BEGIN(t, N)
+        const bool v = t >= 1 && (uint32_t)t < nv;
+        const int32_t shortfall = (int32_t)c_need[t] - (int32_t)(x_out[t] - c_out[t]);
+        xs[t] = v ? (uint32_t)shortfall + 0x80000000u : 0u;
+    SIMT_END
+    simt::wave_scan_max_incl<N>(xs);
+    const uint32_t mneed = simt::wave_read<N>(xs, N - 1);
+    const uint32_t last = nv >= 1u ? nv - 1u : 0u;
+    const uint32_t end_last = simt::wave_read<N>(endp, (int)last), tail_last = simt::wave_read<N>(c_tail, (int)last), start1 = simt::wave_read<N>(start, 1);
+    SIMT_BEGIN(t, N)
+        R.c_lit[t] = c_lit[t]; R.c_rec[t] = c_rec[t];
+        if (t == 0) {
+            R.nv = nv; R.eob = eob ? 1u : 0u; R.ok = ok && nv >= 2u ? 1u : 0u;
+            R.adopt = 0u;   // (the helper's own slot: the master writes it behind the barrier that follows, and not again before the next one)
+            R.start1 = start1; R.end_last = end_last; R.tail_last = tail_last;
+            R.tot_lit = tot_lit; R.tot_rec = tot_rec; R.tot_out = tot_out; R.mneed = mneed;
+        }
+    SIMT_END_WAVE
+}
+// an adopted helper moves its rows to the offsets the master named (all helpers at once)
+SWC_D void team_helper_copy(const Team& tm, int h, gptr lits, SWC_AS_GLOBAL uint32_t* recs) {
+    using simt::PT;
+    constexpr int N = kWave;
+    const TeamRound& R = tm.sh->r[h - 1];
+    if (simt::uniform(R.adopt) == 0u) return;
+    gptr hp = tm.scratch + (size_t)(h - 1) * kTeamProvBytes;
+    const uint64_t nlit = ((uint64_t)simt::uniform((uint32_t)(R.nlit_base >> 32)) << 32) | simt::uniform((uint32_t)R.nlit_base);
+    const uint32_t nrec = simt::uniform(R.nrec_base);
+    PT<uint32_t, N> c_lit, c_rec, x_lit, x_rec;
+    SIMT_BEGIN(t, N) c_lit[t] = R.c_lit[t]; c_rec[t] = R.c_rec[t]; x_lit[t] = c_lit[t]; x_rec[t] = c_rec[t]; SIMT_END
+    simt::wave_scan_incl<N>(x_lit);
+    simt::wave_scan_incl<N>(x_rec);
+    SIMT_BEGIN(t, N)
+        if (c_lit[t] | c_rec[t]) {
+            copy_prov(hp + lzr::kProvRecBytes + 4u * (uint32_t)t, hp + 4u * (uint32_t)t, c_lit[t], c_rec[t],
+                      lits + nlit + (x_lit[t] - c_lit[t]), recs + nrec + (x_rec[t] - c_rec[t]));
+        }
+    SIMT_END
+}
+
+// the master opens a super-round (the helpers leave their barrier) ...
+SWC_D void team_begin(Team& tm, gcptr in, uint32_t in_len, uint32_t B, const SubTab st, gptr lits, SWC_AS_GLOBAL uint32_t* recs) {
+    TeamShared* sh = tm.sh;
+    SIMT_BEGIN(t, kWave)
+        if (t == 0) { sh->cmd = 1u; sh->gen = tm.gen; sh->B = B; sh->in_len = in_len; sh->in = (uint64_t)(uintptr_t)in; sh->subg = (uint64_t)(uintptr_t)st.g; sh->lits = (uint64_t)(uintptr_t)lits; sh->recs = (uint64_t)(uintptr_t)recs; }
+    SIMT_END_WAVE
+#if defined(__HIP_DEVICE_COMPILE__)
+    __syncthreads();
+#endif
+}
+// ... and closes it: behind this the helpers' results are in LDS and their rows in memory (the host emulation runs them here,
+// one after the other)
+SWC_D void team_end(Team& tm) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __syncthreads();
+#else
+    for (int h = 1; h <= tm.helpers; h++) team_helper_round(tm, h);
+#endif
+}
+// ... and, when it has said which of them it adopts, lets the helpers copy (it does not wait for them: nothing of this job reads
+// the records again, and the next barrier -- the next super-round or the end of the job -- is behind the copies)
+SWC_D void team_go(Team& tm, gptr lits, SWC_AS_GLOBAL uint32_t* recs) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    simt::wave_fence();
+    __syncthreads();
+    (void)lits; (void)recs;
+#else
+    for (int h = 1; h <= tm.helpers; h++) team_helper_copy(tm, h, lits, recs);
+#endif
+}
+// the job is over: the helpers leave
+SWC_D void team_dismiss(Team& tm) {
+    SIMT_BEGIN(t, kWave) if (t == 0) tm.sh->cmd = 0u; SIMT_END_WAVE
+#if defined(__HIP_DEVICE_COMPILE__)
+    __syncthreads();
+#endif
+}
+// what the wavefronts 1 .. helpers of the workgroup run (device only: the host emulation runs the helpers' rounds in team_end)
+SWC_D void team_helper_loop(const Team& tm, int h) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    for (;;) {
+        __syncthreads();
+        if (simt::uniform(tm.sh->cmd) == 0u) return;
+        team_helper_round(tm, h);
+        simt::wave_fence();
+        __syncthreads();
+        __syncthreads();   // (the master has said which rounds it adopts)
+        team_helper_copy(tm, h, (gptr)(uintptr_t)(((uint64_t)simt::uniform((uint32_t)(tm.sh->lits >> 32)) << 32) | simt::uniform((uint32_t)tm.sh->lits)),
+                         (SWC_AS_GLOBAL uint32_t*)(uintptr_t)(((uint64_t)simt::uniform((uint32_t)(tm.sh->recs >> 32)) << 32) | simt::uniform((uint32_t)tm.sh->recs)));
+    }
+#else
+    (void)tm; (void)h;
+#endif
+}
+
 // ---- the rounds of one block ---------------------------------------------------------------------------------------
 // Decodes from the reader's position until the end-of-block symbol (kSyncEob) or until something the fast path leaves
 // to the checked step (kSyncBail; kSyncBailCap: the capacity lies inside the next round).  Commits whole rounds only.
-SWC_D int sync_block(Lane& ln, SyncLds* sl, const SubTab st, SyncProf& pf) {
+template <bool TEAM = false>
+SWC_D int sync_block(Lane& ln, SyncLds* sl, const SubTab st, SyncProf& pf, Team* tm = nullptr) {
     using simt::PT;
     constexpr int N = kWave;
     // Literals in front of the block that no record covers yet (the tail of the previous block, stored bytes): the first
@@ -854,6 +1120,11 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, const SubTab st, SyncProf& pf) {
         const uint32_t q0 = (uint32_t)(P - 8ull * B);
         SWC_SP(pf, 6)
         SWC_SPC(pf, 7, 1);
+        bool helped = false;
+        if constexpr (TEAM) if (tm != nullptr && tm->sh != nullptr && pos < ln.cap) {   // the helpers take the rounds behind this one, at once
+            team_begin(*tm, in, in_len, B, st, ln.lits, ln.recs);
+            helped = true;
+        }
         const uint64_t left = (uint64_t)(in_len - B) * 8;
         const uint32_t in_bits = left > 0x3FFFFFFFull ? 0x3FFFFFFFu : (uint32_t)left;
         // stage [B, B + kSyncStage), zero-filled beyond the input, shifted left by two bits: LDS bit p + 2 is stream bit p.
@@ -960,6 +1231,7 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, const SubTab st, SyncProf& pf) {
                 SIMT_END
                 SWC_SP(pf, 3)
             }
+            if constexpr (TEAM) if (helped) team_end(*tm);   // (the helpers' rounds are in their rows and in LDS now, whatever becomes of this one)
             if (ok) {
                 SIMT_BEGIN(t, N)
                     const bool v = (uint32_t)t < nv;
@@ -995,11 +1267,37 @@ SWC_D int sync_block(Lane& ln, SyncLds* sl, const SubTab st, SyncProf& pf) {
                     P = 8ull * B + simt::wave_read<N>(endp, (int)nv - 1);
                     ln.last_end = pos - (eob ? simt::wave_read<N>(c_tail, (int)nv - 1) : 0u);
                     pending = 0;
+                    if constexpr (TEAM) if (helped) {
+                        // The helpers' rounds, in order, as long as each began where the one in front of it ended.  Everything the
+                        // master's own commit checks is checked here as well, on the numbers the helper reduced its round to; whatever
+                        // fails ends the adoption, and the master decodes on from P itself (and meets the same thing in its own time).
+                        for (int h = 1; h <= tm->helpers && !eob; h++) {
+                            TeamRound& R = tm->sh->r[h - 1];
+                            const uint64_t Bh8 = 8ull * ((uint64_t)B + (uint64_t)h * kTeamStride);
+                            const uint32_t hnv = simt::uniform(R.nv);
+                            if (simt::uniform(R.ok) == 0u || hnv < 2u || hnv > (uint32_t)N || P < Bh8 || P - Bh8 != (uint64_t)simt::uniform(R.start1)) break;
+                            const bool heob = simt::uniform(R.eob) != 0u;
+                            if (!heob && hnv != (uint32_t)N) break;
+                            const uint32_t hl = simt::uniform(R.tot_lit), hr = simt::uniform(R.tot_rec), ho = simt::uniform(R.tot_out);
+                            if (pos < 32768u && (int64_t)(int32_t)(simt::uniform(R.mneed) - 0x80000000u) >= (int64_t)pos) break;   // a distance beyond the output
+                            if (pos + ho > ln.cap || (uint64_t)nrec + hr > ln.max_rec) break;
+                            SIMT_BEGIN(t, N) if (t == 0) { R.adopt = 1u; R.nlit_base = nlit; R.nrec_base = nrec; } SIMT_END
+                            SWC_TEAM_STAT();       // rounds adopted
+                            pos += ho;
+                            nlit += hl;
+                            nrec += hr;
+                            P = Bh8 + simt::uniform(R.end_last);
+                            ln.last_end = pos - (heob ? simt::uniform(R.tail_last) : 0u);
+                            if (heob) eob = true;
+                        }
+                        team_go(*tm, ln.lits, ln.recs);
+                    }
                     if (eob) { result = kSyncEob; break; }
                     continue;
                 }
             }
             // abandoned: the general passes start over
+            if constexpr (TEAM) if (helped) team_go(*tm, ln.lits, ln.recs);   // (nobody is adopted)
             SIMT_BEGIN(t, N) have[t] = false; flg[t] = 0; SIMT_END
             eob = false;
         }
@@ -1289,7 +1587,8 @@ SWC_D void build_static_par(SyncLds* sl, const Spill sp, SubTab& st, bool& fast,
 // (lzr::StreamHeader | records | scratch rows + table spill | literal stream).  On the device every lane of the wave calls
 // this with its lane number; the host emulation calls it once (lane 0 of 1) and runs the 64 lanes of the parallel parts one
 // after another.
-SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes, int lane, int lanes, uint64_t* prof = nullptr) {
+template <bool TEAM = false>
+SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes, int lane, int lanes, uint64_t* prof = nullptr, Team* tm = nullptr) {
     Lane ln;
     SyncProf pf;
 #if defined(SWC_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -1346,10 +1645,11 @@ SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes,
                 if (type == 1) build_static_par(sl, sp, stb, fast, pf);
                 else st = build_dynamic_par(ln, sl, sp, stb, fast, pf);
                 SWC_SP(pf, 1)
+                if constexpr (TEAM) if (tm != nullptr) tm->gen++;   // (new tables: the helpers copy them before their next round)
                 if (st == SWC_OK) {
                     for (;;) {   // Deflate.swift:171-236
                         if (fast) {
-                            const int r = sync_block(ln, sl, stb, pf);
+                            const int r = sync_block<TEAM>(ln, sl, stb, pf, tm);
                             if (r == kSyncEob) break;
                             if (r == kSyncBail) fast = false;   // the checked step takes the rest of the block
                             // kSyncBailCap: checked steps until the capacity is behind us
@@ -1368,6 +1668,7 @@ SWC_D void inflate_sync_job(Job& job, SyncLds* sl, uint8_t* ws, size_t ws_bytes,
         }
         ln.flush_tail();
     }
+    if constexpr (TEAM) if (tm != nullptr && tm->sh != nullptr) team_dismiss(*tm);
     if (ln.nrec > ln.max_rec) {
         st = SWC_E_NEED_WORKSPACE;  // the record list outgrew the workspace (sized from out_cap)
         ln.nrec = ln.max_rec;

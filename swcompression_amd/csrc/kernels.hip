@@ -255,12 +255,36 @@ int last_phase_ms(float* ms, int cap) {
 }
 size_t inflate_ws_bytes_per_job(uint64_t cap) { return lzr::ws_bytes_per_job(cap); }
 
+// "deflate_team" (swc_set_tuning): 1 = launches of up to kTeamMaxStreams streams give every stream a team of wavefronts (default),
+// 0 = one wavefront per stream whatever the launch, -1 = a team for launches of up to kTeamForceStreams (tests)
+static std::atomic<int> g_deflate_team{1};
+void set_deflate_team(int v) { g_deflate_team = v; }
+constexpr size_t kTeamMaxStreams = 256, kTeamForceStreams = 4096;
+
 hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream, const uint64_t* ws_off) {
     if (n == 0) return hipSuccess;
     size_t stride = ws ? (ws_bytes / n) & ~(size_t)15 : 0;
     if (!ws_off && stride < sizeof(lzr::StreamHeader)) return hipErrorInvalidValue;
     const WsMap wm{(uint8_t*)ws, stride, ws_off};
     const dim3 block(kWave);
+    const int team = g_deflate_team;
+    if (!g_prof && ((team == 1 && n <= kTeamMaxStreams) || (team < 0 && n <= kTeamForceStreams))) {
+        // a team per stream (inflate_team.hip): the helpers' rows come from the stream-ordered pool for the length of the launch; no
+        // ordering pass (a workgroup per stream and at most two per CU: the launch is one residency round)
+        void* scratch = nullptr;
+        if (hipMallocAsync(&scratch, inflate_team_scratch_bytes(n), stream) == hipSuccess) {
+            g_pt.begin(stream);
+            launch_inflate_team(jobs, n, (uint8_t*)ws, stride, ws_off, (uint8_t*)scratch, stream);
+            g_pt.mark(stream);
+            (void)hipFreeAsync(scratch, stream);
+            const int copier = copier_for(n);
+            if (copier) launch_lz_copy(copier, false, jobs, n, wm, nullptr, stream);
+            else hipLaunchKernelGGL(swc_lz_resolve_kernel, dim3((unsigned)n), dim3(kInflateResolveThreads), 0, stream, jobs, (uint32_t)n, wm, g_prof, (const uint32_t*)nullptr);
+            g_pt.mark(stream);
+            return hipGetLastError();
+        }
+        (void)hipGetLastError();   // no room for the rows: one wavefront per stream
+    }
     // (streams of unequal cost -- stored blocks, incompressible stretches -- are launched longest first, like the LZ4 blocks)
     g_pt.begin(stream);   // (the ordering kernels are part of the first phase's figure: ADVICE r4)
     const uint32_t* order = SWC_INFLATE_ORDER ? job_order(jobs, n, stream) : nullptr;

@@ -6,6 +6,9 @@
 namespace swc {
 // ws_off != nullptr: device array of n + 1 prefix-summed per-job workspace offsets (then ws_bytes is ignored)
 hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStream_t stream, const uint64_t* ws_off = nullptr);
+// inflate_team.hip: phase 1 with a team of wavefronts per stream (launches of few streams); `scratch`: inflate_team_scratch_bytes(n)
+size_t inflate_team_scratch_bytes(size_t n);
+hipError_t launch_inflate_team(Job* jobs, size_t n, uint8_t* ws, size_t stride, const uint64_t* ws_off, uint8_t* scratch, hipStream_t stream);
 size_t inflate_ws_bytes_per_job(uint64_t cap);
 hipError_t launch_crc32(const Job* jobs, size_t n, uint32_t* crcs, hipStream_t stream);
 hipError_t launch_delta(Job* jobs, size_t n, hipStream_t stream);
@@ -14,6 +17,7 @@ void set_profile_buffer(void* p);
 void set_phase_timing(int on);
 void set_lzma_coder_cache(int on);
 void set_lz_copier(int v);
+void set_deflate_team(int v);
 void set_bzip2_hot_cxx(int v);
 void set_bzip2_team_walk(int v);
 void set_bzip2_team_per_cu(int v);

@@ -59,10 +59,13 @@ for kind, size in (("text", 300000), ("mix", 200000), ("rep", 100000), ("zero", 
     assert run("emu_lz4_block", z, p)[0], ("lz4", kind)
     assert not run("emu_lz4_block", z[:len(z) * 2 // 3], p)[0]      # truncated: an error status, no stray access
     z = corpus.deflate_raw(p, 6)
-    for fn in ("emu_inflate_sync",):
-        assert run(fn, z, p)[0], (fn, kind)
-        assert not run(fn, z[:len(z) * 2 // 3], p)[0]
-        n += 2
+    for team in (0, 1):   # one wavefront per stream / a team of wavefronts (the helpers stage rounds up to 21 KB beyond the master's)
+        lib.emu_set_deflate_team(team)
+        for fn in ("emu_inflate_sync",):
+            assert run(fn, z, p)[0], (fn, kind, team)
+            assert not run(fn, z[:len(z) * 2 // 3], p)[0]
+            n += 2
+    lib.emu_set_deflate_team(0)
     n += 2
 # LZMA2 in both model layouts (all literal coders in LDS / LDS as a cache of four), whole and truncated
 import lzma as _lzma

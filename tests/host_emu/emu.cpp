@@ -53,13 +53,29 @@ static void emu_copy_any(int deflate, swc::Job& job, const uint8_t* ws, size_t w
 
 // Deflate, one stream per wavefront with 64 sub-chunks decoded at once (inflate_sync.h): the uniform parts run once, the
 // 64 lanes of every parallel region one after another (csrc/simt.h).
+// phase 1 with a team of wavefronts per stream (inflate_sync.h; kernels.hip: launches of few streams): 0 = one wavefront
+static int g_team = 0;
+extern "C" void emu_set_deflate_team(int on) { g_team = on; }
+extern "C" uint64_t emu_team_adopted(int reset) { const uint64_t v = swc::inflate::g_team_adopted; if (reset) swc::inflate::g_team_adopted = 0; return v; }
 extern "C" void emu_inflate_sync(swc::Job* jobs, size_t n) {
     alignas(16) static swc::inflate::SyncLds sl;
+    alignas(16) static swc::inflate::SyncLds tl[swc::inflate::kTeamWaves];
+    alignas(16) static swc::inflate::TeamShared tsh;
     alignas(16) static swc::lzr::Lds<512, 16> rl;
     for (size_t g = 0; g < n; g++) {
         std::memset(&sl, 0xEE, sizeof sl);
         size_t wsb = swc::lzr::ws_bytes_per_job(jobs[g].out_cap);
         std::vector<uint8_t> ws(wsb + 16, (uint8_t)0xCD);
+        if (g_team) {
+            std::memset(tl, 0xEE, sizeof tl);
+            std::memset(&tsh, 0xEE, sizeof tsh);
+            for (auto& h : tsh.hgen) h = 0;
+            tsh.cmd = 0;
+            std::vector<uint8_t> rows((swc::inflate::kTeamWaves - 1) * swc::inflate::kTeamProvBytes + 16, (uint8_t)0xCD);
+            swc::inflate::Team tm;
+            tm.sh = &tsh; tm.lds = tl; tm.scratch = rows.data(); tm.helpers = swc::inflate::kTeamWaves - 1; tm.gen = 0;
+            swc::inflate::inflate_sync_job<true>(jobs[g], &tl[0], ws.data(), wsb, 0, 1, nullptr, &tm);
+        } else
         swc::inflate::inflate_sync_job(jobs[g], &sl, ws.data(), wsb, 0, 1);
         if (g_copier) {
             emu_copy_any(1, jobs[g], ws.data(), wsb);

@@ -254,3 +254,55 @@ def test_randomised_encoder_settings_batch():
     for i in range(0, len(plains), 17):
         st, out, cons = O.deflate(streams[i])
         assert (st, out, cons) == (0, plains[i], int(r["in_consumed"][i]))
+
+
+def test_phase1_team_and_single_wavefront_write_the_same():
+    """Phase 1 has two forms (kernels.hip: launch_inflate): a team of six wavefronts per stream for launches of up to 256 streams
+    (inflate_team.hip), one wavefront per stream above.  The same 1,200 streams -- encoder settings and sizes of every kind, damaged
+    copies among them -- as launches of 200 (teams), as one launch with the teams forced, and with the teams off: the oracle's
+    status, bytes, consumed input and length every time."""
+    from swcompression_amd import _lib
+    lib = _lib.load()
+    rnd = random.Random(606)
+    gens = [corpus.p_text, corpus.p_rep, corpus.p_mix, corpus.p_rand, lambda n, s: corpus.p_zero(n), corpus.PAYLOADS["bin"]]
+    O.lib.refcpu_set_max_output(1 << 24)
+    streams = []
+    for i in range(1000):
+        p = gens[i % len(gens)](rnd.choice([0, 1, 100, 4000, 20000, 65536, 65536, 65536, 150000, 400000]), 3000 + i)
+        co = zlib.compressobj(rnd.choice([1, 6, 9]), zlib.DEFLATED, -rnd.choice([9, 12, 15]), rnd.choice([1, 8, 9]), rnd.choice([zlib.Z_DEFAULT_STRATEGY, zlib.Z_FIXED, zlib.Z_RLE]))
+        cut = rnd.randrange(len(p) + 1)
+        streams.append(co.compress(p[:cut]) + co.flush(rnd.choice([zlib.Z_NO_FLUSH, zlib.Z_FULL_FLUSH])) + co.compress(p[cut:]) + co.flush())
+    for i in range(200):
+        b = bytearray(streams[rnd.randrange(1000)])
+        if rnd.random() < 0.5 and len(b) > 1:
+            b = b[:rnd.randrange(1, len(b))]
+        elif b:
+            b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+        streams.append(bytes(b))
+    exp = [O.deflate(z) for z in streams]
+    keep = [i for i, e in enumerate(exp) if e[0] != 901]
+    ins, want = [streams[i] for i in keep], [exp[i] for i in keep]
+    caps = [max(len(e[1]), 1) for e in want]
+
+    def check(lo, hi, label):
+        b = DeviceBatch("deflate", ins[lo:hi], caps[lo:hi])
+        b.launch(sync=True)
+        r = b.results()
+        for k in range(lo, hi):
+            e = want[k]
+            assert int(r["status"][k - lo]) == e[0], "%s: status %d, oracle %d on stream %d" % (label, int(r["status"][k - lo]), e[0], k)
+            if e[0] == 0:
+                assert int(r["out_len"][k - lo]) == len(e[1]) and int(r["in_consumed"][k - lo]) == e[2], (label, k)
+                assert b.output(k - lo, len(e[1])) == e[1], "%s: bytes differ on stream %d" % (label, k)
+    try:
+        assert lib.swc_set_tuning(b"deflate_team", 1) == 0
+        for lo in range(0, len(ins), 200):
+            check(lo, min(lo + 200, len(ins)), "teams, launches of 200")
+        assert lib.swc_set_tuning(b"deflate_team", -1) == 0
+        check(0, len(ins), "teams forced, one launch")
+        assert lib.swc_set_tuning(b"deflate_team", 0) == 0
+        check(0, len(ins), "one wavefront per stream")
+        check(0, 150, "one wavefront per stream, a small launch")
+    finally:
+        lib.swc_set_tuning(b"deflate_team", 1)
+        O.lib.refcpu_set_max_output(1 << 30)

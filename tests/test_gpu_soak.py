@@ -82,7 +82,14 @@ def test_deflate_streams_over_spliced_text(seed):
         exp = [O.deflate(z) for z in streams]
         keep = [i for i, e in enumerate(exp) if e[0] != 901]
         caps = [max(len(exp[i][1]), 1) + rnd.choice([0, 0, 0, 5]) for i in keep]
-        _both_kernels(lambda label: _check("deflate", [streams[i] for i in keep], [exp[i] for i in keep], caps, "seed %d, %s" % (seed, label)))
+        from swcompression_amd import _lib
+        lib = _lib.load()
+        try:
+            for team in (1, 0, -1):   # phase 1: the library's choice (launches of up to 256 streams: a team of wavefronts per stream), one wavefront per stream, teams forced
+                assert lib.swc_set_tuning(b"deflate_team", team) == 0
+                _both_kernels(lambda label: _check("deflate", [streams[i] for i in keep], [exp[i] for i in keep], caps, "seed %d, team %d, %s" % (seed, team, label)))
+        finally:
+            lib.swc_set_tuning(b"deflate_team", 1)
     finally:
         O.lib.refcpu_set_max_output(1 << 30)
 

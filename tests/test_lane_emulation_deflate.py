@@ -10,6 +10,17 @@ import _emu as E
 import _oracle as O
 import _streams as S
 
+@pytest.fixture(autouse=True, params=["one-wavefront", "team"])
+def phase1_form(request):
+    """Phase 1 has two forms that must write the same records: one wavefront per stream (launches of many streams) and a TEAM of
+    wavefronts per stream (inflate_sync.h: the master on the job, five helpers on the rounds behind the master's, whose results the
+    master adopts when their first sub-chunk began where the round in front ended; kernels.hip: launches of up to 256 streams).  The
+    emulation runs the helpers' rounds one after the other where the device has its barrier.  Every test here runs with both."""
+    E.lib.emu_set_deflate_team(1 if request.param == "team" else 0)
+    yield request.param
+    E.lib.emu_set_deflate_team(0)
+
+
 @pytest.fixture
 def inflate():
     return E.inflate
@@ -157,3 +168,20 @@ def test_a_block_per_byte_at_exact_capacity(inflate, flush, n):
     assert e[:2] == (0, p)
     r = inflate([z], [n])[0]
     assert r[0] == 0 and r[1] == p and r[2] == e[2]
+
+
+def test_the_team_adopts_its_helpers_rounds():
+    """Text of 256 KiB is 19 rounds of the fast path: with five helpers the master decodes four of them and adopts fifteen (a helper's
+    lane 0 walks 544 bits before its end is used: in step 99.3 % of the time).  Incompressible data has no rounds to adopt."""
+    import ctypes as C
+    from swcompression_amd import corpus
+    E.lib.emu_team_adopted.restype = C.c_uint64
+    E.lib.emu_set_deflate_team(1)
+    for kind, least in (("text", 12), ("mix", 12), ("bin", 12), ("rand", 0)):
+        p = corpus.PAYLOADS[kind](262144, 3)
+        z = corpus.deflate_raw(p, 6)
+        E.lib.emu_team_adopted(1)
+        st, out, cons, n = E.inflate([z], [len(p)])[0]
+        assert (st, out, cons) == (0, p, len(z))
+        got = E.lib.emu_team_adopted(1)
+        assert got >= least and (least or got == 0), (kind, got)

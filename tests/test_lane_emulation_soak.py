@@ -61,9 +61,14 @@ def test_deflate_streams_over_spliced_text(seed, bounded_oracle):
     ins, want = [streams[i] for i in keep], [exp[i] for i in keep]
     caps = [max(len(e[1]), 1) + rnd.choice([0, 0, 0, 5]) for e in want]
     E.set_order(seed % 3)
-    for copier in (1, 2, 0):    # the Deflate window, the LZ4 window, the workgroup resolver
-        E.lib.emu_set_copier(copier)
-        _compare(E.inflate(ins, caps, misalign=seed % 16), want, ins, "seed %d, copier %d" % (seed, copier))
+    try:
+        for team in (0, 1):         # one wavefront per stream / a team of wavefronts
+            E.lib.emu_set_deflate_team(team)
+            for copier in (1, 2, 0):    # the Deflate window, the LZ4 window, the workgroup resolver
+                E.lib.emu_set_copier(copier)
+                _compare(E.inflate(ins, caps, misalign=seed % 16), want, ins, "seed %d, team %d, copier %d" % (seed, team, copier))
+    finally:
+        E.lib.emu_set_deflate_team(0)
 
 
 @pytest.mark.parametrize("seed", range(4))
