@@ -274,7 +274,7 @@ hipError_t launch_inflate(Job* jobs, size_t n, void* ws, size_t ws_bytes, hipStr
         void* scratch = nullptr;
         if (hipMallocAsync(&scratch, inflate_team_scratch_bytes(n), stream) == hipSuccess) {
             g_pt.begin(stream);
-            launch_inflate_team(jobs, n, (uint8_t*)ws, stride, ws_off, (uint8_t*)scratch, stream);
+            (void)launch_inflate_team(jobs, n, (uint8_t*)ws, stride, ws_off, (uint8_t*)scratch, stream);   // (hipGetLastError below)
             g_pt.mark(stream);
             (void)hipFreeAsync(scratch, stream);
             const int copier = copier_for(n);
