@@ -453,6 +453,7 @@ struct Stage1 {
     static constexpr int N = 64;
     struct Loop {
         simt::PT<uint32_t, N> my_lim, my_delta, my_sh, sym_lo, sym_a, sym_b, sym_c;   // the active table
+        simt::PT<uint32_t, N> sym_m;             // sym_lo as the assembly loop reads it: list position (symbol - 1); RUNA / RUNB: 2^31 | symbol
         simt::PT<uint32_t, N> l0, l1, l2, l3;    // the list: position 64 i + t in l<i>[t]
         simt::PT<uint32_t, N> stg;               // L[sbase .. sbase + k) staged: lane j holds byte sbase + k - 1 - j
         uint32_t sbase, k;
@@ -471,6 +472,7 @@ struct Stage1 {
             L.my_sh[t] = len_lane ? (uint32_t)(kMaxLen - t) : 0u;
             const uint16_t* sy = s->sym[tb];
             L.sym_lo[t] = (uint32_t)sy[t];
+            L.sym_m[t] = sy[t] < 2u ? 0x80000000u | (uint32_t)sy[t] : (uint32_t)sy[t] - 1u;
             L.sym_a[t] = (uint32_t)sy[t] | ((uint32_t)sy[t + 64] << 16);
             L.sym_b[t] = (uint32_t)sy[t + 128] | ((uint32_t)sy[t + 192] << 16);
             L.sym_c[t] = t < kMaxSyms + 2 - 256 ? (uint32_t)sy[256 + t] : 0u;
@@ -525,18 +527,19 @@ struct Stage1 {
         return hot_symbols_cxx(L, i, pending, pending_len);
     }
 #if defined(__HIP_DEVICE_COMPILE__)
-    // The same loop as hot_symbols_cxx below, written in gfx950 assembly: 32 instructions per byte symbol and 24 per RUNA /
+    // The same loop as hot_symbols_cxx below, written in gfx950 assembly: 28 instructions per byte symbol and 25 per RUNA /
     // RUNB against the 58 / 41 the compiler makes of the C++ (it keeps the loop-carried values in different registers on
     // different paths and copies them at every merge point, and it will not shift a register in place).  All scalar state
     // lives in fixed registers inside the block (s80 - s99: the halves of the 64-bit values are needed on their own, and an
     // operand has no syntax for that); it is handed over at entry and exit.  What differs from the C++ in form only:
     //   * `v_mov_b32_dpp x, x wave_shr:1` shifts a register in place, lane 0 is written afterwards with v_writelane (lane
-    //     select 0: no second scalar operand);
+    //     select 0: no second scalar operand: a v_writelane whose value AND lane select are scalar registers violates the constant-bus
+    //     rule of gfx9 -- which is why the staged bytes are a shift register and not indexed by the count);
     //   * the bit window is refilled inside too, by SCALAR loads (s_load_dwordx2 of the aligned pair that holds the next dword,
     //     asked for one refill ahead; the input is read-only for the kernel, and a FAST group has its 163 bytes): the word
     //     arrives in scalar registers, and the loop is left only at the end of a group or for a symbol it does not handle.
     // Wait states the assembler does not insert into inline code: a lane select that was written by v_readlane needs four
-    // (the s_nop in front of the symbol read); DPP sources are written at least two instructions earlier on every path.
+    // (the symbol's bookkeeping stands between the two lane reads); DPP sources are written at least two instructions earlier on every path.
     SWC_D int hot_symbols_isa(Loop& L, int& i, uint32_t& pending, uint32_t& pending_len) {
         const uint32_t lane = (uint32_t)threadIdx.x;
         uint32_t ev, pend, plen, t0, t1;
@@ -572,21 +575,17 @@ struct Stage1 {
                 "v_add_u32_e32 %[t0], %[t0], %[delta]\n\t"
                 "s_bcnt1_i32_b64 s92, vcc\n\t"
                 "s_lshl_b64 s[80:81], s[80:81], s92\n\t"
-                "s_sub_u32 s82, s82, s92\n\t"
-                "s_add_u32 s83, s83, 1\n\t"
                 "v_readlane_b32 s93, %[t0], s92\n\t"
+                "s_sub_u32 s82, s82, s92\n\t"                // (the bookkeeping of the symbol IS the four wait states of the lane select)
+                "s_add_u32 s83, s83, 1\n\t"
                 "s_cmp_gt_u32 s93, 63\n\t"
                 "s_cbranch_scc1 Lindex%=\n\t"
-                "s_nop 1\n\t"
-                "v_readlane_b32 s94, %[symlo], s93\n\t"
-                "s_cmp_lt_u32 s94, 2\n\t"
-                "s_cbranch_scc1 Lrun%=\n\t"
+                "v_readlane_b32 s94, %[symlo], s93\n\t"      // the list position of a byte symbol; RUNA / RUNB: 2^31 | symbol
+                "s_cmp_ge_u32 s94, s90\n\t"                  // ONE test for everything but a byte symbol of the short way
+                "s_cbranch_scc1 Lnotfast%=\n\t"
                 "s_cmp_lg_u64 s[88:89], 1\n\t"
                 "s_cbranch_scc1 Lpend%=\n"
                 "Lbyte%=:\n\t"
-                "s_add_u32 s94, s94, -1\n\t"
-                "s_cmp_ge_u32 s94, s90\n\t"
-                "s_cbranch_scc1 Lsym%=\n\t"
                 "v_readlane_b32 s95, %[l0], s94\n\t"
                 "v_cmp_ge_u32_e32 vcc, s94, %[lane]\n\t"
                 "v_mov_b32_dpp %[t0], %[l0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
@@ -599,8 +598,10 @@ struct Stage1 {
                 "s_cmp_lt_u32 s83, 50\n\t"
                 "s_cbranch_scc1 Ltop%=\n\t"
                 "s_branch Ldone%=\n"
-                "Lrun%=:\n\t"
-                "s_lshl_b64 s[96:97], s[88:89], s94\n\t"
+                "Lnotfast%=:\n\t"
+                "s_cmp_lt_i32 s94, 0\n\t"
+                "s_cbranch_scc0 Lsym%=\n\t"
+                "s_lshl_b64 s[96:97], s[88:89], s94\n\t"     // RUNA / RUNB (a 64-bit shift takes the low six bits of its count: 0 / 1)
                 "s_add_u32 s86, s86, s96\n\t"
                 "s_addc_u32 s87, s87, s97\n\t"
                 "s_lshl_b64 s[88:89], s[88:89], 1\n\t"
@@ -628,7 +629,7 @@ struct Stage1 {
                 "s_mov_b64 s[88:89], 1\n\t"
                 "s_branch Lbyte%=\n"
                 "Lsym0%=:\n\t"
-                "s_mov_b32 s93, s94\n\t"
+                "s_add_u32 s93, s94, 1\n\t"
                 "s_mov_b32 s98, 1\n\t"
                 "s_branch Ldone%=\n"
                 "Lsym%=:\n\t"
@@ -648,15 +649,11 @@ struct Stage1 {
                 "s_and_b32 s76, s78, -4\n\t"
                 "s_mov_b32 s77, s79\n\t"
                 "s_load_dwordx2 s[74:75], s[76:77], 0x0\n\t"
-                "s_lshr_b32 s97, s96, 24\n\t"                 // the dword's bytes in stream order (no scalar byte swap)
-                "s_lshl_b32 s99, s96, 24\n\t"
-                "s_or_b32 s97, s97, s99\n\t"
-                "s_lshr_b32 s99, s96, 8\n\t"
-                "s_and_b32 s99, s99, 0xff00\n\t"
-                "s_or_b32 s97, s97, s99\n\t"
-                "s_lshl_b32 s99, s96, 8\n\t"
-                "s_and_b32 s99, s99, 0xff0000\n\t"
-                "s_or_b32 s96, s97, s99\n\t"
+                "v_mov_b32_e32 %[t1], s96\n\t"               // the dword's bytes in stream order: there is no scalar byte swap, the vector
+                "s_mov_b32 s97, 0x00010203\n\t"              // unit permutes bytes in one instruction (three here against nine scalar ones)
+                "v_perm_b32 %[t1], %[t1], %[t1], s97\n\t"
+                "s_nop 0\n\t"
+                "v_readfirstlane_b32 s96, %[t1]\n\t"
                 "s_mov_b32 s97, 0\n\t"
                 "s_sub_u32 s99, 32, s82\n\t"
                 "s_lshl_b64 s[96:97], s[96:97], s99\n\t"
@@ -677,7 +674,7 @@ struct Stage1 {
                 "s_mov_b32 %[plen], s92"
                 : [bb] "+s"(bb), [bc] "+s"(bc), [i] "+s"(ii), [k] "+s"(k), [rl] "+s"(rl), [rp] "+s"(rp), [addr] "+s"(addr),
                   [ev] "=s"(ev), [pend] "=s"(pend), [plen] "=s"(plen), [l0] "+v"(L.l0.v), [stg] "+v"(L.stg.v), [t0] "=&v"(t0), [t1] "=&v"(t1)
-                : [mfast] "s"(mfast), [lim] "v"(L.my_lim.v), [sh] "v"(L.my_sh.v), [delta] "v"(L.my_delta.v), [symlo] "v"(L.sym_lo.v), [lane] "v"(lane)
+                : [mfast] "s"(mfast), [lim] "v"(L.my_lim.v), [sh] "v"(L.my_sh.v), [delta] "v"(L.my_delta.v), [symlo] "v"(L.sym_m.v), [lane] "v"(lane)
                 : "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
                   "s98", "s99", "vcc", "scc");
         }
