@@ -455,7 +455,7 @@ struct Stage1 {
         simt::PT<uint32_t, N> my_lim, my_delta, my_sh, sym_lo, sym_a, sym_b, sym_c;   // the active table
         simt::PT<uint32_t, N> sym_m;             // sym_lo as the assembly loop reads it: list position (symbol - 1); RUNA / RUNB: 2^31 | symbol
         simt::PT<uint32_t, N> l0, l1, l2, l3;    // the list: position 64 i + t in l<i>[t]
-        simt::PT<uint32_t, N> stg;               // L[sbase .. sbase + k) staged: lane j holds byte sbase + k - 1 - j
+        simt::PT<uint32_t, N> stg;               // L[sbase .. sbase + k) staged: lane j holds byte sbase + j
         uint32_t sbase, k;
         uint64_t run_length, repeat_power;       // repeat_power != 1: RUNA / RUNB symbols since the last byte symbol
         int n_selectors, used_count, n_used, selector_index, table;
@@ -478,10 +478,16 @@ struct Stage1 {
             L.sym_c[t] = t < kMaxSyms + 2 - 256 ? (uint32_t)sy[256 + t] : 0u;
         SIMT_END
     }
+    // one more staged byte (the C++ paths; the assembly loop: ONE v_writelane with the count, kept in M0, as the lane select)
+    SWC_HD void stage_byte(Loop& L, uint32_t el) {
+        const uint32_t k = L.k;
+        SIMT_BEGIN(t, N) L.stg[t] = (uint32_t)t == k ? el : L.stg[t]; SIMT_END
+        L.k = k + 1u;
+    }
     SWC_HD void flush(Loop& L) {
         // (a fast group tests the room in L once, at its end: bytes staged beyond it are dropped here, never stored)
         SIMT_BEGIN(t, N)
-            const uint32_t at = L.sbase + L.k - 1u - (uint32_t)t;   // (the newest byte is in lane 0)
+            const uint32_t at = L.sbase + (uint32_t)t;
             if ((uint32_t)t < L.k && at < lcap32) ws.L[at] = (uint8_t)L.stg[t];
         SIMT_END
         // (said explicitly: the compiler merges these updates into the per-lane region above and then treats the counters --
@@ -527,14 +533,14 @@ struct Stage1 {
         return hot_symbols_cxx(L, i, pending, pending_len);
     }
 #if defined(__HIP_DEVICE_COMPILE__)
-    // The same loop as hot_symbols_cxx below, written in gfx950 assembly: 28 instructions per byte symbol and 25 per RUNA /
+    // The same loop as hot_symbols_cxx below, written in gfx950 assembly: 27 instructions per byte symbol and 25 per RUNA /
     // RUNB against the 58 / 41 the compiler makes of the C++ (it keeps the loop-carried values in different registers on
     // different paths and copies them at every merge point, and it will not shift a register in place).  All scalar state
     // lives in fixed registers inside the block (s80 - s99: the halves of the 64-bit values are needed on their own, and an
     // operand has no syntax for that); it is handed over at entry and exit.  What differs from the C++ in form only:
-    //   * `v_mov_b32_dpp x, x wave_shr:1` shifts a register in place, lane 0 is written afterwards with v_writelane (lane
-    //     select 0: no second scalar operand: a v_writelane whose value AND lane select are scalar registers violates the constant-bus
-    //     rule of gfx9 -- which is why the staged bytes are a shift register and not indexed by the count);
+    //   * the list: `v_mov_b32_dpp` by one lane under a compare, lane 0 written afterwards with v_writelane; the staged bytes: ONE
+    //     v_writelane per byte with the count as the lane select -- in M0, because a v_writelane whose value AND lane select are
+    //     SGPRs violates the constant-bus rule of gfx9, and M0 as the lane select does not; a run: lanes k .. k + run - 1 under a compare;
     //   * the bit window is refilled inside too, by SCALAR loads (s_load_dwordx2 of the aligned pair that holds the next dword,
     //     asked for one refill ahead; the input is read-only for the kernel, and a FAST group has its 163 bytes): the word
     //     arrives in scalar registers, and the loop is left only at the end of a group or for a symbol it does not handle.
@@ -556,7 +562,7 @@ struct Stage1 {
                 "s_mov_b64 s[80:81], %[bb]\n\t"
                 "s_mov_b32 s82, %[bc]\n\t"
                 "s_mov_b32 s83, %[i]\n\t"
-                "s_mov_b32 s84, %[k]\n\t"
+                "s_mov_b32 m0, %[k]\n\t"                      // (the count of staged bytes lives in M0: see Lbyte)
                 "s_mov_b64 s[86:87], %[rl]\n\t"
                 "s_mov_b64 s[88:89], %[rp]\n\t"
                 "s_mov_b32 s90, %[mfast]\n\t"
@@ -591,9 +597,8 @@ struct Stage1 {
                 "v_mov_b32_dpp %[t0], %[l0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
                 "v_cndmask_b32_e32 %[l0], %[l0], %[t0], vcc\n\t"
                 "v_writelane_b32 %[l0], s95, 0\n\t"
-                "v_mov_b32_dpp %[stg], %[stg] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
-                "v_writelane_b32 %[stg], s95, 0\n\t"
-                "s_add_u32 s84, s84, 1\n"
+                "v_writelane_b32 %[stg], s95, m0\n\t"         // staged: lane k.  Value AND lane select in scalar registers is one too many
+                "s_add_u32 m0, m0, 1\n"                       // for the constant bus of gfx9 -- unless the lane select is M0
                 "Lnext%=:\n\t"
                 "s_cmp_lt_u32 s83, 50\n\t"
                 "s_cbranch_scc1 Ltop%=\n\t"
@@ -609,22 +614,19 @@ struct Stage1 {
                 "Lpend%=:\n\t"
                 "s_add_u32 s96, s86, -1\n\t"
                 "s_addc_u32 s97, s87, -1\n\t"
-                "s_sub_u32 s99, s83, s84\n\t"
+                "s_sub_u32 s99, s83, m0\n\t"
                 "s_add_u32 s99, s99, 13\n\t"
                 "s_cmp_lg_u32 s97, 0\n\t"
                 "s_cbranch_scc1 Lsym0%=\n\t"
                 "s_cmp_ge_u32 s96, s99\n\t"
                 "s_cbranch_scc1 Lsym0%=\n\t"
                 "v_readlane_b32 s95, %[l0], 0\n\t"
-                "v_subrev_u32_e32 %[t0], s86, %[lane]\n\t"
-                "v_lshlrev_b32_e32 %[t0], 2, %[t0]\n\t"
-                "ds_bpermute_b32 %[t0], %[t0], %[stg]\n\t"
+                "v_subrev_u32_e32 %[t0], m0, %[lane]\n\t"     // lane - k (huge below k)
                 "s_and_b32 s95, s95, 0xff\n\t"
-                "v_cmp_gt_u32_e32 vcc, s86, %[lane]\n\t"
+                "v_cmp_gt_u32_e32 vcc, s86, %[t0]\n\t"        // lanes k .. k + run - 1 take the run's byte
                 "v_mov_b32_e32 %[t1], s95\n\t"
-                "s_waitcnt lgkmcnt(0)\n\t"
-                "v_cndmask_b32_e32 %[stg], %[t0], %[t1], vcc\n\t"
-                "s_add_u32 s84, s84, s86\n\t"
+                "v_cndmask_b32_e32 %[stg], %[stg], %[t1], vcc\n\t"
+                "s_add_u32 m0, m0, s86\n\t"
                 "s_mov_b64 s[86:87], 0\n\t"
                 "s_mov_b64 s[88:89], 1\n\t"
                 "s_branch Lbyte%=\n"
@@ -666,7 +668,7 @@ struct Stage1 {
                 "s_mov_b64 %[bb], s[80:81]\n\t"
                 "s_mov_b32 %[bc], s82\n\t"
                 "s_mov_b32 %[i], s83\n\t"
-                "s_mov_b32 %[k], s84\n\t"
+                "s_mov_b32 %[k], m0\n\t"
                 "s_mov_b64 %[rl], s[86:87]\n\t"
                 "s_mov_b64 %[rp], s[88:89]\n\t"
                 "s_mov_b32 %[ev], s98\n\t"
@@ -676,7 +678,7 @@ struct Stage1 {
                   [ev] "=s"(ev), [pend] "=s"(pend), [plen] "=s"(plen), [l0] "+v"(L.l0.v), [stg] "+v"(L.stg.v), [t0] "=&v"(t0), [t1] "=&v"(t1)
                 : [mfast] "s"(mfast), [lim] "v"(L.my_lim.v), [sh] "v"(L.my_sh.v), [delta] "v"(L.my_delta.v), [symlo] "v"(L.sym_m.v), [lane] "v"(lane)
                 : "s74", "s75", "s76", "s77", "s78", "s79", "s80", "s81", "s82", "s83", "s84", "s85", "s86", "s87", "s88", "s89", "s90", "s91", "s92", "s93", "s94", "s95", "s96", "s97",
-                  "s98", "s99", "vcc", "scc");
+                  "s98", "s99", "vcc", "scc", "m0");
         }
         br.bb = bb; br.bc = bc;
         br.next = addr - (uint64_t)(uintptr_t)br.in;
@@ -688,7 +690,7 @@ struct Stage1 {
     }
 #endif
     SWC_HD int hot_symbols_cxx(Loop& L, int& i, uint32_t& pending, uint32_t& pending_len) {
-        simt::PT<uint32_t, N> idxv, sh, src;
+        simt::PT<uint32_t, N> idxv, sh;
         simt::PT<bool, N> pb;
         // ONE exit test at the bottom and one way round: the backend gives a loop with several exits a guard variable and
         // a block of moves per exit (UnifyLoopExits), and a `continue` a second latch with its own copies.  `ev` is made opaque
@@ -716,9 +718,8 @@ struct Stage1 {
                         if (L.run_length - 1ull < (uint64_t)(13u + (uint32_t)i - L.k)) {
                             const uint32_t run = (uint32_t)L.run_length;
                             const uint32_t b = simt::wave_read<N>(L.l0, 0) & 255u;
-                            SIMT_BEGIN(t, N) src[t] = (uint32_t)t - run; SIMT_END
-                            simt::wave_gather<N>(sh, L.stg, src);           // lane t takes what lane t - run held
-                            SIMT_BEGIN(t, N) L.stg[t] = (uint32_t)t < run ? b : sh[t]; SIMT_END
+                            const uint32_t k0 = L.k;
+                            SIMT_BEGIN(t, N) L.stg[t] = (uint32_t)t - k0 < run ? b : L.stg[t]; SIMT_END   // lanes k .. k + run - 1
                             L.k += run;
                             L.run_length = 0;
                             L.repeat_power = 1;
@@ -729,9 +730,7 @@ struct Stage1 {
                         const uint32_t el = simt::wave_read<N>(L.l0, (int)m);
                         simt::wave_shift_up_dpp<N>(sh, L.l0, el);
                         SIMT_BEGIN(t, N) L.l0[t] = (uint32_t)t <= m ? sh[t] : L.l0[t]; SIMT_END
-                        simt::wave_shift_up_dpp<N>(sh, L.stg, el);
-                        L.stg = sh;
-                        L.k++;
+                        stage_byte(L, el);
                     } else { pending = symbol; ev = kSymbol; }
                 }
             } else { pending = idx; pending_len = len; ev = kIndex; }
@@ -825,9 +824,7 @@ struct Stage1 {
                 const uint32_t el = mtf_general(L, symbol - 1u);
                 // L[n_out] = el, staged a byte per lane
                 if (!FAST && L.sbase + L.k >= lcap32) return SWC_E_NEED_WORKSPACE;
-                simt::wave_shift_up_dpp<N>(sh, L.stg, el);
-                L.stg = sh;
-                L.k++;
+                stage_byte(L, el);
             }
             // FAST: runs staged inside the group may have used up the room in L.  (The byte that does not fit is reported here,
             // not where it was staged: an error in the rest of the group comes first -- only for a column that outgrows its
