@@ -480,7 +480,7 @@ hipError_t launch_lzma(bool lzma2, Job* jobs, size_t n, void* spill, hipStream_t
 constexpr size_t kBzLdsBytes = (bzip2::kStage1LdsBytes > sizeof(bzip2::Stage3Lds) ? (size_t)bzip2::kStage1LdsBytes : sizeof(bzip2::Stage3Lds)) + SWC_BZ_LDS_PAD;
 static_assert(kBzLdsBytes >= 256 * sizeof(uint32_t), "stage 2 counters");
 #ifndef SWC_BZ_WAVES
-#define SWC_BZ_WAVES 6   // (7: 72 VGPRs + 8 bytes of scratch, 28 waves per CU, 495 ms against 479 -- the walk is at the gather rate, more waves do not add to it)
+#define SWC_BZ_WAVES 6   // (round 4, stage 3 inside: 7 -> 72 VGPRs + 8 bytes of scratch, 495 ms against 479; round 6, stages 1 + 2 only: 6 / 7 / 8 -> 198.4 / 200.3 / 199.4 ms)
 #endif
 // CXX: the plain-symbol loop of stage 1 compiled from its C++ twin instead of the hand-written assembly ("bzip2_hot_cxx",
 // swc_set_tuning: the differential GPU test of the two, tests/test_gpu_bzip2.py)
