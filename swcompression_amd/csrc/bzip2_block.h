@@ -610,7 +610,9 @@ struct Stage1 {
                 "s_add_u32 s86, s86, s96\n\t"
                 "s_addc_u32 s87, s87, s97\n\t"
                 "s_lshl_b64 s[88:89], s[88:89], 1\n\t"
-                "s_branch Lnext%=\n"
+                "s_cmp_lt_u32 s83, 50\n\t"                   // (every path closes the loop itself: a taken branch costs the wave its
+                "s_cbranch_scc1 Ltop%=\n\t"                  // instruction buffer, and a run digit took three of them per symbol)
+                "s_branch Ldone%=\n"
                 "Lpend%=:\n\t"
                 "s_add_u32 s96, s86, -1\n\t"
                 "s_addc_u32 s97, s87, -1\n\t"
@@ -629,7 +631,16 @@ struct Stage1 {
                 "s_add_u32 m0, m0, s86\n\t"
                 "s_mov_b64 s[86:87], 0\n\t"
                 "s_mov_b64 s[88:89], 1\n\t"
-                "s_branch Lbyte%=\n"
+                "v_readlane_b32 s95, %[l0], s94\n\t"        // (Lbyte once more, instead of a branch there and one back)
+                "v_cmp_ge_u32_e32 vcc, s94, %[lane]\n\t"
+                "v_mov_b32_dpp %[t0], %[l0] wave_shr:1 row_mask:0xf bank_mask:0xf\n\t"
+                "v_cndmask_b32_e32 %[l0], %[l0], %[t0], vcc\n\t"
+                "v_writelane_b32 %[l0], s95, 0\n\t"
+                "v_writelane_b32 %[stg], s95, m0\n\t"
+                "s_add_u32 m0, m0, 1\n\t"
+                "s_cmp_lt_u32 s83, 50\n\t"
+                "s_cbranch_scc1 Ltop%=\n\t"
+                "s_branch Ldone%=\n"
                 "Lsym0%=:\n\t"
                 "s_add_u32 s93, s94, 1\n\t"
                 "s_mov_b32 s98, 1\n\t"
